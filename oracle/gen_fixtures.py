@@ -1,0 +1,259 @@
+"""Generate golden vectors under tests/golden/ by running the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference, read-only).  The reference's
+Python never leaves that container: this script stores seeds, small inputs and the
+reference's OUTPUTS as .npz fixtures.  Re-run with:  python oracle/gen_fixtures.py
+
+Import notes: `models.PointDSC` imports torchvision only to
+download ImageNet weights for the ResNet image encoder, which is upstream of the hot
+path.  torchvision is not installed, so a stub module that returns a random-init
+state dict is registered before the import, and the model's `image_encoder` is then
+replaced by nn.Identity so that image TOKENS are fed directly (the [B,128,H,W] view the
+reference flattens at PointDSC.py:129-135).
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import gmf_oracle as O  # noqa: E402
+
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _import_reference():
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvu = types.ModuleType("torchvision.models.utils")
+    tvu.load_state_dict_from_url = lambda *a, **k: _STUB_SD[0]
+    tv.models, tvm.utils = tvm, tvu
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.utils": tvu})
+    sys.path.insert(0, os.path.join(REF, "GMF_PointDSC"))
+    import models.resnet as resnet
+    _STUB_SD[0] = resnet.ResNet(3, resnet.BasicBlock, [3, 4, 6, 3]).state_dict()
+    import models.PointDSC as pdsc
+    import models.fusion_layer as fl
+    import models.common as common
+    spec = importlib.util.spec_from_file_location(
+        "dgr_perceiver_io", os.path.join(REF, "GMF_DeepGlobalRegistration/GMF_DeepGlobalRegistration_fcgf/model/perceiver_io.py"))
+    pio = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pio)
+    # core/registration.py imports core.knn / core.loss; load it with its package dir on the path
+    dgr_root = os.path.join(REF, "GMF_DeepGlobalRegistration/GMF_DeepGlobalRegistration_fcgf")
+    sys.path.insert(0, dgr_root)
+    spec = importlib.util.spec_from_file_location("dgr_registration", os.path.join(dgr_root, "core/registration.py"))
+    reg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(reg)
+    return pdsc, fl, common, pio, reg
+
+
+_STUB_SD = [None]
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _strip(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def _tok_to_image(tok):
+    """[B,T,C] tokens -> the [B,C,1,T] map whose .view(B,C,H*W).permute(0,2,1) is `tok`."""
+    return tok.permute(0, 2, 1)[:, :, None, :].contiguous()
+
+
+def build_ref_pointdsc(pdsc, sd, num_layers=12, sigma_d=0.1, tau=0.10, nms=0.10, k=40, ratio=0.1):
+    m = pdsc.PointDSC(in_dim=6, num_layers=num_layers, num_channels=128, num_iterations=10, ratio=ratio,
+                      inlier_threshold=tau, sigma_d=sigma_d, k=k, nms_radius=nms)
+    m.encoder.image_encoder = torch.nn.Identity()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert not missing, missing
+    return m.eval()
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    pdsc, fl, common, pio, reg = _import_reference()
+    os.makedirs(GOLD, exist_ok=True)
+
+    # ---------------- F1: Fusion-1 -------------------------------------------------
+    shapes = O.fusion_layer_shapes("", 128, 128, 64, pe=False)
+    sd = O.seeded_state_dict(shapes, seed=101)
+    ref = fl.FusionLayer(depth=0, dim=128, latent_dim=128, cross_heads=1, latent_heads=8,
+                         cross_dim_head=64, latent_dim_head=64).eval()
+    ref.load_state_dict(sd)
+    out = {}
+    for T in (12, 196, 300):
+        b = O.synthetic_batch([11, 12], N=8, T=T)
+        out[f"out_T{T}"] = _np(ref(b["p_tokens"], queries_encoder=b["q_tokens"]))
+    np.savez_compressed(os.path.join(GOLD, "f1_fusion1.npz"), seed=101, pair_seeds=[11, 12], **out)
+
+    # ---------------- F2: one Fusion-2 layer (with LCPE) ---------------------------
+    shapes = O.fusion_layer_shapes("", 128, 128, 64, pe=True)
+    sd = O.seeded_state_dict(shapes, seed=102)
+    ref = fl.FusionLayer(depth=0, dim=128, latent_dim=128, cross_heads=1, latent_heads=8,
+                         cross_dim_head=64, latent_dim_head=64, pe=True).eval()
+    ref.load_state_dict(sd)
+    out = {}
+    for N, T in ((64, 12), (257, 196), (1000, 196), (33, 1), (1, 7)):
+        r = np.random.default_rng([102, N, T])
+        x = torch.from_numpy(r.normal(0, 1, (1, N, 128)).astype(np.float32))
+        ctx = torch.from_numpy(r.normal(0, 1, (1, T, 128)).astype(np.float32))
+        caps = {}
+        h1 = ref.cpe.register_forward_hook(lambda m, i, o: caps.__setitem__("cpe", o))
+        h2 = ref.cross_attend_blocks[0].register_forward_hook(lambda m, i, o: caps.__setitem__("attn", o))
+        y = ref(ctx, queries_encoder=x)
+        h1.remove(), h2.remove()
+        out[f"out_N{N}_T{T}"] = _np(y)
+        if N <= 257:
+            out[f"xpe_N{N}_T{T}"] = _np(caps["cpe"][0])
+            out[f"ctxpe_N{N}_T{T}"] = _np(caps["cpe"][1])
+            out[f"attn_N{N}_T{T}"] = _np(caps["attn"])   # Attention output before the residual add
+    np.savez_compressed(os.path.join(GOLD, "f2_fusion2.npz"), seed=102, **out)
+
+    # ---------------- F9: DGR PerceiverIO, latent 256 / dim 128 / head 128 ----------
+    shapes = O.fusion_layer_shapes("", 128, 256, 128, pe=True, out_to_query=True)
+    sd = O.seeded_state_dict(shapes, seed=109)
+    ref = pio.PerceiverIO(depth=0, dim=128, latent_dim=256, cross_heads=1, latent_heads=8,
+                          cross_dim_head=128, latent_dim_head=128, pe=True).eval()
+    ref.load_state_dict(sd)
+    out = {}
+    for M, T in ((100, 12), (515, 300)):
+        r = np.random.default_rng([109, M, T])
+        x = torch.from_numpy(r.normal(0, 1, (1, M, 256)).astype(np.float32))
+        ctx = torch.from_numpy(r.normal(0, 1, (1, T, 128)).astype(np.float32))
+        out[f"out_M{M}_T{T}"] = _np(ref(ctx, queries_encoder=x))
+    np.savez_compressed(os.path.join(GOLD, "f9_dgr_perceiver.npz"), seed=109, **out)
+
+    # ---------------- full-model weights ------------------------------------------
+    full_shapes = O.pointdsc_shapes(6, 12, 128)
+    sd_full = O.seeded_state_dict(full_shapes, seed=7)
+    model = build_ref_pointdsc(pdsc, sd_full)
+
+    # ---------------- F3: one NonLocalBlock ----------------------------------------
+    blk = model.encoder.blocks["NonLocal_layer_3"]
+    b = O.synthetic_batch([31, 32], N=257, T=196)
+    r = np.random.default_rng([103])
+    feat = torch.from_numpy(r.normal(0, 1, (2, 257, 128)).astype(np.float32))   # token-major
+    img = torch.from_numpy(r.normal(0, 1, (2, 196, 128)).astype(np.float32))
+    src_d = torch.norm(b["src_keypts"][:, :, None] - b["src_keypts"][:, None], dim=-1)
+    tgt_d = torch.norm(b["tgt_keypts"][:, :, None] - b["tgt_keypts"][:, None], dim=-1)
+    compat = torch.clamp(1.0 - (src_d - tgt_d) ** 2 / 0.1 ** 2, min=0)
+    y = blk(feat.permute(0, 2, 1).contiguous(), compat, img).permute(0, 2, 1)
+    np.savez_compressed(os.path.join(GOLD, "f3_nonlocal_block.npz"), seed=7, layer=3, pair_seeds=[31, 32],
+                        feat=_np(feat), img=_np(img), out=_np(y), compat_row5=_np(compat[0, 5]))
+
+    # ---------------- F4: encoder features + logits; F10: whole forward ------------
+    out = {}
+    for N, seeds in ((64, [41]), (257, [42, 43]), (1000, [44])):
+        b = O.synthetic_batch(seeds, N=N, T=196)
+        caps = {}
+        h1 = model.classification.register_forward_hook(lambda m, i, o: caps.__setitem__("logits", o))
+        h2 = model.encoder.register_forward_hook(lambda m, i, o: caps.__setitem__("feat", o))
+        res_list = []
+        for bi in range(len(seeds)):       # test mode is B=1 (PointDSC.py:279,504)
+            data = {"corr_pos": b["corr_pos"][bi:bi + 1], "src_keypts": b["src_keypts"][bi:bi + 1],
+                    "tgt_keypts": b["tgt_keypts"][bi:bi + 1],
+                    "p_image": _tok_to_image(b["p_tokens"][bi:bi + 1]),
+                    "q_image": _tok_to_image(b["q_tokens"][bi:bi + 1]), "testing": True}
+            res = model(data)
+            res_list.append((res, caps["logits"].squeeze(1).clone(), caps["feat"].permute(0, 2, 1).clone()))
+        h1.remove(), h2.remove()
+        out[f"logits_N{N}"] = np.concatenate([_np(r[1]) for r in res_list])
+        out[f"final_trans_N{N}"] = np.concatenate([_np(r[0]["final_trans"]) for r in res_list])
+        out[f"final_labels_N{N}"] = np.concatenate([_np(r[0]["final_labels"]) for r in res_list])
+        out[f"gt_trans_N{N}"] = _np(b["gt_trans"])
+        feat = np.concatenate([_np(r[2]) for r in res_list])
+        if N <= 257:
+            out[f"feat_N{N}"] = feat
+        else:
+            out[f"feat_rows_N{N}"] = feat[:, ::50]
+            out[f"feat_sum_N{N}"] = feat.astype(np.float64).sum(axis=(1, 2))
+        out[f"pair_seeds_N{N}"] = np.array(seeds)
+        # batched train-mode call (B=2): logits must be batch independent
+        if len(seeds) == 2:
+            data = {"corr_pos": b["corr_pos"], "src_keypts": b["src_keypts"], "tgt_keypts": b["tgt_keypts"],
+                    "p_image": _tok_to_image(b["p_tokens"]), "q_image": _tok_to_image(b["q_tokens"])}
+            res = model(data)
+            out[f"train_logits_N{N}"] = _np(res["final_labels"])
+            out[f"train_final_trans_N{N}"] = _np(res["final_trans"])
+    np.savez_compressed(os.path.join(GOLD, "f4_f10_pointdsc.npz"), seed=7, **out)
+
+    # ---------------- F5: cal_seed_trans with fixed seeds; F7 refinement trace ------
+    out = {}
+    N = 400
+    b = O.synthetic_batch([51], N=N, T=12)
+    r = np.random.default_rng([105])
+    feat = torch.from_numpy(r.normal(0, 1, (1, N, 128)).astype(np.float32))
+    # make inlier features cluster so the seed neighbourhoods are meaningful
+    inl = b["gt_labels"][0] > 0
+    feat[0, inl] += 2.5 * torch.from_numpy(r.normal(0, 1, (1, 128)).astype(np.float32))
+    feat_n = torch.nn.functional.normalize(feat, p=2, dim=-1)
+    scores = torch.from_numpy(r.normal(0, 1, (1, N)).astype(np.float32)) + 2.0 * b["gt_labels"]
+    src_d = torch.norm(b["src_keypts"][:, :, None] - b["src_keypts"][:, None], dim=-1)
+    seeds = model.pick_seeds(src_d, scores, R=0.10, max_num=int(N * 0.1))
+    seed_T, fit, final_T, labels = model.cal_seed_trans(seeds, feat_n, b["src_keypts"], b["tgt_keypts"])
+    k = 40
+    knn_idx = common.knn(feat_n, k=k, ignore_self=True, normalized=True).gather(
+        dim=1, index=seeds[:, :, None].expand(-1, -1, k))
+    refined = model.post_refinement(final_T.clone(), b["src_keypts"], b["tgt_keypts"])
+    np.savez_compressed(os.path.join(GOLD, "f5_f7_pose_head.npz"), pair_seed=51, N=N,
+                        feat_n=_np(feat_n), scores=_np(scores), seeds=_np(seeds), knn_idx=_np(knn_idx),
+                        seed_trans=_np(seed_T), fitness=_np(fit), final_trans=_np(final_T),
+                        labels=_np(labels), refined=_np(refined), gt_trans=_np(b["gt_trans"]))
+
+    # ---------------- F6: rigid_transform_3d ---------------------------------------
+    r = np.random.default_rng([106])
+    n, k = 64, 40
+    A = r.uniform(0, 3, (n, k, 3)).astype(np.float32)
+    Bm = np.empty_like(A)
+    for i in range(n):
+        R = O.random_rotation(r)
+        Bm[i] = A[i] @ R.T + r.uniform(-1, 1, 3) + r.normal(0, 0.02, (k, 3))
+    w = r.uniform(0, 1, (n, k)).astype(np.float32)
+    w[:8, ::3] = 0.0                       # zero weights
+    w[8:12, 1::4] = -0.5                   # negative weights (clipped in place by the reference)
+    A[12:16, :, 2] = 0.3 + 0.02 * r.normal(size=(4, k))   # thin (near-planar) clouds
+    Bm[12:16] = A[12:16] @ O.random_rotation(r).T.astype(np.float32) + 0.5
+    Bm[16:20] = Bm[16:20] * np.array([1, 1, -1], np.float32)   # reflected target: forces det fix
+    Tref = common.rigid_transform_3d(torch.from_numpy(A), torch.from_numpy(Bm), torch.from_numpy(w.copy()))
+    Tref_now = common.rigid_transform_3d(torch.from_numpy(A), torch.from_numpy(Bm))
+    np.savez_compressed(os.path.join(GOLD, "f6_rigid_transform.npz"), A=A, B=Bm, w=w, T=_np(Tref), T_noweight=_np(Tref_now))
+
+    # ---------------- F8: DGR weighted_procrustes ----------------------------------
+    out = {}
+    for N in (10, 1000, 8000):
+        r = np.random.default_rng([108, N])
+        X = r.uniform(0, 3, (N, 3)).astype(np.float32)
+        R = O.random_rotation(r)
+        t = r.uniform(-0.5, 0.5, 3)
+        Y = (X @ R.T + t).astype(np.float32)
+        nout = int(N * 0.7)
+        Y[:nout] = r.uniform(0, 3, (nout, 3)).astype(np.float32)
+        logit = r.normal(-3.0, 1.0, (N, 1)).astype(np.float32)
+        logit[nout:] = r.normal(3.0, 1.0, (N - nout, 1)).astype(np.float32)
+        wgt = O.dgr_inlier_weights(torch.from_numpy(logit))
+        Rr, tr = reg.weighted_procrustes(torch.from_numpy(X), torch.from_numpy(Y), wgt, np.finfo(np.float32).eps)
+        out[f"X_{N}"], out[f"Y_{N}"], out[f"w_{N}"] = X, Y, _np(wgt)
+        out[f"R_{N}"], out[f"t_{N}"] = _np(Rr), _np(tr)
+        out[f"Rgt_{N}"], out[f"tgt_{N}"] = R.astype(np.float32), t.astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "f8_weighted_procrustes.npz"), **out)
+
+    for f in sorted(os.listdir(GOLD)):
+        print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KB")
+
+
+if __name__ == "__main__":
+    main()

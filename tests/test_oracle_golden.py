@@ -1,0 +1,133 @@
+"""The CPU oracle (oracle/gmf_oracle.py) against golden vectors produced by the reference itself.
+
+The fixtures under tests/golden/ were written by oracle/gen_fixtures.py, which ran the
+reference's own modules in the build container.  This pins the oracle (task rule 3).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gmf_oracle as O
+
+TOL = 2e-5
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _close(a, b, tol=TOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.abs(a - b).max() / max(1.0, np.abs(b).max())
+    assert err < tol, err
+
+
+def test_f1_fusion1(golden_dir):
+    g = _load(golden_dir, "f1_fusion1.npz")
+    sd = O.seeded_state_dict(O.fusion_layer_shapes("", 128, 128, 64, pe=False), seed=int(g["seed"]))
+    for T in (12, 196, 300):
+        b = O.synthetic_batch(list(g["pair_seeds"]), N=8, T=T)
+        y = O.fusion_layer(sd, "", b["p_tokens"], b["q_tokens"], pe=False)
+        _close(y, g[f"out_T{T}"])
+
+
+@pytest.mark.parametrize("N,T", [(64, 12), (257, 196), (1000, 196), (33, 1), (1, 7)])
+def test_f2_fusion2(golden_dir, N, T):
+    g = _load(golden_dir, "f2_fusion2.npz")
+    sd = O.seeded_state_dict(O.fusion_layer_shapes("", 128, 128, 64, pe=True), seed=int(g["seed"]))
+    r = np.random.default_rng([102, N, T])
+    x = torch.from_numpy(r.normal(0, 1, (1, N, 128)).astype(np.float32))
+    ctx = torch.from_numpy(r.normal(0, 1, (1, T, 128)).astype(np.float32))
+    _close(O.fusion_layer(sd, "", ctx, x, pe=True), g[f"out_N{N}_T{T}"])
+    if N <= 257:
+        _close(O.conv_pos_enc_1(x, sd["cpe.proj_q.weight"], sd["cpe.proj_q.bias"]), g[f"xpe_N{N}_T{T}"])
+        _close(O.conv_pos_enc_1(ctx, sd["cpe.proj_content.weight"], sd["cpe.proj_content.bias"]), g[f"ctxpe_N{N}_T{T}"])
+
+
+@pytest.mark.parametrize("M,T", [(100, 12), (515, 300)])
+def test_f9_dgr_perceiver(golden_dir, M, T):
+    g = _load(golden_dir, "f9_dgr_perceiver.npz")
+    sd = O.seeded_state_dict(O.fusion_layer_shapes("", 128, 256, 128, pe=True, out_to_query=True), seed=int(g["seed"]))
+    r = np.random.default_rng([109, M, T])
+    x = torch.from_numpy(r.normal(0, 1, (1, M, 256)).astype(np.float32))
+    ctx = torch.from_numpy(r.normal(0, 1, (1, T, 128)).astype(np.float32))
+    _close(O.fusion_layer(sd, "", ctx, x, pe=True), g[f"out_M{M}_T{T}"])
+
+
+@pytest.fixture(scope="module")
+def sd_full():
+    return O.seeded_state_dict(O.pointdsc_shapes(6, 12, 128), seed=7)
+
+
+def test_f3_nonlocal_block(golden_dir, sd_full):
+    g = _load(golden_dir, "f3_nonlocal_block.npz")
+    b = O.synthetic_batch(list(g["pair_seeds"]), N=257, T=196)
+    compat, _ = O.compat_matrix(b["src_keypts"], b["tgt_keypts"], 0.1)
+    _close(compat[0, 5], g["compat_row5"], 1e-4)
+    y = O.nonlocal_block(sd_full, f"encoder.blocks.NonLocal_layer_{int(g['layer'])}.",
+                         torch.from_numpy(g["feat"]), compat, torch.from_numpy(g["img"]))
+    _close(y, g["out"])
+
+
+@pytest.mark.parametrize("N", [64, 257, 1000])
+def test_f4_f10_pointdsc(golden_dir, sd_full, N):
+    g = _load(golden_dir, "f4_f10_pointdsc.npz")
+    seeds = list(g[f"pair_seeds_N{N}"])
+    b = O.synthetic_batch(seeds, N=N, T=196)
+    res = O.pointdsc_forward(sd_full, b, testing=True)
+    ref_logits = g[f"logits_N{N}"]
+    assert ref_logits.max() - ref_logits.min() > 1.5      # logit spread is >= 15000x the 1e-4 gate
+    assert np.abs(res["logits"].numpy() - ref_logits).max() < 1e-4
+    if N <= 257:
+        _close(res["corr_features"], g[f"feat_N{N}"])
+    else:
+        _close(res["corr_features"][:, ::50], g[f"feat_rows_N{N}"])
+        _close(res["corr_features"].double().sum((1, 2)), g[f"feat_sum_N{N}"], 1e-5)
+    assert np.abs(res["final_trans"].numpy() - g[f"final_trans_N{N}"]).max() < 1e-4
+    assert (res["final_labels"].numpy() == g[f"final_labels_N{N}"]).mean() > 0.999
+    if len(seeds) == 2:
+        tr = O.pointdsc_forward(sd_full, b, testing=False)
+        assert np.abs(tr["final_labels"].numpy() - g[f"train_logits_N{N}"]).max() < 1e-4
+        assert np.abs(tr["final_trans"].numpy() - g[f"train_final_trans_N{N}"]).max() < 1e-4
+
+
+def test_f5_f7_pose_head(golden_dir, sd_full):
+    g = _load(golden_dir, "f5_f7_pose_head.npz")
+    N = int(g["N"])
+    b = O.synthetic_batch([int(g["pair_seed"])], N=N, T=12)
+    feat_n, scores = torch.from_numpy(g["feat_n"]), torch.from_numpy(g["scores"])
+    src, tgt = b["src_keypts"], b["tgt_keypts"]
+    seeds = O.pick_seeds(torch.cdist(src, src), scores, 0.10, int(N * 0.1))
+    assert (seeds.numpy() == g["seeds"]).all()
+    Ts, fit, fT, lab, knn_idx = O.cal_seed_trans(feat_n, src, tgt, torch.from_numpy(g["seeds"]), 1.0, 0.1, 40, 10, 0.10)
+    assert (np.sort(knn_idx.numpy(), -1) == np.sort(g["knn_idx"], -1)).mean() > 0.999
+    assert np.abs(Ts.numpy() - g["seed_trans"]).max() < 1e-3
+    assert np.abs(fit.numpy() - g["fitness"]).max() < 1e-6
+    assert np.abs(fT.numpy() - g["final_trans"]).max() < 1e-4
+    assert (lab.numpy() == g["labels"]).all()
+    ref = O.post_refinement(torch.from_numpy(g["final_trans"]), src, tgt, 0.10)
+    assert np.abs(ref.numpy() - g["refined"]).max() < 1e-4
+    # the synthetic scene is recoverable: the refined pose is the ground truth
+    assert np.abs(g["refined"][0] - g["gt_trans"][0]).max() < 2e-2
+
+
+def test_f6_rigid_transform(golden_dir):
+    g = _load(golden_dir, "f6_rigid_transform.npz")
+    A, B, w = (torch.from_numpy(g[k]) for k in ("A", "B", "w"))
+    assert np.abs(O.rigid_transform_3d(A, B, w.clone()).numpy() - g["T"]).max() < 1e-4
+    assert np.abs(O.rigid_transform_3d(A, B).numpy() - g["T_noweight"]).max() < 1e-4
+    R = g["T"][:, :3, :3]
+    assert np.abs(np.linalg.det(R) - 1).max() < 1e-4      # proper rotations, also for reflected targets
+
+
+@pytest.mark.parametrize("N", [10, 1000, 8000])
+def test_f8_weighted_procrustes(golden_dir, N):
+    g = _load(golden_dir, "f8_weighted_procrustes.npz")
+    X, Y, w = (torch.from_numpy(g[f"{k}_{N}"]) for k in ("X", "Y", "w"))
+    R, t = O.weighted_procrustes(X, Y, w, np.finfo(np.float32).eps)
+    assert np.abs(R.numpy() - g[f"R_{N}"]).max() < 1e-5
+    assert np.abs(t.numpy() - g[f"t_{N}"]).max() < 1e-5
+    if N >= 1000:
+        assert np.abs(g[f"R_{N}"] - g[f"Rgt_{N}"]).max() < 5e-2

@@ -1,0 +1,155 @@
+"""ctypes binding of libgmf_hip.so (C ABI: include/gmf_hip.h).
+
+There is NO fallback: if the shared library is missing, or a call returns a non-zero status,
+a RuntimeError is raised (the reference's assert/exception semantics).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Dict, Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgmf_hip.so")
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int)
+_vp = C.c_void_p
+_ll = C.c_longlong
+
+
+class EncoderWeights(C.Structure):
+    """Mirror of `struct gmf_encoder_weights` (include/gmf_hip.h)."""
+    _fields_ = [
+        ("num_layers", C.c_int),
+        ("f1_ctx_wst", _vp), ("f1_ctx_vec", _vp),
+        ("f1_attn_wst", _vp), ("f1_attn_vec", _vp),
+        ("f1_ff_wst", _vp), ("f1_ff_vec", _vp),
+        ("ctx_wst", _vp), ("ctx_vec", _vp), ("ctx_wst_stride", C.c_int), ("ctx_vec_stride", C.c_int),
+        ("attn_wst", _vp), ("attn_vec", _vp), ("attn_wst_stride", C.c_int), ("attn_vec_stride", C.c_int),
+        ("ff_wst", _vp), ("ff_vec", _vp), ("ff_wst_stride", C.c_int), ("ff_vec_stride", C.c_int),
+        ("front_wst", _vp), ("front_vec", _vp), ("front_wst_stride", C.c_int), ("front_vec_stride", C.c_int),
+        ("tail_wst", _vp), ("tail_vec", _vp), ("tail_wst_stride", C.c_int), ("tail_vec_stride", C.c_int),
+        ("head_wst", _vp), ("head_vec", _vp),
+        ("sigma_d", C.c_float),
+    ]
+
+
+class PoseParams(C.Structure):
+    """Mirror of `struct gmf_pose_params` (include/gmf_hip.h)."""
+    _fields_ = [
+        ("num_seeds", C.c_int), ("k", C.c_int), ("num_iterations", C.c_int), ("use_nms", C.c_int),
+        ("refine_iters", C.c_int),
+        ("sigma", C.c_float), ("sigma_d", C.c_float), ("inlier_threshold", C.c_float),
+        ("nms_radius", C.c_float), ("refine_threshold", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes).  Every symbol declared in include/gmf_hip.h appears here.
+SIGNATURES = {
+    "gmf_abi_version": (C.c_int, []),
+    "gmf_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "gmf_destroy": (None, [_vp]),
+    "gmf_last_error_string": (C.c_char_p, [_vp]),
+    "gmf_workspace_bytes": (_ll, [_vp]),
+    "gmf_pack_rows_p32": (C.c_int, [_vp, _vp, _ll, _ll, _ll, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "gmf_unpack_rows_p32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _ll, _ll, _ll, _vp]),
+    "gmf_pack_pts8": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "gmf_front_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "gmf_scattn_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp]),
+    "gmf_scattn_forward_dense": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "gmf_fusion_ctx_prepare": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "gmf_fusion_attn_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "gmf_fusion_ff_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "gmf_classifier_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "gmf_encoder_forward": (C.c_int, [_vp, C.POINTER(EncoderWeights), _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
+                                      _vp, _vp, _vp, _vp]),
+    "gmf_nonlocal_block_forward": (C.c_int, [_vp, C.POINTER(EncoderWeights), C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp,
+                                             C.c_int, C.c_int, C.c_int, _vp]),
+    "gmf_fusion_layer_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _ll, _vp,
+                                           _ll, _ll, _ll, C.c_int, C.c_int, C.c_int, _vp]),
+    "gmf_pose_head": (C.c_int, [_vp, C.POINTER(PoseParams), _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp]),
+    "gmf_pick_seeds": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _vp, _vp]),
+    "gmf_knn_rows": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "gmf_procrustes_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp]),
+    "gmf_post_refinement": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp]),
+    "gmf_weighted_procrustes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_float, _vp, _vp, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load_library() -> C.CDLL:
+    """dlopen libgmf_hip.so and bind every entry point.  Raises RuntimeError if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"gmf_amd: {LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C gmf_amd/csrc`.  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if lib.gmf_abi_version() != 1:
+            raise RuntimeError("gmf_amd: libgmf_hip.so ABI version mismatch")
+        _lib = lib
+        return lib
+
+
+class Handle:
+    """Per-device library handle (`gmf_create`).  Not thread-safe; one per device per process."""
+
+    def __init__(self, device: int):
+        self.lib = load_library()
+        h = _vp()
+        rc = self.lib.gmf_create(int(device), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"gmf_amd: gmf_create(device={device}) failed with status {rc} "
+                               "(no HIP device?) - the HIP path is mandatory, there is no CPU fallback")
+        self.h = h
+        self.device = device
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.gmf_last_error_string(self.h)
+            raise RuntimeError(f"gmf_amd: {what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+    def call(self, name: str, *args):
+        self.check(getattr(self.lib, name)(self.h, *args), name)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.gmf_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+_handles: Dict[int, Handle] = {}
+
+
+def handle_for(device_index: Optional[int]) -> Handle:
+    idx = 0 if device_index is None else int(device_index)
+    hd = _handles.get(idx)
+    if hd is None:
+        hd = Handle(idx)
+        _handles[idx] = hd
+    return hd
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_ptr(device) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

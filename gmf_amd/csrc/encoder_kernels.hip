@@ -1,0 +1,792 @@
+// GMF correspondence encoder on gfx950: hand-written fp32-MFMA kernels.
+//
+// Replaces (file:line relative to /root/reference/GMF_PointDSC/):
+//   k_front      models/PointDSC.py:88,104-109,56-58   layer0 / PointCN conv1x1+BN+ReLU, Q/K/V conv1x1
+//   k_scattn     models/PointDSC.py:216-221,60-65,73   compat matrix (recomputed, never stored) +
+//                                                      softmax(compat*QK^T/sqrt(C)) V + fc_message + block sum
+//   k_ctx_prep   models/fusion_layer.py:124-126,46-49,86-87   LCPE(content) + LayerNorm + to_kv
+//   k_fusion_attn models/fusion_layer.py:119-121,44,84-94,190 LCPE(q) + LayerNorm + to_q + softmax(QK^T) V + to_out + residual
+//   k_fusion_ff  models/fusion_layer.py:54-69,191      LayerNorm + Linear + GEGLU + Linear + residual
+//   k_head       models/PointDSC.py:175-181,229,241    classifier head + F.normalize
+//
+// Every kernel runs 4 waves per workgroup, each wave owning one 32-row tile ("rows on lanes",
+// see mfma_core.hpp).  Weights, K/V tiles and context tiles stream L2 -> LDS in 16 KiB stages by
+// LDS-DMA; activations chain from one MFMA's accumulators into the next MFMA's operand registers.
+#include "mfma_core.hpp"
+
+namespace gmf {
+
+constexpr int C = 128;        // correspondence feature width
+constexpr int CF = C / 2;     // fragment length of a C-wide row
+constexpr int DH = 64;        // cross-attention head width (PointDSC: C/2)
+constexpr int DHF = DH / 2;
+constexpr int FFH = 512;      // GEGLU hidden width (4*C)
+constexpr int kWavesPerWG = 4;
+
+// ---- small helpers ---------------------------------------------------------------------
+// bias (or any per-feature vector) for out-block mb in fragment order
+GMF_DEVINL void load_vec_block(float (&v)[16], const float* __restrict__ vec, int mb, int h) {
+  const float4* p = reinterpret_cast<const float4*>(vec + 32 * mb) + h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 t = p[2 * q];
+    v[4 * q + 0] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
+}
+
+// store a Y^T block (16 regs, rows on lanes) as the P32 columns [32mb, 32mb+32) of a K-wide tile
+GMF_DEVINL void store_block_p32(float* __restrict__ tile_base, int mb, const float (&t)[16], int lane) {
+  float4* p = reinterpret_cast<float4*>(tile_base) + (4 * mb) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p[q * 64] = make_float4(t[4 * q + 0], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+}
+
+GMF_DEVINL void load_block_p32(float (&t)[16], const float* __restrict__ tile_base, int mb, int lane) {
+  const float4* p = reinterpret_cast<const float4*>(tile_base) + (4 * mb) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = p[q * 64];
+    t[4 * q + 0] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w;
+  }
+}
+
+// store a Y block (feature on lane) as d-block db of a T image tile
+GMF_DEVINL void store_block_timg(float* __restrict__ tile_base, int db, const f32x16& a, float bias, int lane) {
+  float4* p = reinterpret_cast<float4*>(tile_base) + (4 * db) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    p[q * 64] = make_float4(a[4 * q + 0] + bias, a[4 * q + 1] + bias, a[4 * q + 2] + bias, a[4 * q + 3] + bias);
+}
+
+// LCPE (fusion_layer.py:118-128): y[row] = x[row] + b + w0*x[row-1] + w1*x[row] + w2*x[row+1],
+// zero padding outside [0, n_rows).  taps = w0[C] | w1[C] | w2[C] | b[C].
+GMF_DEVINL void lcpe_frag(float (&y)[CF], const float* __restrict__ pair_base, int row, int n_rows,
+                          const float* __restrict__ taps, int h) {
+  const float4* base = reinterpret_cast<const float4*>(pair_base);
+  const bool has_m = row >= 1, has_p = row + 1 < n_rows;
+  const int rm = has_m ? row - 1 : row, rp = has_p ? row + 1 : row;
+  const float4* pc = base + (size_t)(row >> 5) * (CF / 4) * 64 + h * 32 + (row & 31);
+  const float4* pm = base + (size_t)(rm >> 5) * (CF / 4) * 64 + h * 32 + (rm & 31);
+  const float4* pp = base + (size_t)(rp >> 5) * (CF / 4) * 64 + h * 32 + (rp & 31);
+  const float4* t0 = reinterpret_cast<const float4*>(taps) + h;
+  const float fm = has_m ? 1.f : 0.f, fp = has_p ? 1.f : 0.f;
+#pragma unroll
+  for (int g = 0; g < CF / 4; ++g) {
+    const float4 xc = pc[g * 64], xm = pm[g * 64], xp = pp[g * 64];
+    const float4 w0 = t0[2 * g], w1 = t0[2 * g + C / 4], w2 = t0[2 * g + 2 * (C / 4)], b = t0[2 * g + 3 * (C / 4)];
+    y[4 * g + 0] = xc.x + b.x + w0.x * (fm * xm.x) + w1.x * xc.x + w2.x * (fp * xp.x);
+    y[4 * g + 1] = xc.y + b.y + w0.y * (fm * xm.y) + w1.y * xc.y + w2.y * (fp * xp.y);
+    y[4 * g + 2] = xc.z + b.z + w0.z * (fm * xm.z) + w1.z * xc.z + w2.z * (fp * xp.z);
+    y[4 * g + 3] = xc.w + b.w + w0.w * (fm * xm.w) + w1.w * xc.w + w2.w * (fp * xp.w);
+  }
+}
+
+GMF_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// =========================================================================================
+// k_front:  [layer0] -> PointCN (BN folded) -> f ; Q' = (Wq f + bq) * log2(e)/sqrt(C) ; K ; V
+//   stages (16): Wp[4] | Wq'[4] | Wk[4] | Wv[4]      vecs: bp | bq' | bk | bv | b0 | W0 image (K=8)
+//   outputs: f, Q', K as P32 images; V as T image.
+// =========================================================================================
+// MODE 0: in = feat image, PointCN applied.  MODE 1: in = corr_pos, layer0 then PointCN.
+// MODE 2: in = feat image used as-is (stand-alone NonLocalBlock whose caller already applied PointCN).
+template <int MODE>
+__global__ void __launch_bounds__(256, 2)
+k_front(const float* __restrict__ in, const float* __restrict__ wst, const float* __restrict__ vecs,
+        float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out,
+        float* __restrict__ v_out, int N, int tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i = lane & 31;
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+
+  constexpr bool FIRST = (MODE == 1);
+  StageStream ss;
+  if (MODE == 2) ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst + 4 * kStageFloats, 12);
+  else ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 16);
+  ss.prime();
+
+  float x[CF];
+  if (FIRST) {
+    const int row = tile * 32 + i;
+    float pk[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * h + e;
+      pk[e] = (row < N && k < 6) ? in[((size_t)pair * N + row) * 6 + k] : 0.f;
+    }
+    const float4* w0 = reinterpret_cast<const float4*>(vecs + 5 * C) + lane;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      f32x16 acc = zero16();
+      const float4 w = w0[mb * 64];
+      acc = mfma32(w.x, pk[0], acc); acc = mfma32(w.y, pk[1], acc);
+      acc = mfma32(w.z, pk[2], acc); acc = mfma32(w.w, pk[3], acc);
+      float b[16];
+      load_vec_block(b, vecs + 4 * C, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[16 * mb + r] = acc[r] + b[r];
+    }
+  } else {
+    load_frag_p32<CF>(x, in + toff, lane);
+  }
+
+  float f[CF];
+  if (MODE == 2) {
+#pragma unroll
+    for (int e = 0; e < CF; ++e) f[e] = x[e];
+  } else {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const float4* lw = ss.acquire();
+      f32x16 acc = zero16();
+      mma_wx<CF>(acc, lw, x);
+      float b[16];
+      load_vec_block(b, vecs, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) f[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+    }
+  }
+  if (active) store_frag_p32<CF>(f_out + toff, f, lane);
+
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {   // Q', K
+    float* dst = (which == 0 ? q_out : k_out) + toff;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const float4* lw = ss.acquire();
+      f32x16 acc = zero16();
+      mma_wx<CF>(acc, lw, f);
+      float b[16], t[16];
+      load_vec_block(b, vecs + (1 + which) * C, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r];
+      if (active) store_block_p32(dst, mb, t, lane);
+    }
+  }
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {             // V (feature on lane)
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_xw<CF>(acc, lw, f);
+    const float bv = vecs[3 * C + 32 * db + i];
+    if (active) store_block_timg(v_out + toff, db, acc, bv, lane);
+  }
+}
+
+// =========================================================================================
+// k_scattn: spatial-consistency self-attention, flash style, compat recomputed per (i,j).
+//   S^T = K Q'^T (keys on registers, queries on lanes) ; x = c_ij * s ; online softmax in base 2 ;
+//   O^T += V^T P^T.  Epilogue: fc_message (BN folded) and  out = msg + fusion2_out.
+//   stages (5): Wa[2] (64x128) | Wb (64x64, 2 blocks) | Wc[2] (128x64, 2 blocks each)
+//   vecs: ba[64] | bb[64] | bc[128]
+//   pts8: [B, Npad, 8] = (sx,sy,sz,0,tx,ty,tz,0)
+// =========================================================================================
+constexpr int kAttnBufFloats = 2 * kStageFloats + 256;   // K tile | V tile | 32 x pts8
+
+// DENSE = true: c_ij is read from the caller's [B,N,N] matrix `pts8` points to (drop-in NonLocalBlock).
+template <bool DENSE>
+__global__ void __launch_bounds__(256, 2)
+k_scattn(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
+         const float* __restrict__ pts8, const float* __restrict__ fus, const float* __restrict__ wst,
+         const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kAttnBufFloats];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i = lane & 31;
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t pbase = (size_t)pair * tiles;
+  const size_t toff = (pbase + tile) * (32 * C);
+
+  float qf[CF];
+  load_frag_p32<CF>(qf, q_img + toff, lane);
+  float si[3] = {0.f, 0.f, 0.f}, ti[3] = {0.f, 0.f, 0.f};
+  const float* crow = nullptr;   // DENSE: row i of the pair's compat matrix
+  if (DENSE) {
+    const int row = min(tile * 32 + i, N - 1);
+    crow = pts8 + ((size_t)pair * N + row) * (size_t)N;
+  } else {
+    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)tile * 32 + i) * 8);
+    const float4 a = pp[0], b = pp[1];
+    si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
+  }
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
+  float m_run = -INFINITY, l_half = 0.f;
+
+  const float* gk = k_img + pbase * (32 * C);
+  const float* gv = v_img + pbase * (32 * C);
+  const float* gp = pts8 + pbase * 32 * 8;
+
+  auto issue_tile = [&](int t) {
+    float* buf = lds + (t & 1) * kAttnBufFloats;
+    dma_issue(gk + (size_t)t * kStageFloats, buf, 16, wave, kWavesPerWG, lane);
+    dma_issue(gv + (size_t)t * kStageFloats, buf + kStageFloats, 16, wave, kWavesPerWG, lane);
+    if (!DENSE && wave == (t & 3)) dma_piece_1k(gp + (size_t)t * 256, buf + 2 * kStageFloats, lane);
+  };
+
+  issue_tile(0);
+  for (int t = 0; t < tiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < tiles) issue_tile(t + 1);
+    const float* buf = lds + (t & 1) * kAttnBufFloats;
+    const float4* lk = reinterpret_cast<const float4*>(buf) + lane;
+    const float4* lv = reinterpret_cast<const float4*>(buf + kStageFloats) + lane;
+    const float4* lp = reinterpret_cast<const float4*>(buf + 2 * kStageFloats) + 8 * h;
+
+    f32x16 s = zero16();
+    mma_wx<CF>(s, lk, qf);
+
+    float x[16];
+    const int jbase = t * 32 + 4 * h;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jl = 8 * (r >> 2) + (r & 3);           // + 4h folded into lp / jbase
+      float c;
+      if (DENSE) {
+        c = crow[min(jbase + jl, N - 1)];
+      } else {
+        const float4 a = lp[2 * jl], b = lp[2 * jl + 1];
+        const float ax = si[0] - a.x, ay = si[1] - a.y, az = si[2] - a.z;
+        const float bx = ti[0] - b.x, by = ti[1] - b.y, bz = ti[2] - b.z;
+        const float ds = sqrtf(fmaf(az, az, fmaf(ay, ay, ax * ax)));
+        const float dt = sqrtf(fmaf(bz, bz, fmaf(by, by, bx * bx)));
+        const float d = ds - dt;
+        c = fmaxf(1.0f - d * d * inv_sig2, 0.f);
+      }
+      float v = c * s[r];
+      v = (jbase + jl < N) ? v : -INFINITY;
+      x[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_new); ls += x[r]; }
+    l_half = fmaf(l_half, alpha, ls);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 vv = lv[(db * 4 + q) * 64];
+        oacc[db] = mfma32(vv.x, x[4 * q + 0], oacc[db]);
+        oacc[db] = mfma32(vv.y, x[4 * q + 1], oacc[db]);
+        oacc[db] = mfma32(vv.z, x[4 * q + 2], oacc[db]);
+        oacc[db] = mfma32(vv.w, x[4 * q + 3], oacc[db]);
+      }
+    }
+  }
+
+  // ---- epilogue: normalise, fc_message, add the Fusion-2 branch -------------------------
+  float o[CF];
+  {
+    const float inv = 1.0f / xhalf_sum(l_half);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
+  }
+  __syncthreads();   // all waves are done with the K/V buffers before weights stream into them
+  StageStream ss;
+  ss.init(lds, lds + kAttnBufFloats, wave, kWavesPerWG, lane, wst, 5);
+  ss.prime();
+  float m1[DHF], m2[DHF];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_wx<CF>(acc, lw, o);
+    float b[16];
+    load_vec_block(b, vecs, mb, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+  }
+  {
+    const float4* lw = ss.acquire();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      f32x16 acc = zero16();
+      mma_wx<DHF>(acc, lw + mb * (32 * DH / 4), m1);
+      float b[16];
+      load_vec_block(b, vecs + 64, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const float4* lw = ss.acquire();
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int mb = 2 * st + hb;
+      f32x16 acc = zero16();
+      mma_wx<DHF>(acc, lw + hb * (32 * DH / 4), m2);
+      float b[16], fz[16], t[16];
+      load_vec_block(b, vecs + 128, mb, h);
+      load_block_p32(fz, fus + toff, mb, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r] + fz[r];
+      if (active) store_block_p32(out + toff, mb, t, lane);
+    }
+  }
+}
+
+// =========================================================================================
+// k_ctx_prep: context side of a FusionLayer, once per (weight set, pair, token tile):
+//   ctx' = LCPE(ctx) [PE] ; cn = LayerNorm_ctx(ctx') ; Kc = cn Wk^T ; Vc = cn Wv^T
+//   output per tile: 4096 floats = Kc as P32 (K=64) | Vc as T image (D=64)
+//   stages (4): Wk[2] | Wv[2]        vecs: w0|w1|w2|b (LCPE content taps) | gamma | beta
+//   grid: (ceil(ttiles/4), B, L)   wst/vecs/out advance by set_stride per blockIdx.z
+// =========================================================================================
+template <bool PE>
+__global__ void __launch_bounds__(256, 2)
+k_ctx_prep(const float* __restrict__ ctx, const float* __restrict__ wst, const float* __restrict__ vecs,
+           float* __restrict__ out, int T, int ttiles, int wst_stride, int vec_stride) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i = lane & 31;
+  const int pair = blockIdx.y, set = blockIdx.z, nb = gridDim.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < ttiles;
+  const int tile = active ? tile_raw : ttiles - 1;
+  wst += (size_t)set * wst_stride;
+  vecs += (size_t)set * vec_stride;
+  const float* pair_base = ctx + (size_t)pair * ttiles * (32 * C);
+  float* dst = out + (((size_t)set * nb + pair) * ttiles + tile) * kStageFloats;
+
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 4);
+  ss.prime();
+
+  float x[CF], cn[CF];
+  if (PE) lcpe_frag(x, pair_base, tile * 32 + i, T, vecs, h);
+  else load_frag_p32<CF>(x, pair_base + (size_t)tile * (32 * C), lane);
+  layernorm_frag<CF>(cn, x, vecs + 4 * C, vecs + 5 * C, h);
+
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_wx<CF>(acc, lw, cn);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = acc[r];
+    if (active) store_block_p32(dst, mb, t, lane);
+  }
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_xw<CF>(acc, lw, cn);
+    if (active) store_block_timg(dst + 32 * DH, db, acc, 0.f, lane);
+  }
+}
+
+// =========================================================================================
+// k_fusion_attn: query side of a FusionLayer up to the first residual:
+//   x' = LCPE(x) [PE] ; q = LayerNorm(x') Wq'^T (Wq' pre-scaled by log2(e)/sqrt(DH)) ;
+//   a = softmax(q Kc^T) Vc ; x1 = a Wo^T + bo + x'
+//   stages: Wq'[2] | ctx tiles [ttiles] | Wo[2] (2 blocks of 32x64 each)
+//   vecs: w0|w1|w2|b (LCPE q taps) | gamma | beta | bo
+// =========================================================================================
+template <bool PE>
+__global__ void __launch_bounds__(256, 2)
+k_fusion_attn(const float* __restrict__ xin, const float* __restrict__ ctx_img, const float* __restrict__ wst,
+              const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i = lane & 31;
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const float* pair_base = xin + (size_t)pair * tiles * (32 * C);
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 2,
+          ctx_img + (size_t)pair * ttiles * kStageFloats, ttiles, wst + 2 * kStageFloats, 2);
+  ss.prime();
+
+  float xp[CF];
+  if (PE) lcpe_frag(xp, pair_base, tile * 32 + i, N, vecs, h);
+  else load_frag_p32<CF>(xp, pair_base + (size_t)tile * (32 * C), lane);
+
+  float qf[DHF];
+  {
+    float xn[CF];
+    layernorm_frag<CF>(xn, xp, vecs + 4 * C, vecs + 5 * C, h);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const float4* lw = ss.acquire();
+      f32x16 acc = zero16();
+      mma_wx<CF>(acc, lw, xn);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qf[16 * mb + r] = acc[r];
+    }
+  }
+
+  f32x16 oacc[2];
+  oacc[0] = zero16(); oacc[1] = zero16();
+  float m_run = -INFINITY, l_half = 0.f;
+  for (int t = 0; t < ttiles; ++t) {
+    const float4* lk = ss.acquire();
+    const float4* lv = lk + (32 * DH / 4);
+    f32x16 s = zero16();
+    mma_wx<DHF>(s, lk, qf);
+    float x[16];
+    float mx = -INFINITY;
+    const int jbase = t * 32 + 4 * h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jl = 8 * (r >> 2) + (r & 3);
+      const float v = (jbase + jl < T) ? s[r] : -INFINITY;
+      x[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_new); ls += x[r]; }
+    l_half = fmaf(l_half, alpha, ls);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 vv = lv[(db * 4 + q) * 64];
+        oacc[db] = mfma32(vv.x, x[4 * q + 0], oacc[db]);
+        oacc[db] = mfma32(vv.y, x[4 * q + 1], oacc[db]);
+        oacc[db] = mfma32(vv.z, x[4 * q + 2], oacc[db]);
+        oacc[db] = mfma32(vv.w, x[4 * q + 3], oacc[db]);
+      }
+    }
+  }
+  float o[DHF];
+  {
+    const float inv = 1.0f / xhalf_sum(l_half);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
+  }
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const float4* lw = ss.acquire();
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int mb = 2 * st + hb;
+      f32x16 acc = zero16();
+      mma_wx<DHF>(acc, lw + hb * (32 * DH / 4), o);
+      float b[16], t[16];
+      load_vec_block(b, vecs + 6 * C, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r] + xp[16 * mb + r];
+      if (active) store_block_p32(x1_out + toff, mb, t, lane);
+    }
+  }
+}
+
+// =========================================================================================
+// k_fusion_ff:  x2 = x1 + W2 ( (W1a xn + b1a) * gelu(W1g xn + b1g) ) + b2 ,  xn = LayerNorm(x1)
+//   The 1024-wide hidden layer never leaves registers: per chunk of 32 hidden units the two
+//   W1 products are 16 accumulator registers each, GEGLU is elementwise on them, and the result
+//   is directly the B operand of the W2 product.
+//   stages (48): for c in 0..15: W1a_c (32x128) | W1g_c (32x128) | W2_c (4 blocks of 32x32)
+//   vecs: gamma | beta | b1a[512] | b1g[512] | b2[128]
+// =========================================================================================
+__global__ void __launch_bounds__(256, 2)
+k_fusion_ff(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
+            float* __restrict__ x2_out, int tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 3 * (FFH / 32));
+  ss.prime();
+
+  float xn[CF];
+  {
+    float x[CF];
+    load_frag_p32<CF>(x, x1 + toff, lane);
+    layernorm_frag<CF>(xn, x, vecs, vecs + C, h);
+  }
+  f32x16 y[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) y[mb] = zero16();
+  const float* b1a = vecs + 2 * C;
+  const float* b1g = vecs + 2 * C + FFH;
+
+  for (int c = 0; c < FFH / 32; ++c) {
+    float ga[16];
+    {
+      const float4* lw = ss.acquire();
+      f32x16 acc = zero16();
+      mma_wx<CF>(acc, lw, xn);
+      float b[16];
+      load_vec_block(b, b1a, c, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ga[r] = acc[r] + b[r];
+    }
+    {
+      const float4* lw = ss.acquire();
+      f32x16 acc = zero16();
+      mma_wx<CF>(acc, lw, xn);
+      float b[16];
+      load_vec_block(b, b1g, c, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ga[r] *= gelu_erf(acc[r] + b[r]);
+    }
+    {
+      const float4* lw = ss.acquire();
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) mma_wx<16>(y[mb], lw + mb * (32 * 32 / 4), ga);
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    float b[16], xr[16], t[16];
+    load_vec_block(b, vecs + 2 * C + 2 * FFH, mb, h);
+    load_block_p32(xr, x1 + toff, mb, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = y[mb][r] + b[r] + xr[r];
+    if (active) store_block_p32(x2_out + toff, mb, t, lane);
+  }
+}
+
+// =========================================================================================
+// k_head: classifier 128->32 ReLU ->32 ReLU ->1 and row L2 normalisation.
+//   stages (2): Wc1 (32x128) | Wc2 (32x32, padded)     vecs: b1[32] | b2[32] | w3[32] | b3
+//   outputs (row-major, the layout the pose head and the caller consume):
+//     logits [B,N], feat_n [B,N,128] (unit rows), feat [B,N,128] (optional, may be null)
+// =========================================================================================
+__global__ void __launch_bounds__(256, 2)
+k_head(const float* __restrict__ feat_img, const float* __restrict__ wst, const float* __restrict__ vecs,
+       float* __restrict__ logits, float* __restrict__ feat_n, float* __restrict__ feat_rm, int N, int tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i = lane & 31;
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+  const int row = tile * 32 + i;
+
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 2);
+  ss.prime();
+
+  float x[CF];
+  load_frag_p32<CF>(x, feat_img + toff, lane);
+  float h1[16], h2[16];
+  {
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_wx<CF>(acc, lw, x);
+    float b[16];
+    load_vec_block(b, vecs, 0, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h1[r] = fmaxf(acc[r] + b[r], 0.f);
+  }
+  {
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_wx<16>(acc, lw, h1);
+    float b[16];
+    load_vec_block(b, vecs + 32, 0, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h2[r] = fmaxf(acc[r] + b[r], 0.f);
+  }
+  float w3[16];
+  load_vec_block(w3, vecs + 64, 0, h);
+  float part = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part = fmaf(h2[r], w3[r], part);
+  const float logit = xhalf_sum(part) + vecs[96];
+
+  float ss2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < CF; ++k) ss2 = fmaf(x[k], x[k], ss2);
+  const float inv = 1.0f / fmaxf(sqrtf(xhalf_sum(ss2)), 1e-12f);
+
+  if (active && row < N) {
+    const size_t ro = ((size_t)pair * N + row);
+    if (h == 0) logits[ro] = logit;
+    float4* pn = reinterpret_cast<float4*>(feat_n + ro * C) + h;
+#pragma unroll
+    for (int g = 0; g < CF / 4; ++g)
+      pn[2 * g] = make_float4(x[4 * g] * inv, x[4 * g + 1] * inv, x[4 * g + 2] * inv, x[4 * g + 3] * inv);
+    if (feat_rm) {
+      float4* pr = reinterpret_cast<float4*>(feat_rm + ro * C) + h;
+#pragma unroll
+      for (int g = 0; g < CF / 4; ++g) pr[2 * g] = make_float4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+    }
+  }
+}
+
+// =========================================================================================
+// layout conversion kernels (the drop-in boundary hands over row-major / channel-major tensors)
+// =========================================================================================
+// strided [B, n_rows, K] (element (b,r,k) at b*sb + r*sr + k*sk) -> P32 image [B, tiles, 32*K]; rows >= n_rows are 0
+__global__ void k_pack_p32(const float* __restrict__ src, float* __restrict__ dst, int n_rows, int tiles, int K,
+                           long sb, long sr, long sk, long total4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int lane = idx & 63;
+  const long gi = idx >> 6;
+  const int kg = K / 8;
+  const int g = gi % kg;
+  const long bt = gi / kg;
+  const int tile = bt % tiles;
+  const long b = bt / tiles;
+  const int row = tile * 32 + (lane & 31);
+  const int k0 = 8 * g + 4 * (lane >> 5);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < n_rows) {
+    const float* p = src + b * sb + (long)row * sr + (long)k0 * sk;
+    v = make_float4(p[0], p[sk], p[2 * sk], p[3 * sk]);
+  }
+  reinterpret_cast<float4*>(dst)[idx] = v;
+}
+
+// P32 image -> strided [B, n_rows, K]
+__global__ void k_unpack_p32(const float* __restrict__ src, float* __restrict__ dst, int n_rows, int tiles, int K,
+                             long sb, long sr, long sk, long total4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int lane = idx & 63;
+  const long gi = idx >> 6;
+  const int kg = K / 8;
+  const int g = gi % kg;
+  const long bt = gi / kg;
+  const int tile = bt % tiles;
+  const long b = bt / tiles;
+  const int row = tile * 32 + (lane & 31);
+  const int k0 = 8 * g + 4 * (lane >> 5);
+  if (row < n_rows) {
+    const float4 v = reinterpret_cast<const float4*>(src)[idx];
+    float* p = dst + b * sb + (long)row * sr + (long)k0 * sk;
+    p[0] = v.x; p[sk] = v.y; p[2 * sk] = v.z; p[3 * sk] = v.w;
+  }
+}
+
+// src,tgt [B,N,3] -> pts8 [B, Npad, 8] (zero padded rows)
+__global__ void k_pack_pts8(const float* __restrict__ src, const float* __restrict__ tgt, float* __restrict__ dst,
+                            int N, int Npad, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int row = idx % Npad;
+  const long b = idx / Npad;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+  if (row < N) {
+    const float* ps = src + (b * N + row) * 3;
+    const float* pt = tgt + (b * N + row) * 3;
+    a = make_float4(ps[0], ps[1], ps[2], 0.f);
+    c = make_float4(pt[0], pt[1], pt[2], 0.f);
+  }
+  reinterpret_cast<float4*>(dst)[2 * idx] = a;
+  reinterpret_cast<float4*>(dst)[2 * idx + 1] = c;
+}
+
+}  // namespace gmf
+
+// -----------------------------------------------------------------------------------------
+// host-side launchers (C++ linkage inside the library; the C ABI in gmf_api.cpp calls these)
+// -----------------------------------------------------------------------------------------
+#include "launchers.hpp"
+
+namespace gmf {
+
+static inline dim3 tile_grid(int tiles, int B, int sets = 1) { return dim3((tiles + kWavesPerWG - 1) / kWavesPerWG, B, sets); }
+
+hipError_t launch_front(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
+                        float* v, int B, int N, int tiles, hipStream_t s) {
+  if (mode == 1) hipLaunchKernelGGL(k_front<1>, tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  else if (mode == 2) hipLaunchKernelGGL(k_front<2>, tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  else hipLaunchKernelGGL(k_front<0>, tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_scattn(const float* q, const float* k, const float* v, const float* pts8, const float* fus,
+                         const float* wst, const float* vecs, float* out, int B, int N, int tiles, float sigma_d,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(k_scattn<false>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles,
+                     1.0f / (sigma_d * sigma_d));
+  return hipGetLastError();
+}
+
+hipError_t launch_scattn_dense(const float* q, const float* k, const float* v, const float* compat, const float* fus,
+                               const float* wst, const float* vecs, float* out, int B, int N, int tiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_scattn<true>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, compat, fus, wst, vecs, out, N, tiles, 0.f);
+  return hipGetLastError();
+}
+
+hipError_t launch_ctx_prep(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
+                           int ttiles, int sets, int wst_stride, int vec_stride, hipStream_t s) {
+  if (pe) hipLaunchKernelGGL(k_ctx_prep<true>, tile_grid(ttiles, B, sets), dim3(256), 0, s, ctx, wst, vecs, out, T, ttiles, wst_stride, vec_stride);
+  else hipLaunchKernelGGL(k_ctx_prep<false>, tile_grid(ttiles, B, sets), dim3(256), 0, s, ctx, wst, vecs, out, T, ttiles, wst_stride, vec_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_fusion_attn(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
+                              float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s) {
+  if (pe) hipLaunchKernelGGL(k_fusion_attn<true>, tile_grid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
+  else hipLaunchKernelGGL(k_fusion_attn<false>, tile_grid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_fusion_ff, tile_grid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_head(const float* feat_img, const float* wst, const float* vecs, float* logits, float* feat_n,
+                       float* feat_rm, int B, int N, int tiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_head, tile_grid(tiles, B), dim3(256), 0, s, feat_img, wst, vecs, logits, feat_n, feat_rm, N, tiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s) {
+  const int tiles = (n_rows + 31) / 32;
+  const long total4 = (long)B * tiles * (K / 8) * 64;
+  hipLaunchKernelGGL(k_pack_p32, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, src, dst, n_rows, tiles, K, sb, sr, sk, total4);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s) {
+  const int tiles = (n_rows + 31) / 32;
+  const long total4 = (long)B * tiles * (K / 8) * 64;
+  hipLaunchKernelGGL(k_unpack_p32, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, src, dst, n_rows, tiles, K, sb, sr, sk, total4);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s) {
+  const int Npad = ((N + 31) / 32) * 32;
+  const long total = (long)B * Npad;
+  hipLaunchKernelGGL(k_pack_pts8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, tgt, dst, N, Npad, total);
+  return hipGetLastError();
+}
+
+}  // namespace gmf

@@ -1,0 +1,473 @@
+// C ABI of libgmf_hip.so (see include/gmf_hip.h).  Thin host layer: argument checks, the
+// library-owned workspace arena, and the launch sequences.  No torch types, no host syncs.
+#include "../../include/gmf_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "launchers.hpp"
+#include "launchers_pose.hpp"
+
+struct gmf_handle {
+  int device = 0;
+  std::string err;
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+  size_t arena_used = 0;
+};
+
+namespace {
+
+constexpr int kC = 128;
+constexpr size_t kTileFloats = 32 * kC;
+
+int fail(gmf_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+int hip_fail(gmf_handle* h, hipError_t e, const char* where) {
+  return fail(h, GMF_ERR_HIP, std::string(where) + ": " + hipGetErrorString(e));
+}
+
+#define GMF_HIP(call)                                        \
+  do {                                                       \
+    hipError_t _e = (call);                                  \
+    if (_e != hipSuccess) return hip_fail(h, _e, #call);     \
+  } while (0)
+
+#define GMF_REQUIRE(cond, code, msg)                          \
+  do {                                                        \
+    if (!(cond)) return fail(h, code, std::string("gmf: ") + msg); \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Bump allocator over one device block.  Growing frees and reallocates (hipFree synchronises the
+// device, so no kernel can still be using the old block).
+int arena_reserve(gmf_handle* h, size_t bytes) {
+  h->arena_used = 0;
+  if (bytes <= h->arena_bytes) return GMF_OK;
+  if (h->arena) {
+    hipError_t e = hipFree(h->arena);
+    h->arena = nullptr;
+    h->arena_bytes = 0;
+    if (e != hipSuccess) return hip_fail(h, e, "hipFree(workspace)");
+  }
+  const size_t want = align_up(bytes + bytes / 8, 1 << 20);
+  hipError_t e = hipMalloc(&h->arena, want);
+  if (e != hipSuccess) {
+    h->arena = nullptr;
+    return fail(h, GMF_ERR_OOM, std::string("hipMalloc(workspace ") + std::to_string(want) + " B): " + hipGetErrorString(e));
+  }
+  h->arena_bytes = want;
+  return GMF_OK;
+}
+
+template <typename T>
+T* arena_take(gmf_handle* h, size_t count) {
+  const size_t off = align_up(h->arena_used, 256);
+  h->arena_used = off + count * sizeof(T);
+  return reinterpret_cast<T*>(static_cast<char*>(h->arena) + off);
+}
+
+inline size_t arena_need(size_t count, size_t elem) { return align_up(count * elem, 256) + 256; }
+
+inline hipStream_t S(gmf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline int tiles_of(int n) { return (n + 31) / 32; }
+
+struct SetDevice {
+  gmf_handle* h;
+  explicit SetDevice(gmf_handle* hh) : h(hh) { (void)hipSetDevice(hh->device); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int gmf_abi_version(void) { return GMF_ABI_VERSION; }
+
+int gmf_create(int device, gmf_handle** out) {
+  if (!out) return GMF_ERR_BAD_ARG;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0 || device < 0 || device >= n) return GMF_ERR_NO_DEVICE;
+  gmf_handle* h = new (std::nothrow) gmf_handle();
+  if (!h) return GMF_ERR_OOM;
+  h->device = device;
+  *out = h;
+  return GMF_OK;
+}
+
+void gmf_destroy(gmf_handle* h) {
+  if (!h) return;
+  if (h->arena) {
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->arena);
+  }
+  delete h;
+}
+
+const char* gmf_last_error_string(gmf_handle* h) { return h ? h->err.c_str() : "gmf: null handle"; }
+
+long long gmf_workspace_bytes(gmf_handle* h) { return h ? (long long)h->arena_bytes : 0; }
+
+// ---------------------------------------------------------------------------------------------
+int gmf_pack_rows_p32(gmf_handle* h, const float* src, long long sb, long long sr, long long sk, int B, int n_rows,
+                      int K, float* dst, gmf_stream_t stream) {
+  GMF_REQUIRE(h && src && dst, GMF_ERR_BAD_ARG, "pack_rows_p32: null pointer");
+  GMF_REQUIRE(B > 0 && n_rows > 0 && K > 0 && K % 8 == 0, GMF_ERR_UNSUPPORTED_SHAPE, "pack_rows_p32: K must be a positive multiple of 8");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_pack_p32(src, dst, B, n_rows, K, sb, sr, sk, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_unpack_rows_p32(gmf_handle* h, const float* src_img, int B, int n_rows, int K, float* dst, long long sb,
+                        long long sr, long long sk, gmf_stream_t stream) {
+  GMF_REQUIRE(h && src_img && dst, GMF_ERR_BAD_ARG, "unpack_rows_p32: null pointer");
+  GMF_REQUIRE(B > 0 && n_rows > 0 && K > 0 && K % 8 == 0, GMF_ERR_UNSUPPORTED_SHAPE, "unpack_rows_p32: K must be a positive multiple of 8");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_unpack_p32(src_img, dst, B, n_rows, K, sb, sr, sk, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_pack_pts8(gmf_handle* h, const float* src, const float* tgt, int B, int N, float* dst, gmf_stream_t stream) {
+  GMF_REQUIRE(h && src && tgt && dst, GMF_ERR_BAD_ARG, "pack_pts8: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "pack_pts8: empty input");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_pack_pts8(src, tgt, dst, B, N, S(stream)));
+  return GMF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int gmf_front_forward(gmf_handle* h, int first, const float* in, const float* wst, const float* vecs, float* f,
+                      float* q, float* k, float* v, int B, int N, gmf_stream_t stream) {
+  GMF_REQUIRE(h && in && wst && vecs && f && q && k && v, GMF_ERR_BAD_ARG, "front_forward: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "front_forward: empty input");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_front(first ? 1 : 0, in, wst, vecs, f, q, k, v, B, N, tiles_of(N), S(stream)));
+  return GMF_OK;
+}
+
+int gmf_scattn_forward(gmf_handle* h, const float* q, const float* k, const float* v, const float* pts8,
+                       const float* fusion2_out, const float* wst, const float* vecs, float* out, int B, int N,
+                       float sigma_d, gmf_stream_t stream) {
+  GMF_REQUIRE(h && q && k && v && pts8 && fusion2_out && wst && vecs && out, GMF_ERR_BAD_ARG, "scattn_forward: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "scattn_forward: empty input");
+  GMF_REQUIRE(sigma_d > 0.f, GMF_ERR_BAD_ARG, "scattn_forward: sigma_d must be positive");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_scattn(q, k, v, pts8, fusion2_out, wst, vecs, out, B, N, tiles_of(N), sigma_d, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_scattn_forward_dense(gmf_handle* h, const float* q, const float* k, const float* v, const float* attention,
+                             const float* fusion2_out, const float* wst, const float* vecs, float* out, int B, int N,
+                             gmf_stream_t stream) {
+  GMF_REQUIRE(h && q && k && v && attention && fusion2_out && wst && vecs && out, GMF_ERR_BAD_ARG, "scattn_forward_dense: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "scattn_forward_dense: empty input");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_scattn_dense(q, k, v, attention, fusion2_out, wst, vecs, out, B, N, tiles_of(N), S(stream)));
+  return GMF_OK;
+}
+
+int gmf_fusion_ctx_prepare(gmf_handle* h, int pe, const float* ctx, const float* wst, const float* vecs, float* out,
+                           int B, int T, int sets, int wst_stride, int vec_stride, gmf_stream_t stream) {
+  GMF_REQUIRE(h && ctx && wst && vecs && out, GMF_ERR_BAD_ARG, "fusion_ctx_prepare: null pointer");
+  GMF_REQUIRE(B > 0 && T > 0 && sets > 0, GMF_ERR_UNSUPPORTED_SHAPE, "fusion_ctx_prepare: empty input");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_ctx_prep(pe != 0, ctx, wst, vecs, out, B, T, tiles_of(T), sets, wst_stride, vec_stride, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_fusion_attn_forward(gmf_handle* h, int pe, const float* x, const float* ctx_img, const float* wst,
+                            const float* vecs, float* x1, int B, int N, int T, gmf_stream_t stream) {
+  GMF_REQUIRE(h && x && ctx_img && wst && vecs && x1, GMF_ERR_BAD_ARG, "fusion_attn_forward: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "fusion_attn_forward: empty input");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_fusion_attn(pe != 0, x, ctx_img, wst, vecs, x1, B, N, tiles_of(N), T, tiles_of(T), S(stream)));
+  return GMF_OK;
+}
+
+int gmf_fusion_ff_forward(gmf_handle* h, const float* x1, const float* wst, const float* vecs, float* x2, int B,
+                          int N, gmf_stream_t stream) {
+  GMF_REQUIRE(h && x1 && wst && vecs && x2, GMF_ERR_BAD_ARG, "fusion_ff_forward: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "fusion_ff_forward: empty input");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_fusion_ff(x1, wst, vecs, x2, B, tiles_of(N), S(stream)));
+  return GMF_OK;
+}
+
+int gmf_classifier_forward(gmf_handle* h, const float* feat_img, const float* wst, const float* vecs, float* logits,
+                           float* feat_n, float* feat, int B, int N, gmf_stream_t stream) {
+  GMF_REQUIRE(h && feat_img && wst && vecs && logits && feat_n, GMF_ERR_BAD_ARG, "classifier_forward: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "classifier_forward: empty input");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_head(feat_img, wst, vecs, logits, feat_n, feat, B, N, tiles_of(N), S(stream)));
+  return GMF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int check_weights(gmf_handle* h, const gmf_encoder_weights* w) {
+  GMF_REQUIRE(w, GMF_ERR_BAD_ARG, "encoder weights: null");
+  GMF_REQUIRE(w->num_layers >= 0 && w->num_layers <= 64, GMF_ERR_BAD_ARG, "encoder weights: bad num_layers");
+  GMF_REQUIRE(w->sigma_d > 0.f, GMF_ERR_BAD_ARG, "encoder weights: sigma_d must be positive");
+  return GMF_OK;
+}
+
+// Runs Fusion-2 + the spatial-consistency block of layer `l` given f,q,k,v.
+static int run_block_tail(gmf_handle* h, const gmf_encoder_weights* w, int l, const float* f, const float* q,
+                          const float* k, const float* v, const float* pts8, const float* ctx_l, float* x1, float* x2,
+                          float* out, int B, int N, int T, hipStream_t st, const float* dense_compat = nullptr) {
+  const int tiles = tiles_of(N), tt = tiles_of(T);
+  GMF_HIP(gmf::launch_fusion_attn(true, f, ctx_l, w->attn_wst + (size_t)l * w->attn_wst_stride,
+                                  w->attn_vec + (size_t)l * w->attn_vec_stride, x1, B, N, tiles, T, tt, st));
+  GMF_HIP(gmf::launch_fusion_ff(x1, w->ff_wst + (size_t)l * w->ff_wst_stride, w->ff_vec + (size_t)l * w->ff_vec_stride,
+                                x2, B, tiles, st));
+  if (dense_compat)
+    GMF_HIP(gmf::launch_scattn_dense(q, k, v, dense_compat, x2, w->tail_wst + (size_t)l * w->tail_wst_stride,
+                                     w->tail_vec + (size_t)l * w->tail_vec_stride, out, B, N, tiles, st));
+  else
+    GMF_HIP(gmf::launch_scattn(q, k, v, pts8, x2, w->tail_wst + (size_t)l * w->tail_wst_stride,
+                               w->tail_vec + (size_t)l * w->tail_vec_stride, out, B, N, tiles, w->sigma_d, st));
+  return GMF_OK;
+}
+
+int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float* corr_pos, const float* src_keypts,
+                        const float* tgt_keypts, const float* p_tokens, const float* q_tokens, int B, int N, int T,
+                        float* logits, float* feat_n, float* feat, gmf_stream_t stream) {
+  GMF_REQUIRE(h, GMF_ERR_BAD_ARG, "encoder_forward: null handle");
+  if (int rc = check_weights(h, w)) return rc;
+  GMF_REQUIRE(corr_pos && src_keypts && tgt_keypts && p_tokens && q_tokens && logits && feat_n, GMF_ERR_BAD_ARG,
+              "encoder_forward: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "encoder_forward: empty input");
+  SetDevice sd(h);
+  hipStream_t st = S(stream);
+  const int L = w->num_layers;
+  const int tiles = tiles_of(N), tt = tiles_of(T);
+  const size_t act = (size_t)B * tiles * kTileFloats;
+  const size_t tok = (size_t)B * tt * kTileFloats;
+  const size_t need = 8 * arena_need(act, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) + 5 * arena_need(tok, 4) +
+                      arena_need((size_t)(L > 0 ? L : 1) * tok, 4);
+  if (int rc = arena_reserve(h, need)) return rc;
+  float* featA = arena_take<float>(h, act);
+  float* featB = arena_take<float>(h, act);
+  float* f = arena_take<float>(h, act);
+  float* q = arena_take<float>(h, act);
+  float* k = arena_take<float>(h, act);
+  float* v = arena_take<float>(h, act);
+  float* x1 = arena_take<float>(h, act);
+  float* x2 = arena_take<float>(h, act);
+  float* pts8 = arena_take<float>(h, (size_t)B * tiles * 32 * 8);
+  float* pimg = arena_take<float>(h, tok);
+  float* qimg = arena_take<float>(h, tok);
+  float* f1ctx = arena_take<float>(h, tok);
+  float* x1t = arena_take<float>(h, tok);
+  float* imgfeat = arena_take<float>(h, tok);
+  float* ctxall = arena_take<float>(h, (size_t)(L > 0 ? L : 1) * tok);
+
+  // Fusion-1: image_feat = FusionLayer(p_tok (context), queries = q_tok), pe = False (PointDSC.py:137)
+  GMF_HIP(gmf::launch_pack_p32(p_tokens, pimg, B, T, kC, (long)T * kC, kC, 1, st));
+  GMF_HIP(gmf::launch_pack_p32(q_tokens, qimg, B, T, kC, (long)T * kC, kC, 1, st));
+  GMF_HIP(gmf::launch_ctx_prep(false, pimg, w->f1_ctx_wst, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st));
+  GMF_HIP(gmf::launch_fusion_attn(false, qimg, f1ctx, w->f1_attn_wst, w->f1_attn_vec, x1t, B, T, tt, T, tt, st));
+  GMF_HIP(gmf::launch_fusion_ff(x1t, w->f1_ff_wst, w->f1_ff_vec, imgfeat, B, tt, st));
+  // context side of all L Fusion-2 layers in one launch
+  if (L > 0)
+    GMF_HIP(gmf::launch_ctx_prep(true, imgfeat, w->ctx_wst, w->ctx_vec, ctxall, B, T, tt, L, w->ctx_wst_stride,
+                                 w->ctx_vec_stride, st));
+  GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st));
+
+  float* cur = featA;
+  float* nxt = featB;
+  if (L == 0) {
+    // degenerate: features are layer0(corr_pos) only
+    GMF_HIP(gmf::launch_front(1, corr_pos, w->front_wst, w->front_vec, cur, q, k, v, B, N, tiles, st));
+  }
+  for (int l = 0; l < L; ++l) {
+    const float* in = (l == 0) ? corr_pos : cur;
+    GMF_HIP(gmf::launch_front(l == 0 ? 1 : 0, in, w->front_wst + (size_t)l * w->front_wst_stride,
+                              w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
+    if (int rc = run_block_tail(h, w, l, f, q, k, v, pts8, ctxall + (size_t)l * tok, x1, x2, nxt, B, N, T, st)) return rc;
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  GMF_HIP(gmf::launch_head(cur, w->head_wst, w->head_vec, logits, feat_n, feat, B, N, tiles, st));
+  return GMF_OK;
+}
+
+int gmf_nonlocal_block_forward(gmf_handle* h, const gmf_encoder_weights* w, int layer, int apply_pointcn,
+                               const float* feat_img, const float* pts8, const float* attention,
+                               const float* image_feat_img, float* out_img, int B, int N, int T, gmf_stream_t stream) {
+  GMF_REQUIRE(h, GMF_ERR_BAD_ARG, "nonlocal_block_forward: null handle");
+  if (int rc = check_weights(h, w)) return rc;
+  GMF_REQUIRE(feat_img && image_feat_img && out_img, GMF_ERR_BAD_ARG, "nonlocal_block_forward: null pointer");
+  GMF_REQUIRE((pts8 != nullptr) != (attention != nullptr), GMF_ERR_BAD_ARG, "nonlocal_block_forward: pass exactly one of pts8 / attention");
+  GMF_REQUIRE(layer >= 0 && layer < w->num_layers, GMF_ERR_BAD_ARG, "nonlocal_block_forward: layer out of range");
+  GMF_REQUIRE(B > 0 && N > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "nonlocal_block_forward: empty input");
+  GMF_REQUIRE(apply_pointcn == 0 || apply_pointcn == 1, GMF_ERR_BAD_ARG, "nonlocal_block_forward: bad flag");
+  SetDevice sd(h);
+  hipStream_t st = S(stream);
+  const int tiles = tiles_of(N), tt = tiles_of(T);
+  const size_t act = (size_t)B * tiles * kTileFloats;
+  const size_t tok = (size_t)B * tt * kTileFloats;
+  if (int rc = arena_reserve(h, 6 * arena_need(act, 4) + arena_need(tok, 4))) return rc;
+  float* f = arena_take<float>(h, act);
+  float* q = arena_take<float>(h, act);
+  float* k = arena_take<float>(h, act);
+  float* v = arena_take<float>(h, act);
+  float* x1 = arena_take<float>(h, act);
+  float* x2 = arena_take<float>(h, act);
+  float* ctx = arena_take<float>(h, tok);
+  // apply_pointcn = 0: the caller's feat is already the block input (NonLocalBlock.forward, PointDSC.py:40-45)
+  GMF_HIP(gmf::launch_front(apply_pointcn ? 0 : 2, feat_img, w->front_wst + (size_t)layer * w->front_wst_stride,
+                            w->front_vec + (size_t)layer * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
+  GMF_HIP(gmf::launch_ctx_prep(true, image_feat_img, w->ctx_wst + (size_t)layer * w->ctx_wst_stride,
+                               w->ctx_vec + (size_t)layer * w->ctx_vec_stride, ctx, B, T, tt, 1, 0, 0, st));
+  return run_block_tail(h, w, layer, f, q, k, v, pts8, ctx, x1, x2, out_img, B, N, T, st, attention);
+}
+
+int gmf_fusion_layer_forward(gmf_handle* h, int pe, const float* ctx_wst, const float* ctx_vec, const float* attn_wst,
+                             const float* attn_vec, const float* ff_wst, const float* ff_vec, const float* data,
+                             const float* queries, long long q_sb, long long q_sr, long long q_sk, float* out,
+                             long long o_sb, long long o_sr, long long o_sk, int B, int N, int T, gmf_stream_t stream) {
+  GMF_REQUIRE(h && ctx_wst && ctx_vec && attn_wst && attn_vec && ff_wst && ff_vec && data && queries && out,
+              GMF_ERR_BAD_ARG, "fusion_layer_forward: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "fusion_layer_forward: empty input");
+  SetDevice sd(h);
+  hipStream_t st = S(stream);
+  const int tiles = tiles_of(N), tt = tiles_of(T);
+  const size_t act = (size_t)B * tiles * kTileFloats;
+  const size_t tok = (size_t)B * tt * kTileFloats;
+  if (int rc = arena_reserve(h, 3 * arena_need(act, 4) + 2 * arena_need(tok, 4))) return rc;
+  float* xin = arena_take<float>(h, act);
+  float* x1 = arena_take<float>(h, act);
+  float* x2 = arena_take<float>(h, act);
+  float* cimg = arena_take<float>(h, tok);
+  float* ctx = arena_take<float>(h, tok);
+  GMF_HIP(gmf::launch_pack_p32(data, cimg, B, T, kC, (long)T * kC, kC, 1, st));
+  GMF_HIP(gmf::launch_pack_p32(queries, xin, B, N, kC, q_sb, q_sr, q_sk, st));
+  GMF_HIP(gmf::launch_ctx_prep(pe != 0, cimg, ctx_wst, ctx_vec, ctx, B, T, tt, 1, 0, 0, st));
+  GMF_HIP(gmf::launch_fusion_attn(pe != 0, xin, ctx, attn_wst, attn_vec, x1, B, N, tiles, T, tt, st));
+  GMF_HIP(gmf::launch_fusion_ff(x1, ff_wst, ff_vec, x2, B, tiles, st));
+  GMF_HIP(gmf::launch_unpack_p32(x2, out, B, N, kC, o_sb, o_sr, o_sk, st));
+  return GMF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int gmf_pick_seeds(gmf_handle* h, const float* src_keypts, const float* scores, int B, int N, float nms_radius,
+                   int use_nms, int num_seeds, int* seeds_out, gmf_stream_t stream) {
+  GMF_REQUIRE(h && src_keypts && scores && seeds_out, GMF_ERR_BAD_ARG, "pick_seeds: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0 && num_seeds > 0 && num_seeds <= N, GMF_ERR_UNSUPPORTED_SHAPE, "pick_seeds: need 0 < num_seeds <= N");
+  GMF_REQUIRE(N <= 16384, GMF_ERR_UNSUPPORTED_SHAPE, "pick_seeds: N > 16384 is not supported by the in-LDS sort");
+  SetDevice sd(h);
+  hipStream_t st = S(stream);
+  const float* keys = scores;
+  if (use_nms) {
+    if (int rc = arena_reserve(h, arena_need((size_t)B * N, 4))) return rc;
+    float* kbuf = arena_take<float>(h, (size_t)B * N);
+    GMF_HIP(gmf::launch_nms_keys(src_keypts, scores, kbuf, B, N, nms_radius, st));
+    keys = kbuf;
+  }
+  GMF_HIP(gmf::launch_sort_topk(keys, seeds_out, B, N, num_seeds, st));
+  return GMF_OK;
+}
+
+int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, const float* src_keypts,
+                  const float* tgt_keypts, const float* logits, const int* seeds_in, int B, int N, float* final_trans,
+                  float* final_labels, int* seeds_out, int* knn_out, float* seed_trans, float* fitness,
+                  gmf_stream_t stream) {
+  GMF_REQUIRE(h && p && feat_n && src_keypts && tgt_keypts && final_trans && final_labels, GMF_ERR_BAD_ARG, "pose_head: null pointer");
+  GMF_REQUIRE(seeds_in || logits, GMF_ERR_BAD_ARG, "pose_head: need logits or seeds_in");
+  const int Sn = p->num_seeds, k = p->k, iters = p->num_iterations;
+  GMF_REQUIRE(B > 0 && N > 1, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: need N > 1");
+  GMF_REQUIRE(Sn > 0 && Sn <= N, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: need 0 < num_seeds <= N");
+  GMF_REQUIRE(k > 0 && k <= 64 && k <= N - 1, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: need 0 < k <= min(64, N-1)");
+  GMF_REQUIRE(iters > 0 && iters <= 64, GMF_ERR_BAD_ARG, "pose_head: bad num_iterations");
+  GMF_REQUIRE(N <= 16384 || seeds_in, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: N > 16384 needs caller-provided seeds");
+  GMF_REQUIRE((size_t)N * 4 <= 150 * 1024, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: N too large for the in-LDS kNN (max 38400)");
+  GMF_REQUIRE(p->sigma > 0.f && p->sigma_d > 0.f, GMF_ERR_BAD_ARG, "pose_head: sigma, sigma_d must be positive");
+  SetDevice sd(h);
+  hipStream_t st = S(stream);
+  const size_t BS = (size_t)B * Sn;
+  const size_t need = arena_need((size_t)B * N, 4) + arena_need(BS, 4) + arena_need(BS * k, 4) +
+                      arena_need(BS * iters * k, 4) + arena_need(BS * iters, 1) + arena_need(BS * 16, 4) +
+                      arena_need(BS, 4) + arena_need(BS, 4) + arena_need(B, 4);
+  if (int rc = arena_reserve(h, need)) return rc;
+  float* keys = arena_take<float>(h, (size_t)B * N);
+  int* seeds = arena_take<int>(h, BS);
+  int* knn = arena_take<int>(h, BS * k);
+  float* snaps = arena_take<float>(h, BS * iters * k);
+  unsigned char* conv = arena_take<unsigned char>(h, BS * iters);
+  float* sT = arena_take<float>(h, BS * 16);
+  int* counts = arena_take<int>(h, BS);
+  float* fit = arena_take<float>(h, BS);
+  int* best = arena_take<int>(h, B);
+  if (seeds_out) seeds = seeds_out;
+  if (knn_out) knn = knn_out;
+  if (seed_trans) sT = seed_trans;
+  if (fitness) fit = fitness;
+
+  const int* seeds_use = seeds_in;
+  if (!seeds_in) {
+    const float* kk = logits;
+    if (p->use_nms) {
+      GMF_HIP(gmf::launch_nms_keys(src_keypts, logits, keys, B, N, p->nms_radius, st));
+      kk = keys;
+    }
+    GMF_HIP(gmf::launch_sort_topk(kk, seeds, B, N, Sn, st));
+    seeds_use = seeds;
+  } else if (seeds_out) {
+    GMF_HIP(hipMemcpyAsync(seeds_out, seeds_in, BS * sizeof(int), hipMemcpyDeviceToDevice, st));
+  }
+  GMF_HIP(gmf::launch_knn_seeds(feat_n, seeds_use, knn, B, N, Sn, k, st));
+  GMF_HIP(gmf::launch_seed_power(feat_n, src_keypts, tgt_keypts, knn, snaps, conv, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));
+  GMF_HIP(gmf::launch_seed_kabsch(src_keypts, tgt_keypts, knn, snaps, conv, sT, B, N, Sn, k, iters, st));
+  GMF_HIP(gmf::launch_score_hyp(src_keypts, tgt_keypts, sT, counts, B, N, Sn, p->inlier_threshold, st));
+  GMF_HIP(gmf::launch_finalize_pose(src_keypts, tgt_keypts, sT, counts, fit, final_trans, final_labels, best, B, N, Sn,
+                                    p->inlier_threshold, p->refine_threshold, p->refine_iters, st));
+  return GMF_OK;
+}
+
+int gmf_knn_rows(gmf_handle* h, const float* feat_n, const int* rows, int B, int N, int Sn, int k, int* knn_out,
+                 gmf_stream_t stream) {
+  GMF_REQUIRE(h && feat_n && rows && knn_out, GMF_ERR_BAD_ARG, "knn_rows: null pointer");
+  GMF_REQUIRE(B > 0 && N > 1 && Sn > 0 && k > 0 && k <= N - 1, GMF_ERR_UNSUPPORTED_SHAPE, "knn_rows: need 0 < k <= N-1");
+  GMF_REQUIRE((size_t)N * 4 <= 150 * 1024, GMF_ERR_UNSUPPORTED_SHAPE, "knn_rows: N too large for the in-LDS kNN (max 38400)");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_knn_seeds(feat_n, rows, knn_out, B, N, Sn, k, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_procrustes_batched(gmf_handle* h, const float* A, const float* Bp, const float* weights, int n, int k,
+                           float weight_threshold, float* T44, gmf_stream_t stream) {
+  GMF_REQUIRE(h && A && Bp && T44, GMF_ERR_BAD_ARG, "procrustes_batched: null pointer");
+  GMF_REQUIRE(n > 0 && k > 0, GMF_ERR_UNSUPPORTED_SHAPE, "procrustes_batched: empty input");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_rigid_transform(A, Bp, weights, T44, n, k, weight_threshold, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_post_refinement(gmf_handle* h, const float* T_in, const float* src_keypts, const float* tgt_keypts, int B, int N,
+                        float refine_threshold, int iters, float* T_out, gmf_stream_t stream) {
+  GMF_REQUIRE(h && T_in && src_keypts && tgt_keypts && T_out, GMF_ERR_BAD_ARG, "post_refinement: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0 && iters >= 0, GMF_ERR_UNSUPPORTED_SHAPE, "post_refinement: empty input");
+  GMF_REQUIRE(refine_threshold > 0.f, GMF_ERR_BAD_ARG, "post_refinement: threshold must be positive");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_post_refine(T_in, src_keypts, tgt_keypts, T_out, B, N, refine_threshold, iters, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_weighted_procrustes(gmf_handle* h, const float* X, const float* Y, const float* w, const int* offsets, int B,
+                            float eps, float* R, float* t, gmf_stream_t stream) {
+  GMF_REQUIRE(h && X && Y && w && offsets && R && t, GMF_ERR_BAD_ARG, "weighted_procrustes: null pointer");
+  GMF_REQUIRE(B > 0, GMF_ERR_UNSUPPORTED_SHAPE, "weighted_procrustes: empty batch");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_weighted_procrustes(X, Y, w, offsets, B, eps, R, t, S(stream)));
+  return GMF_OK;
+}
+
+}  // extern "C"

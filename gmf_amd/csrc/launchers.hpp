@@ -1,0 +1,25 @@
+// Internal C++ launch entry points (one per kernel family).  The public C ABI is include/gmf_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gmf {
+
+hipError_t launch_front(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
+                        float* v, int B, int N, int tiles, hipStream_t s);
+hipError_t launch_scattn(const float* q, const float* k, const float* v, const float* pts8, const float* fus,
+                         const float* wst, const float* vecs, float* out, int B, int N, int tiles, float sigma_d,
+                         hipStream_t s);
+hipError_t launch_scattn_dense(const float* q, const float* k, const float* v, const float* compat, const float* fus,
+                               const float* wst, const float* vecs, float* out, int B, int N, int tiles, hipStream_t s);
+hipError_t launch_ctx_prep(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
+                           int ttiles, int sets, int wst_stride, int vec_stride, hipStream_t s);
+hipError_t launch_fusion_attn(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
+                              float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
+hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
+hipError_t launch_head(const float* feat_img, const float* wst, const float* vecs, float* logits, float* feat_n,
+                       float* feat_rm, int B, int N, int tiles, hipStream_t s);
+hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s);
+hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s);
+hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s);
+
+}  // namespace gmf

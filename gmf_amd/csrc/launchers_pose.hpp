@@ -1,0 +1,27 @@
+// Internal C++ launch entry points of the pose-head kernels.  Public C ABI: include/gmf_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gmf {
+
+hipError_t launch_nms_keys(const float* src, const float* scores, float* keys, int B, int N, float R, hipStream_t s);
+hipError_t launch_sort_topk(const float* keys, int* out_idx, int B, int N, int S, hipStream_t s);
+hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, int* knn_idx, int B, int N, int S, int k, hipStream_t s);
+hipError_t launch_seed_power(const float* feat_n, const float* src, const float* tgt, const int* knn_idx, float* snaps,
+                             unsigned char* conv, int B, int N, int S, int k, int iters, float sigma, float sigma_d,
+                             hipStream_t s);
+hipError_t launch_seed_kabsch(const float* src, const float* tgt, const int* knn_idx, const float* snaps,
+                              const unsigned char* conv, float* seed_T, int B, int N, int S, int k, int iters, hipStream_t s);
+hipError_t launch_score_hyp(const float* src, const float* tgt, const float* seed_T, int* counts, int B, int N, int S,
+                            float tau, hipStream_t s);
+hipError_t launch_finalize_pose(const float* src, const float* tgt, const float* seed_T, const int* counts, float* fitness,
+                                float* final_T, float* labels, int* best, int B, int N, int S, float tau, float refine_thr,
+                                int refine_iters, hipStream_t s);
+hipError_t launch_post_refine(const float* T_in, const float* src, const float* tgt, float* T_out, int B, int N, float thr,
+                              int iters, hipStream_t s);
+hipError_t launch_rigid_transform(const float* A, const float* Bp, const float* w, float* T, int n, int k,
+                                  float weight_threshold, hipStream_t s);
+hipError_t launch_weighted_procrustes(const float* X, const float* Y, const float* w, const int* offsets, int B, float eps,
+                                      float* R, float* t, hipStream_t s);
+
+}  // namespace gmf

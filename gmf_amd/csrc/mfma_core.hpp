@@ -1,0 +1,218 @@
+// Device-side building blocks shared by every encoder kernel (gfx950 / CDNA4 only).
+//
+// Execution model used throughout ("rows on lanes"):
+//   * a wavefront (64 lanes) owns one TILE of 32 rows (correspondences or image tokens);
+//     lane l = (h, i) with i = l & 31 the row inside the tile and h = l >> 5 the K-half;
+//   * a row vector of width K lives in registers as a FRAGMENT  float x[K/2]  with
+//         x[4*g + e] = X[row i][8*g + 4*h + e]          g in [0,K/8), e in [0,4)
+//     which is at the same time the A- and the B-operand layout of
+//     v_mfma_f32_32x32x2_f32 (one f32 per lane, lane l holds element (l&31, k = l>>5)),
+//     with the contraction index visited in the order k(step s = 4g+e, half h) = 8g+4h+e;
+//   * D = mfma(A = weight image, B = fragment) gives  Y^T[m][i]  for 32 output features:
+//     lane (h,i), register r holds  m = 8*(r>>2) + 4*h + (r&3)  - exactly fragment
+//     element r of the 32-wide block, so the result chains into the next layer with no
+//     data movement (no LDS round trip, no shuffles);
+//   * D = mfma(A = fragment, B = weight image) gives  Y[i'][m]  with the FEATURE on the
+//     lane (m = l & 31) and rows i' = 8*(r>>2)+4*h+(r&3) in the registers: this is the
+//     layout the attention kernels want for V (A-operand of O^T += V^T P^T).
+//
+// Memory images (all fp32, float4 granularity, 1 KiB per (tile, g) = one coalesced
+// wave-wide access, and one LDS-DMA instruction):
+//   P32 image of X[rows, K]   : float4 index ((tile*(K/8) + g)*64 + lane)
+//                               = X[32*tile + i][8g+4h .. 8g+4h+3]
+//   T   image of V[rows, D]   : float4 index (((tile*(D/32) + db)*4 + q)*64 + lane)
+//                               = V[32*tile + 8q+4h+e][32*db + i], e = 0..3
+//   A weight matrix W[M, K] (PyTorch [out, in]) is stored as its own P32 image, so
+//   out-block mb (32 output features) is the contiguous 32*K floats at mb*32*K.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gmf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kTileRows = 32;
+constexpr int kStageFloats = 4096;  // one weight / K / V stage = 16 KiB
+
+#define GMF_DEVINL __device__ __forceinline__
+
+GMF_DEVINL f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+GMF_DEVINL f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+// acc += Wimg(32 x K) * X^T   ->  Y^T block (rows on lanes).  lw = LDS image + lane.
+template <int KF>
+GMF_DEVINL void mma_wx(f32x16& acc, const float4* lw, const float (&x)[KF]) {
+#pragma unroll
+  for (int g = 0; g < KF / 4; ++g) {
+    const float4 w = lw[g * 64];
+    acc = mfma32(w.x, x[4 * g + 0], acc);
+    acc = mfma32(w.y, x[4 * g + 1], acc);
+    acc = mfma32(w.z, x[4 * g + 2], acc);
+    acc = mfma32(w.w, x[4 * g + 3], acc);
+  }
+}
+
+// acc += X * Wimg^T  ->  Y block with the output feature on the lane (T layout).
+template <int KF>
+GMF_DEVINL void mma_xw(f32x16& acc, const float4* lw, const float (&x)[KF]) {
+#pragma unroll
+  for (int g = 0; g < KF / 4; ++g) {
+    const float4 w = lw[g * 64];
+    acc = mfma32(x[4 * g + 0], w.x, acc);
+    acc = mfma32(x[4 * g + 1], w.y, acc);
+    acc = mfma32(x[4 * g + 2], w.z, acc);
+    acc = mfma32(x[4 * g + 3], w.w, acc);
+  }
+}
+
+// fragment element offset helper: r in [0,16) of a 32-wide block -> feature index
+GMF_DEVINL int frag_feature(int r, int h) { return 8 * (r >> 2) + 4 * h + (r & 3); }
+
+// Load a per-feature vector (bias, LN gamma, ...) in fragment order:
+//   v[4*g+e] = vec[8g + 4h + e]
+template <int KF>
+GMF_DEVINL void load_vec_frag(float (&v)[KF], const float* __restrict__ vec, int h) {
+  const float4* p = reinterpret_cast<const float4*>(vec) + h;
+#pragma unroll
+  for (int g = 0; g < KF / 4; ++g) {
+    const float4 t = p[2 * g];
+    v[4 * g + 0] = t.x; v[4 * g + 1] = t.y; v[4 * g + 2] = t.z; v[4 * g + 3] = t.w;
+  }
+}
+
+// P32 tile load / store.  tile_base points at the tile (32*K floats).
+template <int KF>
+GMF_DEVINL void load_frag_p32(float (&x)[KF], const float* __restrict__ tile_base, int lane) {
+  const float4* p = reinterpret_cast<const float4*>(tile_base) + lane;
+#pragma unroll
+  for (int g = 0; g < KF / 4; ++g) {
+    const float4 t = p[g * 64];
+    x[4 * g + 0] = t.x; x[4 * g + 1] = t.y; x[4 * g + 2] = t.z; x[4 * g + 3] = t.w;
+  }
+}
+
+template <int KF>
+GMF_DEVINL void store_frag_p32(float* __restrict__ tile_base, const float (&x)[KF], int lane) {
+  float4* p = reinterpret_cast<float4*>(tile_base) + lane;
+#pragma unroll
+  for (int g = 0; g < KF / 4; ++g) p[g * 64] = make_float4(x[4 * g + 0], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+}
+
+// Load row `row` (any row of the same [rows,K] P32 tensor, pair-local index) as a fragment,
+// zero if the row is outside [0, n_rows).  Used for the LCPE neighbours i-1 / i+1.
+template <int KF>
+GMF_DEVINL void load_row_frag_p32(float (&x)[KF], const float* __restrict__ pair_base, int row, int n_rows, int h) {
+  if (row >= 0 && row < n_rows) {
+    const float4* p = reinterpret_cast<const float4*>(pair_base) + (size_t)(row >> 5) * (KF / 4) * 64 + h * 32 + (row & 31);
+#pragma unroll
+    for (int g = 0; g < KF / 4; ++g) {
+      const float4 t = p[g * 64];
+      x[4 * g + 0] = t.x; x[4 * g + 1] = t.y; x[4 * g + 2] = t.z; x[4 * g + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < KF; ++k) x[k] = 0.f;
+  }
+}
+
+// Sum / max over the two K-halves of a row (lane l and l^32 hold the two halves).
+GMF_DEVINL float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+GMF_DEVINL float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+
+// LayerNorm of a row fragment (eps 1e-5, biased variance, two-pass as nn.LayerNorm).
+template <int KF>
+GMF_DEVINL void layernorm_frag(float (&y)[KF], const float (&x)[KF], const float* __restrict__ gamma,
+                               const float* __restrict__ beta, int h) {
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < KF; ++k) s += x[k];
+  const float mu = xhalf_sum(s) * (1.0f / (2 * KF));
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < KF; ++k) { const float d = x[k] - mu; v = fmaf(d, d, v); }
+  const float rstd = rsqrtf(xhalf_sum(v) * (1.0f / (2 * KF)) + 1e-5f);
+  const float4* pg = reinterpret_cast<const float4*>(gamma) + h;
+  const float4* pb = reinterpret_cast<const float4*>(beta) + h;
+#pragma unroll
+  for (int g = 0; g < KF / 4; ++g) {
+    const float4 ga = pg[2 * g], be = pb[2 * g];
+    y[4 * g + 0] = fmaf((x[4 * g + 0] - mu) * rstd, ga.x, be.x);
+    y[4 * g + 1] = fmaf((x[4 * g + 1] - mu) * rstd, ga.y, be.y);
+    y[4 * g + 2] = fmaf((x[4 * g + 2] - mu) * rstd, ga.z, be.z);
+    y[4 * g + 3] = fmaf((x[4 * g + 3] - mu) * rstd, ga.w, be.w);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// 16 KiB stage streaming: global (L2) -> LDS by LDS-DMA, double buffered, one barrier
+// per stage.  The LDS image of a stage is byte-identical to its global image, which is
+// lane-linear per 1 KiB piece, so global_load_lds_dwordx4 applies with no swizzle.
+// ---------------------------------------------------------------------------------
+GMF_DEVINL void dma_piece_1k(const float* __restrict__ gsrc_piece, float* lds_piece, int lane) {
+  __builtin_amdgcn_global_load_lds(
+      (const void __attribute__((address_space(1)))*)(gsrc_piece + lane * 4),
+      (void __attribute__((address_space(3)))*)(lds_piece), 16, 0, 0);
+}
+
+// Copy `n_pieces` KiB from gsrc to lds_dst, pieces distributed round-robin over the waves.
+GMF_DEVINL void dma_issue(const float* __restrict__ gsrc, float* lds_dst, int n_pieces, int wave, int n_waves, int lane) {
+  for (int p = wave; p < n_pieces; p += n_waves) dma_piece_1k(gsrc + p * 256, lds_dst + p * 256, lane);
+}
+
+// Streams 16 KiB stages through two LDS buffers.  The stage sequence is the concatenation of up
+// to three contiguous global blobs (e.g. projection weights | per-tile context images | output
+// weights), consumed strictly in order by every wave of the workgroup.
+struct StageStream {
+  const float* seg_ptr[3];
+  int seg_end[3];   // cumulative stage counts
+  float* buf0;
+  float* buf1;
+  int issued;       // stages issued so far
+  int consumed;     // stages handed to the consumer so far
+  int total;
+  int wave, n_waves, lane;
+
+  GMF_DEVINL void init(float* b0, float* b1, int wave_, int n_waves_, int lane_, const float* p0, int n0,
+                       const float* p1 = nullptr, int n1 = 0, const float* p2 = nullptr, int n2 = 0) {
+    seg_ptr[0] = p0; seg_ptr[1] = p1; seg_ptr[2] = p2;
+    seg_end[0] = n0; seg_end[1] = n0 + n1; seg_end[2] = n0 + n1 + n2;
+    total = seg_end[2];
+    buf0 = b0; buf1 = b1; issued = 0; consumed = 0;
+    wave = wave_; n_waves = n_waves_; lane = lane_;
+  }
+  GMF_DEVINL void issue_one() {
+    if (issued < total) {
+      const float* g;
+      if (issued < seg_end[0]) g = seg_ptr[0] + (size_t)issued * kStageFloats;
+      else if (issued < seg_end[1]) g = seg_ptr[1] + (size_t)(issued - seg_end[0]) * kStageFloats;
+      else g = seg_ptr[2] + (size_t)(issued - seg_end[1]) * kStageFloats;
+      dma_issue(g, (issued & 1) ? buf1 : buf0, 16, wave, n_waves, lane);
+      ++issued;
+    }
+  }
+  // Call once before the first acquire() (after a barrier if the buffers were in use): stage 0 in flight.
+  GMF_DEVINL void prime() { issue_one(); }
+  // Wait for the next stage, make it visible to the whole workgroup, start the one after it,
+  // and return the LDS image (+lane, in float4 units) of the stage to consume now.
+  GMF_DEVINL const float4* acquire() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed in LDS
+    __syncthreads();                                  // everyone's pieces landed; prior readers of the other buffer done
+    const float* cur = (consumed & 1) ? buf1 : buf0;
+    ++consumed;
+    issue_one();
+    return reinterpret_cast<const float4*>(cur) + lane;
+  }
+};
+
+}  // namespace gmf

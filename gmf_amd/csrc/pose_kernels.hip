@@ -1,0 +1,778 @@
+// Pose head of GMF-PointDSC and the DGR weighted-Procrustes solve on gfx950.
+//
+// Replaces (file:line relative to /root/reference/):
+//   k_nms_keys          GMF_PointDSC/models/PointDSC.py:268-285   parallel NMS -> score * is_local_max
+//   k_sort_topk         GMF_PointDSC/models/PointDSC.py:246,286   argsort(descending)[:S]
+//   k_knn_seeds         GMF_PointDSC/models/common.py:53-75 + PointDSC.py:327-329  kNN rows of the seeds only
+//   k_seed_power        GMF_PointDSC/models/PointDSC.py:335-361,437-448  seed compatibility matrices + power iteration
+//   k_seed_kabsch       GMF_PointDSC/models/PointDSC.py:364-365,405; models/common.py:10-50  weights + weighted Kabsch
+//   k_score_hyp         GMF_PointDSC/models/PointDSC.py:413-417   inlier count of every hypothesis
+//   k_finalize_pose     GMF_PointDSC/models/PointDSC.py:419-425,493-528  argmax, labels, IRLS post-refinement
+//   k_rigid_transform   GMF_PointDSC/models/common.py:10-50       batched weighted Kabsch (public op)
+//   k_weighted_procrustes  GMF_DeepGlobalRegistration/*/core/registration.py:91-113
+//
+// These stages are HBM/latency bound integer-and-float work (no MFMA).  The reference moves every
+// 3x3 covariance to the CPU for LAPACK (common.py:40-41, registration.py:105); here the SVD is a
+// one-sided Jacobi in fp64 registers, one lane per matrix, with no host round trip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "launchers_pose.hpp"
+
+namespace gmf {
+
+#define GMF_DEVINL __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------
+// 3x3 SVD -> rotation.  H = U S V^T.  Returns  R = V diag(1,1,det(V U^T)) U^T  (Kabsch, common.py:43-45)
+// in the determinant-free form  R = v1 u1^T + v2 u2^T + (v1 x v2)(u1 x u2)^T  over the two dominant
+// singular pairs, which equals the reference's formula for any sign convention of the SVD and stays
+// well defined when the smallest singular value is 0 (planar neighbourhoods).
+// ---------------------------------------------------------------------------------------
+GMF_DEVINL void cross3(const double* a, const double* b, double* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+GMF_DEVINL void any_perp(const double* a, double* p) {
+  // unit vector perpendicular to unit a
+  double ax = fabs(a[0]), ay = fabs(a[1]), az = fabs(a[2]);
+  double e[3] = {0, 0, 0};
+  if (ax <= ay && ax <= az) e[0] = 1; else if (ay <= az) e[1] = 1; else e[2] = 1;
+  cross3(a, e, p);
+  const double n = rsqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+  p[0] *= n; p[1] *= n; p[2] *= n;
+}
+
+// A: row-major 3x3 H.  R (row-major) = V D U^T.
+GMF_DEVINL void kabsch_rotation_from_H(const double* Hin, double* R) {
+  double A[3][3], V[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { A[r][c] = Hin[3 * r + c]; V[r][c] = (r == c) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
+      double al = 0, be = 0, ga = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { al += A[r][p] * A[r][p]; be += A[r][q] * A[r][q]; ga += A[r][p] * A[r][q]; }
+      const double lim = 1e-15 * sqrt(al * be);
+      if (fabs(ga) > lim && ga != 0.0) {
+        off = fmax(off, fabs(ga) / fmax(sqrt(al * be), 1e-300));
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = rsqrt(1.0 + t * t), sn = cs * t;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const double ap = A[r][p], aq = A[r][q];
+          A[r][p] = cs * ap - sn * aq; A[r][q] = sn * ap + cs * aq;
+          const double vp = V[r][p], vq = V[r][q];
+          V[r][p] = cs * vp - sn * vq; V[r][q] = sn * vp + cs * vq;
+        }
+      }
+    }
+    if (off < 1e-15) break;
+  }
+  double sg[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) sg[c] = sqrt(A[0][c] * A[0][c] + A[1][c] * A[1][c] + A[2][c] * A[2][c]);
+  int j1 = 0;
+  if (sg[1] > sg[j1]) j1 = 1;
+  if (sg[2] > sg[j1]) j1 = 2;
+  int j2 = (j1 == 0) ? 1 : 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) if (c != j1 && sg[c] > sg[j2]) j2 = c;
+  double u1[3], u2[3], v1[3], v2[3], u3[3], v3[3];
+  if (!(sg[j1] > 0.0)) {           // H == 0 (or NaN): identity
+#pragma unroll
+    for (int r = 0; r < 9; ++r) R[r] = (r % 4 == 0) ? 1.0 : 0.0;
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { u1[r] = A[r][j1] / sg[j1]; v1[r] = V[r][j1]; }
+  if (sg[j2] > 1e-14 * sg[j1]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { u2[r] = A[r][j2] / sg[j2]; v2[r] = V[r][j2]; }
+  } else {                           // rank 1: any completion (LAPACK's choice is arbitrary too)
+    any_perp(u1, u2);
+    any_perp(v1, v2);
+  }
+  cross3(u1, u2, u3);
+  cross3(v1, v2, v3);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) R[3 * r + c] = v1[r] * u1[c] + v2[r] * u2[c] + v3[r] * u3[c];
+}
+
+// T (row-major 4x4 fp32) from R (double) and centroids:  t = cB - R cA   (common.py:46-50)
+GMF_DEVINL void write_T(float* T, const double* R, const double* ca, const double* cb) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float r0 = (float)R[3 * r], r1 = (float)R[3 * r + 1], r2 = (float)R[3 * r + 2];
+    T[4 * r + 0] = r0; T[4 * r + 1] = r1; T[4 * r + 2] = r2;
+    T[4 * r + 3] = (float)cb[r] - (r0 * (float)ca[0] + r1 * (float)ca[1] + r2 * (float)ca[2]);
+  }
+  T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+}
+
+// ---- reductions --------------------------------------------------------------------------
+GMF_DEVINL double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int NV>
+GMF_DEVINL void block_sum(double (&v)[NV], double* sh /* >= NV*16 doubles */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+  __syncthreads();
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sh[k * 16 + wave] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double s = 0;
+    for (int w = 0; w < nw; ++w) s += sh[k * 16 + w];
+    v[k] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// NMS keys: key_i = score_i * [ for all j: score_i >= score_j  or  ||src_i - src_j|| >= R ]
+// grid (ceil(N/256), B)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_nms_keys(const float* __restrict__ src, const float* __restrict__ scores, float* __restrict__ keys, int N, float R) {
+  __shared__ float4 sh[256];
+  const int pair = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float* ps = src + (size_t)pair * N * 3;
+  const float* sc = scores + (size_t)pair * N;
+  float xi = 0, yi = 0, zi = 0, si = 0;
+  if (i < N) { xi = ps[3 * i]; yi = ps[3 * i + 1]; zi = ps[3 * i + 2]; si = sc[i]; }
+  bool is_max = true;
+  for (int j0 = 0; j0 < N; j0 += 256) {
+    const int j = j0 + threadIdx.x;
+    __syncthreads();
+    sh[threadIdx.x] = (j < N) ? make_float4(ps[3 * j], ps[3 * j + 1], ps[3 * j + 2], sc[j])
+                              : make_float4(0.f, 0.f, 0.f, -INFINITY);
+    __syncthreads();
+    const int lim = min(256, N - j0);
+    for (int jj = 0; jj < lim; ++jj) {
+      const float4 p = sh[jj];
+      const float dx = xi - p.x, dy = yi - p.y, dz = zi - p.z;
+      const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+      is_max = is_max && ((si >= p.w) || (d >= R));
+    }
+  }
+  if (i < N) keys[(size_t)pair * N + i] = si * (is_max ? 1.f : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------
+// Per pair: indices of the S largest keys, ordered (key descending, index ascending) - the order
+// torch's stable CPU sort gives argsort(descending=True).  Bitonic sort in LDS, N <= 16384.
+// grid (B), block 1024, dynamic LDS = M*8 bytes (M = next pow2 >= N)
+// ---------------------------------------------------------------------------------------
+GMF_DEVINL bool key_before(float ka, int ia, float kb, int ib) { return (ka > kb) || (ka == kb && ia < ib); }
+
+__global__ void __launch_bounds__(1024)
+k_sort_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, int M, int S) {
+  extern __shared__ unsigned char smem_raw[];
+  float* sk = reinterpret_cast<float*>(smem_raw);
+  int* si = reinterpret_cast<int*>(smem_raw + (size_t)M * 4);
+  const int pair = blockIdx.x;
+  for (int t = threadIdx.x; t < M; t += blockDim.x) {
+    sk[t] = (t < N) ? keys[(size_t)pair * N + t] : -INFINITY;
+    si[t] = (t < N) ? t : 0x7fffffff;
+  }
+  __syncthreads();
+  for (int size = 2; size <= M; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (M >> 1); t += blockDim.x) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);      // ascending position order = "before" first
+        const float ka = sk[lo], kb = sk[hi];
+        const int ia = si[lo], ib = si[hi];
+        const bool a_first = key_before(ka, ia, kb, ib);
+        if (a_first != up) { sk[lo] = kb; sk[hi] = ka; si[lo] = ib; si[hi] = ia; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = threadIdx.x; t < S; t += blockDim.x) out_idx[(size_t)pair * S + t] = si[t];
+}
+
+// ---------------------------------------------------------------------------------------
+// kNN of the seed rows only: for seed s, the k+1 smallest of d_j = 2 - 2 <f_s, f_j>, ascending
+// (ties: lower index first), first one dropped (common.py:70-74).  feat_n row-major [B,N,128].
+// grid (S, B), block 256, dynamic LDS = N*4 bytes
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_knn_seeds(const float* __restrict__ feat_n, const int* __restrict__ seeds, int* __restrict__ knn_idx,
+            int N, int S, int k) {
+  extern __shared__ float dist[];
+  __shared__ float fs[128];
+  __shared__ float red_v[4];
+  __shared__ int red_i[4];
+  const int pair = blockIdx.y, s = blockIdx.x;
+  const float* fb = feat_n + (size_t)pair * N * 128;
+  const int seed = seeds[(size_t)pair * S + s];
+  if (threadIdx.x < 128) fs[threadIdx.x] = fb[(size_t)seed * 128 + threadIdx.x];
+  __syncthreads();
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const float4* pj = reinterpret_cast<const float4*>(fb + (size_t)j * 128);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < 32; ++c) {
+      const float4 v = pj[c];
+      acc = fmaf(v.x, fs[4 * c], acc); acc = fmaf(v.y, fs[4 * c + 1], acc);
+      acc = fmaf(v.z, fs[4 * c + 2], acc); acc = fmaf(v.w, fs[4 * c + 3], acc);
+    }
+    dist[j] = 2.0f - 2.0f * acc;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int it = 0; it <= k; ++it) {
+    float bv = INFINITY; int bi = 0x7fffffff;
+    for (int j = threadIdx.x; j < N; j += 256) {
+      const float v = dist[j];
+      if (v < bv) { bv = v; bi = j; }          // strided scan keeps the lowest index among equal values per thread
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float v = red_v[0]; int ix = red_i[0];
+      for (int w = 1; w < 4; ++w) if (red_v[w] < v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
+      if (it > 0) knn_idx[((size_t)pair * S + s) * k + (it - 1)] = ix;
+      dist[ix] = INFINITY;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Per seed: M = clamp(1-(1-F F^T)/sigma^2,0) * clamp(1-(ds-dt)^2/sigma_d^2,0), diag 0; power iteration
+// with every iterate stored (the reference's early exit is a GLOBAL allclose over all seeds of the
+// pair, resolved by k_seed_kabsch).  One wave per seed, lane a = neighbour a.  k <= 64.
+// grid (S, B), block 64
+// snaps [B,S,iters,k], conv [B,S,iters] (1 if allclose(v_it, v_{it-1}))
+// ---------------------------------------------------------------------------------------
+constexpr int kKMax = 64;
+
+__global__ void __launch_bounds__(64)
+k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, const float* __restrict__ tgt,
+             const int* __restrict__ knn_idx, float* __restrict__ snaps, unsigned char* __restrict__ conv,
+             int N, int S, int k, int iters, float inv_sigma2, float inv_sigmad2) {
+  __shared__ float F[kKMax * 129];
+  __shared__ float Mx[kKMax * (kKMax + 1)];
+  __shared__ float P[kKMax * 8];
+  __shared__ float vec[kKMax];
+  const int pair = blockIdx.y, s = blockIdx.x, a = threadIdx.x;
+  const int* nb = knn_idx + ((size_t)pair * S + s) * k;
+  const float* fb = feat_n + (size_t)pair * N * 128;
+  for (int r = 0; r < k; ++r) {
+    const int j = nb[r];
+    F[r * 129 + a] = fb[(size_t)j * 128 + a];
+    F[r * 129 + 64 + a] = fb[(size_t)j * 128 + 64 + a];
+  }
+  if (a < k) {
+    const int j = nb[a];
+    const float* ps = src + ((size_t)pair * N + j) * 3;
+    const float* pt = tgt + ((size_t)pair * N + j) * 3;
+    P[a * 8 + 0] = ps[0]; P[a * 8 + 1] = ps[1]; P[a * 8 + 2] = ps[2];
+    P[a * 8 + 4] = pt[0]; P[a * 8 + 5] = pt[1]; P[a * 8 + 6] = pt[2];
+  }
+  __syncthreads();
+  if (a < k) {
+    const float sx = P[a * 8], sy = P[a * 8 + 1], sz = P[a * 8 + 2];
+    const float tx = P[a * 8 + 4], ty = P[a * 8 + 5], tz = P[a * 8 + 6];
+    for (int b = 0; b < k; ++b) {
+      float dot = 0.f;
+#pragma unroll 8
+      for (int c = 0; c < 128; ++c) dot = fmaf(F[a * 129 + c], F[b * 129 + c], dot);
+      const float mf = fmaxf(1.0f - (1.0f - dot) * inv_sigma2, 0.f);
+      const float ax = sx - P[b * 8], ay = sy - P[b * 8 + 1], az = sz - P[b * 8 + 2];
+      const float bx = tx - P[b * 8 + 4], by = ty - P[b * 8 + 5], bz = tz - P[b * 8 + 6];
+      const float d = sqrtf(ax * ax + ay * ay + az * az) - sqrtf(bx * bx + by * by + bz * bz);
+      const float ms = fmaxf(1.0f - d * d * inv_sigmad2, 0.f);
+      Mx[a * (kKMax + 1) + b] = (a == b) ? 0.f : mf * ms;
+    }
+  }
+  vec[a] = 1.0f;
+  __syncthreads();
+  float last = 1.0f;
+  float* sn = snaps + ((size_t)pair * S + s) * iters * k;
+  unsigned char* cv = conv + ((size_t)pair * S + s) * iters;
+  for (int it = 0; it < iters; ++it) {
+    float v = 0.f;
+    if (a < k) for (int b = 0; b < k; ++b) v = fmaf(Mx[a * (kKMax + 1) + b], vec[b], v);
+    float n2 = (a < k) ? v * v : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o, 64);
+    v = v / (sqrtf(n2) + 1e-6f);
+    const bool close = (a >= k) || (fabsf(v - last) <= 1e-8f + 1e-5f * fabsf(last));
+    const bool all_close = __all(close);
+    __syncthreads();
+    if (a < k) { vec[a] = v; sn[it * k + a] = v; }
+    if (a == 0) cv[it] = all_close ? 1 : 0;
+    last = v;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Per seed: pick the iterate the reference would have stopped at, normalise to weights
+// w = v/(sum v + 1e-6) (PointDSC.py:364-365) and solve the weighted Kabsch problem on the k neighbours.
+// One thread per seed.  grid (ceil(S/64), B), block 64.  seed_T [B,S,16]
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_seed_kabsch(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ knn_idx,
+              const float* __restrict__ snaps, const unsigned char* __restrict__ conv, float* __restrict__ seed_T,
+              int N, int S, int k, int iters) {
+  __shared__ int stop_it;
+  const int pair = blockIdx.y;
+  // global early exit: first iteration at which EVERY seed of the pair passed allclose (PointDSC.py:444)
+  if (threadIdx.x == 0) stop_it = iters - 1;
+  __syncthreads();
+  {
+    const unsigned char* cv = conv + (size_t)pair * S * iters;
+    int first = iters - 1;
+    for (int it = 0; it < iters - 1; ++it) {
+      bool ok = true;
+      for (int s2 = threadIdx.x; s2 < S; s2 += 64) ok = ok && (cv[(size_t)s2 * iters + it] != 0);
+      if (__all(ok)) { first = it; break; }
+    }
+    if (threadIdx.x == 0) stop_it = first;
+  }
+  __syncthreads();
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= S) return;
+  const int* nb = knn_idx + ((size_t)pair * S + s) * k;
+  const float* v = snaps + (((size_t)pair * S + s) * iters + stop_it) * k;
+  float sv = 0.f;
+  for (int r = 0; r < k; ++r) sv += v[r];
+  const float inv = 1.0f / (sv + 1e-6f);
+  const float* ps = src + (size_t)pair * N * 3;
+  const float* pt = tgt + (size_t)pair * N * 3;
+  double sw = 0, ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
+  for (int r = 0; r < k; ++r) {
+    float w = v[r] * inv;
+    w = (w < 0.f) ? 0.f : w;                      // weights[weights < 0] = 0 (common.py:24)
+    const int j = nb[r];
+    sw += w;
+    for (int c = 0; c < 3; ++c) { ca[c] += (double)w * ps[3 * j + c]; cb[c] += (double)w * pt[3 * j + c]; }
+  }
+  for (int c = 0; c < 3; ++c) { ca[c] /= (sw + 1e-6); cb[c] /= (sw + 1e-6); }
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = 0; r < k; ++r) {
+    float w = v[r] * inv;
+    w = (w < 0.f) ? 0.f : w;
+    const int j = nb[r];
+    double am[3], bm[3];
+    for (int c = 0; c < 3; ++c) { am[c] = ps[3 * j + c] - ca[c]; bm[c] = pt[3 * j + c] - cb[c]; }
+    for (int r2 = 0; r2 < 3; ++r2) for (int c = 0; c < 3; ++c) H[3 * r2 + c] += w * am[r2] * bm[c];
+  }
+  double R[9];
+  kabsch_rotation_from_H(H, R);
+  write_T(seed_T + ((size_t)pair * S + s) * 16, R, ca, cb);
+}
+
+// ---------------------------------------------------------------------------------------
+// Inlier count of each hypothesis over all N correspondences.  grid (S, B), block 256.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_score_hyp(const float* __restrict__ src, const float* __restrict__ tgt, const float* __restrict__ seed_T,
+            int* __restrict__ counts, int N, int S, float tau) {
+  __shared__ int red[4];
+  const int pair = blockIdx.y, s = blockIdx.x;
+  const float* T = seed_T + ((size_t)pair * S + s) * 16;
+  const float r00 = T[0], r01 = T[1], r02 = T[2], t0 = T[3], r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7],
+              r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
+  const float* ps = src + (size_t)pair * N * 3;
+  const float* pt = tgt + (size_t)pair * N * 3;
+  int cnt = 0;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const float x = ps[3 * j], y = ps[3 * j + 1], z = ps[3 * j + 2];
+    const float dx = (r00 * x + r01 * y + r02 * z) + t0 - pt[3 * j];
+    const float dy = (r10 * x + r11 * y + r12 * z) + t1 - pt[3 * j + 1];
+    const float dz = (r20 * x + r21 * y + r22 * z) + t2 - pt[3 * j + 2];
+    cnt += (sqrtf(dx * dx + dy * dy + dz * dz) < tau) ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[(size_t)pair * S + s] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------------------
+// Weighted Kabsch over a (masked) point set by a whole workgroup; T updated in shared memory.
+// ---------------------------------------------------------------------------------------
+GMF_DEVINL void block_kabsch(const float* ps, const float* pt, int N, const float* Tin, float thr, bool use_mask,
+                             float* Tout /*shared, 16*/, double* sh) {
+  const float r00 = Tin[0], r01 = Tin[1], r02 = Tin[2], t0 = Tin[3], r10 = Tin[4], r11 = Tin[5], r12 = Tin[6],
+              t1 = Tin[7], r20 = Tin[8], r21 = Tin[9], r22 = Tin[10], t2 = Tin[11];
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    const float x = ps[3 * j], y = ps[3 * j + 1], z = ps[3 * j + 2];
+    const float dx = (r00 * x + r01 * y + r02 * z) + t0 - pt[3 * j];
+    const float dy = (r10 * x + r11 * y + r12 * z) + t1 - pt[3 * j + 1];
+    const float dz = (r20 * x + r21 * y + r22 * z) + t2 - pt[3 * j + 2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (!use_mask || d < thr) {
+      const float q = d / thr;
+      const double w = 1.0f / (1.0f + q * q);
+      acc[0] += w;
+      acc[1] += w * x; acc[2] += w * y; acc[3] += w * z;
+      acc[4] += w * pt[3 * j]; acc[5] += w * pt[3 * j + 1]; acc[6] += w * pt[3 * j + 2];
+    }
+  }
+  block_sum<7>(acc, sh);
+  const double den = acc[0] + 1e-6;
+  const double ca[3] = {acc[1] / den, acc[2] / den, acc[3] / den};
+  const double cb[3] = {acc[4] / den, acc[5] / den, acc[6] / den};
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    const float x = ps[3 * j], y = ps[3 * j + 1], z = ps[3 * j + 2];
+    const float dx = (r00 * x + r01 * y + r02 * z) + t0 - pt[3 * j];
+    const float dy = (r10 * x + r11 * y + r12 * z) + t1 - pt[3 * j + 1];
+    const float dz = (r20 * x + r21 * y + r22 * z) + t2 - pt[3 * j + 2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (!use_mask || d < thr) {
+      const float q = d / thr;
+      const double w = 1.0f / (1.0f + q * q);
+      const double am[3] = {x - ca[0], y - ca[1], z - ca[2]};
+      const double bm[3] = {pt[3 * j] - cb[0], pt[3 * j + 1] - cb[1], pt[3 * j + 2] - cb[2]};
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) H[3 * r + c] += w * am[r] * bm[c];
+    }
+  }
+  block_sum<9>(H, sh);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double R[9];
+    kabsch_rotation_from_H(H, R);
+    write_T(Tout, R, ca, cb);
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
+// Per pair: best hypothesis (first argmax of the inlier count), its inlier labels, and the
+// reference's <=20-step IRLS refinement with early exit on an unchanged inlier count.
+// grid (B), block 1024.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_finalize_pose(const float* __restrict__ src, const float* __restrict__ tgt, const float* __restrict__ seed_T,
+                const int* __restrict__ counts, float* __restrict__ fitness, float* __restrict__ final_T,
+                float* __restrict__ labels, int* __restrict__ best_out, int N, int S, float tau, float refine_thr,
+                int refine_iters) {
+  __shared__ double sh[9 * 16];
+  __shared__ float Tcur[16];
+  __shared__ int s_best, s_cnt;
+  __shared__ int red_c[16], red_i[16];
+  const int pair = blockIdx.x;
+  const float* ps = src + (size_t)pair * N * 3;
+  const float* pt = tgt + (size_t)pair * N * 3;
+  // argmax (first maximal index)
+  int bc = -1, bi = 0x7fffffff;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    const int c = counts[(size_t)pair * S + s];
+    fitness[(size_t)pair * S + s] = (float)c / (float)N;
+    if (c > bc) { bc = c; bi = s; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int oc = __shfl_xor(bc, o, 64), oi = __shfl_xor(bi, o, 64);
+    if (oc > bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { red_c[threadIdx.x >> 6] = bc; red_i[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = red_c[0], ix = red_i[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) if (red_c[w] > c || (red_c[w] == c && red_i[w] < ix)) { c = red_c[w]; ix = red_i[w]; }
+    s_best = ix;
+    best_out[pair] = ix;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) Tcur[threadIdx.x] = seed_T[((size_t)pair * S + s_best) * 16 + threadIdx.x];
+  __syncthreads();
+  // labels under the un-refined best hypothesis (PointDSC.py:423-425)
+  {
+    const float r00 = Tcur[0], r01 = Tcur[1], r02 = Tcur[2], t0 = Tcur[3], r10 = Tcur[4], r11 = Tcur[5], r12 = Tcur[6],
+                t1 = Tcur[7], r20 = Tcur[8], r21 = Tcur[9], r22 = Tcur[10], t2 = Tcur[11];
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      const float x = ps[3 * j], y = ps[3 * j + 1], z = ps[3 * j + 2];
+      const float dx = (r00 * x + r01 * y + r02 * z) + t0 - pt[3 * j];
+      const float dy = (r10 * x + r11 * y + r12 * z) + t1 - pt[3 * j + 1];
+      const float dz = (r20 * x + r21 * y + r22 * z) + t2 - pt[3 * j + 2];
+      labels[(size_t)pair * N + j] = (sqrtf(dx * dx + dy * dy + dz * dz) < tau) ? 1.f : 0.f;
+    }
+  }
+  int prev = 0;
+  for (int it = 0; it < refine_iters; ++it) {
+    __syncthreads();
+    float Tl[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Tl[e] = Tcur[e];
+    int cnt = 0;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      const float x = ps[3 * j], y = ps[3 * j + 1], z = ps[3 * j + 2];
+      const float dx = (Tl[0] * x + Tl[1] * y + Tl[2] * z) + Tl[3] - pt[3 * j];
+      const float dy = (Tl[4] * x + Tl[5] * y + Tl[6] * z) + Tl[7] - pt[3 * j + 1];
+      const float dz = (Tl[8] * x + Tl[9] * y + Tl[10] * z) + Tl[11] - pt[3 * j + 2];
+      cnt += (sqrtf(dx * dx + dy * dy + dz * dz) < refine_thr) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red_c[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int c = 0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) c += red_c[w];
+      s_cnt = c;
+    }
+    __syncthreads();
+    const int n_inl = s_cnt;
+    if (abs(n_inl - prev) < 1) break;
+    prev = n_inl;
+    block_kabsch(ps, pt, N, Tl, refine_thr, true, Tcur, sh);
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) final_T[(size_t)pair * 16 + threadIdx.x] = Tcur[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------
+// Stand-alone post_refinement (PointDSC.py:493-528) for B pairs.  grid (B), block 1024.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_post_refine(const float* __restrict__ T_in, const float* __restrict__ src, const float* __restrict__ tgt,
+              float* __restrict__ T_out, int N, float thr, int iters) {
+  __shared__ double sh[9 * 16];
+  __shared__ float Tcur[16];
+  __shared__ int s_cnt;
+  __shared__ int red_c[16];
+  const int pair = blockIdx.x;
+  const float* ps = src + (size_t)pair * N * 3;
+  const float* pt = tgt + (size_t)pair * N * 3;
+  if (threadIdx.x < 16) Tcur[threadIdx.x] = T_in[(size_t)pair * 16 + threadIdx.x];
+  int prev = 0;
+  for (int it = 0; it < iters; ++it) {
+    __syncthreads();
+    float Tl[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Tl[e] = Tcur[e];
+    int cnt = 0;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      const float x = ps[3 * j], y = ps[3 * j + 1], z = ps[3 * j + 2];
+      const float dx = (Tl[0] * x + Tl[1] * y + Tl[2] * z) + Tl[3] - pt[3 * j];
+      const float dy = (Tl[4] * x + Tl[5] * y + Tl[6] * z) + Tl[7] - pt[3 * j + 1];
+      const float dz = (Tl[8] * x + Tl[9] * y + Tl[10] * z) + Tl[11] - pt[3 * j + 2];
+      cnt += (sqrtf(dx * dx + dy * dy + dz * dz) < thr) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red_c[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int c = 0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) c += red_c[w];
+      s_cnt = c;
+    }
+    __syncthreads();
+    const int n_inl = s_cnt;
+    if (abs(n_inl - prev) < 1) break;
+    prev = n_inl;
+    block_kabsch(ps, pt, N, Tl, thr, true, Tcur, sh);
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) T_out[(size_t)pair * 16 + threadIdx.x] = Tcur[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------
+// Public batched op: rigid_transform_3d(A, B, weights, weight_threshold) (common.py:10-50).
+// One wave per problem; A,B [n,k,3], w [n,k] or null.  grid (n), block 64.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_rigid_transform(const float* __restrict__ A, const float* __restrict__ Bp, const float* __restrict__ w,
+                  float* __restrict__ T, int k, float weight_threshold) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const float* a = A + (size_t)n * k * 3;
+  const float* b = Bp + (size_t)n * k * 3;
+  const float* ww = w ? w + (size_t)n * k : nullptr;
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int j = lane; j < k; j += 64) {
+    float wj = ww ? ww[j] : 1.f;
+    wj = (wj < weight_threshold) ? 0.f : wj;
+    acc[0] += wj;
+    for (int c = 0; c < 3; ++c) { acc[1 + c] += (double)wj * a[3 * j + c]; acc[4 + c] += (double)wj * b[3 * j + c]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 7; ++e) acc[e] = wave_sum(acc[e]);
+  const double den = acc[0] + 1e-6;
+  const double ca[3] = {acc[1] / den, acc[2] / den, acc[3] / den};
+  const double cb[3] = {acc[4] / den, acc[5] / den, acc[6] / den};
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = lane; j < k; j += 64) {
+    float wj = ww ? ww[j] : 1.f;
+    wj = (wj < weight_threshold) ? 0.f : wj;
+    double am[3], bm[3];
+    for (int c = 0; c < 3; ++c) { am[c] = a[3 * j + c] - ca[c]; bm[c] = b[3 * j + c] - cb[c]; }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[3 * r + c] += wj * am[r] * bm[c];
+  }
+#pragma unroll
+  for (int e = 0; e < 9; ++e) H[e] = wave_sum(H[e]);
+  if (lane == 0) {
+    double R[9];
+    kabsch_rotation_from_H(H, R);
+    write_T(T + (size_t)n * 16, R, ca, cb);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// DGR weighted_procrustes (core/registration.py:91-113), batched over pairs with ragged N.
+//   w~ = w/(sum|w| + eps); mu = sum w~ p;  Sxy = sum (y-muy)(w~ (x-mux))^T;  Sxy = U D V^T (fp64);
+//   R = U diag(1,1,det(U)det(V)) V^T;  t = muy - R mux.
+// grid (B), block 1024.  offsets [B+1] row offsets into X,Y,w.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_weighted_procrustes(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ w,
+                      const int* __restrict__ offsets, float eps, float* __restrict__ Rout, float* __restrict__ tout) {
+  __shared__ double sh[9 * 16];
+  const int pair = blockIdx.x;
+  const int o0 = offsets[pair], n = offsets[pair + 1] - o0;
+  const float* x = X + (size_t)o0 * 3;
+  const float* y = Y + (size_t)o0 * 3;
+  const float* ww = w + o0;
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const double wj = ww[j];
+    acc[0] += fabs(wj);
+    for (int c = 0; c < 3; ++c) { acc[1 + c] += wj * x[3 * j + c]; acc[4 + c] += wj * y[3 * j + c]; }
+  }
+  block_sum<7>(acc, sh);
+  const double inv = 1.0 / ((double)(float)acc[0] + (double)eps);
+  const double mx[3] = {acc[1] * inv, acc[2] * inv, acc[3] * inv};
+  const double my[3] = {acc[4] * inv, acc[5] * inv, acc[6] * inv};
+  double Sm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const double wn = ww[j] * inv;
+    double xm[3], ym[3];
+    for (int c = 0; c < 3; ++c) { xm[c] = x[3 * j + c] - mx[c]; ym[c] = y[3 * j + c] - my[c]; }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Sm[3 * r + c] += ym[r] * (wn * xm[c]);
+  }
+  block_sum<9>(Sm, sh);
+  if (threadIdx.x == 0) {
+    // kabsch_rotation_from_H(H) returns V D U^T for H = U S V^T; the DGR rotation is its transpose.
+    double Rt[9];
+    kabsch_rotation_from_H(Sm, Rt);
+    float Rf[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rf[3 * r + c] = (float)Rt[3 * c + r];
+    for (int e = 0; e < 9; ++e) Rout[(size_t)pair * 9 + e] = Rf[e];
+    for (int r = 0; r < 3; ++r)
+      tout[(size_t)pair * 3 + r] = (float)my[r] - (Rf[3 * r] * (float)mx[0] + Rf[3 * r + 1] * (float)mx[1] + Rf[3 * r + 2] * (float)mx[2]);
+  }
+}
+
+// =========================================================================================
+// launchers
+// =========================================================================================
+static inline int next_pow2(int n) { int m = 1; while (m < n) m <<= 1; return m; }
+
+hipError_t launch_nms_keys(const float* src, const float* scores, float* keys, int B, int N, float R, hipStream_t s) {
+  hipLaunchKernelGGL(k_nms_keys, dim3((N + 255) / 256, B), dim3(256), 0, s, src, scores, keys, N, R);
+  return hipGetLastError();
+}
+
+hipError_t launch_sort_topk(const float* keys, int* out_idx, int B, int N, int S, hipStream_t s) {
+  const int M = next_pow2(N < 2 ? 2 : N);
+  if (M > 16384) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_sort_topk, dim3(B), dim3(1024), (size_t)M * 8, s, keys, out_idx, N, M, S);
+  return hipGetLastError();
+}
+
+hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, int* knn_idx, int B, int N, int S, int k, hipStream_t s) {
+  if ((size_t)N * 4 > 150 * 1024) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_seeds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_knn_seeds, dim3(S, B), dim3(256), (size_t)N * 4, s, feat_n, seeds, knn_idx, N, S, k);
+  return hipGetLastError();
+}
+
+hipError_t launch_seed_power(const float* feat_n, const float* src, const float* tgt, const int* knn_idx, float* snaps,
+                             unsigned char* conv, int B, int N, int S, int k, int iters, float sigma, float sigma_d,
+                             hipStream_t s) {
+  if (k > kKMax) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_seed_power, dim3(S, B), dim3(64), 0, s, feat_n, src, tgt, knn_idx, snaps, conv, N, S, k, iters,
+                     1.0f / (sigma * sigma), 1.0f / (sigma_d * sigma_d));
+  return hipGetLastError();
+}
+
+hipError_t launch_seed_kabsch(const float* src, const float* tgt, const int* knn_idx, const float* snaps,
+                              const unsigned char* conv, float* seed_T, int B, int N, int S, int k, int iters, hipStream_t s) {
+  hipLaunchKernelGGL(k_seed_kabsch, dim3((S + 63) / 64, B), dim3(64), 0, s, src, tgt, knn_idx, snaps, conv, seed_T, N, S, k, iters);
+  return hipGetLastError();
+}
+
+hipError_t launch_score_hyp(const float* src, const float* tgt, const float* seed_T, int* counts, int B, int N, int S,
+                            float tau, hipStream_t s) {
+  hipLaunchKernelGGL(k_score_hyp, dim3(S, B), dim3(256), 0, s, src, tgt, seed_T, counts, N, S, tau);
+  return hipGetLastError();
+}
+
+hipError_t launch_finalize_pose(const float* src, const float* tgt, const float* seed_T, const int* counts, float* fitness,
+                                float* final_T, float* labels, int* best, int B, int N, int S, float tau, float refine_thr,
+                                int refine_iters, hipStream_t s) {
+  hipLaunchKernelGGL(k_finalize_pose, dim3(B), dim3(1024), 0, s, src, tgt, seed_T, counts, fitness, final_T, labels, best, N, S,
+                     tau, refine_thr, refine_iters);
+  return hipGetLastError();
+}
+
+hipError_t launch_post_refine(const float* T_in, const float* src, const float* tgt, float* T_out, int B, int N, float thr,
+                              int iters, hipStream_t s) {
+  hipLaunchKernelGGL(k_post_refine, dim3(B), dim3(1024), 0, s, T_in, src, tgt, T_out, N, thr, iters);
+  return hipGetLastError();
+}
+
+hipError_t launch_rigid_transform(const float* A, const float* Bp, const float* w, float* T, int n, int k,
+                                  float weight_threshold, hipStream_t s) {
+  hipLaunchKernelGGL(k_rigid_transform, dim3(n), dim3(64), 0, s, A, Bp, w, T, k, weight_threshold);
+  return hipGetLastError();
+}
+
+hipError_t launch_weighted_procrustes(const float* X, const float* Y, const float* w, const int* offsets, int B, float eps,
+                                      float* R, float* t, hipStream_t s) {
+  hipLaunchKernelGGL(k_weighted_procrustes, dim3(B), dim3(1024), 0, s, X, Y, w, offsets, eps, R, t);
+  return hipGetLastError();
+}
+
+}  // namespace gmf

@@ -1,0 +1,190 @@
+"""Weight packing: reference ``state_dict`` tensors -> the blobs the HIP kernels stream.
+
+Every dense weight W [out, in] becomes its "P32 image" (gmf_amd/csrc/mfma_core.hpp):
+``W.reshape(out/32, 32, in/8, 2, 4).permute(0, 2, 3, 1, 4)`` - 1 KiB per (32 outputs, 8 inputs)
+piece in exactly the order a wavefront's lanes consume it as an MFMA operand, so a 16 KiB stage
+is one contiguous LDS-DMA burst.  Eval-mode BatchNorm is folded into the preceding conv1x1
+(PointDSC.py:104-109,13-21), and the softmax scales (1/sqrt(C), 1/sqrt(d_head)) times log2(e)
+are folded into the Q projections so the kernels use exp2 directly.
+
+Blob layouts (floats), one entry per kernel (see gmf_amd/csrc/encoder_kernels.hip):
+  front : wst 65536 = Wp' | Wq' | Wk | Wv           vec 1664 = bp' | bq' | bk | bv | b0 | W0 image
+  tail  : wst 20480 = Wa' | Wb' | Wc                vec  256 = ba' | bb' | bc
+  ctx   : wst 16384 = Wk | Wv (to_kv halves)        vec  768 = content taps w0|w1|w2|b | gamma_c | beta_c
+  attn  : wst 16384 = Wq'' | Wo                     vec  896 = query taps w0|w1|w2|b | gamma | beta | bo
+  ff    : wst 196608 = 16 x (W1 value | W1 gate | W2 chunk)   vec 1408 = gamma | beta | b1 value | b1 gate | b2
+  head  : wst 8192 = Wc1 | Wc2 (padded)             vec  128 = b1 | b2 | w3 | b3
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+from . import _lib
+
+LOG2E = 1.4426950408889634
+C = 128
+DH = 64
+
+FRONT_WST, FRONT_VEC = 65536, 1664
+TAIL_WST, TAIL_VEC = 20480, 256
+CTX_WST, CTX_VEC = 16384, 768
+ATTN_WST, ATTN_VEC = 16384, 896
+FF_WST, FF_VEC = 196608, 1408
+HEAD_WST, HEAD_VEC = 8192, 128
+
+
+def p32(W: torch.Tensor) -> torch.Tensor:
+    """[M, K] (M % 32 == 0, K % 8 == 0) -> flat P32 image."""
+    M, K = W.shape
+    assert M % 32 == 0 and K % 8 == 0, (M, K)
+    return W.reshape(M // 32, 32, K // 8, 2, 4).permute(0, 2, 3, 1, 4).reshape(-1)
+
+
+def fold_bn(W, b, sd, p, eps=1e-5):
+    """conv1x1 (W [out,in], b) followed by eval BatchNorm `p` -> equivalent (W', b')."""
+    scale = sd[p + "weight"] * torch.rsqrt(sd[p + "running_var"] + eps)
+    return W * scale[:, None], (b - sd[p + "running_mean"]) * scale + sd[p + "bias"]
+
+
+def _f(t):
+    return t.detach().to(torch.float32)
+
+
+def _taps(w, b):
+    w = _f(w)
+    return torch.cat([w[:, 0, 0], w[:, 0, 1], w[:, 0, 2], _f(b)])
+
+
+def check_fusion_dims(sd: Dict[str, torch.Tensor], prefix: str):
+    a = prefix + "cross_attend_blocks.0."
+    wq, wkv, wo = sd[a + "fn.to_q.weight"], sd[a + "fn.to_kv.weight"], sd[a + "fn.to_out.weight"]
+    ok = (tuple(wq.shape) == (DH, C) and tuple(wkv.shape) == (2 * DH, C) and tuple(wo.shape) == (C, DH))
+    if not ok:
+        raise NotImplementedError(
+            f"gmf_amd: the HIP fusion kernels are built for latent_dim = dim = {C}, one head of {DH}; got to_q "
+            f"{tuple(wq.shape)}, to_kv {tuple(wkv.shape)}, to_out {tuple(wo.shape)} (no fallback path exists)")
+
+
+def pack_fusion(sd: Dict[str, torch.Tensor], prefix: str, pe: bool):
+    """One FusionLayer (depth=0) -> dict of 6 blobs (fusion_layer.py:131-201)."""
+    check_fusion_dims(sd, prefix)
+    a = prefix + "cross_attend_blocks.0."
+    f = prefix + "cross_attend_blocks.1."
+    dev = sd[a + "fn.to_q.weight"].device
+    z = torch.zeros(4 * C, device=dev)
+    wkv = _f(sd[a + "fn.to_kv.weight"])
+    ctx_wst = torch.cat([p32(wkv[:DH]), p32(wkv[DH:])])
+    ctx_vec = torch.cat([_taps(sd[prefix + "cpe.proj_content.weight"], sd[prefix + "cpe.proj_content.bias"]) if pe else z,
+                         _f(sd[a + "norm_context.weight"]), _f(sd[a + "norm_context.bias"])])
+    wq = _f(sd[a + "fn.to_q.weight"]) * (DH ** -0.5 * LOG2E)
+    attn_wst = torch.cat([p32(wq), p32(_f(sd[a + "fn.to_out.weight"]))])
+    attn_vec = torch.cat([_taps(sd[prefix + "cpe.proj_q.weight"], sd[prefix + "cpe.proj_q.bias"]) if pe else z,
+                          _f(sd[a + "norm.weight"]), _f(sd[a + "norm.bias"]), _f(sd[a + "fn.to_out.bias"])])
+    W1, b1 = _f(sd[f + "fn.net.0.weight"]), _f(sd[f + "fn.net.0.bias"])
+    W2, b2 = _f(sd[f + "fn.net.2.weight"]), _f(sd[f + "fn.net.2.bias"])
+    hid = W2.shape[1]
+    assert tuple(W1.shape) == (2 * hid, C) and tuple(W2.shape) == (C, hid) and hid == 4 * C
+    chunks = []
+    for c in range(hid // 32):
+        chunks += [p32(W1[32 * c:32 * c + 32]), p32(W1[hid + 32 * c:hid + 32 * c + 32]), p32(W2[:, 32 * c:32 * c + 32])]
+    ff_wst = torch.cat(chunks)
+    ff_vec = torch.cat([_f(sd[f + "norm.weight"]), _f(sd[f + "norm.bias"]), b1[:hid], b1[hid:], b2])
+    out = {"ctx_wst": ctx_wst, "ctx_vec": ctx_vec, "attn_wst": attn_wst, "attn_vec": attn_vec,
+           "ff_wst": ff_wst, "ff_vec": ff_vec}
+    assert out["ctx_wst"].numel() == CTX_WST and out["ctx_vec"].numel() == CTX_VEC
+    assert out["attn_wst"].numel() == ATTN_WST and out["attn_vec"].numel() == ATTN_VEC
+    assert out["ff_wst"].numel() == FF_WST and out["ff_vec"].numel() == FF_VEC
+    return {k: v.contiguous() for k, v in out.items()}
+
+
+def pack_front(sd, layer: int, with_layer0: bool, identity_pointcn: bool = False):
+    """PointCN_layer_i (BN folded) + projection_{q,k,v} (+ layer0) (PointDSC.py:88,104-109,23-25)."""
+    n = f"encoder.blocks.NonLocal_layer_{layer}."
+    pc = f"encoder.blocks.PointCN_layer_{layer}."
+    dev = sd[n + "projection_q.weight"].device
+    if identity_pointcn:
+        Wp, bp = torch.eye(C, device=dev), torch.zeros(C, device=dev)
+    else:
+        Wp, bp = fold_bn(_f(sd[pc + "0.weight"])[:, :, 0], _f(sd[pc + "0.bias"]), sd, pc + "1.")
+    cq = LOG2E / math.sqrt(C)
+    Wq, bq = _f(sd[n + "projection_q.weight"])[:, :, 0] * cq, _f(sd[n + "projection_q.bias"]) * cq
+    Wk, bk = _f(sd[n + "projection_k.weight"])[:, :, 0], _f(sd[n + "projection_k.bias"])
+    Wv, bv = _f(sd[n + "projection_v.weight"])[:, :, 0], _f(sd[n + "projection_v.bias"])
+    wst = torch.cat([p32(Wp), p32(Wq), p32(Wk), p32(Wv)])
+    if with_layer0:
+        W0 = _f(sd["encoder.layer0.weight"])[:, :, 0]
+        assert W0.shape[1] <= 8, "in_dim > 8 is not supported by the layer0 MFMA prologue"
+        W0p = torch.zeros(C, 8, device=dev)
+        W0p[:, :W0.shape[1]] = W0
+        extra = torch.cat([_f(sd["encoder.layer0.bias"]), p32(W0p)])
+    else:
+        extra = torch.zeros(C + 1024, device=dev)
+    vec = torch.cat([bp, bq, bk, bv, extra])
+    assert wst.numel() == FRONT_WST and vec.numel() == FRONT_VEC
+    return wst.contiguous(), vec.contiguous()
+
+
+def pack_tail(sd, layer: int):
+    """fc_message with both BatchNorms folded (PointDSC.py:13-21)."""
+    p = f"encoder.blocks.NonLocal_layer_{layer}.fc_message."
+    Wa, ba = fold_bn(_f(sd[p + "0.weight"])[:, :, 0], _f(sd[p + "0.bias"]), sd, p + "1.")
+    Wb, bb = fold_bn(_f(sd[p + "3.weight"])[:, :, 0], _f(sd[p + "3.bias"]), sd, p + "4.")
+    Wc, bc = _f(sd[p + "6.weight"])[:, :, 0], _f(sd[p + "6.bias"])
+    wst = torch.cat([p32(Wa), p32(Wb), p32(Wc)])
+    vec = torch.cat([ba, bb, bc])
+    assert wst.numel() == TAIL_WST and vec.numel() == TAIL_VEC
+    return wst.contiguous(), vec.contiguous()
+
+
+def pack_head(sd):
+    """classification head (PointDSC.py:175-181)."""
+    W1, b1 = _f(sd["classification.0.weight"])[:, :, 0], _f(sd["classification.0.bias"])
+    W2, b2 = _f(sd["classification.2.weight"])[:, :, 0], _f(sd["classification.2.bias"])
+    w3, b3 = _f(sd["classification.4.weight"])[0, :, 0], _f(sd["classification.4.bias"])
+    dev = W1.device
+    wst = torch.cat([p32(W1), p32(W2), torch.zeros(HEAD_WST - 4096 - 1024, device=dev)])
+    vec = torch.cat([b1, b2, w3, b3, torch.zeros(HEAD_VEC - 97, device=dev)])
+    return wst.contiguous(), vec.contiguous()
+
+
+class PackedEncoder:
+    """All blobs of NonLocalNet + classifier on one device, plus the ctypes struct handed to the C ABI."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], num_layers: int, device, standalone_block: bool = False):
+        sd = {k: v.to(device) for k, v in sd.items() if v.is_floating_point()}
+        self.num_layers = num_layers
+        f1 = pack_fusion(sd, "encoder.fusion_layer_1.", pe=False) if "encoder.fusion_layer_1.cross_attend_blocks.0.fn.to_q.weight" in sd else None
+        f2 = [pack_fusion(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.", pe=True) for i in range(num_layers)]
+        fronts = [pack_front(sd, i, with_layer0=(i == 0 and "encoder.layer0.weight" in sd),
+                             identity_pointcn=standalone_block) for i in range(num_layers)]
+        tails = [pack_tail(sd, i) for i in range(num_layers)]
+        st = lambda lst: torch.stack(lst).contiguous() if lst else torch.zeros(1, device=device)
+        self.t = {
+            "ctx_wst": st([f["ctx_wst"] for f in f2]), "ctx_vec": st([f["ctx_vec"] for f in f2]),
+            "attn_wst": st([f["attn_wst"] for f in f2]), "attn_vec": st([f["attn_vec"] for f in f2]),
+            "ff_wst": st([f["ff_wst"] for f in f2]), "ff_vec": st([f["ff_vec"] for f in f2]),
+            "front_wst": st([f[0] for f in fronts]), "front_vec": st([f[1] for f in fronts]),
+            "tail_wst": st([t[0] for t in tails]), "tail_vec": st([t[1] for t in tails]),
+        }
+        if f1 is not None:
+            for k, v in f1.items():
+                self.t["f1_" + k] = v
+        if "classification.0.weight" in sd:
+            self.t["head_wst"], self.t["head_vec"] = pack_head(sd)
+        self.sigma_d = float(sd["sigma_spat"].reshape(-1)[0]) if "sigma_spat" in sd else 0.1
+        w = _lib.EncoderWeights()
+        w.num_layers = num_layers
+        for name in ("f1_ctx_wst", "f1_ctx_vec", "f1_attn_wst", "f1_attn_vec", "f1_ff_wst", "f1_ff_vec",
+                     "ctx_wst", "ctx_vec", "attn_wst", "attn_vec", "ff_wst", "ff_vec", "front_wst", "front_vec",
+                     "tail_wst", "tail_vec", "head_wst", "head_vec"):
+            setattr(w, name, self.t[name].data_ptr() if name in self.t else None)
+        w.ctx_wst_stride, w.ctx_vec_stride = CTX_WST, CTX_VEC
+        w.attn_wst_stride, w.attn_vec_stride = ATTN_WST, ATTN_VEC
+        w.ff_wst_stride, w.ff_vec_stride = FF_WST, FF_VEC
+        w.front_wst_stride, w.front_vec_stride = FRONT_WST, FRONT_VEC
+        w.tail_wst_stride, w.tail_vec_stride = TAIL_WST, TAIL_VEC
+        w.sigma_d = self.sigma_d
+        self.struct = w

@@ -1,0 +1,304 @@
+"""PointDSC / NonLocalNet / NonLocalBlock drop-ins (reference: GMF_PointDSC/models/PointDSC.py).
+
+Same constructor arguments, forward signatures, output dict and ``state_dict`` keys as the reference.
+Sub-modules hold parameters under the reference's names; compute is the HIP library.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib, packing
+from ._util import handle_and_stream, params_version, require_cuda_f32
+from .fusion_layer import FusionLayer
+
+
+# ------------------------------------------------------------------------------------------------
+# Image encoder: ResNet-34 truncated after layer2 (models/resnet.py:195-216, Img_Encoder.py:9-19).
+# Upstream of the hot path: stock convolutions, run by PyTorch-ROCm/MIOpen.
+# ------------------------------------------------------------------------------------------------
+class _BasicBlock(nn.Module):
+    def __init__(self, inp, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inp, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or inp != planes:
+            self.downsample = nn.Sequential(nn.Conv2d(inp, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+
+class _ResNet34ToLayer2(nn.Module):
+    def __init__(self, in_channels=3):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = nn.Sequential(*[_BasicBlock(64, 64) for _ in range(3)])
+        self.layer2 = nn.Sequential(_BasicBlock(64, 128, 2), *[_BasicBlock(128, 128) for _ in range(3)])
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        return self.layer2(self.layer1(x))
+
+
+class ImageEncoder(nn.Module):
+    """Keys match `encoder.image_encoder.backbone.{conv1,bn1,layer1,layer2}.*`; the reference's unused
+    layer3/layer4/fc entries are ignored by the non-strict loads it uses (evaluation/test_3DMatch.py:262)."""
+
+    def __init__(self):
+        super().__init__()
+        self.backbone = _ResNet34ToLayer2(3)
+
+    def forward(self, x):
+        return self.backbone(x)
+
+
+# ------------------------------------------------------------------------------------------------
+class NonLocalBlock(nn.Module):
+    """PointDSC.py:10-74.  forward(feat [B,C,N], attention [B,N,N], image_feat [B,T,C]) -> [B,C,N]."""
+
+    def __init__(self, num_channels=128, num_heads=1):
+        super().__init__()
+        if num_channels != 128 or num_heads != 1:
+            raise NotImplementedError("gmf_amd.NonLocalBlock: HIP kernels are built for num_channels=128, num_heads=1 "
+                                      "(the only configuration GMF instantiates, PointDSC.py:111)")
+        c = num_channels
+        self.fc_message = nn.Sequential(
+            nn.Conv1d(c, c // 2, 1), nn.BatchNorm1d(c // 2), nn.ReLU(inplace=True),
+            nn.Conv1d(c // 2, c // 2, 1), nn.BatchNorm1d(c // 2), nn.ReLU(inplace=True),
+            nn.Conv1d(c // 2, c, 1))
+        self.projection_q = nn.Conv1d(c, c, 1)
+        self.projection_k = nn.Conv1d(c, c, 1)
+        self.projection_v = nn.Conv1d(c, c, 1)
+        self.num_channels, self.head = c, num_heads
+        self.fusion_layer_2 = FusionLayer(dim=c, depth=0, latent_dim=c, cross_heads=1, latent_heads=8,
+                                          cross_dim_head=c // 2, latent_dim_head=c // 2, pe=True)
+        self._packed, self._packed_version = None, None
+
+    def _weights(self, device):
+        ver = (params_version(self), str(device))
+        if self._packed is None or self._packed_version != ver:
+            if self.training:
+                raise RuntimeError("gmf_amd.NonLocalBlock: only eval() mode is implemented (BatchNorm uses running stats)")
+            pre = "encoder.blocks.NonLocal_layer_0."
+            sd = {pre + k: v.detach() for k, v in self.state_dict().items()}
+            self._packed = packing.PackedEncoder(sd, 1, device, standalone_block=True)
+            self._packed_version = ver
+        return self._packed
+
+    def forward(self, feat, attention, image_feat):
+        feat = require_cuda_f32(feat, "feat")
+        attention = require_cuda_f32(attention, "attention").contiguous()
+        image_feat = require_cuda_f32(image_feat, "image_feat").contiguous()
+        B, Cc, N = feat.shape
+        T = image_feat.shape[1]
+        if attention.shape != (B, N, N):
+            raise RuntimeError(f"gmf_amd.NonLocalBlock: attention must be [B,N,N], got {tuple(attention.shape)}")
+        pw = self._weights(feat.device)
+        h, st = handle_and_stream(feat)
+        tiles, tt = (N + 31) // 32, (T + 31) // 32
+        fimg = torch.empty(B * tiles * 4096, device=feat.device)
+        oimg = torch.empty(B * tiles * 4096, device=feat.device)
+        timg = torch.empty(B * tt * 4096, device=feat.device)
+        h.call("gmf_pack_rows_p32", feat.data_ptr(), feat.stride(0), feat.stride(2), feat.stride(1), B, N, Cc, fimg.data_ptr(), st)
+        h.call("gmf_pack_rows_p32", image_feat.data_ptr(), T * Cc, Cc, 1, B, T, Cc, timg.data_ptr(), st)
+        h.call("gmf_nonlocal_block_forward", pw.struct, 0, 0, fimg.data_ptr(), None, attention.data_ptr(),
+               timg.data_ptr(), oimg.data_ptr(), B, N, T, st)
+        out = torch.empty((B, Cc, N), device=feat.device, dtype=torch.float32)
+        h.call("gmf_unpack_rows_p32", oimg.data_ptr(), B, N, Cc, out.data_ptr(), out.stride(0), out.stride(2), out.stride(1), st)
+        return out
+
+
+class NonLocalNet(nn.Module):
+    """PointDSC.py:77-143.  Parameter container + image-token front end; the layer loop lives in
+    `gmf_encoder_forward` (called by PointDSC.forward)."""
+
+    def __init__(self, in_dim=6, num_layers=6, num_channels=128):
+        super().__init__()
+        if num_channels != 128:
+            raise NotImplementedError("gmf_amd.NonLocalNet: HIP kernels are built for num_channels=128")
+        self.num_layers = num_layers
+        self.blocks = nn.ModuleDict()
+        self.layer0 = nn.Conv1d(in_dim, num_channels, 1, bias=True)
+        self.image_encoder = ImageEncoder()
+        c = num_channels
+        self.fusion_layer_1 = FusionLayer(dim=c, depth=0, latent_dim=c, cross_heads=1, latent_heads=8,
+                                          cross_dim_head=c // 2, latent_dim_head=c // 2)
+        for i in range(num_layers):
+            self.blocks[f"PointCN_layer_{i}"] = nn.Sequential(nn.Conv1d(c, c, 1, bias=True), nn.BatchNorm1d(c), nn.ReLU(inplace=True))
+            self.blocks[f"NonLocal_layer_{i}"] = NonLocalBlock(c)
+
+    def image_tokens(self, image):
+        """[B,3,H,W] -> [B,H'*W',128] (PointDSC.py:129-131)."""
+        f = self.image_encoder(image)
+        B, C, H, W = f.shape
+        return f.view(B, C, H * W).permute(0, 2, 1).contiguous()
+
+
+class PointDSC(nn.Module):
+    """PointDSC.py:146-528.
+
+    forward(data) takes the reference's dict (corr_pos, src_keypts, tgt_keypts, p_image, q_image, optional
+    key 'testing' whose PRESENCE selects test mode) and returns {"final_trans", "final_labels", "M"}.
+    Extensions: image tokens may be given directly as data["p_tokens"], data["q_tokens"] [B,T,128]
+    (skips the ResNet); test mode supports B > 1 (= B independent B=1 calls of the reference, which asserts
+    B == 1 at PointDSC.py:279,504); the inlier logits are kept in `self.last_logits` in both modes.
+    """
+
+    def __init__(self, in_dim=6, num_layers=6, num_channels=128, num_iterations=10, ratio=0.1,
+                 inlier_threshold=0.10, sigma_d=0.10, k=40, nms_radius=0.10):
+        super().__init__()
+        self.num_iterations = num_iterations
+        self.ratio = ratio
+        self.num_channels = num_channels
+        self.inlier_threshold = inlier_threshold
+        self.sigma = nn.Parameter(torch.Tensor([1.0]).float(), requires_grad=True)
+        self.sigma_spat = nn.Parameter(torch.Tensor([sigma_d]).float(), requires_grad=False)
+        self.k = k
+        self.nms_radius = nms_radius
+        self.encoder = NonLocalNet(in_dim=in_dim, num_layers=num_layers, num_channels=num_channels)
+        self.classification = nn.Sequential(
+            nn.Conv1d(num_channels, 32, 1, bias=True), nn.ReLU(inplace=True),
+            nn.Conv1d(32, 32, 1, bias=True), nn.ReLU(inplace=True),
+            nn.Conv1d(32, 1, 1, bias=True))
+        for m in self.modules():        # PointDSC.py:183-188
+            if isinstance(m, (nn.Conv1d, nn.Linear)):
+                nn.init.xavier_normal_(m.weight, gain=1)
+            elif isinstance(m, nn.BatchNorm1d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self._packed, self._packed_version = None, None
+        self.last_logits = None
+        self.last_features = None
+
+    # -- packed weights ---------------------------------------------------------------------------
+    def _hot_state(self):
+        return {k: v for k, v in self.state_dict().items() if not k.startswith("encoder.image_encoder.")}
+
+    def _weights(self, device):
+        hot = [p for n, p in list(self.named_parameters()) + list(self.named_buffers()) if not n.startswith("encoder.image_encoder.")]
+        ver = 0
+        for p in hot:
+            ver = (ver * 1000003 + p._version * 31 + p.data_ptr()) & 0xFFFFFFFFFFFF
+        key = (ver, str(device))
+        if self._packed is None or self._packed_version != key:
+            self._packed = packing.PackedEncoder(self._hot_state(), self.encoder.num_layers, device)
+            self._packed_version = key
+        return self._packed
+
+    # -- encoder: logits + normalised features ----------------------------------------------------
+    def encode(self, corr_pos, src_keypts, tgt_keypts, p_tokens, q_tokens, want_features=False):
+        if self.training:
+            raise RuntimeError("gmf_amd.PointDSC: only eval() mode is implemented (inference path; BatchNorm uses running stats)")
+        corr_pos = require_cuda_f32(corr_pos, "corr_pos").contiguous()
+        src = require_cuda_f32(src_keypts, "src_keypts").contiguous()
+        tgt = require_cuda_f32(tgt_keypts, "tgt_keypts").contiguous()
+        p_tokens = require_cuda_f32(p_tokens, "p_tokens").contiguous()
+        q_tokens = require_cuda_f32(q_tokens, "q_tokens").contiguous()
+        B, N, D = corr_pos.shape
+        T = p_tokens.shape[1]
+        if D != self.encoder.layer0.weight.shape[1]:
+            raise RuntimeError(f"gmf_amd.PointDSC: corr_pos last dim {D} != in_dim {self.encoder.layer0.weight.shape[1]}")
+        if p_tokens.shape != (B, T, 128) or q_tokens.shape != (B, T, 128):
+            raise RuntimeError("gmf_amd.PointDSC: image tokens must be [B,T,128] for both images")
+        if src.shape != (B, N, 3) or tgt.shape != (B, N, 3):
+            raise RuntimeError("gmf_amd.PointDSC: src_keypts/tgt_keypts must be [B,N,3]")
+        pw = self._weights(corr_pos.device)
+        dev = corr_pos.device
+        logits = torch.empty((B, N), device=dev)
+        feat_n = torch.empty((B, N, 128), device=dev)
+        feat = torch.empty((B, N, 128), device=dev) if want_features else None
+        h, st = handle_and_stream(corr_pos)
+        h.call("gmf_encoder_forward", pw.struct, corr_pos.data_ptr(), src.data_ptr(), tgt.data_ptr(),
+               p_tokens.data_ptr(), q_tokens.data_ptr(), B, N, T, logits.data_ptr(), feat_n.data_ptr(),
+               None if feat is None else feat.data_ptr(), st)
+        return logits, feat_n, feat
+
+    # -- pose head --------------------------------------------------------------------------------
+    def pose_head(self, feat_n, src_keypts, tgt_keypts, logits, testing, seeds=None, return_aux=False):
+        B, N, _ = feat_n.shape
+        S = int(N * self.ratio)
+        k = min(self.k, N - 1)
+        pp = _lib.PoseParams()
+        pp.num_seeds, pp.k, pp.num_iterations = S, k, self.num_iterations
+        pp.use_nms = 1 if testing else 0
+        pp.refine_iters = 20 if testing else 0
+        pp.sigma, pp.sigma_d = float(self.sigma), float(self.sigma_spat)
+        pp.inlier_threshold, pp.nms_radius = float(self.inlier_threshold), float(self.nms_radius)
+        pp.refine_threshold = 0.10 if self.inlier_threshold == 0.10 else 1.2      # PointDSC.py:505-508
+        dev = feat_n.device
+        final_T = torch.empty((B, 4, 4), device=dev)
+        labels = torch.empty((B, N), device=dev)
+        seeds_out = torch.empty((B, S), device=dev, dtype=torch.int32)
+        aux = {}
+        if return_aux:
+            aux = {"knn_idx": torch.empty((B, S, k), device=dev, dtype=torch.int32),
+                   "seed_trans": torch.empty((B, S, 4, 4), device=dev), "fitness": torch.empty((B, S), device=dev)}
+        seeds_in = None if seeds is None else seeds.to(torch.int32).contiguous()
+        h, st = handle_and_stream(feat_n)
+        h.call("gmf_pose_head", pp, feat_n.data_ptr(), src_keypts.data_ptr(), tgt_keypts.data_ptr(), logits.data_ptr(),
+               None if seeds_in is None else seeds_in.data_ptr(), B, N, final_T.data_ptr(), labels.data_ptr(),
+               seeds_out.data_ptr(), aux["knn_idx"].data_ptr() if return_aux else None,
+               aux["seed_trans"].data_ptr() if return_aux else None, aux["fitness"].data_ptr() if return_aux else None, st)
+        aux["seeds"] = seeds_out
+        return final_T, labels, aux
+
+    def forward(self, data):
+        corr_pos, src_keypts, tgt_keypts = data["corr_pos"], data["src_keypts"], data["tgt_keypts"]
+        testing = "testing" in data.keys()
+        if "p_tokens" in data:
+            p_tok, q_tok = data["p_tokens"], data["q_tokens"]
+        else:
+            with torch.no_grad():
+                p_tok = self.encoder.image_tokens(data["p_image"])
+                q_tok = self.encoder.image_tokens(data["q_image"])
+        with torch.no_grad():
+            logits, feat_n, feat = self.encode(corr_pos, src_keypts, tgt_keypts, p_tok, q_tok, want_features=not testing)
+            self.last_logits, self.last_features = logits, feat_n
+            src = src_keypts.contiguous()
+            tgt = tgt_keypts.contiguous()
+            final_trans, labels, _ = self.pose_head(feat_n, src, tgt, logits, testing)
+            M = None
+            if not testing:
+                # training-loss input (PointDSC.py:231-234); not on the inference hot path, plain torch
+                M = torch.matmul(feat_n, feat_n.permute(0, 2, 1))
+                M = torch.clamp(1 - (1 - M) / self.sigma ** 2, min=0, max=1)
+                idx = torch.arange(M.shape[1], device=M.device)
+                M[:, idx, idx] = 0
+        return {"final_trans": final_trans, "final_labels": labels if testing else logits, "M": M}
+
+    # reference-named helpers, batched --------------------------------------------------------------
+    def pick_seeds(self, dists, scores, R, max_num, src_keypts=None):
+        """PointDSC.py:268-286.  The HIP kernel needs the key points, not the N x N distance matrix."""
+        if src_keypts is None:
+            raise RuntimeError("gmf_amd.PointDSC.pick_seeds: pass src_keypts=...; the N x N `dists` matrix is never materialised")
+        src = require_cuda_f32(src_keypts, "src_keypts").contiguous()
+        scores = require_cuda_f32(scores, "scores").contiguous()
+        B, N = scores.shape
+        out = torch.empty((B, max_num), device=src.device, dtype=torch.int32)
+        h, st = handle_and_stream(src)
+        h.call("gmf_pick_seeds", src.data_ptr(), scores.data_ptr(), B, N, float(R), 1, int(max_num), out.data_ptr(), st)
+        return out.long()
+
+    def post_refinement(self, initial_trans, src_keypts, tgt_keypts, weights=None):
+        """PointDSC.py:493-528, for any B."""
+        T = require_cuda_f32(initial_trans, "initial_trans").contiguous()
+        src = require_cuda_f32(src_keypts, "src_keypts").contiguous()
+        tgt = require_cuda_f32(tgt_keypts, "tgt_keypts").contiguous()
+        B, N = src.shape[0], src.shape[1]
+        out = torch.empty_like(T)
+        thr = 0.10 if self.inlier_threshold == 0.10 else 1.2
+        h, st = handle_and_stream(T)
+        h.call("gmf_post_refinement", T.data_ptr(), src.data_ptr(), tgt.data_ptr(), B, N, thr, 20, out.data_ptr(), st)
+        return out

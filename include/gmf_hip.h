@@ -1,0 +1,189 @@
+/* gmf_hip.h - C ABI of libgmf_hip.so: the MI355X (gfx950) implementation of GMF's
+ * multimodal-fusion hot path.
+ *
+ * The reference (XiaoshuiHuang/GMF) has NO native plugin ABI: the path sits behind Python
+ * nn.Module.forward calls.  This header is therefore the boundary a binding
+ * would target; each entry point names the reference interface it replaces (file:line relative to
+ * the reference tree).  The Python drop-in modules in gmf_amd/ bind it with ctypes
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain C types only; every data pointer is a DEVICE pointer owned by the caller
+ *     (e.g. torch.Tensor.data_ptr()); the library never frees caller memory;
+ *   - every call is asynchronous on the caller's stream (gmf_stream_t = hipStream_t passed as
+ *     void*; NULL = the default stream) and performs no host synchronisation;
+ *   - return value: 0 = GMF_OK, negative = error (see enum); gmf_last_error_string(h) has details;
+ *     no exception or abort ever crosses this boundary;
+ *   - a handle is bound to one device and is not thread-safe; distinct handles are independent;
+ *   - all tensors are fp32.  "P32 image" / "T image" are the tiled layouts described in
+ *     gmf_amd/csrc/mfma_core.hpp; gmf_pack_rows_p32 / gmf_unpack_rows_p32 convert from and to
+ *     arbitrary strided [B, rows, K] views (row-major [B,N,C] or channel-major [B,C,N]).
+ */
+#ifndef GMF_HIP_H_
+#define GMF_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gmf_handle gmf_handle;
+typedef void* gmf_stream_t;
+
+enum {
+  GMF_OK = 0,
+  GMF_ERR_BAD_ARG = -1,
+  GMF_ERR_UNSUPPORTED_SHAPE = -2,
+  GMF_ERR_HIP = -3,
+  GMF_ERR_NO_DEVICE = -4,
+  GMF_ERR_OOM = -5
+};
+
+#define GMF_ABI_VERSION 1
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int gmf_abi_version(void);
+/* Creates a handle on HIP device `device` (fails with GMF_ERR_NO_DEVICE if there is none). */
+int gmf_create(int device, gmf_handle** out);
+void gmf_destroy(gmf_handle* h);
+const char* gmf_last_error_string(gmf_handle* h);
+/* Bytes of library-owned device workspace currently held by the handle. */
+long long gmf_workspace_bytes(gmf_handle* h);
+
+/* ---- layout conversion ----------------------------------------------------------------------
+ * src element (b, r, k) lives at src[b*sb + r*sr + k*sk]; dst is the P32 image
+ * [B, ceil(n_rows/32), 32*K] (rows >= n_rows are zero).  K must be a multiple of 8.
+ * Replaces the .permute()/.view() glue around the reference modules (PointDSC.py:70,130-135,223). */
+int gmf_pack_rows_p32(gmf_handle* h, const float* src, long long sb, long long sr, long long sk, int B, int n_rows,
+                      int K, float* dst, gmf_stream_t stream);
+int gmf_unpack_rows_p32(gmf_handle* h, const float* src_img, int B, int n_rows, int K, float* dst, long long sb,
+                        long long sr, long long sk, gmf_stream_t stream);
+/* src_keypts, tgt_keypts [B,N,3] -> pts8 [B, Npad, 8] = (sx,sy,sz,0,tx,ty,tz,0). */
+int gmf_pack_pts8(gmf_handle* h, const float* src, const float* tgt, int B, int N, float* dst, gmf_stream_t stream);
+
+/* ---- encoder stages (operate on images; weights are packed blobs, layouts in gmf_amd/packing.py) */
+/* layer0 (if first) + PointCN_i + projection_{q,k,v} of NonLocalBlock i.
+ * Replaces GMF_PointDSC/models/PointDSC.py:88,104-109 (NonLocalNet) and :56-58 (NonLocalBlock).
+ * in: corr_pos [B,N,6] row-major if first, else feat P32 image.  Outputs f,q,k: P32; v: T image. */
+int gmf_front_forward(gmf_handle* h, int first, const float* in, const float* wst, const float* vecs, float* f,
+                      float* q, float* k, float* v, int B, int N, gmf_stream_t stream);
+/* Spatial-consistency self-attention + fc_message + (message + fusion2_out).
+ * Replaces PointDSC.py:216-221 (compat matrix, recomputed in-kernel from pts8, never stored),
+ * :60-65 and :73. */
+int gmf_scattn_forward(gmf_handle* h, const float* q, const float* k, const float* v, const float* pts8,
+                       const float* fusion2_out, const float* wst, const float* vecs, float* out, int B, int N,
+                       float sigma_d, gmf_stream_t stream);
+/* Same, but with the caller's dense compatibility matrix `attention` [B,N,N] (row-major) as
+ * NonLocalBlock.forward receives it (PointDSC.py:40-45,62) instead of recomputing it from key points. */
+int gmf_scattn_forward_dense(gmf_handle* h, const float* q, const float* k, const float* v, const float* attention,
+                             const float* fusion2_out, const float* wst, const float* vecs, float* out, int B, int N,
+                             gmf_stream_t stream);
+/* Context side of FusionLayer: [LCPE] + LayerNorm_context + to_kv, for `sets` weight sets at once.
+ * Replaces GMF_PointDSC/models/fusion_layer.py:124-126,46-49,86-87 (DGR twin: model/perceiver_io.py:126-128,89-91).
+ * ctx: P32 image [B, Tt, 32*128]; out: [sets, B, Tt, 4096] (K image | V image per 32-token tile). */
+int gmf_fusion_ctx_prepare(gmf_handle* h, int pe, const float* ctx, const float* wst, const float* vecs, float* out,
+                           int B, int T, int sets, int wst_stride, int vec_stride, gmf_stream_t stream);
+/* Query side up to the first residual: [LCPE] + LayerNorm + to_q + softmax(QK^T)V + to_out + x.
+ * Replaces fusion_layer.py:119-121,44,84-94,190. */
+int gmf_fusion_attn_forward(gmf_handle* h, int pe, const float* x, const float* ctx_img, const float* wst,
+                            const float* vecs, float* x1, int B, int N, int T, gmf_stream_t stream);
+/* LayerNorm + Linear(128,1024) + GEGLU + Linear(512,128) + residual.  Replaces fusion_layer.py:54-69,191. */
+int gmf_fusion_ff_forward(gmf_handle* h, const float* x1, const float* wst, const float* vecs, float* x2, int B,
+                          int N, gmf_stream_t stream);
+/* classification head + F.normalize.  Replaces PointDSC.py:175-181,229,241.
+ * Outputs are row-major: logits [B,N], feat_n [B,N,128], feat [B,N,128] (feat may be NULL). */
+int gmf_classifier_forward(gmf_handle* h, const float* feat_img, const float* wst, const float* vecs, float* logits,
+                           float* feat_n, float* feat, int B, int N, gmf_stream_t stream);
+
+/* ---- whole encoder ---------------------------------------------------------------------------
+ * Packed weights of PointDSC's NonLocalNet (minus the ResNet image encoder, which is upstream of the
+ * hot path) + classifier.  All pointers are device pointers; *_stride are in floats between layers. */
+typedef struct gmf_encoder_weights {
+  int num_layers;
+  const float* f1_ctx_wst;  const float* f1_ctx_vec;      /* Fusion-1 context side (pe = 0)  */
+  const float* f1_attn_wst; const float* f1_attn_vec;     /* Fusion-1 query side             */
+  const float* f1_ff_wst;   const float* f1_ff_vec;
+  const float* ctx_wst;     const float* ctx_vec;   int ctx_wst_stride,   ctx_vec_stride;   /* Fusion-2, per layer */
+  const float* attn_wst;    const float* attn_vec;  int attn_wst_stride,  attn_vec_stride;
+  const float* ff_wst;      const float* ff_vec;    int ff_wst_stride,    ff_vec_stride;
+  const float* front_wst;   const float* front_vec; int front_wst_stride, front_vec_stride;
+  const float* tail_wst;    const float* tail_vec;  int tail_wst_stride,  tail_vec_stride;  /* fc_message */
+  const float* head_wst;    const float* head_vec;
+  float sigma_d;
+} gmf_encoder_weights;
+
+/* PointDSC.forward up to the logits (PointDSC.py:216-241) with image TOKENS as input:
+ * corr_pos [B,N,6], src/tgt_keypts [B,N,3], p_tokens/q_tokens [B,T,128] (row-major)
+ * -> logits [B,N], feat_n [B,N,128] (unit rows), feat [B,N,128] (may be NULL). */
+int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float* corr_pos, const float* src_keypts,
+                        const float* tgt_keypts, const float* p_tokens, const float* q_tokens, int B, int N, int T,
+                        float* logits, float* feat_n, float* feat, gmf_stream_t stream);
+
+/* One NonLocalBlock on P32 images (PointDSC.py:40-74): feat_img -> out_img given the fused image tokens
+ * (P32 image [B,Tt,..]) and EITHER pts8 (compat recomputed in-kernel) OR the dense `attention` [B,N,N]
+ * (exactly one of the two non-NULL).  layer selects the weight set inside `w`. */
+int gmf_nonlocal_block_forward(gmf_handle* h, const gmf_encoder_weights* w, int layer, int apply_pointcn,
+                               const float* feat_img, const float* pts8, const float* attention,
+                               const float* image_feat_img, float* out_img, int B, int N, int T, gmf_stream_t stream);
+
+/* FusionLayer.forward with depth=0 on row-major tensors (fusion_layer.py:172-201):
+ * data [B,T,128] (context), queries [B,N,128] -> out [B,N,128].  Weight blobs as for Fusion-1/2. */
+int gmf_fusion_layer_forward(gmf_handle* h, int pe, const float* ctx_wst, const float* ctx_vec, const float* attn_wst,
+                             const float* attn_vec, const float* ff_wst, const float* ff_vec, const float* data,
+                             const float* queries, long long q_sb, long long q_sr, long long q_sk, float* out,
+                             long long o_sb, long long o_sr, long long o_sk, int B, int N, int T, gmf_stream_t stream);
+
+/* ---- pose head ------------------------------------------------------------------------------- */
+typedef struct gmf_pose_params {
+  int num_seeds;        /* S = int(N * ratio)                        PointDSC.py:244 */
+  int k;                /* neighbours per seed (<= 64, <= N-1)        PointDSC.py:324 */
+  int num_iterations;   /* power iterations                          PointDSC.py:437 */
+  int use_nms;          /* 1: pick_seeds (test mode) ; 0: plain top-S (train mode)  PointDSC.py:243-246 */
+  int refine_iters;     /* 20 in test mode, 0 to skip post_refinement PointDSC.py:256-257,505-508 */
+  float sigma;          /* learned feature bandwidth                 PointDSC.py:164 */
+  float sigma_d;        /* spatial bandwidth                         PointDSC.py:165 */
+  float inlier_threshold;
+  float nms_radius;
+  float refine_threshold; /* 0.10 if inlier_threshold == 0.10 else 1.2 PointDSC.py:505-508 */
+} gmf_pose_params;
+
+/* seeds -> kNN -> seed compatibility + power iteration -> weighted Kabsch -> hypothesis scoring ->
+ * argmax -> labels -> post refinement, per pair, all on device.
+ * Replaces PointDSC.py:243-257 (pick_seeds :268-286, cal_seed_trans :303-427, cal_leading_eigenvector
+ * :429-448, post_refinement :493-528) and models/common.py:10-75.
+ * seeds_in may be NULL (seeds are computed from logits) or caller-provided [B,S].
+ * Outputs: final_trans [B,16], final_labels [B,N], and optionally (may be NULL) seeds_out [B,S] int32,
+ * knn_out [B,S,k] int32, seed_trans [B,S,16], fitness [B,S]. */
+int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, const float* src_keypts,
+                  const float* tgt_keypts, const float* logits, const int* seeds_in, int B, int N, float* final_trans,
+                  float* final_labels, int* seeds_out, int* knn_out, float* seed_trans, float* fitness,
+                  gmf_stream_t stream);
+
+/* pick_seeds / plain top-S only (PointDSC.py:268-286 / :246). */
+int gmf_pick_seeds(gmf_handle* h, const float* src_keypts, const float* scores, int B, int N, float nms_radius,
+                   int use_nms, int num_seeds, int* seeds_out, gmf_stream_t stream);
+
+/* knn(x, k, ignore_self=True, normalized=True) restricted to the rows listed in `rows` [B,S]
+ * (models/common.py:53-75 followed by the gather at PointDSC.py:327-329): feat_n [B,N,128] unit rows
+ * -> knn_out [B,S,k] int32, nearest first, the row itself (rank 0) dropped. */
+int gmf_knn_rows(gmf_handle* h, const float* feat_n, const int* rows, int B, int N, int S, int k, int* knn_out,
+                 gmf_stream_t stream);
+
+/* rigid_transform_3d(A, B, weights, weight_threshold) (models/common.py:10-50):
+ * A,B [n,k,3], weights [n,k] or NULL -> T [n,4,4].  The 3x3 SVD runs on the device. */
+int gmf_procrustes_batched(gmf_handle* h, const float* A, const float* B, const float* weights, int n, int k,
+                           float weight_threshold, float* T44, gmf_stream_t stream);
+
+/* post_refinement (PointDSC.py:493-528) for B pairs independently: T_in/out [B,16]. */
+int gmf_post_refinement(gmf_handle* h, const float* T_in, const float* src_keypts, const float* tgt_keypts, int B, int N,
+                        float refine_threshold, int iters, float* T_out, gmf_stream_t stream);
+
+/* DGR weighted_procrustes(X, Y, w, eps) (GMF_DeepGlobalRegistration/.../core/registration.py:91-113),
+ * batched over B pairs with ragged sizes: offsets [B+1] (device int32) delimit rows of X,Y [sum N,3], w [sum N].
+ * R [B,9], t [B,3].  fp64 SVD on device, no host transfer. */
+int gmf_weighted_procrustes(gmf_handle* h, const float* X, const float* Y, const float* w, const int* offsets, int B,
+                            float eps, float* R, float* t, gmf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMF_HIP_H_ */

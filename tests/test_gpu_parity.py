@@ -1,0 +1,248 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference's golden vectors and the oracle.
+
+Tolerances: fp32 path, 1e-4 absolute on logits and poses (BASELINE.json north_star); the stress case
+states its tolerance as a multiple of the measured fp32 noise floor of the computation itself.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gmf_amd
+from gmf_amd import synthetic
+from oracle import gmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _maxerr(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+def _gpu(t):
+    return t.to(DEV)
+
+
+@pytest.fixture(scope="module")
+def sd_full():
+    return synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7)
+
+
+@pytest.fixture(scope="module")
+def model(sd_full):
+    m = gmf_amd.PointDSC(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1,
+                         inlier_threshold=0.10, sigma_d=0.10, k=40, nms_radius=0.10)
+    missing, unexpected = m.load_state_dict(sd_full, strict=False)
+    assert not unexpected
+    return m.to(DEV).eval()
+
+
+def test_native_library_loaded():
+    from gmf_amd import _lib
+    lib = _lib.load_library()
+    assert lib.gmf_abi_version() == 1
+    assert _lib.handle_for(0).h
+
+
+def test_pack_unpack_roundtrip():
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    st = torch.cuda.current_stream().cuda_stream
+    for (B, N, K, chan_major) in [(2, 70, 128, False), (1, 33, 64, False), (3, 257, 128, True)]:
+        x = torch.randn(B, N, K, device=DEV)
+        src = x.permute(0, 2, 1).contiguous().permute(0, 2, 1) if chan_major else x
+        tiles = (N + 31) // 32
+        img = torch.empty(B * tiles * 32 * K, device=DEV)
+        h.call("gmf_pack_rows_p32", src.data_ptr(), src.stride(0), src.stride(1), src.stride(2), B, N, K, img.data_ptr(), st)
+        # image definition: float4 ((tile*(K/8)+g)*64 + lane) = X[32*tile + (lane&31)][8g + 4(lane>>5) ..]
+        ref = torch.zeros(B, tiles * 32, K, device=DEV)
+        ref[:, :N] = x
+        ref = ref.reshape(B, tiles, 32, K // 8, 2, 4).permute(0, 1, 3, 4, 2, 5).reshape(-1)
+        assert torch.equal(img, ref)
+        y = torch.empty_like(x)
+        h.call("gmf_unpack_rows_p32", img.data_ptr(), B, N, K, y.data_ptr(), y.stride(0), y.stride(1), y.stride(2), st)
+        assert torch.equal(x, y)
+
+
+def test_f1_fusion1(golden_dir):
+    g = _load(golden_dir, "f1_fusion1.npz")
+    sd = synthetic.seeded_state_dict(synthetic.fusion_layer_shapes("", 128, 128, 64, pe=False), seed=int(g["seed"]))
+    m = gmf_amd.FusionLayer(depth=0, dim=128, latent_dim=128, cross_heads=1, latent_heads=8, cross_dim_head=64, latent_dim_head=64)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    for T in (12, 196, 300):
+        b = synthetic.synthetic_batch(list(g["pair_seeds"]), N=8, T=T)
+        y = m(_gpu(b["p_tokens"]), queries_encoder=_gpu(b["q_tokens"]))
+        assert _maxerr(y.cpu(), g[f"out_T{T}"]) < 1e-4
+
+
+@pytest.mark.parametrize("N,T", [(64, 12), (257, 196), (1000, 196), (33, 1), (1, 7)])
+def test_f2_fusion2(golden_dir, N, T):
+    g = _load(golden_dir, "f2_fusion2.npz")
+    sd = synthetic.seeded_state_dict(synthetic.fusion_layer_shapes("", 128, 128, 64, pe=True), seed=int(g["seed"]))
+    m = gmf_amd.FusionLayer(depth=0, dim=128, latent_dim=128, cross_heads=1, latent_heads=8, cross_dim_head=64,
+                            latent_dim_head=64, pe=True)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    r = np.random.default_rng([102, N, T])
+    x = torch.from_numpy(r.normal(0, 1, (1, N, 128)).astype(np.float32))
+    ctx = torch.from_numpy(r.normal(0, 1, (1, T, 128)).astype(np.float32))
+    y = m(_gpu(ctx), queries_encoder=_gpu(x))
+    assert _maxerr(y.cpu(), g[f"out_N{N}_T{T}"]) < 1e-4
+    # the reference feeds a transposed [B,C,N] view (PointDSC.py:70): strided queries must give the same result
+    xt = _gpu(x).permute(0, 2, 1).contiguous().permute(0, 2, 1)
+    assert torch.equal(m(_gpu(ctx), queries_encoder=xt), y)
+
+
+def test_f3_nonlocal_block(golden_dir, sd_full):
+    g = _load(golden_dir, "f3_nonlocal_block.npz")
+    layer = int(g["layer"])
+    pre = f"encoder.blocks.NonLocal_layer_{layer}."
+    blk = gmf_amd.NonLocalBlock(128)
+    blk.load_state_dict({k[len(pre):]: v for k, v in sd_full.items() if k.startswith(pre)})
+    blk = blk.to(DEV).eval()
+    b = synthetic.synthetic_batch(list(g["pair_seeds"]), N=257, T=196)
+    compat, _ = O.compat_matrix(b["src_keypts"], b["tgt_keypts"], 0.1)
+    feat = torch.from_numpy(g["feat"])
+    y = blk(_gpu(feat).permute(0, 2, 1).contiguous(), _gpu(compat), _gpu(torch.from_numpy(g["img"])))
+    assert y.shape == (2, 128, 257)
+    assert _maxerr(y.permute(0, 2, 1).cpu(), g["out"]) < 1e-4
+
+
+@pytest.mark.parametrize("N", [64, 257, 1000])
+def test_f4_f10_pointdsc(golden_dir, model, N):
+    g = _load(golden_dir, "f4_f10_pointdsc.npz")
+    seeds = list(g[f"pair_seeds_N{N}"])
+    b = synthetic.synthetic_batch(seeds, N=N, T=196)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    res = model(data)
+    logits = model.last_logits.cpu().numpy()
+    assert _maxerr(logits, g[f"logits_N{N}"]) < 1e-4
+    assert _maxerr(res["final_trans"].cpu(), g[f"final_trans_N{N}"]) < 1e-4
+    assert (res["final_labels"].cpu().numpy() == g[f"final_labels_N{N}"]).mean() > 0.999
+    _, _, feat = model.encode(data["corr_pos"], data["src_keypts"], data["tgt_keypts"], data["p_tokens"], data["q_tokens"], True)
+    if N <= 257:
+        assert _maxerr(feat.cpu(), g[f"feat_N{N}"]) < 1e-4
+    else:
+        assert _maxerr(feat[:, ::50].cpu(), g[f"feat_rows_N{N}"]) < 1e-4
+    if len(seeds) == 2:      # train mode: logits are the labels, B=2 in one call
+        del data["testing"]
+        tr = model(data)
+        assert _maxerr(tr["final_labels"].cpu(), g[f"train_logits_N{N}"]) < 1e-4
+        assert _maxerr(tr["final_trans"].cpu(), g[f"train_final_trans_N{N}"]) < 1e-4
+        assert tr["M"].shape == (2, N, N)
+
+
+def test_batched_equals_per_pair(model):
+    """B>1 in one launch == B independent B=1 calls, bit for bit (pairs never interact)."""
+    b = synthetic.synthetic_batch([61, 62, 63], N=333, T=50)
+    keys = ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")
+    full = model.encode(*[_gpu(b[k]) for k in keys])[0]
+    for i in range(3):
+        one = model.encode(*[_gpu(b[k][i:i + 1]) for k in keys])[0]
+        assert torch.equal(full[i:i + 1], one)
+
+
+def test_stress_conditioning(golden_dir):
+    """gain 0.9 weights amplify rounding by ~1.4x per block: two fp32 evaluations that only differ in summation
+    order disagree by the noise floor |oracle32 - oracle64|.  The HIP path must stay within 4x that floor."""
+    sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7, gain=0.9)
+    b = synthetic.synthetic_batch([42], N=257, T=196)
+    o32 = O.pointdsc_forward(sd, b, testing=False)["logits"]
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    b64 = {k: v.double() for k, v in b.items()}
+    compat, _ = O.compat_matrix(b64["src_keypts"], b64["tgt_keypts"], 0.1)
+    o64 = O.classifier(sd64, O.encoder(sd64, b64["corr_pos"], compat, b64["p_tokens"], b64["q_tokens"], 12))
+    floor = float((o32.double() - o64).abs().max())
+    m = gmf_amd.PointDSC(num_layers=12)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(DEV).eval()
+    lg = m.encode(*[_gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")])[0]
+    err = float((lg.cpu().double() - o64).abs().max())
+    assert err < 4 * max(floor, 2e-5), (err, floor)
+
+
+def test_f5_f7_pose_head(golden_dir, model):
+    g = _load(golden_dir, "f5_f7_pose_head.npz")
+    N = int(g["N"])
+    b = synthetic.synthetic_batch([int(g["pair_seed"])], N=N, T=12)
+    feat_n, scores = _gpu(torch.from_numpy(g["feat_n"])), _gpu(torch.from_numpy(g["scores"]))
+    src, tgt = _gpu(b["src_keypts"]), _gpu(b["tgt_keypts"])
+    seeds = model.pick_seeds(None, scores, R=0.10, max_num=int(N * 0.1), src_keypts=src)
+    assert (seeds.cpu().numpy() == g["seeds"]).all()
+    fT, labels, aux = model.pose_head(feat_n, src, tgt, scores, testing=True, return_aux=True)
+    assert (aux["seeds"].cpu().numpy() == g["seeds"]).all()
+    assert (np.sort(aux["knn_idx"].cpu().numpy(), -1) == np.sort(g["knn_idx"], -1)).mean() > 0.999
+    assert _maxerr(aux["seed_trans"].cpu(), g["seed_trans"]) < 1e-3
+    assert _maxerr(aux["fitness"].cpu(), g["fitness"]) < 1e-6
+    assert (labels.cpu().numpy() == g["labels"]).all()
+    assert _maxerr(fT.cpu(), g["refined"]) < 1e-4
+    fT0, _, _ = model.pose_head(feat_n, src, tgt, scores, testing=False, seeds=_gpu(torch.from_numpy(g["seeds"])))
+    assert _maxerr(fT0.cpu(), g["final_trans"]) < 1e-4
+    ref = model.post_refinement(_gpu(torch.from_numpy(g["final_trans"])), src, tgt)
+    assert _maxerr(ref.cpu(), g["refined"]) < 1e-4
+
+
+def test_f6_rigid_transform(golden_dir):
+    g = _load(golden_dir, "f6_rigid_transform.npz")
+    A, B, w = (_gpu(torch.from_numpy(g[k])) for k in ("A", "B", "w"))
+    wc = w.clone()
+    T = gmf_amd.rigid_transform_3d(A, B, wc)
+    assert _maxerr(T.cpu(), g["T"]) < 1e-4
+    assert float(wc.min()) >= 0          # negative weights are zeroed in place, as in the reference
+    assert _maxerr(gmf_amd.rigid_transform_3d(A, B).cpu(), g["T_noweight"]) < 1e-4
+    R = T[:, :3, :3].cpu().numpy()
+    assert np.abs(np.linalg.det(R) - 1).max() < 1e-5
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5
+    # degenerate inputs must not produce NaN: all-zero weights, a single repeated point
+    Tz = gmf_amd.rigid_transform_3d(A[:2], B[:2], torch.zeros_like(w[:2]))
+    assert torch.isfinite(Tz).all()
+    Tp = gmf_amd.rigid_transform_3d(A[:1, :1].repeat(1, 5, 1), B[:1, :1].repeat(1, 5, 1))
+    assert torch.isfinite(Tp).all()
+
+
+@pytest.mark.parametrize("N", [10, 1000, 8000])
+def test_f8_weighted_procrustes(golden_dir, N):
+    g = _load(golden_dir, "f8_weighted_procrustes.npz")
+    X, Y, w = (_gpu(torch.from_numpy(g[f"{k}_{N}"])) for k in ("X", "Y", "w"))
+    R, t = gmf_amd.weighted_procrustes(X, Y, w, np.finfo(np.float32).eps)
+    assert _maxerr(R.cpu(), g[f"R_{N}"]) < 1e-4
+    assert _maxerr(t.cpu(), g[f"t_{N}"]) < 1e-4
+
+
+def test_weighted_procrustes_ragged_batch(golden_dir):
+    g = _load(golden_dir, "f8_weighted_procrustes.npz")
+    Ns = [10, 1000, 8000, 1000]
+    X = _gpu(torch.from_numpy(np.concatenate([g[f"X_{n}"] for n in Ns])))
+    Y = _gpu(torch.from_numpy(np.concatenate([g[f"Y_{n}"] for n in Ns])))
+    w = _gpu(torch.from_numpy(np.concatenate([g[f"w_{n}"] for n in Ns])))
+    R, t = gmf_amd.weighted_procrustes_batched(X, Y, w, np.cumsum([0] + Ns).tolist(), np.finfo(np.float32).eps)
+    for i, n in enumerate(Ns):
+        assert _maxerr(R[i].cpu(), g[f"R_{n}"]) < 1e-4 and _maxerr(t[i].cpu(), g[f"t_{n}"]) < 1e-4
+
+
+def test_full_size_properties(model):
+    """BASELINE config sizes, checked through size-independent properties (the oracle would take minutes):
+    finite outputs, rigid poses, pose close to ground truth, logits invariant to the rigid frame of tgt."""
+    b = synthetic.synthetic_batch([71, 72], N=5000, T=196)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    res = model(data)
+    T = res["final_trans"].cpu().numpy()
+    assert np.isfinite(T).all() and torch.isfinite(model.last_logits).all()
+    R = T[:, :3, :3]
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5
+    assert np.abs(T - b["gt_trans"].numpy()).max() < 5e-2
+    lab = res["final_labels"].cpu().numpy()
+    assert ((lab > 0.5) == (b["gt_labels"].numpy() > 0.5)).mean() > 0.97
+    # one pair against the oracle at full size (about 2 s of CPU)
+    one = {k: v[:1] for k, v in b.items()}
+    ref = O.pointdsc_forward(synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7), one, testing=False)
+    assert _maxerr(model.last_logits[:1].cpu(), ref["logits"]) < 1e-4

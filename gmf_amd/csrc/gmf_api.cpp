@@ -8,6 +8,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "launchers.hpp"
 #include "launchers_pose.hpp"
@@ -18,6 +20,10 @@ struct gmf_handle {
   void* arena = nullptr;
   size_t arena_bytes = 0;
   size_t arena_used = 0;
+  // optional in-situ timing of the dominant kernel (k_scattn): event pairs recorded on the caller's stream
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
 };
 
 namespace {
@@ -104,8 +110,32 @@ int gmf_create(int device, gmf_handle** out) {
   return GMF_OK;
 }
 
+int gmf_profile_enable(gmf_handle* h, int on) {
+  GMF_REQUIRE(h, GMF_ERR_BAD_ARG, "profile_enable: null handle");
+  h->profile = (on != 0);
+  h->prof_used = 0;
+  return GMF_OK;
+}
+
+int gmf_profile_read(gmf_handle* h, double* scattn_ms_total, int* scattn_launches) {
+  GMF_REQUIRE(h && scattn_ms_total && scattn_launches, GMF_ERR_BAD_ARG, "profile_read: null pointer");
+  SetDevice sd(h);
+  double total = 0.0;
+  for (size_t i = 0; i < h->prof_used; ++i) {
+    GMF_HIP(hipEventSynchronize(h->prof_events[i].second));
+    float ms = 0.f;
+    GMF_HIP(hipEventElapsedTime(&ms, h->prof_events[i].first, h->prof_events[i].second));
+    total += ms;
+  }
+  *scattn_ms_total = total;
+  *scattn_launches = (int)h->prof_used;
+  h->prof_used = 0;
+  return GMF_OK;
+}
+
 void gmf_destroy(gmf_handle* h) {
   if (!h) return;
+  for (auto& e : h->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (h->arena) {
     (void)hipSetDevice(h->device);
     (void)hipFree(h->arena);
@@ -228,12 +258,26 @@ static int run_block_tail(gmf_handle* h, const gmf_encoder_weights* w, int l, co
                                   w->attn_vec + (size_t)l * w->attn_vec_stride, x1, B, N, tiles, T, tt, st));
   GMF_HIP(gmf::launch_fusion_ff(x1, w->ff_wst + (size_t)l * w->ff_wst_stride, w->ff_vec + (size_t)l * w->ff_vec_stride,
                                 x2, B, tiles, st));
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (h->profile) {
+    if (h->prof_used == h->prof_events.size()) {
+      hipEvent_t a, b;
+      GMF_HIP(hipEventCreate(&a));
+      GMF_HIP(hipEventCreate(&b));
+      h->prof_events.emplace_back(a, b);
+    }
+    ev0 = h->prof_events[h->prof_used].first;
+    ev1 = h->prof_events[h->prof_used].second;
+    ++h->prof_used;
+    GMF_HIP(hipEventRecord(ev0, st));
+  }
   if (dense_compat)
     GMF_HIP(gmf::launch_scattn_dense(q, k, v, dense_compat, x2, w->tail_wst + (size_t)l * w->tail_wst_stride,
                                      w->tail_vec + (size_t)l * w->tail_vec_stride, out, B, N, tiles, st));
   else
     GMF_HIP(gmf::launch_scattn(q, k, v, pts8, x2, w->tail_wst + (size_t)l * w->tail_wst_stride,
                                w->tail_vec + (size_t)l * w->tail_vec_stride, out, B, N, tiles, w->sigma_d, st));
+  if (ev1) GMF_HIP(hipEventRecord(ev1, st));
   return GMF_OK;
 }
 

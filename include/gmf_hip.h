@@ -49,6 +49,13 @@ const char* gmf_last_error_string(gmf_handle* h);
 /* Bytes of library-owned device workspace currently held by the handle. */
 long long gmf_workspace_bytes(gmf_handle* h);
 
+/* In-situ timing of the dominant kernel (the spatial-consistency attention): while enabled, every
+ * k_scattn launch made through gmf_encoder_forward / gmf_nonlocal_block_forward is bracketed by HIP events
+ * recorded on the caller's stream.  gmf_profile_read synchronises those events (host sync - call it outside
+ * timed regions), returns their summed duration and count, and resets the list.  Used by bench.py. */
+int gmf_profile_enable(gmf_handle* h, int on);
+int gmf_profile_read(gmf_handle* h, double* scattn_ms_total, int* scattn_launches);
+
 /* ---- layout conversion ----------------------------------------------------------------------
  * src element (b, r, k) lives at src[b*sb + r*sr + k*sk]; dst is the P32 image
  * [B, ceil(n_rows/32), 32*K] (rows >= n_rows are zero).  K must be a multiple of 8.

@@ -251,6 +251,18 @@ def main():
         out[f"Rgt_{N}"], out[f"tgt_{N}"] = R.astype(np.float32), t.astype(np.float32)
     np.savez_compressed(os.path.join(GOLD, "f8_weighted_procrustes.npz"), **out)
 
+    # ---------------- state_dict surface (key names + shapes) of the reference modules -------------
+    import json
+    ref_full = pdsc.PointDSC(in_dim=6, num_layers=12, num_channels=128)
+    keys = {"pointdsc": {k: list(v.shape) for k, v in ref_full.state_dict().items()},
+            "fusion_layer_pe": {k: list(v.shape) for k, v in fl.FusionLayer(
+                depth=0, dim=128, latent_dim=128, cross_heads=1, latent_heads=8, cross_dim_head=64,
+                latent_dim_head=64, pe=True).state_dict().items()},
+            "perceiver_io_128": {k: list(v.shape) for k, v in pio.PerceiverIO(
+                depth=0, dim=128, latent_dim=128, cross_heads=1, latent_heads=8, cross_dim_head=64,
+                latent_dim_head=64).state_dict().items()}}
+    json.dump(keys, open(os.path.join(GOLD, "state_dict_keys.json"), "w"), indent=0, sort_keys=True)
+
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)) // 1024, "KB")
 

@@ -128,13 +128,26 @@ def main():
     driver.close()
 
 
+def host_cpu_share() -> int:
+    """CPUs this process may really use: min(affinity mask, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(sd, batch, gpu_out, N, T, tau):
     """Time the CPU oracle (port of the reference's PyTorch CPU path) on a bounded sample: pair 0 of the same
     batch, test mode, B=1 as the reference runs it; 1 warm-up + 3 repetitions, median.  Also report parity."""
     from oracle import gmf_oracle as O
     import statistics
     one = {k: v[:1] for k, v in batch.items()}
-    cores = torch.get_num_threads()
+    cores = host_cpu_share()
+    torch.set_num_threads(cores)
     with torch.no_grad():
         ref = O.pointdsc_forward(sd, one, inlier_threshold=tau, nms_radius=tau, testing=True)
         ts = []

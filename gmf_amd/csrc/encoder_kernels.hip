@@ -347,6 +347,229 @@ k_scattn(const float* __restrict__ q_img, const float* __restrict__ k_img, const
 }
 
 // =========================================================================================
+// k_scattn_pipe: software-pipelined form of k_scattn (same math, same images, same epilogue).
+//   Inside one wave the QK^T MFMA chain of tile t+1 is issued together with the compat/softmax VALU
+//   work of tile t (independent instruction streams in one basic block), so the matrix pipe does not
+//   idle while the vector pipe builds c_ij and the exponentials.  K tiles therefore run one tile
+//   ahead of V / pts8 tiles in the LDS double buffers.  The j < N mask exists only in the last tile
+//   and the O rescale is skipped when no row's running max moved.
+//   FASTSQRT: v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf expansion.
+// =========================================================================================
+template <bool FASTSQRT>
+GMF_DEVINL float sqrt_sel(float x) {
+  if (FASTSQRT) return __builtin_amdgcn_sqrtf(x);
+  return sqrtf(x);
+}
+
+// compat * score for one element; lp points at this lane-half's first key of the tile (pts8 rows)
+template <bool FASTSQRT>
+GMF_DEVINL float compat_times(const float4* lp, int jl, const float (&si)[3], const float (&ti)[3], float inv_sig2, float sc) {
+  const float4 a = lp[2 * jl], b = lp[2 * jl + 1];
+  const float ax = si[0] - a.x, ay = si[1] - a.y, az = si[2] - a.z;
+  const float bx = ti[0] - b.x, by = ti[1] - b.y, bz = ti[2] - b.z;
+  const float ds = sqrt_sel<FASTSQRT>(fmaf(az, az, fmaf(ay, ay, ax * ax)));
+  const float dt = sqrt_sel<FASTSQRT>(fmaf(bz, bz, fmaf(by, by, bx * bx)));
+  const float d = ds - dt;
+  return fmaxf(1.0f - d * d * inv_sig2, 0.f) * sc;
+}
+
+template <bool FASTSQRT>
+__global__ void __launch_bounds__(256, 2)
+k_scattn_pipe(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
+              const float* __restrict__ pts8, const float* __restrict__ fus, const float* __restrict__ wst,
+              const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2) {
+  // LDS: K slots [2][4096] | V slots [2][4096] | pts slots [2][256]
+  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats + 512];
+  float* const ldsK = lds;
+  float* const ldsV = lds + 2 * kStageFloats;
+  float* const ldsP = lds + 4 * kStageFloats;
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t pbase = (size_t)pair * tiles;
+  const size_t toff = (pbase + tile) * (32 * C);
+
+  float qf[CF];
+  load_frag_p32<CF>(qf, q_img + toff, lane);
+  float si[3], ti[3];
+  {
+    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)tile * 32 + i) * 8);
+    const float4 a = pp[0], b = pp[1];
+    si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
+  }
+  const float* gk = k_img + pbase * (32 * C);
+  const float* gv = v_img + pbase * (32 * C);
+  const float* gp = pts8 + pbase * 32 * 8;
+
+  auto issueK = [&](int t) { dma_issue(gk + (size_t)t * kStageFloats, ldsK + (t & 1) * kStageFloats, 16, wave, kWavesPerWG, lane); };
+  auto issueV = [&](int t) {
+    dma_issue(gv + (size_t)t * kStageFloats, ldsV + (t & 1) * kStageFloats, 16, wave, kWavesPerWG, lane);
+    if (wave == (t & 3)) dma_piece_1k(gp + (size_t)t * 256, ldsP + (t & 1) * 256, lane);
+  };
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
+  float m_run = -INFINITY, l_half = 0.f;
+
+  issueK(0);
+  if (tiles > 1) issueK(1);
+  issueV(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16 s_cur = zero16();
+  mma_wx<CF>(s_cur, reinterpret_cast<const float4*>(ldsK) + lane, qf);
+
+  for (int t = 0; t < tiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();            // K_{t+1}, V_t, pts_t landed; every wave is done with K_t, V_{t-1}, pts_{t-1}
+    if (t + 2 < tiles) issueK(t + 2);
+    if (t + 1 < tiles) issueV(t + 1);
+    const float4* lp = reinterpret_cast<const float4*>(ldsP + (t & 1) * 256) + 8 * h;
+    const float4* lv = reinterpret_cast<const float4*>(ldsV + (t & 1) * kStageFloats) + lane;
+    float x[16];
+    float mx = -INFINITY;
+    f32x16 s_next = zero16();
+    if (t + 1 < tiles) {
+      // ---- phase 1: S_{t+1} MFMA chain  ||  compat + scores of tile t (no key mask: tile t is full) ----
+      // Hand-placed interleave: unit u = one MFMA + a quarter of one element's VALU work, fenced by
+      // sched_barrier(0).  Left to itself hipcc emits the whole dependent MFMA chain in one run (the wave
+      // then waits 64 cycles in front of every MFMA with its VALU work queued behind), and
+      // sched_group_barrier pipelines were not honoured for this block (ROCm 7.2).
+      const float4* lk = reinterpret_cast<const float4*>(ldsK + ((t + 1) & 1) * kStageFloats) + lane;
+      float4 kf = lk[0], pa = lp[0], pb = lp[1];
+      float4 kf_n = kf, pa_n = pa, pb_n = pb;
+      float d2s = 0.f, d2t = 0.f, cc = 0.f;
+#pragma unroll
+      for (int u = 0; u < 64; ++u) {
+        const int g = u >> 2, e = u & 3;
+        if (e == 0 && g < 15) {
+          const int jn = 8 * ((g + 1) >> 2) + ((g + 1) & 3);
+          kf_n = lk[(g + 1) * 64]; pa_n = lp[2 * jn]; pb_n = lp[2 * jn + 1];
+        }
+        s_next = mfma32(e == 0 ? kf.x : e == 1 ? kf.y : e == 2 ? kf.z : kf.w, qf[u], s_next);
+        if (e == 0) {
+          const float ax = si[0] - pa.x, ay = si[1] - pa.y, az = si[2] - pa.z;
+          d2s = fmaf(az, az, fmaf(ay, ay, ax * ax));
+        } else if (e == 1) {
+          const float bx = ti[0] - pb.x, by = ti[1] - pb.y, bz = ti[2] - pb.z;
+          d2t = fmaf(bz, bz, fmaf(by, by, bx * bx));
+        } else if (e == 2) {
+          const float d = sqrt_sel<FASTSQRT>(d2s) - sqrt_sel<FASTSQRT>(d2t);
+          cc = fmaxf(1.0f - d * d * inv_sig2, 0.f);
+        } else {
+          x[g] = cc * s_cur[g];
+          mx = fmaxf(mx, x[g]);
+          kf = kf_n; pa = pa_n; pb = pb_n;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      const int jbase = t * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int jl = 8 * (g >> 2) + (g & 3);
+        const float v = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, s_cur[g]);
+        x[g] = (jbase + jl < N) ? v : -INFINITY;
+        mx = fmaxf(mx, x[g]);
+      }
+    }
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const bool moved = m_new > m_run;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    if (__any(moved)) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
+    // ---- phase 2: O^T += V_t^T P^T, with the exponentials of the next 4 keys under each run of 16 MFMAs ----
+    float ls = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[e] = __builtin_amdgcn_exp2f(x[e] - m_new); ls += x[e]; }
+    {
+      float4 vv = lv[0], vv_n = vv;
+#pragma unroll
+      for (int u = 0; u < 64; ++u) {
+        const int q = u >> 4, db = (u >> 2) & 3, e = u & 3;
+        if (e == 0 && u < 60) {
+          const int un = u + 4, qn = un >> 4, dbn = (un >> 2) & 3;
+          vv_n = lv[(dbn * 4 + qn) * 64];
+        }
+        oacc[db] = mfma32(e == 0 ? vv.x : e == 1 ? vv.y : e == 2 ? vv.z : vv.w, x[4 * q + e], oacc[db]);
+        if (db == 0 && q < 3) {
+          const int r = 4 * (q + 1) + e;
+          x[r] = __builtin_amdgcn_exp2f(x[r] - m_new);
+          ls += x[r];
+        }
+        if (e == 3) vv = vv_n;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    l_half = fmaf(l_half, alpha, ls);
+    s_cur = s_next;
+  }
+
+  // ---- epilogue: normalise, fc_message, add the Fusion-2 branch (identical to k_scattn) ----
+  float o[CF];
+  {
+    const float inv = 1.0f / xhalf_sum(l_half);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
+  }
+  __syncthreads();
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 5);
+  ss.prime();
+  float m1[DHF], m2[DHF];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_wx<CF>(acc, lw, o);
+    float b[16];
+    load_vec_block(b, vecs, mb, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+  }
+  {
+    const float4* lw = ss.acquire();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      f32x16 acc = zero16();
+      mma_wx<DHF>(acc, lw + mb * (32 * DH / 4), m1);
+      float b[16];
+      load_vec_block(b, vecs + 64, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const float4* lw = ss.acquire();
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int mb = 2 * st + hb;
+      f32x16 acc = zero16();
+      mma_wx<DHF>(acc, lw + hb * (32 * DH / 4), m2);
+      float b[16], fz[16], t[16];
+      load_vec_block(b, vecs + 128, mb, h);
+      load_block_p32(fz, fus + toff, mb, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r] + fz[r];
+      if (active) store_block_p32(out + toff, mb, t, lane);
+    }
+  }
+}
+
+// =========================================================================================
 // k_ctx_prep: context side of a FusionLayer, once per (weight set, pair, token tile):
 //   ctx' = LCPE(ctx) [PE] ; cn = LayerNorm_ctx(ctx') ; Kc = cn Wk^T ; Vc = cn Wv^T
 //   output per tile: 4096 floats = Kc as P32 (K=64) | Vc as T image (D=64)
@@ -647,6 +870,46 @@ k_head(const float* __restrict__ feat_img, const float* __restrict__ wst, const 
 }
 
 // =========================================================================================
+// k_seed_dist: feature-space distances of the seed rows to every correspondence,
+//   dist[seed][j] = 2 - 2 <f_seed, f_j>   (models/common.py:64-66 restricted to the rows PointDSC.py:329 keeps).
+//   One wave = 32 seeds (fragment gathered from the P32 image of the unit features), key tiles streamed
+//   through LDS; D = mfma(A = seed fragment, B = key tile) puts the key on the lane, so every store is a
+//   128-byte run of one seed's row.  grid (ceil(S/128), B); dist [B, S, N].
+// =========================================================================================
+__global__ void __launch_bounds__(256, 2)
+k_seed_dist(const float* __restrict__ featn_img, const int* __restrict__ seeds, float* __restrict__ dist,
+            int N, int tiles, int S) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int seed_base = (blockIdx.x * kWavesPerWG + wave) * 32;
+  const float* pair_img = featn_img + (size_t)pair * tiles * (32 * C);
+  const int my = seed_base + i;
+  const int row = (my < S) ? seeds[(size_t)pair * S + my] : 0;
+  float sf[CF];
+  load_row_frag_p32<CF>(sf, pair_img, row, N, h);
+
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, pair_img, tiles);
+  ss.prime();
+  float* drow = dist + ((size_t)pair * S) * N;
+  for (int t = 0; t < tiles; ++t) {
+    const float4* lk = ss.acquire();
+    f32x16 acc = zero16();
+    mma_xw<CF>(acc, lk, sf);
+    const int j = t * 32 + i;
+    if (j < N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int sd = seed_base + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (sd < S) drow[(size_t)sd * N + j] = 2.0f - 2.0f * acc[r];
+      }
+    }
+  }
+}
+
+// =========================================================================================
 // layout conversion kernels (the drop-in boundary hands over row-major / channel-major tensors)
 // =========================================================================================
 // strided [B, n_rows, K] (element (b,r,k) at b*sb + r*sr + k*sk) -> P32 image [B, tiles, 32*K]; rows >= n_rows are 0
@@ -716,8 +979,13 @@ __global__ void k_pack_pts8(const float* __restrict__ src, const float* __restri
 // host-side launchers (C++ linkage inside the library; the C ABI in gmf_api.cpp calls these)
 // -----------------------------------------------------------------------------------------
 #include "launchers.hpp"
+#include <cstdlib>
 
 namespace gmf {
+
+static int g_scattn_variant = [] { const char* e = getenv("GMF_SCATTN"); return e ? atoi(e) : 1; }();
+void set_scattn_variant(int v) { g_scattn_variant = v; }
+int get_scattn_variant() { return g_scattn_variant; }
 
 static inline dim3 tile_grid(int tiles, int B, int sets = 1) { return dim3((tiles + kWavesPerWG - 1) / kWavesPerWG, B, sets); }
 
@@ -732,8 +1000,13 @@ hipError_t launch_front(int mode, const float* in, const float* wst, const float
 hipError_t launch_scattn(const float* q, const float* k, const float* v, const float* pts8, const float* fus,
                          const float* wst, const float* vecs, float* out, int B, int N, int tiles, float sigma_d,
                          hipStream_t s) {
-  hipLaunchKernelGGL(k_scattn<false>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles,
-                     1.0f / (sigma_d * sigma_d));
+  // GMF_SCATTN selects the kernel form for A/B measurements: 0 = two-phase reference form,
+  // 1 = software-pipelined (default), 2 = software-pipelined with v_sqrt_f32.
+  const int variant = g_scattn_variant;
+  const float inv = 1.0f / (sigma_d * sigma_d);
+  if (variant == 0) hipLaunchKernelGGL(k_scattn<false>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
+  else if (variant == 2) hipLaunchKernelGGL(k_scattn_pipe<true>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
+  else hipLaunchKernelGGL(k_scattn_pipe<false>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
   return hipGetLastError();
 }
 
@@ -765,6 +1038,12 @@ hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs
 hipError_t launch_head(const float* feat_img, const float* wst, const float* vecs, float* logits, float* feat_n,
                        float* feat_rm, int B, int N, int tiles, hipStream_t s) {
   hipLaunchKernelGGL(k_head, tile_grid(tiles, B), dim3(256), 0, s, feat_img, wst, vecs, logits, feat_n, feat_rm, N, tiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_seed_dist(const float* featn_img, const int* seeds, float* dist, int B, int N, int S, hipStream_t s) {
+  const int tiles = (N + 31) / 32;
+  hipLaunchKernelGGL(k_seed_dist, dim3((S + 127) / 128, B), dim3(256), 0, s, featn_img, seeds, dist, N, tiles, S);
   return hipGetLastError();
 }
 

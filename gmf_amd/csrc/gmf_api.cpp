@@ -110,6 +110,16 @@ int gmf_create(int device, gmf_handle** out) {
   return GMF_OK;
 }
 
+int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
+  GMF_REQUIRE(h && name, GMF_ERR_BAD_ARG, "set_tuning: null pointer");
+  if (std::strcmp(name, "scattn_variant") == 0) {
+    GMF_REQUIRE(value >= 0 && value <= 2, GMF_ERR_BAD_ARG, "set_tuning: scattn_variant must be 0, 1 or 2");
+    gmf::set_scattn_variant(value);
+    return GMF_OK;
+  }
+  return fail(h, GMF_ERR_BAD_ARG, std::string("gmf: set_tuning: unknown knob ") + name);
+}
+
 int gmf_profile_enable(gmf_handle* h, int on) {
   GMF_REQUIRE(h, GMF_ERR_BAD_ARG, "profile_enable: null handle");
   h->profile = (on != 0);
@@ -439,8 +449,11 @@ int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, 
   const size_t BS = (size_t)B * Sn;
   const size_t need = arena_need((size_t)B * N, 4) + arena_need(BS, 4) + arena_need(BS * k, 4) +
                       arena_need(BS * iters * k, 4) + arena_need(BS * iters, 1) + arena_need(BS * 16, 4) +
-                      arena_need(BS, 4) + arena_need(BS, 4) + arena_need(B, 4);
+                      arena_need(BS, 4) + arena_need(BS, 4) + arena_need(B, 4) +
+                      arena_need((size_t)B * tiles_of(N) * kTileFloats, 4) + arena_need(BS * N, 4);
   if (int rc = arena_reserve(h, need)) return rc;
+  float* fimg = arena_take<float>(h, (size_t)B * tiles_of(N) * kTileFloats);
+  float* dmat = arena_take<float>(h, BS * N);
   float* keys = arena_take<float>(h, (size_t)B * N);
   int* seeds = arena_take<int>(h, BS);
   int* knn = arena_take<int>(h, BS * k);
@@ -467,7 +480,10 @@ int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, 
   } else if (seeds_out) {
     GMF_HIP(hipMemcpyAsync(seeds_out, seeds_in, BS * sizeof(int), hipMemcpyDeviceToDevice, st));
   }
-  GMF_HIP(gmf::launch_knn_seeds(feat_n, seeds_use, knn, B, N, Sn, k, st));
+  // feature-space distances of the seed rows by MFMA (k_seed_dist), then per-seed top-(k+1) selection
+  GMF_HIP(gmf::launch_pack_p32(feat_n, fimg, B, N, kC, (long)N * kC, kC, 1, st));
+  GMF_HIP(gmf::launch_seed_dist(fimg, seeds_use, dmat, B, N, Sn, st));
+  GMF_HIP(gmf::launch_knn_seeds(feat_n, seeds_use, dmat, knn, B, N, Sn, k, st));
   GMF_HIP(gmf::launch_seed_power(feat_n, src_keypts, tgt_keypts, knn, snaps, conv, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));
   GMF_HIP(gmf::launch_seed_kabsch(src_keypts, tgt_keypts, knn, snaps, conv, sT, B, N, Sn, k, iters, st));
   GMF_HIP(gmf::launch_score_hyp(src_keypts, tgt_keypts, sT, counts, B, N, Sn, p->inlier_threshold, st));
@@ -482,7 +498,7 @@ int gmf_knn_rows(gmf_handle* h, const float* feat_n, const int* rows, int B, int
   GMF_REQUIRE(B > 0 && N > 1 && Sn > 0 && k > 0 && k <= N - 1, GMF_ERR_UNSUPPORTED_SHAPE, "knn_rows: need 0 < k <= N-1");
   GMF_REQUIRE((size_t)N * 4 <= 150 * 1024, GMF_ERR_UNSUPPORTED_SHAPE, "knn_rows: N too large for the in-LDS kNN (max 38400)");
   SetDevice sd(h);
-  GMF_HIP(gmf::launch_knn_seeds(feat_n, rows, knn_out, B, N, Sn, k, S(stream)));
+  GMF_HIP(gmf::launch_knn_seeds(feat_n, rows, nullptr, knn_out, B, N, Sn, k, S(stream)));
   return GMF_OK;
 }
 

@@ -4,6 +4,8 @@
 
 namespace gmf {
 
+void set_scattn_variant(int v);
+int get_scattn_variant();
 hipError_t launch_front(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
                         float* v, int B, int N, int tiles, hipStream_t s);
 hipError_t launch_scattn(const float* q, const float* k, const float* v, const float* pts8, const float* fus,
@@ -18,6 +20,7 @@ hipError_t launch_fusion_attn(bool pe, const float* x, const float* ctx_img, con
 hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
 hipError_t launch_head(const float* feat_img, const float* wst, const float* vecs, float* logits, float* feat_n,
                        float* feat_rm, int B, int N, int tiles, hipStream_t s);
+hipError_t launch_seed_dist(const float* featn_img, const int* seeds, float* dist, int B, int N, int S, hipStream_t s);
 hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s);
 hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s);
 hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s);

@@ -218,14 +218,18 @@ k_sort_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, in
 // grid (S, B), block 256, dynamic LDS = N*4 bytes
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_knn_seeds(const float* __restrict__ feat_n, const int* __restrict__ seeds, int* __restrict__ knn_idx,
-            int N, int S, int k) {
+k_knn_seeds(const float* __restrict__ feat_n, const int* __restrict__ seeds, const float* __restrict__ dist_in,
+            int* __restrict__ knn_idx, int N, int S, int k) {
   extern __shared__ float dist[];
   __shared__ float fs[128];
   __shared__ float red_v[4];
   __shared__ int red_i[4];
   const int pair = blockIdx.y, s = blockIdx.x;
   const float* fb = feat_n + (size_t)pair * N * 128;
+  if (dist_in) {        // distances precomputed by k_seed_dist (MFMA): just stage the row in LDS
+    const float* dr = dist_in + ((size_t)pair * S + s) * N;
+    for (int j = threadIdx.x; j < N; j += 256) dist[j] = dr[j];
+  } else {
   const int seed = seeds[(size_t)pair * S + s];
   if (threadIdx.x < 128) fs[threadIdx.x] = fb[(size_t)seed * 128 + threadIdx.x];
   __syncthreads();
@@ -239,6 +243,7 @@ k_knn_seeds(const float* __restrict__ feat_n, const int* __restrict__ seeds, int
       acc = fmaf(v.z, fs[4 * c + 2], acc); acc = fmaf(v.w, fs[4 * c + 3], acc);
     }
     dist[j] = 2.0f - 2.0f * acc;
+  }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -278,10 +283,11 @@ __global__ void __launch_bounds__(64)
 k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, const float* __restrict__ tgt,
              const int* __restrict__ knn_idx, float* __restrict__ snaps, unsigned char* __restrict__ conv,
              int N, int S, int k, int iters, float inv_sigma2, float inv_sigmad2) {
-  __shared__ float F[kKMax * 129];
-  __shared__ float Mx[kKMax * (kKMax + 1)];
-  __shared__ float P[kKMax * 8];
-  __shared__ float vec[kKMax];
+  extern __shared__ float sp_smem[];            // F[k][129] | Mx[k][kKMax+1] | P[kKMax*8] | vec[kKMax]
+  float* F = sp_smem;
+  float* Mx = F + k * 129;
+  float* P = Mx + k * (kKMax + 1);
+  float* vec = P + kKMax * 8;
   const int pair = blockIdx.y, s = blockIdx.x, a = threadIdx.x;
   const int* nb = knn_idx + ((size_t)pair * S + s) * k;
   const float* fb = feat_n + (size_t)pair * N * 128;
@@ -716,7 +722,8 @@ hipError_t launch_sort_topk(const float* keys, int* out_idx, int B, int N, int S
   return hipGetLastError();
 }
 
-hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, int* knn_idx, int B, int N, int S, int k, hipStream_t s) {
+hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* dist_in, int* knn_idx, int B, int N, int S,
+                            int k, hipStream_t s) {
   if ((size_t)N * 4 > 150 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
@@ -724,7 +731,7 @@ hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, int* knn_idx,
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_knn_seeds, dim3(S, B), dim3(256), (size_t)N * 4, s, feat_n, seeds, knn_idx, N, S, k);
+  hipLaunchKernelGGL(k_knn_seeds, dim3(S, B), dim3(256), (size_t)N * 4, s, feat_n, seeds, dist_in, knn_idx, N, S, k);
   return hipGetLastError();
 }
 
@@ -732,7 +739,8 @@ hipError_t launch_seed_power(const float* feat_n, const float* src, const float*
                              unsigned char* conv, int B, int N, int S, int k, int iters, float sigma, float sigma_d,
                              hipStream_t s) {
   if (k > kKMax) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_seed_power, dim3(S, B), dim3(64), 0, s, feat_n, src, tgt, knn_idx, snaps, conv, N, S, k, iters,
+  const size_t sp_lds = ((size_t)k * 129 + (size_t)k * (kKMax + 1) + kKMax * 8 + kKMax) * sizeof(float);
+  hipLaunchKernelGGL(k_seed_power, dim3(S, B), dim3(64), sp_lds, s, feat_n, src, tgt, knn_idx, snaps, conv, N, S, k, iters,
                      1.0f / (sigma * sigma), 1.0f / (sigma_d * sigma_d));
   return hipGetLastError();
 }

@@ -49,6 +49,11 @@ const char* gmf_last_error_string(gmf_handle* h);
 /* Bytes of library-owned device workspace currently held by the handle. */
 long long gmf_workspace_bytes(gmf_handle* h);
 
+/* Process-wide tuning knobs for A/B measurements (results are identical up to rounding):
+ *   "scattn_variant": 0 = two-phase attention loop, 1 = software-pipelined (default),
+ *                     2 = software-pipelined with v_sqrt_f32 (1 ulp) in the compatibility term. */
+int gmf_set_tuning(gmf_handle* h, const char* name, int value);
+
 /* In-situ timing of the dominant kernel (the spatial-consistency attention): while enabled, every
  * k_scattn launch made through gmf_encoder_forward / gmf_nonlocal_block_forward is bracketed by HIP events
  * recorded on the caller's stream.  gmf_profile_read synchronises those events (host sync - call it outside

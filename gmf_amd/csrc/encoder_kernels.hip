@@ -58,6 +58,21 @@ GMF_DEVINL void store_block_timg(float* __restrict__ tile_base, int db, const f3
     p[q * 64] = make_float4(a[4 * q + 0] + bias, a[4 * q + 1] + bias, a[4 * q + 2] + bias, a[4 * q + 3] + bias);
 }
 
+// bf16x3 image of a 32 x 128 tile: 16-byte unit index ((plane*8 + slot)*64 + lane); slot = MFMA k-step.
+// Y^T block mb (rows on lanes) fills slots 2mb, 2mb+1; a T-layout block db fills slots 2db, 2db+1.
+GMF_DEVINL void store_block_b3(float* __restrict__ tile_base, int blk, const float (&t)[16], int lane) {
+  bf16x8* base = reinterpret_cast<bf16x8*>(tile_base);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    bf16x8 hi, mi, lo;
+    split8(&t[8 * half], hi, mi, lo);
+    const int slot = 2 * blk + half;
+    base[(0 * 8 + slot) * 64 + lane] = hi;
+    base[(1 * 8 + slot) * 64 + lane] = mi;
+    base[(2 * 8 + slot) * 64 + lane] = lo;
+  }
+}
+
 // LCPE (fusion_layer.py:118-128): y[row] = x[row] + b + w0*x[row-1] + w1*x[row] + w2*x[row+1],
 // zero padding outside [0, n_rows).  taps = w0[C] | w1[C] | w2[C] | b[C].
 GMF_DEVINL void lcpe_frag(float (&y)[CF], const float* __restrict__ pair_base, int row, int n_rows,
@@ -90,7 +105,8 @@ GMF_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.707106
 // =========================================================================================
 // MODE 0: in = feat image, PointCN applied.  MODE 1: in = corr_pos, layer0 then PointCN.
 // MODE 2: in = feat image used as-is (stand-alone NonLocalBlock whose caller already applied PointCN).
-template <int MODE>
+// B3: Q', K, V are written as bf16x3 plane images (24 KiB per tile) for k_scattn_b3.
+template <int MODE, bool B3>
 __global__ void __launch_bounds__(256, 2)
 k_front(const float* __restrict__ in, const float* __restrict__ wst, const float* __restrict__ vecs,
         float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out,
@@ -102,6 +118,7 @@ k_front(const float* __restrict__ in, const float* __restrict__ wst, const float
   const bool active = tile_raw < tiles;
   const int tile = active ? tile_raw : tiles - 1;
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+  const size_t toff3 = ((size_t)pair * tiles + tile) * (size_t)(B3 ? kB3TileFloats : 32 * C);
 
   constexpr bool FIRST = (MODE == 1);
   StageStream ss;
@@ -154,7 +171,7 @@ k_front(const float* __restrict__ in, const float* __restrict__ wst, const float
 
 #pragma unroll
   for (int which = 0; which < 2; ++which) {   // Q', K
-    float* dst = (which == 0 ? q_out : k_out) + toff;
+    float* dst = (which == 0 ? q_out : k_out) + toff3;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       const float4* lw = ss.acquire();
@@ -164,7 +181,10 @@ k_front(const float* __restrict__ in, const float* __restrict__ wst, const float
       load_vec_block(b, vecs + (1 + which) * C, mb, h);
 #pragma unroll
       for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r];
-      if (active) store_block_p32(dst, mb, t, lane);
+      if (active) {
+        if (B3) store_block_b3(dst, mb, t, lane);
+        else store_block_p32(dst, mb, t, lane);
+      }
     }
   }
 #pragma unroll
@@ -173,7 +193,16 @@ k_front(const float* __restrict__ in, const float* __restrict__ wst, const float
     f32x16 acc = zero16();
     mma_xw<CF>(acc, lw, f);
     const float bv = vecs[3 * C + 32 * db + i];
-    if (active) store_block_timg(v_out + toff, db, acc, bv, lane);
+    if (active) {
+      if (B3) {
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = acc[r] + bv;
+        store_block_b3(v_out + toff3, db, t, lane);
+      } else {
+        store_block_timg(v_out + toff3, db, acc, bv, lane);
+      }
+    }
   }
 }
 
@@ -527,6 +556,179 @@ k_scattn_pipe(const float* __restrict__ q_img, const float* __restrict__ k_img, 
   __syncthreads();
   StageStream ss;
   ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 5);
+  ss.prime();
+  float m1[DHF], m2[DHF];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_wx<CF>(acc, lw, o);
+    float b[16];
+    load_vec_block(b, vecs, mb, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+  }
+  {
+    const float4* lw = ss.acquire();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      f32x16 acc = zero16();
+      mma_wx<DHF>(acc, lw + mb * (32 * DH / 4), m1);
+      float b[16];
+      load_vec_block(b, vecs + 64, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const float4* lw = ss.acquire();
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int mb = 2 * st + hb;
+      f32x16 acc = zero16();
+      mma_wx<DHF>(acc, lw + hb * (32 * DH / 4), m2);
+      float b[16], fz[16], t[16];
+      load_vec_block(b, vecs + 128, mb, h);
+      load_block_p32(fz, fus + toff, mb, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r] + fz[r];
+      if (active) store_block_p32(out + toff, mb, t, lane);
+    }
+  }
+}
+
+// =========================================================================================
+// k_scattn_b3: the attention loop on the bf16 MFMA with split-bf16 operands (fp32-equivalent accuracy).
+//   Same algorithm and epilogue as k_scattn; Q', K, V arrive as bf16x3 plane images from k_front<.,true>.
+//   8 waves per workgroup (256 queries), one workgroup per CU (100 KB LDS: two buffers of K|V|pts8), two
+//   waves per SIMD: one wave's MFMA runs under the other's compat/softmax VALU work.
+//   Per 32x32 tile and wave: 48 + 48 MFMAs of 32 cycles (vs 128 of 64 in fp32).
+// =========================================================================================
+constexpr int kB3Waves = 8;
+constexpr int kB3BufFloats = 2 * kB3TileFloats + 256;
+
+template <bool FASTSQRT>
+__global__ void __launch_bounds__(512, 2)
+k_scattn_b3(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
+            const float* __restrict__ pts8, const float* __restrict__ fus, const float* __restrict__ wst,
+            const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kB3BufFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kB3Waves + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t pbase = (size_t)pair * tiles;
+  const size_t toff = (pbase + tile) * (32 * C);
+
+  bf16x8 qh[8], qm[8], ql[8];
+  {
+    const bf16x8* qp = reinterpret_cast<const bf16x8*>(q_img + (pbase + tile) * (size_t)kB3TileFloats) + lane;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { qh[s] = qp[(0 * 8 + s) * 64]; qm[s] = qp[(1 * 8 + s) * 64]; ql[s] = qp[(2 * 8 + s) * 64]; }
+  }
+  float si[3], ti[3];
+  {
+    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)tile * 32 + i) * 8);
+    const float4 a = pp[0], b = pp[1];
+    si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
+  }
+  const float* gk = k_img + pbase * (size_t)kB3TileFloats;
+  const float* gv = v_img + pbase * (size_t)kB3TileFloats;
+  const float* gp = pts8 + pbase * 32 * 8;
+
+  auto issue_tile = [&](int t) {
+    float* buf = lds + (t & 1) * kB3BufFloats;
+    dma_issue(gk + (size_t)t * kB3TileFloats, buf, 24, wave, kB3Waves, lane);
+    dma_issue(gv + (size_t)t * kB3TileFloats, buf + kB3TileFloats, 24, wave, kB3Waves, lane);
+    if (wave == (t & 7)) dma_piece_1k(gp + (size_t)t * 256, buf + 2 * kB3TileFloats, lane);
+  };
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
+  float m_run = -INFINITY, l_half = 0.f;
+
+  issue_tile(0);
+  for (int t = 0; t < tiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < tiles) issue_tile(t + 1);
+    const float* buf = lds + (t & 1) * kB3BufFloats;
+    const bf16x8* lk = reinterpret_cast<const bf16x8*>(buf) + lane;
+    const bf16x8* lv = reinterpret_cast<const bf16x8*>(buf + kB3TileFloats) + lane;
+    const float4* lp = reinterpret_cast<const float4*>(buf + 2 * kB3TileFloats) + 8 * h;
+
+    // ---- S^T = K Q'^T : 8 k-steps x 6 partial products ----
+    f32x16 sacc = zero16();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const bf16x8 kh = lk[(0 * 8 + s) * 64], km = lk[(1 * 8 + s) * 64], kl = lk[(2 * 8 + s) * 64];
+      mma6(sacc, kh, km, kl, qh[s], qm[s], ql[s]);
+    }
+    // ---- compat, scores, online softmax ----
+    float x[16];
+    float mx = -INFINITY;
+    if (t + 1 < tiles) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jl = 8 * (r >> 2) + (r & 3);
+        x[r] = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
+        mx = fmaxf(mx, x[r]);
+      }
+    } else {
+      const int jbase = t * 32 + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jl = 8 * (r >> 2) + (r & 3);
+        const float v = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
+        x[r] = (jbase + jl < N) ? v : -INFINITY;
+        mx = fmaxf(mx, x[r]);
+      }
+    }
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const bool moved = m_new > m_run;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_new); ls += x[r]; }
+    l_half = fmaf(l_half, alpha, ls);
+    if (__any(moved)) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
+    // ---- O^T += V^T P^T : P planes straight from the accumulator registers ----
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 ph, pm, pl;
+      split8(&x[8 * s2], ph, pm, pl);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int slot = 2 * db + s2;
+        const bf16x8 vh = lv[(0 * 8 + slot) * 64], vm = lv[(1 * 8 + slot) * 64], vl = lv[(2 * 8 + slot) * 64];
+        mma6(oacc[db], vh, vm, vl, ph, pm, pl);
+      }
+    }
+  }
+
+  // ---- epilogue: normalise, fc_message (fp32 MFMA), add the Fusion-2 branch ----
+  float o[CF];
+  {
+    const float inv = 1.0f / xhalf_sum(l_half);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
+  }
+  __syncthreads();
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, kB3Waves, lane, wst, 5);
   ss.prime();
   float m1[DHF], m2[DHF];
 #pragma unroll
@@ -983,7 +1185,9 @@ __global__ void k_pack_pts8(const float* __restrict__ src, const float* __restri
 
 namespace gmf {
 
-static int g_scattn_variant = [] { const char* e = getenv("GMF_SCATTN"); return e ? atoi(e) : 1; }();
+static int g_scattn_variant = [] { const char* e = getenv("GMF_SCATTN"); return e ? atoi(e) : 3; }();
+static bool g_force_fp32_qkv = false;   // set while the dense-compat (drop-in NonLocalBlock) path runs
+void set_force_fp32_qkv(bool v) { g_force_fp32_qkv = v; }
 void set_scattn_variant(int v) { g_scattn_variant = v; }
 int get_scattn_variant() { return g_scattn_variant; }
 
@@ -991,19 +1195,33 @@ static inline dim3 tile_grid(int tiles, int B, int sets = 1) { return dim3((tile
 
 hipError_t launch_front(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
                         float* v, int B, int N, int tiles, hipStream_t s) {
-  if (mode == 1) hipLaunchKernelGGL(k_front<1>, tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
-  else if (mode == 2) hipLaunchKernelGGL(k_front<2>, tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
-  else hipLaunchKernelGGL(k_front<0>, tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  const bool b3 = (g_scattn_variant >= 3) && !g_force_fp32_qkv;
+  if (b3) {
+    if (mode == 1) hipLaunchKernelGGL((k_front<1, true>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+    else if (mode == 2) hipLaunchKernelGGL((k_front<2, true>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+    else hipLaunchKernelGGL((k_front<0, true>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  } else {
+    if (mode == 1) hipLaunchKernelGGL((k_front<1, false>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+    else if (mode == 2) hipLaunchKernelGGL((k_front<2, false>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+    else hipLaunchKernelGGL((k_front<0, false>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_scattn(const float* q, const float* k, const float* v, const float* pts8, const float* fus,
                          const float* wst, const float* vecs, float* out, int B, int N, int tiles, float sigma_d,
                          hipStream_t s) {
-  // GMF_SCATTN selects the kernel form for A/B measurements: 0 = two-phase reference form,
-  // 1 = software-pipelined (default), 2 = software-pipelined with v_sqrt_f32.
+  // GMF_SCATTN / gmf_set_tuning("scattn_variant") selects the kernel form for A/B measurements:
+  // 0 = fp32 MFMA, two-phase loop; 1 = fp32 MFMA, software-pipelined; 2 = 1 with v_sqrt_f32;
+  // 3 = split-bf16 MFMA (default); 4 = 3 with v_sqrt_f32.
   const int variant = g_scattn_variant;
   const float inv = 1.0f / (sigma_d * sigma_d);
+  if (variant >= 3) {
+    const dim3 grid((tiles + kB3Waves - 1) / kB3Waves, B);
+    if (variant == 4) hipLaunchKernelGGL(k_scattn_b3<true>, grid, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
+    else hipLaunchKernelGGL(k_scattn_b3<false>, grid, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
+    return hipGetLastError();
+  }
   if (variant == 0) hipLaunchKernelGGL(k_scattn<false>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
   else if (variant == 2) hipLaunchKernelGGL(k_scattn_pipe<true>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
   else hipLaunchKernelGGL(k_scattn_pipe<false>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);

@@ -113,7 +113,7 @@ int gmf_create(int device, gmf_handle** out) {
 int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
   GMF_REQUIRE(h && name, GMF_ERR_BAD_ARG, "set_tuning: null pointer");
   if (std::strcmp(name, "scattn_variant") == 0) {
-    GMF_REQUIRE(value >= 0 && value <= 2, GMF_ERR_BAD_ARG, "set_tuning: scattn_variant must be 0, 1 or 2");
+    GMF_REQUIRE(value >= 0 && value <= 4, GMF_ERR_BAD_ARG, "set_tuning: scattn_variant must be 0..4");
     gmf::set_scattn_variant(value);
     return GMF_OK;
   }
@@ -305,15 +305,16 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   const int tiles = tiles_of(N), tt = tiles_of(T);
   const size_t act = (size_t)B * tiles * kTileFloats;
   const size_t tok = (size_t)B * tt * kTileFloats;
-  const size_t need = 8 * arena_need(act, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) + 5 * arena_need(tok, 4) +
-                      arena_need((size_t)(L > 0 ? L : 1) * tok, 4);
+  const size_t act3 = act + act / 2;   // Q', K, V may be bf16x3 plane images (24 KiB per tile)
+  const size_t need = 5 * arena_need(act, 4) + 3 * arena_need(act3, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +
+                      5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4);
   if (int rc = arena_reserve(h, need)) return rc;
   float* featA = arena_take<float>(h, act);
   float* featB = arena_take<float>(h, act);
   float* f = arena_take<float>(h, act);
-  float* q = arena_take<float>(h, act);
-  float* k = arena_take<float>(h, act);
-  float* v = arena_take<float>(h, act);
+  float* q = arena_take<float>(h, act3);
+  float* k = arena_take<float>(h, act3);
+  float* v = arena_take<float>(h, act3);
   float* x1 = arena_take<float>(h, act);
   float* x2 = arena_take<float>(h, act);
   float* pts8 = arena_take<float>(h, (size_t)B * tiles * 32 * 8);
@@ -368,11 +369,13 @@ int gmf_nonlocal_block_forward(gmf_handle* h, const gmf_encoder_weights* w, int 
   const int tiles = tiles_of(N), tt = tiles_of(T);
   const size_t act = (size_t)B * tiles * kTileFloats;
   const size_t tok = (size_t)B * tt * kTileFloats;
-  if (int rc = arena_reserve(h, 6 * arena_need(act, 4) + arena_need(tok, 4))) return rc;
+  const size_t act3 = act + act / 2;
+  if (int rc = arena_reserve(h, 3 * arena_need(act, 4) + 3 * arena_need(act3, 4) + arena_need(tok, 4))) return rc;
   float* f = arena_take<float>(h, act);
-  float* q = arena_take<float>(h, act);
-  float* k = arena_take<float>(h, act);
-  float* v = arena_take<float>(h, act);
+  float* q = arena_take<float>(h, act3);
+  float* k = arena_take<float>(h, act3);
+  float* v = arena_take<float>(h, act3);
+  gmf::set_force_fp32_qkv(attention != nullptr);   // the dense-compat kernel consumes fp32 images
   float* x1 = arena_take<float>(h, act);
   float* x2 = arena_take<float>(h, act);
   float* ctx = arena_take<float>(h, tok);
@@ -381,7 +384,9 @@ int gmf_nonlocal_block_forward(gmf_handle* h, const gmf_encoder_weights* w, int 
                             w->front_vec + (size_t)layer * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
   GMF_HIP(gmf::launch_ctx_prep(true, image_feat_img, w->ctx_wst + (size_t)layer * w->ctx_wst_stride,
                                w->ctx_vec + (size_t)layer * w->ctx_vec_stride, ctx, B, T, tt, 1, 0, 0, st));
-  return run_block_tail(h, w, layer, f, q, k, v, pts8, ctx, x1, x2, out_img, B, N, T, st, attention);
+  const int rc_tail = run_block_tail(h, w, layer, f, q, k, v, pts8, ctx, x1, x2, out_img, B, N, T, st, attention);
+  gmf::set_force_fp32_qkv(false);
+  return rc_tail;
 }
 
 int gmf_fusion_layer_forward(gmf_handle* h, int pe, const float* ctx_wst, const float* ctx_vec, const float* attn_wst,

@@ -43,6 +43,48 @@ GMF_DEVINL f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- split-bf16 ("bf16x3") arithmetic -------------------------------------------------------------
+// An fp32 value is carried as three bf16 planes x = xh + xm + xl (exact to ~2^-25 relative); a product is
+// evaluated as the six partial products of weight >= 2^-16 (hh, hm, mh, hl, lh, mm) on the bf16 MFMA with
+// fp32 accumulation.  bf16 x bf16 products are exact in fp32, so the result carries the same ~1e-7 relative
+// error per term as an fp32 FMA chain, at 6/16 of the fp32-MFMA cycles - and, unlike v_mfma_f32_32x32x2_f32,
+// the bf16 MFMA co-executes with VALU work on gfx950.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+GMF_DEVINL f32x16 mfma_b16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// v[0..7] -> planes (round-to-nearest-even conversions; v_cvt_pk_bf16_f32 + shifts + v_pk_add_f32)
+GMF_DEVINL void split8(const float* v, bf16x8& hi, bf16x8& mi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const f32x2 x = {v[j], v[j + 1]};
+    const bf16x2 hh = __builtin_convertvector(x, bf16x2);
+    const f32x2 r1 = x - __builtin_convertvector(hh, f32x2);
+    const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
+    const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+    hi[j] = hh[0]; hi[j + 1] = hh[1];
+    mi[j] = mm[0]; mi[j + 1] = mm[1];
+    lo[j] = ll[0]; lo[j + 1] = ll[1];
+  }
+}
+
+// acc += A * B with A = (ah, am, al), B = (bh, bm, bl); small terms first
+GMF_DEVINL void mma6(f32x16& acc, bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl) {
+  acc = mfma_b16(al, bh, acc);
+  acc = mfma_b16(ah, bl, acc);
+  acc = mfma_b16(am, bm, acc);
+  acc = mfma_b16(am, bh, acc);
+  acc = mfma_b16(ah, bm, acc);
+  acc = mfma_b16(ah, bh, acc);
+}
+
+constexpr int kB3TileFloats = 3 * 8 * 64 * 4;   // one 32 x 128 tile as three bf16 planes = 24 KiB
+
 GMF_DEVINL f32x16 zero16() {
   f32x16 z;
 #pragma unroll

@@ -50,8 +50,11 @@ const char* gmf_last_error_string(gmf_handle* h);
 long long gmf_workspace_bytes(gmf_handle* h);
 
 /* Process-wide tuning knobs for A/B measurements (results are identical up to rounding):
- *   "scattn_variant": 0 = two-phase attention loop, 1 = software-pipelined (default),
- *                     2 = software-pipelined with v_sqrt_f32 (1 ulp) in the compatibility term. */
+ *   "scattn_variant": 0 = fp32-MFMA attention, two-phase loop; 1 = fp32 MFMA, software-pipelined;
+ *                     2 = 1 with v_sqrt_f32 (1 ulp) in the compatibility term;
+ *                     3 = split-bf16 MFMA, fp32-equivalent accuracy (default); 4 = 3 with v_sqrt_f32.
+ *   With variants >= 3 gmf_front_forward writes Q', K, V as bf16x3 plane images of 24 KiB per 32-row tile
+ *   (the q, k, v buffers must hold 1.5x the fp32 image size). */
 int gmf_set_tuning(gmf_handle* h, const char* name, int value);
 
 /* In-situ timing of the dominant kernel (the spatial-consistency attention): while enabled, every

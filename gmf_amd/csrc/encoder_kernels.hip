@@ -384,10 +384,21 @@ k_scattn(const float* __restrict__ q_img, const float* __restrict__ k_img, const
 //   and the O rescale is skipped when no row's running max moved.
 //   FASTSQRT: v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf expansion.
 // =========================================================================================
+// d = ||a|| - ||b|| from the squared lengths.
+//   FASTSQRT = false: the reference's form, sqrtf(a2) - sqrtf(b2) with correctly rounded square roots
+//                     (hipcc expands each into ~14 VALU instructions).
+//   FASTSQRT = true : the rational form (a2 - b2) / (sqrt(a2) + sqrt(b2)).  The two lengths are nearly equal
+//                     exactly where c_ij > 0 matters, so the subtraction of two rounded square roots in the
+//                     reference form is where its error comes from; here the difference is taken on the
+//                     squared lengths and the square roots (v_sqrt_f32, 1 ulp) and the reciprocal
+//                     (v_rcp_f32) only enter through a well-conditioned denominator.  7 instructions.
 template <bool FASTSQRT>
-GMF_DEVINL float sqrt_sel(float x) {
-  if (FASTSQRT) return __builtin_amdgcn_sqrtf(x);
-  return sqrtf(x);
+GMF_DEVINL float len_diff(float a2, float b2) {
+  if (FASTSQRT) {
+    const float den = fmaxf(__builtin_amdgcn_sqrtf(a2) + __builtin_amdgcn_sqrtf(b2), 1e-30f);
+    return (a2 - b2) * __builtin_amdgcn_rcpf(den);
+  }
+  return sqrtf(a2) - sqrtf(b2);
 }
 
 // compat * score for one element; lp points at this lane-half's first key of the tile (pts8 rows)
@@ -396,9 +407,7 @@ GMF_DEVINL float compat_times(const float4* lp, int jl, const float (&si)[3], co
   const float4 a = lp[2 * jl], b = lp[2 * jl + 1];
   const float ax = si[0] - a.x, ay = si[1] - a.y, az = si[2] - a.z;
   const float bx = ti[0] - b.x, by = ti[1] - b.y, bz = ti[2] - b.z;
-  const float ds = sqrt_sel<FASTSQRT>(fmaf(az, az, fmaf(ay, ay, ax * ax)));
-  const float dt = sqrt_sel<FASTSQRT>(fmaf(bz, bz, fmaf(by, by, bx * bx)));
-  const float d = ds - dt;
+  const float d = len_diff<FASTSQRT>(fmaf(az, az, fmaf(ay, ay, ax * ax)), fmaf(bz, bz, fmaf(by, by, bx * bx)));
   return fmaxf(1.0f - d * d * inv_sig2, 0.f) * sc;
 }
 
@@ -487,7 +496,7 @@ k_scattn_pipe(const float* __restrict__ q_img, const float* __restrict__ k_img, 
           const float bx = ti[0] - pb.x, by = ti[1] - pb.y, bz = ti[2] - pb.z;
           d2t = fmaf(bz, bz, fmaf(by, by, bx * bx));
         } else if (e == 2) {
-          const float d = sqrt_sel<FASTSQRT>(d2s) - sqrt_sel<FASTSQRT>(d2t);
+          const float d = len_diff<FASTSQRT>(d2s, d2t);
           cc = fmaxf(1.0f - d * d * inv_sig2, 0.f);
         } else {
           x[g] = cc * s_cur[g];
@@ -605,15 +614,241 @@ k_scattn_pipe(const float* __restrict__ q_img, const float* __restrict__ k_img, 
 //   waves per SIMD: one wave's MFMA runs under the other's compat/softmax VALU work.
 //   Per 32x32 tile and wave: 48 + 48 MFMAs of 32 cycles (vs 128 of 64 in fp32).
 // =========================================================================================
-constexpr int kB3Waves = 8;
+constexpr int kB3Waves = 8;                       // k_scattn_b3p (double-buffered, 1 workgroup per CU)
+constexpr int kB3sWaves = 4;                      // k_scattn_b3  (single-buffered, 2 workgroups per CU)
 constexpr int kB3BufFloats = 2 * kB3TileFloats + 256;
+
+// Single-buffered K | V | pts8 (49 KB) so that TWO independent 4-wave workgroups fit on a CU: the two waves
+// that share a SIMD then belong to different workgroups, are not barrier-locked to each other, and one's
+// MFMA phase runs under the other's VALU phase.  Two barriers per tile: B1 after the QK^T phase (K_t is
+// free -> K_{t+1} streams in under the softmax and PV phases), B2 after the PV phase (V_t, pts_t are free
+// -> V_{t+1}, pts_{t+1} stream in under the next QK^T phase).
+// ABL (timing-only ablations, results wrong): 1 = no compat term, 2 = no compat and no exponentials,
+// 3 = K/V operands not re-read from LDS, 4 = no DMA of K/V tiles, 5 = no barriers B1/B2 (racy).
+template <bool FASTSQRT, int WAVES, int ABL = 0>
+__global__ void __launch_bounds__(64 * WAVES, 2)
+k_scattn_b3(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
+            const float* __restrict__ pts8, const float* __restrict__ fus, const float* __restrict__ wst,
+            const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2, int wgs_per_pair) {
+  __shared__ __attribute__((aligned(16))) float lds[kB3BufFloats];
+  float* const ldsK = lds;
+  float* const ldsV = lds + kB3TileFloats;
+  float* const ldsP = lds + 2 * kB3TileFloats;
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-aware work mapping: hardware deals workgroup L to XCD L % 8, so give XCD x one contiguous run of
+  // (pair, query-block) items.  All workgroups of a pair then stream the SAME K/V tiles through ONE L2 at
+  // about the same time (each tile is fetched from HBM/MALL once per pair instead of once per workgroup).
+  // Pure speed choice: any placement computes the same result.
+  int pair, qblock;
+  {
+    const int total = gridDim.x, L = blockIdx.x;
+    const int chunk = total >> 3, rem = total & 7, xcd = L & 7, kth = L >> 3;
+    const int start = (xcd < rem) ? xcd * (chunk + 1) : rem * (chunk + 1) + (xcd - rem) * chunk;
+    const int logical = start + kth;
+    pair = logical / wgs_per_pair;
+    qblock = logical - pair * wgs_per_pair;
+  }
+  const int tile_raw = qblock * WAVES + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t pbase = (size_t)pair * tiles;
+  const size_t toff = (pbase + tile) * (32 * C);
+
+  bf16x8 qh[8], qm[8], ql[8];
+  {
+    const bf16x8* qp = reinterpret_cast<const bf16x8*>(q_img + (pbase + tile) * (size_t)kB3TileFloats) + lane;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { qh[s] = qp[(0 * 8 + s) * 64]; qm[s] = qp[(1 * 8 + s) * 64]; ql[s] = qp[(2 * 8 + s) * 64]; }
+  }
+  float si[3], ti[3];
+  {
+    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)tile * 32 + i) * 8);
+    const float4 a = pp[0], b = pp[1];
+    si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
+  }
+  const float* gk = k_img + pbase * (size_t)kB3TileFloats;
+  const float* gv = v_img + pbase * (size_t)kB3TileFloats;
+  const float* gp = pts8 + pbase * 32 * 8;
+  auto issueK = [&](int t) { if (ABL != 4) dma_issue(gk + (size_t)t * kB3TileFloats, ldsK, 24, wave, WAVES, lane); };
+  auto issueV = [&](int t) {
+    if (ABL != 4) dma_issue(gv + (size_t)t * kB3TileFloats, ldsV, 24, wave, WAVES, lane);
+    if (wave == (t & (WAVES - 1))) dma_piece_1k(gp + (size_t)t * 256, ldsP, lane);
+  };
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
+  float m_run = -INFINITY, l_half = 0.f;
+  const bf16x8* lk = reinterpret_cast<const bf16x8*>(ldsK) + lane;
+  const bf16x8* lv = reinterpret_cast<const bf16x8*>(ldsV) + lane;
+  const float4* lp = reinterpret_cast<const float4*>(ldsP) + 8 * h;
+
+  issueK(0);
+  issueV(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < tiles; ++t) {
+    // ---- S^T = K_t Q'^T : 8 k-steps x 6 partial products ----
+    f32x16 sacc = zero16();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int ss_ = (ABL == 3) ? 0 : s;
+      const bf16x8 kh = lk[(0 * 8 + ss_) * 64], km = lk[(1 * 8 + ss_) * 64], kl = lk[(2 * 8 + ss_) * 64];
+      mma6(sacc, kh, km, kl, qh[s], qm[s], ql[s]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V_t, pts_t (issued one phase ago) have landed
+    if (ABL != 5) __syncthreads();                     // B1: every wave is done reading K_t
+    if (t + 1 < tiles) issueK(t + 1);
+    // ---- compat, scores, online softmax ----
+    float x[16];
+    float mx = -INFINITY;
+    if (t + 1 < tiles) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jl = 8 * (r >> 2) + (r & 3);
+        x[r] = (ABL == 1 || ABL == 2) ? sacc[r] : compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
+        mx = fmaxf(mx, x[r]);
+      }
+    } else {
+      const int jbase = t * 32 + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jl = 8 * (r >> 2) + (r & 3);
+        const float v = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
+        x[r] = (jbase + jl < N) ? v : -INFINITY;
+        mx = fmaxf(mx, x[r]);
+      }
+    }
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const bool moved = m_new > m_run;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = (ABL == 2) ? (x[r] - m_new) : __builtin_amdgcn_exp2f(x[r] - m_new); ls += x[r]; }
+    l_half = fmaf(l_half, alpha, ls);
+    if (__any(moved)) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
+    // ---- O^T += V_t^T P^T : P planes straight from the accumulator registers ----
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 ph, pm, pl;
+      split8(&x[8 * s2], ph, pm, pl);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int slot = (ABL == 3) ? 0 : 2 * db + s2;
+        const bf16x8 vh = lv[(0 * 8 + slot) * 64], vm = lv[(1 * 8 + slot) * 64], vl = lv[(2 * 8 + slot) * 64];
+        mma6(oacc[db], vh, vm, vl, ph, pm, pl);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K_{t+1} (issued two phases ago) has landed
+    if (ABL != 5) __syncthreads();                     // B2: every wave is done reading V_t, pts_t
+    if (t + 1 < tiles) issueV(t + 1);
+  }
+
+  // ---- epilogue: normalise, fc_message (fp32 MFMA), add the Fusion-2 branch ----
+  float o[CF];
+  {
+    const float inv = 1.0f / xhalf_sum(l_half);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
+  }
+  __syncthreads();
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5);
+  ss.prime();
+  float m1[DHF], m2[DHF];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_wx<CF>(acc, lw, o);
+    float b[16];
+    load_vec_block(b, vecs, mb, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+  }
+  {
+    const float4* lw = ss.acquire();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      f32x16 acc = zero16();
+      mma_wx<DHF>(acc, lw + mb * (32 * DH / 4), m1);
+      float b[16];
+      load_vec_block(b, vecs + 64, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const float4* lw = ss.acquire();
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int mb = 2 * st + hb;
+      f32x16 acc = zero16();
+      mma_wx<DHF>(acc, lw + hb * (32 * DH / 4), m2);
+      float b[16], fz[16], t[16];
+      load_vec_block(b, vecs + 128, mb, h);
+      load_block_p32(fz, fus + toff, mb, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r] + fz[r];
+      if (active) store_block_p32(out + toff, mb, t, lane);
+    }
+  }
+}
+
+// =========================================================================================
+// k_scattn_b3p: k_scattn_b3 with the tile loop software-pipelined inside each wave.
+//   K tiles run one tile ahead of V / pts8 in the LDS double buffers.  Phase 1 issues the 48 MFMAs of
+//   S_{t+1} = K_{t+1} Q'^T one per sched_barrier(0) unit, each unit carrying its share of tile t's
+//   compat / score / max work and then the first half of the exponentials and their bf16 split; phase 2
+//   issues the 48 MFMAs of O^T += V_t^T P^T with the second half of the exponentials underneath.
+//   (The bf16 MFMA co-executes with VALU work, so a wave overlaps its own matrix and vector streams; the
+//   barrier-locked waves of k_scattn_b3 do all their matrix work, then all their vector work, together.)
+// =========================================================================================
+GMF_DEVINL void split2(float x0, float x1, bf16x8& hi, bf16x8& mi, bf16x8& lo, int j) {
+  const f32x2 x = {x0, x1};
+  const bf16x2 hh = __builtin_convertvector(x, bf16x2);
+  const f32x2 r1 = x - __builtin_convertvector(hh, f32x2);
+  const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
+  const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+  hi[j] = hh[0]; hi[j + 1] = hh[1];
+  mi[j] = mm[0]; mi[j + 1] = mm[1];
+  lo[j] = ll[0]; lo[j + 1] = ll[1];
+}
+
+// the u-th of the six partial products of one k-step (small terms first)
+GMF_DEVINL f32x16 mma6_part(int u, f32x16 acc, bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl) {
+  switch (u) {
+    case 0: return mfma_b16(al, bh, acc);
+    case 1: return mfma_b16(ah, bl, acc);
+    case 2: return mfma_b16(am, bm, acc);
+    case 3: return mfma_b16(am, bh, acc);
+    case 4: return mfma_b16(ah, bm, acc);
+    default: return mfma_b16(ah, bh, acc);
+  }
+}
 
 template <bool FASTSQRT>
 __global__ void __launch_bounds__(512, 2)
-k_scattn_b3(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
-            const float* __restrict__ pts8, const float* __restrict__ fus, const float* __restrict__ wst,
-            const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * kB3BufFloats];
+k_scattn_b3p(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
+             const float* __restrict__ pts8, const float* __restrict__ fus, const float* __restrict__ wst,
+             const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2) {
+  // LDS: K slots [2][6144] | V slots [2][6144] | pts slots [2][256]
+  __shared__ __attribute__((aligned(16))) float lds[4 * kB3TileFloats + 512];
+  float* const ldsK = lds;
+  float* const ldsV = lds + 2 * kB3TileFloats;
+  float* const ldsP = lds + 4 * kB3TileFloats;
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y;
@@ -638,12 +873,10 @@ k_scattn_b3(const float* __restrict__ q_img, const float* __restrict__ k_img, co
   const float* gk = k_img + pbase * (size_t)kB3TileFloats;
   const float* gv = v_img + pbase * (size_t)kB3TileFloats;
   const float* gp = pts8 + pbase * 32 * 8;
-
-  auto issue_tile = [&](int t) {
-    float* buf = lds + (t & 1) * kB3BufFloats;
-    dma_issue(gk + (size_t)t * kB3TileFloats, buf, 24, wave, kB3Waves, lane);
-    dma_issue(gv + (size_t)t * kB3TileFloats, buf + kB3TileFloats, 24, wave, kB3Waves, lane);
-    if (wave == (t & 7)) dma_piece_1k(gp + (size_t)t * 256, buf + 2 * kB3TileFloats, lane);
+  auto issueK = [&](int t) { dma_issue(gk + (size_t)t * kB3TileFloats, ldsK + (t & 1) * kB3TileFloats, 24, wave, kB3Waves, lane); };
+  auto issueV = [&](int t) {
+    dma_issue(gv + (size_t)t * kB3TileFloats, ldsV + (t & 1) * kB3TileFloats, 24, wave, kB3Waves, lane);
+    if (wave == (t & 7)) dma_piece_1k(gp + (size_t)t * 256, ldsP + (t & 1) * 256, lane);
   };
 
   f32x16 oacc[4];
@@ -651,70 +884,123 @@ k_scattn_b3(const float* __restrict__ q_img, const float* __restrict__ k_img, co
   for (int db = 0; db < 4; ++db) oacc[db] = zero16();
   float m_run = -INFINITY, l_half = 0.f;
 
-  issue_tile(0);
+  issueK(0);
+  if (tiles > 1) issueK(1);
+  issueV(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16 s_cur = zero16();
+  {
+    const bf16x8* lk = reinterpret_cast<const bf16x8*>(ldsK) + lane;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) mma6(s_cur, lk[(0 * 8 + s) * 64], lk[(1 * 8 + s) * 64], lk[(2 * 8 + s) * 64], qh[s], qm[s], ql[s]);
+  }
+
   for (int t = 0; t < tiles; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < tiles) issue_tile(t + 1);
-    const float* buf = lds + (t & 1) * kB3BufFloats;
-    const bf16x8* lk = reinterpret_cast<const bf16x8*>(buf) + lane;
-    const bf16x8* lv = reinterpret_cast<const bf16x8*>(buf + kB3TileFloats) + lane;
-    const float4* lp = reinterpret_cast<const float4*>(buf + 2 * kB3TileFloats) + 8 * h;
-
-    // ---- S^T = K Q'^T : 8 k-steps x 6 partial products ----
-    f32x16 sacc = zero16();
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const bf16x8 kh = lk[(0 * 8 + s) * 64], km = lk[(1 * 8 + s) * 64], kl = lk[(2 * 8 + s) * 64];
-      mma6(sacc, kh, km, kl, qh[s], qm[s], ql[s]);
-    }
-    // ---- compat, scores, online softmax ----
+    __syncthreads();            // K_{t+1}, V_t, pts_t landed; every wave is done with K_t, V_{t-1}, pts_{t-1}
+    if (t + 2 < tiles) issueK(t + 2);
+    if (t + 1 < tiles) issueV(t + 1);
+    const float4* lp = reinterpret_cast<const float4*>(ldsP + (t & 1) * 256) + 8 * h;
+    const bf16x8* lv = reinterpret_cast<const bf16x8*>(ldsV + (t & 1) * kB3TileFloats) + lane;
     float x[16];
-    float mx = -INFINITY;
+    float mx = -INFINITY, m_new = 0.f, alpha = 1.f, ls = 0.f;
+    bool moved = false;
+    bf16x8 ph0, pm0, pl0;
+    f32x16 s_next = zero16();
     if (t + 1 < tiles) {
+      const bf16x8* lk = reinterpret_cast<const bf16x8*>(ldsK + ((t + 1) & 1) * kB3TileFloats) + lane;
+      bf16x8 kh = lk[0], km = lk[8 * 64], kl = lk[16 * 64];
+      bf16x8 kh_n = kh, km_n = km, kl_n = kl;
+      float4 pa = lp[0], pb = lp[1];
+      float d2s = 0.f, d2t = 0.f, cc = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int jl = 8 * (r >> 2) + (r & 3);
-        x[r] = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
-        mx = fmaxf(mx, x[r]);
+      for (int u = 0; u < 48; ++u) {
+        const int s = u / 6, pr = u % 6;
+        if (pr == 0 && s < 7) { kh_n = lk[(0 * 8 + s + 1) * 64]; km_n = lk[(1 * 8 + s + 1) * 64]; kl_n = lk[(2 * 8 + s + 1) * 64]; }
+        s_next = mma6_part(pr, s_next, kh, km, kl, qh[s], qm[s], ql[s]);
+        if (pr == 5) { kh = kh_n; km = km_n; kl = kl_n; }
+        if (u < 32) {                       // two quarter-elements per unit: element g = u/2
+          const int g = u >> 1;
+          if ((u & 1) == 0) {
+            const float ax = si[0] - pa.x, ay = si[1] - pa.y, az = si[2] - pa.z;
+            d2s = fmaf(az, az, fmaf(ay, ay, ax * ax));
+            const float bx = ti[0] - pb.x, by = ti[1] - pb.y, bz = ti[2] - pb.z;
+            d2t = fmaf(bz, bz, fmaf(by, by, bx * bx));
+            if (g < 15) { const int jn = 8 * ((g + 1) >> 2) + ((g + 1) & 3); pa = lp[2 * jn]; pb = lp[2 * jn + 1]; }
+          } else {
+            const float d = len_diff<FASTSQRT>(d2s, d2t);
+            cc = fmaxf(1.0f - d * d * inv_sig2, 0.f);
+            x[g] = cc * s_cur[g];
+            mx = fmaxf(mx, x[g]);
+          }
+        } else if (u == 32) {
+          mx = xhalf_max(mx);
+          m_new = fmaxf(m_run, mx);
+          moved = m_new > m_run;
+          alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          m_run = m_new;
+        } else if (u <= 40) {
+          const int r = u - 33;
+          x[r] = __builtin_amdgcn_exp2f(x[r] - m_new);
+          ls += x[r];
+        } else if (u <= 44) {
+          const int j = 2 * (u - 41);
+          split2(x[j], x[j + 1], ph0, pm0, pl0, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       const int jbase = t * 32 + 4 * h;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int jl = 8 * (r >> 2) + (r & 3);
-        const float v = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
-        x[r] = (jbase + jl < N) ? v : -INFINITY;
-        mx = fmaxf(mx, x[r]);
+      for (int g = 0; g < 16; ++g) {
+        const int jl = 8 * (g >> 2) + (g & 3);
+        const float v = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, s_cur[g]);
+        x[g] = (jbase + jl < N) ? v : -INFINITY;
+        mx = fmaxf(mx, x[g]);
       }
-    }
-    mx = xhalf_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const bool moved = m_new > m_run;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float ls = 0.f;
+      mx = xhalf_max(mx);
+      m_new = fmaxf(m_run, mx);
+      moved = m_new > m_run;
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_new); ls += x[r]; }
-    l_half = fmaf(l_half, alpha, ls);
+      for (int r = 0; r < 8; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_new); ls += x[r]; }
+      split8(&x[0], ph0, pm0, pl0);
+    }
     if (__any(moved)) {
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
     }
-    // ---- O^T += V^T P^T : P planes straight from the accumulator registers ----
+    // ---- phase 2: O^T += V_t^T P^T ----
+    {
+      bf16x8 ph1, pm1, pl1;
+      bf16x8 vh = lv[0], vm = lv[8 * 64], vl = lv[16 * 64];
+      bf16x8 vh_n = vh, vm_n = vm, vl_n = vl;
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 ph, pm, pl;
-      split8(&x[8 * s2], ph, pm, pl);
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const int slot = 2 * db + s2;
-        const bf16x8 vh = lv[(0 * 8 + slot) * 64], vm = lv[(1 * 8 + slot) * 64], vl = lv[(2 * 8 + slot) * 64];
-        mma6(oacc[db], vh, vm, vl, ph, pm, pl);
+      for (int u = 0; u < 48; ++u) {
+        const int s2 = u / 24, db = (u % 24) / 6, pr = u % 6;
+        if (pr == 0 && u < 42) {
+          const int un = u + 6, s2n = un / 24, dbn = (un % 24) / 6, slot = 2 * dbn + s2n;
+          vh_n = lv[(0 * 8 + slot) * 64]; vm_n = lv[(1 * 8 + slot) * 64]; vl_n = lv[(2 * 8 + slot) * 64];
+        }
+        oacc[db] = mma6_part(pr, oacc[db], vh, vm, vl, s2 ? ph1 : ph0, s2 ? pm1 : pm0, s2 ? pl1 : pl0);
+        if (pr == 5) { vh = vh_n; vm = vm_n; vl = vl_n; }
+        if (u < 8) {
+          const int r = 8 + u;
+          x[r] = __builtin_amdgcn_exp2f(x[r] - m_new);
+          ls += x[r];
+        } else if (u < 12) {
+          const int j = 2 * (u - 8);
+          split2(x[8 + j], x[8 + j + 1], ph1, pm1, pl1, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    l_half = fmaf(l_half, alpha, ls);
+    s_cur = s_next;
   }
 
   // ---- epilogue: normalise, fc_message (fp32 MFMA), add the Fusion-2 branch ----
@@ -1218,8 +1504,25 @@ hipError_t launch_scattn(const float* q, const float* k, const float* v, const f
   const float inv = 1.0f / (sigma_d * sigma_d);
   if (variant >= 3) {
     const dim3 grid((tiles + kB3Waves - 1) / kB3Waves, B);
-    if (variant == 4) hipLaunchKernelGGL(k_scattn_b3<true>, grid, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
-    else hipLaunchKernelGGL(k_scattn_b3<false>, grid, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
+    const int wpp = (tiles + kB3sWaves - 1) / kB3sWaves;
+    const dim3 grid4(wpp * B);
+    const int wpp8 = (tiles + 7) / 8;
+    const dim3 grid8(wpp8 * B);
+    if (variant == 4) hipLaunchKernelGGL((k_scattn_b3<true, 4>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
+    else if (variant >= 11 && variant <= 15) {
+      switch (variant) {
+        case 11: hipLaunchKernelGGL((k_scattn_b3<true, 4, 1>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp); break;
+        case 12: hipLaunchKernelGGL((k_scattn_b3<true, 4, 2>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp); break;
+        case 13: hipLaunchKernelGGL((k_scattn_b3<true, 4, 3>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp); break;
+        case 14: hipLaunchKernelGGL((k_scattn_b3<true, 4, 4>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp); break;
+        default: hipLaunchKernelGGL((k_scattn_b3<true, 4, 5>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp); break;
+      }
+    }
+    else if (variant == 7) hipLaunchKernelGGL((k_scattn_b3<false, 8>), grid8, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp8);
+    else if (variant == 8) hipLaunchKernelGGL((k_scattn_b3<true, 8>), grid8, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp8);
+    else if (variant == 5) hipLaunchKernelGGL(k_scattn_b3p<false>, grid, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
+    else if (variant == 6) hipLaunchKernelGGL(k_scattn_b3p<true>, grid, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
+    else hipLaunchKernelGGL((k_scattn_b3<false, 4>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
     return hipGetLastError();
   }
   if (variant == 0) hipLaunchKernelGGL(k_scattn<false>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);

@@ -113,7 +113,7 @@ int gmf_create(int device, gmf_handle** out) {
 int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
   GMF_REQUIRE(h && name, GMF_ERR_BAD_ARG, "set_tuning: null pointer");
   if (std::strcmp(name, "scattn_variant") == 0) {
-    GMF_REQUIRE(value >= 0 && value <= 4, GMF_ERR_BAD_ARG, "set_tuning: scattn_variant must be 0..4");
+    GMF_REQUIRE(value >= 0 && value <= 15, GMF_ERR_BAD_ARG, "set_tuning: scattn_variant out of range");
     gmf::set_scattn_variant(value);
     return GMF_OK;
   }

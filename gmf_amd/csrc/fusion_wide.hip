@@ -1,0 +1,347 @@
+// FusionLayer / PerceiverIO kernels for the DGR bottleneck configuration
+//   latent_dim (query width) = 256, context dim = 128, one head of d_head = 128, GEGLU hidden 2 x 1024
+// (reference: GMF_DeepGlobalRegistration/*/model/resunet_new.py:516-525,660,694-705 calling
+//  model/perceiver_io.py:139-221; note to_out maps the head back to the QUERY width, perceiver_io.py:83).
+//
+// Same "rows on lanes" scheme and the same stage streaming as encoder_kernels.hip; a 256-wide row is a
+// 128-register fragment, so these kernels run one wave per SIMD (<= 512 VGPRs) instead of two.
+//   k_ctx_prep_w     perceiver_io.py:126-128,46-49,89-91    LCPE(content) + LayerNorm_ctx + to_kv (128 -> 128 | 128)
+//   k_fusion_attn_w  perceiver_io.py:121-123,44,87-101,208  LCPE(q) + LayerNorm + to_q + softmax(QK^T)V + to_out + residual
+//   k_fusion_ff_w    perceiver_io.py:54-69,211              LayerNorm + Linear(256,2048) + GEGLU + Linear(1024,256) + residual
+#include "mfma_core.hpp"
+#include "launchers.hpp"
+
+namespace gmf {
+
+namespace wide {
+
+constexpr int CX = 128;        // context (image token) width
+constexpr int CXF = CX / 2;
+constexpr int LAT = 256;       // query / latent width
+constexpr int LATF = LAT / 2;
+constexpr int DHW = 128;       // head width
+constexpr int DHWF = DHW / 2;
+constexpr int FFHW = 4 * LAT;  // GEGLU hidden width (value half)
+constexpr int kWaves = 4;
+
+GMF_DEVINL void load_vec16(float (&v)[16], const float* __restrict__ vec, int mb, int h) {
+  const float4* p = reinterpret_cast<const float4*>(vec + 32 * mb) + h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 t = p[2 * q];
+    v[4 * q + 0] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
+}
+
+// block mb (32 features) of a K-wide P32 tile
+template <int K>
+GMF_DEVINL void store_blk(float* __restrict__ tile_base, int mb, const float (&t)[16], int lane) {
+  float4* p = reinterpret_cast<float4*>(tile_base) + (4 * mb) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p[q * 64] = make_float4(t[4 * q + 0], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+}
+
+template <int K>
+GMF_DEVINL void load_blk(float (&t)[16], const float* __restrict__ tile_base, int mb, int lane) {
+  const float4* p = reinterpret_cast<const float4*>(tile_base) + (4 * mb) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = p[q * 64];
+    t[4 * q + 0] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w;
+  }
+}
+
+GMF_DEVINL void store_timg(float* __restrict__ tile_base, int db, const f32x16& a, int lane) {
+  float4* p = reinterpret_cast<float4*>(tile_base) + (4 * db) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p[q * 64] = make_float4(a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+}
+
+// LCPE over a K-wide P32 tensor (K = 2*KF): taps = w0[K] | w1[K] | w2[K] | b[K]
+template <int KF>
+GMF_DEVINL void lcpe_w(float (&y)[KF], const float* __restrict__ pair_base, int row, int n_rows,
+                       const float* __restrict__ taps, int h) {
+  constexpr int K = 2 * KF;
+  const float4* base = reinterpret_cast<const float4*>(pair_base);
+  const bool has_m = row >= 1, has_p = row + 1 < n_rows;
+  const int rm = has_m ? row - 1 : row, rp = has_p ? row + 1 : row;
+  const float4* pc = base + (size_t)(row >> 5) * (KF / 4) * 64 + h * 32 + (row & 31);
+  const float4* pm = base + (size_t)(rm >> 5) * (KF / 4) * 64 + h * 32 + (rm & 31);
+  const float4* pp = base + (size_t)(rp >> 5) * (KF / 4) * 64 + h * 32 + (rp & 31);
+  const float4* t0 = reinterpret_cast<const float4*>(taps) + h;
+  const float fm = has_m ? 1.f : 0.f, fp = has_p ? 1.f : 0.f;
+#pragma unroll
+  for (int g = 0; g < KF / 4; ++g) {
+    const float4 xc = pc[g * 64], xm = pm[g * 64], xp = pp[g * 64];
+    const float4 w0 = t0[2 * g], w1 = t0[2 * g + K / 4], w2 = t0[2 * g + 2 * (K / 4)], b = t0[2 * g + 3 * (K / 4)];
+    y[4 * g + 0] = xc.x + b.x + w0.x * (fm * xm.x) + w1.x * xc.x + w2.x * (fp * xp.x);
+    y[4 * g + 1] = xc.y + b.y + w0.y * (fm * xm.y) + w1.y * xc.y + w2.y * (fp * xp.y);
+    y[4 * g + 2] = xc.z + b.z + w0.z * (fm * xm.z) + w1.z * xc.z + w2.z * (fp * xp.z);
+    y[4 * g + 3] = xc.w + b.w + w0.w * (fm * xm.w) + w1.w * xc.w + w2.w * (fp * xp.w);
+  }
+}
+
+// acc += Wimg(32 x 8*NG) * x[off .. off + 4*NG) : one K-slice of a wider product
+template <int NG, int KF>
+GMF_DEVINL void mma_slice(f32x16& acc, const float4* lw, const float (&x)[KF], int off) {
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const float4 w = lw[g * 64];
+    acc = mfma32(w.x, x[off + 4 * g + 0], acc);
+    acc = mfma32(w.y, x[off + 4 * g + 1], acc);
+    acc = mfma32(w.z, x[off + 4 * g + 2], acc);
+    acc = mfma32(w.w, x[off + 4 * g + 3], acc);
+  }
+}
+
+GMF_DEVINL float gelu_erf_w(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+}  // namespace wide
+
+using namespace wide;
+
+// ---------------------------------------------------------------------------------------------
+// output per token tile: 8192 floats = Kc as P32 (K=128) | Vc as T image (D=128)
+// stages (8): Wk[4] | Wv[4]        vecs: content taps w0|w1|w2|b (4x128) | gamma_c | beta_c
+// ---------------------------------------------------------------------------------------------
+template <bool PE>
+__global__ void __launch_bounds__(256, 1)
+k_ctx_prep_w(const float* __restrict__ ctx, const float* __restrict__ wst, const float* __restrict__ vecs,
+             float* __restrict__ out, int T, int ttiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWaves + wave;
+  const bool active = tile_raw < ttiles;
+  const int tile = active ? tile_raw : ttiles - 1;
+  const float* pair_base = ctx + (size_t)pair * ttiles * (32 * CX);
+  float* dst = out + ((size_t)pair * ttiles + tile) * (2 * kStageFloats);
+
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, kWaves, lane, wst, 8);
+  ss.prime();
+  float x[CXF], cn[CXF];
+  if (PE) lcpe_w<CXF>(x, pair_base, tile * 32 + i, T, vecs, h);
+  else load_frag_p32<CXF>(x, pair_base + (size_t)tile * (32 * CX), lane);
+  layernorm_frag<CXF>(cn, x, vecs + 4 * CX, vecs + 5 * CX, h);
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_wx<CXF>(acc, lw, cn);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = acc[r];
+    if (active) store_blk<DHW>(dst, mb, t, lane);
+  }
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_xw<CXF>(acc, lw, cn);
+    if (active) store_timg(dst + kStageFloats, db, acc, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stages: Wq'[4 blocks x 2 K-halves] | ctx tiles [2 per tile: K, V] | Wo[8]
+// vecs: query taps w0|w1|w2|b (4x256) | gamma[256] | beta[256] | bo[256]
+// x, x1: P32 images with K = 256 (8192 floats per tile)
+// ---------------------------------------------------------------------------------------------
+template <bool PE>
+__global__ void __launch_bounds__(256, 1)
+k_fusion_attn_w(const float* __restrict__ xin, const float* __restrict__ ctx_img, const float* __restrict__ wst,
+                const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWaves + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const float* pair_base = xin + (size_t)pair * tiles * (32 * LAT);
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * LAT);
+
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, kWaves, lane, wst, 8,
+          ctx_img + (size_t)pair * ttiles * (2 * kStageFloats), 2 * ttiles, wst + 8 * kStageFloats, 8);
+  ss.prime();
+
+  float xp[LATF];
+  if (PE) lcpe_w<LATF>(xp, pair_base, tile * 32 + i, N, vecs, h);
+  else load_frag_p32<LATF>(xp, pair_base + (size_t)tile * (32 * LAT), lane);
+
+  float qf[DHWF];
+  {
+    float xn[LATF];
+    layernorm_frag<LATF>(xn, xp, vecs + 4 * LAT, vecs + 5 * LAT, h);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      f32x16 acc = zero16();
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const float4* lw = ss.acquire();
+        mma_slice<16, LATF>(acc, lw, xn, 64 * half);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qf[16 * mb + r] = acc[r];
+    }
+  }
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
+  float m_run = -INFINITY, l_half = 0.f;
+  for (int t = 0; t < ttiles; ++t) {
+    f32x16 s = zero16();
+    {
+      const float4* lk = ss.acquire();
+      mma_wx<DHWF>(s, lk, qf);
+    }
+    float x[16];
+    float mx = -INFINITY;
+    const int jbase = t * 32 + 4 * h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jl = 8 * (r >> 2) + (r & 3);
+      const float v = (jbase + jl < T) ? s[r] : -INFINITY;
+      x[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_new); ls += x[r]; }
+    l_half = fmaf(l_half, alpha, ls);
+    const float4* lv = ss.acquire();
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 vv = lv[(db * 4 + q) * 64];
+        oacc[db] = mfma32(vv.x, x[4 * q + 0], oacc[db]);
+        oacc[db] = mfma32(vv.y, x[4 * q + 1], oacc[db]);
+        oacc[db] = mfma32(vv.z, x[4 * q + 2], oacc[db]);
+        oacc[db] = mfma32(vv.w, x[4 * q + 3], oacc[db]);
+      }
+    }
+  }
+  float o[DHWF];
+  {
+    const float inv = 1.0f / xhalf_sum(l_half);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
+  }
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_wx<DHWF>(acc, lw, o);
+    float b[16], t[16];
+    load_vec16(b, vecs + 6 * LAT, mb, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r] + xp[16 * mb + r];
+    if (active) store_blk<LAT>(x1_out + toff, mb, t, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stages (192): for c in 0..31: W1a_c [2 K-halves] | W1g_c [2] | W2_c [2: out-blocks 0-3, 4-7]
+// vecs: gamma[256] | beta[256] | b1a[1024] | b1g[1024] | b2[256]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 1)
+k_fusion_ff_w(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
+              float* __restrict__ x2_out, int tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWaves + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * LAT);
+
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, kWaves, lane, wst, 6 * (FFHW / 32));
+  ss.prime();
+  float xn[LATF];
+  {
+    float x[LATF];
+    load_frag_p32<LATF>(x, x1 + toff, lane);
+    layernorm_frag<LATF>(xn, x, vecs, vecs + LAT, h);
+  }
+  f32x16 y[8];
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) y[mb] = zero16();
+  const float* b1a = vecs + 2 * LAT;
+  const float* b1g = vecs + 2 * LAT + FFHW;
+
+  for (int c = 0; c < FFHW / 32; ++c) {
+    float ga[16];
+    {
+      f32x16 acc = zero16();
+#pragma unroll
+      for (int half = 0; half < 2; ++half) { const float4* lw = ss.acquire(); mma_slice<16, LATF>(acc, lw, xn, 64 * half); }
+      float b[16];
+      load_vec16(b, b1a, c, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ga[r] = acc[r] + b[r];
+    }
+    {
+      f32x16 acc = zero16();
+#pragma unroll
+      for (int half = 0; half < 2; ++half) { const float4* lw = ss.acquire(); mma_slice<16, LATF>(acc, lw, xn, 64 * half); }
+      float b[16];
+      load_vec16(b, b1g, c, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ga[r] *= gelu_erf_w(acc[r] + b[r]);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const float4* lw = ss.acquire();
+#pragma unroll
+      for (int m4 = 0; m4 < 4; ++m4) mma_wx<16>(y[4 * half + m4], lw + m4 * (32 * 32 / 4), ga);
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    float b[16], xr[16], t[16];
+    load_vec16(b, vecs + 2 * LAT + 2 * FFHW, mb, h);
+    load_blk<LAT>(xr, x1 + toff, mb, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = y[mb][r] + b[r] + xr[r];
+    if (active) store_blk<LAT>(x2_out + toff, mb, t, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+static inline dim3 wgrid(int tiles, int B) { return dim3((tiles + kWaves - 1) / kWaves, B); }
+
+hipError_t launch_ctx_prep_w(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
+                             int ttiles, hipStream_t s) {
+  if (pe) hipLaunchKernelGGL(k_ctx_prep_w<true>, wgrid(ttiles, B), dim3(256), 0, s, ctx, wst, vecs, out, T, ttiles);
+  else hipLaunchKernelGGL(k_ctx_prep_w<false>, wgrid(ttiles, B), dim3(256), 0, s, ctx, wst, vecs, out, T, ttiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_fusion_attn_w(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
+                                float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s) {
+  if (pe) hipLaunchKernelGGL(k_fusion_attn_w<true>, wgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
+  else hipLaunchKernelGGL(k_fusion_attn_w<false>, wgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_fusion_ff_w(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_fusion_ff_w, wgrid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
+  return hipGetLastError();
+}
+
+}  // namespace gmf

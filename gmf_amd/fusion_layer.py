@@ -91,12 +91,14 @@ class FusionLayer(nn.Module):
         data = require_cuda_f32(data, "data").contiguous()
         B, N, Cq = x.shape
         T = data.shape[1]
-        if Cq != packing.C or data.shape[2] != packing.C:
-            raise NotImplementedError(f"gmf_amd.FusionLayer: HIP kernels are built for 128-wide tokens, got {Cq}/{data.shape[2]}")
+        if data.shape[2] != packing.C:
+            raise NotImplementedError(f"gmf_amd.FusionLayer: HIP kernels are built for 128-wide context tokens, got {data.shape[2]}")
         blobs = self._blobs(x.device)
+        if Cq != blobs["latent_dim"]:
+            raise RuntimeError(f"gmf_amd.FusionLayer: queries are {Cq} wide but the layer was built for {blobs['latent_dim']}")
         out = torch.empty((B, N, Cq), device=x.device, dtype=torch.float32)
         h, st = handle_and_stream(x)
-        h.call("gmf_fusion_layer_forward", 1 if self.pe else 0,
+        h.call("gmf_fusion_layer_forward", 1 if self.pe else 0, blobs["latent_dim"], blobs["d_head"],
                blobs["ctx_wst"].data_ptr(), blobs["ctx_vec"].data_ptr(), blobs["attn_wst"].data_ptr(),
                blobs["attn_vec"].data_ptr(), blobs["ff_wst"].data_ptr(), blobs["ff_vec"].data_ptr(),
                data.data_ptr(), x.data_ptr(), x.stride(0), x.stride(1), x.stride(2),

@@ -58,46 +58,59 @@ def _taps(w, b):
     return torch.cat([w[:, 0, 0], w[:, 0, 1], w[:, 0, 2], _f(b)])
 
 
-def check_fusion_dims(sd: Dict[str, torch.Tensor], prefix: str):
+def fusion_dims(sd: Dict[str, torch.Tensor], prefix: str):
+    """(latent_dim, d_head) of a FusionLayer / PerceiverIO state dict; raises for widths without a HIP kernel."""
     a = prefix + "cross_attend_blocks.0."
     wq, wkv, wo = sd[a + "fn.to_q.weight"], sd[a + "fn.to_kv.weight"], sd[a + "fn.to_out.weight"]
-    ok = (tuple(wq.shape) == (DH, C) and tuple(wkv.shape) == (2 * DH, C) and tuple(wo.shape) == (C, DH))
+    dh, lat = int(wq.shape[0]), int(wq.shape[1])
+    ok = (lat, dh) in ((128, 64), (256, 128)) and tuple(wkv.shape) == (2 * dh, C) and tuple(wo.shape) == (lat, dh)
     if not ok:
         raise NotImplementedError(
-            f"gmf_amd: the HIP fusion kernels are built for latent_dim = dim = {C}, one head of {DH}; got to_q "
-            f"{tuple(wq.shape)}, to_kv {tuple(wkv.shape)}, to_out {tuple(wo.shape)} (no fallback path exists)")
+            f"gmf_amd: HIP fusion kernels exist for (latent_dim, d_head) = (128, 64) and (256, 128) with context dim {C} "
+            f"and to_out: d_head -> latent_dim; got to_q {tuple(wq.shape)}, to_kv {tuple(wkv.shape)}, to_out "
+            f"{tuple(wo.shape)} (no fallback path exists)")
+    return lat, dh
 
 
 def pack_fusion(sd: Dict[str, torch.Tensor], prefix: str, pe: bool):
-    """One FusionLayer (depth=0) -> dict of 6 blobs (fusion_layer.py:131-201)."""
-    check_fusion_dims(sd, prefix)
+    """One FusionLayer / PerceiverIO (depth=0) -> dict of 6 blobs (fusion_layer.py:131-201, perceiver_io.py:139-221).
+
+    Stage order matches the kernels: ctx = Wk blocks | Wv blocks; attn = Wq'' blocks (each block's K-groups in
+    order, so a 256-wide input naturally spans two 16 KiB stages) | Wo blocks; ff = per 32-unit chunk
+    W1 value | W1 gate | W2 column block."""
+    lat, dh = fusion_dims(sd, prefix)
     a = prefix + "cross_attend_blocks.0."
     f = prefix + "cross_attend_blocks.1."
     dev = sd[a + "fn.to_q.weight"].device
-    z = torch.zeros(4 * C, device=dev)
     wkv = _f(sd[a + "fn.to_kv.weight"])
-    ctx_wst = torch.cat([p32(wkv[:DH]), p32(wkv[DH:])])
-    ctx_vec = torch.cat([_taps(sd[prefix + "cpe.proj_content.weight"], sd[prefix + "cpe.proj_content.bias"]) if pe else z,
+    ctx_wst = torch.cat([p32(wkv[:dh]), p32(wkv[dh:])])
+    ctx_vec = torch.cat([_taps(sd[prefix + "cpe.proj_content.weight"], sd[prefix + "cpe.proj_content.bias"]) if pe
+                         else torch.zeros(4 * C, device=dev),
                          _f(sd[a + "norm_context.weight"]), _f(sd[a + "norm_context.bias"])])
-    wq = _f(sd[a + "fn.to_q.weight"]) * (DH ** -0.5 * LOG2E)
+    wq = _f(sd[a + "fn.to_q.weight"]) * (dh ** -0.5 * LOG2E)
     attn_wst = torch.cat([p32(wq), p32(_f(sd[a + "fn.to_out.weight"]))])
-    attn_vec = torch.cat([_taps(sd[prefix + "cpe.proj_q.weight"], sd[prefix + "cpe.proj_q.bias"]) if pe else z,
+    attn_vec = torch.cat([_taps(sd[prefix + "cpe.proj_q.weight"], sd[prefix + "cpe.proj_q.bias"]) if pe
+                          else torch.zeros(4 * lat, device=dev),
                           _f(sd[a + "norm.weight"]), _f(sd[a + "norm.bias"]), _f(sd[a + "fn.to_out.bias"])])
     W1, b1 = _f(sd[f + "fn.net.0.weight"]), _f(sd[f + "fn.net.0.bias"])
     W2, b2 = _f(sd[f + "fn.net.2.weight"]), _f(sd[f + "fn.net.2.bias"])
     hid = W2.shape[1]
-    assert tuple(W1.shape) == (2 * hid, C) and tuple(W2.shape) == (C, hid) and hid == 4 * C
+    assert tuple(W1.shape) == (2 * hid, lat) and tuple(W2.shape) == (lat, hid) and hid == 4 * lat
     chunks = []
     for c in range(hid // 32):
         chunks += [p32(W1[32 * c:32 * c + 32]), p32(W1[hid + 32 * c:hid + 32 * c + 32]), p32(W2[:, 32 * c:32 * c + 32])]
     ff_wst = torch.cat(chunks)
     ff_vec = torch.cat([_f(sd[f + "norm.weight"]), _f(sd[f + "norm.bias"]), b1[:hid], b1[hid:], b2])
     out = {"ctx_wst": ctx_wst, "ctx_vec": ctx_vec, "attn_wst": attn_wst, "attn_vec": attn_vec,
-           "ff_wst": ff_wst, "ff_vec": ff_vec}
-    assert out["ctx_wst"].numel() == CTX_WST and out["ctx_vec"].numel() == CTX_VEC
-    assert out["attn_wst"].numel() == ATTN_WST and out["attn_vec"].numel() == ATTN_VEC
-    assert out["ff_wst"].numel() == FF_WST and out["ff_vec"].numel() == FF_VEC
-    return {k: v.contiguous() for k, v in out.items()}
+           "ff_wst": ff_wst, "ff_vec": ff_vec, "latent_dim": lat, "d_head": dh}
+    if (lat, dh) == (128, 64):
+        assert ctx_wst.numel() == CTX_WST and ctx_vec.numel() == CTX_VEC
+        assert attn_wst.numel() == ATTN_WST and attn_vec.numel() == ATTN_VEC
+        assert ff_wst.numel() == FF_WST and ff_vec.numel() == FF_VEC
+    else:
+        assert ctx_wst.numel() == 8 * 4096 and attn_wst.numel() == 16 * 4096 and ff_wst.numel() == 192 * 4096
+        assert attn_vec.numel() == 7 * 256 and ff_vec.numel() == 2816
+    return {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in out.items()}
 
 
 def pack_front(sd, layer: int, with_layer0: bool, identity_pointcn: bool = False):
@@ -174,7 +187,8 @@ class PackedEncoder:
                 self.t["f1_" + k] = v
         if "classification.0.weight" in sd:
             self.t["head_wst"], self.t["head_vec"] = pack_head(sd)
-        self.sigma_d = float(sd["sigma_spat"].reshape(-1)[0]) if "sigma_spat" in sd else 0.1
+        self.sigma_d = float(sd["sigma_spat"].detach().reshape(-1)[0]) if "sigma_spat" in sd else 0.1
+        self.sigma = float(sd["sigma"].detach().reshape(-1)[0]) if "sigma" in sd else 1.0   # read once here: no per-call host sync
         w = _lib.EncoderWeights()
         w.num_layers = num_layers
         for name in ("f1_ctx_wst", "f1_ctx_vec", "f1_attn_wst", "f1_attn_vec", "f1_ff_wst", "f1_ff_vec",

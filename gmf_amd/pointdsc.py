@@ -234,7 +234,8 @@ class PointDSC(nn.Module):
         pp.num_seeds, pp.k, pp.num_iterations = S, k, self.num_iterations
         pp.use_nms = 1 if testing else 0
         pp.refine_iters = 20 if testing else 0
-        pp.sigma, pp.sigma_d = float(self.sigma), float(self.sigma_spat)
+        pw = self._weights(feat_n.device)           # sigma / sigma_spat were read when the weights were packed
+        pp.sigma, pp.sigma_d = pw.sigma, pw.sigma_d
         pp.inlier_threshold, pp.nms_radius = float(self.inlier_threshold), float(self.nms_radius)
         pp.refine_threshold = 0.10 if self.inlier_threshold == 0.10 else 1.2      # PointDSC.py:505-508
         dev = feat_n.device

@@ -140,12 +140,16 @@ int gmf_nonlocal_block_forward(gmf_handle* h, const gmf_encoder_weights* w, int 
                                const float* feat_img, const float* pts8, const float* attention,
                                const float* image_feat_img, float* out_img, int B, int N, int T, gmf_stream_t stream);
 
-/* FusionLayer.forward with depth=0 on row-major tensors (fusion_layer.py:172-201):
- * data [B,T,128] (context), queries [B,N,128] -> out [B,N,128].  Weight blobs as for Fusion-1/2. */
-int gmf_fusion_layer_forward(gmf_handle* h, int pe, const float* ctx_wst, const float* ctx_vec, const float* attn_wst,
-                             const float* attn_vec, const float* ff_wst, const float* ff_vec, const float* data,
-                             const float* queries, long long q_sb, long long q_sr, long long q_sk, float* out,
-                             long long o_sb, long long o_sr, long long o_sk, int B, int N, int T, gmf_stream_t stream);
+/* FusionLayer.forward / PerceiverIO.forward with depth=0 (fusion_layer.py:172-201; DGR twin
+ * model/perceiver_io.py:187-221): data [B,T,128] (context, row-major), queries [B,N,latent_dim] (any strides)
+ * -> out [B,N,latent_dim].  (latent_dim, d_head) = (128, 64) is GMF-PointDSC's Fusion-1/2 and DGR's
+ * image_fusion (resunet_new.py:618-626); (256, 128) is the DGR bottleneck instance (resunet_new.py:516-525)
+ * whose to_out maps the head back to the 256-wide query.  Weight blobs: gmf_amd/packing.py. */
+int gmf_fusion_layer_forward(gmf_handle* h, int pe, int latent_dim, int d_head, const float* ctx_wst, const float* ctx_vec,
+                             const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec,
+                             const float* data, const float* queries, long long q_sb, long long q_sr, long long q_sk,
+                             float* out, long long o_sb, long long o_sr, long long o_sk, int B, int N, int T,
+                             gmf_stream_t stream);
 
 /* ---- pose head ------------------------------------------------------------------------------- */
 typedef struct gmf_pose_params {

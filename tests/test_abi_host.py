@@ -61,6 +61,18 @@ def test_state_dict_surface_matches_reference(golden_dir):
     assert {k: list(v.shape) for k, v in p.state_dict().items()} == ref["perceiver_io_128"]
 
 
+def test_wide_fusion_packing():
+    """DGR bottleneck widths (256/128/128): blob sizes match the stage counts of fusion_wide.hip."""
+    from gmf_amd import packing, synthetic
+    sd = synthetic.seeded_state_dict(synthetic.fusion_layer_shapes("", 128, 256, 128, pe=True, out_to_query=True), seed=1)
+    f = packing.pack_fusion(sd, "", pe=True)
+    assert (f["latent_dim"], f["d_head"]) == (256, 128)
+    assert f["ctx_wst"].numel() == 8 * 4096 and f["attn_wst"].numel() == 16 * 4096 and f["ff_wst"].numel() == 192 * 4096
+    bad = synthetic.seeded_state_dict(synthetic.fusion_layer_shapes("", 128, 512, 64, pe=False), seed=1)
+    with pytest.raises(NotImplementedError):
+        packing.pack_fusion(bad, "", pe=False)
+
+
 def test_unsupported_configurations_raise():
     import gmf_amd
     with pytest.raises(NotImplementedError):

@@ -100,6 +100,24 @@ def test_f2_fusion2(golden_dir, N, T):
     assert torch.equal(m(_gpu(ctx), queries_encoder=xt), y)
 
 
+@pytest.mark.parametrize("M,T", [(100, 12), (515, 300)])
+def test_f9_dgr_perceiver_256(golden_dir, M, T):
+    """DGR bottleneck instance: latent 256, context 128, one head of 128 (resunet_new.py:516-525)."""
+    g = _load(golden_dir, "f9_dgr_perceiver.npz")
+    sd = synthetic.seeded_state_dict(synthetic.fusion_layer_shapes("", 128, 256, 128, pe=True, out_to_query=True), seed=int(g["seed"]))
+    m = gmf_amd.PerceiverIO(depth=0, dim=128, latent_dim=256, cross_heads=1, latent_heads=8, cross_dim_head=128,
+                            latent_dim_head=128, pe=True)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    r = np.random.default_rng([109, M, T])
+    x = torch.from_numpy(r.normal(0, 1, (1, M, 256)).astype(np.float32))
+    ctx = torch.from_numpy(r.normal(0, 1, (1, T, 128)).astype(np.float32))
+    # the DGR call site feeds F [M,256] unsqueezed to [1,M,256] (resunet_new.py:696-699)
+    y = m(_gpu(ctx), queries_encoder=_gpu(x))
+    assert y.shape == (1, M, 256)
+    assert _maxerr(y.cpu(), g[f"out_M{M}_T{T}"]) < 1e-4
+
+
 def test_f3_nonlocal_block(golden_dir, sd_full):
     g = _load(golden_dir, "f3_nonlocal_block.npz")
     layer = int(g["layer"])

@@ -39,6 +39,51 @@ __global__ void __launch_bounds__(256, 2) k(float* out, int iters) {
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// even workgroups: MFMA only; odd workgroups: VALU only (V per slot).  With 2 workgroups per CU every SIMD
+// hosts one wave of each kind.
+template <int V, bool F32>
+__global__ void __launch_bounds__(256, 2) k_mixed(float* out, int iters) {
+  f32x16 acc = {0};
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(threadIdx.x * 0.001f + j); b[j] = (__bf16)(j * 0.01f); }
+  float fa = threadIdx.x * 0.001f, fb = 0.5f;
+  float v[8];
+  for (int j = 0; j < 8; ++j) v[j] = threadIdx.x * 0.01f + j;
+  if (blockIdx.x < 256) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int m = 0; m < 48; ++m) {
+        if (F32) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      }
+    }
+  } else {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int q = 0; q < 48 * V; ++q) v[q & 7] = fmaf(v[q & 7], 1.0001f, 0.5f);
+    }
+  }
+  float s = 0;
+  for (int j = 0; j < 8; ++j) s += v[j];
+  for (int r = 0; r < 16; ++r) s += acc[r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int V, bool F32>
+float run_mixed(float* d, int iters) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k_mixed<V, F32>), dim3(512), dim3(256), 0, 0, d, iters);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k_mixed<V, F32>), dim3(512), dim3(256), 0, 0, d, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms;
+}
+
 template <int MODE, int V, bool F32>
 float run(float* d, int blocks, int iters) {
   hipEvent_t e0, e1;
@@ -74,6 +119,14 @@ int main() {
     t = run<0, 0, true>(d, blocks, iters);  printf("f32 MFMA only             %.3f ms  (%.1f)\n", t, cyc(t));
     t = run<2, 5, true>(d, blocks, iters);  printf("f32 + 5 VALU interleaved  %.3f ms  (%.1f)\n", t, cyc(t));
     t = run<3, 5, true>(d, blocks, iters);  printf("f32 then 5 VALU phases    %.3f ms  (%.1f)\n", t, cyc(t));
+  }
+  printf("== one MFMA-only wave + one VALU-only wave per SIMD (2000 x 48 slots each) ==\n");
+  { float t;
+    t = run_mixed<5, false>(d, iters);  printf("bf16 MFMA wave || VALU wave (5/slot)   %.3f ms\n", t);
+    t = run_mixed<8, false>(d, iters);  printf("bf16 MFMA wave || VALU wave (8/slot)   %.3f ms\n", t);
+    t = run_mixed<12, false>(d, iters); printf("bf16 MFMA wave || VALU wave (12/slot)  %.3f ms\n", t);
+    t = run_mixed<5, true>(d, iters);   printf("f32  MFMA wave || VALU wave (5/slot)   %.3f ms\n", t);
+    t = run_mixed<12, true>(d, iters);  printf("f32  MFMA wave || VALU wave (12/slot)  %.3f ms\n", t);
   }
   return 0;
 }

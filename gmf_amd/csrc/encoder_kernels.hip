@@ -384,9 +384,19 @@ k_scattn(const float* __restrict__ q_img, const float* __restrict__ k_img, const
 //   and the O rescale is skipped when no row's running max moved.
 //   FASTSQRT: v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf expansion.
 // =========================================================================================
+// Correctly rounded square root for the squared distances (normal range or exactly 0): v_sqrt_f32 (1 ulp) plus
+// one FMA correction step, y' = y + (x - y*y) * (0.5 * rsq(x)).  Agrees with sqrtf bit for bit on 6.7e7 sampled
+// squared distances (tools/ubench/sqrt_check.hip; raw v_sqrt_f32 differs on 15 % of them) at 6 instructions
+// instead of the ~14 of hipcc's general sqrtf expansion (which also handles denormals and scaling).
+GMF_DEVINL float sqrt_cr(float x) {
+  const float y = __builtin_amdgcn_sqrtf(x);
+  const float hr = 0.5f * __builtin_amdgcn_rsqf(fmaxf(x, 1e-36f));
+  return fmaf(fmaf(-y, y, x), hr, y);
+}
+
 // d = ||a|| - ||b|| from the squared lengths.
-//   FASTSQRT = false: the reference's form, sqrtf(a2) - sqrtf(b2) with correctly rounded square roots
-//                     (hipcc expands each into ~14 VALU instructions).
+//   FASTSQRT = false: the reference's form, sqrt(a2) - sqrt(b2) with correctly rounded square roots (sqrt_cr),
+//                     i.e. the same roundings as torch.norm on the CPU.
 //   FASTSQRT = true : the rational form (a2 - b2) / (sqrt(a2) + sqrt(b2)).  The two lengths are nearly equal
 //                     exactly where c_ij > 0 matters, so the subtraction of two rounded square roots in the
 //                     reference form is where its error comes from; here the difference is taken on the
@@ -398,7 +408,7 @@ GMF_DEVINL float len_diff(float a2, float b2) {
     const float den = fmaxf(__builtin_amdgcn_sqrtf(a2) + __builtin_amdgcn_sqrtf(b2), 1e-30f);
     return (a2 - b2) * __builtin_amdgcn_rcpf(den);
   }
-  return sqrtf(a2) - sqrtf(b2);
+  return sqrt_cr(a2) - sqrt_cr(b2);
 }
 
 // compat * score for one element; lp points at this lane-half's first key of the tile (pts8 rows)

@@ -33,6 +33,7 @@ class EncoderWeights(C.Structure):
         ("tail_wst", _vp), ("tail_vec", _vp), ("tail_wst_stride", C.c_int), ("tail_vec_stride", C.c_int),
         ("head_wst", _vp), ("head_vec", _vp),
         ("sigma_d", C.c_float),
+        ("ff_wst_b3", _vp), ("ff_wst_b3_stride", C.c_int), ("f1_ff_wst_b3", _vp),
     ]
 
 

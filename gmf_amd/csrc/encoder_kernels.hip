@@ -73,6 +73,19 @@ GMF_DEVINL void store_block_b3(float* __restrict__ tile_base, int blk, const flo
   }
 }
 
+// fp16x2 image of a 32 x 128 tile: 16-byte unit ((plane*8 + slot)*64 + lane), planes hi | lo.
+GMF_DEVINL void store_block_h2(float* __restrict__ tile_base, int blk, const float (&t)[16], int lane) {
+  f16x8* base = reinterpret_cast<f16x8*>(tile_base);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f16x8 hi, lo;
+    split8h(&t[8 * half], hi, lo);
+    const int slot = 2 * blk + half;
+    base[(0 * 8 + slot) * 64 + lane] = hi;
+    base[(1 * 8 + slot) * 64 + lane] = lo;
+  }
+}
+
 // LCPE (fusion_layer.py:118-128): y[row] = x[row] + b + w0*x[row-1] + w1*x[row] + w2*x[row+1],
 // zero padding outside [0, n_rows).  taps = w0[C] | w1[C] | w2[C] | b[C].
 GMF_DEVINL void lcpe_frag(float (&y)[CF], const float* __restrict__ pair_base, int row, int n_rows,
@@ -105,8 +118,9 @@ GMF_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.707106
 // =========================================================================================
 // MODE 0: in = feat image, PointCN applied.  MODE 1: in = corr_pos, layer0 then PointCN.
 // MODE 2: in = feat image used as-is (stand-alone NonLocalBlock whose caller already applied PointCN).
-// B3: Q', K, V are written as bf16x3 plane images (24 KiB per tile) for k_scattn_b3.
-template <int MODE, bool B3>
+// FMT 0: Q', K (P32) and V (T image) in fp32.  FMT 1: bf16x3 plane images (24 KiB per tile) for k_scattn_b3.
+// FMT 2: fp16x2 plane images (16 KiB per tile) for k_scattn_h2.
+template <int MODE, int FMT>
 __global__ void __launch_bounds__(256, 2)
 k_front(const float* __restrict__ in, const float* __restrict__ wst, const float* __restrict__ vecs,
         float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out,
@@ -118,7 +132,7 @@ k_front(const float* __restrict__ in, const float* __restrict__ wst, const float
   const bool active = tile_raw < tiles;
   const int tile = active ? tile_raw : tiles - 1;
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
-  const size_t toff3 = ((size_t)pair * tiles + tile) * (size_t)(B3 ? kB3TileFloats : 32 * C);
+  const size_t toff3 = ((size_t)pair * tiles + tile) * (size_t)(FMT == 1 ? kB3TileFloats : 32 * C);
 
   constexpr bool FIRST = (MODE == 1);
   StageStream ss;
@@ -182,7 +196,8 @@ k_front(const float* __restrict__ in, const float* __restrict__ wst, const float
 #pragma unroll
       for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r];
       if (active) {
-        if (B3) store_block_b3(dst, mb, t, lane);
+        if (FMT == 1) store_block_b3(dst, mb, t, lane);
+        else if (FMT == 2) store_block_h2(dst, mb, t, lane);
         else store_block_p32(dst, mb, t, lane);
       }
     }
@@ -194,11 +209,12 @@ k_front(const float* __restrict__ in, const float* __restrict__ wst, const float
     mma_xw<CF>(acc, lw, f);
     const float bv = vecs[3 * C + 32 * db + i];
     if (active) {
-      if (B3) {
+      if (FMT != 0) {
         float t[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = acc[r] + bv;
-        store_block_b3(v_out + toff3, db, t, lane);
+        if (FMT == 1) store_block_b3(v_out + toff3, db, t, lane);
+        else store_block_h2(v_out + toff3, db, t, lane);
       } else {
         store_block_timg(v_out + toff3, db, acc, bv, lane);
       }
@@ -816,6 +832,195 @@ k_scattn_b3(const float* __restrict__ q_img, const float* __restrict__ k_img, co
   }
 }
 
+// k_scattn_h2: k_scattn_b3 with split-fp16 operands (two planes, three partial products, 16 KiB tiles).
+// P is scaled by 2^10 (folded into the exponent; the row sum carries the same factor, so O/l is unchanged) to keep
+// its low plane out of the fp16 subnormal range.
+// Single-buffered K | V | pts8 (33 KB) so that TWO independent 4-wave workgroups fit on a CU: the two waves
+// that share a SIMD then belong to different workgroups, are not barrier-locked to each other, and one's
+// MFMA phase runs under the other's VALU phase.  Two barriers per tile: B1 after the QK^T phase (K_t is
+// free -> K_{t+1} streams in under the softmax and PV phases), B2 after the PV phase (V_t, pts_t are free
+// -> V_{t+1}, pts_{t+1} stream in under the next QK^T phase).
+template <bool FASTSQRT, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 2)
+k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
+            const float* __restrict__ pts8, const float* __restrict__ fus, const float* __restrict__ wst,
+            const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2, int wgs_per_pair) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats + 256];
+  float* const ldsK = lds;
+  float* const ldsV = lds + kStageFloats;
+  float* const ldsP = lds + 2 * kStageFloats;
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-aware work mapping: hardware deals workgroup L to XCD L % 8, so give XCD x one contiguous run of
+  // (pair, query-block) items.  All workgroups of a pair then stream the SAME K/V tiles through ONE L2 at
+  // about the same time (each tile is fetched from HBM/MALL once per pair instead of once per workgroup).
+  // Pure speed choice: any placement computes the same result.
+  int pair, qblock;
+  {
+    const int total = gridDim.x, L = blockIdx.x;
+    const int chunk = total >> 3, rem = total & 7, xcd = L & 7, kth = L >> 3;
+    const int start = (xcd < rem) ? xcd * (chunk + 1) : rem * (chunk + 1) + (xcd - rem) * chunk;
+    const int logical = start + kth;
+    pair = logical / wgs_per_pair;
+    qblock = logical - pair * wgs_per_pair;
+  }
+  const int tile_raw = qblock * WAVES + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t pbase = (size_t)pair * tiles;
+  const size_t toff = (pbase + tile) * (32 * C);
+
+  f16x8 qh[8], ql[8];
+  {
+    const f16x8* qp = reinterpret_cast<const f16x8*>(q_img + (pbase + tile) * (size_t)kStageFloats) + lane;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { qh[s] = qp[(0 * 8 + s) * 64]; ql[s] = qp[(1 * 8 + s) * 64]; }
+  }
+  float si[3], ti[3];
+  {
+    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)tile * 32 + i) * 8);
+    const float4 a = pp[0], b = pp[1];
+    si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
+  }
+  const float* gk = k_img + pbase * (size_t)kStageFloats;
+  const float* gv = v_img + pbase * (size_t)kStageFloats;
+  const float* gp = pts8 + pbase * 32 * 8;
+  auto issueK = [&](int t) { dma_issue(gk + (size_t)t * kStageFloats, ldsK, 16, wave, WAVES, lane); };
+  auto issueV = [&](int t) {
+    dma_issue(gv + (size_t)t * kStageFloats, ldsV, 16, wave, WAVES, lane);
+    if (wave == (t & (WAVES - 1))) dma_piece_1k(gp + (size_t)t * 256, ldsP, lane);
+  };
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
+  float m_run = -INFINITY, l_half = 0.f;
+  const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK) + lane;
+  const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV) + lane;
+  const float4* lp = reinterpret_cast<const float4*>(ldsP) + 8 * h;
+
+  issueK(0);
+  issueV(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < tiles; ++t) {
+    // ---- S^T = K_t Q'^T : 8 k-steps x 6 partial products ----
+    f32x16 sacc = zero16();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const f16x8 kh = lk[(0 * 8 + s) * 64], kl = lk[(1 * 8 + s) * 64];
+      mma3(sacc, kh, kl, qh[s], ql[s]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V_t, pts_t (issued one phase ago) have landed
+    __syncthreads();                     // B1: every wave is done reading K_t
+    if (t + 1 < tiles) issueK(t + 1);
+    // ---- compat, scores, online softmax ----
+    float x[16];
+    float mx = -INFINITY;
+    if (t + 1 < tiles) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jl = 8 * (r >> 2) + (r & 3);
+        x[r] = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
+        mx = fmaxf(mx, x[r]);
+      }
+    } else {
+      const int jbase = t * 32 + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jl = 8 * (r >> 2) + (r & 3);
+        const float v = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
+        x[r] = (jbase + jl < N) ? v : -INFINITY;
+        mx = fmaxf(mx, x[r]);
+      }
+    }
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const bool moved = m_new > m_run;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float ls = 0.f;
+    const float m_off = m_new - 10.0f;   // P' = 2^10 P
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
+    l_half = fmaf(l_half, alpha, ls);
+    if (__any(moved)) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
+    // ---- O^T += V_t^T P^T : P planes straight from the accumulator registers ----
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f16x8 ph, pl;
+      split8h(&x[8 * s2], ph, pl);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int slot = 2 * db + s2;
+        const f16x8 vh = lv[(0 * 8 + slot) * 64], vl = lv[(1 * 8 + slot) * 64];
+        mma3(oacc[db], vh, vl, ph, pl);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K_{t+1} (issued two phases ago) has landed
+    __syncthreads();                     // B2: every wave is done reading V_t, pts_t
+    if (t + 1 < tiles) issueV(t + 1);
+  }
+
+  // ---- epilogue: normalise, fc_message (fp32 MFMA), add the Fusion-2 branch ----
+  float o[CF];
+  {
+    const float inv = 1.0f / xhalf_sum(l_half);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
+  }
+  __syncthreads();
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5);
+  ss.prime();
+  float m1[DHF], m2[DHF];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_wx<CF>(acc, lw, o);
+    float b[16];
+    load_vec_block(b, vecs, mb, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+  }
+  {
+    const float4* lw = ss.acquire();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      f32x16 acc = zero16();
+      mma_wx<DHF>(acc, lw + mb * (32 * DH / 4), m1);
+      float b[16];
+      load_vec_block(b, vecs + 64, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const float4* lw = ss.acquire();
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int mb = 2 * st + hb;
+      f32x16 acc = zero16();
+      mma_wx<DHF>(acc, lw + hb * (32 * DH / 4), m2);
+      float b[16], fz[16], t[16];
+      load_vec_block(b, vecs + 128, mb, h);
+      load_block_p32(fz, fus + toff, mb, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r] + fz[r];
+      if (active) store_block_p32(out + toff, mb, t, lane);
+    }
+  }
+}
+
 // =========================================================================================
 // k_scattn_b3p: k_scattn_b3 with the tile loop software-pipelined inside each wave.
 //   K tiles run one tile ahead of V / pts8 in the LDS double buffers.  Phase 1 issues the 48 MFMAs of
@@ -1298,6 +1503,85 @@ k_fusion_ff(const float* __restrict__ x1, const float* __restrict__ wst, const f
 }
 
 // =========================================================================================
+// k_fusion_ff_b3: k_fusion_ff on the bf16 MFMA with split-bf16 operands (fp32-equivalent accuracy).
+//   Weights arrive pre-split (three bf16 planes per 32-output block, 24 KiB per stage); LayerNorm output and
+//   the GEGLU product are split in registers.  144 MFMAs of 32 cycles per 32-unit chunk instead of 192 of 64.
+//   stages (48 x 24 KiB): for c in 0..15: W1a_c | W1g_c | W2_c (4 blocks of 32 x 32)
+// =========================================================================================
+__global__ void __launch_bounds__(256, 2)
+k_fusion_ff_b3(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
+               float* __restrict__ x2_out, int tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kB3TileFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+
+  StageStream ss;
+  ss.stage_floats = kB3TileFloats;
+  ss.init(lds, lds + kB3TileFloats, wave, kWavesPerWG, lane, wst, 3 * (FFH / 32));
+  ss.prime();
+
+  bf16x8 xh[8], xm[8], xl[8];
+  {
+    float x[CF], xn[CF];
+    load_frag_p32<CF>(x, x1 + toff, lane);
+    layernorm_frag<CF>(xn, x, vecs, vecs + C, h);
+    split_frag<CF>(xn, xh, xm, xl);
+  }
+  f32x16 y[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) y[mb] = zero16();
+  const float* b1a = vecs + 2 * C;
+  const float* b1g = vecs + 2 * C + FFH;
+
+  for (int c = 0; c < FFH / 32; ++c) {
+    float ga[16];
+    {
+      const bf16x8* lw = reinterpret_cast<const bf16x8*>(ss.acquire());
+      f32x16 acc = zero16();
+      mma_wx_b3<8>(acc, lw, xh, xm, xl);
+      float b[16];
+      load_vec_block(b, b1a, c, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ga[r] = acc[r] + b[r];
+    }
+    {
+      const bf16x8* lw = reinterpret_cast<const bf16x8*>(ss.acquire());
+      f32x16 acc = zero16();
+      mma_wx_b3<8>(acc, lw, xh, xm, xl);
+      float b[16];
+      load_vec_block(b, b1g, c, h);
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {      // erff in groups of four: bounds the live temporaries (no spills)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ga[4 * r4 + e] *= gelu_erf(acc[4 * r4 + e] + b[4 * r4 + e]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    {
+      bf16x8 gh[2], gm[2], gl[2];
+      split_frag<16>(ga, gh, gm, gl);
+      const bf16x8* lw = reinterpret_cast<const bf16x8*>(ss.acquire());
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) mma_wx_b3<2>(y[mb], lw + mb * (3 * 2 * 64), gh, gm, gl);
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    float b[16], xr[16], t[16];
+    load_vec_block(b, vecs + 2 * C + 2 * FFH, mb, h);
+    load_block_p32(xr, x1 + toff, mb, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = y[mb][r] + b[r] + xr[r];
+    if (active) store_block_p32(x2_out + toff, mb, t, lane);
+  }
+}
+
+// =========================================================================================
 // k_head: classifier 128->32 ReLU ->32 ReLU ->1 and row L2 normalisation.
 //   stages (2): Wc1 (32x128) | Wc2 (32x32, padded)     vecs: b1[32] | b2[32] | w3[32] | b3
 //   outputs (row-major, the layout the pose head and the caller consume):
@@ -1481,7 +1765,7 @@ __global__ void k_pack_pts8(const float* __restrict__ src, const float* __restri
 
 namespace gmf {
 
-static int g_scattn_variant = [] { const char* e = getenv("GMF_SCATTN"); return e ? atoi(e) : 3; }();
+static int g_scattn_variant = [] { const char* e = getenv("GMF_SCATTN"); return e ? atoi(e) : 9; }();
 static bool g_force_fp32_qkv = false;   // set while the dense-compat (drop-in NonLocalBlock) path runs
 void set_force_fp32_qkv(bool v) { g_force_fp32_qkv = v; }
 void set_scattn_variant(int v) { g_scattn_variant = v; }
@@ -1491,16 +1775,12 @@ static inline dim3 tile_grid(int tiles, int B, int sets = 1) { return dim3((tile
 
 hipError_t launch_front(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
                         float* v, int B, int N, int tiles, hipStream_t s) {
-  const bool b3 = (g_scattn_variant >= 3) && !g_force_fp32_qkv;
-  if (b3) {
-    if (mode == 1) hipLaunchKernelGGL((k_front<1, true>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
-    else if (mode == 2) hipLaunchKernelGGL((k_front<2, true>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
-    else hipLaunchKernelGGL((k_front<0, true>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
-  } else {
-    if (mode == 1) hipLaunchKernelGGL((k_front<1, false>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
-    else if (mode == 2) hipLaunchKernelGGL((k_front<2, false>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
-    else hipLaunchKernelGGL((k_front<0, false>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
-  }
+  const int fmt = g_force_fp32_qkv ? 0 : (g_scattn_variant == 9 || g_scattn_variant == 10) ? 2 : (g_scattn_variant >= 3) ? 1 : 0;
+#define GMF_LAUNCH_FRONT(M, F) hipLaunchKernelGGL((k_front<M, F>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles)
+  if (fmt == 1) { if (mode == 1) GMF_LAUNCH_FRONT(1, 1); else if (mode == 2) GMF_LAUNCH_FRONT(2, 1); else GMF_LAUNCH_FRONT(0, 1); }
+  else if (fmt == 2) { if (mode == 1) GMF_LAUNCH_FRONT(1, 2); else if (mode == 2) GMF_LAUNCH_FRONT(2, 2); else GMF_LAUNCH_FRONT(0, 2); }
+  else { if (mode == 1) GMF_LAUNCH_FRONT(1, 0); else if (mode == 2) GMF_LAUNCH_FRONT(2, 0); else GMF_LAUNCH_FRONT(0, 0); }
+#undef GMF_LAUNCH_FRONT
   return hipGetLastError();
 }
 
@@ -1509,7 +1789,9 @@ hipError_t launch_scattn(const float* q, const float* k, const float* v, const f
                          hipStream_t s) {
   // GMF_SCATTN / gmf_set_tuning("scattn_variant") selects the kernel form for A/B measurements:
   // 0 = fp32 MFMA, two-phase loop; 1 = fp32 MFMA, software-pipelined; 2 = 1 with v_sqrt_f32;
-  // 3 = split-bf16 MFMA (default); 4 = 3 with v_sqrt_f32.
+  // 3 = split-bf16 (3 planes, 6 products) MFMA; 4 = 3 with the rational compat form; 5/6 = 3/4 software-pipelined,
+  // 8 waves; 7/8 = 3/4 with 8-wave workgroups; 9 = split-fp16 (2 planes, 3 products) MFMA (default);
+  // 10 = 9 with the rational compat form; 11..15 = timing-only ablations of 4.
   const int variant = g_scattn_variant;
   const float inv = 1.0f / (sigma_d * sigma_d);
   if (variant >= 3) {
@@ -1528,6 +1810,8 @@ hipError_t launch_scattn(const float* q, const float* k, const float* v, const f
         default: hipLaunchKernelGGL((k_scattn_b3<true, 4, 5>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp); break;
       }
     }
+    else if (variant == 9) hipLaunchKernelGGL((k_scattn_h2<false, 4>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
+    else if (variant == 10) hipLaunchKernelGGL((k_scattn_h2<true, 4>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
     else if (variant == 7) hipLaunchKernelGGL((k_scattn_b3<false, 8>), grid8, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp8);
     else if (variant == 8) hipLaunchKernelGGL((k_scattn_b3<true, 8>), grid8, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp8);
     else if (variant == 5) hipLaunchKernelGGL(k_scattn_b3p<false>, grid, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
@@ -1563,6 +1847,11 @@ hipError_t launch_fusion_attn(bool pe, const float* x, const float* ctx_img, con
 
 hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s) {
   hipLaunchKernelGGL(k_fusion_ff, tile_grid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_fusion_ff_b3(const float* x1, const float* wst_b3, const float* vecs, float* x2, int B, int tiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_fusion_ff_b3, tile_grid(tiles, B), dim3(256), 0, s, x1, wst_b3, vecs, x2, tiles);
   return hipGetLastError();
 }
 

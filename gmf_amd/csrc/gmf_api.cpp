@@ -113,7 +113,7 @@ int gmf_create(int device, gmf_handle** out) {
 int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
   GMF_REQUIRE(h && name, GMF_ERR_BAD_ARG, "set_tuning: null pointer");
   if (std::strcmp(name, "scattn_variant") == 0) {
-    GMF_REQUIRE(value >= 0 && value <= 15, GMF_ERR_BAD_ARG, "set_tuning: scattn_variant out of range");
+    GMF_REQUIRE(value >= 0 && value <= 15, GMF_ERR_BAD_ARG, "set_tuning: scattn_variant out of range (0..15)");
     gmf::set_scattn_variant(value);
     return GMF_OK;
   }
@@ -266,8 +266,12 @@ static int run_block_tail(gmf_handle* h, const gmf_encoder_weights* w, int l, co
   const int tiles = tiles_of(N), tt = tiles_of(T);
   GMF_HIP(gmf::launch_fusion_attn(true, f, ctx_l, w->attn_wst + (size_t)l * w->attn_wst_stride,
                                   w->attn_vec + (size_t)l * w->attn_vec_stride, x1, B, N, tiles, T, tt, st));
-  GMF_HIP(gmf::launch_fusion_ff(x1, w->ff_wst + (size_t)l * w->ff_wst_stride, w->ff_vec + (size_t)l * w->ff_vec_stride,
-                                x2, B, tiles, st));
+  if (w->ff_wst_b3)
+    GMF_HIP(gmf::launch_fusion_ff_b3(x1, w->ff_wst_b3 + (size_t)l * w->ff_wst_b3_stride,
+                                     w->ff_vec + (size_t)l * w->ff_vec_stride, x2, B, tiles, st));
+  else
+    GMF_HIP(gmf::launch_fusion_ff(x1, w->ff_wst + (size_t)l * w->ff_wst_stride, w->ff_vec + (size_t)l * w->ff_vec_stride,
+                                  x2, B, tiles, st));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (h->profile) {
     if (h->prof_used == h->prof_events.size()) {
@@ -330,7 +334,8 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   GMF_HIP(gmf::launch_pack_p32(q_tokens, qimg, B, T, kC, (long)T * kC, kC, 1, st));
   GMF_HIP(gmf::launch_ctx_prep(false, pimg, w->f1_ctx_wst, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st));
   GMF_HIP(gmf::launch_fusion_attn(false, qimg, f1ctx, w->f1_attn_wst, w->f1_attn_vec, x1t, B, T, tt, T, tt, st));
-  GMF_HIP(gmf::launch_fusion_ff(x1t, w->f1_ff_wst, w->f1_ff_vec, imgfeat, B, tt, st));
+  if (w->f1_ff_wst_b3) GMF_HIP(gmf::launch_fusion_ff_b3(x1t, w->f1_ff_wst_b3, w->f1_ff_vec, imgfeat, B, tt, st));
+  else GMF_HIP(gmf::launch_fusion_ff(x1t, w->f1_ff_wst, w->f1_ff_vec, imgfeat, B, tt, st));
   // context side of all L Fusion-2 layers in one launch
   if (L > 0)
     GMF_HIP(gmf::launch_ctx_prep(true, imgfeat, w->ctx_wst, w->ctx_vec, ctxall, B, T, tt, L, w->ctx_wst_stride,

@@ -19,6 +19,7 @@ hipError_t launch_ctx_prep(bool pe, const float* ctx, const float* wst, const fl
 hipError_t launch_fusion_attn(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
                               float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
 hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
+hipError_t launch_fusion_ff_b3(const float* x1, const float* wst_b3, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
 hipError_t launch_head(const float* feat_img, const float* wst, const float* vecs, float* logits, float* feat_n,
                        float* feat_rm, int B, int N, int tiles, hipStream_t s);
 hipError_t launch_ctx_prep_w(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,

@@ -83,6 +83,52 @@ GMF_DEVINL void mma6(f32x16& acc, bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf
   acc = mfma_b16(ah, bh, acc);
 }
 
+// a K-wide row fragment (K/2 floats) -> K/16 k-steps of three planes
+template <int KF>
+GMF_DEVINL void split_frag(const float (&x)[KF], bf16x8 (&hi)[KF / 8], bf16x8 (&mi)[KF / 8], bf16x8 (&lo)[KF / 8]) {
+#pragma unroll
+  for (int s = 0; s < KF / 8; ++s) split8(&x[8 * s], hi[s], mi[s], lo[s]);
+}
+
+// acc += Wb3(32 x K) * X^T with the weight block as a bf16x3 image in LDS: 16-byte unit ((plane*NS + s)*64 + lane)
+template <int NS>
+GMF_DEVINL void mma_wx_b3(f32x16& acc, const bf16x8* lw, const bf16x8 (&xh)[NS], const bf16x8 (&xm)[NS], const bf16x8 (&xl)[NS]) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    mma6(acc, lw[(0 * NS + s) * 64], lw[(1 * NS + s) * 64], lw[(2 * NS + s) * 64], xh[s], xm[s], xl[s]);
+}
+
+// ---- split-fp16 ("fp16x2") arithmetic ------------------------------------------------------------
+// x = xh + xl with two fp16 planes (11 + 11 significant bits, round-to-nearest-even: |x - xh - xl| <= 2^-22 |x|)
+// and three partial products hh, hl, lh (the dropped l*l term is <= 2^-22 |ab|).  Per-term error ~2.4e-7 worst
+// case - below the fp32 accumulation noise of a 128-term dot product - at 3/16 of the fp32-MFMA cycles, with
+// operand images the size of the fp32 ones (4 B per element).  Ranges: |x| < 65504; low parts that fall into the
+// fp16 subnormal range keep an absolute error <= 3e-8.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+GMF_DEVINL f32x16 mfma_h16(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+GMF_DEVINL void split8h(const float* v, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const f32x2 x = {v[j], v[j + 1]};
+    const f16x2 hh = __builtin_convertvector(x, f16x2);
+    const f32x2 r1 = x - __builtin_convertvector(hh, f32x2);
+    const f16x2 ll = __builtin_convertvector(r1, f16x2);
+    hi[j] = hh[0]; hi[j + 1] = hh[1];
+    lo[j] = ll[0]; lo[j + 1] = ll[1];
+  }
+}
+
+GMF_DEVINL void mma3(f32x16& acc, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
+  acc = mfma_h16(al, bh, acc);
+  acc = mfma_h16(ah, bl, acc);
+  acc = mfma_h16(ah, bh, acc);
+}
+
 constexpr int kB3TileFloats = 3 * 8 * 64 * 4;   // one 32 x 128 tile as three bf16 planes = 24 KiB
 
 GMF_DEVINL f32x16 zero16() {
@@ -218,6 +264,7 @@ GMF_DEVINL void dma_issue(const float* __restrict__ gsrc, float* lds_dst, int n_
 struct StageStream {
   const float* seg_ptr[3];
   int seg_end[3];   // cumulative stage counts
+  int stage_floats = kStageFloats;   // 4096 (16 KiB fp32 image) or kB3TileFloats (24 KiB bf16x3 image)
   float* buf0;
   float* buf1;
   int issued;       // stages issued so far
@@ -236,10 +283,10 @@ struct StageStream {
   GMF_DEVINL void issue_one() {
     if (issued < total) {
       const float* g;
-      if (issued < seg_end[0]) g = seg_ptr[0] + (size_t)issued * kStageFloats;
-      else if (issued < seg_end[1]) g = seg_ptr[1] + (size_t)(issued - seg_end[0]) * kStageFloats;
-      else g = seg_ptr[2] + (size_t)(issued - seg_end[1]) * kStageFloats;
-      dma_issue(g, (issued & 1) ? buf1 : buf0, 16, wave, n_waves, lane);
+      if (issued < seg_end[0]) g = seg_ptr[0] + (size_t)issued * stage_floats;
+      else if (issued < seg_end[1]) g = seg_ptr[1] + (size_t)(issued - seg_end[0]) * stage_floats;
+      else g = seg_ptr[2] + (size_t)(issued - seg_end[1]) * stage_floats;
+      dma_issue(g, (issued & 1) ? buf1 : buf0, stage_floats / 256, wave, n_waves, lane);
       ++issued;
     }
   }

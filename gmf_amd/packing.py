@@ -43,6 +43,47 @@ def p32(W: torch.Tensor) -> torch.Tensor:
     return W.reshape(M // 32, 32, K // 8, 2, 4).permute(0, 2, 3, 1, 4).reshape(-1)
 
 
+def _b3_index(K: int, device):
+    """Feature index visited by (k-step s, K-half h, element j) of a K-wide fragment: f = 8s + j is the fragment
+    index, feature = 32*(f >> 4) + 8*((f & 15) >> 2) + 4h + (f & 3)   (gmf_amd/csrc/mfma_core.hpp)."""
+    s_ = torch.arange(K // 16, device=device)[:, None, None]
+    h_ = torch.arange(2, device=device)[None, :, None]
+    j_ = torch.arange(8, device=device)[None, None, :]
+    f = 8 * s_ + j_
+    return 32 * (f >> 4) + 8 * ((f & 15) >> 2) + 4 * h_ + (f & 3)          # [K/16, 2, 8]
+
+
+def p32_b3(W: torch.Tensor) -> torch.Tensor:
+    """[M, K] fp32 (M % 32 == 0, K % 16 == 0) -> flat split-bf16 image, returned as float32 words.
+
+    Per 32-output block: [plane hi|mid|lo][k-step][lane = (h, i)][8 bf16]; W = hi + mid + lo with round-to-nearest-even
+    conversions (torch's .to(bfloat16) = v_cvt_pk_bf16_f32)."""
+    M, K = W.shape
+    assert M % 32 == 0 and K % 16 == 0, (M, K)
+    hi = W.to(torch.bfloat16)
+    r1 = W - hi.float()
+    mi = r1.to(torch.bfloat16)
+    lo = (r1 - mi.float()).to(torch.bfloat16)
+    idx = _b3_index(K, W.device)                                            # [S, 2, 8]
+    planes = torch.stack([hi, mi, lo])                                      # [3, M, K]
+    g = planes[:, :, idx]                                                   # [3, M, S, 2, 8]
+    g = g.reshape(3, M // 32, 32, K // 16, 2, 8).permute(1, 0, 3, 4, 2, 5)  # [mb, plane, S, h, i, 8]
+    return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
+
+
+def pack_ff_b3(sd, prefix: str) -> torch.Tensor:
+    """GEGLU feed-forward weights of one FusionLayer (128-wide) as 48 bf16x3 stages of 24 KiB."""
+    f = prefix + "cross_attend_blocks.1."
+    W1, W2 = _f(sd[f + "fn.net.0.weight"]), _f(sd[f + "fn.net.2.weight"])
+    hid = W2.shape[1]
+    chunks = []
+    for c in range(hid // 32):
+        chunks += [p32_b3(W1[32 * c:32 * c + 32]), p32_b3(W1[hid + 32 * c:hid + 32 * c + 32]), p32_b3(W2[:, 32 * c:32 * c + 32])]
+    out = torch.cat(chunks)
+    assert out.numel() == 48 * 6144
+    return out.contiguous()
+
+
 def fold_bn(W, b, sd, p, eps=1e-5):
     """conv1x1 (W [out,in], b) followed by eval BatchNorm `p` -> equivalent (W', b')."""
     scale = sd[p + "weight"] * torch.rsqrt(sd[p + "running_var"] + eps)
@@ -185,6 +226,10 @@ class PackedEncoder:
         if f1 is not None:
             for k, v in f1.items():
                 self.t["f1_" + k] = v
+            self.t["f1_ff_wst_b3"] = pack_ff_b3(sd, "encoder.fusion_layer_1.")
+        if num_layers > 0:
+            self.t["ff_wst_b3"] = torch.stack([pack_ff_b3(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.")
+                                               for i in range(num_layers)]).contiguous()
         if "classification.0.weight" in sd:
             self.t["head_wst"], self.t["head_vec"] = pack_head(sd)
         self.sigma_d = float(sd["sigma_spat"].detach().reshape(-1)[0]) if "sigma_spat" in sd else 0.1
@@ -201,4 +246,7 @@ class PackedEncoder:
         w.front_wst_stride, w.front_vec_stride = FRONT_WST, FRONT_VEC
         w.tail_wst_stride, w.tail_vec_stride = TAIL_WST, TAIL_VEC
         w.sigma_d = self.sigma_d
+        w.ff_wst_b3 = self.t["ff_wst_b3"].data_ptr() if "ff_wst_b3" in self.t else None
+        w.ff_wst_b3_stride = 48 * 6144
+        w.f1_ff_wst_b3 = self.t["f1_ff_wst_b3"].data_ptr() if "f1_ff_wst_b3" in self.t else None
         self.struct = w

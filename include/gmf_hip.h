@@ -50,11 +50,13 @@ const char* gmf_last_error_string(gmf_handle* h);
 long long gmf_workspace_bytes(gmf_handle* h);
 
 /* Process-wide tuning knobs for A/B measurements (results are identical up to rounding):
- *   "scattn_variant": 0 = fp32-MFMA attention, two-phase loop; 1 = fp32 MFMA, software-pipelined;
- *                     2 = 1 with v_sqrt_f32 (1 ulp) in the compatibility term;
- *                     3 = split-bf16 MFMA, fp32-equivalent accuracy (default); 4 = 3 with v_sqrt_f32.
- *   With variants >= 3 gmf_front_forward writes Q', K, V as bf16x3 plane images of 24 KiB per 32-row tile
- *   (the q, k, v buffers must hold 1.5x the fp32 image size). */
+ *   "scattn_variant": 0 = fp32-MFMA attention, two-phase loop; 1 = fp32 MFMA, software-pipelined; 2 = 1 with the
+ *                     rational form of the compatibility term; 3 = split-bf16 MFMA (3 planes, 6 products);
+ *                     4 = 3 with the rational form; 5..8 = structural variants of 3/4 (pipelined, 8-wave);
+ *                     9 = split-fp16 MFMA (2 planes, 3 products; default); 10 = 9 with the rational form;
+ *                     11..15 = timing-only ablations (wrong results).
+ *   With variants 3..8 gmf_front_forward writes Q', K, V as bf16x3 plane images of 24 KiB per 32-row tile (the
+ *   q, k, v buffers must hold 1.5x the fp32 image size); with 9/10 as fp16x2 plane images of 16 KiB per tile. */
 int gmf_set_tuning(gmf_handle* h, const char* name, int value);
 
 /* In-situ timing of the dominant kernel (the spatial-consistency attention): while enabled, every
@@ -124,6 +126,10 @@ typedef struct gmf_encoder_weights {
   const float* tail_wst;    const float* tail_vec;  int tail_wst_stride,  tail_vec_stride;  /* fc_message */
   const float* head_wst;    const float* head_vec;
   float sigma_d;
+  /* optional split-bf16 (bf16x3) images of the GEGLU feed-forward weights: 48 stages of 24 KiB per layer.
+   * When non-NULL the feed-forward runs on the bf16 MFMA (fp32-equivalent accuracy, 2.7x fewer MFMA cycles). */
+  const float* ff_wst_b3;   int ff_wst_b3_stride;
+  const float* f1_ff_wst_b3;
 } gmf_encoder_weights;
 
 /* PointDSC.forward up to the logits (PointDSC.py:216-241) with image TOKENS as input:

@@ -1,0 +1,103 @@
+// Constants and small device helpers shared by the encoder kernel files.
+#pragma once
+#include "mfma_core.hpp"
+
+namespace gmf {
+
+constexpr int C = 128;        // correspondence feature width
+constexpr int CF = C / 2;     // fragment length of a C-wide row
+constexpr int DH = 64;        // cross-attention head width (PointDSC: C/2)
+constexpr int DHF = DH / 2;
+constexpr int FFH = 512;      // GEGLU hidden width (4*C)
+constexpr int kWavesPerWG = 4;
+
+// ---- small helpers ---------------------------------------------------------------------
+// bias (or any per-feature vector) for out-block mb in fragment order
+GMF_DEVINL void load_vec_block(float (&v)[16], const float* __restrict__ vec, int mb, int h) {
+  const float4* p = reinterpret_cast<const float4*>(vec + 32 * mb) + h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 t = p[2 * q];
+    v[4 * q + 0] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
+}
+
+// store a Y^T block (16 regs, rows on lanes) as the P32 columns [32mb, 32mb+32) of a K-wide tile
+GMF_DEVINL void store_block_p32(float* __restrict__ tile_base, int mb, const float (&t)[16], int lane) {
+  float4* p = reinterpret_cast<float4*>(tile_base) + (4 * mb) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p[q * 64] = make_float4(t[4 * q + 0], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+}
+
+GMF_DEVINL void load_block_p32(float (&t)[16], const float* __restrict__ tile_base, int mb, int lane) {
+  const float4* p = reinterpret_cast<const float4*>(tile_base) + (4 * mb) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = p[q * 64];
+    t[4 * q + 0] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w;
+  }
+}
+
+// store a Y block (feature on lane) as d-block db of a T image tile
+GMF_DEVINL void store_block_timg(float* __restrict__ tile_base, int db, const f32x16& a, float bias, int lane) {
+  float4* p = reinterpret_cast<float4*>(tile_base) + (4 * db) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    p[q * 64] = make_float4(a[4 * q + 0] + bias, a[4 * q + 1] + bias, a[4 * q + 2] + bias, a[4 * q + 3] + bias);
+}
+
+// bf16x3 image of a 32 x 128 tile: 16-byte unit index ((plane*8 + slot)*64 + lane); slot = MFMA k-step.
+// Y^T block mb (rows on lanes) fills slots 2mb, 2mb+1; a T-layout block db fills slots 2db, 2db+1.
+GMF_DEVINL void store_block_b3(float* __restrict__ tile_base, int blk, const float (&t)[16], int lane) {
+  bf16x8* base = reinterpret_cast<bf16x8*>(tile_base);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    bf16x8 hi, mi, lo;
+    split8(&t[8 * half], hi, mi, lo);
+    const int slot = 2 * blk + half;
+    base[(0 * 8 + slot) * 64 + lane] = hi;
+    base[(1 * 8 + slot) * 64 + lane] = mi;
+    base[(2 * 8 + slot) * 64 + lane] = lo;
+  }
+}
+
+// fp16x2 image of a 32 x 128 tile: 16-byte unit ((plane*8 + slot)*64 + lane), planes hi | lo.
+GMF_DEVINL void store_block_h2(float* __restrict__ tile_base, int blk, const float (&t)[16], int lane) {
+  f16x8* base = reinterpret_cast<f16x8*>(tile_base);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f16x8 hi, lo;
+    split8h(&t[8 * half], hi, lo);
+    const int slot = 2 * blk + half;
+    base[(0 * 8 + slot) * 64 + lane] = hi;
+    base[(1 * 8 + slot) * 64 + lane] = lo;
+  }
+}
+
+// LCPE (fusion_layer.py:118-128): y[row] = x[row] + b + w0*x[row-1] + w1*x[row] + w2*x[row+1],
+// zero padding outside [0, n_rows).  taps = w0[C] | w1[C] | w2[C] | b[C].
+GMF_DEVINL void lcpe_frag(float (&y)[CF], const float* __restrict__ pair_base, int row, int n_rows,
+                          const float* __restrict__ taps, int h) {
+  const float4* base = reinterpret_cast<const float4*>(pair_base);
+  const bool has_m = row >= 1, has_p = row + 1 < n_rows;
+  const int rm = has_m ? row - 1 : row, rp = has_p ? row + 1 : row;
+  const float4* pc = base + (size_t)(row >> 5) * (CF / 4) * 64 + h * 32 + (row & 31);
+  const float4* pm = base + (size_t)(rm >> 5) * (CF / 4) * 64 + h * 32 + (rm & 31);
+  const float4* pp = base + (size_t)(rp >> 5) * (CF / 4) * 64 + h * 32 + (rp & 31);
+  const float4* t0 = reinterpret_cast<const float4*>(taps) + h;
+  const float fm = has_m ? 1.f : 0.f, fp = has_p ? 1.f : 0.f;
+#pragma unroll
+  for (int g = 0; g < CF / 4; ++g) {
+    const float4 xc = pc[g * 64], xm = pm[g * 64], xp = pp[g * 64];
+    const float4 w0 = t0[2 * g], w1 = t0[2 * g + C / 4], w2 = t0[2 * g + 2 * (C / 4)], b = t0[2 * g + 3 * (C / 4)];
+    y[4 * g + 0] = xc.x + b.x + w0.x * (fm * xm.x) + w1.x * xc.x + w2.x * (fp * xp.x);
+    y[4 * g + 1] = xc.y + b.y + w0.y * (fm * xm.y) + w1.y * xc.y + w2.y * (fp * xp.y);
+    y[4 * g + 2] = xc.z + b.z + w0.z * (fm * xm.z) + w1.z * xc.z + w2.z * (fp * xp.z);
+    y[4 * g + 3] = xc.w + b.w + w0.w * (fm * xm.w) + w1.w * xc.w + w2.w * (fp * xp.w);
+  }
+}
+
+GMF_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+
+}  // namespace gmf

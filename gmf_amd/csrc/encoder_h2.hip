@@ -1,0 +1,435 @@
+// Linear stages of the encoder on the f16 MFMA with split-fp16 operands ("fp16x2": two planes, three partial
+// products, fp32 accumulate; arithmetic notes in mfma_core.hpp).  Same math, same fusion and same blob/stage
+// sizes as the fp32-MFMA kernels in encoder_kernels.hip - a 32 x K weight block is 4 B per element either way -
+// but 8 x 3 MFMAs of 32 cycles per 32 x 128 block instead of 64 MFMAs of 64 cycles.
+//   k_front_h2        PointDSC.py:88,104-109,56-58     [layer0] + PointCN + Q'/K/V projections -> fp16x2 images
+//   k_fusion_attn_h2  fusion_layer.py:119-121,44,84-94,190
+//   k_fusion_ff_h2    fusion_layer.py:54-69,191
+//   k_ctx_prep_h2     fusion_layer.py:124-126,46-49,86-87
+#include "enc_common.hpp"
+#include "launchers.hpp"
+
+namespace gmf {
+
+// a row fragment as two fp16 planes: NS = K/16 k-steps
+template <int NS>
+struct FragH2 {
+  f16x8 h[NS], l[NS];
+  GMF_DEVINL void set(const float* x) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) split8h(x + 8 * s, h[s], l[s]);
+  }
+  // fill k-steps [2*blk, 2*blk+2) from one 32-wide block of accumulators / fragment values
+  GMF_DEVINL void set_block(int blk, const float (&t)[16]) {
+    split8h(&t[0], h[2 * blk], l[2 * blk]);
+    split8h(&t[8], h[2 * blk + 1], l[2 * blk + 1]);
+  }
+};
+
+// acc += W(32 x 16*NS) * X^T   (rows on lanes); weight block image: 16-byte unit ((plane*NS + s)*64 + lane)
+template <int NS>
+GMF_DEVINL void mma_wx_h2(f32x16& acc, const f16x8* lw, const FragH2<NS>& x) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) mma3(acc, lw[(0 * NS + s) * 64], lw[(1 * NS + s) * 64], x.h[s], x.l[s]);
+}
+
+// acc += X * W^T   (feature on lane)
+template <int NS>
+GMF_DEVINL void mma_xw_h2(f32x16& acc, const f16x8* lw, const FragH2<NS>& x) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) mma3(acc, x.h[s], x.l[s], lw[(0 * NS + s) * 64], lw[(1 * NS + s) * 64]);
+}
+
+GMF_DEVINL const f16x8* as_h2(const float4* p) { return reinterpret_cast<const f16x8*>(p); }
+
+// =========================================================================================
+// k_front_h2: stages (16 x 16 KiB, fp16x2 images): Wp[4] | Wq'[4] | Wk[4] | Wv[4]
+//   vecs (fp32): bp | bq' | bk | bv | b0 | W0 image (fp32, K=8: layer0 stays on the f32 MFMA, 4 MFMAs per block)
+//   outputs: f as fp32 P32 image; Q', K, V as fp16x2 plane images (16 KiB per tile).
+// =========================================================================================
+template <int MODE>
+__global__ void __launch_bounds__(256, 2)
+k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const float* __restrict__ vecs,
+           float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out,
+           float* __restrict__ v_out, int N, int tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+
+  StageStream ss;
+  if (MODE == 2) ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst + 4 * kStageFloats, 12);
+  else ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 16);
+  ss.prime();
+
+  float f[CF];
+  FragH2<8> fx;
+  {
+    float x[CF];
+    if (MODE == 1) {
+      const int row = tile * 32 + i;
+      float pk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = 4 * h + e;
+        pk[e] = (row < N && k < 6) ? in[((size_t)pair * N + row) * 6 + k] : 0.f;
+      }
+      const float4* w0 = reinterpret_cast<const float4*>(vecs + 5 * C) + lane;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        f32x16 acc = zero16();
+        const float4 w = w0[mb * 64];
+        acc = mfma32(w.x, pk[0], acc); acc = mfma32(w.y, pk[1], acc);
+        acc = mfma32(w.z, pk[2], acc); acc = mfma32(w.w, pk[3], acc);
+        float b[16];
+        load_vec_block(b, vecs + 4 * C, mb, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[16 * mb + r] = acc[r] + b[r];
+      }
+    } else {
+      load_frag_p32<CF>(x, in + toff, lane);
+    }
+    if (MODE == 2) {
+#pragma unroll
+      for (int e = 0; e < CF; ++e) f[e] = x[e];
+    } else {
+      fx.set(x);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const f16x8* lw = as_h2(ss.acquire());
+        f32x16 acc = zero16();
+        mma_wx_h2<8>(acc, lw, fx);
+        float b[16];
+        load_vec_block(b, vecs, mb, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) f[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+      }
+    }
+  }
+  if (active) store_frag_p32<CF>(f_out + toff, f, lane);
+  fx.set(f);
+
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {   // Q', K
+    float* dst = (which == 0 ? q_out : k_out) + toff;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const f16x8* lw = as_h2(ss.acquire());
+      f32x16 acc = zero16();
+      mma_wx_h2<8>(acc, lw, fx);
+      float b[16], t[16];
+      load_vec_block(b, vecs + (1 + which) * C, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r];
+      if (active) store_block_h2(dst, mb, t, lane);
+    }
+  }
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {             // V (feature on lane)
+    const f16x8* lw = as_h2(ss.acquire());
+    f32x16 acc = zero16();
+    mma_xw_h2<8>(acc, lw, fx);
+    const float bv = vecs[3 * C + 32 * db + i];
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = acc[r] + bv;
+    if (active) store_block_h2(v_out + toff, db, t, lane);
+  }
+}
+
+// =========================================================================================
+// k_ctx_prep_h2: output per token tile (4096 floats): Kc | Vc as fp16x2 images for d_head = 64:
+//   Kc: unit ((plane*4 + s)*64 + lane), 2 planes x 4 k-steps = 2048 floats ; Vc: unit ((plane*4 + slot)*64 + lane),
+//   slot = 2*db + s2, 2048 floats.   stages (4): Wk[2] | Wv[2] as fp16x2 images.
+// =========================================================================================
+template <bool PE>
+__global__ void __launch_bounds__(256, 2)
+k_ctx_prep_h2(const float* __restrict__ ctx, const float* __restrict__ wst, const float* __restrict__ vecs,
+              float* __restrict__ out, int T, int ttiles, int wst_stride, int vec_stride) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y, set = blockIdx.z, nb = gridDim.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < ttiles;
+  const int tile = active ? tile_raw : ttiles - 1;
+  wst += (size_t)set * wst_stride;
+  vecs += (size_t)set * vec_stride;
+  const float* pair_base = ctx + (size_t)pair * ttiles * (32 * C);
+  float* dst = out + (((size_t)set * nb + pair) * ttiles + tile) * kStageFloats;
+
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 4);
+  ss.prime();
+  FragH2<8> cx;
+  {
+    float x[CF], cn[CF];
+    if (PE) lcpe_frag(x, pair_base, tile * 32 + i, T, vecs, h);
+    else load_frag_p32<CF>(x, pair_base + (size_t)tile * (32 * C), lane);
+    layernorm_frag<CF>(cn, x, vecs + 4 * C, vecs + 5 * C, h);
+    cx.set(cn);
+  }
+  f16x8* kdst = reinterpret_cast<f16x8*>(dst);
+  f16x8* vdst = reinterpret_cast<f16x8*>(dst + 32 * DH);
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const f16x8* lw = as_h2(ss.acquire());
+    f32x16 acc = zero16();
+    mma_wx_h2<8>(acc, lw, cx);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = acc[r];
+    if (active) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        f16x8 hi, lo;
+        split8h(&t[8 * half], hi, lo);
+        const int s = 2 * mb + half;
+        kdst[(0 * 4 + s) * 64 + lane] = hi;
+        kdst[(1 * 4 + s) * 64 + lane] = lo;
+      }
+    }
+  }
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    const f16x8* lw = as_h2(ss.acquire());
+    f32x16 acc = zero16();
+    mma_xw_h2<8>(acc, lw, cx);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = acc[r];
+    if (active) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8 hi, lo;
+        split8h(&t[8 * s2], hi, lo);
+        const int slot = 2 * db + s2;
+        vdst[(0 * 4 + slot) * 64 + lane] = hi;
+        vdst[(1 * 4 + slot) * 64 + lane] = lo;
+      }
+    }
+  }
+}
+
+// =========================================================================================
+// k_fusion_attn_h2: stages: Wq''[2] | ctx tiles [ttiles] (Kc | Vc fp16x2 images from k_ctx_prep_h2) | Wo[2]
+//   vecs: query taps | gamma | beta | bo (fp32).  P is scaled by 2^10 as in k_scattn_h2.
+// =========================================================================================
+template <bool PE>
+__global__ void __launch_bounds__(256, 2)
+k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_img, const float* __restrict__ wst,
+                 const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const float* pair_base = xin + (size_t)pair * tiles * (32 * C);
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 2,
+          ctx_img + (size_t)pair * ttiles * kStageFloats, ttiles, wst + 2 * kStageFloats, 2);
+  ss.prime();
+
+  float xp[CF];
+  if (PE) lcpe_frag(xp, pair_base, tile * 32 + i, N, vecs, h);
+  else load_frag_p32<CF>(xp, pair_base + (size_t)tile * (32 * C), lane);
+
+  FragH2<4> qx;
+  {
+    FragH2<8> nx;
+    {
+      float xn[CF];
+      layernorm_frag<CF>(xn, xp, vecs + 4 * C, vecs + 5 * C, h);
+      nx.set(xn);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const f16x8* lw = as_h2(ss.acquire());
+      f32x16 acc = zero16();
+      mma_wx_h2<8>(acc, lw, nx);
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = acc[r];
+      qx.set_block(mb, t);
+    }
+  }
+
+  f32x16 oacc[2];
+  oacc[0] = zero16(); oacc[1] = zero16();
+  float m_run = -INFINITY, l_half = 0.f;
+  for (int t = 0; t < ttiles; ++t) {
+    const f16x8* lk = as_h2(ss.acquire());
+    const f16x8* lv = lk + 2 * 4 * 64;            // Vc image follows the Kc image (2 planes x 4 steps)
+    f32x16 s = zero16();
+    mma_wx_h2<4>(s, lk, qx);
+    float x[16];
+    float mx = -INFINITY;
+    const int jbase = t * 32 + 4 * h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jl = 8 * (r >> 2) + (r & 3);
+      const float v = (jbase + jl < T) ? s[r] : -INFINITY;
+      x[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    const float m_off = m_new - 10.0f;
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
+    l_half = fmaf(l_half, alpha, ls);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f16x8 ph, pl;
+      split8h(&x[8 * s2], ph, pl);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int slot = 2 * db + s2;
+        mma3(oacc[db], lv[(0 * 4 + slot) * 64], lv[(1 * 4 + slot) * 64], ph, pl);
+      }
+    }
+  }
+  FragH2<4> ox;
+  {
+    const float inv = 1.0f / xhalf_sum(l_half);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = oacc[db][r] * inv;
+      ox.set_block(db, t);
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const f16x8* lw = as_h2(ss.acquire());
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int mb = 2 * st + hb;
+      f32x16 acc = zero16();
+      mma_wx_h2<4>(acc, lw + hb * (2 * 4 * 64), ox);     // a 32 x 64 block = 2 planes x 4 steps x 64 units
+      float b[16], t[16];
+      load_vec_block(b, vecs + 6 * C, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r] + xp[16 * mb + r];
+      if (active) store_block_p32(x1_out + toff, mb, t, lane);
+    }
+  }
+}
+
+// =========================================================================================
+// k_fusion_ff_h2: stages (48 x 16 KiB): for c in 0..15: W1a_c | W1g_c | W2_c (4 blocks of 32 x 32: 2 planes x 2 steps)
+// =========================================================================================
+__global__ void __launch_bounds__(256, 2)
+k_fusion_ff_h2(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
+               float* __restrict__ x2_out, int tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 3 * (FFH / 32));
+  ss.prime();
+  FragH2<8> nx;
+  {
+    float x[CF], xn[CF];
+    load_frag_p32<CF>(x, x1 + toff, lane);
+    layernorm_frag<CF>(xn, x, vecs, vecs + C, h);
+    nx.set(xn);
+  }
+  f32x16 y[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) y[mb] = zero16();
+  const float* b1a = vecs + 2 * C;
+  const float* b1g = vecs + 2 * C + FFH;
+
+  for (int c = 0; c < FFH / 32; ++c) {
+    float ga[16];
+    {
+      const f16x8* lw = as_h2(ss.acquire());
+      f32x16 acc = zero16();
+      mma_wx_h2<8>(acc, lw, nx);
+      float b[16];
+      load_vec_block(b, b1a, c, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ga[r] = acc[r] + b[r];
+    }
+    {
+      const f16x8* lw = as_h2(ss.acquire());
+      f32x16 acc = zero16();
+      mma_wx_h2<8>(acc, lw, nx);
+      float b[16];
+      load_vec_block(b, b1g, c, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ga[r] *= gelu_erf(acc[r] + b[r]);
+    }
+    {
+      FragH2<2> gx;
+      gx.set(ga);
+      const f16x8* lw = as_h2(ss.acquire());
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) mma_wx_h2<2>(y[mb], lw + mb * (2 * 2 * 64), gx);
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    float b[16], xr[16], t[16];
+    load_vec_block(b, vecs + 2 * C + 2 * FFH, mb, h);
+    load_block_p32(xr, x1 + toff, mb, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = y[mb][r] + b[r] + xr[r];
+    if (active) store_block_p32(x2_out + toff, mb, t, lane);
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+static inline dim3 tgrid(int tiles, int B, int sets = 1) { return dim3((tiles + kWavesPerWG - 1) / kWavesPerWG, B, sets); }
+
+hipError_t launch_front_h2(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
+                           float* v, int B, int N, int tiles, hipStream_t s) {
+  if (mode == 1) hipLaunchKernelGGL(k_front_h2<1>, tgrid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  else if (mode == 2) hipLaunchKernelGGL(k_front_h2<2>, tgrid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  else hipLaunchKernelGGL(k_front_h2<0>, tgrid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_ctx_prep_h2(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
+                              int ttiles, int sets, int wst_stride, int vec_stride, hipStream_t s) {
+  if (pe) hipLaunchKernelGGL(k_ctx_prep_h2<true>, tgrid(ttiles, B, sets), dim3(256), 0, s, ctx, wst, vecs, out, T, ttiles, wst_stride, vec_stride);
+  else hipLaunchKernelGGL(k_ctx_prep_h2<false>, tgrid(ttiles, B, sets), dim3(256), 0, s, ctx, wst, vecs, out, T, ttiles, wst_stride, vec_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
+                                 float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s) {
+  if (pe) hipLaunchKernelGGL(k_fusion_attn_h2<true>, tgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
+  else hipLaunchKernelGGL(k_fusion_attn_h2<false>, tgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_fusion_ff_h2(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_fusion_ff_h2, tgrid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
+  return hipGetLastError();
+}
+
+}  // namespace gmf

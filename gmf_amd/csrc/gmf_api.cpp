@@ -259,11 +259,23 @@ static int check_weights(gmf_handle* h, const gmf_encoder_weights* w) {
   return GMF_OK;
 }
 
+static bool use_h2(const gmf_encoder_weights* w, bool dense) {
+  const int v = gmf::get_scattn_variant();
+  return !dense && (v == 9 || v == 10) && w->front_wst_h2 && w->ctx_wst_h2 && w->attn_wst_h2 && w->ff_wst_h2;
+}
+
 // Runs Fusion-2 + the spatial-consistency block of layer `l` given f,q,k,v.
 static int run_block_tail(gmf_handle* h, const gmf_encoder_weights* w, int l, const float* f, const float* q,
                           const float* k, const float* v, const float* pts8, const float* ctx_l, float* x1, float* x2,
                           float* out, int B, int N, int T, hipStream_t st, const float* dense_compat = nullptr) {
   const int tiles = tiles_of(N), tt = tiles_of(T);
+  const bool h2 = use_h2(w, dense_compat != nullptr);
+  if (h2) {
+    GMF_HIP(gmf::launch_fusion_attn_h2(true, f, ctx_l, w->attn_wst_h2 + (size_t)l * w->attn_wst_stride,
+                                       w->attn_vec + (size_t)l * w->attn_vec_stride, x1, B, N, tiles, T, tt, st));
+    GMF_HIP(gmf::launch_fusion_ff_h2(x1, w->ff_wst_h2 + (size_t)l * w->ff_wst_stride,
+                                     w->ff_vec + (size_t)l * w->ff_vec_stride, x2, B, tiles, st));
+  } else {
   GMF_HIP(gmf::launch_fusion_attn(true, f, ctx_l, w->attn_wst + (size_t)l * w->attn_wst_stride,
                                   w->attn_vec + (size_t)l * w->attn_vec_stride, x1, B, N, tiles, T, tt, st));
   if (w->ff_wst_b3)
@@ -272,6 +284,7 @@ static int run_block_tail(gmf_handle* h, const gmf_encoder_weights* w, int l, co
   else
     GMF_HIP(gmf::launch_fusion_ff(x1, w->ff_wst + (size_t)l * w->ff_wst_stride, w->ff_vec + (size_t)l * w->ff_vec_stride,
                                   x2, B, tiles, st));
+  }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (h->profile) {
     if (h->prof_used == h->prof_events.size()) {
@@ -332,14 +345,24 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   // Fusion-1: image_feat = FusionLayer(p_tok (context), queries = q_tok), pe = False (PointDSC.py:137)
   GMF_HIP(gmf::launch_pack_p32(p_tokens, pimg, B, T, kC, (long)T * kC, kC, 1, st));
   GMF_HIP(gmf::launch_pack_p32(q_tokens, qimg, B, T, kC, (long)T * kC, kC, 1, st));
-  GMF_HIP(gmf::launch_ctx_prep(false, pimg, w->f1_ctx_wst, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st));
-  GMF_HIP(gmf::launch_fusion_attn(false, qimg, f1ctx, w->f1_attn_wst, w->f1_attn_vec, x1t, B, T, tt, T, tt, st));
-  if (w->f1_ff_wst_b3) GMF_HIP(gmf::launch_fusion_ff_b3(x1t, w->f1_ff_wst_b3, w->f1_ff_vec, imgfeat, B, tt, st));
-  else GMF_HIP(gmf::launch_fusion_ff(x1t, w->f1_ff_wst, w->f1_ff_vec, imgfeat, B, tt, st));
+  const bool h2 = use_h2(w, false);
+  if (h2 && w->f1_ctx_wst_h2 && w->f1_attn_wst_h2 && w->f1_ff_wst_h2) {
+    GMF_HIP(gmf::launch_ctx_prep_h2(false, pimg, w->f1_ctx_wst_h2, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st));
+    GMF_HIP(gmf::launch_fusion_attn_h2(false, qimg, f1ctx, w->f1_attn_wst_h2, w->f1_attn_vec, x1t, B, T, tt, T, tt, st));
+    GMF_HIP(gmf::launch_fusion_ff_h2(x1t, w->f1_ff_wst_h2, w->f1_ff_vec, imgfeat, B, tt, st));
+  } else {
+    GMF_HIP(gmf::launch_ctx_prep(false, pimg, w->f1_ctx_wst, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st));
+    GMF_HIP(gmf::launch_fusion_attn(false, qimg, f1ctx, w->f1_attn_wst, w->f1_attn_vec, x1t, B, T, tt, T, tt, st));
+    if (w->f1_ff_wst_b3) GMF_HIP(gmf::launch_fusion_ff_b3(x1t, w->f1_ff_wst_b3, w->f1_ff_vec, imgfeat, B, tt, st));
+    else GMF_HIP(gmf::launch_fusion_ff(x1t, w->f1_ff_wst, w->f1_ff_vec, imgfeat, B, tt, st));
+  }
   // context side of all L Fusion-2 layers in one launch
-  if (L > 0)
-    GMF_HIP(gmf::launch_ctx_prep(true, imgfeat, w->ctx_wst, w->ctx_vec, ctxall, B, T, tt, L, w->ctx_wst_stride,
-                                 w->ctx_vec_stride, st));
+  if (L > 0) {
+    if (h2) GMF_HIP(gmf::launch_ctx_prep_h2(true, imgfeat, w->ctx_wst_h2, w->ctx_vec, ctxall, B, T, tt, L, w->ctx_wst_stride,
+                                            w->ctx_vec_stride, st));
+    else GMF_HIP(gmf::launch_ctx_prep(true, imgfeat, w->ctx_wst, w->ctx_vec, ctxall, B, T, tt, L, w->ctx_wst_stride,
+                                      w->ctx_vec_stride, st));
+  }
   GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st));
 
   float* cur = featA;
@@ -350,8 +373,10 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   }
   for (int l = 0; l < L; ++l) {
     const float* in = (l == 0) ? corr_pos : cur;
-    GMF_HIP(gmf::launch_front(l == 0 ? 1 : 0, in, w->front_wst + (size_t)l * w->front_wst_stride,
-                              w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
+    if (h2) GMF_HIP(gmf::launch_front_h2(l == 0 ? 1 : 0, in, w->front_wst_h2 + (size_t)l * w->front_wst_stride,
+                                         w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
+    else GMF_HIP(gmf::launch_front(l == 0 ? 1 : 0, in, w->front_wst + (size_t)l * w->front_wst_stride,
+                                   w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
     if (int rc = run_block_tail(h, w, l, f, q, k, v, pts8, ctxall + (size_t)l * tok, x1, x2, nxt, B, N, T, st)) return rc;
     float* t = cur; cur = nxt; nxt = t;
   }
@@ -385,10 +410,17 @@ int gmf_nonlocal_block_forward(gmf_handle* h, const gmf_encoder_weights* w, int 
   float* x2 = arena_take<float>(h, act);
   float* ctx = arena_take<float>(h, tok);
   // apply_pointcn = 0: the caller's feat is already the block input (NonLocalBlock.forward, PointDSC.py:40-45)
-  GMF_HIP(gmf::launch_front(apply_pointcn ? 0 : 2, feat_img, w->front_wst + (size_t)layer * w->front_wst_stride,
-                            w->front_vec + (size_t)layer * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
-  GMF_HIP(gmf::launch_ctx_prep(true, image_feat_img, w->ctx_wst + (size_t)layer * w->ctx_wst_stride,
-                               w->ctx_vec + (size_t)layer * w->ctx_vec_stride, ctx, B, T, tt, 1, 0, 0, st));
+  if (use_h2(w, attention != nullptr)) {
+    GMF_HIP(gmf::launch_front_h2(apply_pointcn ? 0 : 2, feat_img, w->front_wst_h2 + (size_t)layer * w->front_wst_stride,
+                                 w->front_vec + (size_t)layer * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
+    GMF_HIP(gmf::launch_ctx_prep_h2(true, image_feat_img, w->ctx_wst_h2 + (size_t)layer * w->ctx_wst_stride,
+                                    w->ctx_vec + (size_t)layer * w->ctx_vec_stride, ctx, B, T, tt, 1, 0, 0, st));
+  } else {
+    GMF_HIP(gmf::launch_front(apply_pointcn ? 0 : 2, feat_img, w->front_wst + (size_t)layer * w->front_wst_stride,
+                              w->front_vec + (size_t)layer * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
+    GMF_HIP(gmf::launch_ctx_prep(true, image_feat_img, w->ctx_wst + (size_t)layer * w->ctx_wst_stride,
+                                 w->ctx_vec + (size_t)layer * w->ctx_vec_stride, ctx, B, T, tt, 1, 0, 0, st));
+  }
   const int rc_tail = run_block_tail(h, w, layer, f, q, k, v, pts8, ctx, x1, x2, out_img, B, N, T, st, attention);
   gmf::set_force_fp32_qkv(false);
   return rc_tail;

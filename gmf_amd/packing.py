@@ -71,6 +71,20 @@ def p32_b3(W: torch.Tensor) -> torch.Tensor:
     return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
 
 
+def p32_h2(W: torch.Tensor) -> torch.Tensor:
+    """[M, K] fp32 (M % 32 == 0, K % 16 == 0) -> flat split-fp16 image (4 B per element), as float32 words.
+
+    Per 32-output block: [plane hi|lo][k-step][lane = (h, i)][8 fp16]; W ~ hi + lo, both round-to-nearest-even."""
+    M, K = W.shape
+    assert M % 32 == 0 and K % 16 == 0, (M, K)
+    hi = W.to(torch.float16)
+    lo = (W - hi.float()).to(torch.float16)
+    idx = _b3_index(K, W.device)
+    g = torch.stack([hi, lo])[:, :, idx]                                    # [2, M, S, 2, 8]
+    g = g.reshape(2, M // 32, 32, K // 16, 2, 8).permute(1, 0, 3, 4, 2, 5)  # [mb, plane, S, h, i, 8]
+    return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
+
+
 def pack_ff_b3(sd, prefix: str) -> torch.Tensor:
     """GEGLU feed-forward weights of one FusionLayer (128-wide) as 48 bf16x3 stages of 24 KiB."""
     f = prefix + "cross_attend_blocks.1."
@@ -113,23 +127,24 @@ def fusion_dims(sd: Dict[str, torch.Tensor], prefix: str):
     return lat, dh
 
 
-def pack_fusion(sd: Dict[str, torch.Tensor], prefix: str, pe: bool):
+def pack_fusion(sd: Dict[str, torch.Tensor], prefix: str, pe: bool, img=None):
     """One FusionLayer / PerceiverIO (depth=0) -> dict of 6 blobs (fusion_layer.py:131-201, perceiver_io.py:139-221).
 
     Stage order matches the kernels: ctx = Wk blocks | Wv blocks; attn = Wq'' blocks (each block's K-groups in
     order, so a 256-wide input naturally spans two 16 KiB stages) | Wo blocks; ff = per 32-unit chunk
     W1 value | W1 gate | W2 column block."""
+    img = img or p32          # p32 (fp32 images) or p32_h2 (split-fp16 images): same sizes, same stage order
     lat, dh = fusion_dims(sd, prefix)
     a = prefix + "cross_attend_blocks.0."
     f = prefix + "cross_attend_blocks.1."
     dev = sd[a + "fn.to_q.weight"].device
     wkv = _f(sd[a + "fn.to_kv.weight"])
-    ctx_wst = torch.cat([p32(wkv[:dh]), p32(wkv[dh:])])
+    ctx_wst = torch.cat([img(wkv[:dh]), img(wkv[dh:])])
     ctx_vec = torch.cat([_taps(sd[prefix + "cpe.proj_content.weight"], sd[prefix + "cpe.proj_content.bias"]) if pe
                          else torch.zeros(4 * C, device=dev),
                          _f(sd[a + "norm_context.weight"]), _f(sd[a + "norm_context.bias"])])
     wq = _f(sd[a + "fn.to_q.weight"]) * (dh ** -0.5 * LOG2E)
-    attn_wst = torch.cat([p32(wq), p32(_f(sd[a + "fn.to_out.weight"]))])
+    attn_wst = torch.cat([img(wq), img(_f(sd[a + "fn.to_out.weight"]))])
     attn_vec = torch.cat([_taps(sd[prefix + "cpe.proj_q.weight"], sd[prefix + "cpe.proj_q.bias"]) if pe
                           else torch.zeros(4 * lat, device=dev),
                           _f(sd[a + "norm.weight"]), _f(sd[a + "norm.bias"]), _f(sd[a + "fn.to_out.bias"])])
@@ -139,7 +154,7 @@ def pack_fusion(sd: Dict[str, torch.Tensor], prefix: str, pe: bool):
     assert tuple(W1.shape) == (2 * hid, lat) and tuple(W2.shape) == (lat, hid) and hid == 4 * lat
     chunks = []
     for c in range(hid // 32):
-        chunks += [p32(W1[32 * c:32 * c + 32]), p32(W1[hid + 32 * c:hid + 32 * c + 32]), p32(W2[:, 32 * c:32 * c + 32])]
+        chunks += [img(W1[32 * c:32 * c + 32]), img(W1[hid + 32 * c:hid + 32 * c + 32]), img(W2[:, 32 * c:32 * c + 32])]
     ff_wst = torch.cat(chunks)
     ff_vec = torch.cat([_f(sd[f + "norm.weight"]), _f(sd[f + "norm.bias"]), b1[:hid], b1[hid:], b2])
     out = {"ctx_wst": ctx_wst, "ctx_vec": ctx_vec, "attn_wst": attn_wst, "attn_vec": attn_vec,
@@ -154,7 +169,7 @@ def pack_fusion(sd: Dict[str, torch.Tensor], prefix: str, pe: bool):
     return {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in out.items()}
 
 
-def pack_front(sd, layer: int, with_layer0: bool, identity_pointcn: bool = False):
+def pack_front(sd, layer: int, with_layer0: bool, identity_pointcn: bool = False, img=None):
     """PointCN_layer_i (BN folded) + projection_{q,k,v} (+ layer0) (PointDSC.py:88,104-109,23-25)."""
     n = f"encoder.blocks.NonLocal_layer_{layer}."
     pc = f"encoder.blocks.PointCN_layer_{layer}."
@@ -167,7 +182,8 @@ def pack_front(sd, layer: int, with_layer0: bool, identity_pointcn: bool = False
     Wq, bq = _f(sd[n + "projection_q.weight"])[:, :, 0] * cq, _f(sd[n + "projection_q.bias"]) * cq
     Wk, bk = _f(sd[n + "projection_k.weight"])[:, :, 0], _f(sd[n + "projection_k.bias"])
     Wv, bv = _f(sd[n + "projection_v.weight"])[:, :, 0], _f(sd[n + "projection_v.bias"])
-    wst = torch.cat([p32(Wp), p32(Wq), p32(Wk), p32(Wv)])
+    img = img or p32
+    wst = torch.cat([img(Wp), img(Wq), img(Wk), img(Wv)])
     if with_layer0:
         W0 = _f(sd["encoder.layer0.weight"])[:, :, 0]
         assert W0.shape[1] <= 8, "in_dim > 8 is not supported by the layer0 MFMA prologue"
@@ -227,6 +243,16 @@ class PackedEncoder:
             for k, v in f1.items():
                 self.t["f1_" + k] = v
             self.t["f1_ff_wst_b3"] = pack_ff_b3(sd, "encoder.fusion_layer_1.")
+            f1h = pack_fusion(sd, "encoder.fusion_layer_1.", pe=False, img=p32_h2)
+            for k in ("ctx_wst", "attn_wst", "ff_wst"):
+                self.t["f1_" + k + "_h2"] = f1h[k]
+        if num_layers > 0:
+            f2h = [pack_fusion(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.", pe=True, img=p32_h2) for i in range(num_layers)]
+            for k in ("ctx_wst", "attn_wst", "ff_wst"):
+                self.t[k + "_h2"] = torch.stack([f[k] for f in f2h]).contiguous()
+            self.t["front_wst_h2"] = torch.stack([pack_front(sd, i, with_layer0=(i == 0 and "encoder.layer0.weight" in sd),
+                                                             identity_pointcn=standalone_block, img=p32_h2)[0]
+                                                  for i in range(num_layers)]).contiguous()
         if num_layers > 0:
             self.t["ff_wst_b3"] = torch.stack([pack_ff_b3(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.")
                                                for i in range(num_layers)]).contiguous()
@@ -249,4 +275,6 @@ class PackedEncoder:
         w.ff_wst_b3 = self.t["ff_wst_b3"].data_ptr() if "ff_wst_b3" in self.t else None
         w.ff_wst_b3_stride = 48 * 6144
         w.f1_ff_wst_b3 = self.t["f1_ff_wst_b3"].data_ptr() if "f1_ff_wst_b3" in self.t else None
+        for name in ("front_wst_h2", "ctx_wst_h2", "attn_wst_h2", "ff_wst_h2", "f1_ctx_wst_h2", "f1_attn_wst_h2", "f1_ff_wst_h2"):
+            setattr(w, name, self.t[name].data_ptr() if name in self.t else None)
         self.struct = w

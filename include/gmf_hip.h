@@ -130,6 +130,11 @@ typedef struct gmf_encoder_weights {
    * When non-NULL the feed-forward runs on the bf16 MFMA (fp32-equivalent accuracy, 2.7x fewer MFMA cycles). */
   const float* ff_wst_b3;   int ff_wst_b3_stride;
   const float* f1_ff_wst_b3;
+  /* optional split-fp16 (fp16x2) images of every dense weight of the linear stages, same sizes and strides as the
+   * fp32 blobs.  When all are non-NULL and the attention variant is 9/10 (the default), [layer0]+PointCN+QKV, the
+   * context prepare, the cross-attention and the feed-forward run on the f16 MFMA (fp32-equivalent accuracy). */
+  const float* front_wst_h2; const float* ctx_wst_h2; const float* attn_wst_h2; const float* ff_wst_h2;
+  const float* f1_ctx_wst_h2; const float* f1_attn_wst_h2; const float* f1_ff_wst_h2;
 } gmf_encoder_weights;
 
 /* PointDSC.forward up to the logits (PointDSC.py:216-241) with image TOKENS as input:

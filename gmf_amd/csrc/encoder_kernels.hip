@@ -1565,23 +1565,26 @@ k_head(const float* __restrict__ feat_img, const float* __restrict__ wst, const 
 // =========================================================================================
 __global__ void __launch_bounds__(256, 2)
 k_seed_dist(const float* __restrict__ featn_img, const int* __restrict__ seeds, float* __restrict__ dist,
-            int N, int tiles, int S) {
+            int N, int tiles, int S, int chunks) {
   __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = blockIdx.y;
+  const int pair = blockIdx.y / chunks, chunk = blockIdx.y - pair * chunks;   // key tiles are split over `chunks` workgroups
+  const int per = (tiles + chunks - 1) / chunks;
+  const int t0 = chunk * per, t1 = min(tiles, t0 + per);
   const int seed_base = (blockIdx.x * kWavesPerWG + wave) * 32;
   const float* pair_img = featn_img + (size_t)pair * tiles * (32 * C);
   const int my = seed_base + i;
   const int row = (my < S) ? seeds[(size_t)pair * S + my] : 0;
   float sf[CF];
   load_row_frag_p32<CF>(sf, pair_img, row, N, h);
+  if (t0 >= t1) return;                         // uniform over the workgroup
 
   StageStream ss;
-  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, pair_img, tiles);
+  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, pair_img + (size_t)t0 * kStageFloats, t1 - t0);
   ss.prime();
   float* drow = dist + ((size_t)pair * S) * N;
-  for (int t = 0; t < tiles; ++t) {
+  for (int t = t0; t < t1; ++t) {
     const float4* lk = ss.acquire();
     f32x16 acc = zero16();
     mma_xw<CF>(acc, lk, sf);
@@ -1768,7 +1771,10 @@ hipError_t launch_head(const float* feat_img, const float* wst, const float* vec
 
 hipError_t launch_seed_dist(const float* featn_img, const int* seeds, float* dist, int B, int N, int S, hipStream_t s) {
   const int tiles = (N + 31) / 32;
-  hipLaunchKernelGGL(k_seed_dist, dim3((S + 127) / 128, B), dim3(256), 0, s, featn_img, seeds, dist, N, tiles, S);
+  const int sblocks = (S + 127) / 128;
+  int chunks = 1;                                  // enough workgroups to fill 256 CUs twice over
+  while (chunks < 16 && sblocks * B * chunks < 1024 && tiles / (2 * chunks) >= 4) chunks *= 2;
+  hipLaunchKernelGGL(k_seed_dist, dim3(sblocks, B * chunks), dim3(256), 0, s, featn_img, seeds, dist, N, tiles, S, chunks);
   return hipGetLastError();
 }
 

@@ -8,7 +8,7 @@ hipError_t launch_nms_keys(const float* src, const float* scores, float* keys, i
 hipError_t launch_sort_topk(const float* keys, int* out_idx, int B, int N, int S, hipStream_t s);
 hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* dist_in, int* knn_idx, int B, int N, int S,
                             int k, hipStream_t s);
-hipError_t launch_seed_power(const float* feat_n, const float* src, const float* tgt, const int* knn_idx, float* snaps,
+hipError_t launch_seed_power(const float* featn_img, const float* src, const float* tgt, const int* knn_idx, float* snaps,
                              unsigned char* conv, int B, int N, int S, int k, int iters, float sigma, float sigma_d,
                              hipStream_t s);
 hipError_t launch_seed_kabsch(const float* src, const float* tgt, const int* knn_idx, const float* snaps,

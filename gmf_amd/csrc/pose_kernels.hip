@@ -19,6 +19,7 @@
 #include <math.h>
 
 #include "launchers_pose.hpp"
+#include "mfma_core.hpp"
 
 namespace gmf {
 
@@ -151,7 +152,7 @@ GMF_DEVINL void block_sum(double (&v)[NV], double* sh /* >= NV*16 doubles */) {
 // grid (ceil(N/256), B)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_nms_keys(const float* __restrict__ src, const float* __restrict__ scores, float* __restrict__ keys, int N, float R) {
+k_nms_keys(const float* __restrict__ src, const float* __restrict__ scores, float* __restrict__ keys, int N, float R2t) {
   __shared__ float4 sh[256];
   const int pair = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -170,8 +171,8 @@ k_nms_keys(const float* __restrict__ src, const float* __restrict__ scores, floa
     for (int jj = 0; jj < lim; ++jj) {
       const float4 p = sh[jj];
       const float dx = xi - p.x, dy = yi - p.y, dz = zi - p.z;
-      const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-      is_max = is_max && ((si >= p.w) || (d >= R));
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      is_max = is_max && ((si >= p.w) || (d2 >= R2t));     // d2 >= R2t  <=>  sqrtf(d2) >= R  (see launch_nms_keys)
     }
   }
   if (i < N) keys[(size_t)pair * N + i] = si * (is_max ? 1.f : 0.f);
@@ -271,6 +272,152 @@ k_knn_seeds(const float* __restrict__ feat_n, const int* __restrict__ seeds, con
 }
 
 // ---------------------------------------------------------------------------------------
+// Top-(k+1) selection with the seed's distance row held in registers (EPT values per thread, N <= 256*EPT):
+// each thread caches its local minimum; a round is one block-wide argmin over the 256 cached minima and a rescan by
+// the single owner of the extracted element.  Same order as k_knn_seeds: ascending distance, lower index first.
+// grid (S, B), block 256.
+// ---------------------------------------------------------------------------------------
+template <int EPT>
+__global__ void __launch_bounds__(256)
+k_knn_select(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N, int S, int k) {
+  __shared__ float red_v[2][4];
+  __shared__ int red_i[2][4];
+  const int pair = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const float* dr = dist_in + ((size_t)pair * S + s) * N;
+  float v[EPT];
+#pragma unroll
+  for (int m = 0; m < EPT; ++m) { const int j = tid + 256 * m; v[m] = (j < N) ? dr[j] : INFINITY; }
+  float bv = INFINITY; int bm = 0;
+#pragma unroll
+  for (int m = 0; m < EPT; ++m) if (v[m] < bv) { bv = v[m]; bm = m; }
+  for (int it = 0; it <= k; ++it) {
+    float rv = bv; int ri = (bv < INFINITY) ? tid + 256 * bm : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(rv, o, 64); const int oi = __shfl_xor(ri, o, 64);
+      if (ov < rv || (ov == rv && oi < ri)) { rv = ov; ri = oi; }
+    }
+    const int buf = it & 1;
+    if (lane == 0) { red_v[buf][wave] = rv; red_i[buf][wave] = ri; }
+    __syncthreads();
+    float wv = red_v[buf][0]; int wi = red_i[buf][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float ov = red_v[buf][w]; const int oi = red_i[buf][w];
+      if (ov < wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
+    }
+    if (it > 0 && tid == 0) knn_idx[((size_t)pair * S + s) * k + (it - 1)] = wi;
+    if ((wi & 255) == tid) {               // owner: drop the element, rescan the registers
+      const int mm = wi >> 8;
+      bv = INFINITY; bm = 0;
+#pragma unroll
+      for (int m = 0; m < EPT; ++m) {
+        if (m == mm) v[m] = INFINITY;
+        if (v[m] < bv) { bv = v[m]; bm = m; }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Top-(k+1) selection in O(1) barriers.  T = the (k+1)-th smallest of the 256 per-thread minima bounds the
+// (k+1)-th smallest element overall, so every wanted element is among the c elements <= T (c ~ k+1 for random
+// rows); those are gathered into LDS and ranked by counting under the order (distance, index).  Falls back to the
+// round-based loop of k_knn_select in the (adversarial) case c > kCandMax.   grid (S, B), block 256.
+// ---------------------------------------------------------------------------------------
+constexpr int kCandMax = 1024;
+
+template <int EPT>
+__global__ void __launch_bounds__(256)
+k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N, int S, int k) {
+  __shared__ float mins[256];
+  __shared__ float cand_v[kCandMax];
+  __shared__ int cand_i[kCandMax];
+  __shared__ float T_sh;
+  __shared__ int count;
+  __shared__ float red_v[2][4];
+  __shared__ int red_i[2][4];
+  const int pair = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+  const float* dr = dist_in + ((size_t)pair * S + s) * N;
+  int* out = knn_idx + ((size_t)pair * S + s) * k;
+  float v[EPT];
+#pragma unroll
+  for (int m = 0; m < EPT; ++m) { const int j = tid + 256 * m; v[m] = (j < N) ? dr[j] : INFINITY; }
+  float bv = INFINITY; int bm = 0;
+#pragma unroll
+  for (int m = 0; m < EPT; ++m) if (v[m] < bv) { bv = v[m]; bm = m; }
+  mins[tid] = bv;
+  if (tid == 0) count = 0;
+  __syncthreads();
+  {
+    int rank = 0;
+    const float4* m4 = reinterpret_cast<const float4*>(mins);
+#pragma unroll 8
+    for (int u = 0; u < 64; ++u) {
+      const float4 q = m4[u];
+      rank += (q.x < bv || (q.x == bv && 4 * u + 0 < tid)) ? 1 : 0;
+      rank += (q.y < bv || (q.y == bv && 4 * u + 1 < tid)) ? 1 : 0;
+      rank += (q.z < bv || (q.z == bv && 4 * u + 2 < tid)) ? 1 : 0;
+      rank += (q.w < bv || (q.w == bv && 4 * u + 3 < tid)) ? 1 : 0;
+    }
+    if (rank == k) T_sh = bv;            // k <= 64 < 256: exactly one thread has this rank
+  }
+  __syncthreads();
+  const float T = T_sh;
+#pragma unroll
+  for (int m = 0; m < EPT; ++m) {
+    if (v[m] <= T) {
+      const int pos = atomicAdd(&count, 1);
+      if (pos < kCandMax) { cand_v[pos] = v[m]; cand_i[pos] = tid + 256 * m; }
+    }
+  }
+  __syncthreads();
+  const int c = count;
+  if (c <= kCandMax) {
+    for (int p = tid; p < c; p += 256) {
+      const float pv = cand_v[p]; const int pi = cand_i[p];
+      int rank = 0;
+      for (int q = 0; q < c; ++q) {
+        const float qv = cand_v[q]; const int qi = cand_i[q];
+        rank += (qv < pv || (qv == pv && qi < pi)) ? 1 : 0;
+      }
+      if (rank >= 1 && rank <= k) out[rank - 1] = pi;     // rank 0 (the row itself) is dropped, common.py:74
+    }
+    return;
+  }
+  // fallback: k+1 rounds of block-wide argmin over the cached per-thread minima
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int it = 0; it <= k; ++it) {
+    float rv = bv; int ri = (bv < INFINITY) ? tid + 256 * bm : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(rv, o, 64); const int oi = __shfl_xor(ri, o, 64);
+      if (ov < rv || (ov == rv && oi < ri)) { rv = ov; ri = oi; }
+    }
+    const int buf = it & 1;
+    if (lane == 0) { red_v[buf][wave] = rv; red_i[buf][wave] = ri; }
+    __syncthreads();
+    float wv = red_v[buf][0]; int wi = red_i[buf][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float ov = red_v[buf][w]; const int oi = red_i[buf][w];
+      if (ov < wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
+    }
+    if (it > 0 && tid == 0) out[it - 1] = wi;
+    if ((wi & 255) == tid) {
+      const int mm = wi >> 8;
+      bv = INFINITY; bm = 0;
+#pragma unroll
+      for (int m = 0; m < EPT; ++m) {
+        if (m == mm) v[m] = INFINITY;
+        if (v[m] < bv) { bv = v[m]; bm = m; }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Per seed: M = clamp(1-(1-F F^T)/sigma^2,0) * clamp(1-(ds-dt)^2/sigma_d^2,0), diag 0; power iteration
 // with every iterate stored (the reference's early exit is a GLOBAL allclose over all seeds of the
 // pair, resolved by k_seed_kabsch).  One wave per seed, lane a = neighbour a.  k <= 64.
@@ -279,22 +426,25 @@ k_knn_seeds(const float* __restrict__ feat_n, const int* __restrict__ seeds, con
 // ---------------------------------------------------------------------------------------
 constexpr int kKMax = 64;
 
+// The k x k feature Gram matrix comes from the f32 MFMA: the wave gathers its neighbours' unit features as two
+// 32-row fragments straight from the P32 image (no LDS staging of features) and forms G00, G01, G11
+// (G10 = G01^T) with 64 MFMAs each; lane (h, b) then owns column b of each tile and turns the dot products into
+// M entries together with the spatial term.
 __global__ void __launch_bounds__(64)
-k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, const float* __restrict__ tgt,
+k_seed_power(const float* __restrict__ featn_img, const float* __restrict__ src, const float* __restrict__ tgt,
              const int* __restrict__ knn_idx, float* __restrict__ snaps, unsigned char* __restrict__ conv,
-             int N, int S, int k, int iters, float inv_sigma2, float inv_sigmad2) {
-  extern __shared__ float sp_smem[];            // F[k][129] | Mx[k][kKMax+1] | P[kKMax*8] | vec[kKMax]
-  float* F = sp_smem;
-  float* Mx = F + k * 129;
-  float* P = Mx + k * (kKMax + 1);
-  float* vec = P + kKMax * 8;
+             int N, int tiles, int S, int k, int iters, float inv_sigma2, float inv_sigmad2) {
+  __shared__ float Mx[kKMax * (kKMax + 1)];
+  __shared__ float P[kKMax * 8];
+  __shared__ float vec[kKMax];
   const int pair = blockIdx.y, s = blockIdx.x, a = threadIdx.x;
+  const int lane = a, h = lane >> 5, i = lane & 31;
   const int* nb = knn_idx + ((size_t)pair * S + s) * k;
-  const float* fb = feat_n + (size_t)pair * N * 128;
-  for (int r = 0; r < k; ++r) {
-    const int j = nb[r];
-    F[r * 129 + a] = fb[(size_t)j * 128 + a];
-    F[r * 129 + 64 + a] = fb[(size_t)j * 128 + 64 + a];
+  const float* pair_img = featn_img + (size_t)pair * tiles * (32 * 128);
+  {
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* Pz = reinterpret_cast<float4*>(P);
+    Pz[2 * a] = z; Pz[2 * a + 1] = z;
   }
   if (a < k) {
     const int j = nb[a];
@@ -303,21 +453,46 @@ k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, co
     P[a * 8 + 0] = ps[0]; P[a * 8 + 1] = ps[1]; P[a * 8 + 2] = ps[2];
     P[a * 8 + 4] = pt[0]; P[a * 8 + 5] = pt[1]; P[a * 8 + 6] = pt[2];
   }
+  float fa[64], fb[64];
+  gmf::load_row_frag_p32<64>(fa, pair_img, (i < k) ? nb[i] : -1, N, h);
+  gmf::load_row_frag_p32<64>(fb, pair_img, (32 + i < k) ? nb[32 + i] : -1, N, h);
   __syncthreads();
-  if (a < k) {
-    const float sx = P[a * 8], sy = P[a * 8 + 1], sz = P[a * 8 + 2];
-    const float tx = P[a * 8 + 4], ty = P[a * 8 + 5], tz = P[a * 8 + 6];
-    for (int b = 0; b < k; ++b) {
-      float dot = 0.f;
-#pragma unroll 8
-      for (int c = 0; c < 128; ++c) dot = fmaf(F[a * 129 + c], F[b * 129 + c], dot);
-      const float mf = fmaxf(1.0f - (1.0f - dot) * inv_sigma2, 0.f);
-      const float ax = sx - P[b * 8], ay = sy - P[b * 8 + 1], az = sz - P[b * 8 + 2];
-      const float bx = tx - P[b * 8 + 4], by = ty - P[b * 8 + 5], bz = tz - P[b * 8 + 6];
-      const float d = sqrtf(ax * ax + ay * ay + az * az) - sqrtf(bx * bx + by * by + bz * bz);
-      const float ms = fmaxf(1.0f - d * d * inv_sigmad2, 0.f);
-      Mx[a * (kKMax + 1) + b] = (a == b) ? 0.f : mf * ms;
+
+  // tile (ta, tb): rows 32*ta + a', cols 32*tb + (lane & 31)
+  auto emit_tile = [&](const gmf::f32x16& g, int ta, int tb, bool mirror) {
+    const int b = 32 * tb + i;
+    const float bsx = P[b * 8], bsy = P[b * 8 + 1], bsz = P[b * 8 + 2];
+    const float btx = P[b * 8 + 4], bty = P[b * 8 + 5], btz = P[b * 8 + 6];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ar = 32 * ta + 8 * (r >> 2) + 4 * h + (r & 3);
+      if (ar < k && b < k) {
+        const float mf = fmaxf(1.0f - (1.0f - g[r]) * inv_sigma2, 0.f);
+        const float ax = P[ar * 8] - bsx, ay = P[ar * 8 + 1] - bsy, az = P[ar * 8 + 2] - bsz;
+        const float bx = P[ar * 8 + 4] - btx, by = P[ar * 8 + 5] - bty, bz = P[ar * 8 + 6] - btz;
+        const float d = sqrtf(ax * ax + ay * ay + az * az) - sqrtf(bx * bx + by * by + bz * bz);
+        const float ms = fmaxf(1.0f - d * d * inv_sigmad2, 0.f);
+        const float m = (ar == b) ? 0.f : mf * ms;
+        Mx[ar * (kKMax + 1) + b] = m;
+        if (mirror) Mx[b * (kKMax + 1) + ar] = m;
+      }
     }
+  };
+  {
+    gmf::f32x16 g = gmf::zero16();
+#pragma unroll
+    for (int c = 0; c < 64; ++c) g = gmf::mfma32(fa[c], fa[c], g);
+    emit_tile(g, 0, 0, false);
+  }
+  if (k > 32) {
+    gmf::f32x16 g = gmf::zero16();
+#pragma unroll
+    for (int c = 0; c < 64; ++c) g = gmf::mfma32(fa[c], fb[c], g);
+    emit_tile(g, 0, 1, true);
+    g = gmf::zero16();
+#pragma unroll
+    for (int c = 0; c < 64; ++c) g = gmf::mfma32(fb[c], fb[c], g);
+    emit_tile(g, 1, 1, false);
   }
   vec[a] = 1.0f;
   __syncthreads();
@@ -705,7 +880,16 @@ k_weighted_procrustes(const float* __restrict__ X, const float* __restrict__ Y, 
 static inline int next_pow2(int n) { int m = 1; while (m < n) m <<= 1; return m; }
 
 hipError_t launch_nms_keys(const float* src, const float* scores, float* keys, int B, int N, float R, hipStream_t s) {
-  hipLaunchKernelGGL(k_nms_keys, dim3((N + 255) / 256, B), dim3(256), 0, s, src, scores, keys, N, R);
+  // The reference tests sqrt(d2) >= R (PointDSC.py:283).  sqrtf is monotone, so that is d2 >= t for the smallest float t
+  // with sqrtf(t) >= R; finding t on the host removes the square root from the N^2 loop without changing one decision.
+  float t = R * R;
+  if (R > 0.f) {
+    while (sqrtf(t) >= R && t > 0.f) t = nextafterf(t, 0.f);
+    while (sqrtf(t) < R) t = nextafterf(t, INFINITY);
+  } else {
+    t = 0.f;
+  }
+  hipLaunchKernelGGL(k_nms_keys, dim3((N + 255) / 256, B), dim3(256), 0, s, src, scores, keys, N, t);
   return hipGetLastError();
 }
 
@@ -731,17 +915,24 @@ hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* 
     if (e != hipSuccess) return e;
     attr_set = true;
   }
+  if (dist_in && N <= 256 * 32) {
+    hipLaunchKernelGGL(k_knn_select_fast<32>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k);
+    return hipGetLastError();
+  }
+  if (dist_in && N <= 256 * 64) {
+    hipLaunchKernelGGL(k_knn_select_fast<64>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_knn_seeds, dim3(S, B), dim3(256), (size_t)N * 4, s, feat_n, seeds, dist_in, knn_idx, N, S, k);
   return hipGetLastError();
 }
 
-hipError_t launch_seed_power(const float* feat_n, const float* src, const float* tgt, const int* knn_idx, float* snaps,
+hipError_t launch_seed_power(const float* featn_img, const float* src, const float* tgt, const int* knn_idx, float* snaps,
                              unsigned char* conv, int B, int N, int S, int k, int iters, float sigma, float sigma_d,
                              hipStream_t s) {
   if (k > kKMax) return hipErrorInvalidValue;
-  const size_t sp_lds = ((size_t)k * 129 + (size_t)k * (kKMax + 1) + kKMax * 8 + kKMax) * sizeof(float);
-  hipLaunchKernelGGL(k_seed_power, dim3(S, B), dim3(64), sp_lds, s, feat_n, src, tgt, knn_idx, snaps, conv, N, S, k, iters,
-                     1.0f / (sigma * sigma), 1.0f / (sigma_d * sigma_d));
+  hipLaunchKernelGGL(k_seed_power, dim3(S, B), dim3(64), 0, s, featn_img, src, tgt, knn_idx, snaps, conv, N, (N + 31) / 32, S, k,
+                     iters, 1.0f / (sigma * sigma), 1.0f / (sigma_d * sigma_d));
   return hipGetLastError();
 }
 

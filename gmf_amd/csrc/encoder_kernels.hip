@@ -745,12 +745,15 @@ k_scattn_b3(const float* __restrict__ q_img, const float* __restrict__ k_img, co
 // MFMA phase runs under the other's VALU phase.  Two barriers per tile: B1 after the QK^T phase (K_t is
 // free -> K_{t+1} streams in under the softmax and PV phases), B2 after the PV phase (V_t, pts_t are free
 // -> V_{t+1}, pts_{t+1} stream in under the next QK^T phase).
-template <bool FASTSQRT, int WAVES>
+// DBUF: K | V | pts8 double buffered (66 KB per workgroup, still two workgroups per CU) with ONE barrier per tile:
+// the split-fp16 QK^T phase (24 MFMAs) is too short to hide the V_t transfer of the single-buffered scheme.
+template <bool FASTSQRT, int WAVES, bool DBUF>
 __global__ void __launch_bounds__(64 * WAVES, 2)
 k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
             const float* __restrict__ pts8, const float* __restrict__ fus, const float* __restrict__ wst,
             const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2, int wgs_per_pair) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats + 256];
+  __shared__ __attribute__((aligned(16))) float lds[(DBUF ? 2 : 1) * (2 * kStageFloats + 256)];
+  constexpr int kBuf = 2 * kStageFloats + 256;
   float* const ldsK = lds;
   float* const ldsV = lds + kStageFloats;
   float* const ldsP = lds + 2 * kStageFloats;
@@ -790,25 +793,36 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
   const float* gk = k_img + pbase * (size_t)kStageFloats;
   const float* gv = v_img + pbase * (size_t)kStageFloats;
   const float* gp = pts8 + pbase * 32 * 8;
-  auto issueK = [&](int t) { dma_issue(gk + (size_t)t * kStageFloats, ldsK, 16, wave, WAVES, lane); };
+  auto issueK = [&](int t) { dma_issue(gk + (size_t)t * kStageFloats, ldsK + (DBUF ? (t & 1) * kBuf : 0), 16, wave, WAVES, lane); };
   auto issueV = [&](int t) {
-    dma_issue(gv + (size_t)t * kStageFloats, ldsV, 16, wave, WAVES, lane);
-    if (wave == (t & (WAVES - 1))) dma_piece_1k(gp + (size_t)t * 256, ldsP, lane);
+    dma_issue(gv + (size_t)t * kStageFloats, ldsV + (DBUF ? (t & 1) * kBuf : 0), 16, wave, WAVES, lane);
+    if (wave == (t & (WAVES - 1))) dma_piece_1k(gp + (size_t)t * 256, ldsP + (DBUF ? (t & 1) * kBuf : 0), lane);
   };
 
   f32x16 oacc[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) oacc[db] = zero16();
   float m_run = -INFINITY, l_half = 0.f;
-  const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK) + lane;
-  const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV) + lane;
-  const float4* lp = reinterpret_cast<const float4*>(ldsP) + 8 * h;
+  const f16x8* lk0 = reinterpret_cast<const f16x8*>(ldsK) + lane;
+  const f16x8* lv0 = reinterpret_cast<const f16x8*>(ldsV) + lane;
+  const float4* lp0 = reinterpret_cast<const float4*>(ldsP) + 8 * h;
 
   issueK(0);
   issueV(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (!DBUF) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   for (int t = 0; t < tiles; ++t) {
+    if (DBUF) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t (issued one whole tile ago) has landed
+      __syncthreads();                                   // ... for every wave; buffer (t+1)&1 is free again
+      if (t + 1 < tiles) { issueK(t + 1); issueV(t + 1); }
+    }
+    const int boff = DBUF ? (t & 1) * (kBuf / 4) : 0;    // in 16-byte units
+    const f16x8* lk = lk0 + boff;
+    const f16x8* lv = lv0 + boff;
+    const float4* lp = lp0 + boff;
     // ---- S^T = K_t Q'^T : 8 k-steps x 6 partial products ----
     f32x16 sacc = zero16();
 #pragma unroll
@@ -816,9 +830,11 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
       const f16x8 kh = lk[(0 * 8 + s) * 64], kl = lk[(1 * 8 + s) * 64];
       mma3(sacc, kh, kl, qh[s], ql[s]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V_t, pts_t (issued one phase ago) have landed
-    __syncthreads();                     // B1: every wave is done reading K_t
-    if (t + 1 < tiles) issueK(t + 1);
+    if (!DBUF) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V_t, pts_t (issued one phase ago) have landed
+      __syncthreads();                                   // B1: every wave is done reading K_t
+      if (t + 1 < tiles) issueK(t + 1);
+    }
     // ---- compat, scores, online softmax ----
     float x[16];
     float mx = -INFINITY;
@@ -867,9 +883,11 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
         mma3(oacc[db], vh, vl, ph, pl);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K_{t+1} (issued two phases ago) has landed
-    __syncthreads();                     // B2: every wave is done reading V_t, pts_t
-    if (t + 1 < tiles) issueV(t + 1);
+    if (!DBUF) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K_{t+1} (issued two phases ago) has landed
+      __syncthreads();                                   // B2: every wave is done reading V_t, pts_t
+      if (t + 1 < tiles) issueV(t + 1);
+    }
   }
 
   // ---- epilogue: normalise, fc_message (fp32 MFMA), add the Fusion-2 branch ----
@@ -1674,6 +1692,8 @@ __global__ void k_pack_pts8(const float* __restrict__ src, const float* __restri
 namespace gmf {
 
 static int g_scattn_variant = [] { const char* e = getenv("GMF_SCATTN"); return e ? atoi(e) : 9; }();
+static bool g_h2_dbuf = [] { const char* e = getenv("GMF_H2_DBUF"); return e ? atoi(e) != 0 : true; }();
+void set_h2_dbuf(bool v) { g_h2_dbuf = v; }
 static bool g_force_fp32_qkv = false;   // set while the dense-compat (drop-in NonLocalBlock) path runs
 void set_force_fp32_qkv(bool v) { g_force_fp32_qkv = v; }
 void set_scattn_variant(int v) { g_scattn_variant = v; }
@@ -1718,8 +1738,11 @@ hipError_t launch_scattn(const float* q, const float* k, const float* v, const f
         default: hipLaunchKernelGGL((k_scattn_b3<true, 4, 5>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp); break;
       }
     }
-    else if (variant == 9) hipLaunchKernelGGL((k_scattn_h2<false, 4>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
-    else if (variant == 10) hipLaunchKernelGGL((k_scattn_h2<true, 4>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
+    else if (variant == 9) {
+      if (g_h2_dbuf) hipLaunchKernelGGL((k_scattn_h2<false, 4, true>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
+      else hipLaunchKernelGGL((k_scattn_h2<false, 4, false>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
+    }
+    else if (variant == 10) hipLaunchKernelGGL((k_scattn_h2<true, 4, true>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
     else if (variant == 7) hipLaunchKernelGGL((k_scattn_b3<false, 8>), grid8, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp8);
     else if (variant == 8) hipLaunchKernelGGL((k_scattn_b3<true, 8>), grid8, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp8);
     else if (variant == 5) hipLaunchKernelGGL(k_scattn_b3p<false>, grid, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);

@@ -117,6 +117,10 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     gmf::set_scattn_variant(value);
     return GMF_OK;
   }
+  if (std::strcmp(name, "h2_double_buffer") == 0) {
+    gmf::set_h2_dbuf(value != 0);
+    return GMF_OK;
+  }
   return fail(h, GMF_ERR_BAD_ARG, std::string("gmf: set_tuning: unknown knob ") + name);
 }
 

@@ -6,6 +6,7 @@ namespace gmf {
 
 void set_scattn_variant(int v);
 void set_force_fp32_qkv(bool v);
+void set_h2_dbuf(bool v);
 int get_scattn_variant();
 hipError_t launch_front(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
                         float* v, int B, int N, int tiles, hipStream_t s);

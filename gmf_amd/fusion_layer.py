@@ -78,8 +78,9 @@ class FusionLayer(nn.Module):
     def _blobs(self, device):
         ver = (params_version(self), str(device))
         if self._packed is None or self._packed_version != ver:
-            sd = {k: v.detach().to(device) for k, v in self.state_dict().items()}
-            self._packed = packing.pack_fusion(sd, "", self.pe)
+            sd = {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()}
+            packed = packing.pack_fusion(sd, "", self.pe)
+            self._packed = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in packed.items()}
             self._packed_version = ver
         return self._packed
 

@@ -224,14 +224,15 @@ class PackedEncoder:
     """All blobs of NonLocalNet + classifier on one device, plus the ctypes struct handed to the C ABI."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], num_layers: int, device, standalone_block: bool = False):
-        sd = {k: v.to(device) for k, v in sd.items() if v.is_floating_point()}
+        # pack on the host (a few hundred small permutes), then move the finished blobs to the device once
+        sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items() if v.is_floating_point()}
         self.num_layers = num_layers
         f1 = pack_fusion(sd, "encoder.fusion_layer_1.", pe=False) if "encoder.fusion_layer_1.cross_attend_blocks.0.fn.to_q.weight" in sd else None
         f2 = [pack_fusion(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.", pe=True) for i in range(num_layers)]
         fronts = [pack_front(sd, i, with_layer0=(i == 0 and "encoder.layer0.weight" in sd),
                              identity_pointcn=standalone_block) for i in range(num_layers)]
         tails = [pack_tail(sd, i) for i in range(num_layers)]
-        st = lambda lst: torch.stack(lst).contiguous() if lst else torch.zeros(1, device=device)
+        st = lambda lst: torch.stack(lst).contiguous() if lst else torch.zeros(1)
         self.t = {
             "ctx_wst": st([f["ctx_wst"] for f in f2]), "ctx_vec": st([f["ctx_vec"] for f in f2]),
             "attn_wst": st([f["attn_wst"] for f in f2]), "attn_vec": st([f["attn_vec"] for f in f2]),
@@ -258,6 +259,7 @@ class PackedEncoder:
                                                for i in range(num_layers)]).contiguous()
         if "classification.0.weight" in sd:
             self.t["head_wst"], self.t["head_vec"] = pack_head(sd)
+        self.t = {k: v.to(device) for k, v in self.t.items() if torch.is_tensor(v)}
         self.sigma_d = float(sd["sigma_spat"].detach().reshape(-1)[0]) if "sigma_spat" in sd else 0.1
         self.sigma = float(sd["sigma"].detach().reshape(-1)[0]) if "sigma" in sd else 1.0   # read once here: no per-call host sync
         w = _lib.EncoderWeights()

@@ -16,6 +16,8 @@ from gmf_amd import _lib, synthetic              # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 variants = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "0,1,2".split(","))]
+if len(sys.argv) > 4:      # optional extra knob, e.g. h2_double_buffer=0
+    knob, val = sys.argv[4].split("=")
 dev = torch.device("cuda:0")
 sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7)
 model = gmf_amd.PointDSC(num_layers=12)
@@ -24,6 +26,8 @@ model = model.to(dev).eval()
 b = synthetic.synthetic_batch(list(range(B)), N=N, T=196)
 args = [b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")]
 h = _lib.handle_for(0)
+if len(sys.argv) > 4:
+    h.call("gmf_set_tuning", knob.encode(), int(val))
 
 ref = None
 if N <= 5000:

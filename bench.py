@@ -29,7 +29,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+# /opt/skills/guides/MI355X_MICROARCH.md, "Chip-level parameters": dense MFMA peaks
+PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_F16_MFMA_TFLOPS = 2500.0
+# MFMA products issued per algorithmic multiply-add by each form of the attention kernel (gmf_set_tuning "scattn_variant")
+PRODUCTS = {0: 1, 1: 1, 2: 1, 3: 6, 4: 6, 5: 6, 6: 6, 7: 6, 8: 6, 9: 3, 10: 3}
 
 
 def scattn_flops_per_launch(B: int, N: int) -> float:
@@ -108,16 +112,30 @@ def main():
     value = world * B * N * args.steps / dt
     avg_ms = ms_total.value / max(1, launches.value)
     achieved = scattn_flops_per_launch(B, N) / (avg_ms * 1e-3) / 1e12
+    variant = int(os.environ.get("GMF_SCATTN", "9"))
+    nprod = PRODUCTS.get(variant, 3)
+    if nprod == 1:
+        peak, peak_note, dtype = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA dense peak", "f32"
+    else:
+        peak = PEAK_F16_MFMA_TFLOPS / nprod
+        peak_note = (f"f16/bf16 MFMA dense peak 2500 TFLOP/s / {nprod} partial products per algorithmic multiply-add "
+                     "(split-precision operands, fp32 accumulate, fp32-equivalent results)")
+        dtype = "f32 (split-fp16 MFMA operands, fp32 accumulate)" if nprod == 3 else "f32 (split-bf16 MFMA operands, fp32 accumulate)"
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_scattn_h2_pmc.json")
+    if variant == 9 and (B, N, T) == (32, 5000, 196) and os.path.exists(pmc_file):
+        traffic = json.load(open(pmc_file))["derived"]["traffic_bytes_per_launch"]   # rocprofv3 PMC, see the file
     line = {
         "metric": "correspondences/sec (whole node)", "value": value, "unit": "correspondences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": f"synthetic {args.kind}-shape pairs, PointDSC.forward test mode (logits + R,t)",
                    "pairs_per_gpu": B, "global_pairs": world * B, "n_corr": N, "feat_dim": 128, "image_tokens": T,
                    "layers": 12, "parallelism": f"pairs sharded over {world} GPU(s), RCCL all-gather of logits+poses"},
         "roofline": {"bound": "mfma", "kernel": "k_scattn (spatial-consistency attention + fc_message)",
-                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": traffic, "peak_note": peak_note,
+                     "executed_mfma_tflops": achieved * nprod, "x_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "avg_launch_ms": avg_ms, "launches_timed": launches.value,
                      "flops_per_launch": scattn_flops_per_launch(B, N)},
     }

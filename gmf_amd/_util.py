@@ -24,8 +24,33 @@ def handle_and_stream(t: torch.Tensor):
     return _lib.handle_for(idx), torch.cuda.current_stream(idx).cuda_stream
 
 
+class WeightWatcher:
+    """Cheap change detector for the packed-weight cache.
+
+    Walking named_parameters() costs milliseconds per call on a 600-tensor model; the tensor list is therefore
+    captured once (and again whenever Module._apply / load_state_dict may have replaced tensors - the owner calls
+    `invalidate()` from those hooks) and a call only sums the in-place version counters (~0.1 ms)."""
+
+    def __init__(self, module: torch.nn.Module, skip_prefix: str = None):
+        self.module, self.skip = module, skip_prefix
+        self.tensors = None
+
+    def invalidate(self):
+        self.tensors = None
+
+    def version(self) -> int:
+        if self.tensors is None:
+            named = list(self.module.named_parameters()) + list(self.module.named_buffers())
+            self.tensors = [t for n, t in named if not (self.skip and n.startswith(self.skip))]
+            self.base = hash(tuple(t.data_ptr() for t in self.tensors))
+        v = self.base
+        for t in self.tensors:
+            v += t._version
+        return v
+
+
 def params_version(module: torch.nn.Module) -> int:
-    """Cheap change detector for the packed-weight cache: sum of tensor versions + storage pointers."""
+    """One-shot form (small modules)."""
     v = 0
     for p in list(module.parameters()) + list(module.buffers()):
         v = (v * 1000003 + p._version * 31 + p.data_ptr()) & 0xFFFFFFFFFFFF

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib, packing
-from ._util import handle_and_stream, params_version, require_cuda_f32
+from ._util import WeightWatcher, handle_and_stream, params_version, require_cuda_f32
 from .fusion_layer import FusionLayer
 
 
@@ -179,6 +179,7 @@ class PointDSC(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
         self._packed, self._packed_version = None, None
+        self._watch = WeightWatcher(self, skip_prefix="encoder.image_encoder.")
         self.last_logits = None
         self.last_features = None
 
@@ -186,12 +187,20 @@ class PointDSC(nn.Module):
     def _hot_state(self):
         return {k: v for k, v in self.state_dict().items() if not k.startswith("encoder.image_encoder.")}
 
+    def _apply(self, fn, *a, **kw):            # .to() / .cuda() / .float(): tensors may be replaced
+        out = super()._apply(fn, *a, **kw)
+        if hasattr(self, "_watch"):
+            self._watch.invalidate()
+        return out
+
+    def load_state_dict(self, *a, **kw):
+        out = super().load_state_dict(*a, **kw)
+        self._watch.invalidate()
+        self._packed = None
+        return out
+
     def _weights(self, device):
-        hot = [p for n, p in list(self.named_parameters()) + list(self.named_buffers()) if not n.startswith("encoder.image_encoder.")]
-        ver = 0
-        for p in hot:
-            ver = (ver * 1000003 + p._version * 31 + p.data_ptr()) & 0xFFFFFFFFFFFF
-        key = (ver, str(device))
+        key = (self._watch.version(), device)
         if self._packed is None or self._packed_version != key:
             self._packed = packing.PackedEncoder(self._hot_state(), self.encoder.num_layers, device)
             self._packed_version = key

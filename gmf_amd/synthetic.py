@@ -137,7 +137,7 @@ def seeded_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, gain: float
         elif leaf == "weight" and ".cpe." in k:   # depthwise k=3 taps
             v = r.normal(0.0, 0.3, shp)
         else:                                      # dense weight [out, in, (1)]
-            fan_in = shp[1]
+            fan_in = int(np.prod(shp[1:]))         # [out, in, (k...)]: conv1x1, Linear and Conv2d alike
             g = gain
             if ".projection_q." in k or ".projection_k." in k:
                 g *= 2.5                           # sharper spatial-consistency attention

@@ -251,6 +251,18 @@ def main():
         out[f"Rgt_{N}"], out[f"tgt_{N}"] = R.astype(np.float32), t.astype(np.float32)
     np.savez_compressed(os.path.join(GOLD, "f8_weighted_procrustes.npz"), **out)
 
+    # ---------------- F11: image encoder (ResNet-34 -> layer2), SURVEY section 8 row f-1 -----------------
+    import models.Img_Encoder as ie
+    enc = ie.ImageEncoder().eval()
+    shapes_ie = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    sd_ie = O.seeded_state_dict(shapes_ie, seed=111, gain=1.0)
+    enc.load_state_dict(sd_ie)
+    r = np.random.default_rng([111])
+    img = torch.from_numpy(r.uniform(0, 1, (2, 3, 120, 160)).astype(np.float32))
+    feat = enc(img)                                   # [2,128,15,20]
+    tok = feat.view(2, 128, -1).permute(0, 2, 1)      # PointDSC.py:129-131
+    np.savez_compressed(os.path.join(GOLD, "f11_image_encoder.npz"), seed=111, tokens=_np(tok).astype(np.float32))
+
     # ---------------- state_dict surface (key names + shapes) of the reference modules -------------
     import json
     ref_full = pdsc.PointDSC(in_dim=6, num_layers=12, num_channels=128)

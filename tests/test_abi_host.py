@@ -129,3 +129,21 @@ def test_se3_helpers():
     R, t = SE3.decompose_trans(T1)
     assert torch.equal(SE3.integrate_trans(R, t), T1)
     assert torch.allclose(SE3.concatenate(T1, T1)[:, :3, 3], torch.tensor([2.0, 4.0, 6.0]).repeat(2, 1))
+
+
+def test_image_encoder_matches_reference(golden_dir):
+    """the ResNet-34 -> layer2 image encoder (plain PyTorch module, MIOpen on the GPU) produces
+    the reference's tokens from the same seeded weights (reference keys; its unused layer3/layer4/fc are ignored)."""
+    import gmf_amd
+    from gmf_amd import synthetic
+    g = np.load(os.path.join(golden_dir, "f11_image_encoder.npz"))
+    enc = gmf_amd.ImageEncoder().eval()
+    shapes = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    enc.load_state_dict(synthetic.seeded_state_dict(shapes, seed=int(g["seed"]), gain=1.0))
+    r = np.random.default_rng([111])
+    img = torch.from_numpy(r.uniform(0, 1, (2, 3, 120, 160)).astype(np.float32))
+    with torch.no_grad():
+        f = enc(img)
+    assert f.shape == (2, 128, 15, 20)
+    tok = f.view(2, 128, -1).permute(0, 2, 1)
+    assert np.abs(tok.numpy() - g["tokens"]).max() < 1e-4 * max(1.0, np.abs(g["tokens"]).max())

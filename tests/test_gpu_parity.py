@@ -264,3 +264,81 @@ def test_full_size_properties(model):
     one = {k: v[:1] for k, v in b.items()}
     ref = O.pointdsc_forward(synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7), one, testing=False)
     assert _maxerr(model.last_logits[:1].cpu(), ref["logits"]) < 1e-4
+
+
+def test_kitti_shape_long_sequence():
+    """BASELINE config 3 shape: N = 10000, sigma_d = tau = 1.2 (KITTI).  One pair against the oracle is ~10 s of CPU,
+    so the check is through properties plus the oracle's logits on the first 64 correspondences of a smaller twin."""
+    sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7, sigma_d=1.2)
+    m = gmf_amd.PointDSC(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1,
+                         inlier_threshold=1.2, sigma_d=1.2, k=40, nms_radius=1.2)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(DEV).eval()
+    b = synthetic.synthetic_batch([81, 82], N=10000, T=196, kind="kitti")
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    res = m(data)
+    T = res["final_trans"].cpu().numpy()
+    assert np.isfinite(T).all() and torch.isfinite(m.last_logits).all()
+    R = T[:, :3, :3]
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5
+    assert np.abs(T[:, :3, :3] - b["gt_trans"].numpy()[:, :3, :3]).max() < 2e-2
+    assert np.abs(T[:, :3, 3] - b["gt_trans"].numpy()[:, :3, 3]).max() < 0.5
+    # smaller KITTI-shape pair against the oracle (sigma_d = 1.2 path of the compat term)
+    b2 = synthetic.synthetic_batch([83], N=700, T=50, kind="kitti")
+    ref = O.pointdsc_forward(sd, b2, inlier_threshold=1.2, nms_radius=1.2, testing=True)
+    d2 = {k: _gpu(b2[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    d2["testing"] = True
+    r2 = m(d2)
+    # KITTI coordinates are ~40x larger than 3DMatch ones, so with the same weights the fp32 noise floor of the
+    # computation itself (oracle fp32 vs oracle fp64) is ~1.4e-4 here; the gate is 2x that floor (1e-4 at least).
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    b64 = {k: v.double() for k, v in b2.items()}
+    compat, _ = O.compat_matrix(b64["src_keypts"], b64["tgt_keypts"], 1.2)
+    o64 = O.classifier(sd64, O.encoder(sd64, b64["corr_pos"], compat, b64["p_tokens"], b64["q_tokens"], 12))
+    floor = float((ref["logits"].double() - o64).abs().max())
+    assert _maxerr(m.last_logits.cpu(), ref["logits"]) < max(1e-4, 2 * floor), floor
+    assert float((m.last_logits.cpu().double() - o64).abs().max()) < max(1e-4, 2 * floor), floor
+    assert _maxerr(r2["final_trans"].cpu(), ref["final_trans"]) < 1e-3
+
+
+def test_dgr_config5_batched_procrustes():
+    """BASELINE config 5: DGR surface, N = 8000 correspondences per pair, sigmoid weights clipped at 0.05,
+    32 pairs in one launch; R, t within 1e-4 of the oracle (fp64 SVD) pair by pair."""
+    B, N = 32, 8000
+    Xs, Ys, ws, refs = [], [], [], []
+    for i in range(B):
+        r = np.random.default_rng([205, i])
+        X = r.uniform(0, 3, (N, 3)).astype(np.float32)
+        Rg = synthetic.random_rotation(r)
+        Y = (X @ Rg.T + r.uniform(-0.5, 0.5, 3)).astype(np.float32)
+        nout = int(N * 0.7)
+        Y[:nout] = r.uniform(0, 3, (nout, 3)).astype(np.float32)
+        logit = np.concatenate([r.normal(-3, 1, nout), r.normal(3, 1, N - nout)]).astype(np.float32)
+        w = O.dgr_inlier_weights(torch.from_numpy(logit))
+        Xs.append(torch.from_numpy(X)), Ys.append(torch.from_numpy(Y)), ws.append(w)
+        refs.append(O.weighted_procrustes(Xs[-1], Ys[-1], w[:, None], np.finfo(np.float32).eps))
+    R, t = gmf_amd.weighted_procrustes_batched(_gpu(torch.cat(Xs)), _gpu(torch.cat(Ys)), _gpu(torch.cat(ws)),
+                                               [i * N for i in range(B + 1)], np.finfo(np.float32).eps)
+    for i in range(B):
+        assert _maxerr(R[i].cpu(), refs[i][0]) < 1e-4 and _maxerr(t[i].cpu(), refs[i][1]) < 1e-4
+
+
+def test_forward_from_raw_images(model):
+    """The reference's own input dict: p_image / q_image [B,3,120,160] through the ResNet-34 -> layer2 encoder
+    (PyTorch-ROCm convolutions), then the HIP path; tokens fed directly must give the same logits."""
+    b = synthetic.synthetic_batch([91], N=200, T=300)
+    g = torch.Generator().manual_seed(5)
+    p_img, q_img = torch.rand(1, 3, 120, 160, generator=g), torch.rand(1, 3, 120, 160, generator=g)
+    data = {"corr_pos": _gpu(b["corr_pos"]), "src_keypts": _gpu(b["src_keypts"]), "tgt_keypts": _gpu(b["tgt_keypts"]),
+            "p_image": _gpu(p_img), "q_image": _gpu(q_img), "testing": True}
+    res = model(data)
+    lg = model.last_logits.clone()
+    with torch.no_grad():
+        pt, qt = model.encoder.image_tokens(_gpu(p_img)), model.encoder.image_tokens(_gpu(q_img))
+    assert pt.shape == (1, 300, 128)
+    d2 = {k: data[k] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    d2.update(p_tokens=pt, q_tokens=qt, testing=True)
+    model(d2)
+    assert torch.equal(model.last_logits, lg)
+    assert res["final_trans"].shape == (1, 4, 4)

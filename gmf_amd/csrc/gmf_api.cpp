@@ -559,6 +559,23 @@ int gmf_knn_rows(gmf_handle* h, const float* feat_n, const int* rows, int B, int
   return GMF_OK;
 }
 
+int gmf_nn_match(gmf_handle* h, const float* F0, const float* F1, int N0, int N1, int d, int mode, int* idx_out,
+                 float* dist_out, gmf_stream_t stream) {
+  GMF_REQUIRE(h && F0 && F1 && idx_out && dist_out, GMF_ERR_BAD_ARG, "nn_match: null pointer");
+  GMF_REQUIRE(N0 > 0 && N1 > 0 && d > 0, GMF_ERR_UNSUPPORTED_SHAPE, "nn_match: empty input");
+  GMF_REQUIRE(mode >= 0 && mode <= 2, GMF_ERR_BAD_ARG, "nn_match: mode must be 0 (PointDSC), 1 (DGR L2) or 2 (DGR SquareL2)");
+  const int K = gmf::padded_desc_width(d);
+  GMF_REQUIRE(K > 0, GMF_ERR_UNSUPPORTED_SHAPE, "nn_match: descriptor width above 128 is not supported");
+  SetDevice sd(h);
+  const size_t n0 = (size_t)tiles_of(N0) * 32 * K, n1 = (size_t)tiles_of(N1) * 32 * K + 4096;
+  if (int rc = arena_reserve(h, arena_need(n0, 4) + arena_need(n1, 4) + arena_need((size_t)N1, 4))) return rc;
+  float* i0 = arena_take<float>(h, n0);
+  float* i1 = arena_take<float>(h, n1);      // + one stage of slack: the last stage may be read past the final tile
+  float* nb = arena_take<float>(h, (size_t)N1);
+  GMF_HIP(gmf::launch_nn_match(F0, F1, i0, i1, nb, idx_out, dist_out, N0, N1, d, mode, S(stream)));
+  return GMF_OK;
+}
+
 int gmf_procrustes_batched(gmf_handle* h, const float* A, const float* Bp, const float* weights, int n, int k,
                            float weight_threshold, float* T44, gmf_stream_t stream) {
   GMF_REQUIRE(h && A && Bp && T44, GMF_ERR_BAD_ARG, "procrustes_batched: null pointer");

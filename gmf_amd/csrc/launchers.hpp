@@ -35,6 +35,9 @@ hipError_t launch_ctx_prep_h2(bool pe, const float* ctx, const float* wst, const
 hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
                                  float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
 hipError_t launch_fusion_ff_h2(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
+int padded_desc_width(int d);
+hipError_t launch_nn_match(const float* F0, const float* F1, float* f0_img, float* f1_img, float* norm2, int* idx,
+                           float* dist, int N0, int N1, int d, int mode, hipStream_t s);
 hipError_t launch_seed_dist(const float* featn_img, const int* seeds, float* dist, int B, int N, int S, hipStream_t s);
 hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s);
 hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s);

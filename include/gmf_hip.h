@@ -198,6 +198,16 @@ int gmf_pick_seeds(gmf_handle* h, const float* src_keypts, const float* scores, 
 int gmf_knn_rows(gmf_handle* h, const float* feat_n, const int* rows, int B, int N, int S, int k, int* knn_out,
                  gmf_stream_t stream);
 
+/* Descriptor-space nearest neighbour: for every row of F0 [N0,d] the closest row of F1 [N1,d] (row-major, d <= 128),
+ * ties to the lower index, fused distance GEMM + row argmin (no N0 x N1 matrix).
+ *   mode 0: PointDSC matching (datasets/ThreeDMatch.py:164-166, demo_registration.py:101-103), unit descriptors:
+ *           dist = sqrt(2 - 2 <a,b> + 1e-6);
+ *   mode 1: DGR find_knn_gpu with nn_max_n > 1 (core/knn.py:50-64): dist = sqrt(||a-b||^2 + 1e-7) (pdist 'L2');
+ *   mode 2: DGR find_knn_gpu with nn_max_n <= 1 (core/knn.py:66-70): dist = ||a-b||^2 (pdist 'SquareL2').
+ * idx_out [N0] int32, dist_out [N0]. */
+int gmf_nn_match(gmf_handle* h, const float* F0, const float* F1, int N0, int N1, int d, int mode, int* idx_out,
+                 float* dist_out, gmf_stream_t stream);
+
 /* rigid_transform_3d(A, B, weights, weight_threshold) (models/common.py:10-50):
  * A,B [n,k,3], weights [n,k] or NULL -> T [n,4,4].  The 3x3 SVD runs on the device. */
 int gmf_procrustes_batched(gmf_handle* h, const float* A, const float* B, const float* weights, int n, int k,

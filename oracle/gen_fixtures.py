@@ -263,6 +263,26 @@ def main():
     tok = feat.view(2, 128, -1).permute(0, 2, 1)      # PointDSC.py:129-131
     np.savez_compressed(os.path.join(GOLD, "f11_image_encoder.npz"), seed=111, tokens=_np(tok).astype(np.float32))
 
+    # ---------------- F12: descriptor matching (row f-2) ---------------------------------------------
+    import core.knn as dgr_knn
+    out = {}
+    for d, N0, N1 in ((32, 500, 700), (33, 257, 300)):
+        r = np.random.default_rng([112, d])
+        F1 = r.normal(0, 1, (N1, d)).astype(np.float32)
+        F1 /= np.linalg.norm(F1, axis=1, keepdims=True)
+        F0 = F1[r.integers(0, N1, N0)] + 0.15 * r.normal(0, 1, (N0, d)).astype(np.float32)
+        F0 /= np.linalg.norm(F0, axis=1, keepdims=True)
+        F0, F1 = F0.astype(np.float32), F1.astype(np.float32)
+        # PointDSC: the numpy expressions of datasets/ThreeDMatch.py:164-166
+        distance = np.sqrt(2 - 2 * (F0 @ F1.T) + 1e-6)
+        out[f"pdsc_idx_{d}"], out[f"pdsc_dis_{d}"] = np.argmin(distance, axis=1), np.min(distance, axis=1)
+        i1, d1 = dgr_knn.find_knn_gpu(torch.from_numpy(F0), torch.from_numpy(F1), nn_max_n=250, knn=1, return_distance=True)
+        i2, d2 = dgr_knn.find_knn_gpu(torch.from_numpy(F0), torch.from_numpy(F1), nn_max_n=-1, knn=1, return_distance=True)
+        out[f"dgr_idx_chunk_{d}"], out[f"dgr_dis_chunk_{d}"] = _np(i1), _np(d1)
+        out[f"dgr_idx_{d}"], out[f"dgr_dis_{d}"] = _np(i2), _np(d2)
+        out[f"F0_{d}"], out[f"F1_{d}"] = F0, F1
+    np.savez_compressed(os.path.join(GOLD, "f12_descriptor_matching.npz"), **out)
+
     # ---------------- state_dict surface (key names + shapes) of the reference modules -------------
     import json
     ref_full = pdsc.PointDSC(in_dim=6, num_layers=12, num_channels=128)

@@ -344,3 +344,29 @@ def dgr_inlier_weights(logits, clip: float = 0.05):
     """sigmoid then zero weights below `clip` (core/deep_global_registration.py:323-325)."""
     w = torch.sigmoid(logits)
     return torch.where(w < clip, torch.zeros_like(w), w)
+
+
+# --------------------------------------------------------------------------
+# Descriptor matching (SURVEY section 8 row f-2)
+# --------------------------------------------------------------------------
+def nn_match_pointdsc(src_desc, tgt_desc):
+    """GMF_PointDSC/datasets/ThreeDMatch.py:164-166 / demo_registration.py:101-103 for unit descriptors."""
+    distance = torch.sqrt(2 - 2 * (src_desc @ tgt_desc.t()) + 1e-6)
+    dis, idx = distance.min(dim=1)
+    return idx, dis
+
+
+def find_knn_dgr(F0, F1, nn_max_n: int = -1):
+    """DGR find_knn_gpu with knn=1 (core/knn.py:23-74; pdist core/metrics.py:62-69): chunks of nn_max_n rows use the
+    L2 distance sqrt(D2 + 1e-7), the unchunked path the squared distance."""
+    def d2(a, b):
+        return ((a[:, None, :] - b[None, :, :]) ** 2).sum(2)
+    if nn_max_n > 1:
+        ds, ix = [], []
+        for i in range(0, len(F0), nn_max_n):
+            dist = torch.sqrt(d2(F0[i:i + nn_max_n], F1) + 1e-7)
+            m, j = dist.min(dim=1, keepdim=True)
+            ds.append(m), ix.append(j)
+        return torch.cat(ix), torch.cat(ds)
+    m, j = d2(F0, F1).min(dim=1)
+    return j, m[:, None]

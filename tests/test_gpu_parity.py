@@ -342,3 +342,31 @@ def test_forward_from_raw_images(model):
     model(d2)
     assert torch.equal(model.last_logits, lg)
     assert res["final_trans"].shape == (1, 4, 4)
+
+
+@pytest.mark.parametrize("d", [32, 33])
+def test_f12_descriptor_matching(golden_dir, d):
+    """Row f-2: fused distance GEMM + row argmin against the reference's matching on both plugin surfaces."""
+    g = _load(golden_dir, "f12_descriptor_matching.npz")
+    F0, F1 = _gpu(torch.from_numpy(g[f"F0_{d}"])), _gpu(torch.from_numpy(g[f"F1_{d}"]))
+    idx, dis = gmf_amd.nn_match(F0, F1)
+    assert (idx.cpu().numpy() == g[f"pdsc_idx_{d}"]).all()
+    assert _maxerr(dis.cpu(), g[f"pdsc_dis_{d}"]) < 1e-4
+    i1, d1 = gmf_amd.find_knn_gpu(F0, F1, nn_max_n=250, knn=1, return_distance=True)
+    assert i1.shape == (F0.shape[0], 1) and (i1.cpu().numpy() == g[f"dgr_idx_chunk_{d}"]).all()
+    assert _maxerr(d1.cpu(), g[f"dgr_dis_chunk_{d}"]) < 1e-5
+    i2, d2 = gmf_amd.find_knn_gpu(F0, F1, nn_max_n=-1, knn=1, return_distance=True)
+    assert (i2.cpu().numpy() == g[f"dgr_idx_{d}"]).all() and _maxerr(d2.cpu(), g[f"dgr_dis_{d}"]) < 1e-5
+
+
+def test_descriptor_matching_full_size():
+    """BASELINE config 5 shape: FCGF d = 32, 8000 x 8000; property: the match of a perturbed copy is its original."""
+    r = np.random.default_rng(8000)
+    F1 = r.normal(0, 1, (8000, 32)).astype(np.float32)
+    F1 /= np.linalg.norm(F1, axis=1, keepdims=True)
+    perm = r.permutation(8000)
+    F0 = F1[perm] + 0.02 * r.normal(0, 1, (8000, 32)).astype(np.float32)
+    F0 /= np.linalg.norm(F0, axis=1, keepdims=True)
+    idx, dis = gmf_amd.nn_match(_gpu(torch.from_numpy(F0.astype(np.float32))), _gpu(torch.from_numpy(F1)))
+    assert (idx.cpu().numpy() == perm).all()
+    assert float(dis.max()) < 0.3

@@ -131,3 +131,15 @@ def test_f8_weighted_procrustes(golden_dir, N):
     assert np.abs(t.numpy() - g[f"t_{N}"]).max() < 1e-5
     if N >= 1000:
         assert np.abs(g[f"R_{N}"] - g[f"Rgt_{N}"]).max() < 5e-2
+
+
+@pytest.mark.parametrize("d", [32, 33])
+def test_f12_descriptor_matching(golden_dir, d):
+    g = _load(golden_dir, "f12_descriptor_matching.npz")
+    F0, F1 = torch.from_numpy(g[f"F0_{d}"]), torch.from_numpy(g[f"F1_{d}"])
+    idx, dis = O.nn_match_pointdsc(F0, F1)
+    assert (idx.numpy() == g[f"pdsc_idx_{d}"]).all() and np.abs(dis.numpy() - g[f"pdsc_dis_{d}"]).max() < 1e-5
+    i1, d1 = O.find_knn_dgr(F0, F1, nn_max_n=250)
+    assert (i1.numpy() == g[f"dgr_idx_chunk_{d}"]).all() and np.abs(d1.numpy() - g[f"dgr_dis_chunk_{d}"]).max() < 1e-6
+    i2, d2 = O.find_knn_dgr(F0, F1, nn_max_n=-1)
+    assert (i2.numpy() == g[f"dgr_idx_{d}"]).all() and np.abs(d2.numpy() - g[f"dgr_dis_{d}"]).max() < 1e-6

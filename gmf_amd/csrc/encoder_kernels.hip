@@ -747,11 +747,19 @@ k_scattn_b3(const float* __restrict__ q_img, const float* __restrict__ k_img, co
 // -> V_{t+1}, pts_{t+1} stream in under the next QK^T phase).
 // DBUF: K | V | pts8 double buffered (66 KB per workgroup, still two workgroups per CU) with ONE barrier per tile:
 // the split-fp16 QK^T phase (24 MFMAs) is too short to hide the V_t transfer of the single-buffered scheme.
-template <bool FASTSQRT, int WAVES, bool DBUF>
+// ABL (timing-only ablations, results wrong): 1 = no compat term, 2 = no K/V tile DMA, 3 = no barrier,
+// 4 = no MFMA (VALU and LDS work only), 5 = no compat, no exponentials, no splits (MFMA + LDS + DMA only).
+// CACHED: c_ij does not depend on the layer, so k_compat_build evaluates it ONCE per batch and stores it in the element
+// order of this kernel (4 KiB per 32x32 tile: [q][lane][4 floats], registers r = 4q .. 4q+3 of each lane).  The 12
+// attention launches then stream it back with four coalesced, non-temporal 16-byte loads per lane and tile (prefetched
+// one tile ahead) instead of re-evaluating 2 square roots and ~20 more VALU instructions per element: 100 MB per pair
+// and layer at N = 5000 - HBM bandwidth this otherwise compute-bound kernel was not using.
+template <bool FASTSQRT, int WAVES, bool DBUF, int ABL = 0, bool CACHED = false>
 __global__ void __launch_bounds__(64 * WAVES, 2)
 k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
             const float* __restrict__ pts8, const float* __restrict__ fus, const float* __restrict__ wst,
-            const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2, int wgs_per_pair) {
+            const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2, int wgs_per_pair,
+            const float* __restrict__ c_dense) {
   __shared__ __attribute__((aligned(16))) float lds[(DBUF ? 2 : 1) * (2 * kStageFloats + 256)];
   constexpr int kBuf = 2 * kStageFloats + 256;
   float* const ldsK = lds;
@@ -790,12 +798,23 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
     const float4 a = pp[0], b = pp[1];
     si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
   }
+  const f32x4* crow = nullptr;
+  float c_nxt[16];
+  if (CACHED) crow = reinterpret_cast<const f32x4*>(c_dense) + ((pbase + tile) * (size_t)tiles) * 256 + lane;
+  auto fetch_c = [&](int t) {                 // cached c of key tile t for this wave's 32 queries
+    const f32x4* ct = crow + (size_t)t * 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = __builtin_nontemporal_load(ct + q * 64);
+      c_nxt[4 * q + 0] = v[0]; c_nxt[4 * q + 1] = v[1]; c_nxt[4 * q + 2] = v[2]; c_nxt[4 * q + 3] = v[3];
+    }
+  };
   const float* gk = k_img + pbase * (size_t)kStageFloats;
   const float* gv = v_img + pbase * (size_t)kStageFloats;
   const float* gp = pts8 + pbase * 32 * 8;
-  auto issueK = [&](int t) { dma_issue(gk + (size_t)t * kStageFloats, ldsK + (DBUF ? (t & 1) * kBuf : 0), 16, wave, WAVES, lane); };
+  auto issueK = [&](int t) { if (ABL != 2) dma_issue(gk + (size_t)t * kStageFloats, ldsK + (DBUF ? (t & 1) * kBuf : 0), 16, wave, WAVES, lane); };
   auto issueV = [&](int t) {
-    dma_issue(gv + (size_t)t * kStageFloats, ldsV + (DBUF ? (t & 1) * kBuf : 0), 16, wave, WAVES, lane);
+    if (ABL != 2) dma_issue(gv + (size_t)t * kStageFloats, ldsV + (DBUF ? (t & 1) * kBuf : 0), 16, wave, WAVES, lane);
     if (wave == (t & (WAVES - 1))) dma_piece_1k(gp + (size_t)t * 256, ldsP + (DBUF ? (t & 1) * kBuf : 0), lane);
   };
 
@@ -809,6 +828,7 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
 
   issueK(0);
   issueV(0);
+  if (CACHED) fetch_c(0);
   if (!DBUF) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -816,8 +836,14 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
   for (int t = 0; t < tiles; ++t) {
     if (DBUF) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t (issued one whole tile ago) has landed
-      __syncthreads();                                   // ... for every wave; buffer (t+1)&1 is free again
+      if (ABL != 3) __syncthreads();                     // ... for every wave; buffer (t+1)&1 is free again
       if (t + 1 < tiles) { issueK(t + 1); issueV(t + 1); }
+    }
+    float c_cur[16];
+    if (CACHED) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c_cur[r] = c_nxt[r];
+      if (t + 1 < tiles) fetch_c(t + 1);
     }
     const int boff = DBUF ? (t & 1) * (kBuf / 4) : 0;    // in 16-byte units
     const f16x8* lk = lk0 + boff;
@@ -828,7 +854,8 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const f16x8 kh = lk[(0 * 8 + s) * 64], kl = lk[(1 * 8 + s) * 64];
-      mma3(sacc, kh, kl, qh[s], ql[s]);
+      if (ABL == 4) { sacc[s] += (float)kh[0] + (float)kl[1]; sacc[s + 8] += (float)qh[s][0] * (float)ql[s][1]; }
+      else mma3(sacc, kh, kl, qh[s], ql[s]);
     }
     if (!DBUF) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V_t, pts_t (issued one phase ago) have landed
@@ -842,7 +869,7 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int jl = 8 * (r >> 2) + (r & 3);
-        x[r] = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
+        x[r] = (ABL == 1 || ABL == 5) ? sacc[r] : CACHED ? c_cur[r] * sacc[r] : compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
         mx = fmaxf(mx, x[r]);
       }
     } else {
@@ -850,7 +877,7 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int jl = 8 * (r >> 2) + (r & 3);
-        const float v = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
+        const float v = CACHED ? c_cur[r] * sacc[r] : compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
         x[r] = (jbase + jl < N) ? v : -INFINITY;
         mx = fmaxf(mx, x[r]);
       }
@@ -863,7 +890,7 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
     float ls = 0.f;
     const float m_off = m_new - 10.0f;   // P' = 2^10 P
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
+    for (int r = 0; r < 16; ++r) { x[r] = (ABL == 5) ? (x[r] - m_off) : __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
     l_half = fmaf(l_half, alpha, ls);
     if (__any(moved)) {
 #pragma unroll
@@ -880,7 +907,8 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
       for (int db = 0; db < 4; ++db) {
         const int slot = 2 * db + s2;
         const f16x8 vh = lv[(0 * 8 + slot) * 64], vl = lv[(1 * 8 + slot) * 64];
-        mma3(oacc[db], vh, vl, ph, pl);
+        if (ABL == 4) oacc[db][slot] += (float)vh[0] * (float)ph[1] + (float)vl[2] * (float)pl[3];
+        else mma3(oacc[db], vh, vl, ph, pl);
       }
     }
     if (!DBUF) {
@@ -1192,6 +1220,40 @@ k_scattn_b3p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
       for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r] + fz[r];
       if (active) store_block_p32(out + toff, mb, t, lane);
     }
+  }
+}
+
+// =========================================================================================
+// k_compat_build: the spatial-consistency matrix c_ij = max(0, 1 - (||s_i-s_j|| - ||t_i-t_j||)^2 / sigma_d^2)
+// (PointDSC.py:216-221), evaluated once per batch with the reference's roundings and stored in the element order of the
+// attention kernels: for query tile I and key tile J, lane (h, i) register r is the pair
+// (32I + i, 32J + 8(r>>2) + 4h + (r&3)); tile (I, J) is the 4 KiB block [q][lane][4] with r = 4q + e.
+// grid (tiles, ceil(tiles / (4 * kJPerWave)), B), block 256
+// =========================================================================================
+constexpr int kJPerWave = 8;
+
+__global__ void __launch_bounds__(256)
+k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int N, int tiles, float inv_sig2) {
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.z, I = blockIdx.x;
+  const size_t pbase = (size_t)pair * tiles;
+  float si[3], ti[3];
+  {
+    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)I * 32 + i) * 8);
+    const float4 a = pp[0], b = pp[1];
+    si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
+  }
+  float4* crow = reinterpret_cast<float4*>(c_dense) + ((pbase + I) * (size_t)tiles) * 256 + lane;
+  const int j0 = (blockIdx.y * 4 + wave) * kJPerWave;
+  for (int J = j0; J < min(tiles, j0 + kJPerWave); ++J) {
+    const float4* lp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)J * 32) * 8) + 8 * h;
+    float c[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = compat_times<false>(lp, 8 * (r >> 2) + (r & 3), si, ti, inv_sig2, 1.0f);
+    float4* ct = crow + (size_t)J * 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ct[q * 64] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
   }
 }
 
@@ -1694,6 +1756,9 @@ namespace gmf {
 static int g_scattn_variant = [] { const char* e = getenv("GMF_SCATTN"); return e ? atoi(e) : 9; }();
 static bool g_h2_dbuf = [] { const char* e = getenv("GMF_H2_DBUF"); return e ? atoi(e) != 0 : true; }();
 void set_h2_dbuf(bool v) { g_h2_dbuf = v; }
+static bool g_use_cache = [] { const char* e = getenv("GMF_COMPAT_CACHE"); return e ? atoi(e) != 0 : true; }();
+void set_use_cache(bool v) { g_use_cache = v; }
+bool get_use_cache() { return g_use_cache; }
 static bool g_force_fp32_qkv = false;   // set while the dense-compat (drop-in NonLocalBlock) path runs
 void set_force_fp32_qkv(bool v) { g_force_fp32_qkv = v; }
 void set_scattn_variant(int v) { g_scattn_variant = v; }
@@ -1703,7 +1768,7 @@ static inline dim3 tile_grid(int tiles, int B, int sets = 1) { return dim3((tile
 
 hipError_t launch_front(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
                         float* v, int B, int N, int tiles, hipStream_t s) {
-  const int fmt = g_force_fp32_qkv ? 0 : (g_scattn_variant == 9 || g_scattn_variant == 10) ? 2 : (g_scattn_variant >= 3) ? 1 : 0;
+  const int fmt = g_force_fp32_qkv ? 0 : (g_scattn_variant >= 9) ? 2 : (g_scattn_variant >= 3) ? 1 : 0;
 #define GMF_LAUNCH_FRONT(M, F) hipLaunchKernelGGL((k_front<M, F>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles)
   if (fmt == 1) { if (mode == 1) GMF_LAUNCH_FRONT(1, 1); else if (mode == 2) GMF_LAUNCH_FRONT(2, 1); else GMF_LAUNCH_FRONT(0, 1); }
   else if (fmt == 2) { if (mode == 1) GMF_LAUNCH_FRONT(1, 2); else if (mode == 2) GMF_LAUNCH_FRONT(2, 2); else GMF_LAUNCH_FRONT(0, 2); }
@@ -1712,9 +1777,15 @@ hipError_t launch_front(int mode, const float* in, const float* wst, const float
   return hipGetLastError();
 }
 
+hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s) {
+  const dim3 grid(tiles, (tiles + 4 * kJPerWave - 1) / (4 * kJPerWave), B);
+  hipLaunchKernelGGL(k_compat_build, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, 1.0f / (sigma_d * sigma_d));
+  return hipGetLastError();
+}
+
 hipError_t launch_scattn(const float* q, const float* k, const float* v, const float* pts8, const float* fus,
                          const float* wst, const float* vecs, float* out, int B, int N, int tiles, float sigma_d,
-                         hipStream_t s) {
+                         hipStream_t s, const CompatCache* cc) {
   // GMF_SCATTN / gmf_set_tuning("scattn_variant") selects the kernel form for A/B measurements:
   // 0 = fp32 MFMA, two-phase loop; 1 = fp32 MFMA, software-pipelined; 2 = 1 with v_sqrt_f32;
   // 3 = split-bf16 (3 planes, 6 products) MFMA; 4 = 3 with the rational compat form; 5/6 = 3/4 software-pipelined,
@@ -1731,18 +1802,20 @@ hipError_t launch_scattn(const float* q, const float* k, const float* v, const f
     if (variant == 4) hipLaunchKernelGGL((k_scattn_b3<true, 4>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
     else if (variant >= 11 && variant <= 15) {
       switch (variant) {
-        case 11: hipLaunchKernelGGL((k_scattn_b3<true, 4, 1>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp); break;
-        case 12: hipLaunchKernelGGL((k_scattn_b3<true, 4, 2>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp); break;
-        case 13: hipLaunchKernelGGL((k_scattn_b3<true, 4, 3>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp); break;
-        case 14: hipLaunchKernelGGL((k_scattn_b3<true, 4, 4>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp); break;
-        default: hipLaunchKernelGGL((k_scattn_b3<true, 4, 5>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp); break;
+        case 11: hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 1>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr); break;
+        case 12: hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 2>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr); break;
+        case 13: hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 3>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr); break;
+        case 14: hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 4>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr); break;
+        default: hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 5>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr); break;
       }
     }
     else if (variant == 9) {
-      if (g_h2_dbuf) hipLaunchKernelGGL((k_scattn_h2<false, 4, true>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
-      else hipLaunchKernelGGL((k_scattn_h2<false, 4, false>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
+      const float* cd = (cc && g_use_cache) ? cc->dense : nullptr;
+      if (cd) hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 0, true>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
+      else if (g_h2_dbuf) hipLaunchKernelGGL((k_scattn_h2<false, 4, true>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
+      else hipLaunchKernelGGL((k_scattn_h2<false, 4, false>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
     }
-    else if (variant == 10) hipLaunchKernelGGL((k_scattn_h2<true, 4, true>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
+    else if (variant == 10) hipLaunchKernelGGL((k_scattn_h2<true, 4, true>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr);
     else if (variant == 7) hipLaunchKernelGGL((k_scattn_b3<false, 8>), grid8, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp8);
     else if (variant == 8) hipLaunchKernelGGL((k_scattn_b3<true, 8>), grid8, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp8);
     else if (variant == 5) hipLaunchKernelGGL(k_scattn_b3p<false>, grid, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);

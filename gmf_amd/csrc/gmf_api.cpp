@@ -117,6 +117,10 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     gmf::set_scattn_variant(value);
     return GMF_OK;
   }
+  if (std::strcmp(name, "compat_cache") == 0) {
+    gmf::set_use_cache(value != 0);
+    return GMF_OK;
+  }
   if (std::strcmp(name, "h2_double_buffer") == 0) {
     gmf::set_h2_dbuf(value != 0);
     return GMF_OK;
@@ -265,13 +269,14 @@ static int check_weights(gmf_handle* h, const gmf_encoder_weights* w) {
 
 static bool use_h2(const gmf_encoder_weights* w, bool dense) {
   const int v = gmf::get_scattn_variant();
-  return !dense && (v == 9 || v == 10) && w->front_wst_h2 && w->ctx_wst_h2 && w->attn_wst_h2 && w->ff_wst_h2;
+  return !dense && v >= 9 && w->front_wst_h2 && w->ctx_wst_h2 && w->attn_wst_h2 && w->ff_wst_h2;
 }
 
 // Runs Fusion-2 + the spatial-consistency block of layer `l` given f,q,k,v.
 static int run_block_tail(gmf_handle* h, const gmf_encoder_weights* w, int l, const float* f, const float* q,
                           const float* k, const float* v, const float* pts8, const float* ctx_l, float* x1, float* x2,
-                          float* out, int B, int N, int T, hipStream_t st, const float* dense_compat = nullptr) {
+                          float* out, int B, int N, int T, hipStream_t st, const float* dense_compat = nullptr,
+                          const gmf::CompatCache* cc = nullptr) {
   const int tiles = tiles_of(N), tt = tiles_of(T);
   const bool h2 = use_h2(w, dense_compat != nullptr);
   if (h2) {
@@ -307,7 +312,7 @@ static int run_block_tail(gmf_handle* h, const gmf_encoder_weights* w, int l, co
                                      w->tail_vec + (size_t)l * w->tail_vec_stride, out, B, N, tiles, st));
   else
     GMF_HIP(gmf::launch_scattn(q, k, v, pts8, x2, w->tail_wst + (size_t)l * w->tail_wst_stride,
-                               w->tail_vec + (size_t)l * w->tail_vec_stride, out, B, N, tiles, w->sigma_d, st));
+                               w->tail_vec + (size_t)l * w->tail_vec_stride, out, B, N, tiles, w->sigma_d, st, cc));
   if (ev1) GMF_HIP(hipEventRecord(ev1, st));
   return GMF_OK;
 }
@@ -327,8 +332,13 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   const size_t act = (size_t)B * tiles * kTileFloats;
   const size_t tok = (size_t)B * tt * kTileFloats;
   const size_t act3 = act + act / 2;   // Q', K, V may be bf16x3 plane images (24 KiB per tile)
+  // compat cache (built once per batch, streamed by all L attention launches): 4 KiB per pair of 32-row tiles
+  const size_t n_tt = (size_t)B * tiles * tiles;
+  const bool want_cache = (L > 1) && gmf::get_scattn_variant() == 9 && gmf::get_use_cache() &&
+                          n_tt * 4096 <= ((size_t)96 << 30);
+  const size_t cache_need = want_cache ? arena_need(n_tt * 1024, 4) : 0;
   const size_t need = 5 * arena_need(act, 4) + 3 * arena_need(act3, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +
-                      5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4);
+                      5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4) + cache_need;
   if (int rc = arena_reserve(h, need)) return rc;
   float* featA = arena_take<float>(h, act);
   float* featB = arena_take<float>(h, act);
@@ -345,6 +355,12 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   float* x1t = arena_take<float>(h, tok);
   float* imgfeat = arena_take<float>(h, tok);
   float* ctxall = arena_take<float>(h, (size_t)(L > 0 ? L : 1) * tok);
+  gmf::CompatCache cc{nullptr};
+  float* c_dense = nullptr;
+  if (want_cache) {
+    c_dense = arena_take<float>(h, n_tt * 1024);
+    cc.dense = c_dense;
+  }
 
   // Fusion-1: image_feat = FusionLayer(p_tok (context), queries = q_tok), pe = False (PointDSC.py:137)
   GMF_HIP(gmf::launch_pack_p32(p_tokens, pimg, B, T, kC, (long)T * kC, kC, 1, st));
@@ -368,6 +384,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
                                       w->ctx_vec_stride, st));
   }
   GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st));
+  if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, st));
 
   float* cur = featA;
   float* nxt = featB;
@@ -381,7 +398,8 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
                                          w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
     else GMF_HIP(gmf::launch_front(l == 0 ? 1 : 0, in, w->front_wst + (size_t)l * w->front_wst_stride,
                                    w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
-    if (int rc = run_block_tail(h, w, l, f, q, k, v, pts8, ctxall + (size_t)l * tok, x1, x2, nxt, B, N, T, st)) return rc;
+    if (int rc = run_block_tail(h, w, l, f, q, k, v, pts8, ctxall + (size_t)l * tok, x1, x2, nxt, B, N, T, st, nullptr,
+                                want_cache ? &cc : nullptr)) return rc;
     float* t = cur; cur = nxt; nxt = t;
   }
   GMF_HIP(gmf::launch_head(cur, w->head_wst, w->head_vec, logits, feat_n, feat, B, N, tiles, st));

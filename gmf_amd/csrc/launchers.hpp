@@ -4,6 +4,13 @@
 
 namespace gmf {
 
+// compat matrix built once per batch by launch_compat_build (see k_compat_build): [B, tiles, tiles, 1024] floats
+struct CompatCache {
+  const float* dense;
+};
+void set_use_cache(bool v);
+bool get_use_cache();
+hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s);
 void set_scattn_variant(int v);
 void set_force_fp32_qkv(bool v);
 void set_h2_dbuf(bool v);
@@ -12,7 +19,7 @@ hipError_t launch_front(int mode, const float* in, const float* wst, const float
                         float* v, int B, int N, int tiles, hipStream_t s);
 hipError_t launch_scattn(const float* q, const float* k, const float* v, const float* pts8, const float* fus,
                          const float* wst, const float* vecs, float* out, int B, int N, int tiles, float sigma_d,
-                         hipStream_t s);
+                         hipStream_t s, const CompatCache* cc = nullptr);
 hipError_t launch_scattn_dense(const float* q, const float* k, const float* v, const float* compat, const float* fus,
                                const float* wst, const float* vecs, float* out, int B, int N, int tiles, hipStream_t s);
 hipError_t launch_ctx_prep(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,

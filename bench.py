@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0
 # MFMA products issued per algorithmic multiply-add by each form of the attention kernel (gmf_set_tuning "scattn_variant")
-PRODUCTS = {0: 1, 1: 1, 2: 1, 3: 6, 4: 6, 5: 6, 6: 6, 7: 6, 8: 6, 9: 3, 10: 3}
+PRODUCTS = {0: 1, 1: 1, 2: 1, 3: 6, 4: 6, 5: 6, 6: 6, 7: 6, 8: 6, 9: 3, 10: 3, 16: 3, 17: 3, 18: 3}
 
 
 def scattn_flops_per_launch(B: int, N: int) -> float:
@@ -112,7 +112,7 @@ def main():
     value = world * B * N * args.steps / dt
     avg_ms = ms_total.value / max(1, launches.value)
     achieved = scattn_flops_per_launch(B, N) / (avg_ms * 1e-3) / 1e12
-    variant = int(os.environ.get("GMF_SCATTN", "9"))
+    variant = int(os.environ.get("GMF_SCATTN", "18"))
     nprod = PRODUCTS.get(variant, 3)
     if nprod == 1:
         peak, peak_note, dtype = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA dense peak", "f32"
@@ -122,8 +122,8 @@ def main():
                      "(split-precision operands, fp32 accumulate, fp32-equivalent results)")
         dtype = "f32 (split-fp16 MFMA operands, fp32 accumulate)" if nprod == 3 else "f32 (split-bf16 MFMA operands, fp32 accumulate)"
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_scattn_h2_pmc.json")
-    if variant == 9 and (B, N, T) == (32, 5000, 196) and os.path.exists(pmc_file):
+    pmc_file = os.path.join(ROOT, "profiles", "r01_scattn_h2p_pmc.json")
+    if variant == 18 and (B, N, T) == (32, 5000, 196) and os.path.exists(pmc_file):
         traffic = json.load(open(pmc_file))["derived"]["traffic_bytes_per_launch"]   # rocprofv3 PMC, see the file
     line = {
         "metric": "correspondences/sec (whole node)", "value": value, "unit": "correspondences/s",

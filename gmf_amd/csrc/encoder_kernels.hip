@@ -799,9 +799,9 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
     si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
   }
   const f32x4* crow = nullptr;
-  float c_nxt[16];
+  float c_a[16], c_b[16];
   if (CACHED) crow = reinterpret_cast<const f32x4*>(c_dense) + ((pbase + tile) * (size_t)tiles) * 256 + lane;
-  auto fetch_c = [&](int t) {                 // cached c of key tile t for this wave's 32 queries
+  auto fetch_c = [&](int t, float (&c_nxt)[16]) {   // cached c of key tile t for this wave's 32 queries
     const f32x4* ct = crow + (size_t)t * 256;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -815,7 +815,7 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
   auto issueK = [&](int t) { if (ABL != 2) dma_issue(gk + (size_t)t * kStageFloats, ldsK + (DBUF ? (t & 1) * kBuf : 0), 16, wave, WAVES, lane); };
   auto issueV = [&](int t) {
     if (ABL != 2) dma_issue(gv + (size_t)t * kStageFloats, ldsV + (DBUF ? (t & 1) * kBuf : 0), 16, wave, WAVES, lane);
-    if (wave == (t & (WAVES - 1))) dma_piece_1k(gp + (size_t)t * 256, ldsP + (DBUF ? (t & 1) * kBuf : 0), lane);
+    if (!CACHED && wave == (t & (WAVES - 1))) dma_piece_1k(gp + (size_t)t * 256, ldsP + (DBUF ? (t & 1) * kBuf : 0), lane);
   };
 
   f32x16 oacc[4];
@@ -828,23 +828,18 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
 
   issueK(0);
   issueV(0);
-  if (CACHED) fetch_c(0);
+  if (CACHED) fetch_c(0, c_a);
   if (!DBUF) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  for (int t = 0; t < tiles; ++t) {
+  auto tile_step = [&](const int t, float (&c_cur)[16], float (&c_nxt)[16]) {
     if (DBUF) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t (issued one whole tile ago) has landed
       if (ABL != 3) __syncthreads();                     // ... for every wave; buffer (t+1)&1 is free again
       if (t + 1 < tiles) { issueK(t + 1); issueV(t + 1); }
     }
-    float c_cur[16];
-    if (CACHED) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) c_cur[r] = c_nxt[r];
-      if (t + 1 < tiles) fetch_c(t + 1);
-    }
+    if (CACHED && t + 1 < tiles) fetch_c(t + 1, c_nxt);
     const int boff = DBUF ? (t & 1) * (kBuf / 4) : 0;    // in 16-byte units
     const f16x8* lk = lk0 + boff;
     const f16x8* lv = lv0 + boff;
@@ -916,6 +911,11 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
       __syncthreads();                                   // B2: every wave is done reading V_t, pts_t
       if (t + 1 < tiles) issueV(t + 1);
     }
+  };
+  // two register sets for the cached c tile: tile t multiplies out of one while tile t+1 streams into the other
+  for (int t = 0; t < tiles; t += 2) {
+    tile_step(t, c_a, c_b);
+    if (t + 1 < tiles) tile_step(t + 1, c_b, c_a);
   }
 
   // ---- epilogue: normalise, fc_message (fp32 MFMA), add the Fusion-2 branch ----
@@ -1254,6 +1254,323 @@ k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int 
     float4* ct = crow + (size_t)J * 256;
 #pragma unroll
     for (int q = 0; q < 4; ++q) ct[q * 64] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+  }
+}
+
+// =========================================================================================
+// k_scattn_h2p: the cached-c split-fp16 attention with the tile loop software-pipelined inside each wave.
+//   With c_ij streamed from the cache a tile costs 48 MFMAs and ~130 vector instructions per wave - few enough to sit
+//   in the MFMA issue gaps (an MFMA holds the vector issue port for 8 of its 32 cycles).  K tiles run one tile ahead of
+//   V in the LDS rings: phase 1 issues the 24 MFMAs of S_{t+1} = K_{t+1} Q'^T, one per sched_barrier(0) unit, each
+//   unit carrying its share of tile t's scores (c * s, running max), the exponentials of the first 8 keys and their
+//   fp16 split; phase 2 issues the 24 MFMAs of O^T += V_t^T P^T with the other 8 exponentials underneath.  The row
+//   max crosses the two K-halves with v_permlane32_swap (no LDS round trip).  Same accumulation order as
+//   k_scattn_h2<.., CACHED>, so the results are bit-identical to it.
+//   LDS: K ring [2][16 KiB] | V ring [2][16 KiB]; one barrier per tile; two workgroups per CU.
+// =========================================================================================
+GMF_DEVINL f32x16 mma3_part(int u, f32x16 acc, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
+  switch (u) {
+    case 0: return mfma_h16(al, bh, acc);
+    case 1: return mfma_h16(ah, bl, acc);
+    default: return mfma_h16(ah, bh, acc);
+  }
+}
+
+GMF_DEVINL void split2h(float x0, float x1, f16x8& hi, f16x8& lo, int j) {
+  const f32x2 x = {x0, x1};
+  const f16x2 hh = __builtin_convertvector(x, f16x2);
+  const f32x2 r1 = x - __builtin_convertvector(hh, f32x2);
+  const f16x2 ll = __builtin_convertvector(r1, f16x2);
+  hi[j] = hh[0]; hi[j + 1] = hh[1];
+  lo[j] = ll[0]; lo[j + 1] = ll[1];
+}
+
+// max over the two K-halves of a row without the LDS: swap the upper 32 lanes of one copy with the lower 32 of another
+GMF_DEVINL float xhalf_max_swap(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// PLACE: where a tile's 8 LDS-DMA pieces are issued - 0 = at the top of the tile, 1 = one per unit of phase 1,
+// 2 = one per unit in the bare MFMA gaps of phase 2.
+template <int PLACE>
+__global__ void __launch_bounds__(256, 2)
+k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
+             const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
+             float* __restrict__ out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_dense) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+  float* const ldsK = lds;
+  float* const ldsV = lds + 2 * kStageFloats;
+  constexpr int WAVES = 4;
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int pair, qblock;
+  {                                            // XCD-aware work mapping, as k_scattn_h2
+    const int total = gridDim.x, L = blockIdx.x;
+    const int chunk = total >> 3, rem = total & 7, xcd = L & 7, kth = L >> 3;
+    const int start = (xcd < rem) ? xcd * (chunk + 1) : rem * (chunk + 1) + (xcd - rem) * chunk;
+    const int logical = start + kth;
+    pair = logical / wgs_per_pair;
+    qblock = logical - pair * wgs_per_pair;
+  }
+  const int tile_raw = qblock * WAVES + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t pbase = (size_t)pair * tiles;
+  const size_t toff = (pbase + tile) * (32 * C);
+
+  f16x8 qh[8], ql[8];
+  {
+    const f16x8* qp = reinterpret_cast<const f16x8*>(q_img + (pbase + tile) * (size_t)kStageFloats) + lane;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { qh[s] = qp[(0 * 8 + s) * 64]; ql[s] = qp[(1 * 8 + s) * 64]; }
+  }
+  const f32x4* const crow = reinterpret_cast<const f32x4*>(c_dense) + ((pbase + tile) * (size_t)tiles) * 256 + lane;
+  float c[16];
+  auto fetch_c = [&](int t) {
+    const f32x4* ct = crow + (size_t)t * 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = __builtin_nontemporal_load(ct + q * 64);
+      c[4 * q + 0] = v[0]; c[4 * q + 1] = v[1]; c[4 * q + 2] = v[2]; c[4 * q + 3] = v[3];
+    }
+  };
+  const float* gk = k_img + pbase * (size_t)kStageFloats;
+  const float* gv = v_img + pbase * (size_t)kStageFloats;
+  auto issue16k = [&](const float* g, float* l) {      // this wave's 4 of the 16 KiB-pieces of one tile
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + WAVES * q) * 256, l + (wave + WAVES * q) * 256, lane);
+  };
+  auto issueK = [&](int t) { issue16k(gk + (size_t)t * kStageFloats, ldsK + (t & 1) * kStageFloats); };
+  auto issueV = [&](int t) { issue16k(gv + (size_t)t * kStageFloats, ldsV + (t & 1) * kStageFloats); };
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
+  float m_run = -INFINITY, l_half = 0.f;
+
+  issueK(0);
+  if (tiles > 1) issueK(1);
+  issueV(0);
+  fetch_c(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16 s_a = zero16(), s_b;
+  {
+    const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK) + lane;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) mma3(s_a, lk[(0 * 8 + s) * 64], lk[(1 * 8 + s) * 64], qh[s], ql[s]);
+  }
+
+  // top of tile t: K_{t+1}, V_t, c_t have landed and every wave is done with K_t and V_{t-1}.  The scores x = c_t * s_t
+  // are formed BEFORE the refills are issued: the compiler guards every use of a loaded register with its own
+  // s_waitcnt vmcnt, and behind younger LDS-DMA pieces that wait would cover them too.
+  auto tile_top = [&](const int t, const f32x16& s_cur, float (&x)[16], float& mx) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      x[r] = c[r] * s_cur[r];
+      x[r + 1] = c[r + 1] * s_cur[r + 1];
+      mx = __builtin_fmaxf(mx, __builtin_fmaxf(x[r], x[r + 1]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (PLACE == 0) {
+      if (t + 2 < tiles) issueK(t + 2);
+      if (t + 1 < tiles) issueV(t + 1);
+    }
+    if (t + 1 < tiles) fetch_c(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // piece q (0..3 of K_{t+2}, 4..7 of V_{t+1}) of this wave's share of the refills
+  auto issue_piece = [&](const int t, const int q) {
+    if (q < 4) {
+      if (t + 2 < tiles) dma_piece_1k(gk + (size_t)(t + 2) * kStageFloats + (wave + WAVES * q) * 256,
+                                      ldsK + (t & 1) * kStageFloats + (wave + WAVES * q) * 256, lane);
+    } else {
+      dma_piece_1k(gv + (size_t)(t + 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256,
+                   ldsV + ((t + 1) & 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256, lane);
+    }
+  };
+  auto rescale = [&](const bool moved, const float alpha) {
+    if (__any(moved)) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
+  };
+  // one pipelined tile (t + 1 < tiles): scores of tile t are in s_cur, S_{t+1} accumulates into s_next
+  auto tile_step = [&](const int t, const f32x16& s_cur, f32x16& s_next) {
+    float x[16];
+    float mx = -INFINITY, m_off = 0.f, alpha = 1.f, ls = 0.f;
+    tile_top(t, s_cur, x, mx);
+    const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV + (t & 1) * kStageFloats) + lane;
+    const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK + ((t + 1) & 1) * kStageFloats) + lane;
+    bool moved = false;
+    f16x8 ph0, pl0, ph1, pl1;
+    // running maximum first, and the (rare) accumulator rescale with it: no branch may sit between the two phases, or
+    // the compiler sinks the phase-1 vector work below it, out of the MFMA issue gaps
+    {
+      mx = xhalf_max_swap(mx);
+      const float m_new = __builtin_fmaxf(m_run, mx);
+      moved = m_new > m_run;
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      m_off = m_new - 10.0f;                 // P' = 2^10 P
+      rescale(moved, alpha);
+    }
+    s_next = zero16();
+    // ---- phase 1: S_{t+1} on the matrix pipe, tile t's scores / max / first exponentials in its issue gaps ----
+    {
+      f16x8 kh = lk[0], kl = lk[8 * 64];
+      f16x8 kh_n = kh, kl_n = kl;
+#pragma unroll
+      for (int u = 0; u < 24; ++u) {
+        const int s = u / 3, pr = u % 3;
+        if (pr == 0 && s < 7) { kh_n = lk[(0 * 8 + s + 1) * 64]; kl_n = lk[(1 * 8 + s + 1) * 64]; }
+        s_next = mma3_part(pr, s_next, kh, kl, qh[s], ql[s]);
+        if (pr == 2) { kh = kh_n; kl = kl_n; }
+        if (PLACE == 1 && u >= 2 && u < 10) issue_piece(t, u - 2);
+        if (u < 2) {
+          // (the row maximum and the accumulator rescale are settled before the phase: see below)
+        } else if (u <= 11) {
+          const int r = u - 2;               // exponentials 0..9
+          x[r] = __builtin_amdgcn_exp2f(x[r] - m_off);
+          ls += x[r];
+        } else if (u <= 15) {
+          const int j = 2 * (u - 12);        // split pairs 0..3: the first 8 keys
+          split2h(x[j], x[j + 1], ph0, pl0, j);
+        } else if (u <= 21) {
+          const int r = u - 6;               // exponentials 10..15
+          x[r] = __builtin_amdgcn_exp2f(x[r] - m_off);
+          ls += x[r];
+        } else {
+          const int j = 2 * (u - 22);        // split pairs 4, 5
+          split2h(x[8 + j], x[8 + j + 1], ph1, pl1, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- phase 2: O^T += V_t^T P^T, the remaining exponentials and the second split in its issue gaps ----
+    {
+      f16x8 vh = lv[0], vl = lv[8 * 64];
+      f16x8 vh_n = vh, vl_n = vl;
+#pragma unroll
+      for (int u = 0; u < 24; ++u) {
+        const int s2 = u / 12, db = (u % 12) / 3, pr = u % 3;
+        if (pr == 0 && u < 21) {
+          const int un = u + 3, slot = 2 * ((un % 12) / 3) + un / 12;
+          vh_n = lv[(0 * 8 + slot) * 64]; vl_n = lv[(1 * 8 + slot) * 64];
+        }
+        oacc[db] = mma3_part(pr, oacc[db], vh, vl, s2 ? ph1 : ph0, s2 ? pl1 : pl0);
+        if (pr == 2) { vh = vh_n; vl = vl_n; }
+        if (u < 2) {
+          const int j = 4 + 2 * u;           // split pairs 6, 7 (needed from u = 12 on)
+          split2h(x[8 + j], x[8 + j + 1], ph1, pl1, j);
+        }
+        if (PLACE == 2 && u >= 3 && u < 11) issue_piece(t, u - 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    l_half = fmaf(l_half, alpha, ls);
+  };
+  // the last tile (keys >= N masked out), no S_{t+1} to overlap with
+  auto tile_last = [&](const int t, const f32x16& s_cur) {
+    float x[16];
+    float mx = -INFINITY, ls = 0.f;
+    tile_top(t, s_cur, x, mx);
+    const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV + (t & 1) * kStageFloats) + lane;
+    const int jbase = t * 32 + 4 * h;
+    mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jl = 8 * (r >> 2) + (r & 3);
+      x[r] = (jbase + jl < N) ? x[r] : -INFINITY;
+      mx = __builtin_fmaxf(mx, x[r]);
+    }
+    mx = xhalf_max_swap(mx);
+    const float m_new = __builtin_fmaxf(m_run, mx);
+    const bool moved = m_new > m_run;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    const float m_off = m_new - 10.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
+    rescale(moved, alpha);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f16x8 ph, pl;
+      split8h(&x[8 * s2], ph, pl);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int slot = 2 * db + s2;
+        mma3(oacc[db], lv[(0 * 8 + slot) * 64], lv[(1 * 8 + slot) * 64], ph, pl);
+      }
+    }
+    l_half = fmaf(l_half, alpha, ls);
+  };
+  {
+    int t = 0;
+    for (; t + 2 < tiles; t += 2) {          // explicit ping-pong: no accumulator copies at the loop back-edge
+      tile_step(t, s_a, s_b);
+      tile_step(t + 1, s_b, s_a);
+    }
+    if (t + 1 < tiles) { tile_step(t, s_a, s_b); tile_last(t + 1, s_b); }
+    else tile_last(t, s_a);
+  }
+
+  // ---- epilogue: normalise, fc_message (fp32 MFMA), add the Fusion-2 branch ----
+  float o[CF];
+  {
+    const float inv = 1.0f / xhalf_sum(l_half);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
+  }
+  __syncthreads();
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5);
+  ss.prime();
+  float m1[DHF], m2[DHF];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const float4* lw = ss.acquire();
+    f32x16 acc = zero16();
+    mma_wx<CF>(acc, lw, o);
+    float b[16];
+    load_vec_block(b, vecs, mb, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+  }
+  {
+    const float4* lw = ss.acquire();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      f32x16 acc = zero16();
+      mma_wx<DHF>(acc, lw + mb * (32 * DH / 4), m1);
+      float b[16];
+      load_vec_block(b, vecs + 64, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const float4* lw = ss.acquire();
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int mb = 2 * st + hb;
+      f32x16 acc = zero16();
+      mma_wx<DHF>(acc, lw + hb * (32 * DH / 4), m2);
+      float b[16], fz[16], tt[16];
+      load_vec_block(b, vecs + 128, mb, h);
+      load_block_p32(fz, fus + toff, mb, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tt[r] = acc[r] + b[r] + fz[r];
+      if (active) store_block_p32(out + toff, mb, tt, lane);
+    }
   }
 }
 
@@ -1753,7 +2070,7 @@ __global__ void k_pack_pts8(const float* __restrict__ src, const float* __restri
 
 namespace gmf {
 
-static int g_scattn_variant = [] { const char* e = getenv("GMF_SCATTN"); return e ? atoi(e) : 9; }();
+static int g_scattn_variant = [] { const char* e = getenv("GMF_SCATTN"); return e ? atoi(e) : 18; }();
 static bool g_h2_dbuf = [] { const char* e = getenv("GMF_H2_DBUF"); return e ? atoi(e) != 0 : true; }();
 void set_h2_dbuf(bool v) { g_h2_dbuf = v; }
 static bool g_use_cache = [] { const char* e = getenv("GMF_COMPAT_CACHE"); return e ? atoi(e) != 0 : true; }();
@@ -1790,7 +2107,10 @@ hipError_t launch_scattn(const float* q, const float* k, const float* v, const f
   // 0 = fp32 MFMA, two-phase loop; 1 = fp32 MFMA, software-pipelined; 2 = 1 with v_sqrt_f32;
   // 3 = split-bf16 (3 planes, 6 products) MFMA; 4 = 3 with the rational compat form; 5/6 = 3/4 software-pipelined,
   // 8 waves; 7/8 = 3/4 with 8-wave workgroups; 9 = split-fp16 (2 planes, 3 products) MFMA (default);
-  // 10 = 9 with the rational compat form; 11..15 = timing-only ablations of 4.
+  // 10 = 9 with the rational compat form; 11..15 = timing-only ablations of 9;
+  // 16/17/18 = 9 with the compat cache and the tile loop software-pipelined inside each wave (k_scattn_h2p), LDS-DMA
+  // pieces issued at the tile top / in phase 1 / in the bare MFMA gaps of phase 2 (18 = default; falls back to 9 when
+  // the cache is off or too large).
   const int variant = g_scattn_variant;
   const float inv = 1.0f / (sigma_d * sigma_d);
   if (variant >= 3) {
@@ -1809,7 +2129,12 @@ hipError_t launch_scattn(const float* q, const float* k, const float* v, const f
         default: hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 5>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr); break;
       }
     }
-    else if (variant == 9) {
+    else if (variant >= 16 && cc && g_use_cache && cc->dense) {
+      if (variant == 17) hipLaunchKernelGGL(k_scattn_h2p<1>, grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense);
+      else if (variant == 18) hipLaunchKernelGGL(k_scattn_h2p<2>, grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense);
+      else hipLaunchKernelGGL(k_scattn_h2p<0>, grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense);
+    }
+    else if (variant == 9 || variant >= 16) {
       const float* cd = (cc && g_use_cache) ? cc->dense : nullptr;
       if (cd) hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 0, true>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
       else if (g_h2_dbuf) hipLaunchKernelGGL((k_scattn_h2<false, 4, true>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);

@@ -113,7 +113,7 @@ int gmf_create(int device, gmf_handle** out) {
 int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
   GMF_REQUIRE(h && name, GMF_ERR_BAD_ARG, "set_tuning: null pointer");
   if (std::strcmp(name, "scattn_variant") == 0) {
-    GMF_REQUIRE(value >= 0 && value <= 15, GMF_ERR_BAD_ARG, "set_tuning: scattn_variant out of range (0..15)");
+    GMF_REQUIRE(value >= 0 && value <= 18, GMF_ERR_BAD_ARG, "set_tuning: scattn_variant out of range (0..18)");
     gmf::set_scattn_variant(value);
     return GMF_OK;
   }
@@ -334,7 +334,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   const size_t act3 = act + act / 2;   // Q', K, V may be bf16x3 plane images (24 KiB per tile)
   // compat cache (built once per batch, streamed by all L attention launches): 4 KiB per pair of 32-row tiles
   const size_t n_tt = (size_t)B * tiles * tiles;
-  const bool want_cache = (L > 1) && gmf::get_scattn_variant() == 9 && gmf::get_use_cache() &&
+  const bool want_cache = (L > 1) && (gmf::get_scattn_variant() == 9 || gmf::get_scattn_variant() >= 16) && gmf::get_use_cache() &&
                           n_tt * 4096 <= ((size_t)96 << 30);
   const size_t cache_need = want_cache ? arena_need(n_tt * 1024, 4) : 0;
   const size_t need = 5 * arena_need(act, 4) + 3 * arena_need(act3, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +

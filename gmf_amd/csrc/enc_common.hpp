@@ -99,5 +99,33 @@ GMF_DEVINL void lcpe_frag(float (&y)[CF], const float* __restrict__ pair_base, i
 
 GMF_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Branch-free erf for the GELU of the feed-forward kernels.  ocml's erff compiles to a per-element exec-mask branch
+// (two ranges, ~42 instructions plus the mask bookkeeping) that also pins the surrounding MFMAs in place; here both
+// ranges are evaluated (13 FMAs, one v_exp_f32) and selected.  Polynomials: N. Juffa's erff (max error < 1 ulp in
+// each range with a correctly rounded exp; with v_exp_f32 on r * log2(e) the large-|a| range stays below 2 ulp,
+// because exp(r) <= 0.43 there enters 1 - exp(r) with a weight below one half).
+GMF_DEVINL float erf_bf(float a) {
+  const float t = fabsf(a), s = a * a;
+  // |a| > 0.927734375:  erf = 1 - exp(r(t))
+  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+  const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+  r = fmaf(r, s, u);
+  r = fmaf(r, t, -1.06777877e-1f);
+  r = fmaf(r, t, -6.34846687e-1f);
+  r = fmaf(r, t, -1.28717512e-1f);
+  r = fmaf(r, t, -t);
+  const float big = 1.0f - __builtin_amdgcn_exp2f(r * 1.4426950408889634f);
+  // |a| <= 0.927734375:  erf = a + a * p(a^2)
+  float q = -5.96761703e-4f;
+  q = fmaf(q, s, 4.99119423e-3f);
+  q = fmaf(q, s, -2.67681349e-2f);
+  q = fmaf(q, s, 1.12819925e-1f);
+  q = fmaf(q, s, -3.76125336e-1f);
+  q = fmaf(q, s, 1.28379166e-1f);
+  const float small = fmaf(q, t, t);
+  return copysignf(t > 0.927734375f ? big : small, a);
+}
+GMF_DEVINL float gelu_erf_bf(float x) { return 0.5f * x * (1.0f + erf_bf(x * 0.70710678118654752440f)); }
+
 
 }  // namespace gmf

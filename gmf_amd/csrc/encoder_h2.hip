@@ -6,6 +6,7 @@
 //   k_fusion_attn_h2  fusion_layer.py:119-121,44,84-94,190
 //   k_fusion_ff_h2    fusion_layer.py:54-69,191
 //   k_ctx_prep_h2     fusion_layer.py:124-126,46-49,86-87
+#include <cstdlib>
 #include "enc_common.hpp"
 #include "launchers.hpp"
 
@@ -42,6 +43,11 @@ GMF_DEVINL void mma_xw_h2(f32x16& acc, const f16x8* lw, const FragH2<NS>& x) {
 
 GMF_DEVINL const f16x8* as_h2(const float4* p) { return reinterpret_cast<const f16x8*>(p); }
 
+#ifndef GMF_H2_RING
+#define GMF_H2_RING 4
+#endif
+constexpr int kRing = GMF_H2_RING;   // LDS ring depth of the weight / context stage streams (16 KiB each)
+
 // =========================================================================================
 // k_front_h2: stages (16 x 16 KiB, fp16x2 images): Wp[4] | Wq'[4] | Wk[4] | Wv[4]
 //   vecs (fp32): bp | bq' | bk | bv | b0 | W0 image (fp32, K=8: layer0 stays on the f32 MFMA, 4 MFMAs per block)
@@ -52,7 +58,7 @@ __global__ void __launch_bounds__(256, 2)
 k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const float* __restrict__ vecs,
            float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out,
            float* __restrict__ v_out, int N, int tiles) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y;
@@ -61,9 +67,9 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
   const int tile = active ? tile_raw : tiles - 1;
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
 
-  StageStream ss;
-  if (MODE == 2) ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst + 4 * kStageFloats, 12);
-  else ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 16);
+  StageRing<kRing> ss;
+  if (MODE == 2) ss.init(lds, wave, lane, wst + 4 * kStageFloats, 12);
+  else ss.init(lds, wave, lane, wst, 16);
   ss.prime();
 
   float f[CF];
@@ -223,7 +229,7 @@ template <bool PE>
 __global__ void __launch_bounds__(256, 2)
 k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_img, const float* __restrict__ wst,
                  const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y;
@@ -233,8 +239,8 @@ k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_im
   const float* pair_base = xin + (size_t)pair * tiles * (32 * C);
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
 
-  StageStream ss;
-  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 2,
+  StageRing<kRing> ss;
+  ss.init(lds, wave, lane, wst, 2,
           ctx_img + (size_t)pair * ttiles * kStageFloats, ttiles, wst + 2 * kStageFloats, 2);
   ss.prime();
 
@@ -338,7 +344,7 @@ k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_im
 __global__ void __launch_bounds__(256, 2)
 k_fusion_ff_h2(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
                float* __restrict__ x2_out, int tiles) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y;
@@ -347,8 +353,8 @@ k_fusion_ff_h2(const float* __restrict__ x1, const float* __restrict__ wst, cons
   const int tile = active ? tile_raw : tiles - 1;
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
 
-  StageStream ss;
-  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 3 * (FFH / 32));
+  StageRing<kRing> ss;
+  ss.init(lds, wave, lane, wst, 3 * (FFH / 32));
   ss.prime();
   FragH2<8> nx;
   {
@@ -381,7 +387,7 @@ k_fusion_ff_h2(const float* __restrict__ x1, const float* __restrict__ wst, cons
       float b[16];
       load_vec_block(b, b1g, c, h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ga[r] *= gelu_erf(acc[r] + b[r]);
+      for (int r = 0; r < 16; ++r) ga[r] *= gelu_erf_bf(acc[r] + b[r]);
     }
     {
       FragH2<2> gx;
@@ -391,6 +397,147 @@ k_fusion_ff_h2(const float* __restrict__ x1, const float* __restrict__ wst, cons
       for (int mb = 0; mb < 4; ++mb) mma_wx_h2<2>(y[mb], lw + mb * (2 * 2 * 64), gx);
     }
   }
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    float b[16], xr[16], t[16];
+    load_vec_block(b, vecs + 2 * C + 2 * FFH, mb, h);
+    load_block_p32(xr, x1 + toff, mb, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = y[mb][r] + b[r] + xr[r];
+    if (active) store_block_p32(x2_out + toff, mb, t, lane);
+  }
+}
+
+// =========================================================================================
+// k_fusion_ff_h2p: k_fusion_ff_h2 with the chunk loop software-pipelined inside each wave.
+//   A GEGLU chunk is 48 MFMAs of W1 (value | gate, K = 128), 16 GELUs (~24 vector instructions each) and 24 MFMAs of
+//   W2; in program order they run back to back and the kernel costs matrix time PLUS vector time.  Here the W1 MFMAs
+//   of chunk c+1 are issued three at a time with one GELU of chunk c in their issue gaps (16 units), the fp16 split
+//   of the gated values rides in the later units, and only the 24 W2 MFMAs run bare.  The biases start the
+//   accumulators (no separate add), the stage ring is 4 deep and its acquire is branch-free (stage order
+//   A0 G0 | A1 G1 W2_0 | ... | A15 G15 W2_14 | W2_15 addressed into the unchanged blob; past the end the last stage is
+//   re-fetched into a free slot instead of branching), so a whole chunk is one basic block for the scheduler.
+// =========================================================================================
+// ABL (timing only, wrong results): 1 = one LDS-DMA piece per wave and stage instead of four, 2 = no GELU
+template <int ABL>
+__global__ void __launch_bounds__(256, 2)
+k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
+                float* __restrict__ x2_out, int tiles) {
+  constexpr int NB = 4, NCH = FFH / 32;
+  __shared__ __attribute__((aligned(16))) float lds[NB * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+
+  // stage n of the consumption order -> stage index in the blob (16 x (A | G | W2))
+  int n_issued = 0, n_used = 0;
+  auto blob_stage = [&](int n) {
+    n = min(n, 3 * NCH - 1);
+    if (n < 2) return n;
+    if (n == 3 * NCH - 1) return n;
+    const int m = n - 2, c = m / 3, k = m - 3 * c;
+    return (k == 2) ? 3 * c + 2 : 3 * c + 3 + k;
+  };
+  auto issue_one = [&]() {
+    const float* g = wst + (size_t)blob_stage(n_issued) * kStageFloats;
+    float* dst = lds + (n_issued & (NB - 1)) * kStageFloats;
+#pragma unroll
+    for (int q = 0; q < (ABL == 1 ? 1 : 4); ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);
+    ++n_issued;
+  };
+  auto acquire = [&]() {
+    if (ABL == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but this wave's pieces of the 2 younger stages have landed
+    __syncthreads();
+    const f16x8* cur = reinterpret_cast<const f16x8*>(lds + (n_used & (NB - 1)) * kStageFloats) + lane;
+    ++n_used;
+    issue_one();
+    return cur;
+  };
+  issue_one(); issue_one(); issue_one();
+
+  FragH2<8> nx;
+  {
+    float x[CF], xn[CF];
+    load_frag_p32<CF>(x, x1 + toff, lane);
+    layernorm_frag<CF>(xn, x, vecs, vecs + C, h);
+    nx.set(xn);
+  }
+  f32x16 y[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) y[mb] = zero16();
+  const float* b1a = vecs + 2 * C;
+  const float* b1g = vecs + 2 * C + FFH;
+  auto bias_acc = [&](const float* bvec, int c) {
+    float b[16];
+    load_vec_block(b, bvec, c, h);
+    f32x16 a;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = b[r];
+    return a;
+  };
+
+  f32x16 a0 = bias_acc(b1a, 0), g0 = bias_acc(b1g, 0), a1, g1;
+  {
+    const f16x8* lw = acquire();
+    mma_wx_h2<8>(a0, lw, nx);
+    lw = acquire();
+    mma_wx_h2<8>(g0, lw, nx);
+  }
+  // chunk c: gated values from (a_cur, g_cur); W1 of chunk c+1 accumulates into (a_nxt, g_nxt) meanwhile
+  auto chunk = [&](const int c, f32x16& a_cur, const f32x16& g_cur, f32x16& a_nxt, f32x16& g_nxt, const bool has_next) {
+    FragH2<2> gx;
+    if (has_next) {
+      a_nxt = bias_acc(b1a, c + 1);
+      g_nxt = bias_acc(b1g, c + 1);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const f16x8* lw = acquire();
+        f16x8 wh = lw[0], wl = lw[8 * 64];
+        f16x8 wh_n = wh, wl_n = wl;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int u = 8 * half + s;
+          if (s < 7) { wh_n = lw[(0 * 8 + s + 1) * 64]; wl_n = lw[(1 * 8 + s + 1) * 64]; }
+          if (half == 0) mma3(a_nxt, wh, wl, nx.h[s], nx.l[s]);
+          else mma3(g_nxt, wh, wl, nx.h[s], nx.l[s]);
+          wh = wh_n; wl = wl_n;
+          a_cur[u] *= (ABL == 2) ? g_cur[u] : gelu_erf_bf(g_cur[u]);
+          if (half == 1 && (s & 1)) { const int j = s - 1; split2h(a_cur[j], a_cur[j + 1], gx.h[0], gx.l[0], j); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a_cur[u] *= gelu_erf_bf(g_cur[u]);
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) split2h(a_cur[j], a_cur[j + 1], gx.h[0], gx.l[0], j);
+    }
+    {
+      const f16x8* lw = acquire();
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          const f16x8* lb = lw + mb * (2 * 2 * 64);
+          mma3(y[mb], lb[(0 * 2 + s) * 64], lb[(1 * 2 + s) * 64], gx.h[s], gx.l[s]);
+          if (s == 0) { const int j = 2 * mb; split2h(a_cur[8 + j], a_cur[8 + j + 1], gx.h[1], gx.l[1], j); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  };
+  for (int c = 0; c + 2 < NCH; c += 2) {
+    chunk(c, a0, g0, a1, g1, true);
+    chunk(c + 1, a1, g1, a0, g0, true);
+  }
+  chunk(NCH - 2, a0, g0, a1, g1, true);
+  chunk(NCH - 1, a1, g1, a0, g0, false);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-fetched tail stages
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     float b[16], xr[16], t[16];
@@ -428,7 +575,12 @@ hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, 
 }
 
 hipError_t launch_fusion_ff_h2(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s) {
-  hipLaunchKernelGGL(k_fusion_ff_h2, tgrid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
+  static const bool pipelined = [] { const char* e = getenv("GMF_FF_PIPE"); return e ? atoi(e) != 0 : true; }();
+  static const int abl = [] { const char* e = getenv("GMF_FF_ABL"); return e ? atoi(e) : 0; }();
+  if (pipelined && abl == 1) hipLaunchKernelGGL(k_fusion_ff_h2p<1>, tgrid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
+  else if (pipelined && abl == 2) hipLaunchKernelGGL(k_fusion_ff_h2p<2>, tgrid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
+  else if (pipelined) hipLaunchKernelGGL(k_fusion_ff_h2p<0>, tgrid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
+  else hipLaunchKernelGGL(k_fusion_ff_h2, tgrid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
   return hipGetLastError();
 }
 

@@ -1276,15 +1276,6 @@ GMF_DEVINL f32x16 mma3_part(int u, f32x16 acc, f16x8 ah, f16x8 al, f16x8 bh, f16
   }
 }
 
-GMF_DEVINL void split2h(float x0, float x1, f16x8& hi, f16x8& lo, int j) {
-  const f32x2 x = {x0, x1};
-  const f16x2 hh = __builtin_convertvector(x, f16x2);
-  const f32x2 r1 = x - __builtin_convertvector(hh, f32x2);
-  const f16x2 ll = __builtin_convertvector(r1, f16x2);
-  hi[j] = hh[0]; hi[j + 1] = hh[1];
-  lo[j] = ll[0]; lo[j + 1] = ll[1];
-}
-
 // max over the two K-halves of a row without the LDS: swap the upper 32 lanes of one copy with the lower 32 of another
 GMF_DEVINL float xhalf_max_swap(float v) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);

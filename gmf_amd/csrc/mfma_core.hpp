@@ -123,6 +123,16 @@ GMF_DEVINL void split8h(const float* v, f16x8& hi, f16x8& lo) {
   }
 }
 
+// elements j, j+1 of an 8-element k-step
+GMF_DEVINL void split2h(float x0, float x1, f16x8& hi, f16x8& lo, int j) {
+  const f32x2 x = {x0, x1};
+  const f16x2 hh = __builtin_convertvector(x, f16x2);
+  const f32x2 r1 = x - __builtin_convertvector(hh, f32x2);
+  const f16x2 ll = __builtin_convertvector(r1, f16x2);
+  hi[j] = hh[0]; hi[j + 1] = hh[1];
+  lo[j] = ll[0]; lo[j + 1] = ll[1];
+}
+
 GMF_DEVINL void mma3(f32x16& acc, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
   acc = mfma_h16(al, bh, acc);
   acc = mfma_h16(ah, bl, acc);
@@ -298,6 +308,54 @@ struct StageStream {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed in LDS
     __syncthreads();                                  // everyone's pieces landed; prior readers of the other buffer done
     const float* cur = (consumed & 1) ? buf1 : buf0;
+    ++consumed;
+    issue_one();
+    return reinterpret_cast<const float4*>(cur) + lane;
+  }
+};
+
+// StageStream with a deeper ring: NBUF slots of 16 KiB, NBUF - 1 stages in flight, for 4-wave workgroups (4 pieces per
+// wave and stage).  One stage of look-ahead (StageStream) covers an L2 hit only when a stage carries >= ~1000 cycles of
+// MFMAs; the fp16x2 stages carry 24 MFMAs (~800 cycles), so the h2 kernels stalled on every acquire.  acquire() waits
+// with vmcnt(4 * (NBUF - 2)): everything older than this wave's pieces of the NBUF - 2 younger stages has landed (other,
+// younger vector-memory operations only make the wait more conservative).
+template <int NBUF>
+struct StageRing {
+  const float* seg_ptr[3];
+  int seg_end[3];
+  float* base;
+  int issued, consumed, total;
+  int wave, lane;
+
+  GMF_DEVINL void init(float* lds_base, int wave_, int lane_, const float* p0, int n0, const float* p1 = nullptr,
+                       int n1 = 0, const float* p2 = nullptr, int n2 = 0) {
+    seg_ptr[0] = p0; seg_ptr[1] = p1; seg_ptr[2] = p2;
+    seg_end[0] = n0; seg_end[1] = n0 + n1; seg_end[2] = n0 + n1 + n2;
+    total = seg_end[2];
+    base = lds_base; issued = 0; consumed = 0;
+    wave = wave_; lane = lane_;
+  }
+  GMF_DEVINL void issue_one() {
+    if (issued < total) {
+      const float* g;
+      if (issued < seg_end[0]) g = seg_ptr[0] + (size_t)issued * kStageFloats;
+      else if (issued < seg_end[1]) g = seg_ptr[1] + (size_t)(issued - seg_end[0]) * kStageFloats;
+      else g = seg_ptr[2] + (size_t)(issued - seg_end[1]) * kStageFloats;
+      float* dst = base + (issued % NBUF) * kStageFloats;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);
+      ++issued;
+    }
+  }
+  GMF_DEVINL void prime() {
+#pragma unroll
+    for (int k = 0; k < NBUF - 1; ++k) issue_one();
+  }
+  GMF_DEVINL const float4* acquire() {
+    if (issued - consumed == NBUF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NBUF - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();            // everyone's pieces of this stage landed; the slot of the previous stage is free
+    const float* cur = base + (consumed % NBUF) * kStageFloats;
     ++consumed;
     issue_one();
     return reinterpret_cast<const float4*>(cur) + lane;

@@ -1,5 +1,5 @@
-"""weighted_procrustes drop-in for the DGR plugin surface
-(reference: GMF_DeepGlobalRegistration/*/core/registration.py:91-113)."""
+"""DGR plugin surface: weighted_procrustes and GlobalRegistration drop-ins
+(reference: GMF_DeepGlobalRegistration/*/core/registration.py:91-113, 135-194)."""
 from __future__ import annotations
 
 from typing import Sequence
@@ -37,3 +37,65 @@ def weighted_procrustes(X, Y, w, eps):
     assert len(X) == len(Y)
     R, t = weighted_procrustes_batched(X, Y, w, [0, X.shape[0]], eps)
     return R[0], t[0]
+
+
+_F32_EPS = 1.1920928955078125e-07      # np.finfo(np.float32).eps, the default eps of HighDimSmoothL1Loss (core/loss.py:44)
+
+
+def global_registration_batched(points, trans_points, weights, offsets: Sequence[int], max_iter=1000, max_break_count=20,
+                                break_threshold_ratio=1e-5, quantization_size=1, eps=_F32_EPS):
+    """B ragged problems in one launch (one persistent workgroup each): points, trans_points [sum N,3], weights [sum N]
+    / [sum N,1] or None, offsets (B+1 ints) -> R [B,3,3], t [B,3], stats [B,3] = (iterations, loss, break_count)."""
+    X = require_cuda_f32(points, "points").contiguous()
+    Y = require_cuda_f32(trans_points, "trans_points").contiguous()
+    if X.shape != Y.shape or X.dim() != 2 or X.shape[1] != 3:
+        raise RuntimeError("gmf_amd.GlobalRegistration: expected points, trans_points [N,3]")
+    w = None
+    if weights is not None:
+        w = require_cuda_f32(weights, "weights").contiguous().reshape(-1)
+        if w.numel() != X.shape[0]:
+            raise RuntimeError("gmf_amd.GlobalRegistration: weights must hold one value per point")
+    off = torch.as_tensor(list(offsets), dtype=torch.int32)
+    B = off.numel() - 1
+    if B < 1 or int(off[0]) != 0 or int(off[-1]) != X.shape[0] or bool((off[1:] <= off[:-1]).any()):
+        raise RuntimeError("gmf_amd.GlobalRegistration: offsets must be increasing, start at 0 and end at N")
+    off = off.to(X.device)
+    R = torch.empty((B, 3, 3), device=X.device, dtype=torch.float32)
+    t = torch.empty((B, 3), device=X.device, dtype=torch.float32)
+    stats = torch.empty((B, 3), device=X.device, dtype=torch.float32)
+    h, st = handle_and_stream(X)
+    h.call("gmf_global_registration", X.data_ptr(), Y.data_ptr(), None if w is None else w.data_ptr(), off.data_ptr(), B,
+           float(eps), float(quantization_size), int(max_iter), int(max_break_count), float(break_threshold_ratio),
+           R.data_ptr(), t.data_ptr(), stats.data_ptr(), st)
+    return R, t, stats
+
+
+def GlobalRegistration(points, trans_points, weights=None, max_iter=1000, verbose=False, stat_freq=20,
+                       max_break_count=20, break_threshold_ratio=1e-5, loss_fn=None, quantization_size=1):
+    """Drop-in for core/registration.py:135-194: (R [3,3], t [3], {'iterations', 'loss', 'break_count'}).
+
+    numpy inputs are accepted as in the reference (:145-149) and moved to the current HIP device; `verbose` /
+    `stat_freq` only print in the reference and are ignored; a custom `loss_fn` is not supported (the reference's own
+    callers never pass one) and raises."""
+    import numpy as np
+    if loss_fn is not None:
+        raise NotImplementedError("gmf_amd.GlobalRegistration: only the default HighDimSmoothL1Loss is implemented")
+    dev = None
+    for v in (points, trans_points, weights):
+        if isinstance(v, torch.Tensor) and v.is_cuda:
+            dev = v.device
+    if dev is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+    def _t(v):
+        if v is None:
+            return None
+        if isinstance(v, np.ndarray):
+            v = torch.from_numpy(v)
+        return v.detach().float().to(dev)
+
+    P, Q, W = _t(points), _t(trans_points), _t(weights)
+    R, t, stats = global_registration_batched(P, Q, W, [0, P.shape[0]], max_iter, max_break_count,
+                                              break_threshold_ratio, quantization_size)
+    s = stats[0].tolist()
+    return R[0], t[0], {"iterations": int(s[0]), "loss": s[1], "break_count": int(s[2])}

@@ -207,3 +207,24 @@ def synthetic_batch(seeds, N: int, T: int, kind: str = "3dmatch", C: int = 128):
             "q_tokens": torch.from_numpy(np.stack([t[1] for t in toks]))}
 
 
+
+
+def dgr_scene(N: int, seed: int, inlier_ratio: float = 0.3, noise: float = 0.01, clip: float = 0.05):
+    """One DGR-surface problem: X ~ U[0,3)^3, Y = R X + t + noise for the inliers and uniform
+    for the outliers, w = sigmoid(logit) with weights below `clip` zeroed (deep_global_registration.py:322-325).
+    Returns X [N,3], Y [N,3], w [N,1] (float32 torch tensors) and the ground truth R [3,3], t [3] (numpy)."""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng([113, N, seed])
+    X = rng.uniform(0, 3, (N, 3)).astype(np.float32)
+    Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    if np.linalg.det(Q) < 0:
+        Q[:, 0] = -Q[:, 0]
+    t = rng.uniform(-0.5, 0.5, 3)
+    Y = (X @ Q.T + t + rng.normal(0, noise, (N, 3))).astype(np.float32)
+    out = rng.random(N) > inlier_ratio
+    Y[out] = rng.uniform(0, 3, (int(out.sum()), 3)).astype(np.float32)
+    logit = np.where(out, rng.normal(-2, 1.5, N), rng.normal(2, 1.5, N)).astype(np.float32)
+    w = (1.0 / (1.0 + np.exp(-logit.astype(np.float64)))).astype(np.float32)
+    w[w < clip] = 0
+    return torch.from_numpy(X), torch.from_numpy(Y), torch.from_numpy(w)[:, None], Q.astype(np.float32), t.astype(np.float32)

@@ -223,6 +223,16 @@ int gmf_post_refinement(gmf_handle* h, const float* T_in, const float* src_keypt
 int gmf_weighted_procrustes(gmf_handle* h, const float* X, const float* Y, const float* w, const int* offsets, int B,
                             float eps, float* R, float* t, gmf_stream_t stream);
 
+/* DGR GlobalRegistration(points, trans_points, weights, max_iter, ..., max_break_count, break_threshold_ratio, ...,
+ * quantization_size) (GMF_DeepGlobalRegistration/.../core/registration.py:135-194; loss core/loss.py:42-61;
+ * caller core/deep_global_registration.py:334-340): weighted-Procrustes initialisation + robust Adam refinement of a 6-D
+ * rotation and a translation, batched over B ragged pairs like gmf_weighted_procrustes (offsets [B+1] device int32;
+ * X,Y [sum N,3]; w [sum N] or NULL for the unweighted form).  eps = the loss's eps (float32 machine epsilon in the
+ * reference).  R [B,9], t [B,3], stats [B,3] = {iterations, loss, break_count}.  One persistent kernel, no host sync. */
+int gmf_global_registration(gmf_handle* h, const float* X, const float* Y, const float* w, const int* offsets, int B,
+                            float eps, float quantization_size, int max_iter, int max_break_count,
+                            double break_threshold_ratio, float* R, float* t, float* stats, gmf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

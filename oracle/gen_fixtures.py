@@ -82,7 +82,43 @@ def build_ref_pointdsc(pdsc, sd, num_layers=12, sigma_d=0.1, tau=0.10, nms=0.10,
     return m.eval()
 
 
+def gen_f13(reg):
+    """F13: DGR GlobalRegistration (row f-3) - the reference's own function on seeded scenes (gmf_amd.synthetic.dgr_scene).
+    The fixture holds the seeds, the call arguments and the reference's outputs; inputs are regenerated from the seeds."""
+    from gmf_amd import synthetic
+    out, cases = {}, []
+    for N, seed, ratio, q, use_w in ((200, 0, 1e-4, 0.1, True), (1000, 1, 1e-4, 0.1, True), (8000, 2, 1e-4, 0.1, True),
+                                     (1000, 3, 1e-5, 1.0, True), (500, 4, 1e-4, 0.1, False), (3000, 5, 1e-4, 0.05, True)):
+        X, Y, w, _, _ = synthetic.dgr_scene(N, seed)
+        R, t, o = reg.GlobalRegistration(X.clone(), Y.clone(), weights=w.clone() if use_w else None,
+                                         break_threshold_ratio=ratio, quantization_size=q)
+        tag = f"{N}_{seed}"
+        cases.append([N, seed, ratio, q, int(use_w)])
+        out[f"R_{tag}"], out[f"t_{tag}"] = _np(R), _np(t)
+        out[f"stats_{tag}"] = np.array([o["iterations"], o["loss"], o["break_count"]], np.float64)
+        Rp, tp = (reg.weighted_procrustes(X, Y, w, np.finfo(np.float32).eps) if use_w
+                  else reg.argmin_se3_squared_dist(X, Y))
+        out[f"Rinit_{tag}"], out[f"tinit_{tag}"] = _np(Rp), _np(tp)
+        print("F13", tag, o)
+    out["cases"] = np.array(cases, np.float64)
+    # ortho2rotation and the loss on their own
+    r = np.random.default_rng([113])
+    poses = torch.from_numpy(r.normal(size=(16, 6)).astype(np.float32))
+    out["o2r_in"], out["o2r_out"] = _np(poses), _np(reg.ortho2rotation(poses))
+    A = torch.from_numpy(r.normal(size=(300, 3)).astype(np.float32))
+    Bm = A + torch.from_numpy(r.normal(scale=0.7, size=(300, 3)).astype(np.float32))
+    wl = torch.from_numpy(r.uniform(0, 1, (300, 1)).astype(np.float32))
+    from core.loss import HighDimSmoothL1Loss
+    out["loss_A"], out["loss_B"], out["loss_w"] = _np(A), _np(Bm), _np(wl)
+    out["loss_val"] = np.array([float(HighDimSmoothL1Loss(wl, 0.5)(A, Bm)), float(HighDimSmoothL1Loss(None, 0.5)(A, Bm))])
+    np.savez_compressed(os.path.join(GOLD, "f13_global_registration.npz"), **out)
+
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f13":
+        gen_f13(_import_reference()[4])
+        return
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
     pdsc, fl, common, pio, reg = _import_reference()

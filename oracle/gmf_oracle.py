@@ -347,6 +347,76 @@ def dgr_inlier_weights(logits, clip: float = 0.05):
 
 
 # --------------------------------------------------------------------------
+# DGR robust pose refinement:
+# GlobalRegistration (core/registration.py:135-194), Transformation (:116-132),
+# ortho2rotation (:16-63), HighDimSmoothL1Loss (core/loss.py:42-61)
+# --------------------------------------------------------------------------
+def ortho2rotation(poses):
+    """6-D rotation parameters [B,6] -> rotation matrices [B,3,3] (Gram-Schmidt; registration.py:16-63)."""
+    x_raw, y_raw = poses[:, 0:3], poses[:, 3:6]
+    x = x_raw / torch.clamp(torch.sqrt((x_raw ** 2).sum(1, keepdim=True)), min=1e-8)
+    factor = (x * y_raw).sum(1, keepdim=True) / torch.clamp((x ** 2).sum(1, keepdim=True), min=1e-8)
+    v = y_raw - factor * x
+    y = v / torch.clamp(torch.sqrt((v ** 2).sum(1, keepdim=True)), min=1e-8)
+    z = torch.stack((x[:, 1] * y[:, 2] - x[:, 2] * y[:, 1],
+                     x[:, 2] * y[:, 0] - x[:, 0] * y[:, 2],
+                     x[:, 0] * y[:, 1] - x[:, 1] * y[:, 0]), 1)
+    return torch.stack((x, y, z), 2)
+
+
+def high_dim_smooth_l1(X, Y, weights, w1, quantization_size: float, eps: float):
+    """loss.py:51-61: per-point 0.5*d^2 for d^2 < 1, else 0.5*(sqrt(d^2 + eps) - 0.5); weighted mean."""
+    sq_dist = torch.sum(((X - Y) / quantization_size) ** 2, dim=1, keepdim=True)
+    use_sq_half = 0.5 * (sq_dist < 1).float()
+    loss = (0.5 - use_sq_half) * (torch.sqrt(sq_dist + eps) - 0.5) + use_sq_half * sq_dist
+    if weights is None:
+        return loss.mean()
+    return (loss * weights).sum() / w1
+
+
+def global_registration(points, trans_points, weights=None, max_iter: int = 1000, max_break_count: int = 20,
+                        break_threshold_ratio: float = 1e-5, quantization_size: float = 1.0):
+    """Adam (lr 0.1, exponential decay 0.999) on a 6-D rotation + translation initialised by the (weighted) Procrustes
+    solution, stopped when the relative loss change stayed below `break_threshold_ratio` `max_break_count` times
+    (the counter never resets, registration.py:181-184) or the loss drops below 1e-7.
+    Returns R [3,3], t [3], {"iterations", "loss", "break_count"} like the reference."""
+    eps = float(torch.finfo(torch.float32).eps)
+    if weights is None:
+        R, t = weighted_procrustes(points, trans_points, torch.ones(points.shape[0], 1), 0.0)   # = argmin_se3_squared_dist
+        w1 = None
+    else:
+        weights = weights.detach()
+        R, t = weighted_procrustes(points, trans_points, weights, eps)
+        w1 = weights.sum()
+    rot6d = torch.cat((R[:, 0], R[:, 1]))[None].clone().requires_grad_(True)
+    trans = t[None].clone().requires_grad_(True)
+
+    def forward():
+        return points @ ortho2rotation(rot6d)[0].t() + trans
+
+    opt = torch.optim.Adam([rot6d, trans], lr=1e-1)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.999)
+    with torch.no_grad():
+        loss_prev = high_dim_smooth_l1(forward(), trans_points, weights, w1, quantization_size, eps).item()
+    break_counter, i, loss = 0, 0, None
+    for i in range(max_iter):
+        loss = high_dim_smooth_l1(forward(), trans_points, weights, w1, quantization_size, eps)
+        if loss.item() < 1e-7:
+            break
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sched.step()
+        if abs(loss_prev - loss.item()) < loss_prev * break_threshold_ratio:
+            break_counter += 1
+            if break_counter >= max_break_count:
+                break
+        loss_prev = loss.item()
+    return (ortho2rotation(rot6d.detach())[0], trans.detach()[0],
+            {"iterations": i, "loss": loss.item(), "break_count": break_counter})
+
+
+# --------------------------------------------------------------------------
 # Descriptor matching (SURVEY section 8 row f-2)
 # --------------------------------------------------------------------------
 def nn_match_pointdsc(src_desc, tgt_desc):

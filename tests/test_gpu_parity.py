@@ -370,3 +370,97 @@ def test_descriptor_matching_full_size():
     idx, dis = gmf_amd.nn_match(_gpu(torch.from_numpy(F0.astype(np.float32))), _gpu(torch.from_numpy(F1)))
     assert (idx.cpu().numpy() == perm).all()
     assert float(dis.max()) < 0.3
+
+
+# ---- row f-3: DGR GlobalRegistration as one persistent HIP kernel --------------------------------------------------
+def _f13_cases(g):
+    return [(int(c[0]), int(c[1]), float(c[2]), float(c[3]), bool(c[4])) for c in g["cases"]]
+
+
+# The reference's optimisation is not a continuous function of its inputs: the stopping counter compares fp32 losses of
+# consecutive steps (registration.py:181), and the loss derivative jumps from 1/2 to 1/4 where a residual crosses d^2 = 1
+# (core/loss.py:52-56).  Two correct fp32 evaluations that differ in the last bit of one sum can therefore stop a step
+# apart or part ways late in the run - the reference's own answer depends on torch's vector width for `sum`.  Parity is
+# asserted in two parts: the optimisation TRAJECTORY (stopping rule disabled) against the oracle at 1e-5, and the
+# naturally stopped result against the reference's own outputs at a tolerance that covers a late split, with the cases
+# whose stopping iteration is not on such a boundary held to 1e-5.
+@pytest.mark.parametrize("case", range(6))
+def test_f13_trajectory(golden_dir, case):
+    """25 Adam steps with the stopping rule disabled: HIP kernel == oracle (== reference, test_oracle_golden) to 1e-5."""
+    g = _load(golden_dir, "f13_global_registration.npz")
+    N, seed, ratio, q, use_w = _f13_cases(g)[case]
+    X, Y, w, _, _ = synthetic.dgr_scene(N, seed)
+    Ro, to, oo = O.global_registration(X, Y, w if use_w else None, max_iter=25, break_threshold_ratio=0.0,
+                                       quantization_size=q)
+    R, t, o = gmf_amd.GlobalRegistration(_gpu(X), _gpu(Y), weights=_gpu(w) if use_w else None, max_iter=25,
+                                         break_threshold_ratio=0.0, quantization_size=q)
+    assert o["iterations"] == oo["iterations"] == 24 and o["break_count"] == 0
+    assert _maxerr(R.cpu(), Ro) < 1e-5 and _maxerr(t.cpu(), to) < 1e-5
+    assert abs(o["loss"] - oo["loss"]) < 1e-5 * oo["loss"]
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_f13_global_registration(golden_dir, case):
+    """gmf_amd.GlobalRegistration, naturally stopped, against the reference's own outputs (golden F13)."""
+    g = _load(golden_dir, "f13_global_registration.npz")
+    N, seed, ratio, q, use_w = _f13_cases(g)[case]
+    X, Y, w, Rg, tg = synthetic.dgr_scene(N, seed)
+    R, t, o = gmf_amd.GlobalRegistration(_gpu(X), _gpu(Y), weights=_gpu(w) if use_w else None,
+                                         break_threshold_ratio=ratio, quantization_size=q)
+    tag = f"{N}_{seed}"
+    it_ref, loss_ref = int(g[f"stats_{tag}"][0]), float(g[f"stats_{tag}"][1])
+    assert o["break_count"] == 20 and abs(float(torch.det(R.cpu().double())) - 1) < 1e-5
+    assert abs(o["loss"] - loss_ref) < 1e-4 * loss_ref
+    assert _maxerr(R.cpu(), g[f"R_{tag}"]) < 3e-3 and _maxerr(t.cpu(), g[f"t_{tag}"]) < 3e-3
+    if case in (0, 3, 4):          # stopping iteration well away from a rounding boundary
+        assert o["iterations"] == it_ref
+        assert _maxerr(R.cpu(), g[f"R_{tag}"]) < 1e-5 and _maxerr(t.cpu(), g[f"t_{tag}"]) < 1e-5
+    # never worse than the reference's own answer against the ground truth (by more than the split tolerance)
+    assert _maxerr(R.cpu(), Rg) < _maxerr(g[f"R_{tag}"], Rg) + 3e-3
+
+
+def test_global_registration_batched_config5():
+    """BASELINE config 5 shape: 32 DGR problems of 8000 correspondences refined in ONE launch; each equals its own
+    single-problem call bit for bit, recovers the ground-truth pose better than the Procrustes initialisation, and the
+    oracle agrees on a sample of them."""
+    B, N = 32, 8000
+    scenes = [synthetic.dgr_scene(N, 100 + i) for i in range(B)]
+    X = _gpu(torch.cat([s[0] for s in scenes])); Y = _gpu(torch.cat([s[1] for s in scenes]))
+    w = _gpu(torch.cat([s[2] for s in scenes]))
+    R, t, stats = gmf_amd.global_registration_batched(X, Y, w, [i * N for i in range(B + 1)], break_threshold_ratio=1e-4,
+                                                      quantization_size=0.1)
+    R0, t0 = gmf_amd.weighted_procrustes_batched(X, Y, w, [i * N for i in range(B + 1)], np.finfo(np.float32).eps)
+    better = 0
+    for i in range(B):
+        Ri, ti, oi = gmf_amd.GlobalRegistration(_gpu(scenes[i][0]), _gpu(scenes[i][1]), weights=_gpu(scenes[i][2]),
+                                                break_threshold_ratio=1e-4, quantization_size=0.1)
+        assert torch.equal(Ri, R[i]) and torch.equal(ti, t[i]) and oi["iterations"] == int(stats[i, 0])
+        better += _maxerr(R[i].cpu(), scenes[i][3]) < _maxerr(R0[i].cpu(), scenes[i][3])
+        assert _maxerr(R[i].cpu(), scenes[i][3]) < 1e-2 and _maxerr(t[i].cpu(), scenes[i][4]) < 5e-2
+    assert better >= B - 2
+    for i in (0, 17):
+        Ro, to, oo = O.global_registration(*scenes[i][:3], break_threshold_ratio=1e-4, quantization_size=0.1)
+        assert _maxerr(R[i].cpu(), Ro) < 3e-3 and _maxerr(t[i].cpu(), to) < 3e-3      # see the note above test_f13_trajectory
+        assert abs(float(stats[i, 1]) - oo["loss"]) < 1e-4 * oo["loss"]
+
+
+def test_global_registration_edge_cases():
+    """numpy inputs (registration.py:145-149), a ragged batch, max_iter = 0 (returns the initialisation) and bad arguments."""
+    X, Y, w, Rg, tg = synthetic.dgr_scene(300, 7)
+    R, t, o = gmf_amd.GlobalRegistration(X.numpy(), Y.numpy(), weights=w, break_threshold_ratio=1e-4, quantization_size=0.1)
+    R2, t2, o2 = gmf_amd.GlobalRegistration(_gpu(X), _gpu(Y), weights=_gpu(w), break_threshold_ratio=1e-4, quantization_size=0.1)
+    assert torch.equal(R, R2) and o == o2
+    R0, t0, o0 = gmf_amd.GlobalRegistration(_gpu(X), _gpu(Y), weights=_gpu(w), max_iter=0, quantization_size=0.1)
+    Rp, tp = gmf_amd.weighted_procrustes(_gpu(X), _gpu(Y), _gpu(w), np.finfo(np.float32).eps)
+    assert _maxerr(R0.cpu(), Rp.cpu()) < 1e-6 and _maxerr(t0.cpu(), tp.cpu()) < 1e-6
+    Xa, Ya, wa, _, _ = synthetic.dgr_scene(50, 8)
+    Rb, tb, sb = gmf_amd.global_registration_batched(_gpu(torch.cat([X, Xa])), _gpu(torch.cat([Y, Ya])),
+                                                     _gpu(torch.cat([w, wa])), [0, 300, 350], break_threshold_ratio=1e-4,
+                                                     quantization_size=0.1)
+    assert torch.equal(Rb[0], R2)
+    with pytest.raises(RuntimeError):
+        gmf_amd.global_registration_batched(_gpu(X), _gpu(Y), _gpu(w), [0, 100], quantization_size=0.1)
+    with pytest.raises(RuntimeError):
+        gmf_amd.GlobalRegistration(_gpu(X), _gpu(Y), weights=_gpu(w), quantization_size=0.0)
+    with pytest.raises(NotImplementedError):
+        gmf_amd.GlobalRegistration(_gpu(X), _gpu(Y), loss_fn=lambda a, b: 0)

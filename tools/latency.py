@@ -28,3 +28,28 @@ for B, N in ((1, 1000), (1, 5000), (1, 10000), (8, 1000), (32, 1000), (16, 10000
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print(f"B={B:3d} N={N:6d}: {dt * 1e3:8.3f} ms per forward  = {B * N / dt / 1e6:7.3f} M correspondences/s")
+
+# ---- DGR surface (BASELINE config 5): weighted Procrustes and the robust refinement, N = 8000 ------------------------
+import numpy as np                               # noqa: E402
+
+for B in (1, 32, 256):
+    N = 8000
+    scenes = [synthetic.dgr_scene(N, 500 + i) for i in range(min(B, 32))]
+    X = torch.cat([scenes[i % len(scenes)][0] for i in range(B)]).to(dev)
+    Y = torch.cat([scenes[i % len(scenes)][1] for i in range(B)]).to(dev)
+    w = torch.cat([scenes[i % len(scenes)][2] for i in range(B)]).to(dev)
+    off = [i * N for i in range(B + 1)]
+    for name, fn in (("weighted_procrustes", lambda: gmf_amd.weighted_procrustes_batched(X, Y, w, off, np.finfo(np.float32).eps)),
+                     ("GlobalRegistration ", lambda: gmf_amd.global_registration_batched(X, Y, w, off, break_threshold_ratio=1e-4,
+                                                                                         quantization_size=0.1))):
+        for _ in range(2):
+            out = fn()
+        torch.cuda.synchronize()
+        n = 5
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        extra = f"  (mean {float(out[2][:, 0].mean()):.0f} Adam steps)" if len(out) == 3 else ""
+        print(f"DGR {name} B={B:3d} N={N}: {dt * 1e3:8.3f} ms per batch = {B * N / dt / 1e6:8.2f} M correspondences/s{extra}")

@@ -97,6 +97,37 @@ GMF_DEVINL void lcpe_frag(float (&y)[CF], const float* __restrict__ pair_base, i
   }
 }
 
+// a row fragment as two fp16 planes: NS = K/16 k-steps
+template <int NS>
+struct FragH2 {
+  f16x8 h[NS], l[NS];
+  GMF_DEVINL void set(const float* x) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) split8h(x + 8 * s, h[s], l[s]);
+  }
+  // fill k-steps [2*blk, 2*blk+2) from one 32-wide block of accumulators / fragment values
+  GMF_DEVINL void set_block(int blk, const float (&t)[16]) {
+    split8h(&t[0], h[2 * blk], l[2 * blk]);
+    split8h(&t[8], h[2 * blk + 1], l[2 * blk + 1]);
+  }
+};
+
+// acc += W(32 x 16*NS) * X^T   (rows on lanes); weight block image: 16-byte unit ((plane*NS + s)*64 + lane)
+template <int NS>
+GMF_DEVINL void mma_wx_h2(f32x16& acc, const f16x8* lw, const FragH2<NS>& x) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) mma3(acc, lw[(0 * NS + s) * 64], lw[(1 * NS + s) * 64], x.h[s], x.l[s]);
+}
+
+// acc += X * W^T   (feature on lane)
+template <int NS>
+GMF_DEVINL void mma_xw_h2(f32x16& acc, const f16x8* lw, const FragH2<NS>& x) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) mma3(acc, x.h[s], x.l[s], lw[(0 * NS + s) * 64], lw[(1 * NS + s) * 64]);
+}
+
+GMF_DEVINL const f16x8* as_h2(const float4* p) { return reinterpret_cast<const f16x8*>(p); }
+
 GMF_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // Branch-free erf for the GELU of the feed-forward kernels.  ocml's erff compiles to a per-element exec-mask branch

@@ -1284,7 +1284,8 @@ GMF_DEVINL float xhalf_max_swap(float v) {
 
 // PLACE: where a tile's 8 LDS-DMA pieces are issued - 0 = at the top of the tile, 1 = one per unit of phase 1,
 // 2 = one per unit in the bare MFMA gaps of phase 2.
-template <int PLACE>
+// EPI_H2: fc_message epilogue on the f16 MFMA with split-fp16 weights (wst = tail_wst_h2) instead of the fp32 MFMA.
+template <int PLACE, bool EPI_H2>
 __global__ void __launch_bounds__(256, 2)
 k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
              const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
@@ -1524,6 +1525,53 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   StageStream ss;
   ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5);
   ss.prime();
+  if (EPI_H2) {
+    // stages (fp16x2 images, same sizes as the fp32 ones): Wa block 0 | Wa block 1 | Wb (2 blocks) | Wc 0,1 | Wc 2,3
+    FragH2<8> ox;
+    ox.set(o);
+    FragH2<4> m1x, m2x;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const f16x8* lw = as_h2(ss.acquire());
+      f32x16 acc = zero16();
+      mma_wx_h2<8>(acc, lw, ox);
+      float b[16], t1[16];
+      load_vec_block(b, vecs, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t1[r] = fmaxf(acc[r] + b[r], 0.f);
+      m1x.set_block(mb, t1);
+    }
+    {
+      const f16x8* lw = as_h2(ss.acquire());
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        f32x16 acc = zero16();
+        mma_wx_h2<4>(acc, lw + mb * (2 * 4 * 64), m1x);
+        float b[16], t2[16];
+        load_vec_block(b, vecs + 64, mb, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t2[r] = fmaxf(acc[r] + b[r], 0.f);
+        m2x.set_block(mb, t2);
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const f16x8* lw = as_h2(ss.acquire());
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        const int mb = 2 * st + hb;
+        f32x16 acc = zero16();
+        mma_wx_h2<4>(acc, lw + hb * (2 * 4 * 64), m2x);
+        float b[16], fz[16], tt[16];
+        load_vec_block(b, vecs + 128, mb, h);
+        load_block_p32(fz, fus + toff, mb, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tt[r] = acc[r] + b[r] + fz[r];
+        if (active) store_block_p32(out + toff, mb, tt, lane);
+      }
+    }
+    return;
+  }
   float m1[DHF], m2[DHF];
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) {
@@ -2121,9 +2169,11 @@ hipError_t launch_scattn(const float* q, const float* k, const float* v, const f
       }
     }
     else if (variant >= 16 && cc && g_use_cache && cc->dense) {
-      if (variant == 17) hipLaunchKernelGGL(k_scattn_h2p<1>, grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense);
-      else if (variant == 18) hipLaunchKernelGGL(k_scattn_h2p<2>, grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense);
-      else hipLaunchKernelGGL(k_scattn_h2p<0>, grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense);
+      static const bool epi_h2 = [] { const char* e = getenv("GMF_EPI_H2"); return e ? atoi(e) != 0 : true; }();
+      if (variant == 17) hipLaunchKernelGGL((k_scattn_h2p<1, false>), grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense);
+      else if (variant == 18 && cc->tail_wst_h2 && epi_h2) hipLaunchKernelGGL((k_scattn_h2p<2, true>), grid4, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cc->dense);
+      else if (variant == 18) hipLaunchKernelGGL((k_scattn_h2p<2, false>), grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense);
+      else hipLaunchKernelGGL((k_scattn_h2p<0, false>), grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense);
     }
     else if (variant == 9 || variant >= 16) {
       const float* cd = (cc && g_use_cache) ? cc->dense : nullptr;

@@ -355,7 +355,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   float* x1t = arena_take<float>(h, tok);
   float* imgfeat = arena_take<float>(h, tok);
   float* ctxall = arena_take<float>(h, (size_t)(L > 0 ? L : 1) * tok);
-  gmf::CompatCache cc{nullptr};
+  gmf::CompatCache cc{nullptr, nullptr};
   float* c_dense = nullptr;
   if (want_cache) {
     c_dense = arena_take<float>(h, n_tt * 1024);
@@ -398,6 +398,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
                                          w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
     else GMF_HIP(gmf::launch_front(l == 0 ? 1 : 0, in, w->front_wst + (size_t)l * w->front_wst_stride,
                                    w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
+    cc.tail_wst_h2 = w->tail_wst_h2 ? w->tail_wst_h2 + (size_t)l * w->tail_wst_stride : nullptr;
     if (int rc = run_block_tail(h, w, l, f, q, k, v, pts8, ctxall + (size_t)l * tok, x1, x2, nxt, B, N, T, st, nullptr,
                                 want_cache ? &cc : nullptr)) return rc;
     float* t = cur; cur = nxt; nxt = t;

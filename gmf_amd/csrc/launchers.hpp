@@ -7,6 +7,7 @@ namespace gmf {
 // compat matrix built once per batch by launch_compat_build (see k_compat_build): [B, tiles, tiles, 1024] floats
 struct CompatCache {
   const float* dense;
+  const float* tail_wst_h2;   // this layer's fc_message weights as split-fp16 images, or nullptr (fp32-MFMA epilogue)
 };
 void set_use_cache(bool v);
 bool get_use_cache();

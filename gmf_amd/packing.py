@@ -197,13 +197,14 @@ def pack_front(sd, layer: int, with_layer0: bool, identity_pointcn: bool = False
     return wst.contiguous(), vec.contiguous()
 
 
-def pack_tail(sd, layer: int):
-    """fc_message with both BatchNorms folded (PointDSC.py:13-21)."""
+def pack_tail(sd, layer: int, img=None):
+    """fc_message with both BatchNorms folded (PointDSC.py:13-21); img = p32 (fp32 images) or p32_h2 (split-fp16)."""
+    img = img or p32
     p = f"encoder.blocks.NonLocal_layer_{layer}.fc_message."
     Wa, ba = fold_bn(_f(sd[p + "0.weight"])[:, :, 0], _f(sd[p + "0.bias"]), sd, p + "1.")
     Wb, bb = fold_bn(_f(sd[p + "3.weight"])[:, :, 0], _f(sd[p + "3.bias"]), sd, p + "4.")
     Wc, bc = _f(sd[p + "6.weight"])[:, :, 0], _f(sd[p + "6.bias"])
-    wst = torch.cat([p32(Wa), p32(Wb), p32(Wc)])
+    wst = torch.cat([img(Wa), img(Wb), img(Wc)])
     vec = torch.cat([ba, bb, bc])
     assert wst.numel() == TAIL_WST and vec.numel() == TAIL_VEC
     return wst.contiguous(), vec.contiguous()
@@ -254,6 +255,7 @@ class PackedEncoder:
             self.t["front_wst_h2"] = torch.stack([pack_front(sd, i, with_layer0=(i == 0 and "encoder.layer0.weight" in sd),
                                                              identity_pointcn=standalone_block, img=p32_h2)[0]
                                                   for i in range(num_layers)]).contiguous()
+            self.t["tail_wst_h2"] = torch.stack([pack_tail(sd, i, img=p32_h2)[0] for i in range(num_layers)]).contiguous()
         if num_layers > 0:
             self.t["ff_wst_b3"] = torch.stack([pack_ff_b3(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.")
                                                for i in range(num_layers)]).contiguous()
@@ -277,6 +279,7 @@ class PackedEncoder:
         w.ff_wst_b3 = self.t["ff_wst_b3"].data_ptr() if "ff_wst_b3" in self.t else None
         w.ff_wst_b3_stride = 48 * 6144
         w.f1_ff_wst_b3 = self.t["f1_ff_wst_b3"].data_ptr() if "f1_ff_wst_b3" in self.t else None
-        for name in ("front_wst_h2", "ctx_wst_h2", "attn_wst_h2", "ff_wst_h2", "f1_ctx_wst_h2", "f1_attn_wst_h2", "f1_ff_wst_h2"):
+        for name in ("front_wst_h2", "ctx_wst_h2", "attn_wst_h2", "ff_wst_h2", "f1_ctx_wst_h2", "f1_attn_wst_h2", "f1_ff_wst_h2",
+                     "tail_wst_h2"):
             setattr(w, name, self.t[name].data_ptr() if name in self.t else None)
         self.struct = w

@@ -135,6 +135,9 @@ typedef struct gmf_encoder_weights {
    * context prepare, the cross-attention and the feed-forward run on the f16 MFMA (fp32-equivalent accuracy). */
   const float* front_wst_h2; const float* ctx_wst_h2; const float* attn_wst_h2; const float* ff_wst_h2;
   const float* f1_ctx_wst_h2; const float* f1_attn_wst_h2; const float* f1_ff_wst_h2;
+  /* optional split-fp16 image of the fc_message weights (same size and stride as tail_wst): the epilogue of the cached,
+   * software-pipelined attention kernel then runs on the f16 MFMA too. */
+  const float* tail_wst_h2;
 } gmf_encoder_weights;
 
 /* PointDSC.forward up to the logits (PointDSC.py:216-241) with image TOKENS as input:

@@ -158,5 +158,27 @@ GMF_DEVINL float erf_bf(float a) {
 }
 GMF_DEVINL float gelu_erf_bf(float x) { return 0.5f * x * (1.0f + erf_bf(x * 0.70710678118654752440f)); }
 
+// GELU(x) = x * Phi(x) needs Phi to ~6e-8 ABSOLUTE, not erf to a relative ulp, so one formula covers every x:
+//   Phi(x) = 1 - erfc(t)/2 (x >= 0),  erfc(t)/2 (x < 0),  t = |x|/sqrt(2)   =>   GELU(x) = max(x, 0) - 0.5 |x| erfc(t)
+//   erfc(t) = exp2(t * p(t)) with p a degree-8 polynomial fitted (weighted minimax, tools/fit_gelu.py) to log2(erfc(t))/t
+//   on [0, 4.3]: |erfc error| < 2.3e-9; beyond 4.3 erfc < 1.2e-9 and t is clamped.
+// 16 vector instructions with one v_exp_f32 and no select (the two-range erf above: 26).  Max |error| against the exact
+// GELU over |x| <= 12 evaluated in fp32: 2.4e-7 - the reference's own fp32 formula 0.5 x (1 + erf(x/sqrt 2)): 4.5e-7.
+GMF_DEVINL float gelu_erf_1r(float x) {
+  const float ax = fabsf(x);
+  const float t = fminf(ax * 0.70710678118654752440f, 4.3f);
+  float p = 1.160468673e-05f;
+  p = fmaf(p, t, -1.529631263e-04f);
+  p = fmaf(p, t, 8.482293342e-04f);
+  p = fmaf(p, t, -2.274774713e-03f);
+  p = fmaf(p, t, 8.479235839e-05f);
+  p = fmaf(p, t, 2.772448584e-02f);
+  p = fmaf(p, t, -1.483079195e-01f);
+  p = fmaf(p, t, -9.184429049e-01f);
+  p = fmaf(p, t, -1.627907276e+00f);
+  const float e = __builtin_amdgcn_exp2f(p * t);
+  return fmaf(-0.5f * ax, e, fmaxf(x, 0.f));
+}
+
 
 }  // namespace gmf

@@ -356,7 +356,7 @@ k_fusion_ff_h2(const float* __restrict__ x1, const float* __restrict__ wst, cons
       float b[16];
       load_vec_block(b, b1g, c, h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ga[r] *= gelu_erf_bf(acc[r] + b[r]);
+      for (int r = 0; r < 16; ++r) ga[r] *= gelu_erf_1r(acc[r] + b[r]);
     }
     {
       FragH2<2> gx;
@@ -475,14 +475,14 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
           if (half == 0) mma3(a_nxt, wh, wl, nx.h[s], nx.l[s]);
           else mma3(g_nxt, wh, wl, nx.h[s], nx.l[s]);
           wh = wh_n; wl = wl_n;
-          a_cur[u] *= (ABL == 2) ? g_cur[u] : gelu_erf_bf(g_cur[u]);
+          a_cur[u] *= (ABL == 2) ? g_cur[u] : gelu_erf_1r(g_cur[u]);
           if (half == 1 && (s & 1)) { const int j = s - 1; split2h(a_cur[j], a_cur[j + 1], gx.h[0], gx.l[0], j); }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     } else {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) a_cur[u] *= gelu_erf_bf(g_cur[u]);
+      for (int u = 0; u < 16; ++u) a_cur[u] *= gelu_erf_1r(g_cur[u]);
 #pragma unroll
       for (int j = 0; j < 8; j += 2) split2h(a_cur[j], a_cur[j + 1], gx.h[0], gx.l[0], j);
     }

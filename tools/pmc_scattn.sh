@@ -1,7 +1,7 @@
 #!/bin/bash
-# PMC passes over the attention kernel (GPU box):  bash tools/pmc_scattn.sh VARIANT TAG
+# PMC passes over one kernel of the encoder (GPU box):  bash tools/pmc_scattn.sh VARIANT TAG [KERNEL_NAME_PATTERN]
 # One rocprofv3 run per counter group (counters only with --kernel-trace, as the pool requires); summary by tools/pmc_summary.py
-V=${1:-18}; TAG=${2:-pmc}
+V=${1:-18}; TAG=${2:-pmc}; PAT=${3:-k_scattn}
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 GROUPS_=(
@@ -22,5 +22,5 @@ for g in "${GROUPS_[@]}"; do
   rocprofv3 --pmc $g --kernel-trace --output-format csv -d "$out" -o run -- python3 tools/run_scattn_once.py "$V" > "$out.log" 2>&1 || { echo "group $i failed"; tail -5 "$out.log"; }
   i=$((i+1))
 done
-python3 tools/pmc_summary.py "gpurun_out/${TAG}_g*" k_scattn > "gpurun_out/${TAG}_summary.json"
+python3 tools/pmc_summary.py "gpurun_out/${TAG}_g*" "$PAT" > "gpurun_out/${TAG}_summary.json"
 cat "gpurun_out/${TAG}_summary.json"

@@ -36,7 +36,7 @@ class EncoderWeights(C.Structure):
         ("ff_wst_b3", _vp), ("ff_wst_b3_stride", C.c_int), ("f1_ff_wst_b3", _vp),
         ("front_wst_h2", _vp), ("ctx_wst_h2", _vp), ("attn_wst_h2", _vp), ("ff_wst_h2", _vp),
         ("f1_ctx_wst_h2", _vp), ("f1_attn_wst_h2", _vp), ("f1_ff_wst_h2", _vp),
-        ("tail_wst_h2", _vp),
+        ("tail_wst_h2", _vp), ("tail_wst_q16", _vp),
     ]
 
 

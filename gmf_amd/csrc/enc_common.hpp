@@ -74,6 +74,26 @@ GMF_DEVINL void store_block_h2(float* __restrict__ tile_base, int blk, const flo
   }
 }
 
+// V tile image for the 16x16x32 attention kernel (k_scattn_h2q): 16-byte unit ((plane*8 + db16)*64 + 16 g + c) holds, for
+// feature d = 16 db16 + c, the 8 keys {4g .. 4g+3, 16+4g .. 16+4g+3} of the tile - the contraction order in which a lane
+// (g, c) of that kernel holds its probabilities.  `t` is a T-layout block of 32 features (feature on the lane, rows
+// 8(r>>2) + 4h + (r&3) in the registers): lane (h, i) owns the units g = h (registers 0-3, 8-11) and g = 2+h (4-7, 12-15).
+GMF_DEVINL void store_block_vq16(float* __restrict__ tile_base, int db32, const float (&t)[16], int lane) {
+  f16x8* base = reinterpret_cast<f16x8*>(tile_base);
+  const int h = lane >> 5, i = lane & 31;
+  const int db16 = 2 * db32 + (i >> 4), c = i & 15;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const float v8[8] = {t[4 * which], t[4 * which + 1], t[4 * which + 2], t[4 * which + 3],
+                         t[8 + 4 * which], t[8 + 4 * which + 1], t[8 + 4 * which + 2], t[8 + 4 * which + 3]};
+    f16x8 hi, lo;
+    split8h(v8, hi, lo);
+    const int g = 2 * which + h;
+    base[(0 * 8 + db16) * 64 + 16 * g + c] = hi;
+    base[(1 * 8 + db16) * 64 + 16 * g + c] = lo;
+  }
+}
+
 // LCPE (fusion_layer.py:118-128): y[row] = x[row] + b + w0*x[row-1] + w1*x[row] + w2*x[row+1],
 // zero padding outside [0, n_rows).  taps = w0[C] | w1[C] | w2[C] | b[C].
 GMF_DEVINL void lcpe_frag(float (&y)[CF], const float* __restrict__ pair_base, int row, int n_rows,

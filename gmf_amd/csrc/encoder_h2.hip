@@ -22,7 +22,8 @@ constexpr int kRing = GMF_H2_RING;   // LDS ring depth of the weight / context s
 //   vecs (fp32): bp | bq' | bk | bv | b0 | W0 image (fp32, K=8: layer0 stays on the f32 MFMA, 4 MFMAs per block)
 //   outputs: f as fp32 P32 image; Q', K, V as fp16x2 plane images (16 KiB per tile).
 // =========================================================================================
-template <int MODE>
+// VQ: V is written in the q16 tile layout (store_block_vq16) for the 16x16x32 attention kernel.
+template <int MODE, bool VQ>
 __global__ void __launch_bounds__(256, 2)
 k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const float* __restrict__ vecs,
            float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out,
@@ -112,7 +113,7 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
     float t[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = acc[r] + bv;
-    if (active) store_block_h2(v_out + toff, db, t, lane);
+    if (active) { if (VQ) store_block_vq16(v_out + toff, db, t, lane); else store_block_h2(v_out + toff, db, t, lane); }
   }
 }
 
@@ -522,10 +523,14 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
 static inline dim3 tgrid(int tiles, int B, int sets = 1) { return dim3((tiles + kWavesPerWG - 1) / kWavesPerWG, B, sets); }
 
 hipError_t launch_front_h2(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
-                           float* v, int B, int N, int tiles, hipStream_t s) {
-  if (mode == 1) hipLaunchKernelGGL(k_front_h2<1>, tgrid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
-  else if (mode == 2) hipLaunchKernelGGL(k_front_h2<2>, tgrid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
-  else hipLaunchKernelGGL(k_front_h2<0>, tgrid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+                           float* v, int B, int N, int tiles, hipStream_t s, bool v_q16) {
+  const bool vq = v_q16;
+#define GMF_FRONT_H2(M) do { if (vq) hipLaunchKernelGGL((k_front_h2<M, true>), tgrid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles); \
+                             else hipLaunchKernelGGL((k_front_h2<M, false>), tgrid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles); } while (0)
+  if (mode == 1) GMF_FRONT_H2(1);
+  else if (mode == 2) GMF_FRONT_H2(2);
+  else GMF_FRONT_H2(0);
+#undef GMF_FRONT_H2
   return hipGetLastError();
 }
 

@@ -1232,25 +1232,32 @@ k_scattn_b3p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
 // =========================================================================================
 constexpr int kJPerWave = 8;
 
+// Q16: element order of k_scattn_h2q - lane (g, c), float4 q4 = 2 ib + jb holds (query 32 I + 16 ib + c, keys 32 J + 16 jb + 4 g + r).
+template <bool Q16>
 __global__ void __launch_bounds__(256)
 k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int N, int tiles, float inv_sig2) {
-  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31, g = lane >> 4, c16 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.z, I = blockIdx.x;
   const size_t pbase = (size_t)pair * tiles;
-  float si[3], ti[3];
-  {
-    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)I * 32 + i) * 8);
+  float si[2][3], ti[2][3];
+#pragma unroll
+  for (int ib = 0; ib < (Q16 ? 2 : 1); ++ib) {
+    const int row = Q16 ? 16 * ib + c16 : i;
+    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)I * 32 + row) * 8);
     const float4 a = pp[0], b = pp[1];
-    si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
+    si[ib][0] = a.x; si[ib][1] = a.y; si[ib][2] = a.z; ti[ib][0] = b.x; ti[ib][1] = b.y; ti[ib][2] = b.z;
   }
   float4* crow = reinterpret_cast<float4*>(c_dense) + ((pbase + I) * (size_t)tiles) * 256 + lane;
   const int j0 = (blockIdx.y * 4 + wave) * kJPerWave;
   for (int J = j0; J < min(tiles, j0 + kJPerWave); ++J) {
-    const float4* lp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)J * 32) * 8) + 8 * h;
+    const float4* lp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)J * 32) * 8) + (Q16 ? 0 : 8 * h);
     float c[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c[r] = compat_times<false>(lp, 8 * (r >> 2) + (r & 3), si, ti, inv_sig2, 1.0f);
+    for (int r = 0; r < 16; ++r) {
+      if (Q16) c[r] = compat_times<false>(lp, 16 * ((r >> 2) & 1) + 4 * g + (r & 3), si[r >> 3], ti[r >> 3], inv_sig2, 1.0f);
+      else c[r] = compat_times<false>(lp, 8 * (r >> 2) + (r & 3), si[0], ti[0], inv_sig2, 1.0f);
+    }
     float4* ct = crow + (size_t)J * 256;
 #pragma unroll
     for (int q = 0; q < 4; ++q) ct[q * 64] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
@@ -1609,6 +1616,394 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
 #pragma unroll
       for (int r = 0; r < 16; ++r) tt[r] = acc[r] + b[r] + fz[r];
       if (active) store_block_p32(out + toff, mb, tt, lane);
+    }
+  }
+}
+
+// =========================================================================================
+// k_scattn_h2q: k_scattn_h2p on v_mfma_f32_16x16x32_f16 (scattn_variant 19).
+//   At equal cycles per FLOP the chip holds a ~13 % higher clock on the 16x16x32 shape than on 32x32x16
+//   (tools/ubench/mfma_shape.hip: 1690 vs 1494 TFLOP/s with operands re-read from LDS), and this kernel is
+//   clock-limited.  Lane l = (g = l >> 4, c = l & 15).  A wave still owns 32 queries (blocks ib = 0, 1 of 16) and a
+//   tile is still 32 keys (blocks jb):
+//     S^T block (jb, ib) = K_jb Q_ib^T: A = K rows 16 jb + c, B = Q rows 16 ib + c, both as d = 32 s' + 8 g .. + 7 -
+//       16-byte units of the UNCHANGED fp16x2 K / Q' images, gathered with per-lane addresses (conflict-free);
+//       D: lane (g, c) holds keys 16 jb + 4 g + r of query 16 ib + c.
+//     A lane therefore holds, for each of its two queries, 8 probabilities: exactly one B operand of the K = 32
+//       contraction O^T += V^T P^T, in the key order slot(g, e) -> key 16 (e >> 2) + 4 g + (e & 3).  The V image is
+//       written in that order by k_front_h2<.., VQ> (store_block_vq16), the cached c in the matching element order by
+//       k_compat_build<true>, and the fc_message weights by packing.p16_h2, so accumulators chain into operands with no
+//       data movement here either.
+//     O^T block (db16, ib): lane (g, c) holds features 16 db16 + 4 g + r of query 16 ib + c = one float4 of the P32 image.
+//   Row statistics are per (lane, ib); the row maximum crosses the four lane groups with v_permlane16_swap and
+//   v_permlane32_swap.  Software pipelining, LDS rings, the XCD-aware mapping and the DMA placement are those of k_scattn_h2p.
+// =========================================================================================
+GMF_DEVINL f32x4 mfma_q16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+GMF_DEVINL void mma3q(f32x4& acc, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
+  acc = mfma_q16(al, bh, acc);
+  acc = mfma_q16(ah, bl, acc);
+  acc = mfma_q16(ah, bh, acc);
+}
+GMF_DEVINL float vmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// max / sum over the four lane groups g (lanes 16 apart)
+GMF_DEVINL float xg_max(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float m = vmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return vmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+GMF_DEVINL float xg_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+// OCC: workgroups per CU (1 = one wave per SIMD with the whole 512-register file; 1280 workgroups = 5.0 rounds of 256 CUs).
+// PLACE: LDS-DMA pieces issued 0 = at the tile top (a full tile of lead: needed at one wave per SIMD), 2 = in phase 2.
+// LATEC: the c tile of tile t+1 is loaded in phase 2 of tile t (its registers are dead during phase 1) after an L2
+// touch-prefetch issued one tile earlier (one dword per 64-byte line: the whole 4 KiB tile in one instruction).
+template <int OCC, int PLACE, bool LATEC>
+__global__ void __launch_bounds__(256, OCC)
+k_scattn_h2q(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
+             const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
+             float* __restrict__ out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_dense) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+  float* const ldsK = lds;
+  float* const ldsV = lds + 2 * kStageFloats;
+  constexpr int WAVES = 4;
+  const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int pair, qblock;
+  {
+    const int total = gridDim.x, L = blockIdx.x;
+    const int chunk = total >> 3, rem = total & 7, xcd = L & 7, kth = L >> 3;
+    const int start = (xcd < rem) ? xcd * (chunk + 1) : rem * (chunk + 1) + (xcd - rem) * chunk;
+    const int logical = start + kth;
+    pair = logical / wgs_per_pair;
+    qblock = logical - pair * wgs_per_pair;
+  }
+  const int tile_raw = qblock * WAVES + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t pbase = (size_t)pair * tiles;
+  const size_t toff = (pbase + tile) * (32 * C);
+  // unit of row (16 b + c16), d = 32 s' + 8 g .. +7 inside an fp16x2 tile image: (plane*8 + 2 s' + (g >> 1))*64 + 32 (g & 1) + 16 b + c16
+  const int goff = (g >> 1) * 64 + 32 * (g & 1) + c16;
+
+  f16x8 qh[2][4], ql[2][4];
+  {
+    const f16x8* qp = reinterpret_cast<const f16x8*>(q_img + (pbase + tile) * (size_t)kStageFloats) + goff;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        qh[ib][sp] = qp[(0 * 8 + 2 * sp) * 64 + 16 * ib];
+        ql[ib][sp] = qp[(1 * 8 + 2 * sp) * 64 + 16 * ib];
+      }
+  }
+  const f32x4* const crow = reinterpret_cast<const f32x4*>(c_dense) + ((pbase + tile) * (size_t)tiles) * 256 + lane;
+  float c[16];                    // c[8 ib + 4 jb + r]
+  auto fetch_c = [&](int t) {
+    const f32x4* ct = crow + (size_t)t * 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = __builtin_nontemporal_load(ct + q * 64);
+      c[4 * q + 0] = v[0]; c[4 * q + 1] = v[1]; c[4 * q + 2] = v[2]; c[4 * q + 3] = v[3];
+    }
+  };
+  auto touch_c = [&](int t) {       // brings tile t of this wave's c rows into L2: lane l reads one dword of 64-byte line l
+    unsigned dummy;
+    const float* a = reinterpret_cast<const float*>(crow - lane + (size_t)t * 256) + lane * 16;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(a) : "memory");
+  };
+  const float* gk = k_img + pbase * (size_t)kStageFloats;
+  const float* gv = v_img + pbase * (size_t)kStageFloats;
+  auto issue16k = [&](const float* gsrc, float* l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma_piece_1k(gsrc + (wave + WAVES * q) * 256, l + (wave + WAVES * q) * 256, lane);
+  };
+  auto issueK = [&](int t) { issue16k(gk + (size_t)t * kStageFloats, ldsK + (t & 1) * kStageFloats); };
+  auto issueV = [&](int t) { issue16k(gv + (size_t)t * kStageFloats, ldsV + (t & 1) * kStageFloats); };
+  auto issue_piece = [&](const int t, const int q) {
+    if (q < 4) {
+      if (t + 2 < tiles) dma_piece_1k(gk + (size_t)(t + 2) * kStageFloats + (wave + WAVES * q) * 256,
+                                      ldsK + (t & 1) * kStageFloats + (wave + WAVES * q) * 256, lane);
+    } else {
+      dma_piece_1k(gv + (size_t)(t + 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256,
+                   ldsV + ((t + 1) & 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256, lane);
+    }
+  };
+
+  f32x4 oacc[8][2];
+#pragma unroll
+  for (int db = 0; db < 8; ++db)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) oacc[db][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
+
+  struct STile { f32x4 s[2][2]; };   // [jb][ib]
+  auto zero_s = [&](STile& st) {
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) st.s[jb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  issueK(0);
+  if (tiles > 1) issueK(1);
+  issueV(0);
+  fetch_c(0);
+  if (LATEC && tiles > 1) touch_c(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  STile s_a, s_b;
+  zero_s(s_a);
+  {
+    const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK) + goff;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        const f16x8 kh = lk[(0 * 8 + 2 * sp) * 64 + 16 * jb], kl = lk[(1 * 8 + 2 * sp) * 64 + 16 * jb];
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) mma3q(s_a.s[jb][ib], kh, kl, qh[ib][sp], ql[ib][sp]);
+      }
+  }
+
+  // top of tile t (see k_scattn_h2p): scores first, then the c prefetch; x[8 ib + 4 jb + r]
+  auto tile_top = [&](const int t, const STile& s_cur, float (&x)[16], float (&mx)[2]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[8 * ib + 4 * jb + r] = c[8 * ib + 4 * jb + r] * s_cur.s[jb][ib][r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (PLACE == 0) {
+      if (t + 2 < tiles) issueK(t + 2);
+      if (t + 1 < tiles) issueV(t + 1);
+    }
+    if (LATEC) { if (t + 2 < tiles) touch_c(t + 2); }
+    else if (t + 1 < tiles) fetch_c(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto row_max = [&](const float (&x)[16], float (&mx)[2]) {
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      float m = x[8 * ib];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) m = __builtin_fmaxf(m, x[8 * ib + e]);
+      mx[ib] = xg_max(m);
+    }
+  };
+  auto new_max = [&](const float (&mx)[2], float (&m_off)[2], float (&alpha)[2]) {
+    bool moved = false;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      const float m_new = __builtin_fmaxf(m_run[ib], mx[ib]);
+      moved = moved || (m_new > m_run[ib]);
+      alpha[ib] = __builtin_amdgcn_exp2f(m_run[ib] - m_new);
+      m_run[ib] = m_new;
+      m_off[ib] = m_new - 10.0f;            // P' = 2^10 P
+    }
+    if (__any(moved)) {
+#pragma unroll
+      for (int db = 0; db < 8; ++db)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oacc[db][ib][r] *= alpha[ib];
+    }
+  };
+
+  auto tile_step = [&](const int t, const STile& s_cur, STile& s_next) {
+    float x[16], mx[2], m_off[2], alpha[2], ls[2] = {0.f, 0.f};
+    tile_top(t, s_cur, x, mx);
+    row_max(x, mx);
+    new_max(mx, m_off, alpha);
+    const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV + (t & 1) * kStageFloats) + lane;
+    const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK + ((t + 1) & 1) * kStageFloats) + goff;
+    f16x8 ph[2], pl[2];
+    zero_s(s_next);
+    // ---- phase 1: S_{t+1}, 16 groups of 3 MFMAs (jb, s', ib); exponentials of x[u] and the fp16 splits in the gaps ----
+    {
+      f16x8 kh = lk[0], kl = lk[8 * 64];
+      f16x8 kh_n = kh, kl_n = kl;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int jb = u >> 3, sp = (u >> 1) & 3, ib = u & 1;
+        if (ib == 0 && u < 14) {
+          const int un = u + 2, jbn = un >> 3, spn = (un >> 1) & 3;
+          kh_n = lk[(0 * 8 + 2 * spn) * 64 + 16 * jbn]; kl_n = lk[(1 * 8 + 2 * spn) * 64 + 16 * jbn];
+        }
+        mma3q(s_next.s[jb][ib], kh, kl, qh[ib][sp], ql[ib][sp]);
+        if (ib == 1) { kh = kh_n; kl = kl_n; }
+        {
+          const int ibx = u >> 3;            // x[0..7] belong to query block 0, x[8..15] to block 1
+          x[u] = __builtin_amdgcn_exp2f(x[u] - m_off[ibx]);
+          ls[ibx] += x[u];
+        }
+        if (u >= 2 && (u & 1) == 0) {         // pair (u-2, u-1) is complete
+          const int p = u - 2, ibx = p >> 3, j = p & 7;
+          split2h(x[p], x[p + 1], ph[ibx], pl[ibx], j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- phase 2: O^T += V_t^T P^T, 16 groups of 3 MFMAs (db16, ib); the last split and the refills in the gaps ----
+    {
+      f16x8 vh = lv[0], vl = lv[8 * 64];
+      f16x8 vh_n = vh, vl_n = vl;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int db = u >> 1, ib = u & 1;
+        if (u == 0) split2h(x[14], x[15], ph[1], pl[1], 6);
+        if (LATEC && u == 1) fetch_c(t + 1);
+        if (ib == 0 && db < 7) { vh_n = lv[(0 * 8 + db + 1) * 64]; vl_n = lv[(1 * 8 + db + 1) * 64]; }
+        mma3q(oacc[db][ib], vh, vl, ph[ib], pl[ib]);
+        if (ib == 1) { vh = vh_n; vl = vl_n; }
+        if (PLACE == 2 && u >= 2 && u < 10) issue_piece(t, u - 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) l_part[ib] = fmaf(l_part[ib], alpha[ib], ls[ib]);
+  };
+  auto tile_last = [&](const int t, const STile& s_cur) {
+    float x[16], mx[2], m_off[2], alpha[2], ls[2] = {0.f, 0.f};
+    tile_top(t, s_cur, x, mx);
+    const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV + (t & 1) * kStageFloats) + lane;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int jb = (e >> 2) & 1, r = e & 3;
+      x[e] = (t * 32 + 16 * jb + 4 * g + r < N) ? x[e] : -INFINITY;
+    }
+    row_max(x, mx);
+    new_max(mx, m_off, alpha);
+    f16x8 ph[2], pl[2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[8 * ib + e] = __builtin_amdgcn_exp2f(x[8 * ib + e] - m_off[ib]); ls[ib] += x[8 * ib + e]; }
+      split8h(&x[8 * ib], ph[ib], pl[ib]);
+    }
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {
+      const f16x8 vh = lv[(0 * 8 + db) * 64], vl = lv[(1 * 8 + db) * 64];
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) mma3q(oacc[db][ib], vh, vl, ph[ib], pl[ib]);
+    }
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) l_part[ib] = fmaf(l_part[ib], alpha[ib], ls[ib]);
+  };
+  if (LATEC) {
+    for (int t = 0; t + 1 < tiles; ++t) {
+      tile_step(t, s_a, s_b);
+      s_a = s_b;                 // S_{t+1} finished a phase ago: 16 cheap moves, one loop body for the register allocator
+    }
+    tile_last(tiles - 1, s_a);
+  } else {
+    int t = 0;
+    for (; t + 2 < tiles; t += 2) {
+      tile_step(t, s_a, s_b);
+      tile_step(t + 1, s_b, s_a);
+    }
+    if (t + 1 < tiles) { tile_step(t, s_a, s_b); tile_last(t + 1, s_b); }
+    else tile_last(t, s_a);
+  }
+
+  // ---- epilogue: normalise, fc_message on 16x16x32 MFMAs (weights: packing.p16_h2), add the Fusion-2 branch ----
+  //   B operand of contraction step s for query block ib = the lane's accumulator blocks 2s and 2s+1 (8 values)
+  f16x8 oh[2][4], ol[2][4];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib) {
+    const float inv = 1.0f / xg_sum(l_part[ib]);
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+      float v8[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v8[r] = oacc[2 * sp][ib][r] * inv; v8[4 + r] = oacc[2 * sp + 1][ib][r] * inv; }
+      split8h(v8, oh[ib][sp], ol[ib][sp]);
+    }
+  }
+  __syncthreads();
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5);
+  ss.prime();
+  const f32x4* bias4 = reinterpret_cast<const f32x4*>(vecs) + g;        // + 4 * block for features 16 block + 4 g ..
+  // layer a: 128 -> 64 (4 output blocks of 16; stages: blocks 0,1 | 2,3), ReLU
+  f16x8 m1h[2][2], m1l[2][2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const f16x8* lw = as_h2(ss.acquire());
+    float keep[2][8];
+#pragma unroll
+    for (int mbl = 0; mbl < 2; ++mbl) {
+      const int mb = 2 * st + mbl;
+      const f32x4 b4 = bias4[4 * mb];
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp)
+          mma3q(acc, lw[((mbl * 4 + sp) * 2 + 0) * 64], lw[((mbl * 4 + sp) * 2 + 1) * 64], oh[ib][sp], ol[ib][sp]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) keep[ib][4 * mbl + r] = fmaxf(acc[r] + b4[r], 0.f);
+      }
+    }
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) split8h(keep[ib], m1h[ib][st], m1l[ib][st]);
+  }
+  // layer b: 64 -> 64 (one stage, 4 output blocks), ReLU
+  f16x8 m2h[2][2], m2l[2][2];
+  {
+    const f16x8* lw = as_h2(ss.acquire());
+#pragma unroll
+    for (int sp2 = 0; sp2 < 2; ++sp2) {
+      float keep[2][8];
+#pragma unroll
+      for (int mbl = 0; mbl < 2; ++mbl) {
+        const int mb = 2 * sp2 + mbl;
+        const f32x4 b4 = bias4[16 + 4 * mb];
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int sp = 0; sp < 2; ++sp)
+            mma3q(acc, lw[((mb * 2 + sp) * 2 + 0) * 64], lw[((mb * 2 + sp) * 2 + 1) * 64], m1h[ib][sp], m1l[ib][sp]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) keep[ib][4 * mbl + r] = fmaxf(acc[r] + b4[r], 0.f);
+        }
+      }
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) split8h(keep[ib], m2h[ib][sp2], m2l[ib][sp2]);
+    }
+  }
+  // layer c: 64 -> 128 (8 output blocks; stages: blocks 0..3 | 4..7), + bias + Fusion-2 branch, stored as float4s of the
+  // P32 image: features 16 mb + 4 g .. +3 of row 16 ib + c16 = float4 index (2 mb + (g >> 1))*64 + 32 (g & 1) + 16 ib + c16
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const f16x8* lw = as_h2(ss.acquire());
+#pragma unroll
+    for (int mbl = 0; mbl < 4; ++mbl) {
+      const int mb = 4 * st + mbl;
+      const f32x4 b4 = bias4[32 + 4 * mb];
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+          mma3q(acc, lw[((mbl * 2 + sp) * 2 + 0) * 64], lw[((mbl * 2 + sp) * 2 + 1) * 64], m2h[ib][sp], m2l[ib][sp]);
+        const int f4 = (2 * mb + (g >> 1)) * 64 + 32 * (g & 1) + 16 * ib + c16;
+        const float4 fz = reinterpret_cast<const float4*>(fus + toff)[f4];
+        if (active)
+          reinterpret_cast<float4*>(out + toff)[f4] = make_float4(acc[0] + b4[0] + fz.x, acc[1] + b4[1] + fz.y,
+                                                                  acc[2] + b4[2] + fz.z, acc[3] + b4[3] + fz.w);
+      }
     }
   }
 }
@@ -2133,9 +2528,11 @@ hipError_t launch_front(int mode, const float* in, const float* wst, const float
   return hipGetLastError();
 }
 
-hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s) {
+hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s,
+                               bool q16) {
   const dim3 grid(tiles, (tiles + 4 * kJPerWave - 1) / (4 * kJPerWave), B);
-  hipLaunchKernelGGL(k_compat_build, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, 1.0f / (sigma_d * sigma_d));
+  if (q16) hipLaunchKernelGGL(k_compat_build<true>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, 1.0f / (sigma_d * sigma_d));
+  else hipLaunchKernelGGL(k_compat_build<false>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, 1.0f / (sigma_d * sigma_d));
   return hipGetLastError();
 }
 
@@ -2168,6 +2565,12 @@ hipError_t launch_scattn(const float* q, const float* k, const float* v, const f
         default: hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 5>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr); break;
       }
     }
+    else if (variant == 19 && cc && cc->q16 && cc->dense && cc->tail_wst_q16)
+      {
+      static const int q16_mode = [] { const char* e = getenv("GMF_Q16_MODE"); return e ? atoi(e) : 2; }();
+      if (q16_mode == 1) hipLaunchKernelGGL((k_scattn_h2q<1, 0, false>), grid4, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_q16, vecs, out, N, tiles, wpp, cc->dense);
+      else hipLaunchKernelGGL((k_scattn_h2q<2, 2, true>), grid4, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_q16, vecs, out, N, tiles, wpp, cc->dense);
+      }
     else if (variant >= 16 && cc && g_use_cache && cc->dense) {
       static const bool epi_h2 = [] { const char* e = getenv("GMF_EPI_H2"); return e ? atoi(e) != 0 : true; }();
       if (variant == 17) hipLaunchKernelGGL((k_scattn_h2p<1, false>), grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense);

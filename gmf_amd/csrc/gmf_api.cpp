@@ -113,7 +113,7 @@ int gmf_create(int device, gmf_handle** out) {
 int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
   GMF_REQUIRE(h && name, GMF_ERR_BAD_ARG, "set_tuning: null pointer");
   if (std::strcmp(name, "scattn_variant") == 0) {
-    GMF_REQUIRE(value >= 0 && value <= 18, GMF_ERR_BAD_ARG, "set_tuning: scattn_variant out of range (0..18)");
+    GMF_REQUIRE(value >= 0 && value <= 19, GMF_ERR_BAD_ARG, "set_tuning: scattn_variant out of range (0..19)");
     gmf::set_scattn_variant(value);
     return GMF_OK;
   }
@@ -337,6 +337,8 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   const bool want_cache = (L > 1) && (gmf::get_scattn_variant() == 9 || gmf::get_scattn_variant() >= 16) && gmf::get_use_cache() &&
                           n_tt * 4096 <= ((size_t)96 << 30);
   const size_t cache_need = want_cache ? arena_need(n_tt * 1024, 4) : 0;
+  // 16x16x32 form of the attention kernel: needs the cache, the split-fp16 path and the q16 fc_message images
+  const bool q16 = want_cache && gmf::get_scattn_variant() == 19 && w->tail_wst_q16 && use_h2(w, false);
   const size_t need = 5 * arena_need(act, 4) + 3 * arena_need(act3, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +
                       5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4) + cache_need;
   if (int rc = arena_reserve(h, need)) return rc;
@@ -355,11 +357,12 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   float* x1t = arena_take<float>(h, tok);
   float* imgfeat = arena_take<float>(h, tok);
   float* ctxall = arena_take<float>(h, (size_t)(L > 0 ? L : 1) * tok);
-  gmf::CompatCache cc{nullptr, nullptr};
+  gmf::CompatCache cc{nullptr, nullptr, nullptr};
   float* c_dense = nullptr;
   if (want_cache) {
     c_dense = arena_take<float>(h, n_tt * 1024);
     cc.dense = c_dense;
+    cc.q16 = q16;
   }
 
   // Fusion-1: image_feat = FusionLayer(p_tok (context), queries = q_tok), pe = False (PointDSC.py:137)
@@ -384,7 +387,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
                                       w->ctx_vec_stride, st));
   }
   GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st));
-  if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, st));
+  if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, st, q16));
 
   float* cur = featA;
   float* nxt = featB;
@@ -395,10 +398,11 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   for (int l = 0; l < L; ++l) {
     const float* in = (l == 0) ? corr_pos : cur;
     if (h2) GMF_HIP(gmf::launch_front_h2(l == 0 ? 1 : 0, in, w->front_wst_h2 + (size_t)l * w->front_wst_stride,
-                                         w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
+                                         w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st, q16));
     else GMF_HIP(gmf::launch_front(l == 0 ? 1 : 0, in, w->front_wst + (size_t)l * w->front_wst_stride,
                                    w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
     cc.tail_wst_h2 = w->tail_wst_h2 ? w->tail_wst_h2 + (size_t)l * w->tail_wst_stride : nullptr;
+    cc.tail_wst_q16 = w->tail_wst_q16 ? w->tail_wst_q16 + (size_t)l * w->tail_wst_stride : nullptr;
     if (int rc = run_block_tail(h, w, l, f, q, k, v, pts8, ctxall + (size_t)l * tok, x1, x2, nxt, B, N, T, st, nullptr,
                                 want_cache ? &cc : nullptr)) return rc;
     float* t = cur; cur = nxt; nxt = t;

@@ -8,10 +8,13 @@ namespace gmf {
 struct CompatCache {
   const float* dense;
   const float* tail_wst_h2;   // this layer's fc_message weights as split-fp16 images, or nullptr (fp32-MFMA epilogue)
+  const float* tail_wst_q16;  // ... as 16x16x32 A-operand images (k_scattn_h2q)
+  bool q16;                   // scattn_variant 19 is active: the V images and `dense` are in k_scattn_h2q's element order
 };
 void set_use_cache(bool v);
 bool get_use_cache();
-hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s);
+hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s,
+                               bool q16 = false);
 void set_scattn_variant(int v);
 void set_force_fp32_qkv(bool v);
 void set_h2_dbuf(bool v);
@@ -37,7 +40,7 @@ hipError_t launch_fusion_attn_w(bool pe, const float* x, const float* ctx_img, c
                                 float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
 hipError_t launch_fusion_ff_w(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
 hipError_t launch_front_h2(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
-                           float* v, int B, int N, int tiles, hipStream_t s);
+                           float* v, int B, int N, int tiles, hipStream_t s, bool v_q16 = false);
 hipError_t launch_ctx_prep_h2(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
                               int ttiles, int sets, int wst_stride, int vec_stride, hipStream_t s);
 hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,

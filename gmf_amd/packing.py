@@ -85,6 +85,27 @@ def p32_h2(W: torch.Tensor) -> torch.Tensor:
     return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
 
 
+def p16_h2(W: torch.Tensor) -> torch.Tensor:
+    """[M, K] fp32 (M % 16 == 0, K % 32 == 0) -> flat split-fp16 image for v_mfma_f32_16x16x32_f16 A-operands.
+
+    16-byte unit ((mb*S + s)*2 + plane)*64 + lane, lane = 16 g + c: the 8 halfs are W[16 mb + c][32 s + perm(g, e)],
+    perm(g, e) = 16 (e >> 2) + 4 g + (e & 3) - the contraction order in which a lane of the q16 attention kernel holds a
+    pair of 16x16 accumulator blocks (features 4g..4g+3 of blocks 2s and 2s+1), so accumulators chain into the next
+    layer's B operand with no data movement (gmf_amd/csrc/encoder_kernels.hip, k_scattn_h2q)."""
+    M, K = W.shape
+    assert M % 16 == 0 and K % 32 == 0, (M, K)
+    dev = W.device
+    s_ = torch.arange(K // 32, device=dev)[:, None, None]
+    g_ = torch.arange(4, device=dev)[None, :, None]
+    e_ = torch.arange(8, device=dev)[None, None, :]
+    idx = 32 * s_ + 16 * (e_ >> 2) + 4 * g_ + (e_ & 3)                       # [S, 4, 8]
+    hi = W.to(torch.float16)
+    lo = (W - hi.float()).to(torch.float16)
+    gth = torch.stack([hi, lo])[:, :, idx]                                    # [2, M, S, 4, 8]
+    gth = gth.reshape(2, M // 16, 16, K // 32, 4, 8).permute(1, 3, 0, 4, 2, 5)   # [mb, S, plane, g, c, 8]
+    return gth.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
+
+
 def pack_ff_b3(sd, prefix: str) -> torch.Tensor:
     """GEGLU feed-forward weights of one FusionLayer (128-wide) as 48 bf16x3 stages of 24 KiB."""
     f = prefix + "cross_attend_blocks.1."
@@ -256,6 +277,7 @@ class PackedEncoder:
                                                              identity_pointcn=standalone_block, img=p32_h2)[0]
                                                   for i in range(num_layers)]).contiguous()
             self.t["tail_wst_h2"] = torch.stack([pack_tail(sd, i, img=p32_h2)[0] for i in range(num_layers)]).contiguous()
+            self.t["tail_wst_q16"] = torch.stack([pack_tail(sd, i, img=p16_h2)[0] for i in range(num_layers)]).contiguous()
         if num_layers > 0:
             self.t["ff_wst_b3"] = torch.stack([pack_ff_b3(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.")
                                                for i in range(num_layers)]).contiguous()
@@ -280,6 +302,6 @@ class PackedEncoder:
         w.ff_wst_b3_stride = 48 * 6144
         w.f1_ff_wst_b3 = self.t["f1_ff_wst_b3"].data_ptr() if "f1_ff_wst_b3" in self.t else None
         for name in ("front_wst_h2", "ctx_wst_h2", "attn_wst_h2", "ff_wst_h2", "f1_ctx_wst_h2", "f1_attn_wst_h2", "f1_ff_wst_h2",
-                     "tail_wst_h2"):
+                     "tail_wst_h2", "tail_wst_q16"):
             setattr(w, name, self.t[name].data_ptr() if name in self.t else None)
         self.struct = w

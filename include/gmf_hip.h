@@ -138,6 +138,9 @@ typedef struct gmf_encoder_weights {
   /* optional split-fp16 image of the fc_message weights (same size and stride as tail_wst): the epilogue of the cached,
    * software-pipelined attention kernel then runs on the f16 MFMA too. */
   const float* tail_wst_h2;
+  /* the same weights as split-fp16 images for v_mfma_f32_16x16x32_f16 A-operands (gmf_amd.packing.p16_h2), used by
+   * the 16x16x32 form of the attention kernel (scattn_variant 19). */
+  const float* tail_wst_q16;
 } gmf_encoder_weights;
 
 /* PointDSC.forward up to the logits (PointDSC.py:216-241) with image TOKENS as input:

@@ -464,3 +464,24 @@ def test_global_registration_edge_cases():
         gmf_amd.GlobalRegistration(_gpu(X), _gpu(Y), weights=_gpu(w), quantization_size=0.0)
     with pytest.raises(NotImplementedError):
         gmf_amd.GlobalRegistration(_gpu(X), _gpu(Y), loss_fn=lambda a, b: 0)
+
+
+# ---- every selectable form of the attention kernel gives the same logits ----------------------------------------------
+@pytest.mark.parametrize("variant,cache", [(0, 0), (3, 0), (9, 0), (9, 1), (16, 1), (18, 1), (19, 1)])
+def test_attention_kernel_variants(golden_dir, model, variant, cache):
+    """fp32 MFMA (0), split-bf16 (3), split-fp16 without / with the compat cache (9), software-pipelined (16, 18 = default)
+    and the 16x16x32 form with its own V / c / weight layouts (19): each within 1e-4 of the reference's golden logits
+    (F4, N = 257: ragged last tile, 9 tiles -> pipelined loop, peeled tail and the padding waves all run)."""
+    from gmf_amd import _lib
+    g = _load(golden_dir, "f4_f10_pointdsc.npz")
+    h = _lib.handle_for(0)
+    try:
+        h.call("gmf_set_tuning", b"scattn_variant", variant)
+        h.call("gmf_set_tuning", b"compat_cache", cache)
+        b = synthetic.synthetic_batch(list(g["pair_seeds_N257"]), N=257, T=196)
+        data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+        logits = model.encode(*[data[k] for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")])[0]
+        assert _maxerr(logits.cpu(), g["logits_N257"]) < 1e-4
+    finally:
+        h.call("gmf_set_tuning", b"scattn_variant", 18)
+        h.call("gmf_set_tuning", b"compat_cache", 1)

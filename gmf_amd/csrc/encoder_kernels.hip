@@ -1303,6 +1303,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   constexpr int WAVES = 4;
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lane_off16 = lane * 16;
   int pair, qblock;
   {                                            // XCD-aware work mapping, as k_scattn_h2
     const int total = gridDim.x, L = blockIdx.x;
@@ -1338,7 +1339,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   const float* gv = v_img + pbase * (size_t)kStageFloats;
   auto issue16k = [&](const float* g, float* l) {      // this wave's 4 of the 16 KiB-pieces of one tile
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + WAVES * q) * 256, l + (wave + WAVES * q) * 256, lane);
+    for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + WAVES * q) * 256, l + (wave + WAVES * q) * 256, lane_off16);
   };
   auto issueK = [&](int t) { issue16k(gk + (size_t)t * kStageFloats, ldsK + (t & 1) * kStageFloats); };
   auto issueV = [&](int t) { issue16k(gv + (size_t)t * kStageFloats, ldsV + (t & 1) * kStageFloats); };
@@ -1384,11 +1385,11 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   // piece q (0..3 of K_{t+2}, 4..7 of V_{t+1}) of this wave's share of the refills
   auto issue_piece = [&](const int t, const int q) {
     if (q < 4) {
-      if (t + 2 < tiles) dma_piece_1k(gk + (size_t)(t + 2) * kStageFloats + (wave + WAVES * q) * 256,
-                                      ldsK + (t & 1) * kStageFloats + (wave + WAVES * q) * 256, lane);
+      if (t + 2 < tiles) dma_piece_1k_s(gk + (size_t)(t + 2) * kStageFloats + (wave + WAVES * q) * 256,
+                                        ldsK + (t & 1) * kStageFloats + (wave + WAVES * q) * 256, lane_off16);
     } else {
-      dma_piece_1k(gv + (size_t)(t + 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256,
-                   ldsV + ((t + 1) & 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256, lane);
+      dma_piece_1k_s(gv + (size_t)(t + 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256,
+                     ldsV + ((t + 1) & 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256, lane_off16);
     }
   };
   auto rescale = [&](const bool moved, const float alpha) {

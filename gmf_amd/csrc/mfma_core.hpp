@@ -111,13 +111,22 @@ GMF_DEVINL f32x16 mfma_h16(f16x8 a, f16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// x - float(hi) for a pair, one v_fma_mix_f32 each (the mix form reads the fp16 half directly: no convert-back, and the
+// difference is exact either way); bit-identical to (x - (float)hi), checked by tools/ubench/fma_mix_split.hip.
+GMF_DEVINL f32x2 resid2h(f16x2 hh, float x0, float x1) {
+  const unsigned hu = __builtin_bit_cast(unsigned, hh);
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hu), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hu), "v"(x1));
+  return f32x2{r0, r1};
+}
+
 GMF_DEVINL void split8h(const float* v, f16x8& hi, f16x8& lo) {
 #pragma unroll
   for (int j = 0; j < 8; j += 2) {
     const f32x2 x = {v[j], v[j + 1]};
     const f16x2 hh = __builtin_convertvector(x, f16x2);
-    const f32x2 r1 = x - __builtin_convertvector(hh, f32x2);
-    const f16x2 ll = __builtin_convertvector(r1, f16x2);
+    const f16x2 ll = __builtin_convertvector(resid2h(hh, v[j], v[j + 1]), f16x2);
     hi[j] = hh[0]; hi[j + 1] = hh[1];
     lo[j] = ll[0]; lo[j + 1] = ll[1];
   }
@@ -127,8 +136,7 @@ GMF_DEVINL void split8h(const float* v, f16x8& hi, f16x8& lo) {
 GMF_DEVINL void split2h(float x0, float x1, f16x8& hi, f16x8& lo, int j) {
   const f32x2 x = {x0, x1};
   const f16x2 hh = __builtin_convertvector(x, f16x2);
-  const f32x2 r1 = x - __builtin_convertvector(hh, f32x2);
-  const f16x2 ll = __builtin_convertvector(r1, f16x2);
+  const f16x2 ll = __builtin_convertvector(resid2h(hh, x0, x1), f16x2);
   hi[j] = hh[0]; hi[j + 1] = hh[1];
   lo[j] = ll[0]; lo[j + 1] = ll[1];
 }
@@ -261,6 +269,17 @@ GMF_DEVINL void dma_piece_1k(const float* __restrict__ gsrc_piece, float* lds_pi
   __builtin_amdgcn_global_load_lds(
       (const void __attribute__((address_space(1)))*)(gsrc_piece + lane * 4),
       (void __attribute__((address_space(3)))*)(lds_piece), 16, 0, 0);
+}
+
+// The same piece with a wave-uniform source base in SGPRs and the lane offset (lane * 16 bytes) as the 32-bit VGPR offset:
+// no 64-bit vector address arithmetic per piece.  M0 (the LDS destination base) is saved and restored inside the statement
+// because the compiler tracks its own M0 values around its LDS-DMA builtins.  hipcc does not count this load in its
+// s_waitcnt bookkeeping: callers wait with their own vmcnt before a barrier, as for the builtin form.
+GMF_DEVINL void dma_piece_1k_s(const float* __restrict__ gsrc_piece_uniform, float* lds_piece, unsigned lane_off16) {
+  unsigned keep;
+  const unsigned lds_dst = (unsigned)(uintptr_t)(void __attribute__((address_space(3)))*)(lds_piece);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_off16), "s"(gsrc_piece_uniform), "s"(lds_dst) : "memory");
 }
 
 // Copy `n_pieces` KiB from gsrc to lds_dst, pieces distributed round-robin over the waves.

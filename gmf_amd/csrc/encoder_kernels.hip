@@ -1233,9 +1233,13 @@ k_scattn_b3p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
 constexpr int kJPerWave = 8;
 
 // Q16: element order of k_scattn_h2q - lane (g, c), float4 q4 = 2 ib + jb holds (query 32 I + 16 ib + c, keys 32 J + 16 jb + 4 g + r).
+// Default order: c is exactly symmetric (the squared differences do not see the sign of s_i - s_j), so only tiles J >= I are
+// evaluated; a tile with J > I is also written as tile (J, I) after a 32 x 32 transpose through a per-wave LDS buffer
+// (16 ds_write_b32 + 16 ds_read_b32 instead of 16 x ~26 vector instructions with two correctly rounded square roots).
 template <bool Q16>
 __global__ void __launch_bounds__(256)
 k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int N, int tiles, float inv_sig2) {
+  __shared__ float tr[Q16 ? 1 : 4 * 32 * 33];
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31, g = lane >> 4, c16 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.z, I = blockIdx.x;
@@ -1248,9 +1252,11 @@ k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int 
     const float4 a = pp[0], b = pp[1];
     si[ib][0] = a.x; si[ib][1] = a.y; si[ib][2] = a.z; ti[ib][0] = b.x; ti[ib][1] = b.y; ti[ib][2] = b.z;
   }
-  float4* crow = reinterpret_cast<float4*>(c_dense) + ((pbase + I) * (size_t)tiles) * 256 + lane;
+  float4* const cbase = reinterpret_cast<float4*>(c_dense) + pbase * (size_t)tiles * 256 + lane;
+  float4* const crow = cbase + (size_t)I * tiles * 256;
+  float* const mt = tr + (Q16 ? 0 : wave * 32 * 33);
   const int j0 = (blockIdx.y * 4 + wave) * kJPerWave;
-  for (int J = j0; J < min(tiles, j0 + kJPerWave); ++J) {
+  for (int J = Q16 ? j0 : max(j0, I); J < min(tiles, j0 + kJPerWave); ++J) {
     const float4* lp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)J * 32) * 8) + (Q16 ? 0 : 8 * h);
     float c[16];
 #pragma unroll
@@ -1261,6 +1267,19 @@ k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int 
     float4* ct = crow + (size_t)J * 256;
 #pragma unroll
     for (int q = 0; q < 4; ++q) ct[q * 64] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+    if (!Q16 && J > I) {
+      // tile (J, I): lane (h, i), register r = element (row i of J, column jl of I) = c(I: jl, J: i) = M[jl][i]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt[i * 33 + 8 * (r >> 2) + 4 * h + (r & 3)] = c[r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float d[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d[r] = mt[(8 * (r >> 2) + 4 * h + (r & 3)) * 33 + i];
+      float4* dt = cbase + ((size_t)J * tiles + I) * 256;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dt[q * 64] = make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   }
 }
 

@@ -8,7 +8,7 @@
 //   k_ctx_prep_w     perceiver_io.py:126-128,46-49,89-91    LCPE(content) + LayerNorm_ctx + to_kv (128 -> 128 | 128)
 //   k_fusion_attn_w  perceiver_io.py:121-123,44,87-101,208  LCPE(q) + LayerNorm + to_q + softmax(QK^T)V + to_out + residual
 //   k_fusion_ff_w    perceiver_io.py:54-69,211              LayerNorm + Linear(256,2048) + GEGLU + Linear(1024,256) + residual
-#include "mfma_core.hpp"
+#include "enc_common.hpp"
 #include "launchers.hpp"
 
 namespace gmf {
@@ -323,6 +323,94 @@ k_fusion_ff_w(const float* __restrict__ x1, const float* __restrict__ wst, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_fusion_ff_w_h2: the 256-wide GEGLU feed-forward on the f16 MFMA with split-fp16 operands (5.3x fewer matrix cycles than
+// k_fusion_ff_w; arithmetic notes in mfma_core.hpp).  Weight images from packing.p32_h2, same blob size and stage count:
+//   for c in 0..31: W1a_c hi plane | W1a_c lo plane | W1g_c hi | W1g_c lo | W2_c out-blocks 0-3 | W2_c out-blocks 4-7
+//   (a 32 x 256 block is [plane][16 k-steps][lane][8 halfs]: the hi-plane stage carries the products ah*xl and ah*xh, the
+//   lo-plane stage al*xh).  Single-range GELU (enc_common.hpp).  One wave per SIMD: x (128 VGPRs as two fp16 planes) and
+//   the eight output accumulators (128) stay in registers.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 1)
+k_fusion_ff_w_h2(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
+                 float* __restrict__ x2_out, int tiles) {
+  using namespace wide;
+  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWaves + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * LAT);
+
+  StageRing<4> ss;
+  ss.init(lds, wave, lane, wst, 6 * (FFHW / 32));
+  ss.prime();
+  FragH2<16> nx;
+  {
+    float x[LATF], xn[LATF];
+    load_frag_p32<LATF>(x, x1 + toff, lane);
+    layernorm_frag<LATF>(xn, x, vecs, vecs + LAT, h);
+    nx.set(xn);
+  }
+  f32x16 y[8];
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) y[mb] = zero16();
+  const float* b1a = vecs + 2 * LAT;
+  const float* b1g = vecs + 2 * LAT + FFHW;
+
+  // acc (preloaded with the bias) += W(32 x 256) x^T from the two plane stages of one weight block
+  auto w1_block = [&](f32x16& acc) {
+    const f16x8* lw = as_h2(ss.acquire());            // hi plane, 16 k-steps
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { const f16x8 wh = lw[s * 64]; acc = mfma_h16(wh, nx.l[s], acc); acc = mfma_h16(wh, nx.h[s], acc); }
+    lw = as_h2(ss.acquire());                         // lo plane
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = mfma_h16(lw[s * 64], nx.h[s], acc);
+  };
+  for (int c = 0; c < FFHW / 32; ++c) {
+    float ga[16];
+    {
+      float b[16];
+      load_vec16(b, b1a, c, h);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = b[r];
+      w1_block(acc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ga[r] = acc[r];
+    }
+    {
+      float b[16];
+      load_vec16(b, b1g, c, h);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = b[r];
+      w1_block(acc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ga[r] *= gelu_erf_1r(acc[r]);
+    }
+    FragH2<2> gx;
+    gx.set(ga);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const f16x8* lw = as_h2(ss.acquire());
+#pragma unroll
+      for (int m4 = 0; m4 < 4; ++m4) mma_wx_h2<2>(y[4 * half + m4], lw + m4 * (2 * 2 * 64), gx);
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    float b[16], xr[16], t[16];
+    load_vec16(b, vecs + 2 * LAT + 2 * FFHW, mb, h);
+    load_blk<LAT>(xr, x1 + toff, mb, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = y[mb][r] + b[r] + xr[r];
+    if (active) store_blk<LAT>(x2_out + toff, mb, t, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 static inline dim3 wgrid(int tiles, int B) { return dim3((tiles + kWaves - 1) / kWaves, B); }
 
 hipError_t launch_ctx_prep_w(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
@@ -336,6 +424,11 @@ hipError_t launch_fusion_attn_w(bool pe, const float* x, const float* ctx_img, c
                                 float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s) {
   if (pe) hipLaunchKernelGGL(k_fusion_attn_w<true>, wgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
   else hipLaunchKernelGGL(k_fusion_attn_w<false>, wgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const float* vecs, float* x2, int B, int tiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_fusion_ff_w_h2, wgrid(tiles, B), dim3(256), 0, s, x1, wst_h2, vecs, x2, tiles);
   return hipGetLastError();
 }
 

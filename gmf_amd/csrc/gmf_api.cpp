@@ -457,7 +457,7 @@ int gmf_fusion_layer_forward(gmf_handle* h, int pe, int latent_dim, int d_head, 
                              const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec,
                              const float* data, const float* queries, long long q_sb, long long q_sr, long long q_sk,
                              float* out, long long o_sb, long long o_sr, long long o_sk, int B, int N, int T,
-                             gmf_stream_t stream) {
+                             gmf_stream_t stream, const float* ff_wst_h2) {
   GMF_REQUIRE(h && ctx_wst && ctx_vec && attn_wst && attn_vec && ff_wst && ff_vec && data && queries && out,
               GMF_ERR_BAD_ARG, "fusion_layer_forward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "fusion_layer_forward: empty input");
@@ -481,11 +481,13 @@ int gmf_fusion_layer_forward(gmf_handle* h, int pe, int latent_dim, int d_head, 
   if (narrow) {
     GMF_HIP(gmf::launch_ctx_prep(pe != 0, cimg, ctx_wst, ctx_vec, ctx, B, T, tt, 1, 0, 0, st));
     GMF_HIP(gmf::launch_fusion_attn(pe != 0, xin, ctx, attn_wst, attn_vec, x1, B, N, tiles, T, tt, st));
-    GMF_HIP(gmf::launch_fusion_ff(x1, ff_wst, ff_vec, x2, B, tiles, st));
+    if (ff_wst_h2) GMF_HIP(gmf::launch_fusion_ff_h2(x1, ff_wst_h2, ff_vec, x2, B, tiles, st));
+    else GMF_HIP(gmf::launch_fusion_ff(x1, ff_wst, ff_vec, x2, B, tiles, st));
   } else {
     GMF_HIP(gmf::launch_ctx_prep_w(pe != 0, cimg, ctx_wst, ctx_vec, ctx, B, T, tt, st));
     GMF_HIP(gmf::launch_fusion_attn_w(pe != 0, xin, ctx, attn_wst, attn_vec, x1, B, N, tiles, T, tt, st));
-    GMF_HIP(gmf::launch_fusion_ff_w(x1, ff_wst, ff_vec, x2, B, tiles, st));
+    if (ff_wst_h2) GMF_HIP(gmf::launch_fusion_ff_w_h2(x1, ff_wst_h2, ff_vec, x2, B, tiles, st));
+    else GMF_HIP(gmf::launch_fusion_ff_w(x1, ff_wst, ff_vec, x2, B, tiles, st));
   }
   GMF_HIP(gmf::launch_unpack_p32(x2, out, B, N, latent_dim, o_sb, o_sr, o_sk, st));
   return GMF_OK;

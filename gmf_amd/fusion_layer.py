@@ -74,12 +74,14 @@ class FusionLayer(nn.Module):
         self.layers = nn.ModuleList([])
         self._packed = None
         self._packed_version = None
+        self.split_fp16_ff = True      # feed-forward on the f16 MFMA with split-fp16 operands (False: fp32 MFMA, for A/B runs)
 
     def _blobs(self, device):
         ver = (params_version(self), str(device))
         if self._packed is None or self._packed_version != ver:
             sd = {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()}
             packed = packing.pack_fusion(sd, "", self.pe)
+            packed["ff_wst_h2"] = packing.pack_fusion(sd, "", self.pe, img=packing.p32_h2)["ff_wst"]
             self._packed = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in packed.items()}
             self._packed_version = ver
         return self._packed
@@ -103,5 +105,6 @@ class FusionLayer(nn.Module):
                blobs["ctx_wst"].data_ptr(), blobs["ctx_vec"].data_ptr(), blobs["attn_wst"].data_ptr(),
                blobs["attn_vec"].data_ptr(), blobs["ff_wst"].data_ptr(), blobs["ff_vec"].data_ptr(),
                data.data_ptr(), x.data_ptr(), x.stride(0), x.stride(1), x.stride(2),
-               out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), B, N, T, st)
+               out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), B, N, T, st,
+               blobs["ff_wst_h2"].data_ptr() if self.split_fp16_ff else None)
         return out

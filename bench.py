@@ -12,7 +12,8 @@ scaling: pairs are independent, each rank owns its own 32 pairs, and the only ex
 all-gather of the per-pair logits and poses per step (inside the timed region).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     - the dominant kernel (k_scattn) against the fp32-MFMA peak, timed in situ with HIP events
+  roofline     - the dominant kernel (the spatial-consistency attention) against the f16 MFMA peak / 3 partial products,
+                 timed in situ with HIP events on the stream it is launched on
   cpu_baseline - the CPU oracle (a port of the reference's PyTorch CPU path) timed on this host's cores
 """
 from __future__ import annotations

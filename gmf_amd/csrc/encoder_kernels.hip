@@ -1375,7 +1375,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   f32x16 s_a = zero16(), s_b;
-  {
+  if (active) {
     const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK) + lane;
 #pragma unroll
     for (int s = 0; s < 8; ++s) mma3(s_a, lk[(0 * 8 + s) * 64], lk[(1 * 8 + s) * 64], qh[s], ql[s]);
@@ -1529,7 +1529,21 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
     }
     l_half = fmaf(l_half, alpha, ls);
   };
-  {
+  if (!active) {
+    // padding wave of a pair's last workgroup (tiles is rarely a multiple of 4): it owns no queries, but a quarter of
+    // every K/V stage and a seat at every barrier - one barrier per tile, the refills of tile t issued during tile t
+    for (int t = 0; t < tiles; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t + 1 < tiles) {
+        if (PLACE == 0) { if (t + 2 < tiles) issueK(t + 2); issueV(t + 1); }
+        else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) issue_piece(t, q);
+        }
+      }
+    }
+  } else {
     int t = 0;
     for (; t + 2 < tiles; t += 2) {          // explicit ping-pong: no accumulator copies at the loop back-edge
       tile_step(t, s_a, s_b);
@@ -1555,11 +1569,12 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   if (EPI_H2) {
     // stages (fp16x2 images, same sizes as the fp32 ones): Wa block 0 | Wa block 1 | Wb (2 blocks) | Wc 0,1 | Wc 2,3
     FragH2<8> ox;
-    ox.set(o);
     FragH2<4> m1x, m2x;
+    if (active) ox.set(o);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
       const f16x8* lw = as_h2(ss.acquire());
+      if (!active) continue;
       f32x16 acc = zero16();
       mma_wx_h2<8>(acc, lw, ox);
       float b[16], t1[16];
@@ -1572,6 +1587,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
       const f16x8* lw = as_h2(ss.acquire());
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
+        if (!active) continue;
         f32x16 acc = zero16();
         mma_wx_h2<4>(acc, lw + mb * (2 * 4 * 64), m1x);
         float b[16], t2[16];
@@ -1586,6 +1602,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
       const f16x8* lw = as_h2(ss.acquire());
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
+        if (!active) continue;
         const int mb = 2 * st + hb;
         f32x16 acc = zero16();
         mma_wx_h2<4>(acc, lw + hb * (2 * 4 * 64), m2x);

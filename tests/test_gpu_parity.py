@@ -485,3 +485,16 @@ def test_attention_kernel_variants(golden_dir, model, variant, cache):
     finally:
         h.call("gmf_set_tuning", b"scattn_variant", 18)
         h.call("gmf_set_tuning", b"compat_cache", 1)
+
+
+@pytest.mark.parametrize("N", [48, 96, 129, 160])
+def test_ragged_tile_counts(model, sd_full, N):
+    """Tile counts 2, 3, 5 (N > k + 1 = 41 as the reference's knn requires; all four residues mod 4 of the attention workgroup's wave count together with the other tests):
+    1, 2 or 3 padding waves in a pair's last workgroup, an odd and an even number of pipelined tiles, a ragged last tile."""
+    b = synthetic.synthetic_batch([300 + N, 301 + N], N=N, T=40)
+    ref = O.pointdsc_forward(sd_full, b, testing=True)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    res = model(data)
+    assert _maxerr(model.last_logits.cpu(), ref["logits"]) < 1e-4
+    assert _maxerr(res["final_trans"].cpu(), ref["final_trans"]) < 1e-3

@@ -85,7 +85,7 @@ SIGNATURES = {
     "gmf_post_refinement": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp]),
     "gmf_weighted_procrustes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_float, _vp, _vp, _vp]),
     "gmf_global_registration": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
-                                          C.c_double, _vp, _vp, _vp, _vp]),
+                                          C.c_double, _vp, _vp, _vp, C.c_int, _vp]),
 }
 
 _lib = None

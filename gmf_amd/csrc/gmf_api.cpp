@@ -631,14 +631,15 @@ int gmf_weighted_procrustes(gmf_handle* h, const float* X, const float* Y, const
 
 int gmf_global_registration(gmf_handle* h, const float* X, const float* Y, const float* w, const int* offsets, int B,
                             float eps, float quantization_size, int max_iter, int max_break_count,
-                            double break_threshold_ratio, float* R, float* t, float* stats, gmf_stream_t stream) {
+                            double break_threshold_ratio, float* R, float* t, float* stats, int max_points,
+                            gmf_stream_t stream) {
   GMF_REQUIRE(h && X && Y && offsets && R && t && stats, GMF_ERR_BAD_ARG, "global_registration: null pointer");
   GMF_REQUIRE(B > 0, GMF_ERR_UNSUPPORTED_SHAPE, "global_registration: empty batch");
   GMF_REQUIRE(quantization_size > 0.f && max_iter >= 0 && max_break_count >= 1, GMF_ERR_BAD_ARG,
               "global_registration: quantization_size must be > 0, max_iter >= 0, max_break_count >= 1");
   SetDevice sd(h);
   GMF_HIP(gmf::launch_global_registration(X, Y, w, offsets, B, eps, quantization_size, max_iter, max_break_count,
-                                          break_threshold_ratio, R, t, stats, S(stream)));
+                                          break_threshold_ratio, R, t, stats, max_points > 0 ? max_points : (1 << 30), S(stream)));
   return GMF_OK;
 }
 

@@ -26,6 +26,6 @@ hipError_t launch_weighted_procrustes(const float* X, const float* Y, const floa
                                       float* R, float* t, hipStream_t s);
 hipError_t launch_global_registration(const float* X, const float* Y, const float* w, const int* offsets, int B, float eps,
                                       float qsize, int max_iter, int max_break, double ratio, float* R, float* t,
-                                      float* stats, hipStream_t s);
+                                      float* stats, int max_n, hipStream_t s);
 
 }  // namespace gmf

@@ -147,6 +147,36 @@ GMF_DEVINL void block_sum(double (&v)[NV], double* sh /* >= NV*16 doubles */) {
   }
 }
 
+// block_sum for the inner loop of k_global_registration: after the wave sums, lanes 0..NV-1 of wave 0 add the per-wave
+// partials (NV parallel chains of nw LDS reads) and every thread then reads the NV totals - block_sum has every thread
+// add all nw x NV partials itself (208 LDS reads per thread for 13 values and 16 waves).
+template <int NV>
+GMF_DEVINL void block_sum_tree(double (&v)[NV], double* sh /* >= NV*17 doubles */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  // butterfly over the wave with all NV exchanges of a step in flight together (NV independent ds_bpermute pairs, one wait)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double t[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) t[k] = __shfl_xor(v[k], o, 64);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] += t[k];
+  }
+  __syncthreads();
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sh[k * 16 + wave] = v[k];
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0;
+    for (int w = 0; w < nw; ++w) s += sh[threadIdx.x * 16 + w];
+    sh[NV * 16 + threadIdx.x] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = sh[NV * 16 + k];
+}
+
 // ---------------------------------------------------------------------------------------
 // NMS keys: key_i = score_i * [ for all j: score_i >= score_j  or  ||src_i - src_j|| >= R ]
 // grid (ceil(N/256), B)
@@ -916,7 +946,7 @@ __global__ void __launch_bounds__(1024)
 k_global_registration(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ w,
                       const int* __restrict__ offsets, float eps, float qsize, int max_iter, int max_break, double ratio,
                       float* __restrict__ Rout, float* __restrict__ tout, float* __restrict__ stats) {
-  __shared__ double sh[13 * 16];
+  __shared__ double sh[13 * 17];
   __shared__ float init_rt[12];
   const int pair = blockIdx.x;
   const int o0 = offsets[pair], n = offsets[pair + 1] - o0;
@@ -964,19 +994,30 @@ k_global_registration(const float* __restrict__ X, const float* __restrict__ Y, 
   float tr[3] = {init_rt[9], init_rt[10], init_rt[11]};
   float m1[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, m2[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
+  // The first kGrPts strided points of every thread stay in registers for the whole optimisation (N <= 16 x blockDim:
+  // all of them); only the remainder is re-read from L2 each step.
+  constexpr int kGrPts = 16;
+  float rx[kGrPts][3], ry[kGrPts][3], rw[kGrPts];
+#pragma unroll
+  for (int q = 0; q < kGrPts; ++q) {
+    const int j = threadIdx.x + q * blockDim.x;
+    const bool in = j < n;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { rx[q][c] = in ? x[3 * j + c] : 0.f; ry[q][c] = in ? y[3 * j + c] : 0.f; }
+    rw[q] = in ? (ww ? ww[j] : 1.0f) : 0.f;      // weight 0: a padded slot adds nothing to any sum
+  }
   float Rf[9], aux[10];
   // loss sum and (optionally) the gradient sums for the current parameters
   auto evaluate = [&](bool grad, double (&red)[13]) {
     rot_from_6d(a, Rf, aux);
 #pragma unroll
     for (int e = 0; e < 13; ++e) red[e] = 0.0;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
-      const float px = x[3 * j], py = x[3 * j + 1], pz = x[3 * j + 2];
-      const float wj = ww ? ww[j] : 1.0f;
+    auto point = [&](const float px, const float py, const float pz, const float qx, const float qy, const float qz, const float wj) {
+      const float yv[3] = {qx, qy, qz};
       float d[3];
 #pragma unroll
       for (int r = 0; r < 3; ++r)
-        d[r] = (((px * Rf[3 * r] + py * Rf[3 * r + 1]) + pz * Rf[3 * r + 2]) + tr[r] - y[3 * j + r]) / qsize;
+        d[r] = (((px * Rf[3 * r] + py * Rf[3 * r + 1]) + pz * Rf[3 * r + 2]) + tr[r] - yv[r]) / qsize;
       const float sq = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
       const bool small = sq < 1.0f;
       const float rt = sqrtf(sq + eps);
@@ -993,9 +1034,13 @@ k_global_registration(const float* __restrict__ X, const float* __restrict__ Y, 
           red[10 + r] += g;
         }
       }
-    }
+    };
+#pragma unroll
+    for (int q = 0; q < kGrPts; ++q) point(rx[q][0], rx[q][1], rx[q][2], ry[q][0], ry[q][1], ry[q][2], rw[q]);
+    for (int j = threadIdx.x + kGrPts * blockDim.x; j < n; j += blockDim.x)
+      point(x[3 * j], x[3 * j + 1], x[3 * j + 2], y[3 * j], y[3 * j + 1], y[3 * j + 2], ww ? ww[j] : 1.0f);
     __syncthreads();
-    block_sum<13>(red, sh);
+    block_sum_tree<13>(red, sh);
   };
 
   double red[13];
@@ -1171,8 +1216,10 @@ hipError_t launch_weighted_procrustes(const float* X, const float* Y, const floa
 
 hipError_t launch_global_registration(const float* X, const float* Y, const float* w, const int* offsets, int B, float eps,
                                       float qsize, int max_iter, int max_break, double ratio, float* R, float* t,
-                                      float* stats, hipStream_t s) {
-  hipLaunchKernelGGL(k_global_registration, dim3(B), dim3(1024), 0, s, X, Y, w, offsets, eps, qsize, max_iter, max_break, ratio,
+                                      float* stats, int max_n, hipStream_t s) {
+  // 16 register-resident points per thread cover N <= 16 x threads; fewer waves make the per-step reduction cheaper
+  const int threads = max_n <= 4096 ? 256 : max_n <= 8192 ? 512 : 1024;
+  hipLaunchKernelGGL(k_global_registration, dim3(B), dim3(threads), 0, s, X, Y, w, offsets, eps, qsize, max_iter, max_break, ratio,
                      R, t, stats);
   return hipGetLastError();
 }

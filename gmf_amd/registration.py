@@ -59,6 +59,7 @@ def global_registration_batched(points, trans_points, weights, offsets: Sequence
     B = off.numel() - 1
     if B < 1 or int(off[0]) != 0 or int(off[-1]) != X.shape[0] or bool((off[1:] <= off[:-1]).any()):
         raise RuntimeError("gmf_amd.GlobalRegistration: offsets must be increasing, start at 0 and end at N")
+    max_points = int((off[1:] - off[:-1]).max())
     off = off.to(X.device)
     R = torch.empty((B, 3, 3), device=X.device, dtype=torch.float32)
     t = torch.empty((B, 3), device=X.device, dtype=torch.float32)
@@ -66,7 +67,7 @@ def global_registration_batched(points, trans_points, weights, offsets: Sequence
     h, st = handle_and_stream(X)
     h.call("gmf_global_registration", X.data_ptr(), Y.data_ptr(), None if w is None else w.data_ptr(), off.data_ptr(), B,
            float(eps), float(quantization_size), int(max_iter), int(max_break_count), float(break_threshold_ratio),
-           R.data_ptr(), t.data_ptr(), stats.data_ptr(), st)
+           R.data_ptr(), t.data_ptr(), stats.data_ptr(), max_points, st)
     return R, t, stats
 
 

@@ -236,10 +236,13 @@ int gmf_weighted_procrustes(gmf_handle* h, const float* X, const float* Y, const
  * caller core/deep_global_registration.py:334-340): weighted-Procrustes initialisation + robust Adam refinement of a 6-D
  * rotation and a translation, batched over B ragged pairs like gmf_weighted_procrustes (offsets [B+1] device int32;
  * X,Y [sum N,3]; w [sum N] or NULL for the unweighted form).  eps = the loss's eps (float32 machine epsilon in the
- * reference).  R [B,9], t [B,3], stats [B,3] = {iterations, loss, break_count}.  One persistent kernel, no host sync. */
+ * reference).  R [B,9], t [B,3], stats [B,3] = {iterations, loss, break_count}.  max_points: the largest per-pair point
+ * count if the host knows it (sizes the workgroup: 16 register-resident points per thread), 0 otherwise.  One persistent
+ * kernel, no host sync. */
 int gmf_global_registration(gmf_handle* h, const float* X, const float* Y, const float* w, const int* offsets, int B,
                             float eps, float quantization_size, int max_iter, int max_break_count,
-                            double break_threshold_ratio, float* R, float* t, float* stats, gmf_stream_t stream);
+                            double break_threshold_ratio, float* R, float* t, float* stats, int max_points,
+                            gmf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -326,7 +326,8 @@ def test_dgr_config5_batched_procrustes():
 
 def test_forward_from_raw_images(model):
     """The reference's own input dict: p_image / q_image [B,3,120,160] through the ResNet-34 -> layer2 encoder
-    (PyTorch-ROCm convolutions), then the HIP path; tokens fed directly must give the same logits."""
+    (PyTorch-ROCm convolutions, both images of a pair in one batch), then the HIP path; tokens fed directly give the same
+    logits up to MIOpen's choice of convolution algorithm per batch size."""
     b = synthetic.synthetic_batch([91], N=200, T=300)
     g = torch.Generator().manual_seed(5)
     p_img, q_img = torch.rand(1, 3, 120, 160, generator=g), torch.rand(1, 3, 120, 160, generator=g)
@@ -340,7 +341,7 @@ def test_forward_from_raw_images(model):
     d2 = {k: data[k] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
     d2.update(p_tokens=pt, q_tokens=qt, testing=True)
     model(d2)
-    assert torch.equal(model.last_logits, lg)
+    assert _maxerr(model.last_logits.cpu(), lg.cpu()) < 1e-5
     assert res["final_trans"].shape == (1, 4, 4)
 
 

@@ -1,19 +1,14 @@
-"""One small-batch configuration a few times (for rocprofv3 kernel traces): python tools/run_small.py B N"""
-import os
-import sys
-
+"""One small PointDSC.forward (B, N from argv) a few times - for rocprofv3 kernel traces of the latency-bound regime."""
+import os, sys
 import torch
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import gmf_amd                                   # noqa: E402
-from gmf_amd import synthetic                    # noqa: E402
-
-B, N = int(sys.argv[1]), int(sys.argv[2])
+import gmf_amd
+from gmf_amd import synthetic
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 dev = torch.device("cuda:0")
 sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7)
-model = gmf_amd.PointDSC(num_layers=12)
-model.load_state_dict(sd, strict=False)
-model = model.to(dev).eval()
+model = gmf_amd.PointDSC(num_layers=12); model.load_state_dict(sd, strict=False); model = model.to(dev).eval()
 b = synthetic.synthetic_batch(list(range(B)), N=N, T=196)
 data = {k: b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
 data["testing"] = True

@@ -161,7 +161,7 @@ def host_cpu_share() -> int:
 
 def cpu_baseline(sd, batch, gpu_out, N, T, tau):
     """Time the CPU oracle (port of the reference's PyTorch CPU path) on a bounded sample: pair 0 of the same
-    batch, test mode, B=1 as the reference runs it; 1 warm-up + 3 repetitions, median.  Also report parity."""
+    batch, test mode, B=1 as the reference runs it; 1 warm-up + 5 repetitions (~12 s of CPU work), median.  Also report parity."""
     from oracle import gmf_oracle as O
     import statistics
     one = {k: v[:1] for k, v in batch.items()}
@@ -170,13 +170,13 @@ def cpu_baseline(sd, batch, gpu_out, N, T, tau):
     with torch.no_grad():
         ref = O.pointdsc_forward(sd, one, inlier_threshold=tau, nms_radius=tau, testing=True)
         ts = []
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.perf_counter()
             ref = O.pointdsc_forward(sd, one, inlier_threshold=tau, nms_radius=tau, testing=True)
             ts.append(time.perf_counter() - t0)
     med = statistics.median(ts)
     base = {"value": N / med, "unit": "correspondences/s", "cores": cores, "kind": "port",
-            "sample": f"1 pair x {N} correspondences x 128-d, {T} tokens, PointDSC.forward test mode, median of 3 "
+            "sample": f"1 pair x {N} correspondences x 128-d, {T} tokens, PointDSC.forward test mode, median of 5 "
                       f"after 1 warm-up ({med:.2f} s per pair), torch {torch.__version__} CPU fp32"}
     parity = {"max_abs_dlogit": float((gpu_out["logits"][:1].cpu() - ref["logits"]).abs().max()),
               "max_abs_dT": float((gpu_out["final_trans"][:1].cpu() - ref["final_trans"]).abs().max()),

@@ -12,6 +12,7 @@
 // Every kernel runs 4 waves per workgroup, each wave owning one 32-row tile ("rows on lanes",
 // see mfma_core.hpp).  Weights, K/V tiles and context tiles stream L2 -> LDS in 16 KiB stages by
 // LDS-DMA; activations chain from one MFMA's accumulators into the next MFMA's operand registers.
+#include <algorithm>
 #include "enc_common.hpp"
 
 namespace gmf {
@@ -1311,11 +1312,69 @@ GMF_DEVINL float xhalf_max_swap(float v) {
 // PLACE: where a tile's 8 LDS-DMA pieces are issued - 0 = at the top of the tile, 1 = one per unit of phase 1,
 // 2 = one per unit in the bare MFMA gaps of phase 2.
 // EPI_H2: fc_message epilogue on the f16 MFMA with split-fp16 weights (wst = tail_wst_h2) instead of the fp32 MFMA.
-template <int PLACE, bool EPI_H2>
+// fc_message on the f16 MFMA (split-fp16 weights, tail_wst_h2) + bias + Fusion-2 branch for the 32 rows of one wave, given
+// the normalised attention output o (fragment order).  `ss` is primed on the 5 weight stages; every wave of the workgroup
+// calls this (padding waves with active = false keep their seat at the stage barriers).
+GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, StageStream& ss, const float* __restrict__ vecs,
+                                   const float* __restrict__ fus_tile, float* __restrict__ out_tile, const int lane, const int h) {
+    // stages (fp16x2 images, same sizes as the fp32 ones): Wa block 0 | Wa block 1 | Wb (2 blocks) | Wc 0,1 | Wc 2,3
+    FragH2<8> ox;
+    FragH2<4> m1x, m2x;
+    if (active) ox.set(o);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const f16x8* lw = as_h2(ss.acquire());
+      if (!active) continue;
+      f32x16 acc = zero16();
+      mma_wx_h2<8>(acc, lw, ox);
+      float b[16], t1[16];
+      load_vec_block(b, vecs, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t1[r] = fmaxf(acc[r] + b[r], 0.f);
+      m1x.set_block(mb, t1);
+    }
+    {
+      const f16x8* lw = as_h2(ss.acquire());
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        if (!active) continue;
+        f32x16 acc = zero16();
+        mma_wx_h2<4>(acc, lw + mb * (2 * 4 * 64), m1x);
+        float b[16], t2[16];
+        load_vec_block(b, vecs + 64, mb, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t2[r] = fmaxf(acc[r] + b[r], 0.f);
+        m2x.set_block(mb, t2);
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const f16x8* lw = as_h2(ss.acquire());
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        if (!active) continue;
+        const int mb = 2 * st + hb;
+        f32x16 acc = zero16();
+        mma_wx_h2<4>(acc, lw + hb * (2 * 4 * 64), m2x);
+        float b[16], fz[16], tt[16];
+        load_vec_block(b, vecs + 128, mb, h);
+        load_block_p32(fz, fus_tile, mb, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tt[r] = acc[r] + b[r] + fz[r];
+        if (active) store_block_p32(out_tile, mb, tt, lane);
+      }
+    }
+}
+
+// KSPLIT (small grids: B x ceil(tiles/4) workgroups fill a fraction of the 512 slots, e.g. B = 1 - the reference's
+// evaluation mode): the keys of a query block are divided over `ksplits` workgroups, each writes its un-normalised partial
+// O (P32 tile image), row maximum and row sum; k_scattn_merge combines them and runs the epilogue.
+template <int PLACE, bool EPI_H2, bool KSPLIT = false>
 __global__ void __launch_bounds__(256, 2)
 k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
              const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
-             float* __restrict__ out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_dense) {
+             float* __restrict__ out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_dense,
+             int ksplits, float* __restrict__ part_o, float* __restrict__ part_ml) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
   float* const ldsK = lds;
   float* const ldsV = lds + 2 * kStageFloats;
@@ -1323,15 +1382,19 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned lane_off16 = lane * 16;
-  int pair, qblock;
+  int pair, qblock, ks = 0;
   {                                            // XCD-aware work mapping, as k_scattn_h2
     const int total = gridDim.x, L = blockIdx.x;
     const int chunk = total >> 3, rem = total & 7, xcd = L & 7, kth = L >> 3;
     const int start = (xcd < rem) ? xcd * (chunk + 1) : rem * (chunk + 1) + (xcd - rem) * chunk;
-    const int logical = start + kth;
+    int logical = start + kth;
+    if (KSPLIT) { ks = logical % ksplits; logical /= ksplits; }
     pair = logical / wgs_per_pair;
     qblock = logical - pair * wgs_per_pair;
   }
+  // key tiles [t_begin, t_end) of this workgroup
+  const int t_begin = KSPLIT ? (tiles * ks) / ksplits : 0;
+  const int t_end = KSPLIT ? (tiles * (ks + 1)) / ksplits : tiles;
   const int tile_raw = qblock * WAVES + wave;
   const bool active = tile_raw < tiles;
   const int tile = active ? tile_raw : tiles - 1;
@@ -1368,15 +1431,15 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   for (int db = 0; db < 4; ++db) oacc[db] = zero16();
   float m_run = -INFINITY, l_half = 0.f;
 
-  issueK(0);
-  if (tiles > 1) issueK(1);
-  issueV(0);
-  fetch_c(0);
+  issueK(t_begin);
+  if (t_begin + 1 < t_end) issueK(t_begin + 1);
+  issueV(t_begin);
+  fetch_c(t_begin);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   f32x16 s_a = zero16(), s_b;
   if (active) {
-    const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK) + lane;
+    const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK + (t_begin & 1) * kStageFloats) + lane;
 #pragma unroll
     for (int s = 0; s < 8; ++s) mma3(s_a, lk[(0 * 8 + s) * 64], lk[(1 * 8 + s) * 64], qh[s], ql[s]);
   }
@@ -1395,16 +1458,16 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
     }
     __builtin_amdgcn_sched_barrier(0);
     if (PLACE == 0) {
-      if (t + 2 < tiles) issueK(t + 2);
-      if (t + 1 < tiles) issueV(t + 1);
+      if (t + 2 < t_end) issueK(t + 2);
+      if (t + 1 < t_end) issueV(t + 1);
     }
-    if (t + 1 < tiles) fetch_c(t + 1);
+    if (t + 1 < t_end) fetch_c(t + 1);
     __builtin_amdgcn_sched_barrier(0);
   };
   // piece q (0..3 of K_{t+2}, 4..7 of V_{t+1}) of this wave's share of the refills
   auto issue_piece = [&](const int t, const int q) {
     if (q < 4) {
-      if (t + 2 < tiles) dma_piece_1k_s(gk + (size_t)(t + 2) * kStageFloats + (wave + WAVES * q) * 256,
+      if (t + 2 < t_end) dma_piece_1k_s(gk + (size_t)(t + 2) * kStageFloats + (wave + WAVES * q) * 256,
                                         ldsK + (t & 1) * kStageFloats + (wave + WAVES * q) * 256, lane_off16);
     } else {
       dma_piece_1k_s(gv + (size_t)(t + 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256,
@@ -1532,11 +1595,11 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   if (!active) {
     // padding wave of a pair's last workgroup (tiles is rarely a multiple of 4): it owns no queries, but a quarter of
     // every K/V stage and a seat at every barrier - one barrier per tile, the refills of tile t issued during tile t
-    for (int t = 0; t < tiles; ++t) {
+    for (int t = t_begin; t < t_end; ++t) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (t + 1 < tiles) {
-        if (PLACE == 0) { if (t + 2 < tiles) issueK(t + 2); issueV(t + 1); }
+      if (t + 1 < t_end) {
+        if (PLACE == 0) { if (t + 2 < t_end) issueK(t + 2); issueV(t + 1); }
         else {
 #pragma unroll
           for (int q = 0; q < 8; ++q) issue_piece(t, q);
@@ -1544,13 +1607,29 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
       }
     }
   } else {
-    int t = 0;
-    for (; t + 2 < tiles; t += 2) {          // explicit ping-pong: no accumulator copies at the loop back-edge
+    int t = t_begin;
+    for (; t + 2 < t_end; t += 2) {          // explicit ping-pong: no accumulator copies at the loop back-edge
       tile_step(t, s_a, s_b);
       tile_step(t + 1, s_b, s_a);
     }
-    if (t + 1 < tiles) { tile_step(t, s_a, s_b); tile_last(t + 1, s_b); }
+    if (t + 1 < t_end) { tile_step(t, s_a, s_b); tile_last(t + 1, s_b); }
     else tile_last(t, s_a);
+  }
+  if (KSPLIT) {
+    // partial result of this key range: un-normalised O as a P32 tile image, row maximum and row sum
+    if (active) {
+      float of[CF];
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) of[16 * db + r] = oacc[db][r];
+      const size_t n_tiles_all = (size_t)(gridDim.x / ksplits / wgs_per_pair) * tiles;     // B * tiles
+      const size_t pt = (size_t)ks * n_tiles_all + pbase + tile;
+      store_frag_p32<CF>(part_o + pt * (32 * C), of, lane);
+      const float lsum = xhalf_sum(l_half);
+      if (h == 0) { part_ml[(pt * 32 + (lane & 31)) * 2] = m_run; part_ml[(pt * 32 + (lane & 31)) * 2 + 1] = lsum; }
+    }
+    return;
   }
 
   // ---- epilogue: normalise, fc_message (fp32 MFMA), add the Fusion-2 branch ----
@@ -1567,53 +1646,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5);
   ss.prime();
   if (EPI_H2) {
-    // stages (fp16x2 images, same sizes as the fp32 ones): Wa block 0 | Wa block 1 | Wb (2 blocks) | Wc 0,1 | Wc 2,3
-    FragH2<8> ox;
-    FragH2<4> m1x, m2x;
-    if (active) ox.set(o);
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      const f16x8* lw = as_h2(ss.acquire());
-      if (!active) continue;
-      f32x16 acc = zero16();
-      mma_wx_h2<8>(acc, lw, ox);
-      float b[16], t1[16];
-      load_vec_block(b, vecs, mb, h);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t1[r] = fmaxf(acc[r] + b[r], 0.f);
-      m1x.set_block(mb, t1);
-    }
-    {
-      const f16x8* lw = as_h2(ss.acquire());
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        if (!active) continue;
-        f32x16 acc = zero16();
-        mma_wx_h2<4>(acc, lw + mb * (2 * 4 * 64), m1x);
-        float b[16], t2[16];
-        load_vec_block(b, vecs + 64, mb, h);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t2[r] = fmaxf(acc[r] + b[r], 0.f);
-        m2x.set_block(mb, t2);
-      }
-    }
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      const f16x8* lw = as_h2(ss.acquire());
-#pragma unroll
-      for (int hb = 0; hb < 2; ++hb) {
-        if (!active) continue;
-        const int mb = 2 * st + hb;
-        f32x16 acc = zero16();
-        mma_wx_h2<4>(acc, lw + hb * (2 * 4 * 64), m2x);
-        float b[16], fz[16], tt[16];
-        load_vec_block(b, vecs + 128, mb, h);
-        load_block_p32(fz, fus + toff, mb, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tt[r] = acc[r] + b[r] + fz[r];
-        if (active) store_block_p32(out + toff, mb, tt, lane);
-      }
-    }
+    scattn_epilogue_h2(o, active, ss, vecs, fus + toff, out + toff, lane, h);
     return;
   }
   float m1[DHF], m2[DHF];
@@ -1655,6 +1688,45 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
       if (active) store_block_p32(out + toff, mb, tt, lane);
     }
   }
+}
+
+// k_scattn_merge: combines the `ksplits` partial results of k_scattn_h2p<.., KSPLIT> per query tile - common maximum M,
+// O = sum_k O_k 2^(m_k - M), l = sum_k l_k 2^(m_k - M) - and runs the epilogue.  grid (ceil(tiles/4), B), block 256.
+__global__ void __launch_bounds__(256, 2)
+k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_ml, const float* __restrict__ fus,
+               const float* __restrict__ wst, const float* __restrict__ vecs, float* __restrict__ out, int tiles, int ksplits) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * 4 + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t n_tiles_all = (size_t)gridDim.y * tiles;
+  const size_t pt0 = (size_t)pair * tiles + tile;
+  const size_t toff = pt0 * (32 * C);
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, 4, lane, wst, 5);
+  ss.prime();
+  float M = -INFINITY;
+  for (int k = 0; k < ksplits; ++k) M = fmaxf(M, part_ml[((k * n_tiles_all + pt0) * 32 + i) * 2]);
+  float o[CF];
+#pragma unroll
+  for (int e = 0; e < CF; ++e) o[e] = 0.f;
+  float l = 0.f;
+  for (int k = 0; k < ksplits; ++k) {
+    const size_t pt = k * n_tiles_all + pt0;
+    const float wk = __builtin_amdgcn_exp2f(part_ml[(pt * 32 + i) * 2] - M);
+    l = fmaf(part_ml[(pt * 32 + i) * 2 + 1], wk, l);
+    float ok[CF];
+    load_frag_p32<CF>(ok, part_o + pt * (32 * C), lane);
+#pragma unroll
+    for (int e = 0; e < CF; ++e) o[e] = fmaf(ok[e], wk, o[e]);
+  }
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int e = 0; e < CF; ++e) o[e] *= inv;
+  scattn_epilogue_h2(o, active, ss, vecs, fus + toff, out + toff, lane, h);
 }
 
 // =========================================================================================
@@ -2544,6 +2616,8 @@ namespace gmf {
 static int g_scattn_variant = [] { const char* e = getenv("GMF_SCATTN"); return e ? atoi(e) : 18; }();
 static bool g_h2_dbuf = [] { const char* e = getenv("GMF_H2_DBUF"); return e ? atoi(e) != 0 : true; }();
 void set_h2_dbuf(bool v) { g_h2_dbuf = v; }
+static int g_key_splits = [] { const char* e = getenv("GMF_KEY_SPLITS"); return e ? atoi(e) : 0; }();   // 0 = automatic
+void set_key_splits(int v) { g_key_splits = v; }
 static bool g_use_cache = [] { const char* e = getenv("GMF_COMPAT_CACHE"); return e ? atoi(e) != 0 : true; }();
 void set_use_cache(bool v) { g_use_cache = v; }
 bool get_use_cache() { return g_use_cache; }
@@ -2610,10 +2684,22 @@ hipError_t launch_scattn(const float* q, const float* k, const float* v, const f
       }
     else if (variant >= 16 && cc && g_use_cache && cc->dense) {
       static const bool epi_h2 = [] { const char* e = getenv("GMF_EPI_H2"); return e ? atoi(e) != 0 : true; }();
-      if (variant == 17) hipLaunchKernelGGL((k_scattn_h2p<1, false>), grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense);
-      else if (variant == 18 && cc->tail_wst_h2 && epi_h2) hipLaunchKernelGGL((k_scattn_h2p<2, true>), grid4, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cc->dense);
-      else if (variant == 18) hipLaunchKernelGGL((k_scattn_h2p<2, false>), grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense);
-      else hipLaunchKernelGGL((k_scattn_h2p<0, false>), grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense);
+      // small grids: divide the keys of each query block over several workgroups (k_scattn_merge finishes)
+      int ksplits = 1;
+      if (variant == 18 && cc->tail_wst_h2 && epi_h2 && cc->part_o && cc->max_splits > 1) {
+        if (g_key_splits > 0) ksplits = g_key_splits;
+        else if (wpp * B < 256 || (wpp * B < 384 && tiles >= 64)) ksplits = (512 + wpp * B - 1) / (wpp * B);   // measured break-even
+        ksplits = std::min(std::min(ksplits, cc->max_splits), std::max(1, tiles / 4));
+      }
+      if (ksplits > 1) {
+        hipLaunchKernelGGL((k_scattn_h2p<2, true, true>), dim3(wpp * B * ksplits), dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out,
+                           N, tiles, wpp, cc->dense, ksplits, cc->part_o, cc->part_ml);
+        hipLaunchKernelGGL(k_scattn_merge, dim3(wpp, B), dim3(256), 0, s, cc->part_o, cc->part_ml, fus, cc->tail_wst_h2, vecs, out, tiles, ksplits);
+      }
+      else if (variant == 17) hipLaunchKernelGGL((k_scattn_h2p<1, false>), grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense, 1, (float*)nullptr, (float*)nullptr);
+      else if (variant == 18 && cc->tail_wst_h2 && epi_h2) hipLaunchKernelGGL((k_scattn_h2p<2, true>), grid4, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cc->dense, 1, (float*)nullptr, (float*)nullptr);
+      else if (variant == 18) hipLaunchKernelGGL((k_scattn_h2p<2, false>), grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense, 1, (float*)nullptr, (float*)nullptr);
+      else hipLaunchKernelGGL((k_scattn_h2p<0, false>), grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense, 1, (float*)nullptr, (float*)nullptr);
     }
     else if (variant == 9 || variant >= 16) {
       const float* cd = (cc && g_use_cache) ? cc->dense : nullptr;

@@ -117,6 +117,11 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     gmf::set_scattn_variant(value);
     return GMF_OK;
   }
+  if (std::strcmp(name, "attn_key_splits") == 0) {     // 0 = automatic (small grids only), 1 = off, n = force n splits
+    GMF_REQUIRE(value >= 0 && value <= 8, GMF_ERR_BAD_ARG, "set_tuning: attn_key_splits out of range (0..8)");
+    gmf::set_key_splits(value);
+    return GMF_OK;
+  }
   if (std::strcmp(name, "compat_cache") == 0) {
     gmf::set_use_cache(value != 0);
     return GMF_OK;
@@ -339,8 +344,12 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   const size_t cache_need = want_cache ? arena_need(n_tt * 1024, 4) : 0;
   // 16x16x32 form of the attention kernel: needs the cache, the split-fp16 path and the q16 fc_message images
   const bool q16 = want_cache && gmf::get_scattn_variant() == 19 && w->tail_wst_q16 && use_h2(w, false);
+  // key-split attention for small grids (fewer than 256 workgroups of 128 queries): partial-result workspace
+  const int kMaxSplits = 8;
+  const bool want_split = want_cache && ((tiles + 3) / 4) * B < 384 && tiles >= 8;
+  const size_t split_need = want_split ? arena_need((size_t)kMaxSplits * act, 4) + arena_need((size_t)kMaxSplits * B * tiles * 64, 4) : 0;
   const size_t need = 5 * arena_need(act, 4) + 3 * arena_need(act3, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +
-                      5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4) + cache_need;
+                      5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4) + cache_need + split_need;
   if (int rc = arena_reserve(h, need)) return rc;
   float* featA = arena_take<float>(h, act);
   float* featB = arena_take<float>(h, act);
@@ -363,6 +372,11 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
     c_dense = arena_take<float>(h, n_tt * 1024);
     cc.dense = c_dense;
     cc.q16 = q16;
+  }
+  if (want_split) {
+    cc.part_o = arena_take<float>(h, (size_t)kMaxSplits * act);
+    cc.part_ml = arena_take<float>(h, (size_t)kMaxSplits * B * tiles * 64);
+    cc.max_splits = kMaxSplits;
   }
 
   // Fusion-1: image_feat = FusionLayer(p_tok (context), queries = q_tok), pe = False (PointDSC.py:137)

@@ -10,8 +10,12 @@ struct CompatCache {
   const float* tail_wst_h2;   // this layer's fc_message weights as split-fp16 images, or nullptr (fp32-MFMA epilogue)
   const float* tail_wst_q16;  // ... as 16x16x32 A-operand images (k_scattn_h2q)
   bool q16;                   // scattn_variant 19 is active: the V images and `dense` are in k_scattn_h2q's element order
+  float* part_o;              // key-split workspace: [max_splits][B * tiles] P32 tile images (or nullptr)
+  float* part_ml;             // ... [max_splits][B * tiles][32][2] row maximum, row sum
+  int max_splits;
 };
 void set_use_cache(bool v);
+void set_key_splits(int v);
 bool get_use_cache();
 hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s,
                                bool q16 = false);

@@ -499,3 +499,21 @@ def test_ragged_tile_counts(model, sd_full, N):
     res = model(data)
     assert _maxerr(model.last_logits.cpu(), ref["logits"]) < 1e-4
     assert _maxerr(res["final_trans"].cpu(), ref["final_trans"]) < 1e-3
+
+
+@pytest.mark.parametrize("N", [257, 1000])
+@pytest.mark.parametrize("splits", [1, 0, 3, 8])
+def test_key_split_attention(golden_dir, model, N, splits):
+    """Small grids divide the keys of a query block over several workgroups (k_scattn_h2p<.., KSPLIT> + k_scattn_merge):
+    off (1), automatic (0) and forced (3, 8; capped at tiles / 4) all reproduce the reference's golden logits (F4)."""
+    from gmf_amd import _lib
+    g = _load(golden_dir, "f4_f10_pointdsc.npz")
+    h = _lib.handle_for(0)
+    try:
+        h.call("gmf_set_tuning", b"attn_key_splits", splits)
+        b = synthetic.synthetic_batch(list(g[f"pair_seeds_N{N}"]), N=N, T=196)
+        args = [_gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")]
+        logits = model.encode(*args)[0]
+        assert _maxerr(logits.cpu(), g[f"logits_N{N}"]) < 1e-4
+    finally:
+        h.call("gmf_set_tuning", b"attn_key_splits", 0)

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <algorithm>
 
 #include "launchers_pose.hpp"
 #include "mfma_core.hpp"
@@ -179,7 +180,10 @@ GMF_DEVINL void block_sum_tree(double (&v)[NV], double* sh /* >= NV*17 doubles *
 
 // ---------------------------------------------------------------------------------------
 // NMS keys: key_i = score_i * [ for all j: score_i >= score_j  or  ||src_i - src_j|| >= R ]
-// grid (ceil(N/256), B)
+// grid (ceil(N/256), B, JS): the candidates j are divided over JS workgroups so that small batches fill the chip (at B = 1
+// a thread otherwise walks all N candidates alone: 0.4 ms at N = 5000).  With JS > 1 `keys` is pre-set to the scores by the
+// launcher and a workgroup only writes zeros for the points its candidate range suppresses (the conjunction over ranges
+// needs no ordering; score * 0 keeps the reference's sort order whatever the sign of the zero).
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_nms_keys(const float* __restrict__ src, const float* __restrict__ scores, float* __restrict__ keys, int N, float R2t) {
@@ -191,7 +195,9 @@ k_nms_keys(const float* __restrict__ src, const float* __restrict__ scores, floa
   float xi = 0, yi = 0, zi = 0, si = 0;
   if (i < N) { xi = ps[3 * i]; yi = ps[3 * i + 1]; zi = ps[3 * i + 2]; si = sc[i]; }
   bool is_max = true;
-  for (int j0 = 0; j0 < N; j0 += 256) {
+  const int nblk = (N + 255) / 256, js = gridDim.z;
+  const int b0 = (nblk * (int)blockIdx.z) / js, b1 = (nblk * ((int)blockIdx.z + 1)) / js;
+  for (int j0 = b0 * 256; j0 < min(N, b1 * 256); j0 += 256) {
     const int j = j0 + threadIdx.x;
     __syncthreads();
     sh[threadIdx.x] = (j < N) ? make_float4(ps[3 * j], ps[3 * j + 1], ps[3 * j + 2], sc[j])
@@ -205,7 +211,10 @@ k_nms_keys(const float* __restrict__ src, const float* __restrict__ scores, floa
       is_max = is_max && ((si >= p.w) || (d2 >= R2t));     // d2 >= R2t  <=>  sqrtf(d2) >= R  (see launch_nms_keys)
     }
   }
-  if (i < N) keys[(size_t)pair * N + i] = si * (is_max ? 1.f : 0.f);
+  if (i < N) {
+    if (js == 1) keys[(size_t)pair * N + i] = si * (is_max ? 1.f : 0.f);
+    else if (!is_max) keys[(size_t)pair * N + i] = si * 0.f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1129,7 +1138,14 @@ hipError_t launch_nms_keys(const float* src, const float* scores, float* keys, i
   } else {
     t = 0.f;
   }
-  hipLaunchKernelGGL(k_nms_keys, dim3((N + 255) / 256, B), dim3(256), 0, s, src, scores, keys, N, t);
+  const int nblk = (N + 255) / 256;
+  int js = 1;
+  if (nblk * B < 256) js = std::min(std::min(16, nblk), (512 + nblk * B - 1) / (nblk * B));
+  if (js > 1) {
+    hipError_t e = hipMemcpyAsync(keys, scores, (size_t)B * N * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_nms_keys, dim3(nblk, B, js), dim3(256), 0, s, src, scores, keys, N, t);
   return hipGetLastError();
 }
 

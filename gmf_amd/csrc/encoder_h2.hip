@@ -6,6 +6,7 @@
 //   k_fusion_attn_h2  fusion_layer.py:119-121,44,84-94,190
 //   k_fusion_ff_h2    fusion_layer.py:54-69,191
 //   k_ctx_prep_h2     fusion_layer.py:124-126,46-49,86-87
+#include <algorithm>
 #include <cstdlib>
 #include "enc_common.hpp"
 #include "launchers.hpp"
@@ -392,8 +393,11 @@ k_fusion_ff_h2(const float* __restrict__ x1, const float* __restrict__ wst, cons
 template <int ABL>
 __global__ void __launch_bounds__(256, 2)
 k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
-                float* __restrict__ x2_out, int tiles) {
-  constexpr int NB = 4, NCH = FFH / 32;
+                float* __restrict__ x2_out, int tiles, float* __restrict__ part) {
+  // gridDim.z = HS > 1 (small grids, e.g. B = 1): workgroup z handles the hidden chunks [z, z+1) * 16 / HS and writes its
+  // partial Linear-2 output (no bias, no residual) to part[z]; k_ff_reduce adds the partials in a fixed order.
+  constexpr int NB = 4;
+  const int HS = gridDim.z, NCH = (FFH / 32) / HS, c_begin = (int)blockIdx.z * NCH;
   __shared__ __attribute__((aligned(16))) float lds[NB * kStageFloats];
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -407,10 +411,10 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
   int n_issued = 0, n_used = 0;
   auto blob_stage = [&](int n) {
     n = min(n, 3 * NCH - 1);
-    if (n < 2) return n;
-    if (n == 3 * NCH - 1) return n;
+    if (n < 2) return 3 * c_begin + n;
+    if (n == 3 * NCH - 1) return 3 * c_begin + n;
     const int m = n - 2, c = m / 3, k = m - 3 * c;
-    return (k == 2) ? 3 * c + 2 : 3 * c + 3 + k;
+    return 3 * c_begin + ((k == 2) ? 3 * c + 2 : 3 * c + 3 + k);
   };
   auto issue_one = [&]() {
     const float* g = wst + (size_t)blob_stage(n_issued) * kStageFloats;
@@ -451,7 +455,7 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
     return a;
   };
 
-  f32x16 a0 = bias_acc(b1a, 0), g0 = bias_acc(b1g, 0), a1, g1;
+  f32x16 a0 = bias_acc(b1a, c_begin), g0 = bias_acc(b1g, c_begin), a1, g1;
   {
     const f16x8* lw = acquire();
     mma_wx_h2<8>(a0, lw, nx);
@@ -501,13 +505,24 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
       }
     }
   };
-  for (int c = 0; c + 2 < NCH; c += 2) {
+  for (int c = c_begin; c + 2 < c_begin + NCH; c += 2) {
     chunk(c, a0, g0, a1, g1, true);
     chunk(c + 1, a1, g1, a0, g0, true);
   }
-  chunk(NCH - 2, a0, g0, a1, g1, true);
-  chunk(NCH - 1, a1, g1, a0, g0, false);
+  chunk(c_begin + NCH - 2, a0, g0, a1, g1, true);
+  chunk(c_begin + NCH - 1, a1, g1, a0, g0, false);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-fetched tail stages
+  if (HS > 1) {
+    float* pt = part + ((size_t)blockIdx.z * gridDim.y * tiles + (size_t)pair * tiles + tile) * (32 * C);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = y[mb][r];
+      if (active) store_block_p32(pt, mb, t, lane);
+    }
+    return;
+  }
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     float b[16], xr[16], t[16];
@@ -516,6 +531,34 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = y[mb][r] + b[r] + xr[r];
     if (active) store_block_p32(x2_out + toff, mb, t, lane);
+  }
+}
+
+// k_ff_reduce: x2 = sum_z part[z] + b2 + x1 for the hidden-split form of k_fusion_ff_h2p.  grid (ceil(tiles/4), B), block 256
+__global__ void __launch_bounds__(256)
+k_ff_reduce(const float* __restrict__ part, const float* __restrict__ x1, const float* __restrict__ vecs,
+            float* __restrict__ x2_out, int tiles, int hs) {
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int tile = blockIdx.x * kWavesPerWG + (threadIdx.x >> 6);
+  if (tile >= tiles) return;
+  const size_t n_all = (size_t)gridDim.y * tiles;
+  const size_t toff = ((size_t)blockIdx.y * tiles + tile) * (32 * C);
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    float b[16], t[16], p[16];
+    load_vec_block(b, vecs + 2 * C + 2 * FFH, mb, h);
+    load_block_p32(p, part + toff, mb, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = p[r];
+    for (int z = 1; z < hs; ++z) {
+      load_block_p32(p, part + (size_t)z * n_all * (32 * C) + toff, mb, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] += p[r];
+    }
+    load_block_p32(p, x1 + toff, mb, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = t[r] + b[r] + p[r];
+    store_block_p32(x2_out + toff, mb, t, lane);
   }
 }
 
@@ -548,13 +591,32 @@ hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, 
   return hipGetLastError();
 }
 
-hipError_t launch_fusion_ff_h2(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s) {
+static int g_ff_split = [] { const char* e = getenv("GMF_FF_SPLIT"); return e ? atoi(e) : 0; }();
+void set_ff_split(int v) { g_ff_split = v; }
+
+hipError_t launch_fusion_ff_h2(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s,
+                               float* part, int max_parts) {
   static const bool pipelined = [] { const char* e = getenv("GMF_FF_PIPE"); return e ? atoi(e) != 0 : true; }();
   static const int abl = [] { const char* e = getenv("GMF_FF_ABL"); return e ? atoi(e) : 0; }();
-  if (pipelined && abl == 1) hipLaunchKernelGGL(k_fusion_ff_h2p<1>, tgrid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
-  else if (pipelined && abl == 2) hipLaunchKernelGGL(k_fusion_ff_h2p<2>, tgrid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
-  else if (pipelined) hipLaunchKernelGGL(k_fusion_ff_h2p<0>, tgrid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
-  else hipLaunchKernelGGL(k_fusion_ff_h2, tgrid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
+  const int force_hs = g_ff_split;   // 0 = automatic, 1 = off, 2 / 4 / 8 = forced
+  const dim3 g = tgrid(tiles, B);
+  // small grids: divide the 16 hidden chunks over 2 / 4 / 8 workgroups (deterministic two-pass sum)
+  int hs = 1;
+  if (pipelined && abl == 0 && part && max_parts >= 2) {
+    const int base = g.x * B;
+    if (force_hs > 0) hs = force_hs;
+    else if (base < 256) hs = base <= 64 ? 8 : base <= 128 ? 4 : 2;
+    hs = std::min(hs, max_parts);
+    if (hs != 2 && hs != 4 && hs != 8) hs = 1;
+  }
+  if (hs > 1) {
+    hipLaunchKernelGGL(k_fusion_ff_h2p<0>, dim3(g.x, g.y, hs), dim3(256), 0, s, x1, wst, vecs, x2, tiles, part);
+    hipLaunchKernelGGL(k_ff_reduce, g, dim3(256), 0, s, part, x1, vecs, x2, tiles, hs);
+  }
+  else if (pipelined && abl == 1) hipLaunchKernelGGL(k_fusion_ff_h2p<1>, g, dim3(256), 0, s, x1, wst, vecs, x2, tiles, (float*)nullptr);
+  else if (pipelined && abl == 2) hipLaunchKernelGGL(k_fusion_ff_h2p<2>, g, dim3(256), 0, s, x1, wst, vecs, x2, tiles, (float*)nullptr);
+  else if (pipelined) hipLaunchKernelGGL(k_fusion_ff_h2p<0>, g, dim3(256), 0, s, x1, wst, vecs, x2, tiles, (float*)nullptr);
+  else hipLaunchKernelGGL(k_fusion_ff_h2, g, dim3(256), 0, s, x1, wst, vecs, x2, tiles);
   return hipGetLastError();
 }
 

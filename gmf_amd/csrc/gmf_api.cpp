@@ -117,6 +117,12 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     gmf::set_scattn_variant(value);
     return GMF_OK;
   }
+  if (std::strcmp(name, "ff_hidden_splits") == 0) {    // 0 = automatic (small grids only), 1 = off, 2 / 4 / 8 = forced
+    GMF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, GMF_ERR_BAD_ARG,
+                "set_tuning: ff_hidden_splits must be 0, 1, 2, 4 or 8");
+    gmf::set_ff_split(value);
+    return GMF_OK;
+  }
   if (std::strcmp(name, "attn_key_splits") == 0) {     // 0 = automatic (small grids only), 1 = off, n = force n splits
     GMF_REQUIRE(value >= 0 && value <= 8, GMF_ERR_BAD_ARG, "set_tuning: attn_key_splits out of range (0..8)");
     gmf::set_key_splits(value);
@@ -288,7 +294,8 @@ static int run_block_tail(gmf_handle* h, const gmf_encoder_weights* w, int l, co
     GMF_HIP(gmf::launch_fusion_attn_h2(true, f, ctx_l, w->attn_wst_h2 + (size_t)l * w->attn_wst_stride,
                                        w->attn_vec + (size_t)l * w->attn_vec_stride, x1, B, N, tiles, T, tt, st));
     GMF_HIP(gmf::launch_fusion_ff_h2(x1, w->ff_wst_h2 + (size_t)l * w->ff_wst_stride,
-                                     w->ff_vec + (size_t)l * w->ff_vec_stride, x2, B, tiles, st));
+                                     w->ff_vec + (size_t)l * w->ff_vec_stride, x2, B, tiles, st,
+                                     cc ? cc->part_o : nullptr, cc ? cc->max_splits : 0));   // the attention's partial buffer is free here
   } else {
   GMF_HIP(gmf::launch_fusion_attn(true, f, ctx_l, w->attn_wst + (size_t)l * w->attn_wst_stride,
                                   w->attn_vec + (size_t)l * w->attn_vec_stride, x1, B, N, tiles, T, tt, st));

@@ -16,6 +16,7 @@ struct CompatCache {
 };
 void set_use_cache(bool v);
 void set_key_splits(int v);
+void set_ff_split(int v);
 bool get_use_cache();
 hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s,
                                bool q16 = false);
@@ -50,7 +51,8 @@ hipError_t launch_ctx_prep_h2(bool pe, const float* ctx, const float* wst, const
                               int ttiles, int sets, int wst_stride, int vec_stride, hipStream_t s);
 hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
                                  float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
-hipError_t launch_fusion_ff_h2(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
+hipError_t launch_fusion_ff_h2(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s,
+                               float* part = nullptr, int max_parts = 0);
 int padded_desc_width(int d);
 hipError_t launch_nn_match(const float* F0, const float* F1, float* f0_img, float* f1_img, float* norm2, int* idx,
                            float* dist, int N0, int N1, int d, int mode, hipStream_t s);

@@ -501,6 +501,23 @@ def test_ragged_tile_counts(model, sd_full, N):
     assert _maxerr(res["final_trans"].cpu(), ref["final_trans"]) < 1e-3
 
 
+@pytest.mark.parametrize("hs", [1, 0, 2, 4])
+def test_hidden_split_feed_forward(golden_dir, model, hs):
+    """Small grids divide the 16 GEGLU chunks of a row block over 2 / 4 / 8 workgroups (partials summed in a fixed order by
+    k_ff_reduce): off (1), automatic (0 -> 8 at this size) and forced 2, 4 reproduce the reference's golden logits (F4)."""
+    from gmf_amd import _lib
+    g = _load(golden_dir, "f4_f10_pointdsc.npz")
+    h = _lib.handle_for(0)
+    try:
+        h.call("gmf_set_tuning", b"ff_hidden_splits", hs)
+        b = synthetic.synthetic_batch(list(g["pair_seeds_N1000"]), N=1000, T=196)
+        args = [_gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")]
+        logits = model.encode(*args)[0]
+        assert _maxerr(logits.cpu(), g["logits_N1000"]) < 1e-4
+    finally:
+        h.call("gmf_set_tuning", b"ff_hidden_splits", 0)
+
+
 @pytest.mark.parametrize("N", [257, 1000])
 @pytest.mark.parametrize("splits", [1, 0, 3, 8])
 def test_key_split_attention(golden_dir, model, N, splits):

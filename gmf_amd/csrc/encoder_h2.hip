@@ -38,8 +38,13 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
   const int tile = active ? tile_raw : tiles - 1;
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
 
+  // gridDim.z == 3 (small grids): workgroup z recomputes PointCN and produces ONE of Q' (z = 0, it also stores f), K, V -
+  // 8 weight stages instead of 16 per workgroup, three times the workgroups.
+  const bool zsplit = (MODE != 2) && gridDim.z == 3;
+  const int zsel = zsplit ? (int)blockIdx.z : -1;
   StageRing<kRing> ss;
   if (MODE == 2) ss.init(lds, wave, lane, wst + 4 * kStageFloats, 12);
+  else if (zsplit) ss.init(lds, wave, lane, wst, 4, wst + (4 + 4 * zsel) * kStageFloats, 4);
   else ss.init(lds, wave, lane, wst, 16);
   ss.prime();
 
@@ -87,11 +92,12 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
       }
     }
   }
-  if (active) store_frag_p32<CF>(f_out + toff, f, lane);
+  if (active && zsel <= 0) store_frag_p32<CF>(f_out + toff, f, lane);
   fx.set(f);
 
 #pragma unroll
   for (int which = 0; which < 2; ++which) {   // Q', K
+    if (zsplit && zsel != which) continue;
     float* dst = (which == 0 ? q_out : k_out) + toff;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
@@ -105,6 +111,7 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
       if (active) store_block_h2(dst, mb, t, lane);
     }
   }
+  if (zsplit && zsel != 2) return;
 #pragma unroll
   for (int db = 0; db < 4; ++db) {             // V (feature on lane)
     const f16x8* lw = as_h2(ss.acquire());
@@ -565,11 +572,16 @@ k_ff_reduce(const float* __restrict__ part, const float* __restrict__ x1, const 
 // -----------------------------------------------------------------------------------------
 static inline dim3 tgrid(int tiles, int B, int sets = 1) { return dim3((tiles + kWavesPerWG - 1) / kWavesPerWG, B, sets); }
 
+static bool g_front_split = [] { const char* e = getenv("GMF_FRONT_SPLIT"); return e ? atoi(e) != 0 : true; }();
+void set_front_split(bool v) { g_front_split = v; }
+
 hipError_t launch_front_h2(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
                            float* v, int B, int N, int tiles, hipStream_t s, bool v_q16) {
   const bool vq = v_q16;
-#define GMF_FRONT_H2(M) do { if (vq) hipLaunchKernelGGL((k_front_h2<M, true>), tgrid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles); \
-                             else hipLaunchKernelGGL((k_front_h2<M, false>), tgrid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles); } while (0)
+  dim3 g = tgrid(tiles, B);
+  if (mode != 2 && g.x * B < 128 && g_front_split) g.z = 3;      // small grids: one workgroup per output (Q' + f | K | V)
+#define GMF_FRONT_H2(M) do { if (vq) hipLaunchKernelGGL((k_front_h2<M, true>), g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles); \
+                             else hipLaunchKernelGGL((k_front_h2<M, false>), g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles); } while (0)
   if (mode == 1) GMF_FRONT_H2(1);
   else if (mode == 2) GMF_FRONT_H2(2);
   else GMF_FRONT_H2(0);

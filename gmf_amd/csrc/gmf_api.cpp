@@ -117,6 +117,10 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     gmf::set_scattn_variant(value);
     return GMF_OK;
   }
+  if (std::strcmp(name, "front_output_split") == 0) {  // 1 = small grids use one workgroup per output of k_front_h2 (default), 0 = never
+    gmf::set_front_split(value != 0);
+    return GMF_OK;
+  }
   if (std::strcmp(name, "ff_hidden_splits") == 0) {    // 0 = automatic (small grids only), 1 = off, 2 / 4 / 8 = forced
     GMF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, GMF_ERR_BAD_ARG,
                 "set_tuning: ff_hidden_splits must be 0, 1, 2, 4 or 8");
@@ -393,7 +397,8 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   if (h2 && w->f1_ctx_wst_h2 && w->f1_attn_wst_h2 && w->f1_ff_wst_h2) {
     GMF_HIP(gmf::launch_ctx_prep_h2(false, pimg, w->f1_ctx_wst_h2, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st));
     GMF_HIP(gmf::launch_fusion_attn_h2(false, qimg, f1ctx, w->f1_attn_wst_h2, w->f1_attn_vec, x1t, B, T, tt, T, tt, st));
-    GMF_HIP(gmf::launch_fusion_ff_h2(x1t, w->f1_ff_wst_h2, w->f1_ff_vec, imgfeat, B, tt, st));
+    GMF_HIP(gmf::launch_fusion_ff_h2(x1t, w->f1_ff_wst_h2, w->f1_ff_vec, imgfeat, B, tt, st,
+                                     tt <= tiles ? cc.part_o : nullptr, tt <= tiles ? cc.max_splits : 0));
   } else {
     GMF_HIP(gmf::launch_ctx_prep(false, pimg, w->f1_ctx_wst, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st));
     GMF_HIP(gmf::launch_fusion_attn(false, qimg, f1ctx, w->f1_attn_wst, w->f1_attn_vec, x1t, B, T, tt, T, tt, st));

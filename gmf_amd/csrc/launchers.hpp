@@ -17,6 +17,7 @@ struct CompatCache {
 void set_use_cache(bool v);
 void set_key_splits(int v);
 void set_ff_split(int v);
+void set_front_split(bool v);
 bool get_use_cache();
 hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s,
                                bool q16 = false);

@@ -501,6 +501,21 @@ def test_ragged_tile_counts(model, sd_full, N):
     assert _maxerr(res["final_trans"].cpu(), ref["final_trans"]) < 1e-3
 
 
+@pytest.mark.parametrize("on", [0, 1])
+def test_front_output_split(golden_dir, model, on):
+    """Small grids run k_front_h2 with one workgroup per output (Q' + f | K | V); on and off give the golden logits (F4)."""
+    from gmf_amd import _lib
+    g = _load(golden_dir, "f4_f10_pointdsc.npz")
+    h = _lib.handle_for(0)
+    try:
+        h.call("gmf_set_tuning", b"front_output_split", on)
+        b = synthetic.synthetic_batch(list(g["pair_seeds_N257"]), N=257, T=196)
+        args = [_gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")]
+        assert _maxerr(model.encode(*args)[0].cpu(), g["logits_N257"]) < 1e-4
+    finally:
+        h.call("gmf_set_tuning", b"front_output_split", 1)
+
+
 @pytest.mark.parametrize("hs", [1, 0, 2, 4])
 def test_hidden_split_feed_forward(golden_dir, model, hs):
     """Small grids divide the 16 GEGLU chunks of a row block over 2 / 4 / 8 workgroups (partials summed in a fixed order by

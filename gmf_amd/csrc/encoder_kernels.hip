@@ -2688,7 +2688,8 @@ hipError_t launch_scattn(const float* q, const float* k, const float* v, const f
       int ksplits = 1;
       if (variant == 18 && cc->tail_wst_h2 && epi_h2 && cc->part_o && cc->max_splits > 1) {
         if (g_key_splits > 0) ksplits = g_key_splits;
-        else if (wpp * B < 256 || (wpp * B < 384 && tiles >= 64)) ksplits = (512 + wpp * B - 1) / (wpp * B);   // measured break-even
+        else if (wpp * B < 256) ksplits = std::max(2, 512 / (wpp * B));   // one resident round of 512 workgroup slots, never more
+        else if (wpp * B < 384 && tiles >= 64) ksplits = 2;               // measured break-even
         ksplits = std::min(std::min(ksplits, cc->max_splits), std::max(1, tiles / 4));
       }
       if (ksplits > 1) {

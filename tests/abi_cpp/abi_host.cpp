@@ -1,0 +1,92 @@
+// A C++ host of the C ABI (include/gmf_hip.h) with no Python and no torch in the process: device buffers from hipMalloc,
+// the DGR pose calls on synthetic scenes with a known rigid motion, status codes and the error string.
+//   hipcc -O2 -I include tests/abi_cpp/abi_host.cpp -L gmf_amd -lgmf_hip -Wl,-rpath,$PWD/gmf_amd -o abi_host && ./abi_host
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "gmf_hip.h"
+
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
+
+int main() {
+  gmf_handle* h = nullptr;
+  if (gmf_create(0, &h) != GMF_OK || !h) { std::printf("gmf_create failed\n"); return 1; }
+
+  const int B = 4, N = 3000;
+  std::mt19937 rng(7);
+  std::uniform_real_distribution<float> U(0.f, 3.f), U01(0.f, 1.f);
+  std::normal_distribution<float> G(0.f, 0.01f);
+  std::vector<float> X((size_t)B * N * 3), Y((size_t)B * N * 3), W((size_t)B * N);
+  std::vector<float> Rgt(B * 9), tgt(B * 3);
+  std::vector<int> off(B + 1);
+  for (int b = 0; b <= B; ++b) off[b] = b * N;
+  for (int b = 0; b < B; ++b) {
+    // rotation about a random axis (Rodrigues)
+    float ax[3] = {U01(rng) - 0.5f, U01(rng) - 0.5f, U01(rng) - 0.5f};
+    const float n = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    for (float& a : ax) a /= n;
+    const float th = 0.3f + U01(rng), c = std::cos(th), s = std::sin(th), C1 = 1.f - c;
+    float* R = &Rgt[b * 9];
+    R[0] = c + ax[0] * ax[0] * C1;         R[1] = ax[0] * ax[1] * C1 - ax[2] * s; R[2] = ax[0] * ax[2] * C1 + ax[1] * s;
+    R[3] = ax[1] * ax[0] * C1 + ax[2] * s; R[4] = c + ax[1] * ax[1] * C1;         R[5] = ax[1] * ax[2] * C1 - ax[0] * s;
+    R[6] = ax[2] * ax[0] * C1 - ax[1] * s; R[7] = ax[2] * ax[1] * C1 + ax[0] * s; R[8] = c + ax[2] * ax[2] * C1;
+    for (int k = 0; k < 3; ++k) tgt[b * 3 + k] = U01(rng) - 0.5f;
+    for (int i = 0; i < N; ++i) {
+      float* x = &X[((size_t)b * N + i) * 3];
+      float* y = &Y[((size_t)b * N + i) * 3];
+      for (int k = 0; k < 3; ++k) x[k] = U(rng);
+      const bool inlier = U01(rng) < 0.4f;
+      for (int k = 0; k < 3; ++k)
+        y[k] = inlier ? R[3 * k] * x[0] + R[3 * k + 1] * x[1] + R[3 * k + 2] * x[2] + tgt[b * 3 + k] + G(rng) : U(rng);
+      W[(size_t)b * N + i] = inlier ? 0.6f + 0.4f * U01(rng) : (U01(rng) < 0.7f ? 0.f : 0.1f * U01(rng));
+    }
+  }
+  float *dX, *dY, *dW, *dR, *dt, *dS;
+  int* dOff;
+  CHECK_HIP(hipMalloc(&dX, X.size() * 4)); CHECK_HIP(hipMalloc(&dY, Y.size() * 4)); CHECK_HIP(hipMalloc(&dW, W.size() * 4));
+  CHECK_HIP(hipMalloc(&dR, B * 9 * 4)); CHECK_HIP(hipMalloc(&dt, B * 3 * 4)); CHECK_HIP(hipMalloc(&dS, B * 3 * 4));
+  CHECK_HIP(hipMalloc(&dOff, (B + 1) * 4));
+  CHECK_HIP(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+  CHECK_HIP(hipMemcpy(dY, Y.data(), Y.size() * 4, hipMemcpyHostToDevice));
+  CHECK_HIP(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice));
+  CHECK_HIP(hipMemcpy(dOff, off.data(), (B + 1) * 4, hipMemcpyHostToDevice));
+  hipStream_t st;
+  CHECK_HIP(hipStreamCreate(&st));
+
+  auto max_err = [&](const char* what, float tolR, float tolt) {
+    std::vector<float> R(B * 9), t(B * 3);
+    if (hipMemcpy(R.data(), dR, B * 9 * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(t.data(), dt, B * 3 * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    float eR = 0, et = 0;
+    for (int i = 0; i < B * 9; ++i) eR = std::fmax(eR, std::fabs(R[i] - Rgt[i]));
+    for (int i = 0; i < B * 3; ++i) et = std::fmax(et, std::fabs(t[i] - tgt[i]));
+    std::printf("%s: max |R - R_gt| = %.3e, max |t - t_gt| = %.3e\n", what, eR, et);
+    return eR < tolR && et < tolt;
+  };
+
+  int rc = gmf_weighted_procrustes(h, dX, dY, dW, dOff, B, 1.1920929e-7f, dR, dt, st);
+  CHECK_HIP(hipStreamSynchronize(st));
+  if (rc != GMF_OK) { std::printf("weighted_procrustes: %s\n", gmf_last_error_string(h)); return 1; }
+  if (!max_err("gmf_weighted_procrustes", 5e-2f, 1e-1f)) return 1;
+
+  rc = gmf_global_registration(h, dX, dY, dW, dOff, B, 1.1920929e-7f, 0.1f, 1000, 20, 1e-4, dR, dt, dS, N, st);
+  CHECK_HIP(hipStreamSynchronize(st));
+  if (rc != GMF_OK) { std::printf("global_registration: %s\n", gmf_last_error_string(h)); return 1; }
+  if (!max_err("gmf_global_registration", 5e-3f, 2e-2f)) return 1;
+  std::vector<float> S(B * 3);
+  CHECK_HIP(hipMemcpy(S.data(), dS, B * 3 * 4, hipMemcpyDeviceToHost));
+  for (int b = 0; b < B; ++b) std::printf("  pair %d: %d Adam steps, loss %.4f, break count %d\n", b, (int)S[3 * b], S[3 * b + 1], (int)S[3 * b + 2]);
+
+  // error path: a null pointer must come back as a status code with a message, never as an abort
+  rc = gmf_weighted_procrustes(h, nullptr, dY, dW, dOff, B, 1.1920929e-7f, dR, dt, st);
+  if (rc == GMF_OK) { std::printf("null pointer was accepted\n"); return 1; }
+  std::printf("bad call -> status %d, \"%s\"\n", rc, gmf_last_error_string(h));
+
+  gmf_destroy(h);
+  std::printf("ABI host OK\n");
+  return 0;
+}

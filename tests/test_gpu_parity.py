@@ -549,3 +549,20 @@ def test_key_split_attention(golden_dir, model, N, splits):
         assert _maxerr(logits.cpu(), g[f"logits_N{N}"]) < 1e-4
     finally:
         h.call("gmf_set_tuning", b"attn_key_splits", 0)
+
+
+def test_cpp_host_of_the_c_abi(tmp_path):
+    """A C++ program (tests/abi_cpp/abi_host.cpp) drives libgmf_hip.so through include/gmf_hip.h with hipMalloc'd buffers -
+    no Python, no torch in that process: weighted Procrustes and the robust refinement recover known rigid motions,
+    and a bad call returns a status code with a message."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_host")
+    libdir = os.path.join(root, "gmf_amd")
+    build = subprocess.run([hipcc, "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "abi_cpp", "abi_host.cpp"),
+                            "-L", libdir, "-lgmf_hip", f"-Wl,-rpath,{libdir}", "-o", exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "ABI host OK" in run.stdout, run.stdout[-2000:] + run.stderr[-1000:]

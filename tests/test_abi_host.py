@@ -40,6 +40,10 @@ def test_no_device_fails_loudly():
         m(torch.zeros(1, 4, 128), queries_encoder=torch.zeros(1, 8, 128))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         gmf_amd.rigid_transform_3d(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gmf_amd.global_registration_batched(torch.zeros(8, 3), torch.zeros(8, 3), torch.ones(8, 1), [0, 8])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gmf_amd.nn_match(torch.zeros(4, 32), torch.zeros(5, 32))
 
 
 def test_state_dict_surface_matches_reference(golden_dir):

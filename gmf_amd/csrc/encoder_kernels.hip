@@ -1,13 +1,22 @@
-// GMF correspondence encoder on gfx950: hand-written fp32-MFMA kernels.
+// GMF correspondence encoder on gfx950: the fp32-MFMA kernels of every stage and every form of the spatial-consistency
+// attention kernel (the split-fp16 linear stages live in encoder_h2.hip).
 //
 // Replaces (file:line relative to /root/reference/GMF_PointDSC/):
 //   k_front      models/PointDSC.py:88,104-109,56-58   layer0 / PointCN conv1x1+BN+ReLU, Q/K/V conv1x1
-//   k_scattn     models/PointDSC.py:216-221,60-65,73   compat matrix (recomputed, never stored) +
-//                                                      softmax(compat*QK^T/sqrt(C)) V + fc_message + block sum
+//   k_scattn*    models/PointDSC.py:216-221,60-65,73   compat matrix + softmax(compat*QK^T/sqrt(C)) V + fc_message + block sum
+//   k_compat_build models/PointDSC.py:216-221          the compat matrix once per batch, in the attention kernel's register order
 //   k_ctx_prep   models/fusion_layer.py:124-126,46-49,86-87   LCPE(content) + LayerNorm + to_kv
 //   k_fusion_attn models/fusion_layer.py:119-121,44,84-94,190 LCPE(q) + LayerNorm + to_q + softmax(QK^T) V + to_out + residual
 //   k_fusion_ff  models/fusion_layer.py:54-69,191      LayerNorm + Linear + GEGLU + Linear + residual
 //   k_head       models/PointDSC.py:175-181,229,241    classifier head + F.normalize
+//
+// Forms of the attention kernel (launch_scattn, `scattn_variant`):
+//   k_scattn_h2p  (18, DEFAULT) split-fp16 MFMA operands, c streamed from the compat cache, tile loop software-pipelined
+//                 inside each wave, split-fp16 fc_message epilogue; KSPLIT form + k_scattn_merge for small grids
+//   k_scattn_h2   (9)  split-fp16, c recomputed in-kernel or cached, not pipelined: fallback when the cache does not fit
+//   k_scattn_h2q  (19) the 16x16x32 MFMA form (own V / c / weight layouts); measured slower, kept for A/B
+//   k_scattn_b3, k_scattn_b3p (3..8) split-bf16 (3 planes, 6 products); k_scattn, k_scattn_pipe (0..2) fp32 MFMA;
+//   k_scattn_dense: the drop-in NonLocalBlock with a caller-supplied dense `attention` [B,N,N]
 //
 // Every kernel runs 4 waves per workgroup, each wave owning one 32-row tile ("rows on lanes",
 // see mfma_core.hpp).  Weights, K/V tiles and context tiles stream L2 -> LDS in 16 KiB stages by

@@ -613,31 +613,50 @@ k_seed_kabsch(const float* __restrict__ src, const float* __restrict__ tgt, cons
 }
 
 // ---------------------------------------------------------------------------------------
-// Inlier count of each hypothesis over all N correspondences.  grid (S, B), block 256.
+// Inlier count of each hypothesis over all N correspondences.  grid (ceil(S / kHypPerWG), B), block 256.
+// A workgroup scores kHypPerWG hypotheses per pass over the points (one hypothesis per workgroup re-read the pair's
+// 24 N bytes from L2 for each of its S hypotheses: 1.9 GB per launch at B = 32, N = 5000, S = 500 - L2-bandwidth bound).
+// tau2t: smallest float t with sqrtf(t) >= tau, so that d2 < t  <=>  sqrtf(d2) < tau  (the reference's test, PointDSC.py:415).
 // ---------------------------------------------------------------------------------------
+constexpr int kHypPerWG = 8;
+
 __global__ void __launch_bounds__(256)
 k_score_hyp(const float* __restrict__ src, const float* __restrict__ tgt, const float* __restrict__ seed_T,
-            int* __restrict__ counts, int N, int S, float tau) {
-  __shared__ int red[4];
-  const int pair = blockIdx.y, s = blockIdx.x;
-  const float* T = seed_T + ((size_t)pair * S + s) * 16;
-  const float r00 = T[0], r01 = T[1], r02 = T[2], t0 = T[3], r10 = T[4], r11 = T[5], r12 = T[6], t1 = T[7],
-              r20 = T[8], r21 = T[9], r22 = T[10], t2 = T[11];
+            int* __restrict__ counts, int N, int S, float tau2t) {
+  __shared__ int red[4][kHypPerWG];
+  const int pair = blockIdx.y, s0 = blockIdx.x * kHypPerWG;
+  float Tm[kHypPerWG][12];
+#pragma unroll
+  for (int q = 0; q < kHypPerWG; ++q) {
+    const float* T = seed_T + ((size_t)pair * S + min(s0 + q, S - 1)) * 16;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) Tm[q][e] = T[e];
+  }
   const float* ps = src + (size_t)pair * N * 3;
   const float* pt = tgt + (size_t)pair * N * 3;
-  int cnt = 0;
+  int cnt[kHypPerWG];
+#pragma unroll
+  for (int q = 0; q < kHypPerWG; ++q) cnt[q] = 0;
   for (int j = threadIdx.x; j < N; j += 256) {
     const float x = ps[3 * j], y = ps[3 * j + 1], z = ps[3 * j + 2];
-    const float dx = (r00 * x + r01 * y + r02 * z) + t0 - pt[3 * j];
-    const float dy = (r10 * x + r11 * y + r12 * z) + t1 - pt[3 * j + 1];
-    const float dz = (r20 * x + r21 * y + r22 * z) + t2 - pt[3 * j + 2];
-    cnt += (sqrtf(dx * dx + dy * dy + dz * dz) < tau) ? 1 : 0;
+    const float u = pt[3 * j], v = pt[3 * j + 1], w = pt[3 * j + 2];
+#pragma unroll
+    for (int q = 0; q < kHypPerWG; ++q) {
+      const float dx = (Tm[q][0] * x + Tm[q][1] * y + Tm[q][2] * z) + Tm[q][3] - u;
+      const float dy = (Tm[q][4] * x + Tm[q][5] * y + Tm[q][6] * z) + Tm[q][7] - v;
+      const float dz = (Tm[q][8] * x + Tm[q][9] * y + Tm[q][10] * z) + Tm[q][11] - w;
+      cnt[q] += (dx * dx + dy * dy + dz * dz < tau2t) ? 1 : 0;
+    }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  for (int q = 0; q < kHypPerWG; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt[q] += __shfl_xor(cnt[q], o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = cnt[q];
+  }
   __syncthreads();
-  if (threadIdx.x == 0) counts[(size_t)pair * S + s] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x < kHypPerWG && s0 + threadIdx.x < S)
+    counts[(size_t)pair * S + s0 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1200,7 +1219,15 @@ hipError_t launch_seed_kabsch(const float* src, const float* tgt, const int* knn
 
 hipError_t launch_score_hyp(const float* src, const float* tgt, const float* seed_T, int* counts, int B, int N, int S,
                             float tau, hipStream_t s) {
-  hipLaunchKernelGGL(k_score_hyp, dim3(S, B), dim3(256), 0, s, src, tgt, seed_T, counts, N, S, tau);
+  // sqrtf(d2) < tau  <=>  d2 < t for the smallest float t with sqrtf(t) >= tau (sqrtf is monotone): no square root per pair
+  float t = tau * tau;
+  if (tau > 0.f) {
+    while (sqrtf(t) >= tau && t > 0.f) t = nextafterf(t, 0.f);
+    while (sqrtf(t) < tau) t = nextafterf(t, INFINITY);
+  } else {
+    t = 0.f;
+  }
+  hipLaunchKernelGGL(k_score_hyp, dim3((S + kHypPerWG - 1) / kHypPerWG, B), dim3(256), 0, s, src, tgt, seed_T, counts, N, S, t);
   return hipGetLastError();
 }
 

@@ -2509,7 +2509,7 @@ k_head(const float* __restrict__ feat_img, const float* __restrict__ wst, const 
 // k_seed_dist: feature-space distances of the seed rows to every correspondence,
 //   dist[seed][j] = 2 - 2 <f_seed, f_j>   (models/common.py:64-66 restricted to the rows PointDSC.py:329 keeps).
 //   One wave = 32 seeds (fragment gathered from the P32 image of the unit features), key tiles streamed
-//   through LDS; D = mfma(A = seed fragment, B = key tile) puts the key on the lane, so every store is a
+//   through LDS; D = mfma(A = seed fragment, B = key tile) (split-fp16 operands) puts the key on the lane, so every store is a
 //   128-byte run of one seed's row.  grid (ceil(S/128), B); dist [B, S, N].
 // =========================================================================================
 __global__ void __launch_bounds__(256, 2)
@@ -2528,6 +2528,10 @@ k_seed_dist(const float* __restrict__ featn_img, const int* __restrict__ seeds, 
   float sf[CF];
   load_row_frag_p32<CF>(sf, pair_img, row, N, h);
   if (t0 >= t1) return;                         // uniform over the workgroup
+  // split-fp16 operands (3 products on the f16 MFMA, fp32-equivalent: mfma_core.hpp): 24 MFMAs of 32 cycles per key tile
+  // instead of 64 of 64; the key tile is split in registers from its fp32 image (the unit features have no h2 image)
+  FragH2<8> sx;
+  sx.set(sf);
 
   StageStream ss;
   ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, pair_img + (size_t)t0 * kStageFloats, t1 - t0);
@@ -2536,7 +2540,18 @@ k_seed_dist(const float* __restrict__ featn_img, const int* __restrict__ seeds, 
   for (int t = t0; t < t1; ++t) {
     const float4* lk = ss.acquire();
     f32x16 acc = zero16();
-    mma_xw<CF>(acc, lk, sf);
+    {
+      float kx[CF];
+#pragma unroll
+      for (int g = 0; g < CF / 4; ++g) {
+        const float4 w = lk[g * 64];
+        kx[4 * g + 0] = w.x; kx[4 * g + 1] = w.y; kx[4 * g + 2] = w.z; kx[4 * g + 3] = w.w;
+      }
+      FragH2<8> kf;
+      kf.set(kx);
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) mma3(acc, sx.h[s8], sx.l[s8], kf.h[s8], kf.l[s8]);
+    }
     const int j = t * 32 + i;
     if (j < N) {
 #pragma unroll

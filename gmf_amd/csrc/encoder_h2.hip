@@ -397,14 +397,15 @@ k_fusion_ff_h2(const float* __restrict__ x1, const float* __restrict__ wst, cons
 //   re-fetched into a free slot instead of branching), so a whole chunk is one basic block for the scheduler.
 // =========================================================================================
 // ABL (timing only, wrong results): 1 = one LDS-DMA piece per wave and stage instead of four, 2 = no GELU
-template <int ABL>
+template <int ABL, bool SPLIT = false>
 __global__ void __launch_bounds__(256, 2)
 k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
                 float* __restrict__ x2_out, int tiles, float* __restrict__ part) {
   // gridDim.z = HS > 1 (small grids, e.g. B = 1): workgroup z handles the hidden chunks [z, z+1) * 16 / HS and writes its
   // partial Linear-2 output (no bias, no residual) to part[z]; k_ff_reduce adds the partials in a fixed order.
   constexpr int NB = 4;
-  const int HS = gridDim.z, NCH = (FFH / 32) / HS, c_begin = (int)blockIdx.z * NCH;
+  // (compile-time trip counts for the common un-split form: a run-time chunk count costs it 9 %)
+  const int HS = SPLIT ? (int)gridDim.z : 1, NCH = SPLIT ? (FFH / 32) / HS : FFH / 32, c_begin = SPLIT ? (int)blockIdx.z * NCH : 0;
   __shared__ __attribute__((aligned(16))) float lds[NB * kStageFloats];
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -622,7 +623,7 @@ hipError_t launch_fusion_ff_h2(const float* x1, const float* wst, const float* v
     if (hs != 2 && hs != 4 && hs != 8) hs = 1;
   }
   if (hs > 1) {
-    hipLaunchKernelGGL(k_fusion_ff_h2p<0>, dim3(g.x, g.y, hs), dim3(256), 0, s, x1, wst, vecs, x2, tiles, part);
+    hipLaunchKernelGGL((k_fusion_ff_h2p<0, true>), dim3(g.x, g.y, hs), dim3(256), 0, s, x1, wst, vecs, x2, tiles, part);
     hipLaunchKernelGGL(k_ff_reduce, g, dim3(256), 0, s, part, x1, vecs, x2, tiles, hs);
   }
   else if (pipelined && abl == 1) hipLaunchKernelGGL(k_fusion_ff_h2p<1>, g, dim3(256), 0, s, x1, wst, vecs, x2, tiles, (float*)nullptr);

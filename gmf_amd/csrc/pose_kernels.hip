@@ -185,30 +185,39 @@ GMF_DEVINL void block_sum_tree(double (&v)[NV], double* sh /* >= NV*17 doubles *
 // launcher and a workgroup only writes zeros for the points its candidate range suppresses (the conjunction over ranges
 // needs no ordering; score * 0 keeps the reference's sort order whatever the sign of the zero).
 // ---------------------------------------------------------------------------------------
+typedef float nms_f2 __attribute__((ext_vector_type(2)));
+
 __global__ void __launch_bounds__(256)
 k_nms_keys(const float* __restrict__ src, const float* __restrict__ scores, float* __restrict__ keys, int N, float R2t) {
-  __shared__ float4 sh[256];
+  // candidates of a block as structure-of-arrays so that two of them load as one register pair: the squared distance of a
+  // point to TWO candidates is 6 packed-fp32 instructions (v_pk_add/mul/fma_f32) with the same roundings as the scalar form
+  __shared__ __attribute__((aligned(8))) float sx[256], sy[256], sz[256], sw[256];
   const int pair = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const float* ps = src + (size_t)pair * N * 3;
   const float* sc = scores + (size_t)pair * N;
   float xi = 0, yi = 0, zi = 0, si = 0;
   if (i < N) { xi = ps[3 * i]; yi = ps[3 * i + 1]; zi = ps[3 * i + 2]; si = sc[i]; }
+  const nms_f2 xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
   bool is_max = true;
   const int nblk = (N + 255) / 256, js = gridDim.z;
   const int b0 = (nblk * (int)blockIdx.z) / js, b1 = (nblk * ((int)blockIdx.z + 1)) / js;
   for (int j0 = b0 * 256; j0 < min(N, b1 * 256); j0 += 256) {
     const int j = j0 + threadIdx.x;
     __syncthreads();
-    sh[threadIdx.x] = (j < N) ? make_float4(ps[3 * j], ps[3 * j + 1], ps[3 * j + 2], sc[j])
-                              : make_float4(0.f, 0.f, 0.f, -INFINITY);
+    // padding candidates: score -inf never suppresses anything
+    sx[threadIdx.x] = (j < N) ? ps[3 * j] : 0.f;
+    sy[threadIdx.x] = (j < N) ? ps[3 * j + 1] : 0.f;
+    sz[threadIdx.x] = (j < N) ? ps[3 * j + 2] : 0.f;
+    sw[threadIdx.x] = (j < N) ? sc[j] : -INFINITY;
     __syncthreads();
-    const int lim = min(256, N - j0);
-    for (int jj = 0; jj < lim; ++jj) {
-      const float4 p = sh[jj];
-      const float dx = xi - p.x, dy = yi - p.y, dz = zi - p.z;
-      const float d2 = dx * dx + dy * dy + dz * dz;
-      is_max = is_max && ((si >= p.w) || (d2 >= R2t));     // d2 >= R2t  <=>  sqrtf(d2) >= R  (see launch_nms_keys)
+    const int lim = (min(256, N - j0) + 1) & ~1;
+    for (int jj = 0; jj < lim; jj += 2) {
+      const nms_f2 px = *reinterpret_cast<const nms_f2*>(&sx[jj]), py = *reinterpret_cast<const nms_f2*>(&sy[jj]);
+      const nms_f2 pz = *reinterpret_cast<const nms_f2*>(&sz[jj]), pw = *reinterpret_cast<const nms_f2*>(&sw[jj]);
+      const nms_f2 dx = xi2 - px, dy = yi2 - py, dz = zi2 - pz;
+      const nms_f2 d2 = dx * dx + dy * dy + dz * dz;
+      is_max = is_max && ((si >= pw[0]) || (d2[0] >= R2t)) && ((si >= pw[1]) || (d2[1] >= R2t));   // see launch_nms_keys
     }
   }
   if (i < N) {

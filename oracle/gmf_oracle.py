@@ -210,11 +210,11 @@ def rigid_transform_3d(A, Bp, w=None, weight_threshold: float = 0.0):
     H = (A - ca).transpose(1, 2) @ (w[:, :, None] * (Bp - cb))
     U, _, Vh = torch.linalg.svd(H)
     V = Vh.transpose(1, 2)
-    D = torch.eye(3).repeat(A.shape[0], 1, 1)
+    D = torch.eye(3, dtype=A.dtype).repeat(A.shape[0], 1, 1)
     D[:, 2, 2] = torch.det(V @ U.transpose(1, 2))
     R = V @ D @ U.transpose(1, 2)
     t = cb.transpose(1, 2) - R @ ca.transpose(1, 2)
-    T = torch.eye(4).repeat(A.shape[0], 1, 1)
+    T = torch.eye(4, dtype=A.dtype).repeat(A.shape[0], 1, 1)
     T[:, :3, :3] = R
     T[:, :3, 3:4] = t
     return T

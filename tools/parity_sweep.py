@@ -15,6 +15,8 @@ model = gmf_amd.PointDSC(num_layers=12); model.load_state_dict(sd, strict=False)
 rng = np.random.default_rng(2024)
 torch.set_num_threads(16)
 errs, terrs, rows = [], [], []
+err64_hip, err64_ref = [], []
+sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
 t0 = time.time()
 for s in range(n_scenes):
     N = int(rng.choice([64, 200, 333, 500, 777, 1000, 1500, 2048, 3000]))
@@ -25,6 +27,11 @@ for s in range(n_scenes):
     data["testing"] = True
     res = model(data)
     e = float((model.last_logits.cpu() - ref["logits"]).abs().max())
+    b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()}
+    compat64, _ = O.compat_matrix(b64["src_keypts"], b64["tgt_keypts"], 0.1)
+    truth = O.classifier(sd64, O.encoder(sd64, b64["corr_pos"], compat64, b64["p_tokens"], b64["q_tokens"], 12))
+    err64_hip.append(float((model.last_logits.cpu().double() - truth).abs().max()))
+    err64_ref.append(float((ref["logits"].double() - truth).abs().max()))
     te = float((res["final_trans"].cpu() - ref["final_trans"]).abs().max())
     # seeds are argsort(score * is_local_max, descending)[:S] (PointDSC.py:284-286): when fewer than S local maxima have a
     # positive score, the list continues inside the tie group of zeros (every suppressed point), whose order torch's
@@ -40,6 +47,8 @@ for s in range(n_scenes):
         print(f"{s + 1} scenes, {time.time() - t0:.0f} s: max|dlogit| so far {max(errs):.2e}, max|dT| {max(terrs):.2e}", flush=True)
 errs = np.array(errs); terrs = np.array(terrs)
 print(f"logits: median {np.median(errs):.2e}  p90 {np.quantile(errs, 0.9):.2e}  max {errs.max():.2e}  (gate 1e-4; above gate: {(errs > 1e-4).sum()} of {len(errs)})")
+a, r_ = np.array(err64_hip), np.array(err64_ref)
+print(f"logits against the fp64 evaluation: HIP median {np.median(a):.2e} p90 {np.quantile(a, 0.9):.2e} max {a.max():.2e}   |   fp32 oracle median {np.median(r_):.2e} p90 {np.quantile(r_, 0.9):.2e} max {r_.max():.2e}")
 tie = np.array([r[4] for r in rows])
 print(f"pose, all scenes:                         median {np.median(terrs):.2e}  p90 {np.quantile(terrs, 0.9):.2e}  max {terrs.max():.2e}")
 if (~tie).any():

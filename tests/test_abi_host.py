@@ -151,3 +151,21 @@ def test_image_encoder_matches_reference(golden_dir):
     assert f.shape == (2, 128, 15, 20)
     tok = f.view(2, 128, -1).permute(0, 2, 1)
     assert np.abs(tok.numpy() - g["tokens"]).max() < 1e-4 * max(1.0, np.abs(g["tokens"]).max())
+
+
+def test_oracle_is_only_reachable_from_the_checkers():
+    """The oracle is test infrastructure: nothing in the product package, the dev tools or the
+    C/HIP sources may import or reference it; only tests/, bench.py's cpu_baseline leg and
+    __graft_entry__.smoke()/build() do."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|gmf_oracle", re.M)
+    offenders = []
+    for sub in ("gmf_amd", "tools", "include"):
+        for dirpath, _, files in os.walk(os.path.join(root, sub)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".sh")):
+                    p = os.path.join(dirpath, f)
+                    if pat.search(open(p, errors="ignore").read()):
+                        offenders.append(os.path.relpath(p, root))
+    assert offenders == []

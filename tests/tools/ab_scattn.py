@@ -1,6 +1,6 @@
 """A/B timing of the attention kernel variants in ONE process, interleaved rounds (guide rule 24),
 plus each variant's logit error against the CPU oracle on one pair.  GPU box only:
-    python tools/ab_scattn.py [B] [N]
+    python tests/tools/ab_scattn.py [B] [N]
 """
 import ctypes as C
 import os
@@ -9,7 +9,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import gmf_amd                                   # noqa: E402
 from gmf_amd import _lib, synthetic              # noqa: E402
 

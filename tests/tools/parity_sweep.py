@@ -1,9 +1,9 @@
 """Randomised parity sweep: HIP path vs the CPU oracle over many seeded scenes and sizes (logits and final pose).
-GPU box:  python tools/parity_sweep.py [n_scenes]"""
+GPU box:  python tests/tools/parity_sweep.py [n_scenes]"""
 import os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import gmf_amd
 from gmf_amd import synthetic
 from oracle import gmf_oracle as O

@@ -2,7 +2,7 @@
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import gmf_amd
 from gmf_amd import synthetic
 from oracle import gmf_oracle as O

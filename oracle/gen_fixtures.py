@@ -115,7 +115,70 @@ def gen_f13(reg):
 
 
 
+def gen_f14(pdsc):
+    """F14: validation step (row f-4, forward half) - the reference's non-test forward (M, logits, pose) and its three
+    metrics (libs/loss.py) on seeded scenes.  Inputs are regenerated from the seeds; M is stored whole at N = 96 and
+    as sampled rows + fp64 checksums at N = 257."""
+    import libs.loss as L
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    model = build_ref_pointdsc(pdsc, O.seeded_state_dict(O.pointdsc_shapes(6, 12, 128), seed=7))
+    out = {}
+    for N, seeds in ((96, [61, 62]), (257, [63, 64, 65])):
+        b = O.synthetic_batch(seeds, N=N, T=196)
+        data = {"corr_pos": b["corr_pos"], "src_keypts": b["src_keypts"], "tgt_keypts": b["tgt_keypts"],
+                "p_image": _tok_to_image(b["p_tokens"]), "q_image": _tok_to_image(b["q_tokens"])}
+        res = model(data)
+        M, logits, T = res["M"], res["final_labels"], res["final_trans"]
+        gt = b["gt_labels"]
+        out[f"pair_seeds_N{N}"] = np.array(seeds)
+        out[f"logits_N{N}"], out[f"final_trans_N{N}"] = _np(logits), _np(T)
+        if N <= 96:
+            out[f"M_N{N}"] = _np(M)
+        else:
+            out[f"M_rows_N{N}"] = _np(M[:, ::16])
+        out[f"M_sum_N{N}"] = _np(M.double().sum((1, 2)))
+        out[f"M_sumsq_N{N}"] = _np((M.double() ** 2).sum((1, 2)))
+        cs = L.ClassificationLoss(balanced=True)(logits, gt)
+        out[f"class_N{N}"] = np.array([float(cs[k]) for k in ("loss", "precision", "recall", "f1", "logit_true", "logit_false")])
+        cu = L.ClassificationLoss(balanced=False)(logits, gt)
+        out[f"class_unbalanced_N{N}"] = np.array([float(cu["loss"])])
+        out[f"sm_N{N}"] = np.array([float(L.SpectralMatchingLoss(balanced=True)(M, gt)),
+                                    float(L.SpectralMatchingLoss(balanced=False)(M, gt))])
+        tl = L.TransformationLoss(re_thre=15, te_thre=30)(T, b["gt_trans"], b["src_keypts"], b["tgt_keypts"], logits)
+        out[f"trans_N{N}"] = np.array([float(v) for v in tl])
+        print("F14", N, out[f"class_N{N}"], out[f"sm_N{N}"], out[f"trans_N{N}"])
+    # the metrics on their own, on inputs that reach the corner cases: no predicted inlier in pair 1 (loss term 0,
+    # loss.py:57-59), a pair without any ground-truth inlier, poses far from the ground truth (recall < 100 %)
+    r = np.random.default_rng([114])
+    Bm, Nm = 3, 200
+    pred = torch.from_numpy(r.normal(0, 2, (Bm, Nm)).astype(np.float32))
+    pred[1] = -pred[1].abs() - 0.1
+    gt = torch.from_numpy((r.uniform(size=(Bm, Nm)) < 0.3).astype(np.float32))
+    gt[2] = 0
+    f = torch.from_numpy(r.normal(size=(Bm, Nm, 16)).astype(np.float32))
+    f = f / f.norm(dim=-1, keepdim=True)
+    Mm = torch.clamp(1 - (1 - f @ f.permute(0, 2, 1)) / 0.8 ** 2, min=0, max=1)
+    bb = O.synthetic_batch([71, 72, 73], N=Nm, T=12)
+    T = bb["gt_trans"].clone()
+    T[1, :3, 3] += 0.5
+    T[2, :3, :3] = T[2, :3, :3] @ torch.tensor([[0.0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    out["alone_pred"], out["alone_gt"], out["alone_M"], out["alone_T"] = _np(pred), _np(gt), _np(Mm), _np(T)
+    out["alone_seeds"] = np.array([71, 72, 73])
+    cs = L.ClassificationLoss(balanced=True)(pred, gt)
+    out["alone_class"] = np.array([float(cs[k]) for k in ("loss", "precision", "recall", "f1", "logit_true", "logit_false")])
+    out["alone_class_unbalanced"] = np.array([float(L.ClassificationLoss(balanced=False)(pred, gt)["loss"])])
+    out["alone_sm"] = np.array([float(L.SpectralMatchingLoss(balanced=True)(Mm, gt)),
+                                float(L.SpectralMatchingLoss(balanced=False)(Mm, gt))])
+    out["alone_trans"] = np.array([float(v) for v in L.TransformationLoss()(T, bb["gt_trans"], bb["src_keypts"], bb["tgt_keypts"], pred)])
+    print("F14 alone", out["alone_class"], out["alone_sm"], out["alone_trans"])
+    np.savez_compressed(os.path.join(GOLD, "f14_validation_step.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f14":
+        gen_f14(_import_reference()[0])
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f13":
         gen_f13(_import_reference()[4])
         return

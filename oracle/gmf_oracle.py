@@ -440,3 +440,75 @@ def find_knn_dgr(F0, F1, nn_max_n: int = -1):
         return torch.cat(ix), torch.cat(ds)
     m, j = d2(F0, F1).min(dim=1)
     return j, m[:, None]
+
+
+# --------------------------------------------------------------------------
+# Validation step (forward half): the feature-similarity matrix the non-test forward
+# returns and the three metrics libs/trainer.py:194-262 evaluates on it.
+# --------------------------------------------------------------------------
+def similarity_matrix(feat_n, sigma: float):
+    """PointDSC.py:231-234: M = clamp(1 - (1 - <f_i, f_j>) / sigma^2, 0, 1) with a zero diagonal."""
+    M = torch.matmul(feat_n, feat_n.permute(0, 2, 1))
+    M = torch.clamp(1 - (1 - M) / sigma ** 2, min=0, max=1)
+    idx = torch.arange(M.shape[1])
+    M[:, idx, idx] = 0
+    return M
+
+
+def classification_loss(pred, gt, balanced: bool = True, weight=None):
+    """libs/loss.py:67-113 (ClassificationLoss).  BCE-with-logits over the whole batch, `pos_weight` = #neg / #pos with
+    both counts floored at one; precision / recall / f1 are those of pair 0 only (loss.py:99-101, sklearn's binary
+    scores, 0 when undefined); the mean logits are over the whole batch.  Returns a dict of floats."""
+    gt = gt.float()
+    num_pos = torch.relu(gt.sum() - 1) + 1
+    num_neg = torch.relu((1 - gt).sum() - 1) + 1
+    sp_pos = F.softplus(-pred)        # -log sigmoid(x)
+    sp_neg = F.softplus(pred)         # -log (1 - sigmoid(x))
+    if weight is not None:
+        loss = ((gt * sp_pos + (1 - gt) * sp_neg) * weight).mean()
+    elif not balanced:
+        loss = (gt * sp_pos + (1 - gt) * sp_neg).mean()
+    else:
+        loss = ((num_neg / num_pos) * gt * sp_pos + (1 - gt) * sp_neg).mean()
+    g0, p0 = gt[0] > 0.5, pred[0] > 0
+    tp, fp, fn = float((g0 & p0).sum()), float((~g0 & p0).sum()), float((g0 & ~p0).sum())
+    precision = tp / (tp + fp) if tp + fp > 0 else 0.0
+    recall = tp / (tp + fn) if tp + fn > 0 else 0.0
+    f1 = 2 * tp / (2 * tp + fp + fn) if 2 * tp + fp + fn > 0 else 0.0
+    return {"loss": float(loss), "precision": precision, "recall": recall, "f1": f1,
+            "logit_true": float((pred * gt).sum() / max(1.0, float(gt.sum()))),
+            "logit_false": float((pred * (1 - gt)).sum() / max(1.0, float((1 - gt).sum())))}
+
+
+def spectral_matching_loss(M, gt_labels, balanced: bool = True):
+    """libs/loss.py:116-140 (SpectralMatchingLoss): gt_M = outer AND of the labels with a zero diagonal; balanced form
+    = mean over pairs of half the mean squared miss on the inlier-inlier entries plus half that on the rest."""
+    gt = gt_labels.float()
+    gt_M = ((gt[:, None, :] + gt[:, :, None]) == 2).float()
+    idx = torch.arange(gt_M.shape[1])
+    gt_M[:, idx, idx] = 0
+    if balanced:
+        lp = ((M - 1) ** 2 * gt_M).sum((-1, -2)) / (torch.relu(gt_M.sum((-1, -2)) - 1.0) + 1.0)
+        ln = (M ** 2 * (1 - gt_M)).sum((-1, -2)) / (torch.relu((1 - gt_M).sum((-1, -2)) - 1.0) + 1.0)
+        return float(torch.mean(lp * 0.5 + ln * 0.5))
+    return float(((M - gt_M) ** 2).mean())
+
+
+def transformation_loss(trans, gt_trans, src_keypts, tgt_keypts, probs, re_thre: float = 15.0, te_thre: float = 30.0):
+    """libs/loss.py:12-64 (TransformationLoss).  As the reference, pair i's warped source points are compared with the
+    target points of EVERY pair of the batch (`warp_src_keypts - tgt_keypts` broadcasts [N,3] against [bs,N,3],
+    loss.py:47-48,61): rmse_i and loss_i are means over bs x N points.  Returns (loss, recall %, RE deg, TE cm, RMSE)."""
+    bs = trans.shape[0]
+    recall, RE, TE, RMSE, loss = 0, 0.0, 0.0, 0.0, 0.0
+    for i in range(bs):
+        R, t, gR, gt_t = trans[i, :3, :3], trans[i, :3, 3], gt_trans[i, :3, :3], gt_trans[i, :3, 3]
+        re = torch.acos(torch.clamp((torch.trace(R.T @ gR) - 1) / 2.0, min=-1, max=1)) * 180 / math.pi
+        te = torch.sqrt(((t - gt_t) ** 2).sum()) * 100
+        warp = src_keypts[i] @ R.T + t
+        diff = warp[None] - tgt_keypts
+        if te < te_thre and re < re_thre:
+            recall += 1
+        RE, TE, RMSE = RE + float(re), TE + float(te), RMSE + float(diff.norm(dim=-1).mean())
+        if int((probs[i] > 0).sum()) >= 1:
+            loss += float((diff ** 2).sum(-1).mean())
+    return loss / bs, recall * 100.0 / bs, RE / bs, TE / bs, RMSE / bs

@@ -178,3 +178,55 @@ def test_f13_global_registration(golden_dir, case):
     assert np.abs(t.numpy() - g[f"t_{tag}"]).max() < 1e-5
     # the refinement moved the Procrustes initialisation (the test is not vacuous)
     assert np.abs(g[f"R_{tag}"] - g[f"Rinit_{tag}"]).max() > 1e-3
+
+
+# ---- F14: validation step (row f-4, forward half) ------------------------------------------------------------------
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(1e-12, np.abs(b).max())
+
+
+@pytest.mark.parametrize("N", [96, 257])
+def test_f14_validation_forward(golden_dir, sd_full, N):
+    g = _load(golden_dir, "f14_validation_step.npz")
+    b = O.synthetic_batch(list(g[f"pair_seeds_N{N}"]), N=N, T=196)
+    tr = O.pointdsc_forward(sd_full, b, testing=False)
+    assert np.abs(tr["final_labels"].numpy() - g[f"logits_N{N}"]).max() < 1e-4
+    assert np.abs(tr["final_trans"].numpy() - g[f"final_trans_N{N}"]).max() < 1e-4
+    feat_n = torch.nn.functional.normalize(tr["corr_features"], p=2, dim=-1)
+    M = O.similarity_matrix(feat_n, float(sd_full["sigma"]))
+    if N <= 96:
+        assert np.abs(M.numpy() - g[f"M_N{N}"]).max() < 1e-5
+    else:
+        assert np.abs(M[:, ::16].numpy() - g[f"M_rows_N{N}"]).max() < 1e-5
+    assert _rel(M.double().sum((1, 2)), g[f"M_sum_N{N}"]) < 1e-5
+    assert _rel((M.double() ** 2).sum((1, 2)), g[f"M_sumsq_N{N}"]) < 1e-5
+    assert (torch.diagonal(M, dim1=1, dim2=2) == 0).all() and float(M.min()) >= 0 and float(M.max()) <= 1
+    # metrics on the REFERENCE's outputs (no error carried over from the forward)
+    logits, T = torch.from_numpy(g[f"logits_N{N}"]), torch.from_numpy(g[f"final_trans_N{N}"])
+    cs = O.classification_loss(logits, b["gt_labels"])
+    got = [cs[k] for k in ("loss", "precision", "recall", "f1", "logit_true", "logit_false")]
+    assert np.abs(np.array(got) - g[f"class_N{N}"]).max() < 1e-5
+    assert abs(O.classification_loss(logits, b["gt_labels"], balanced=False)["loss"] - g[f"class_unbalanced_N{N}"][0]) < 1e-5
+    if N <= 96:
+        Mr = torch.from_numpy(g[f"M_N{N}"])
+        assert abs(O.spectral_matching_loss(Mr, b["gt_labels"]) - g[f"sm_N{N}"][0]) < 1e-6
+        assert abs(O.spectral_matching_loss(Mr, b["gt_labels"], balanced=False) - g[f"sm_N{N}"][1]) < 1e-6
+    else:
+        assert abs(O.spectral_matching_loss(M, b["gt_labels"]) - g[f"sm_N{N}"][0]) < 1e-5
+    tl = O.transformation_loss(T, b["gt_trans"], b["src_keypts"], b["tgt_keypts"], logits)
+    assert _rel(tl, g[f"trans_N{N}"]) < 1e-5
+
+
+def test_f14_metrics_corner_cases(golden_dir):
+    g = _load(golden_dir, "f14_validation_step.npz")
+    pred, gt, M, T = (torch.from_numpy(g[k]) for k in ("alone_pred", "alone_gt", "alone_M", "alone_T"))
+    cs = O.classification_loss(pred, gt)
+    got = [cs[k] for k in ("loss", "precision", "recall", "f1", "logit_true", "logit_false")]
+    assert np.abs(np.array(got) - g["alone_class"]).max() < 1e-5
+    assert abs(O.classification_loss(pred, gt, balanced=False)["loss"] - g["alone_class_unbalanced"][0]) < 1e-5
+    assert abs(O.spectral_matching_loss(M, gt) - g["alone_sm"][0]) < 1e-6
+    assert abs(O.spectral_matching_loss(M, gt, balanced=False) - g["alone_sm"][1]) < 1e-6
+    bb = O.synthetic_batch(list(g["alone_seeds"]), N=pred.shape[1], T=12)
+    tl = O.transformation_loss(T, bb["gt_trans"], bb["src_keypts"], bb["tgt_keypts"], pred)
+    assert _rel(tl, g["alone_trans"]) < 1e-5

@@ -86,6 +86,11 @@ SIGNATURES = {
     "gmf_weighted_procrustes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_float, _vp, _vp, _vp]),
     "gmf_global_registration": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                                           C.c_double, _vp, _vp, _vp, C.c_int, _vp]),
+    "gmf_similarity_matrix": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp]),
+    "gmf_spectral_matching_loss": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "gmf_spectral_matching_loss_fused": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp]),
+    "gmf_classification_loss": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "gmf_transformation_loss": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float, _vp, _vp]),
 }
 
 _lib = None

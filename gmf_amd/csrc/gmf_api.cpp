@@ -669,4 +669,75 @@ int gmf_global_registration(gmf_handle* h, const float* X, const float* Y, const
   return GMF_OK;
 }
 
+int gmf_similarity_matrix(gmf_handle* h, const float* feat_n, int B, int N, float sigma, float* M, int ldm,
+                          gmf_stream_t stream) {
+  GMF_REQUIRE(h && feat_n && M, GMF_ERR_BAD_ARG, "similarity_matrix: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "similarity_matrix: empty input");
+  GMF_REQUIRE(ldm >= N, GMF_ERR_BAD_ARG, "similarity_matrix: ldm (row stride of M in floats) must be >= N");
+  GMF_REQUIRE(sigma != 0.f, GMF_ERR_BAD_ARG, "similarity_matrix: sigma must be non-zero");
+  SetDevice sd(h);
+  const size_t n_img = gmf::similarity_image_floats(B, N);
+  if (int rc = arena_reserve(h, arena_need(n_img, 4))) return rc;
+  float* img = arena_take<float>(h, n_img);
+  GMF_HIP(gmf::launch_similarity_matrix(feat_n, img, M, B, N, ldm, sigma, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_spectral_matching_loss(gmf_handle* h, const float* M, int ldm, const float* gt_labels, int B, int N, int balanced,
+                               float* loss_out, gmf_stream_t stream) {
+  GMF_REQUIRE(h && M && gt_labels && loss_out, GMF_ERR_BAD_ARG, "spectral_matching_loss: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "spectral_matching_loss: empty input");
+  GMF_REQUIRE(ldm >= N, GMF_ERR_BAD_ARG, "spectral_matching_loss: ldm (row stride of M in floats) must be >= N");
+  SetDevice sd(h);
+  const size_t n_part = (size_t)2 * B * gmf::sm_parts_per_pair(B, N);
+  if (int rc = arena_reserve(h, arena_need(n_part, 8) + arena_need((size_t)B, 8))) return rc;
+  double* part = arena_take<double>(h, n_part);
+  double* pair_loss = arena_take<double>(h, (size_t)B);
+  GMF_HIP(gmf::launch_sm_loss(M, ldm, gt_labels, part, pair_loss, B, N, balanced, loss_out, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_spectral_matching_loss_fused(gmf_handle* h, const float* feat_n, const float* gt_labels, int B, int N, float sigma,
+                                     int balanced, float* loss_out, gmf_stream_t stream) {
+  GMF_REQUIRE(h && feat_n && gt_labels && loss_out, GMF_ERR_BAD_ARG, "spectral_matching_loss_fused: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "spectral_matching_loss_fused: empty input");
+  GMF_REQUIRE(sigma != 0.f, GMF_ERR_BAD_ARG, "spectral_matching_loss_fused: sigma must be non-zero");
+  SetDevice sd(h);
+  const size_t n_img = gmf::similarity_image_floats(B, N);
+  const size_t n_part = (size_t)2 * B * gmf::sm_fused_parts_per_pair(B, N);
+  if (int rc = arena_reserve(h, arena_need(n_img, 4) + arena_need(n_part, 8) + arena_need((size_t)B, 8))) return rc;
+  float* img = arena_take<float>(h, n_img);
+  double* part = arena_take<double>(h, n_part);
+  double* pair_loss = arena_take<double>(h, (size_t)B);
+  GMF_HIP(gmf::launch_sm_loss_fused(feat_n, gt_labels, img, part, pair_loss, B, N, sigma, balanced, loss_out, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_classification_loss(gmf_handle* h, const float* pred, const float* gt, const float* weight, int B, int N,
+                            int balanced, float* out6, gmf_stream_t stream) {
+  GMF_REQUIRE(h && pred && gt && out6, GMF_ERR_BAD_ARG, "classification_loss: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "classification_loss: empty input");
+  SetDevice sd(h);
+  const size_t n_part = (size_t)9 * gmf::classification_parts(B, N);
+  if (int rc = arena_reserve(h, arena_need(n_part, 8))) return rc;
+  double* part = arena_take<double>(h, n_part);
+  GMF_HIP(gmf::launch_classification_loss(pred, gt, weight, part, B, N, balanced, out6, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_transformation_loss(gmf_handle* h, const float* trans, const float* gt_trans, const float* src_keypts,
+                            const float* tgt_keypts, const float* probs, int B, int N, float re_thre, float te_thre,
+                            float* out5, gmf_stream_t stream) {
+  GMF_REQUIRE(h && trans && gt_trans && src_keypts && tgt_keypts && probs && out5, GMF_ERR_BAD_ARG,
+              "transformation_loss: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "transformation_loss: empty input");
+  SetDevice sd(h);
+  const size_t n_part = (size_t)3 * B * gmf::transformation_slices(B, N);
+  if (int rc = arena_reserve(h, arena_need(n_part, 8))) return rc;
+  double* part = arena_take<double>(h, n_part);
+  GMF_HIP(gmf::launch_transformation_loss(trans, gt_trans, src_keypts, tgt_keypts, probs, part, B, N, re_thre, te_thre,
+                                          out5, S(stream)));
+  return GMF_OK;
+}
+
 }  // extern "C"

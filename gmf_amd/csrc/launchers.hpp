@@ -62,4 +62,22 @@ hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int 
 hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s);
 hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s);
 
+// validation step (row f-4, forward half): validation_kernels.hip
+size_t similarity_image_floats(int B, int N);
+int sm_fused_parts_per_pair(int B, int N);
+int sm_parts_per_pair(int B, int N);
+int classification_parts(int B, int N);
+int transformation_slices(int B, int N);
+hipError_t launch_similarity_matrix(const float* feat_n, float* img, float* M, int B, int N, int ldm, float sigma,
+                                    hipStream_t s);
+hipError_t launch_sm_loss_fused(const float* feat_n, const float* gt, float* img, double* part, double* pair_loss, int B,
+                                int N, float sigma, int balanced, float* out, hipStream_t s);
+hipError_t launch_sm_loss(const float* M, int ldm, const float* gt, double* part, double* pair_loss, int B, int N,
+                          int balanced, float* out, hipStream_t s);
+hipError_t launch_classification_loss(const float* pred, const float* gt, const float* weight, double* part, int B, int N,
+                                      int balanced, float* out, hipStream_t s);
+hipError_t launch_transformation_loss(const float* trans, const float* gt_trans, const float* src, const float* tgt,
+                                      const float* probs, double* part, int B, int N, float re_thre, float te_thre,
+                                      float* out, hipStream_t s);
+
 }  // namespace gmf

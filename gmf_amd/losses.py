@@ -1,0 +1,127 @@
+"""Validation metrics of the PointDSC plugin surface (reference: GMF_PointDSC/libs/loss.py; caller
+libs/trainer.py:194-262, evaluate()).  Forward only: the three modules the reference's `evaluate_metric` dict holds,
+with its class names, constructor arguments, call signatures and return values, each one launch sequence of
+libgmf_hip.so over the C ABI.  Backward (the training half of SURVEY section 8 row f-4) is not built: the modules
+raise if an input requires grad."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ._util import handle_and_stream, require_cuda_f32
+
+
+def _no_grad(*tensors):
+    for t in tensors:
+        if t is not None and t.requires_grad and torch.is_grad_enabled():
+            raise RuntimeError("gmf_amd.losses: forward-only metrics (validation); call under torch.no_grad() - "
+                               "the backward pass is not implemented")
+
+
+def similarity_matrix(feat_n: torch.Tensor, sigma: float, contiguous: bool = False) -> torch.Tensor:
+    """PointDSC.py:231-234: feat_n [B,N,128] unit rows -> M [B,N,N] = clamp(1 - (1 - Fn Fn^T)/sigma^2, 0, 1), diag 0.
+
+    By default M is a [B,N,N] view whose rows are padded to a multiple of 32 floats (stride(1) = ceil(N/32)*32): every
+    row piece the kernel stores is then a whole 128-byte line, which nearly doubles the store rate at N = 5000.  All
+    torch operations accept the view; `contiguous=True` writes the dense layout instead."""
+    f = require_cuda_f32(feat_n, "feat_n").contiguous()
+    if f.dim() != 3 or f.shape[2] != 128:
+        raise RuntimeError("gmf_amd.similarity_matrix: expected feat_n [B,N,128]")
+    B, N, _ = f.shape
+    ldm = N if contiguous else (N + 31) // 32 * 32
+    buf = torch.empty((B, N, ldm), device=f.device, dtype=torch.float32)
+    h, st = handle_and_stream(f)
+    h.call("gmf_similarity_matrix", f.data_ptr(), B, N, float(sigma), buf.data_ptr(), ldm, st)
+    return buf if ldm == N else buf[:, :, :N]
+
+
+class ClassificationLoss(nn.Module):
+    """libs/loss.py:67-113.  forward(pred [bs,N] logits, gt [bs,N] 0/1, weight=None) -> dict with 'loss' (0-dim device
+    tensor) and the floats 'precision', 'recall', 'f1' (pair 0 only, as the reference), 'logit_true', 'logit_false'."""
+
+    def __init__(self, balanced=True):
+        super().__init__()
+        self.balanced = balanced
+
+    def forward(self, pred, gt, weight=None):
+        _no_grad(pred, weight)
+        pred = require_cuda_f32(pred, "pred").contiguous()
+        gt = gt.to(device=pred.device, dtype=torch.float32).contiguous()
+        if pred.dim() != 2 or gt.shape != pred.shape:
+            raise RuntimeError("gmf_amd.ClassificationLoss: expected pred and gt of shape [bs, num_corr]")
+        w = None
+        if weight is not None:
+            w = require_cuda_f32(weight, "weight").expand_as(pred).contiguous()
+        out = torch.empty(6, device=pred.device, dtype=torch.float32)
+        h, st = handle_and_stream(pred)
+        h.call("gmf_classification_loss", pred.data_ptr(), gt.data_ptr(), None if w is None else w.data_ptr(),
+               pred.shape[0], pred.shape[1], 1 if self.balanced else 0, out.data_ptr(), st)
+        host = out.cpu()          # the reference also leaves the device here (sklearn scores, loss.py:98-104)
+        return {"loss": out[0], "precision": float(host[1]), "recall": float(host[2]), "f1": float(host[3]),
+                "logit_true": float(host[4]), "logit_false": float(host[5])}
+
+
+class SpectralMatchingLoss(nn.Module):
+    """libs/loss.py:116-140.  forward(M [bs,N,N], gt_labels [bs,N]) -> 0-dim device tensor.
+
+    `from_features(feat_n, sigma, gt_labels)` gives the same value without M ever being written (the N x N product is
+    reduced tile by tile): the form to use when only the loss, not M itself, is wanted."""
+
+    def __init__(self, balanced=True):
+        super().__init__()
+        self.balanced = balanced
+
+    def forward(self, M, gt_labels):
+        _no_grad(M)
+        M = require_cuda_f32(M, "M")
+        if M.dim() != 3 or M.shape[1] != M.shape[2] or tuple(gt_labels.shape) != tuple(M.shape[:2]):
+            raise RuntimeError("gmf_amd.SpectralMatchingLoss: expected M [bs,N,N] and gt_labels [bs,N]")
+        N = M.shape[1]
+        if not (M.stride(2) == 1 and M.stride(1) >= N and M.stride(0) == N * M.stride(1)):   # row-padded views pass
+            M = M.contiguous()
+        gt = gt_labels.to(device=M.device, dtype=torch.float32).contiguous()
+        out = torch.empty(1, device=M.device, dtype=torch.float32)
+        h, st = handle_and_stream(M)
+        h.call("gmf_spectral_matching_loss", M.data_ptr(), M.stride(1), gt.data_ptr(), M.shape[0], N,
+               1 if self.balanced else 0, out.data_ptr(), st)
+        return out[0]
+
+    def from_features(self, feat_n, sigma, gt_labels):
+        _no_grad(feat_n)
+        f = require_cuda_f32(feat_n, "feat_n").contiguous()
+        gt = gt_labels.to(device=f.device, dtype=torch.float32).contiguous()
+        if f.dim() != 3 or f.shape[2] != 128 or gt.shape != f.shape[:2]:
+            raise RuntimeError("gmf_amd.SpectralMatchingLoss.from_features: expected feat_n [bs,N,128] and gt_labels [bs,N]")
+        out = torch.empty(1, device=f.device, dtype=torch.float32)
+        h, st = handle_and_stream(f)
+        h.call("gmf_spectral_matching_loss_fused", f.data_ptr(), gt.data_ptr(), f.shape[0], f.shape[1], float(sigma),
+               1 if self.balanced else 0, out.data_ptr(), st)
+        return out[0]
+
+
+class TransformationLoss(nn.Module):
+    """libs/loss.py:12-64.  forward(trans, gt_trans [bs,4,4], src_keypts, tgt_keypts [bs,N,3], probs [bs,N]) ->
+    (loss, recall %, RE deg, TE cm, RMSE); loss, RE, TE, RMSE are 0-dim device tensors, recall a float, as the
+    reference returns them."""
+
+    def __init__(self, re_thre=15, te_thre=30):
+        super().__init__()
+        self.re_thre = re_thre
+        self.te_thre = te_thre
+
+    def forward(self, trans, gt_trans, src_keypts, tgt_keypts, probs):
+        _no_grad(trans, probs)
+        trans = require_cuda_f32(trans, "trans").contiguous()
+        dev = trans.device
+        gt_trans = gt_trans.to(device=dev, dtype=torch.float32).contiguous()
+        src = require_cuda_f32(src_keypts, "src_keypts").contiguous()
+        tgt = require_cuda_f32(tgt_keypts, "tgt_keypts").contiguous()
+        probs = require_cuda_f32(probs, "probs").contiguous()
+        bs, N = probs.shape
+        if trans.shape != (bs, 4, 4) or gt_trans.shape != (bs, 4, 4) or src.shape != (bs, N, 3) or tgt.shape != (bs, N, 3):
+            raise RuntimeError("gmf_amd.TransformationLoss: expected trans, gt_trans [bs,4,4], keypts [bs,N,3], probs [bs,N]")
+        out = torch.empty(5, device=dev, dtype=torch.float32)
+        h, st = handle_and_stream(trans)
+        h.call("gmf_transformation_loss", trans.data_ptr(), gt_trans.data_ptr(), src.data_ptr(), tgt.data_ptr(),
+               probs.data_ptr(), bs, N, float(self.re_thre), float(self.te_thre), out.data_ptr(), st)
+        return out[0], float(out[1]), out[2], out[3], out[4]

@@ -12,6 +12,7 @@ from torch import nn
 from . import _lib, packing
 from ._util import WeightWatcher, handle_and_stream, params_version, require_cuda_f32
 from .fusion_layer import FusionLayer
+from .losses import similarity_matrix
 
 
 # ------------------------------------------------------------------------------------------------
@@ -341,11 +342,7 @@ class PointDSC(nn.Module):
             final_trans, labels, _ = self.pose_head(feat_n, src, tgt, logits, testing)
             M = None
             if not testing:
-                # training-loss input (PointDSC.py:231-234); not on the inference hot path, plain torch
-                M = torch.matmul(feat_n, feat_n.permute(0, 2, 1))
-                M = torch.clamp(1 - (1 - M) / self.sigma ** 2, min=0, max=1)
-                idx = torch.arange(M.shape[1], device=M.device)
-                M[:, idx, idx] = 0
+                M = similarity_matrix(feat_n, self._weights(feat_n.device).sigma)       # PointDSC.py:231-234
         return {"final_trans": final_trans, "final_labels": labels if testing else logits, "M": M}
 
     # reference-named helpers, batched --------------------------------------------------------------

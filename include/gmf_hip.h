@@ -244,6 +244,39 @@ int gmf_global_registration(gmf_handle* h, const float* X, const float* Y, const
                             double break_threshold_ratio, float* R, float* t, float* stats, int max_points,
                             gmf_stream_t stream);
 
+/* ---- validation step: the non-test forward's similarity matrix and the metrics of libs/trainer.py:194-262 ---------- */
+
+/* M = clamp(1 - (1 - Fn Fn^T) / sigma^2, 0, 1) with a zero diagonal (GMF_PointDSC/models/PointDSC.py:231-234):
+ * feat_n [B,N,128] unit rows -> M [B,N,N] with row stride ldm >= N floats (element (b,i,j) at M[(b*N + i)*ldm + j];
+ * the padding columns are not written).  Split-fp16 MFMA product, fp32 accumulate; writing M is the bound, and a row
+ * stride that is a multiple of 32 floats (whole 128-byte lines per row piece) nearly doubles the store rate. */
+int gmf_similarity_matrix(gmf_handle* h, const float* feat_n, int B, int N, float sigma, float* M, int ldm,
+                          gmf_stream_t stream);
+
+/* SpectralMatchingLoss.forward(M, gt_labels) (GMF_PointDSC/libs/loss.py:116-140): M [B,N,N] with row stride ldm,
+ * gt_labels [B,N] float 0/1 -> loss_out [1] (device).  balanced != 0 is the reference's default form. */
+int gmf_spectral_matching_loss(gmf_handle* h, const float* M, int ldm, const float* gt_labels, int B, int N, int balanced,
+                               float* loss_out, gmf_stream_t stream);
+
+/* The same loss straight from the features: gmf_similarity_matrix followed by gmf_spectral_matching_loss without M
+ * ever reaching memory (upper triangle of tiles only, reduced on the fly). */
+int gmf_spectral_matching_loss_fused(gmf_handle* h, const float* feat_n, const float* gt_labels, int B, int N, float sigma,
+                                     int balanced, float* loss_out, gmf_stream_t stream);
+
+/* ClassificationLoss.forward(pred, gt, weight) (GMF_PointDSC/libs/loss.py:67-113): pred [B,N] logits, gt [B,N] float
+ * 0/1, weight [B,N] or NULL -> out [6] (device) = loss, precision, recall, f1 (pair 0, as loss.py:99-101), mean logit of
+ * the inliers, mean logit of the outliers. */
+int gmf_classification_loss(gmf_handle* h, const float* pred, const float* gt, const float* weight, int B, int N,
+                            int balanced, float* out6, gmf_stream_t stream);
+
+/* TransformationLoss.forward(trans, gt_trans, src_keypts, tgt_keypts, probs) (GMF_PointDSC/libs/loss.py:12-64):
+ * trans, gt_trans [B,4,4]; src_keypts, tgt_keypts [B,N,3]; probs [B,N] -> out [5] (device) = loss, recall (%), RE (deg),
+ * TE (cm), RMSE.  As the reference, pair i's warped source points are compared with the target points of every pair of
+ * the batch (loss.py:47-48,61 broadcast [N,3] against [bs,N,3]). */
+int gmf_transformation_loss(gmf_handle* h, const float* trans, const float* gt_trans, const float* src_keypts,
+                            const float* tgt_keypts, const float* probs, int B, int N, float re_thre, float te_thre,
+                            float* out5, gmf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -593,3 +593,104 @@ def test_pose_parity_beyond_golden_sizes(sd_full, N):
     _, _, aux = m.pose_head(m.last_features, data["src_keypts"], data["tgt_keypts"], m.last_logits, True, return_aux=True)
     assert np.array_equal(aux["seeds"][0].cpu().numpy(), ref["seeds"][0].numpy())
     assert _maxerr(res["final_trans"].cpu(), ref["final_trans"]) < 1e-4
+
+
+# ---- validation step (row f-4, forward half): golden F14 from the reference's forward and libs/loss.py ---------------
+_CLS = ("loss", "precision", "recall", "f1", "logit_true", "logit_false")
+
+
+def _rel(a, b):
+    a, b = np.asarray([float(v) for v in a], np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("N", [96, 257])
+def test_f14_validation_step(golden_dir, model, N):
+    """eval-mode forward without 'testing' (libs/trainer.py:233) -> M, logits, pose; then the three metrics."""
+    g = _load(golden_dir, "f14_validation_step.npz")
+    b = synthetic.synthetic_batch(list(g[f"pair_seeds_N{N}"]), N=N, T=196)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    res = model(data)
+    M, logits, T = res["M"], res["final_labels"], res["final_trans"]
+    assert _maxerr(logits.cpu(), g[f"logits_N{N}"]) < 1e-4
+    assert _maxerr(T.cpu(), g[f"final_trans_N{N}"]) < 1e-4
+    assert M.shape == (len(b["corr_pos"]), N, N)
+    if N <= 96:
+        assert _maxerr(M.cpu(), g[f"M_N{N}"]) < 2e-5
+    else:
+        assert _maxerr(M[:, ::16].cpu(), g[f"M_rows_N{N}"]) < 2e-5
+    assert _rel(M.double().sum((1, 2)).cpu(), g[f"M_sum_N{N}"]) < 1e-5
+    assert _rel((M.double() ** 2).sum((1, 2)).cpu(), g[f"M_sumsq_N{N}"]) < 1e-5
+    assert bool((torch.diagonal(M, dim1=1, dim2=2) == 0).all()) and float(M.min()) >= 0 and float(M.max()) <= 1
+    gt = _gpu(b["gt_labels"])
+    # metrics on the reference's own outputs: isolates each metric kernel
+    rl, rT = _gpu(torch.from_numpy(g[f"logits_N{N}"])), _gpu(torch.from_numpy(g[f"final_trans_N{N}"]))
+    cs = gmf_amd.ClassificationLoss(balanced=True)(rl, gt)
+    assert np.abs(np.array([float(cs[k]) for k in _CLS]) - g[f"class_N{N}"]).max() < 1e-5
+    cu = gmf_amd.ClassificationLoss(balanced=False)(rl, gt)
+    assert abs(float(cu["loss"]) - g[f"class_unbalanced_N{N}"][0]) < 1e-5
+    sm_b, sm_u = gmf_amd.SpectralMatchingLoss(balanced=True), gmf_amd.SpectralMatchingLoss(balanced=False)
+    if N <= 96:
+        Mr = _gpu(torch.from_numpy(g[f"M_N{N}"]))
+        assert abs(float(sm_b(Mr, gt)) - g[f"sm_N{N}"][0]) < 1e-6
+        assert abs(float(sm_u(Mr, gt)) - g[f"sm_N{N}"][1]) < 1e-6
+    # ... and end to end on the HIP path's own M, both forms
+    assert abs(float(sm_b(M, gt)) - g[f"sm_N{N}"][0]) < 1e-5
+    assert abs(float(sm_u(M, gt)) - g[f"sm_N{N}"][1]) < 1e-5
+    feat_n = model.last_features
+    assert abs(float(sm_b.from_features(feat_n, model._weights(feat_n.device).sigma, gt)) - g[f"sm_N{N}"][0]) < 1e-5
+    assert abs(float(sm_u.from_features(feat_n, model._weights(feat_n.device).sigma, gt)) - g[f"sm_N{N}"][1]) < 1e-5
+    tl = gmf_amd.TransformationLoss(re_thre=15, te_thre=30)(rT, _gpu(b["gt_trans"]), data["src_keypts"], data["tgt_keypts"], rl)
+    ref = g[f"trans_N{N}"]
+    assert abs(float(tl[0]) - ref[0]) < 1e-5 * abs(ref[0]) and tl[1] == ref[1]
+    assert abs(float(tl[2]) - ref[2]) < 2e-3          # RE: acos of an fp32 trace, ill-conditioned near 0 deg
+    assert abs(float(tl[3]) - ref[3]) < 1e-4 * abs(ref[3]) and abs(float(tl[4]) - ref[4]) < 1e-5 * abs(ref[4])
+
+
+def test_f14_metrics_corner_cases(golden_dir):
+    """No predicted inlier in a pair (zero loss term), a pair without ground-truth inliers, recall below 100 %."""
+    g = _load(golden_dir, "f14_validation_step.npz")
+    pred, gt, M, T = (_gpu(torch.from_numpy(g[k])) for k in ("alone_pred", "alone_gt", "alone_M", "alone_T"))
+    cs = gmf_amd.ClassificationLoss()(pred, gt)
+    assert np.abs(np.array([float(cs[k]) for k in _CLS]) - g["alone_class"]).max() < 1e-5
+    assert abs(float(gmf_amd.ClassificationLoss(balanced=False)(pred, gt)["loss"]) - g["alone_class_unbalanced"][0]) < 1e-5
+    assert abs(float(gmf_amd.SpectralMatchingLoss()(M, gt)) - g["alone_sm"][0]) < 1e-6
+    assert abs(float(gmf_amd.SpectralMatchingLoss(balanced=False)(M, gt)) - g["alone_sm"][1]) < 1e-6
+    bb = synthetic.synthetic_batch(list(g["alone_seeds"]), N=pred.shape[1], T=12)
+    tl = gmf_amd.TransformationLoss()(T, _gpu(bb["gt_trans"]), _gpu(bb["src_keypts"]), _gpu(bb["tgt_keypts"]), pred)
+    ref = g["alone_trans"]
+    assert _rel(tl, ref) < 1e-5
+    # weighted form (loss.py:88-90) against the oracle
+    w = torch.rand_like(pred)
+    want = O.classification_loss(pred.cpu(), gt.cpu(), weight=w.cpu())["loss"]
+    assert abs(float(gmf_amd.ClassificationLoss()(pred, gt, weight=w)["loss"]) - want) < 1e-5
+
+
+@pytest.mark.parametrize("B,N", [(1, 31), (2, 1000), (3, 2049)])
+def test_similarity_matrix_sizes(B, N):
+    """Ragged sizes, several column chunks and row groups; against the oracle on the same unit features; the fused
+    loss against the loss of the written matrix."""
+    gen = torch.Generator().manual_seed(N)
+    f = torch.nn.functional.normalize(torch.randn(B, N, 128, generator=gen), dim=-1)
+    f[:, 1::2] = torch.nn.functional.normalize(f[:, 1::2] + 2.0 * f[:, 0::2][:, : f[:, 1::2].shape[1]], dim=-1)   # correlated rows: M not all zero
+    gt = (torch.rand(B, N, generator=gen) < 0.3).float()
+    for sigma in (1.0, 0.6):
+        want = O.similarity_matrix(f, sigma)
+        got = gmf_amd.similarity_matrix(_gpu(f), sigma)
+        assert _maxerr(got.cpu(), want) < 2e-5
+        assert float(want.max()) > 0.3
+        dense = gmf_amd.similarity_matrix(_gpu(f), sigma, contiguous=True)     # ldm = N: same values, dense layout
+        assert dense.is_contiguous() and got.stride(1) % 32 == 0 and torch.equal(dense, got)
+        for balanced in (True, False):
+            sm = gmf_amd.SpectralMatchingLoss(balanced=balanced)
+            ref = O.spectral_matching_loss(want, gt, balanced=balanced)
+            assert abs(float(sm(got, _gpu(gt))) - ref) < 1e-5 * max(1.0, abs(ref))
+            assert abs(float(sm.from_features(_gpu(f), sigma, _gpu(gt))) - ref) < 1e-5 * max(1.0, abs(ref))
+
+
+def test_validation_modules_are_forward_only():
+    x = torch.zeros(1, 8, device=DEV, requires_grad=True)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        gmf_amd.ClassificationLoss()(x, torch.zeros(1, 8, device=DEV))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        gmf_amd.ClassificationLoss()(torch.zeros(1, 8), torch.zeros(1, 8))

@@ -136,6 +136,10 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     gmf::set_use_cache(value != 0);
     return GMF_OK;
   }
+  if (std::strcmp(name, "topk_select") == 0) {         // 1 = radix select of the S seeds (default), 0 = full bitonic sort
+    gmf::set_topk_select(value != 0);
+    return GMF_OK;
+  }
   if (std::strcmp(name, "h2_double_buffer") == 0) {
     gmf::set_h2_dbuf(value != 0);
     return GMF_OK;

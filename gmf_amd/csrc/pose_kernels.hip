@@ -262,6 +262,110 @@ k_sort_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, in
 }
 
 // ---------------------------------------------------------------------------------------
+// The same result without sorting all N keys: radix-select the S-th element of the order (key descending, index
+// ascending), compact the S winners in index order, then place each by counting the winners before it.
+//   d = ~monotone(key) as uint32 (ascending d = descending key; -0 is folded onto +0 so that float equality and bit
+//   equality agree); four 8-bit passes of an LDS histogram narrow the threshold; keys equal to the threshold are taken
+//   lowest index first.  After NMS most keys are exactly zero (PointDSC.py:285), so zeros are counted per wave with a
+//   popcount instead of one LDS atomic each.  ~10 passes over LDS with ~20 barriers instead of the 91 compare-exchange
+//   passes of the bitonic network at N = 5000.
+// grid (B), block 1024, dynamic LDS = N*4 + S*8 bytes
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_select_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, int S) {
+  extern __shared__ unsigned char smem_raw[];
+  unsigned* d = reinterpret_cast<unsigned*>(smem_raw);                                   // [N]
+  unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem_raw + (((size_t)N * 4 + 7) & ~(size_t)7));   // [S]
+  __shared__ unsigned hist[256];
+  __shared__ unsigned wtot[16];
+  __shared__ unsigned s_prefix, s_rank;
+  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr unsigned kZero = 0x7fffffffu;          // d of +0.0
+  for (int t = tid; t < N; t += 1024) {
+    float f = keys[(size_t)pair * N + t];
+    if (f == 0.0f) f = 0.0f;                       // -0 -> +0
+    const unsigned bits = __float_as_uint(f);
+    const unsigned u = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+    d[t] = ~u;
+  }
+  __syncthreads();
+  unsigned prefix = 0, mask = 0, r = (unsigned)(S - 1);                                  // 0-based rank still to resolve
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    unsigned zc = 0;
+    for (int t = tid; t < N; t += 1024) {
+      const unsigned v = d[t];
+      if ((v & mask) == prefix) {
+        if (v == kZero) ++zc; else atomicAdd(&hist[(v >> shift) & 255u], 1u);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zc += __shfl_xor(zc, o, 64);
+    if (lane == 0 && zc) atomicAdd(&hist[(kZero >> shift) & 255u], zc);
+    __syncthreads();
+    if (tid < 256) {                               // inclusive scan of the 256 bins: four waves of 64 bins
+      unsigned inc = hist[tid];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+      }
+      if (lane == 63) wtot[wave] = inc;
+      hist[tid] = inc;                             // own bin only: no hazard
+    }
+    __syncthreads();
+    if (tid < 256) {
+      unsigned base = 0;
+      for (int w = 0; w < wave; ++w) base += wtot[w];
+      const unsigned own = (lane == 0) ? hist[tid] : hist[tid] - hist[tid - 1];         // count of bin tid
+      const unsigned inc = hist[tid] + base, before = inc - own;
+      if (before <= r && r < inc) { s_prefix = (unsigned)tid; s_rank = r - before; }
+    }
+    __syncthreads();
+    prefix |= s_prefix << shift;
+    mask |= 255u << shift;
+    r = s_rank;
+    __syncthreads();
+  }
+  const unsigned thr = prefix, need_eq = r + 1;    // winners: d < thr, and the first need_eq of d == thr by index
+  // ordered compaction: thread t owns the contiguous indices [t * per, (t + 1) * per)
+  const int per = (N + 1023) / 1024, lo = tid * per, hi = min(N, lo + per);
+  unsigned cnt = 0;                                // low 16 bits: d < thr, high 16 bits: d == thr  (N <= 16384)
+  for (int t = lo; t < hi; ++t) cnt += (d[t] < thr ? 1u : 0u) + (d[t] == thr ? 0x10000u : 0u);
+  unsigned inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  unsigned base = 0;
+  for (int w = 0; w < wave; ++w) base += wtot[w];
+  unsigned before = base + inc - cnt;
+  unsigned lt_b = before & 0xffffu, eq_b = before >> 16;
+  for (int t = lo; t < hi; ++t) {
+    const unsigned v = d[t];
+    if (v < thr) {
+      sel[lt_b + min(eq_b, need_eq)] = ((unsigned long long)v << 32) | (unsigned)t;
+      ++lt_b;
+    } else if (v == thr) {
+      if (eq_b < need_eq) sel[lt_b + eq_b] = ((unsigned long long)v << 32) | (unsigned)t;
+      ++eq_b;
+    }
+  }
+  __syncthreads();
+  // rank of every winner among the winners = its output position
+  for (int e = tid; e < S; e += 1024) {
+    const unsigned long long me = sel[e];
+    int rank = 0;
+    for (int j = 0; j < S; ++j) rank += sel[j] < me ? 1 : 0;
+    out_idx[(size_t)pair * S + rank] = (int)(unsigned)(me & 0xffffffffull);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // kNN of the seed rows only: for seed s, the k+1 smallest of d_j = 2 - 2 <f_s, f_j>, ascending
 // (ties: lower index first), first one dropped (common.py:70-74).  feat_n row-major [B,N,128].
 // grid (S, B), block 256, dynamic LDS = N*4 bytes
@@ -1182,9 +1286,25 @@ hipError_t launch_nms_keys(const float* src, const float* scores, float* keys, i
   return hipGetLastError();
 }
 
+static int g_topk_select = 1;      // 1 = radix select + rank placement (default), 0 = full bitonic sort
+void set_topk_select(bool on) { g_topk_select = on ? 1 : 0; }
+
 hipError_t launch_sort_topk(const float* keys, int* out_idx, int B, int N, int S, hipStream_t s) {
   const int M = next_pow2(N < 2 ? 2 : N);
   if (M > 16384) return hipErrorInvalidValue;
+  constexpr size_t kSelectLds = 156 * 1024;        // dynamic LDS the select kernel may use (160 KiB minus its static arrays)
+  const size_t need = (size_t)N * 4 + 8 + (size_t)S * 8;
+  if (g_topk_select && S >= 1 && S <= N && need <= kSelectLds) {
+    static bool attr2_set = false;
+    if (!attr2_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_topk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)kSelectLds);
+      if (e != hipSuccess) return e;
+      attr2_set = true;
+    }
+    hipLaunchKernelGGL(k_select_topk, dim3(B), dim3(1024), need, s, keys, out_idx, N, S);
+    return hipGetLastError();
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);

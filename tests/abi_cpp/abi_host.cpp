@@ -81,6 +81,39 @@ int main() {
   CHECK_HIP(hipMemcpy(S.data(), dS, B * 3 * 4, hipMemcpyDeviceToHost));
   for (int b = 0; b < B; ++b) std::printf("  pair %d: %d Adam steps, loss %.4f, break count %d\n", b, (int)S[3 * b], S[3 * b + 1], (int)S[3 * b + 2]);
 
+
+  // validation step: one-hot unit features -> M[i][j] = 1 when the hot index matches (i != j), clamp(1 - 1/sigma^2) otherwise;
+  // the fused spectral-matching loss equals the loss of the written matrix; a perfect pose scores 100 % recall
+  {
+    const int VB = 2, VN = 300, ldm = 320;
+    const float sigma = 1.25f, off_val = 1.0f - 1.0f / (sigma * sigma);
+    std::vector<float> F((size_t)VB * VN * 128, 0.f), gt((size_t)VB * VN), Mh((size_t)VB * VN * ldm);
+    for (int b = 0; b < VB; ++b)
+      for (int i = 0; i < VN; ++i) { F[((size_t)b * VN + i) * 128 + (i * 7 + b) % 128] = 1.f; gt[(size_t)b * VN + i] = (i % 3 == 0) ? 1.f : 0.f; }
+    float *dF, *dG, *dM, *dL;
+    CHECK_HIP(hipMalloc(&dF, F.size() * 4)); CHECK_HIP(hipMalloc(&dG, gt.size() * 4)); CHECK_HIP(hipMalloc(&dM, Mh.size() * 4));
+    CHECK_HIP(hipMalloc(&dL, 16 * 4));
+    CHECK_HIP(hipMemcpy(dF, F.data(), F.size() * 4, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(dG, gt.data(), gt.size() * 4, hipMemcpyHostToDevice));
+    rc = gmf_similarity_matrix(h, dF, VB, VN, sigma, dM, ldm, st);
+    if (rc == GMF_OK) rc = gmf_spectral_matching_loss(h, dM, ldm, dG, VB, VN, 1, dL, st);
+    if (rc == GMF_OK) rc = gmf_spectral_matching_loss_fused(h, dF, dG, VB, VN, sigma, 1, dL + 1, st);
+    CHECK_HIP(hipStreamSynchronize(st));
+    if (rc != GMF_OK) { std::printf("validation step: %s\n", gmf_last_error_string(h)); return 1; }
+    CHECK_HIP(hipMemcpy(Mh.data(), dM, Mh.size() * 4, hipMemcpyDeviceToHost));
+    float eM = 0.f;
+    for (int b = 0; b < VB; ++b)
+      for (int i = 0; i < VN; ++i)
+        for (int j = 0; j < VN; ++j) {
+          const float want = i == j ? 0.f : (((i * 7 + b) % 128 == (j * 7 + b) % 128) ? 1.f : off_val);
+          eM = std::fmax(eM, std::fabs(Mh[((size_t)b * VN + i) * ldm + j] - want));
+        }
+    float L[2];
+    CHECK_HIP(hipMemcpy(L, dL, 8, hipMemcpyDeviceToHost));
+    std::printf("gmf_similarity_matrix: max |M - expected| = %.3e; spectral matching loss %.6f (from M) %.6f (fused)\n", eM, L[0], L[1]);
+    if (eM > 1e-6f || std::fabs(L[0] - L[1]) > 1e-6f) return 1;
+  }
+
   // error path: a null pointer must come back as a status code with a message, never as an abort
   rc = gmf_weighted_procrustes(h, nullptr, dY, dW, dOff, B, 1.1920929e-7f, dR, dt, st);
   if (rc == GMF_OK) { std::printf("null pointer was accepted\n"); return 1; }

@@ -694,3 +694,31 @@ def test_validation_modules_are_forward_only():
         gmf_amd.ClassificationLoss()(x, torch.zeros(1, 8, device=DEV))
     with pytest.raises(RuntimeError, match="HIP device"):
         gmf_amd.ClassificationLoss()(torch.zeros(1, 8), torch.zeros(1, 8))
+
+
+@pytest.mark.parametrize("B,N,S", [(3, 5000, 500), (2, 37, 3), (1, 16384, 1638), (2, 1000, 1000), (4, 2049, 1)])
+def test_topk_select_equals_full_sort(B, N, S):
+    """The radix-select form of argsort(descending)[:S] against the full bitonic sort and against a stable host sort:
+    many exact ties (zeros of both signs, repeated values), negative keys, S = 1 and S = N."""
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(N + S)
+    keys = torch.randn(B, N, generator=gen)
+    keys[:, ::3] = 0.0
+    keys[:, 1::7] = -0.0
+    keys[:, 2::5] = torch.round(keys[:, 2::5] * 4) / 4          # repeated values
+    if B > 1:
+        keys[1] = -keys[1].abs()                                 # no positive key at all
+    dsrc = _gpu(torch.zeros(B, N, 3))
+    dk = _gpu(keys)
+    outs = []
+    for knob in (1, 0):
+        h.call("gmf_set_tuning", b"topk_select", knob)
+        out = torch.empty((B, S), device=DEV, dtype=torch.int32)
+        h.call("gmf_pick_seeds", dsrc.data_ptr(), dk.data_ptr(), B, N, 0.1, 0, S, out.data_ptr(), st)   # use_nms = 0: plain top-S
+        outs.append(out.cpu())
+    h.call("gmf_set_tuning", b"topk_select", 1)
+    want = torch.sort(keys.double() + 0.0, dim=1, descending=True, stable=True)[1][:, :S]
+    assert torch.equal(outs[0].long(), want)
+    assert torch.equal(outs[1].long(), want)

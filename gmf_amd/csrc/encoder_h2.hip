@@ -542,32 +542,35 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
   }
 }
 
-// k_ff_reduce: x2 = sum_z part[z] + b2 + x1 for the hidden-split form of k_fusion_ff_h2p.  grid (ceil(tiles/4), B), block 256
+// k_ff_reduce: x2 = sum_z part[z] + b2 + x1 (z in index order) for the hidden-split form of k_fusion_ff_h2p.
+// grid (ceil(tiles/4), B, 4): a wave adds one 32 x 32 block; all hs partial blocks are requested before the first add.
 __global__ void __launch_bounds__(256)
 k_ff_reduce(const float* __restrict__ part, const float* __restrict__ x1, const float* __restrict__ vecs,
             float* __restrict__ x2_out, int tiles, int hs) {
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int tile = blockIdx.x * kWavesPerWG + (threadIdx.x >> 6);
   if (tile >= tiles) return;
+  const int mb = blockIdx.z;
   const size_t n_all = (size_t)gridDim.y * tiles;
   const size_t toff = ((size_t)blockIdx.y * tiles + tile) * (32 * C);
+  float b[16], xr[16], p[8][16];
+  load_vec_block(b, vecs + 2 * C + 2 * FFH, mb, h);
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    float b[16], t[16], p[16];
-    load_vec_block(b, vecs + 2 * C + 2 * FFH, mb, h);
-    load_block_p32(p, part + toff, mb, lane);
+  for (int z = 0; z < 8; ++z)
+    if (z < hs) load_block_p32(p[z], part + (size_t)z * n_all * (32 * C) + toff, mb, lane);
+  load_block_p32(xr, x1 + toff, mb, lane);
+  float t[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = p[r];
-    for (int z = 1; z < hs; ++z) {
-      load_block_p32(p, part + (size_t)z * n_all * (32 * C) + toff, mb, lane);
+  for (int r = 0; r < 16; ++r) t[r] = p[0][r];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] += p[r];
+  for (int z = 1; z < 8; ++z)
+    if (z < hs) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] += p[z][r];
     }
-    load_block_p32(p, x1 + toff, mb, lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = t[r] + b[r] + p[r];
-    store_block_p32(x2_out + toff, mb, t, lane);
-  }
+  for (int r = 0; r < 16; ++r) t[r] = t[r] + b[r] + xr[r];
+  store_block_p32(x2_out + toff, mb, t, lane);
 }
 
 // -----------------------------------------------------------------------------------------
@@ -624,7 +627,7 @@ hipError_t launch_fusion_ff_h2(const float* x1, const float* wst, const float* v
   }
   if (hs > 1) {
     hipLaunchKernelGGL((k_fusion_ff_h2p<0, true>), dim3(g.x, g.y, hs), dim3(256), 0, s, x1, wst, vecs, x2, tiles, part);
-    hipLaunchKernelGGL(k_ff_reduce, g, dim3(256), 0, s, part, x1, vecs, x2, tiles, hs);
+    hipLaunchKernelGGL(k_ff_reduce, dim3(g.x, g.y, 4), dim3(256), 0, s, part, x1, vecs, x2, tiles, hs);
   }
   else if (pipelined && abl == 1) hipLaunchKernelGGL(k_fusion_ff_h2p<1>, g, dim3(256), 0, s, x1, wst, vecs, x2, tiles, (float*)nullptr);
   else if (pipelined && abl == 2) hipLaunchKernelGGL(k_fusion_ff_h2p<2>, g, dim3(256), 0, s, x1, wst, vecs, x2, tiles, (float*)nullptr);

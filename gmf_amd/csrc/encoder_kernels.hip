@@ -1324,7 +1324,8 @@ GMF_DEVINL float xhalf_max_swap(float v) {
 // fc_message on the f16 MFMA (split-fp16 weights, tail_wst_h2) + bias + Fusion-2 branch for the 32 rows of one wave, given
 // the normalised attention output o (fragment order).  `ss` is primed on the 5 weight stages; every wave of the workgroup
 // calls this (padding waves with active = false keep their seat at the stage barriers).
-GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, StageStream& ss, const float* __restrict__ vecs,
+template <class Stages>
+GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stages& ss, const float* __restrict__ vecs,
                                    const float* __restrict__ fus_tile, float* __restrict__ out_tile, const int lane, const int h) {
     // stages (fp16x2 images, same sizes as the fp32 ones): Wa block 0 | Wa block 1 | Wb (2 blocks) | Wc 0,1 | Wc 2,3
     FragH2<8> ox;
@@ -1699,12 +1700,37 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   }
 }
 
+// All five fc_message weight stages in LDS at once (80 KiB): for grids that do not fill the chip anyway (the merge step
+// of the key-split form) the chain "wait for a stage, use it for ~0.3 us, wait for the next" is what the kernel costs, so
+// every stage is requested up front and there is a single wait.
+struct StagesPreloaded {
+  const float* base;
+  int used, lane;
+  GMF_DEVINL void init(float* lds, int wave, int lane_, const float* g, int n_stages) {
+    base = lds; used = 0; lane = lane_;
+    for (int st = 0; st < n_stages; ++st)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        dma_piece_1k(g + (size_t)st * kStageFloats + (wave + 4 * q) * 256, lds + st * kStageFloats + (wave + 4 * q) * 256, lane_);
+  }
+  GMF_DEVINL const float4* acquire() {
+    if (used == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    const float* cur = base + used * kStageFloats;
+    ++used;
+    return reinterpret_cast<const float4*>(cur) + lane;
+  }
+};
+
 // k_scattn_merge: combines the `ksplits` partial results of k_scattn_h2p<.., KSPLIT> per query tile - common maximum M,
-// O = sum_k O_k 2^(m_k - M), l = sum_k l_k 2^(m_k - M) - and runs the epilogue.  grid (ceil(tiles/4), B), block 256.
-__global__ void __launch_bounds__(256, 2)
+// O = sum_k O_k 2^(m_k - M), l = sum_k l_k 2^(m_k - M), splits added in index order - and runs the epilogue.
+// grid (ceil(tiles/4), B), block 256.  The partials are fetched four splits at a time (all loads of a group in flight).
+__global__ void __launch_bounds__(256, 1)
 k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_ml, const float* __restrict__ fus,
                const float* __restrict__ wst, const float* __restrict__ vecs, float* __restrict__ out, int tiles, int ksplits) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  __shared__ __attribute__((aligned(16))) float lds[5 * kStageFloats];
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y;
@@ -1714,23 +1740,40 @@ k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_
   const size_t n_tiles_all = (size_t)gridDim.y * tiles;
   const size_t pt0 = (size_t)pair * tiles + tile;
   const size_t toff = pt0 * (32 * C);
-  StageStream ss;
-  ss.init(lds, lds + kStageFloats, wave, 4, lane, wst, 5);
-  ss.prime();
+  StagesPreloaded ss;
+  ss.init(lds, wave, lane, wst, 5);
+  float mk[8], lk[8];
   float M = -INFINITY;
-  for (int k = 0; k < ksplits; ++k) M = fmaxf(M, part_ml[((k * n_tiles_all + pt0) * 32 + i) * 2]);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    mk[k] = -INFINITY; lk[k] = 0.f;
+    if (k < ksplits) {
+      const float2 ml = *reinterpret_cast<const float2*>(part_ml + ((k * n_tiles_all + pt0) * 32 + i) * 2);
+      mk[k] = ml.x; lk[k] = ml.y;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) M = fmaxf(M, mk[k]);
   float o[CF];
 #pragma unroll
   for (int e = 0; e < CF; ++e) o[e] = 0.f;
   float l = 0.f;
-  for (int k = 0; k < ksplits; ++k) {
-    const size_t pt = k * n_tiles_all + pt0;
-    const float wk = __builtin_amdgcn_exp2f(part_ml[(pt * 32 + i) * 2] - M);
-    l = fmaf(part_ml[(pt * 32 + i) * 2 + 1], wk, l);
-    float ok[CF];
-    load_frag_p32<CF>(ok, part_o + pt * (32 * C), lane);
 #pragma unroll
-    for (int e = 0; e < CF; ++e) o[e] = fmaf(ok[e], wk, o[e]);
+  for (int k0 = 0; k0 < 8; k0 += 4) {
+    if (k0 >= ksplits) break;
+    float ok[4][CF];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + j < ksplits) load_frag_p32<CF>(ok[j], part_o + ((k0 + j) * n_tiles_all + pt0) * (32 * C), lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (k0 + j < ksplits) {
+        const float wk = __builtin_amdgcn_exp2f(mk[k0 + j] - M);
+        l = fmaf(lk[k0 + j], wk, l);
+#pragma unroll
+        for (int e = 0; e < CF; ++e) o[e] = fmaf(ok[j][e], wk, o[e]);
+      }
+    }
   }
   const float inv = 1.0f / l;
 #pragma unroll

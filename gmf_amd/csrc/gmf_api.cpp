@@ -136,6 +136,11 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     gmf::set_use_cache(value != 0);
     return GMF_OK;
   }
+  if (std::strcmp(name, "nms_binned") == 0) {          // 1 = grid-binned NMS candidates on large grids (default), 2 = always, 0 = all pairs
+    GMF_REQUIRE(value >= 0 && value <= 2, GMF_ERR_BAD_ARG, "set_tuning: nms_binned must be 0, 1 or 2");
+    gmf::set_nms_binned(value);
+    return GMF_OK;
+  }
   if (std::strcmp(name, "topk_select") == 0) {         // 1 = radix select of the S seeds (default), 0 = full bitonic sort
     gmf::set_topk_select(value != 0);
     return GMF_OK;
@@ -533,9 +538,11 @@ int gmf_pick_seeds(gmf_handle* h, const float* src_keypts, const float* scores, 
   hipStream_t st = S(stream);
   const float* keys = scores;
   if (use_nms) {
-    if (int rc = arena_reserve(h, arena_need((size_t)B * N, 4))) return rc;
+    const size_t n_scr = gmf::nms_scratch_floats(B, N);
+    if (int rc = arena_reserve(h, arena_need((size_t)B * N, 4) + arena_need(n_scr, 4))) return rc;
     float* kbuf = arena_take<float>(h, (size_t)B * N);
-    GMF_HIP(gmf::launch_nms_keys(src_keypts, scores, kbuf, B, N, nms_radius, st));
+    float* scr = arena_take<float>(h, n_scr);
+    GMF_HIP(gmf::launch_nms_keys(src_keypts, scores, kbuf, B, N, nms_radius, st, scr));
     keys = kbuf;
   }
   GMF_HIP(gmf::launch_sort_topk(keys, seeds_out, B, N, num_seeds, st));
@@ -584,7 +591,9 @@ int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, 
   if (!seeds_in) {
     const float* kk = logits;
     if (p->use_nms) {
-      GMF_HIP(gmf::launch_nms_keys(src_keypts, logits, keys, B, N, p->nms_radius, st));
+      // dmat is free until k_seed_dist: it doubles as the grid-binning scratch of the NMS when it is large enough
+      float* scr = (BS * N >= gmf::nms_scratch_floats(B, N)) ? dmat : nullptr;
+      GMF_HIP(gmf::launch_nms_keys(src_keypts, logits, keys, B, N, p->nms_radius, st, scr));
       kk = keys;
     }
     GMF_HIP(gmf::launch_sort_topk(kk, seeds, B, N, Sn, st));

@@ -227,6 +227,109 @@ k_nms_keys(const float* __restrict__ src, const float* __restrict__ scores, floa
 }
 
 // ---------------------------------------------------------------------------------------
+// The same keys with the candidates of a point limited to its 27 neighbouring cells of a uniform grid (cell edge 1.01 R,
+// coordinates wrapped to 16 x 16 x 16 cells): every j with ||src_i - src_j|| < R lies in one of them, the others pass the
+// test through the distance term, so the conjunction - and every key - is exactly that of the all-pairs kernel.
+//   k_nms_bin   (grid B, block 1024): counting sort of the pair's points by cell -> cell_start [4097], sorted (x, y, z, score).
+//               A pair with a coordinate beyond 6e4 cells (where the float rounding of x / cell could separate neighbours by
+//               two cells) or a non-finite coordinate is flagged: its points test every candidate.
+//   k_nms_keys_binned (grid (ceil(N/256), B)): one point per thread.
+// scratch per pair: 4 N floats (sorted points) + 4104 ints (cell_start | flag), see nms_scratch_floats().
+// ---------------------------------------------------------------------------------------
+constexpr int kNmsCells = 4096, kNmsHdr = 4104;
+
+GMF_DEVINL int nms_cell_coord(float x, float inv_cell) { return ((int)floorf(x * inv_cell)) & 15; }
+
+__global__ void __launch_bounds__(1024)
+k_nms_bin(const float* __restrict__ src, const float* __restrict__ scores, float* __restrict__ scratch, int N, float inv_cell) {
+  __shared__ unsigned cnt[kNmsCells];
+  __shared__ unsigned wtot[16];
+  __shared__ int bad;
+  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* ps = src + (size_t)pair * N * 3;
+  const float* sc = scores + (size_t)pair * N;
+  float4* sorted = reinterpret_cast<float4*>(scratch + (size_t)pair * ((size_t)4 * N + kNmsHdr));
+  int* hdr = reinterpret_cast<int*>(sorted + N);
+  for (int c = tid; c < kNmsCells; c += 1024) cnt[c] = 0;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  for (int i = tid; i < N; i += 1024) {
+    const float x = ps[3 * i], y = ps[3 * i + 1], z = ps[3 * i + 2];
+    const float m = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))) * inv_cell;
+    if (!(m < 6.0e4f)) bad = 1;                     // also catches NaN / inf
+    const int key = nms_cell_coord(x, inv_cell) | (nms_cell_coord(y, inv_cell) << 4) | (nms_cell_coord(z, inv_cell) << 8);
+    atomicAdd(&cnt[key], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of the 4096 counts: 4 cells per thread
+  unsigned c4[4], tsum = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { c4[q] = cnt[4 * tid + q]; tsum += c4[q]; }
+  unsigned inc = tsum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  unsigned base = 0;
+  for (int w = 0; w < wave; ++w) base += wtot[w];
+  unsigned run = base + inc - tsum;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { hdr[4 * tid + q] = (int)run; cnt[4 * tid + q] = run; run += c4[q]; }   // cnt becomes the fill cursor
+  if (tid == 1023) hdr[kNmsCells] = (int)run;       // = N
+  __syncthreads();
+  if (tid == 0) hdr[kNmsCells + 1] = bad;
+  for (int i = tid; i < N; i += 1024) {
+    const float x = ps[3 * i], y = ps[3 * i + 1], z = ps[3 * i + 2];
+    const int key = nms_cell_coord(x, inv_cell) | (nms_cell_coord(y, inv_cell) << 4) | (nms_cell_coord(z, inv_cell) << 8);
+    const unsigned pos = atomicAdd(&cnt[key], 1u);
+    sorted[pos] = make_float4(x, y, z, sc[i]);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_nms_keys_binned(const float* __restrict__ src, const float* __restrict__ scores, const float* __restrict__ scratch,
+                  float* __restrict__ keys, int N, float R2t, float inv_cell) {
+  const int pair = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float4* sorted = reinterpret_cast<const float4*>(scratch + (size_t)pair * ((size_t)4 * N + kNmsHdr));
+  const int* hdr = reinterpret_cast<const int*>(sorted + N);
+  const float* ps = src + (size_t)pair * N * 3;
+  const float xi = ps[3 * i], yi = ps[3 * i + 1], zi = ps[3 * i + 2], si = scores[(size_t)pair * N + i];
+  bool is_max = true;
+  auto scan = [&](int j0, int j1) {
+    for (int j = j0; j < j1; ++j) {
+      const float4 p = sorted[j];
+      const float dx = xi - p.x, dy = yi - p.y, dz = zi - p.z;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      is_max = is_max && ((si >= p.w) || (d2 >= R2t));
+    }
+  };
+  if (hdr[kNmsCells + 1]) {
+    scan(0, N);
+  } else {
+    const int cx = nms_cell_coord(xi, inv_cell), cy = nms_cell_coord(yi, inv_cell), cz = nms_cell_coord(zi, inv_cell);
+    for (int oz = -1; oz <= 1; ++oz)
+      for (int oy = -1; oy <= 1; ++oy) {
+        const int rowkey = (((cy + oy) & 15) << 4) | (((cz + oz) & 15) << 8);
+        // the three x-neighbours are consecutive cells unless the row wraps
+        const int xa = (cx - 1) & 15, xb = cx, xc = (cx + 1) & 15;
+        if (xa + 1 == xb && xb + 1 == xc) {
+          scan(hdr[rowkey | xa], hdr[(rowkey | xc) + 1]);
+        } else {
+          scan(hdr[rowkey | xa], hdr[(rowkey | xa) + 1]);
+          scan(hdr[rowkey | xb], hdr[(rowkey | xb) + 1]);
+          scan(hdr[rowkey | xc], hdr[(rowkey | xc) + 1]);
+        }
+      }
+  }
+  keys[(size_t)pair * N + i] = si * (is_max ? 1.f : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------
 // Per pair: indices of the S largest keys, ordered (key descending, index ascending) - the order
 // torch's stable CPU sort gives argsort(descending=True).  Bitonic sort in LDS, N <= 16384.
 // grid (B), block 1024, dynamic LDS = M*8 bytes (M = next pow2 >= N)
@@ -1265,7 +1368,12 @@ k_global_registration(const float* __restrict__ X, const float* __restrict__ Y, 
 // =========================================================================================
 static inline int next_pow2(int n) { int m = 1; while (m < n) m <<= 1; return m; }
 
-hipError_t launch_nms_keys(const float* src, const float* scores, float* keys, int B, int N, float R, hipStream_t s) {
+static int g_nms_binned = 1;        // 1 = grid-binned candidates for N >= 1024 on grids of >= 128 workgroups (default), 2 = whenever N >= 1024, 0 = all pairs
+void set_nms_binned(int v) { g_nms_binned = v; }
+size_t nms_scratch_floats(int B, int N) { return (size_t)B * ((size_t)4 * N + kNmsHdr); }
+
+hipError_t launch_nms_keys(const float* src, const float* scores, float* keys, int B, int N, float R, hipStream_t s,
+                           float* scratch) {
   // The reference tests sqrt(d2) >= R (PointDSC.py:283).  sqrtf is monotone, so that is d2 >= t for the smallest float t
   // with sqrtf(t) >= R; finding t on the host removes the square root from the N^2 loop without changing one decision.
   float t = R * R;
@@ -1276,6 +1384,13 @@ hipError_t launch_nms_keys(const float* src, const float* scores, float* keys, i
     t = 0.f;
   }
   const int nblk = (N + 255) / 256;
+  // (on small grids - B = 1 - the two binned launches cost more latency than the candidate-split all-pairs kernel saves)
+  if (scratch && g_nms_binned && N >= 1024 && (nblk * B >= 128 || g_nms_binned == 2) && R > 0.f && std::isfinite(R)) {
+    const float inv_cell = 1.0f / (1.01f * R);
+    hipLaunchKernelGGL(k_nms_bin, dim3(B), dim3(1024), 0, s, src, scores, scratch, N, inv_cell);
+    hipLaunchKernelGGL(k_nms_keys_binned, dim3(nblk, B), dim3(256), 0, s, src, scores, scratch, keys, N, t, inv_cell);
+    return hipGetLastError();
+  }
   int js = 1;
   if (nblk * B < 256) js = std::min(std::min(16, nblk), (512 + nblk * B - 1) / (nblk * B));
   if (js > 1) {

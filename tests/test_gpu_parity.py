@@ -722,3 +722,46 @@ def test_topk_select_equals_full_sort(B, N, S):
     want = torch.sort(keys.double() + 0.0, dim=1, descending=True, stable=True)[1][:, :S]
     assert torch.equal(outs[0].long(), want)
     assert torch.equal(outs[1].long(), want)
+
+
+@pytest.mark.parametrize("case", ["3dmatch", "kitti", "clustered", "wrapped", "far", "tiny_radius"])
+def test_binned_nms_equals_all_pairs(case):
+    """pick_seeds with the grid-binned candidate lists against the all-pairs kernel: the full order (S = N) must be
+    identical - uniform clouds, dense clusters inside one cell, clouds spanning many wraps of the 16-cell grid, coordinates
+    far from the origin (the flagged all-candidates path) and a radius below the point spacing."""
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(len(case))
+    B, N, R = 3, 3000, 0.1
+    pts = torch.rand(B, N, 3, generator=gen) * 3.0
+    if case == "kitti":
+        N, R = 6000, 1.2
+        pts = torch.rand(B, N, 3, generator=gen) * torch.tensor([80.0, 80.0, 4.0]) - torch.tensor([40.0, 40.0, 2.0])
+    elif case == "clustered":
+        pts = torch.randn(B, N, 3, generator=gen) * 0.03 + torch.randint(0, 4, (B, N, 1), generator=gen).float()
+    elif case == "wrapped":
+        pts = torch.rand(B, N, 3, generator=gen) * 40.0 - 20.0            # 400 cells per axis: 25 wraps
+        pts[:, 1::2] = pts[:, 0::2] + 0.05 * torch.randn(B, N // 2, 3, generator=gen)   # close partners across the cloud
+    elif case == "far":
+        pts = pts + torch.tensor([9.0e3, -7.0e3, 0.0])                    # 9e4 cells from the origin: flagged pair
+    elif case == "tiny_radius":
+        R = 1e-3
+    scores = torch.randn(B, N, generator=gen)
+    scores[:, ::11] = scores[:, 1::11][:, : scores[:, ::11].shape[1]]     # equal scores: the >= test matters
+    dp, ds = _gpu(pts.contiguous()), _gpu(scores.contiguous())
+    outs = []
+    for knob in (2, 0):                                                   # 2 = binned whatever the grid size
+        h.call("gmf_set_tuning", b"nms_binned", knob)
+        out = torch.empty((B, N), device=DEV, dtype=torch.int32)
+        h.call("gmf_pick_seeds", dp.data_ptr(), ds.data_ptr(), B, N, R, 1, N, out.data_ptr(), st)
+        outs.append(out.cpu())
+    h.call("gmf_set_tuning", b"nms_binned", 1)
+    assert torch.equal(outs[0], outs[1])
+    # and against the reference formula on pair 0 (oracle.pick_seeds works on the N x N distance matrix)
+    d = torch.norm(pts[0][:, None] - pts[0][None], dim=-1)
+    want = O.pick_seeds(d[None], scores[:1], R, N)
+    n_pos = int((want[0] >= 0).sum())
+    keys_ref = scores[0] * ((scores[0][:, None] >= scores[0][None]) | (d >= R)).all(1).float()
+    n_lead = int((keys_ref > 0).sum())                                    # the order of the positive keys is unique
+    assert torch.equal(outs[0][0, :n_lead].long(), torch.sort(keys_ref, descending=True, stable=True)[1][:n_lead]) and n_pos == N

@@ -117,6 +117,13 @@ GMF_DEVINL void lcpe_frag(float (&y)[CF], const float* __restrict__ pair_base, i
   }
 }
 
+// Split-fp16 weight images are stored as 256 W (packing.p32_h2s / p16_h2s): lo = fp16(256 w - hi) then stays a normal
+// fp16 number for |w| >= 2^-11 instead of falling into the subnormals (spacing 2^-24: a weight of 0.006 - the folded
+// softmax scale makes Wq that small - kept only 16 significant bits).  Consumers fold 2^-8 into the bias add
+// (fmaf(acc, kH2Inv, b): same instruction count).  The GEGLU W1 matrices stay unscaled (their accumulators start from the
+// bias and feed the GELU directly).
+constexpr float kH2Inv = 1.0f / 256.0f;
+
 // a row fragment as two fp16 planes: NS = K/16 k-steps
 template <int NS>
 struct FragH2 {

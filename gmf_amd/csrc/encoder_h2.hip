@@ -88,7 +88,7 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
         float b[16];
         load_vec_block(b, vecs, mb, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) f[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+        for (int r = 0; r < 16; ++r) f[16 * mb + r] = fmaxf(fmaf(acc[r], kH2Inv, b[r]), 0.f);
       }
     }
   }
@@ -107,7 +107,7 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
       float b[16], t[16];
       load_vec_block(b, vecs + (1 + which) * C, mb, h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r];
+      for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, b[r]);
       if (active) store_block_h2(dst, mb, t, lane);
     }
   }
@@ -120,7 +120,7 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
     const float bv = vecs[3 * C + 32 * db + i];
     float t[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = acc[r] + bv;
+    for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bv);
     if (active) { if (VQ) store_block_vq16(v_out + toff, db, t, lane); else store_block_h2(v_out + toff, db, t, lane); }
   }
 }
@@ -166,7 +166,7 @@ k_ctx_prep_h2(const float* __restrict__ ctx, const float* __restrict__ wst, cons
     mma_wx_h2<8>(acc, lw, cx);
     float t[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = acc[r];
+    for (int r = 0; r < 16; ++r) t[r] = acc[r] * kH2Inv;
     if (active) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -185,7 +185,7 @@ k_ctx_prep_h2(const float* __restrict__ ctx, const float* __restrict__ wst, cons
     mma_xw_h2<8>(acc, lw, cx);
     float t[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = acc[r];
+    for (int r = 0; r < 16; ++r) t[r] = acc[r] * kH2Inv;
     if (active) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -241,7 +241,7 @@ k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_im
       mma_wx_h2<8>(acc, lw, nx);
       float t[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = acc[r];
+      for (int r = 0; r < 16; ++r) t[r] = acc[r] * kH2Inv;
       qx.set_block(mb, t);
     }
   }
@@ -310,7 +310,7 @@ k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_im
       float b[16], t[16];
       load_vec_block(b, vecs + 6 * C, mb, h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r] + xp[16 * mb + r];
+      for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, b[r]) + xp[16 * mb + r];
       if (active) store_block_p32(x1_out + toff, mb, t, lane);
     }
   }
@@ -381,7 +381,7 @@ k_fusion_ff_h2(const float* __restrict__ x1, const float* __restrict__ wst, cons
     load_vec_block(b, vecs + 2 * C + 2 * FFH, mb, h);
     load_block_p32(xr, x1 + toff, mb, lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = y[mb][r] + b[r] + xr[r];
+    for (int r = 0; r < 16; ++r) t[r] = fmaf(y[mb][r], kH2Inv, b[r]) + xr[r];
     if (active) store_block_p32(x2_out + toff, mb, t, lane);
   }
 }
@@ -537,7 +537,7 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
     load_vec_block(b, vecs + 2 * C + 2 * FFH, mb, h);
     load_block_p32(xr, x1 + toff, mb, lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = y[mb][r] + b[r] + xr[r];
+    for (int r = 0; r < 16; ++r) t[r] = fmaf(y[mb][r], kH2Inv, b[r]) + xr[r];
     if (active) store_block_p32(x2_out + toff, mb, t, lane);
   }
 }
@@ -569,7 +569,7 @@ k_ff_reduce(const float* __restrict__ part, const float* __restrict__ x1, const 
       for (int r = 0; r < 16; ++r) t[r] += p[z][r];
     }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) t[r] = t[r] + b[r] + xr[r];
+  for (int r = 0; r < 16; ++r) t[r] = fmaf(t[r], kH2Inv, b[r]) + xr[r];
   store_block_p32(x2_out + toff, mb, t, lane);
 }
 

@@ -1340,7 +1340,7 @@ GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stag
       float b[16], t1[16];
       load_vec_block(b, vecs, mb, h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t1[r] = fmaxf(acc[r] + b[r], 0.f);
+      for (int r = 0; r < 16; ++r) t1[r] = fmaxf(fmaf(acc[r], kH2Inv, b[r]), 0.f);
       m1x.set_block(mb, t1);
     }
     {
@@ -1353,7 +1353,7 @@ GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stag
         float b[16], t2[16];
         load_vec_block(b, vecs + 64, mb, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t2[r] = fmaxf(acc[r] + b[r], 0.f);
+        for (int r = 0; r < 16; ++r) t2[r] = fmaxf(fmaf(acc[r], kH2Inv, b[r]), 0.f);
         m2x.set_block(mb, t2);
       }
     }
@@ -1370,7 +1370,7 @@ GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stag
         load_vec_block(b, vecs + 128, mb, h);
         load_block_p32(fz, fus_tile, mb, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tt[r] = acc[r] + b[r] + fz[r];
+        for (int r = 0; r < 16; ++r) tt[r] = fmaf(acc[r], kH2Inv, b[r]) + fz[r];
         if (active) store_block_p32(out_tile, mb, tt, lane);
       }
     }
@@ -2113,7 +2113,7 @@ k_scattn_h2q(const float* __restrict__ q_img, const float* __restrict__ k_img, c
         for (int sp = 0; sp < 4; ++sp)
           mma3q(acc, lw[((mbl * 4 + sp) * 2 + 0) * 64], lw[((mbl * 4 + sp) * 2 + 1) * 64], oh[ib][sp], ol[ib][sp]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) keep[ib][4 * mbl + r] = fmaxf(acc[r] + b4[r], 0.f);
+        for (int r = 0; r < 4; ++r) keep[ib][4 * mbl + r] = fmaxf(fmaf(acc[r], kH2Inv, b4[r]), 0.f);
       }
     }
 #pragma unroll
@@ -2137,7 +2137,7 @@ k_scattn_h2q(const float* __restrict__ q_img, const float* __restrict__ k_img, c
           for (int sp = 0; sp < 2; ++sp)
             mma3q(acc, lw[((mb * 2 + sp) * 2 + 0) * 64], lw[((mb * 2 + sp) * 2 + 1) * 64], m1h[ib][sp], m1l[ib][sp]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) keep[ib][4 * mbl + r] = fmaxf(acc[r] + b4[r], 0.f);
+          for (int r = 0; r < 4; ++r) keep[ib][4 * mbl + r] = fmaxf(fmaf(acc[r], kH2Inv, b4[r]), 0.f);
         }
       }
 #pragma unroll
@@ -2162,8 +2162,8 @@ k_scattn_h2q(const float* __restrict__ q_img, const float* __restrict__ k_img, c
         const int f4 = (2 * mb + (g >> 1)) * 64 + 32 * (g & 1) + 16 * ib + c16;
         const float4 fz = reinterpret_cast<const float4*>(fus + toff)[f4];
         if (active)
-          reinterpret_cast<float4*>(out + toff)[f4] = make_float4(acc[0] + b4[0] + fz.x, acc[1] + b4[1] + fz.y,
-                                                                  acc[2] + b4[2] + fz.z, acc[3] + b4[3] + fz.w);
+          reinterpret_cast<float4*>(out + toff)[f4] = make_float4(fmaf(acc[0], kH2Inv, b4[0]) + fz.x, fmaf(acc[1], kH2Inv, b4[1]) + fz.y,
+                                                                  fmaf(acc[2], kH2Inv, b4[2]) + fz.z, fmaf(acc[3], kH2Inv, b4[3]) + fz.w);
       }
     }
   }

@@ -405,7 +405,7 @@ k_fusion_ff_w_h2(const float* __restrict__ x1, const float* __restrict__ wst, co
     load_vec16(b, vecs + 2 * LAT + 2 * FFHW, mb, h);
     load_blk<LAT>(xr, x1 + toff, mb, lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = y[mb][r] + b[r] + xr[r];
+    for (int r = 0; r < 16; ++r) t[r] = fmaf(y[mb][r], kH2Inv, b[r]) + xr[r];
     if (active) store_blk<LAT>(x2_out + toff, mb, t, lane);
   }
 }

@@ -81,7 +81,7 @@ class FusionLayer(nn.Module):
         if self._packed is None or self._packed_version != ver:
             sd = {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()}
             packed = packing.pack_fusion(sd, "", self.pe)
-            packed["ff_wst_h2"] = packing.pack_fusion(sd, "", self.pe, img=packing.p32_h2)["ff_wst"]
+            packed["ff_wst_h2"] = packing.pack_fusion(sd, "", self.pe, img=packing.p32_h2s)["ff_wst"]
             self._packed = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in packed.items()}
             self._packed_version = ver
         return self._packed

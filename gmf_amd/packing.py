@@ -85,6 +85,20 @@ def p32_h2(W: torch.Tensor) -> torch.Tensor:
     return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
 
 
+H2_SCALE = 256.0     # = 1 / kH2Inv (gmf_amd/csrc/enc_common.hpp)
+
+
+def p32_h2s(W: torch.Tensor) -> torch.Tensor:
+    """p32_h2 of 256 W: the lo plane fp16(256 w - hi) stays a normal fp16 number for |w| >= 2^-11 instead of a subnormal
+    (spacing 2^-24: an unscaled weight of 0.006 kept 16 significant bits).  The kernels fold 2^-8 into their bias add."""
+    return p32_h2(W * H2_SCALE)
+
+
+def p16_h2s(W: torch.Tensor) -> torch.Tensor:
+    """p16_h2 of 256 W (see p32_h2s)."""
+    return p16_h2(W * H2_SCALE)
+
+
 def p16_h2(W: torch.Tensor) -> torch.Tensor:
     """[M, K] fp32 (M % 16 == 0, K % 32 == 0) -> flat split-fp16 image for v_mfma_f32_16x16x32_f16 A-operands.
 
@@ -154,7 +168,8 @@ def pack_fusion(sd: Dict[str, torch.Tensor], prefix: str, pe: bool, img=None):
     Stage order matches the kernels: ctx = Wk blocks | Wv blocks; attn = Wq'' blocks (each block's K-groups in
     order, so a 256-wide input naturally spans two 16 KiB stages) | Wo blocks; ff = per 32-unit chunk
     W1 value | W1 gate | W2 column block."""
-    img = img or p32          # p32 (fp32 images) or p32_h2 (split-fp16 images): same sizes, same stage order
+    img = img or p32          # p32 (fp32 images) or p32_h2s (split-fp16 images of 256 W): same sizes, same stage order
+    img_w1 = p32_h2 if img is p32_h2s else img     # the GEGLU W1 images stay unscaled (enc_common.hpp, kH2Inv)
     lat, dh = fusion_dims(sd, prefix)
     a = prefix + "cross_attend_blocks.0."
     f = prefix + "cross_attend_blocks.1."
@@ -175,7 +190,7 @@ def pack_fusion(sd: Dict[str, torch.Tensor], prefix: str, pe: bool, img=None):
     assert tuple(W1.shape) == (2 * hid, lat) and tuple(W2.shape) == (lat, hid) and hid == 4 * lat
     chunks = []
     for c in range(hid // 32):
-        chunks += [img(W1[32 * c:32 * c + 32]), img(W1[hid + 32 * c:hid + 32 * c + 32]), img(W2[:, 32 * c:32 * c + 32])]
+        chunks += [img_w1(W1[32 * c:32 * c + 32]), img_w1(W1[hid + 32 * c:hid + 32 * c + 32]), img(W2[:, 32 * c:32 * c + 32])]
     ff_wst = torch.cat(chunks)
     ff_vec = torch.cat([_f(sd[f + "norm.weight"]), _f(sd[f + "norm.bias"]), b1[:hid], b1[hid:], b2])
     out = {"ctx_wst": ctx_wst, "ctx_vec": ctx_vec, "attn_wst": attn_wst, "attn_vec": attn_vec,
@@ -266,18 +281,18 @@ class PackedEncoder:
             for k, v in f1.items():
                 self.t["f1_" + k] = v
             self.t["f1_ff_wst_b3"] = pack_ff_b3(sd, "encoder.fusion_layer_1.")
-            f1h = pack_fusion(sd, "encoder.fusion_layer_1.", pe=False, img=p32_h2)
+            f1h = pack_fusion(sd, "encoder.fusion_layer_1.", pe=False, img=p32_h2s)
             for k in ("ctx_wst", "attn_wst", "ff_wst"):
                 self.t["f1_" + k + "_h2"] = f1h[k]
         if num_layers > 0:
-            f2h = [pack_fusion(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.", pe=True, img=p32_h2) for i in range(num_layers)]
+            f2h = [pack_fusion(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.", pe=True, img=p32_h2s) for i in range(num_layers)]
             for k in ("ctx_wst", "attn_wst", "ff_wst"):
                 self.t[k + "_h2"] = torch.stack([f[k] for f in f2h]).contiguous()
             self.t["front_wst_h2"] = torch.stack([pack_front(sd, i, with_layer0=(i == 0 and "encoder.layer0.weight" in sd),
-                                                             identity_pointcn=standalone_block, img=p32_h2)[0]
+                                                             identity_pointcn=standalone_block, img=p32_h2s)[0]
                                                   for i in range(num_layers)]).contiguous()
-            self.t["tail_wst_h2"] = torch.stack([pack_tail(sd, i, img=p32_h2)[0] for i in range(num_layers)]).contiguous()
-            self.t["tail_wst_q16"] = torch.stack([pack_tail(sd, i, img=p16_h2)[0] for i in range(num_layers)]).contiguous()
+            self.t["tail_wst_h2"] = torch.stack([pack_tail(sd, i, img=p32_h2s)[0] for i in range(num_layers)]).contiguous()
+            self.t["tail_wst_q16"] = torch.stack([pack_tail(sd, i, img=p16_h2s)[0] for i in range(num_layers)]).contiguous()
         if num_layers > 0:
             self.t["ff_wst_b3"] = torch.stack([pack_ff_b3(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.")
                                                for i in range(num_layers)]).contiguous()

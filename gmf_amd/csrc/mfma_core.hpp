@@ -121,12 +121,24 @@ GMF_DEVINL f32x2 resid2h(f16x2 hh, float x0, float x1) {
   return f32x2{r0, r1};
 }
 
+// fp16(x - float(hi)) for a pair, written straight into the two halves of one register: v_fma_mixlo_f16 / v_fma_mixhi_f16
+// round the (exact) difference to fp16 themselves, so the low plane of a pair costs 2 instructions instead of 2 + a
+// v_cvt_pk (3 per pair with the hi conversion instead of 4).  Bit-identical to convert(resid2h(...)), checked over all
+// magnitudes by tools/ubench/fma_mixlo_split.hip.
+GMF_DEVINL f16x2 lo2h(f16x2 hh, float x0, float x1) {
+  const unsigned hu = __builtin_bit_cast(unsigned, hh);
+  unsigned d;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hu), "v"(x0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hu), "v"(x1));
+  return __builtin_bit_cast(f16x2, d);
+}
+
 GMF_DEVINL void split8h(const float* v, f16x8& hi, f16x8& lo) {
 #pragma unroll
   for (int j = 0; j < 8; j += 2) {
     const f32x2 x = {v[j], v[j + 1]};
     const f16x2 hh = __builtin_convertvector(x, f16x2);
-    const f16x2 ll = __builtin_convertvector(resid2h(hh, v[j], v[j + 1]), f16x2);
+    const f16x2 ll = lo2h(hh, v[j], v[j + 1]);
     hi[j] = hh[0]; hi[j + 1] = hh[1];
     lo[j] = ll[0]; lo[j + 1] = ll[1];
   }
@@ -136,7 +148,7 @@ GMF_DEVINL void split8h(const float* v, f16x8& hi, f16x8& lo) {
 GMF_DEVINL void split2h(float x0, float x1, f16x8& hi, f16x8& lo, int j) {
   const f32x2 x = {x0, x1};
   const f16x2 hh = __builtin_convertvector(x, f16x2);
-  const f16x2 ll = __builtin_convertvector(resid2h(hh, x0, x1), f16x2);
+  const f16x2 ll = lo2h(hh, x0, x1);
   hi[j] = hh[0]; hi[j + 1] = hh[1];
   lo[j] = ll[0]; lo[j + 1] = ll[1];
 }

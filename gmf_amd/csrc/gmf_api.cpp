@@ -753,4 +753,13 @@ int gmf_transformation_loss(gmf_handle* h, const float* trans, const float* gt_t
   return GMF_OK;
 }
 
+int gmf_bias_relu_nhwc(gmf_handle* h, float* y, const float* bias, const float* residual, long long n_pixels, int C,
+                       gmf_stream_t stream) {
+  GMF_REQUIRE(h && y && bias, GMF_ERR_BAD_ARG, "bias_relu_nhwc: null pointer");
+  GMF_REQUIRE(n_pixels > 0 && C > 0 && C % 4 == 0, GMF_ERR_UNSUPPORTED_SHAPE, "bias_relu_nhwc: need n_pixels > 0 and C a positive multiple of 4");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_bias_relu_nhwc(y, bias, residual, (long)n_pixels, C, S(stream)));
+  return GMF_OK;
+}
+
 }  // extern "C"

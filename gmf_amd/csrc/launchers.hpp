@@ -80,4 +80,7 @@ hipError_t launch_transformation_loss(const float* trans, const float* gt_trans,
                                       const float* probs, double* part, int B, int N, float re_thre, float te_thre,
                                       float* out, hipStream_t s);
 
+// image encoder epilogue (row f-1): image_kernels.hip
+hipError_t launch_bias_relu_nhwc(float* y, const float* bias, const float* residual, long n_pixels, int C, hipStream_t s);
+
 }  // namespace gmf

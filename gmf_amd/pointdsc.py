@@ -53,6 +53,48 @@ class _ResNet34ToLayer2(nn.Module):
         return self.layer2(self.layer1(x))
 
 
+class _FusedResNet:
+    """Inference form of `_ResNet34ToLayer2` on a HIP device (models/resnet.py:195-216, BasicBlock.forward :59-75)."""
+
+    def __init__(self, bb):
+        from torch.nn.utils.fusion import fuse_conv_bn_eval
+        cl = torch.channels_last
+
+        def fold(conv, bn):
+            f = fuse_conv_bn_eval(conv.eval(), bn.eval())
+            return (f.weight.detach().contiguous(memory_format=cl), f.bias.detach().contiguous(), conv.stride, conv.padding)
+
+        import copy
+        bb = copy.deepcopy(bb).eval()
+        self.stem = fold(bb.conv1, bb.bn1)
+        self.blocks = []
+        for layer in (bb.layer1, bb.layer2):
+            for blk in layer:
+                c1, c2 = fold(blk.conv1, blk.bn1), fold(blk.conv2, blk.bn2)
+                ds = fold(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+                # out = relu(conv2 + b2 + identity); with a downsample the identity is conv_ds + b_ds: fold b_ds into b2
+                b2 = c2[1] if ds is None else (c2[1] + ds[1]).contiguous()
+                self.blocks.append((c1, (c2[0], b2, c2[2], c2[3]), ds))
+
+    @staticmethod
+    def _bias_relu(y, bias, residual=None):
+        assert y.is_contiguous(memory_format=torch.channels_last)
+        B, C, H, W = y.shape
+        h, st = handle_and_stream(y)
+        h.call("gmf_bias_relu_nhwc", y.data_ptr(), bias.data_ptr(), None if residual is None else residual.data_ptr(),
+               B * H * W, C, st)
+        return y
+
+    def __call__(self, x):
+        w, b, s, p = self.stem
+        x = F.max_pool2d(self._bias_relu(F.conv2d(x, w, None, s, p), b), 3, 2, 1)
+        for c1, c2, ds in self.blocks:
+            idt = x if ds is None else F.conv2d(x, ds[0], None, ds[2], ds[3])
+            y = self._bias_relu(F.conv2d(x, c1[0], None, c1[2], c1[3]), c1[1])
+            x = self._bias_relu(F.conv2d(y, c2[0], None, c2[2], c2[3]), c2[1], idt.contiguous(memory_format=torch.channels_last))
+        return x
+
+
 class ImageEncoder(nn.Module):
     """Keys match `encoder.image_encoder.backbone.{conv1,bn1,layer1,layer2}.*`; the reference's unused
     layer3/layer4/fc entries are ignored by the non-strict loads it uses (evaluation/test_3DMatch.py:262)."""
@@ -141,23 +183,12 @@ class NonLocalNet(nn.Module):
             self.blocks[f"NonLocal_layer_{i}"] = NonLocalBlock(c)
 
     def _fused_image_encoder(self):
-        """eval-mode copy of the ResNet with every BatchNorm folded into its convolution (a third fewer launches; the
-        encoder is launch-bound: ~110 small MIOpen / elementwise kernels per pass).  Rebuilt when the weights change."""
-        import copy
-        from torch.nn.utils.fusion import fuse_conv_bn_eval
+        """eval-mode form of the ResNet: every BatchNorm folded into its convolution, weights and activations NHWC, and the
+        bias + residual + ReLU that follow each MIOpen convolution done by one HIP pass (`gmf_bias_relu_nhwc`) instead of
+        three element-wise kernels.  Rebuilt when the weights change."""
         ver = params_version(self.image_encoder)
         if getattr(self, "_img_fused_version", None) != ver:
-            m = copy.deepcopy(self.image_encoder).eval()
-            bb = m.backbone
-            bb.conv1, bb.bn1 = fuse_conv_bn_eval(bb.conv1, bb.bn1), nn.Identity()
-            for layer in (bb.layer1, bb.layer2):
-                for blk in layer:
-                    blk.conv1, blk.bn1 = fuse_conv_bn_eval(blk.conv1, blk.bn1), nn.Identity()
-                    blk.conv2, blk.bn2 = fuse_conv_bn_eval(blk.conv2, blk.bn2), nn.Identity()
-                    if blk.downsample is not None:
-                        blk.downsample = nn.Sequential(fuse_conv_bn_eval(blk.downsample[0], blk.downsample[1]))
-            m = m.to(memory_format=torch.channels_last)      # NHWC: MIOpen's fp32 convolutions run ~10 % faster (1.46 -> 1.31 ms for 64 images)
-            object.__setattr__(self, "_img_fused", m)          # not a registered sub-module: keeps the state_dict surface
+            object.__setattr__(self, "_img_fused", _FusedResNet(self.image_encoder.backbone))   # not a sub-module: keeps the state_dict surface
             self._img_fused_version = ver
         return self._img_fused
 

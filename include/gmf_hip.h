@@ -277,6 +277,13 @@ int gmf_transformation_loss(gmf_handle* h, const float* trans, const float* gt_t
                             const float* tgt_keypts, const float* probs, int B, int N, float re_thre, float te_thre,
                             float* out5, gmf_stream_t stream);
 
+/* ---- image encoder epilogue (ResNet BasicBlock, GMF_PointDSC/models/resnet.py:59-75) ------------------------------- */
+
+/* y = max(y + bias[c] (+ residual), 0) in place on an NHWC fp32 tensor of n_pixels x C (C % 4 == 0): the folded
+ * BatchNorm bias, the residual add and the ReLU that follow each MIOpen convolution, in one pass.  residual may be NULL. */
+int gmf_bias_relu_nhwc(gmf_handle* h, float* y, const float* bias, const float* residual, long long n_pixels, int C,
+                       gmf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

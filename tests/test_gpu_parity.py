@@ -765,3 +765,19 @@ def test_binned_nms_equals_all_pairs(case):
     keys_ref = scores[0] * ((scores[0][:, None] >= scores[0][None]) | (d >= R)).all(1).float()
     n_lead = int((keys_ref > 0).sum())                                    # the order of the positive keys is unique
     assert torch.equal(outs[0][0, :n_lead].long(), torch.sort(keys_ref, descending=True, stable=True)[1][:n_lead]) and n_pos == N
+
+
+def test_bias_relu_nhwc_epilogue():
+    """gmf_bias_relu_nhwc (the fused bias + residual + ReLU pass of the image encoder) against the same torch expression."""
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    st = torch.cuda.current_stream().cuda_stream
+    for (B, C, H, W, with_res) in [(3, 64, 30, 40, False), (2, 128, 15, 20, True), (1, 4, 1, 1, True)]:
+        y = torch.randn(B, C, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(C, device=DEV)
+        r = torch.randn(B, C, H, W, device=DEV).contiguous(memory_format=torch.channels_last) if with_res else None
+        want = torch.relu(y + b[None, :, None, None] + (r if with_res else 0))
+        h.call("gmf_bias_relu_nhwc", y.data_ptr(), b.data_ptr(), r.data_ptr() if with_res else None, B * H * W, C, st)
+        assert torch.equal(y, want)
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        h.call("gmf_bias_relu_nhwc", y.data_ptr(), b.data_ptr(), None, 4, 6, st)

@@ -762,4 +762,17 @@ int gmf_bias_relu_nhwc(gmf_handle* h, float* y, const float* bias, const float* 
   return GMF_OK;
 }
 
+int gmf_conv_nhwc(gmf_handle* h, const float* x, const float* wimg, const float* bias, const float* residual, float* y,
+                  int B, int H, int W, int cin, int cout, int ksize, int stride, int relu, gmf_stream_t stream) {
+  GMF_REQUIRE(h && x && wimg && bias && y, GMF_ERR_BAD_ARG, "conv_nhwc: null pointer");
+  GMF_REQUIRE(B > 0 && H > 0 && W > 0, GMF_ERR_UNSUPPORTED_SHAPE, "conv_nhwc: empty input");
+  const bool known = (cin == 64 && cout == 64 && ksize == 3 && stride == 1) || (cin == 64 && cout == 128 && ksize == 3 && stride == 2) ||
+                     (cin == 128 && cout == 128 && ksize == 3 && stride == 1) || (cin == 64 && cout == 128 && ksize == 1 && stride == 2);
+  GMF_REQUIRE(known, GMF_ERR_UNSUPPORTED_SHAPE,
+              "conv_nhwc: supported are the ResNet-34 layer1 / layer2 shapes (64->64 3x3 s1, 64->128 3x3 s2, 128->128 3x3 s1, 64->128 1x1 s2)");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_conv_nhwc_h2(x, wimg, bias, residual, y, B, H, W, cin, cout, ksize, stride, relu, S(stream)));
+  return GMF_OK;
+}
+
 }  // extern "C"

@@ -4,9 +4,101 @@
 //   y = max(y + bias[c] (+ residual), 0)   in place on an NHWC tensor (resnet.py:59-75, BasicBlock.forward).
 #include <hip/hip_runtime.h>
 
+#include "mfma_core.hpp"
 #include "launchers.hpp"
 
 namespace gmf {
+
+// =========================================================================================
+// k_conv_nhwc_h2: 3x3 (pad 1) or 1x1 convolution, stride 1 or 2, NHWC fp32 in and out, as an implicit GEMM on the f16 MFMA
+// with split-fp16 operands (the arithmetic of the attention kernel: three products per multiply-add, fp32 accumulate,
+// weights stored as 256 W).  M = output pixels (32 per wave, 128 per workgroup), N = COUT (all blocks of 32 per wave),
+// K = taps x CIN in k-steps of 16 = (tap, 16 input channels).
+//   A operand: lane (pixel i, half h) loads input channels 16 cb + 8 h .. + 7 of the tap's input pixel (two float4s, zeros
+//              outside the image), splits them to fp16 hi/lo in registers; the next k-step's loads are in flight meanwhile.
+//   B operand: the weight image streams through a ring of 16 KiB LDS stages by DMA; per k-step and output block one
+//              (hi, lo) pair of 1 KiB units: unit ((ks_in_stage * NBLK + blk) * 2 + plane) * 64 + lane, lane (h, i) holding
+//              W[32 blk + i][k = 16 ks + 8 h .. + 7], k = tap * CIN + cin (packing.conv_image).
+//   epilogue:  y = acc / 256 + bias[cout] (+ residual) -> optional ReLU; a register row of a lane is one pixel, lanes run
+//              over 32 consecutive output channels: 128-byte rows.
+// =========================================================================================
+template <int CIN, int COUT, int KS, int STRIDE>
+__global__ void __launch_bounds__(256, 2)
+k_conv_nhwc_h2(const float* __restrict__ x, const float* __restrict__ wimg, const float* __restrict__ bias,
+               const float* __restrict__ residual, float* __restrict__ y, int B, int H, int W, int Ho, int Wo, int relu) {
+  constexpr int NBLK = COUT / 32, CB = CIN / 16, NK = KS * KS * CB;
+  constexpr int KPS = 4096 / (NBLK * 512);          // k-steps per 16 KiB stage (NBLK * 2 KiB per k-step)
+  constexpr int NST = (NK + KPS - 1) / KPS, PAD = KS / 2, NB = 3;
+  __shared__ __attribute__((aligned(16))) float lds[NB * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long P = (long)B * Ho * Wo;
+  const long pix0 = ((long)blockIdx.x * 4 + wave) * 32;
+  const long pix = pix0 + i;
+  const bool pvalid = pix < P;
+  int yo = 0, xo = 0;
+  long bimg = 0;
+  if (pvalid) { bimg = pix / ((long)Ho * Wo); const int rem = (int)(pix - bimg * Ho * Wo); yo = rem / Wo; xo = rem - yo * Wo; }
+  const int yc = yo * STRIDE - PAD, xc = xo * STRIDE - PAD;     // top-left input pixel of the window
+  const float* xb = x + (size_t)bimg * H * W * CIN + 8 * h;
+
+  StageRing<NB> ss;
+  ss.init(lds, wave, lane, wimg, NST);
+  ss.prime();
+
+  auto load_a = [&](int ks, float (&a)[8]) {
+    const int tap = ks / CB, cb = ks - tap * CB;
+    const int dy = tap / KS, dx = tap - dy * KS;
+    const int yi = yc + dy, xi = xc + dx;
+    const bool ok = pvalid && yi >= 0 && yi < H && xi >= 0 && xi < W;
+    if (ok) {
+      const float4* p = reinterpret_cast<const float4*>(xb + ((size_t)yi * W + xi) * CIN + 16 * cb);
+      const float4 u = p[0], v = p[1];
+      a[0] = u.x; a[1] = u.y; a[2] = u.z; a[3] = u.w; a[4] = v.x; a[5] = v.y; a[6] = v.z; a[7] = v.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    }
+  };
+
+  f32x16 acc[NBLK];
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) acc[blk] = zero16();
+  float a_cur[8], a_nxt[8];
+  load_a(0, a_cur);
+  for (int st = 0; st < NST; ++st) {
+    const f16x8* lw = reinterpret_cast<const f16x8*>(ss.acquire());
+#pragma unroll
+    for (int kk = 0; kk < KPS; ++kk) {
+      const int ks = st * KPS + kk;
+      if (ks < NK) {                                  // uniform
+        if (ks + 1 < NK) load_a(ks + 1, a_nxt);
+        f16x8 ah, al;
+        split8h(a_cur, ah, al);
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk)
+          mma3(acc[blk], ah, al, lw[((kk * NBLK + blk) * 2 + 0) * 64], lw[((kk * NBLK + blk) * 2 + 1) * 64]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a_cur[e] = a_nxt[e];
+      }
+    }
+  }
+  // register r of lane (h, i): pixel pix0 + 8 (r >> 2) + 4 h + (r & 3), output channel 32 blk + i
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    const float bv = bias[32 * blk + i];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long p = pix0 + 8 * (r >> 2) + 4 * h + (r & 3);
+      if (p < P) {
+        const size_t o = (size_t)p * COUT + 32 * blk + i;
+        float v = fmaf(acc[blk][r], 1.0f / 256.0f, bv);
+        if (residual) v += residual[o];
+        y[o] = relu ? fmaxf(v, 0.f) : v;
+      }
+    }
+  }
+}
 
 // total4 = n_pixels * C / 4 float4s; C % 4 == 0, so a float4 never straddles two pixels
 __global__ void __launch_bounds__(256)
@@ -28,6 +120,22 @@ k_bias_relu_nhwc(float* __restrict__ y, const float* __restrict__ bias, const fl
 hipError_t launch_bias_relu_nhwc(float* y, const float* bias, const float* residual, long n_pixels, int C, hipStream_t s) {
   const long total4 = n_pixels * (C / 4);
   hipLaunchKernelGGL(k_bias_relu_nhwc, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, y, bias, residual, total4, C / 4);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_nhwc_h2(const float* x, const float* wimg, const float* bias, const float* residual, float* y, int B,
+                               int H, int W, int cin, int cout, int ks, int stride, int relu, hipStream_t s) {
+  const int pad = ks / 2;
+  const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+  const long P = (long)B * Ho * Wo;
+  const dim3 grid((unsigned)((P + 127) / 128));
+#define GMF_CONV(CI, CO, K, S) hipLaunchKernelGGL((k_conv_nhwc_h2<CI, CO, K, S>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, Ho, Wo, relu)
+  if (cin == 64 && cout == 64 && ks == 3 && stride == 1) GMF_CONV(64, 64, 3, 1);
+  else if (cin == 64 && cout == 128 && ks == 3 && stride == 2) GMF_CONV(64, 128, 3, 2);
+  else if (cin == 128 && cout == 128 && ks == 3 && stride == 1) GMF_CONV(128, 128, 3, 1);
+  else if (cin == 64 && cout == 128 && ks == 1 && stride == 2) GMF_CONV(64, 128, 1, 2);
+  else return hipErrorInvalidValue;
+#undef GMF_CONV
   return hipGetLastError();
 }
 

@@ -781,3 +781,36 @@ def test_bias_relu_nhwc_epilogue():
         assert torch.equal(y, want)
     with pytest.raises(RuntimeError, match="multiple of 4"):
         h.call("gmf_bias_relu_nhwc", y.data_ptr(), b.data_ptr(), None, 4, 6, st)
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,H,W", [(64, 64, 3, 1, 30, 40), (64, 128, 3, 2, 30, 40), (128, 128, 3, 1, 15, 20),
+                                                      (64, 128, 1, 2, 30, 40), (64, 64, 3, 1, 7, 5), (64, 128, 3, 2, 9, 11)])
+def test_conv_nhwc_matches_torch(cin, cout, ks, stride, H, W):
+    """gmf_conv_nhwc (implicit GEMM, split-fp16 MFMA) against torch's fp64 convolution of the same fp32 inputs: ResNet-34
+    layer1 / layer2 shapes, odd sizes, residual and ReLU on and off."""
+    from gmf_amd import _lib, packing
+    h = _lib.handle_for(0)
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(cin + cout + ks + H)
+    B = 3
+    x = torch.randn(B, cin, H, W, generator=gen)
+    Wt = torch.randn(cout, cin, ks, ks, generator=gen) / (cin * ks * ks) ** 0.5
+    b = torch.randn(cout, generator=gen)
+    pad = ks // 2
+    ref = torch.nn.functional.conv2d(x.double(), Wt.double(), b.double(), stride, pad)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    res = torch.randn(B, cout, Ho, Wo, generator=gen)
+    xg = _gpu(x).contiguous(memory_format=torch.channels_last)
+    rg = _gpu(res).contiguous(memory_format=torch.channels_last)
+    wimg, bg = _gpu(packing.conv_image(Wt)), _gpu(b)
+    for with_res, relu in ((False, 0), (True, 1)):
+        y = torch.empty((B, cout, Ho, Wo), device=DEV).contiguous(memory_format=torch.channels_last)
+        h.call("gmf_conv_nhwc", xg.data_ptr(), wimg.data_ptr(), bg.data_ptr(), rg.data_ptr() if with_res else None, y.data_ptr(),
+               B, H, W, cin, cout, ks, stride, relu, st)
+        want = ref + (res.double() if with_res else 0)
+        if relu:
+            want = torch.relu(want)
+        f32 = torch.nn.functional.conv2d(x, Wt, b, stride, pad).double() + (res.double() if with_res else 0)
+        f32 = torch.relu(f32) if relu else f32
+        err, floor = _maxerr(y.cpu().double(), want), _maxerr(f32, want)
+        assert err < max(4.0 * floor, 4e-6), (err, floor)        # floor = error of torch's own fp32 convolution

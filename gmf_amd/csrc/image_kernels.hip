@@ -17,8 +17,8 @@ namespace gmf {
 //   A operand: lane (pixel i, half h) loads input channels 16 cb + 8 h .. + 7 of the tap's input pixel (two float4s, zeros
 //              outside the image), splits them to fp16 hi/lo in registers; the next k-step's loads are in flight meanwhile.
 //   B operand: the weight image streams through a ring of 16 KiB LDS stages by DMA; per k-step and output block one
-//              (hi, lo) pair of 1 KiB units: unit ((ks_in_stage * NBLK + blk) * 2 + plane) * 64 + lane, lane (h, i) holding
-//              W[32 blk + i][k = 16 ks + 8 h .. + 7], k = tap * CIN + cin (packing.conv_image).
+//              (hi, lo) pair of 1 KiB units, per 64-channel half of the output: unit ((ks * 2 + blk) * 2 + plane) * 64 + lane,
+//              lane (h, i) holding W[64 half + 32 blk + i][k = 16 ks + 8 h .. + 7], k = tap * CIN + cin (packing.conv_image).
 //   epilogue:  y = acc / 256 + bias[cout] (+ residual) -> optional ReLU; a register row of a lane is one pixel, lanes run
 //              over 32 consecutive output channels: 128-byte rows.
 // =========================================================================================
@@ -26,12 +26,15 @@ template <int CIN, int COUT, int KS, int STRIDE>
 __global__ void __launch_bounds__(256, 2)
 k_conv_nhwc_h2(const float* __restrict__ x, const float* __restrict__ wimg, const float* __restrict__ bias,
                const float* __restrict__ residual, float* __restrict__ y, int B, int H, int W, int Ho, int Wo, int relu) {
-  constexpr int NBLK = COUT / 32, CB = CIN / 16, NK = KS * KS * CB;
-  constexpr int KPS = 4096 / (NBLK * 512);          // k-steps per 16 KiB stage (NBLK * 2 KiB per k-step)
-  constexpr int NST = (NK + KPS - 1) / KPS, PAD = KS / 2, NB = 3;
+  // a workgroup: 128 output pixels x 64 output channels (blockIdx.y selects the 64-channel half: twice the workgroups for
+  // COUT = 128, whose 15 x 20 maps give only 150 pixel groups for 64 images); a stage = 4 k-steps x 2 blocks x (hi, lo)
+  constexpr int NBLK = 2, CB = CIN / 16, NK = KS * KS * CB, KPS = 4, NST = NK / KPS, PAD = KS / 2, NB = 3;
+  static_assert(NK % KPS == 0 && COUT % 64 == 0, "k-steps come in stages of four, output channels in halves of 64");
   __shared__ __attribute__((aligned(16))) float lds[NB * kStageFloats];
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int co0 = 64 * blockIdx.y;
+  wimg += (size_t)blockIdx.y * NST * kStageFloats;
   const long P = (long)B * Ho * Wo;
   const long pix0 = ((long)blockIdx.x * 4 + wave) * 32;
   const long pix = pix0 + i;
@@ -40,58 +43,71 @@ k_conv_nhwc_h2(const float* __restrict__ x, const float* __restrict__ wimg, cons
   long bimg = 0;
   if (pvalid) { bimg = pix / ((long)Ho * Wo); const int rem = (int)(pix - bimg * Ho * Wo); yo = rem / Wo; xo = rem - yo * Wo; }
   const int yc = yo * STRIDE - PAD, xc = xo * STRIDE - PAD;     // top-left input pixel of the window
-  const float* xb = x + (size_t)bimg * H * W * CIN + 8 * h;
 
-  StageRing<NB> ss;
-  ss.init(lds, wave, lane, wimg, NST);
-  ss.prime();
-
+  auto issue_stage = [&](int st) {
+    const float* g = wimg + (size_t)st * kStageFloats;
+    float* dst = lds + (st % NB) * kStageFloats;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);
+  };
+  // every lane always loads (clamped address, value zeroed afterwards): the number of vector-memory operations in flight
+  // must not depend on the data, the s_waitcnt counts below rely on it
+  const float* xb = x + (size_t)(pvalid ? bimg : 0) * H * W * CIN + 8 * h;
   auto load_a = [&](int ks, float (&a)[8]) {
     const int tap = ks / CB, cb = ks - tap * CB;
     const int dy = tap / KS, dx = tap - dy * KS;
     const int yi = yc + dy, xi = xc + dx;
     const bool ok = pvalid && yi >= 0 && yi < H && xi >= 0 && xi < W;
-    if (ok) {
-      const float4* p = reinterpret_cast<const float4*>(xb + ((size_t)yi * W + xi) * CIN + 16 * cb);
-      const float4 u = p[0], v = p[1];
-      a[0] = u.x; a[1] = u.y; a[2] = u.z; a[3] = u.w; a[4] = v.x; a[5] = v.y; a[6] = v.z; a[7] = v.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = 0.f;
-    }
+    const int yl = min(max(yi, 0), H - 1), xl = min(max(xi, 0), W - 1);
+    const float4* p = reinterpret_cast<const float4*>(xb + ((size_t)yl * W + xl) * CIN + 16 * cb);
+    const float4 u = p[0], v = p[1];
+    a[0] = ok ? u.x : 0.f; a[1] = ok ? u.y : 0.f; a[2] = ok ? u.z : 0.f; a[3] = ok ? u.w : 0.f;
+    a[4] = ok ? v.x : 0.f; a[5] = ok ? v.y : 0.f; a[6] = ok ? v.z : 0.f; a[7] = ok ? v.w : 0.f;
   };
 
   f32x16 acc[NBLK];
 #pragma unroll
   for (int blk = 0; blk < NBLK; ++blk) acc[blk] = zero16();
-  float a_cur[8], a_nxt[8];
-  load_a(0, a_cur);
+  // the activations of a whole stage (4 k-steps) are requested one stage ahead, AFTER that stage's DMA pieces were issued:
+  // in the vmcnt queue they are then younger than the weights they will meet and older than the next stage's DMA
+  float a_cur[KPS][8], a_nxt[KPS][8];
+  issue_stage(0);
+  if (NST > 1) issue_stage(1);
+#pragma unroll
+  for (int kk = 0; kk < KPS; ++kk) load_a(kk, a_cur[kk]);
   for (int st = 0; st < NST; ++st) {
-    const f16x8* lw = reinterpret_cast<const f16x8*>(ss.acquire());
+    // stage st landed for this wave when at most [DMA(st+1): 4] + [A(st): 8, waited for by the compiler anyway] are out
+    if (st + 1 < NST) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __syncthreads();                               // everyone's pieces of stage st landed; slot (st + 2) % 3 is free
+    if (st + 2 < NST) issue_stage(st + 2);
+    if (st + 1 < NST) {
+#pragma unroll
+      for (int kk = 0; kk < KPS; ++kk) load_a((st + 1) * KPS + kk, a_nxt[kk]);
+    }
+    const f16x8* lw = reinterpret_cast<const f16x8*>(lds + (st % NB) * kStageFloats) + lane;
 #pragma unroll
     for (int kk = 0; kk < KPS; ++kk) {
-      const int ks = st * KPS + kk;
-      if (ks < NK) {                                  // uniform
-        if (ks + 1 < NK) load_a(ks + 1, a_nxt);
-        f16x8 ah, al;
-        split8h(a_cur, ah, al);
+      f16x8 ah, al;
+      split8h(a_cur[kk], ah, al);
 #pragma unroll
-        for (int blk = 0; blk < NBLK; ++blk)
-          mma3(acc[blk], ah, al, lw[((kk * NBLK + blk) * 2 + 0) * 64], lw[((kk * NBLK + blk) * 2 + 1) * 64]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a_cur[e] = a_nxt[e];
-      }
+      for (int blk = 0; blk < NBLK; ++blk)
+        mma3(acc[blk], ah, al, lw[((kk * NBLK + blk) * 2 + 0) * 64], lw[((kk * NBLK + blk) * 2 + 1) * 64]);
     }
+#pragma unroll
+    for (int kk = 0; kk < KPS; ++kk)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a_cur[kk][e] = a_nxt[kk][e];
   }
-  // register r of lane (h, i): pixel pix0 + 8 (r >> 2) + 4 h + (r & 3), output channel 32 blk + i
+  // register r of lane (h, i): pixel pix0 + 8 (r >> 2) + 4 h + (r & 3), output channel co0 + 32 blk + i
 #pragma unroll
   for (int blk = 0; blk < NBLK; ++blk) {
-    const float bv = bias[32 * blk + i];
+    const float bv = bias[co0 + 32 * blk + i];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const long p = pix0 + 8 * (r >> 2) + 4 * h + (r & 3);
       if (p < P) {
-        const size_t o = (size_t)p * COUT + 32 * blk + i;
+        const size_t o = (size_t)p * COUT + co0 + 32 * blk + i;
         float v = fmaf(acc[blk][r], 1.0f / 256.0f, bv);
         if (residual) v += residual[o];
         y[o] = relu ? fmaxf(v, 0.f) : v;
@@ -128,7 +144,7 @@ hipError_t launch_conv_nhwc_h2(const float* x, const float* wimg, const float* b
   const int pad = ks / 2;
   const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
   const long P = (long)B * Ho * Wo;
-  const dim3 grid((unsigned)((P + 127) / 128));
+  const dim3 grid((unsigned)((P + 127) / 128), cout / 64);
 #define GMF_CONV(CI, CO, K, S) hipLaunchKernelGGL((k_conv_nhwc_h2<CI, CO, K, S>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, Ho, Wo, relu)
   if (cin == 64 && cout == 64 && ks == 3 && stride == 1) GMF_CONV(64, 64, 3, 1);
   else if (cin == 64 && cout == 128 && ks == 3 && stride == 2) GMF_CONV(64, 128, 3, 2);

@@ -123,16 +123,17 @@ def p16_h2(W: torch.Tensor) -> torch.Tensor:
 def conv_image(W: torch.Tensor) -> torch.Tensor:
     """[COUT, CIN, KS, KS] fp32 (BatchNorm folded) -> split-fp16 image of 256 W for k_conv_nhwc_h2 (image_kernels.hip).
 
-    k = tap * CIN + cin in k-steps of 16; per k-step and 32-output block a (hi, lo) pair of 1 KiB units:
-    unit ((ks * NBLK + blk) * 2 + plane) * 64 + lane, lane = 32 h + i holding W[32 blk + i][16 ks + 8 h .. + 7]."""
+    k = tap * CIN + cin in k-steps of 16; per 64-channel half of the output, k-step and 32-output block a (hi, lo) pair of
+    1 KiB units: unit (((half * NK + ks) * 2 + blk) * 2 + plane) * 64 + lane, lane = 32 h + i holding
+    W[64 half + 32 blk + i][16 ks + 8 h .. + 7]."""
     co, ci, kh, kw = W.shape
-    assert co % 32 == 0 and ci % 16 == 0 and kh == kw
+    assert co % 64 == 0 and ci % 16 == 0 and kh == kw
     Wk = (W.float() * H2_SCALE).permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
     hi = Wk.to(torch.float16)
     lo = (Wk - hi.float()).to(torch.float16)
     nk = Wk.shape[1] // 16
-    g = torch.stack([hi, lo]).reshape(2, co // 32, 32, nk, 2, 8)            # [plane, blk, i, ks, h, e]
-    g = g.permute(3, 1, 0, 4, 2, 5)                                         # [ks, blk, plane, h, i, e]
+    g = torch.stack([hi, lo]).reshape(2, co // 64, 2, 32, nk, 2, 8)         # [plane, half, blk, i, ks, h, e]
+    g = g.permute(1, 4, 2, 0, 5, 3, 6)                                      # [half, ks, blk, plane, h, i, e]
     return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
 
 

@@ -22,7 +22,9 @@ namespace gmf {
 //   epilogue:  y = acc / 256 + bias[cout] (+ residual) -> optional ReLU; a register row of a lane is one pixel, lanes run
 //              over 32 consecutive output channels: 128-byte rows.
 // =========================================================================================
-template <int CIN, int COUT, int KS, int STRIDE>
+// CBT: k order (channel block, tap) instead of (tap, channel block) - the order of the weight images of the stride-1 3x3
+// shapes, which k_conv3x3_patch_h2 shares.
+template <int CIN, int COUT, int KS, int STRIDE, bool CBT = false>
 __global__ void __launch_bounds__(256, 2)
 k_conv_nhwc_h2(const float* __restrict__ x, const float* __restrict__ wimg, const float* __restrict__ bias,
                const float* __restrict__ residual, float* __restrict__ y, int B, int H, int W, int Ho, int Wo, int relu) {
@@ -54,7 +56,7 @@ k_conv_nhwc_h2(const float* __restrict__ x, const float* __restrict__ wimg, cons
   // must not depend on the data, the s_waitcnt counts below rely on it
   const float* xb = x + (size_t)(pvalid ? bimg : 0) * H * W * CIN + 8 * h;
   auto load_a = [&](int ks, float (&a)[8]) {
-    const int tap = ks / CB, cb = ks - tap * CB;
+    const int tap = CBT ? ks % (KS * KS) : ks / CB, cb = CBT ? ks / (KS * KS) : ks - tap * CB;
     const int dy = tap / KS, dx = tap - dy * KS;
     const int yi = yc + dy, xi = xc + dx;
     const bool ok = pvalid && yi >= 0 && yi < H && xi >= 0 && xi < W;
@@ -116,6 +118,145 @@ k_conv_nhwc_h2(const float* __restrict__ x, const float* __restrict__ wimg, cons
   }
 }
 
+// =========================================================================================
+// k_conv3x3_patch_h2: the stride-1 3x3 shapes (64 -> 64, 128 -> 128) with the activations staged through LDS.
+//   For stride 1 the input pixels a workgroup's 128 consecutive (flattened NHWC) output pixels need are themselves one
+//   contiguous flat range [p0 - W - 1, p0 + 128 + W]: per 16-channel block cb it is loaded once (coalesced 64-byte pieces),
+//   split to fp16 hi / lo once and kept in LDS; the nine taps read it back with shifted addresses (two ds_read_b128 per lane
+//   and k-step) instead of nine global gathers and nine splits of the same values.  Taps outside the image read a zero slot.
+//   k order = (channel block, tap); weight image as packing.conv_image(W, order="cb_tap"), streamed as in k_conv_nhwc_h2.
+//   Two patch buffers: block cb + 1 is fetched to registers before block cb is multiplied and written to LDS after it.
+// =========================================================================================
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256, 2)
+k_conv3x3_patch_h2(const float* __restrict__ x, const float* __restrict__ wimg, const float* __restrict__ bias,
+                   const float* __restrict__ residual, float* __restrict__ y, int B, int H, int W, int relu) {
+  constexpr int NBLK = 2, CB = CIN / 16, NK = 9 * CB, KPS = 4, NST = NK / KPS, NB = 3;
+  constexpr int kPatchMax = 128 + 2 * 48 + 2;      // W <= 48
+  constexpr int kPatchUnits = kPatchMax * 2 + 2;   // 16-byte units per plane: pixel * 2 + half; the last two are the zero slot
+  __shared__ __attribute__((aligned(16))) float lds[NB * kStageFloats];
+  __shared__ __attribute__((aligned(16))) f16x8 patch[2][2][kPatchUnits];     // [buffer][plane][unit]
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int co0 = 64 * blockIdx.y;
+  wimg += (size_t)blockIdx.y * NST * kStageFloats;
+  const long P = (long)B * H * W;
+  const long p0 = (long)blockIdx.x * 128;          // first output pixel of the workgroup
+  const long q0 = p0 - W - 1;                      // flat input pixel of patch index 0
+  const int npatch = 128 + 2 * W + 2;
+  const long pix0 = p0 + wave * 32;
+  const long pix = pix0 + i;
+  const bool pvalid = pix < P;
+  int yo = 0, xo = 0;
+  if (pvalid) { const int rem = (int)(pix % ((long)H * W)); yo = rem / W; xo = rem - yo * W; }
+  // patch unit of tap (dy, dx) for this lane, or the zero slot
+  int unit[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int dy = t / 3, dx = t - 3 * dy;
+    const int yi = yo + dy - 1, xi = xo + dx - 1;
+    const bool ok = pvalid && yi >= 0 && yi < H && xi >= 0 && xi < W;
+    unit[t] = ok ? 2 * (wave * 32 + i + dy * W + dx) + h : 2 * kPatchMax + h;
+  }
+  if (threadIdx.x < 8) {                           // the zero slot of both buffers and planes
+    f16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (_Float16)0;
+    patch[threadIdx.x >> 2][(threadIdx.x >> 1) & 1][2 * kPatchMax + (threadIdx.x & 1)] = z;
+  }
+
+  auto issue_stage = [&](int st) {
+    const float* g = wimg + (size_t)st * kStageFloats;
+    float* dst = lds + (st % NB) * kStageFloats;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);
+  };
+  // patch block cb: thread t moves the float4 quarter (t & 3) of patch pixels (t >> 2) + 64 j, j = 0 .. 3 (always four
+  // loads, clamped address: the vmcnt counts below rely on it)
+  constexpr int PJ = 4;
+  static_assert(64 * PJ >= kPatchMax, "four pixels per thread cover the patch");
+  auto load_patch = [&](int cb, float4 (&v)[PJ]) {
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+      const int pp = (threadIdx.x >> 2) + 64 * j;
+      long q = q0 + pp;
+      q = q < 0 ? 0 : (q >= P ? P - 1 : q);
+      v[j] = *reinterpret_cast<const float4*>(x + (size_t)q * CIN + 16 * cb + 4 * (threadIdx.x & 3));
+    }
+  };
+  auto store_patch = [&](int buf, const float4 (&v)[PJ]) {
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+      const int pp = (threadIdx.x >> 2) + 64 * j;
+      if (pp < npatch) {
+        const f32x2 a = {v[j].x, v[j].y}, b = {v[j].z, v[j].w};
+        const f16x2 ah = __builtin_convertvector(a, f16x2), bh = __builtin_convertvector(b, f16x2);
+        const f16x2 al = lo2h(ah, v[j].x, v[j].y), bl = lo2h(bh, v[j].z, v[j].w);
+        // channel 4 * quarter .. + 3 of the pixel: half (quarter >> 1) of the unit, elements 4 (quarter & 1) ..
+        const int u = 2 * pp + ((threadIdx.x & 3) >> 1), e0 = 4 * (threadIdx.x & 1);
+        _Float16* dh = reinterpret_cast<_Float16*>(&patch[buf][0][u]) + e0;
+        _Float16* dl = reinterpret_cast<_Float16*>(&patch[buf][1][u]) + e0;
+        *reinterpret_cast<f16x2*>(dh) = ah; *reinterpret_cast<f16x2*>(dh + 2) = bh;
+        *reinterpret_cast<f16x2*>(dl) = al; *reinterpret_cast<f16x2*>(dl + 2) = bl;
+      }
+    }
+  };
+
+  f32x16 acc[NBLK];
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) acc[blk] = zero16();
+  float4 pv[PJ];
+  issue_stage(0);
+  issue_stage(1);
+  load_patch(0, pv);
+  store_patch(0, pv);                              // (compiler waits for the four loads)
+  if (CB > 1) load_patch(1, pv);
+  // both loops are fully unrolled: the tap index selects a register of `unit`, and the (stage, k-step) position of every
+  // (block, tap) pair is a compile-time constant
+  const f16x8* lw = nullptr;
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ks = cb * 9 + t, st = ks / KPS, kk = ks % KPS;
+      if (kk == 0) {
+        // everything but this wave's pieces of stage st + 1 has landed: stage st, and any patch loads (conservative)
+        if (st + 1 < NST) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // also publishes the patch written before it
+        if (st + 2 < NST) issue_stage(st + 2);
+        lw = reinterpret_cast<const f16x8*>(lds + (st % NB) * kStageFloats) + lane;
+      } else if (t == 0) {
+        __syncthreads();                           // patch block cb is in LDS
+      }
+      const f16x8 ah = patch[cb & 1][0][unit[t]], al = patch[cb & 1][1][unit[t]];
+#pragma unroll
+      for (int blk = 0; blk < NBLK; ++blk)
+        mma3(acc[blk], ah, al, lw[((kk * NBLK + blk) * 2 + 0) * 64], lw[((kk * NBLK + blk) * 2 + 1) * 64]);
+    }
+    // block cb + 1 (in registers since the start of block cb) goes to the other buffer: its last readers finished before
+    // the barrier that opened block cb; block cb + 2 is requested
+    if (cb + 1 < CB) {
+      store_patch((cb + 1) & 1, pv);
+      if (cb + 2 < CB) load_patch(cb + 2, pv);
+    }
+  }
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    const float bv = bias[co0 + 32 * blk + i];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long p = pix0 + 8 * (r >> 2) + 4 * h + (r & 3);
+      if (p < P) {
+        const size_t o = (size_t)p * COUT + co0 + 32 * blk + i;
+        float v = fmaf(acc[blk][r], 1.0f / 256.0f, bv);
+        if (residual) v += residual[o];
+        y[o] = relu ? fmaxf(v, 0.f) : v;
+      }
+    }
+  }
+}
+
 // total4 = n_pixels * C / 4 float4s; C % 4 == 0, so a float4 never straddles two pixels
 __global__ void __launch_bounds__(256)
 k_bias_relu_nhwc(float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ residual, long total4,
@@ -139,6 +280,9 @@ hipError_t launch_bias_relu_nhwc(float* y, const float* bias, const float* resid
   return hipGetLastError();
 }
 
+static bool g_conv_patch = true;      // stride-1 3x3 shapes on the LDS-patch kernel when W <= 48 (else the gather kernel, same image)
+void set_conv_patch(bool v) { g_conv_patch = v; }
+
 hipError_t launch_conv_nhwc_h2(const float* x, const float* wimg, const float* bias, const float* residual, float* y, int B,
                                int H, int W, int cin, int cout, int ks, int stride, int relu, hipStream_t s) {
   const int pad = ks / 2;
@@ -146,12 +290,20 @@ hipError_t launch_conv_nhwc_h2(const float* x, const float* wimg, const float* b
   const long P = (long)B * Ho * Wo;
   const dim3 grid((unsigned)((P + 127) / 128), cout / 64);
 #define GMF_CONV(CI, CO, K, S) hipLaunchKernelGGL((k_conv_nhwc_h2<CI, CO, K, S>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, Ho, Wo, relu)
-  if (cin == 64 && cout == 64 && ks == 3 && stride == 1) GMF_CONV(64, 64, 3, 1);
+  // stride-1 3x3 shapes: activations staged through LDS (weight image in (channel block, tap) order); W <= 48
+  if (g_conv_patch && ks == 3 && stride == 1 && W <= 48 && cin == cout && (cin == 64 || cin == 128)) {
+    if (cin == 64) hipLaunchKernelGGL((k_conv3x3_patch_h2<64, 64>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, relu);
+    else hipLaunchKernelGGL((k_conv3x3_patch_h2<128, 128>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, relu);
+    return hipGetLastError();
+  }
+#define GMF_CONV_CBT(CI, CO) hipLaunchKernelGGL((k_conv_nhwc_h2<CI, CO, 3, 1, true>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, Ho, Wo, relu)
+  if (cin == 64 && cout == 64 && ks == 3 && stride == 1) GMF_CONV_CBT(64, 64);
   else if (cin == 64 && cout == 128 && ks == 3 && stride == 2) GMF_CONV(64, 128, 3, 2);
-  else if (cin == 128 && cout == 128 && ks == 3 && stride == 1) GMF_CONV(128, 128, 3, 1);
+  else if (cin == 128 && cout == 128 && ks == 3 && stride == 1) GMF_CONV_CBT(128, 128);
   else if (cin == 64 && cout == 128 && ks == 1 && stride == 2) GMF_CONV(64, 128, 1, 2);
   else return hipErrorInvalidValue;
 #undef GMF_CONV
+#undef GMF_CONV_CBT
   return hipGetLastError();
 }
 

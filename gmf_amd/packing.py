@@ -120,15 +120,20 @@ def p16_h2(W: torch.Tensor) -> torch.Tensor:
     return gth.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
 
 
-def conv_image(W: torch.Tensor) -> torch.Tensor:
-    """[COUT, CIN, KS, KS] fp32 (BatchNorm folded) -> split-fp16 image of 256 W for k_conv_nhwc_h2 (image_kernels.hip).
+def conv_image(W: torch.Tensor, stride: int = 1) -> torch.Tensor:
+    """[COUT, CIN, KS, KS] fp32 (BatchNorm folded) -> split-fp16 image of 256 W for the convolution kernels (image_kernels.hip).
 
-    k = tap * CIN + cin in k-steps of 16; per 64-channel half of the output, k-step and 32-output block a (hi, lo) pair of
+    k-steps of 16 input channels: k = tap * CIN + cin, or - for the stride-1 3x3 shapes with CIN == COUT, whose kernel stages
+    one 16-channel block of activations at a time - k = (cin // 16) * 9 * 16 + tap * 16 + cin % 16; per 64-channel half of the output, k-step and 32-output block a (hi, lo) pair of
     1 KiB units: unit (((half * NK + ks) * 2 + blk) * 2 + plane) * 64 + lane, lane = 32 h + i holding
     W[64 half + 32 blk + i][16 ks + 8 h .. + 7]."""
     co, ci, kh, kw = W.shape
     assert co % 64 == 0 and ci % 16 == 0 and kh == kw
-    Wk = (W.float() * H2_SCALE).permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+    Wt = (W.float() * H2_SCALE).permute(0, 2, 3, 1)                         # [co, dy, dx, cin]
+    if kh == 3 and stride == 1 and co == ci:
+        Wk = Wt.reshape(co, 9, ci // 16, 16).permute(0, 2, 1, 3).reshape(co, 9 * ci)      # (channel block, tap, c)
+    else:
+        Wk = Wt.reshape(co, kh * kw * ci)                                   # (tap, cin)
     hi = Wk.to(torch.float16)
     lo = (Wk - hi.float()).to(torch.float16)
     nk = Wk.shape[1] // 16

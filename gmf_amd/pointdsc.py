@@ -73,7 +73,7 @@ class _FusedResNet:
             spec = {"w": w.contiguous(memory_format=cl), "b": b, "stride": conv.stride[0], "pad": conv.padding[0],
                     "cin": w.shape[1], "cout": w.shape[0], "ks": w.shape[2]}
             if native_convs and w.shape[1] % 16 == 0:
-                spec["img"] = packing.conv_image(w.cpu()).to(w.device)
+                spec["img"] = packing.conv_image(w.cpu(), conv.stride[0]).to(w.device)
             return spec
 
         self.stem = fold(bb.conv1, bb.bn1)

@@ -287,7 +287,8 @@ int gmf_bias_relu_nhwc(gmf_handle* h, float* y, const float* bias, const float* 
 /* Convolution of the ResNet-34 layer1 / layer2 shapes (GMF_PointDSC/models/resnet.py:36-75, 144-170) as an implicit GEMM on
  * the f16 MFMA with split-fp16 operands: x [B,H,W,cin] NHWC fp32 -> y [B,Ho,Wo,cout] NHWC fp32 (pad = ksize / 2),
  *   y = conv(x, W) + bias (+ residual [B,Ho,Wo,cout]) -> ReLU if relu != 0.
- * wimg: the BatchNorm-folded weights as a split-fp16 image of 256 W (gmf_amd/packing.py: conv_image).  Supported:
+ * wimg: the BatchNorm-folded weights as a split-fp16 image of 256 W (gmf_amd/packing.py: conv_image(W, stride); k order
+ * (channel block, tap) for the stride-1 3x3 shapes, (tap, channel block) for the others).  Supported:
  * (cin, cout, ksize, stride) = (64,64,3,1), (64,128,3,2), (128,128,3,1), (64,128,1,2). */
 int gmf_conv_nhwc(gmf_handle* h, const float* x, const float* wimg, const float* bias, const float* residual, float* y,
                   int B, int H, int W, int cin, int cout, int ksize, int stride, int relu, gmf_stream_t stream);

@@ -784,7 +784,8 @@ def test_bias_relu_nhwc_epilogue():
 
 
 @pytest.mark.parametrize("cin,cout,ks,stride,H,W", [(64, 64, 3, 1, 30, 40), (64, 128, 3, 2, 30, 40), (128, 128, 3, 1, 15, 20),
-                                                      (64, 128, 1, 2, 30, 40), (64, 64, 3, 1, 7, 5), (64, 128, 3, 2, 9, 11)])
+                                                      (64, 128, 1, 2, 30, 40), (64, 64, 3, 1, 7, 5), (64, 128, 3, 2, 9, 11),
+                                                      (128, 128, 3, 1, 5, 48), (64, 64, 3, 1, 3, 50)])
 def test_conv_nhwc_matches_torch(cin, cout, ks, stride, H, W):
     """gmf_conv_nhwc (implicit GEMM, split-fp16 MFMA) against torch's fp64 convolution of the same fp32 inputs: ResNet-34
     layer1 / layer2 shapes, odd sizes, residual and ReLU on and off."""
@@ -802,8 +803,9 @@ def test_conv_nhwc_matches_torch(cin, cout, ks, stride, H, W):
     res = torch.randn(B, cout, Ho, Wo, generator=gen)
     xg = _gpu(x).contiguous(memory_format=torch.channels_last)
     rg = _gpu(res).contiguous(memory_format=torch.channels_last)
-    wimg, bg = _gpu(packing.conv_image(Wt)), _gpu(b)
-    for with_res, relu in ((False, 0), (True, 1)):
+    wimg, bg = _gpu(packing.conv_image(Wt, stride)), _gpu(b)
+    for with_res, relu, patch in ((False, 0, 1), (True, 1, 1), (True, 1, 0)):
+        h.call("gmf_set_tuning", b"conv_lds_patch", patch)      # stride-1 3x3 shapes: LDS-patch kernel / gather kernel
         y = torch.empty((B, cout, Ho, Wo), device=DEV).contiguous(memory_format=torch.channels_last)
         h.call("gmf_conv_nhwc", xg.data_ptr(), wimg.data_ptr(), bg.data_ptr(), rg.data_ptr() if with_res else None, y.data_ptr(),
                B, H, W, cin, cout, ks, stride, relu, st)
@@ -814,3 +816,4 @@ def test_conv_nhwc_matches_torch(cin, cout, ks, stride, H, W):
         f32 = torch.relu(f32) if relu else f32
         err, floor = _maxerr(y.cpu().double(), want), _maxerr(f32, want)
         assert err < max(4.0 * floor, 4e-6), (err, floor)        # floor = error of torch's own fp32 convolution
+    h.call("gmf_set_tuning", b"conv_lds_patch", 1)

@@ -136,8 +136,9 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     gmf::set_use_cache(value != 0);
     return GMF_OK;
   }
-  if (std::strcmp(name, "conv_lds_patch") == 0) {      // 1 = stride-1 3x3 convolutions stage their activations through LDS (default), 0 = gather form
-    gmf::set_conv_patch(value != 0);
+  if (std::strcmp(name, "conv_lds_patch") == 0) {      // 1 = stride-1 3x3 convolutions stage their activations through LDS (default), 2 = same without the three-workgroup form, 0 = gather form
+    GMF_REQUIRE(value >= 0 && value <= 2, GMF_ERR_BAD_ARG, "set_tuning: conv_lds_patch must be 0, 1 or 2");
+    gmf::set_conv_patch(value);
     return GMF_OK;
   }
   if (std::strcmp(name, "nms_binned") == 0) {          // 1 = grid-binned NMS candidates on large grids (default), 2 = always, 0 = all pairs

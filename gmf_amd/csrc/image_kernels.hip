@@ -127,19 +127,26 @@ k_conv_nhwc_h2(const float* __restrict__ x, const float* __restrict__ wimg, cons
 //   k order = (channel block, tap); weight image as packing.conv_image(W, order="cb_tap"), streamed as in k_conv_nhwc_h2.
 //   Two patch buffers: block cb + 1 is fetched to registers before block cb is multiplied and written to LDS after it.
 // =========================================================================================
-template <int CIN, int COUT>
-__global__ void __launch_bounds__(256, 2)
+// KPS: k-steps per weight stage (4: 16 KiB stages; 3: 12 KiB stages that align with the nine taps of a channel block).
+// WMAX: largest image width the patch buffers hold.  DBUF: two patch buffers, or one with an extra barrier per channel block.
+// <64, 64, 3, 40, false, 3> needs 49.5 KiB of LDS: three workgroups per CU, so that the 600 workgroups of the 64 -> 64 shape
+// (64 images of 30 x 40) run in one round of the 768 slots instead of two rounds of 512.
+template <int CIN, int COUT, int KPS, int WMAX, bool DBUF, int WGS>
+__global__ void __launch_bounds__(256, WGS)
 k_conv3x3_patch_h2(const float* __restrict__ x, const float* __restrict__ wimg, const float* __restrict__ bias,
                    const float* __restrict__ residual, float* __restrict__ y, int B, int H, int W, int relu) {
-  constexpr int NBLK = 2, CB = CIN / 16, NK = 9 * CB, KPS = 4, NST = NK / KPS, NB = 3;
-  constexpr int kPatchMax = 128 + 2 * 48 + 2;      // W <= 48
+  constexpr int NBLK = 2, CB = CIN / 16, NK = 9 * CB, NST = NK / KPS, NB = 3;
+  constexpr int kStage = KPS * NBLK * 512;         // floats per weight stage: KPS k-steps x 2 blocks x (hi, lo) KiB
+  constexpr int kPatchMax = 128 + 2 * WMAX + 2;
   constexpr int kPatchUnits = kPatchMax * 2 + 2;   // 16-byte units per plane: pixel * 2 + half; the last two are the zero slot
-  __shared__ __attribute__((aligned(16))) float lds[NB * kStageFloats];
-  __shared__ __attribute__((aligned(16))) f16x8 patch[2][2][kPatchUnits];     // [buffer][plane][unit]
+  constexpr int NPB = DBUF ? 2 : 1;
+  static_assert(NK % KPS == 0, "k-steps come in whole stages");
+  __shared__ __attribute__((aligned(16))) float lds[NB * kStage];
+  __shared__ __attribute__((aligned(16))) f16x8 patch[NPB][2][kPatchUnits];     // [buffer][plane][unit]
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int co0 = 64 * blockIdx.y;
-  wimg += (size_t)blockIdx.y * NST * kStageFloats;
+  wimg += (size_t)blockIdx.y * NST * kStage;
   const long P = (long)B * H * W;
   const long p0 = (long)blockIdx.x * 128;          // first output pixel of the workgroup
   const long q0 = p0 - W - 1;                      // flat input pixel of patch index 0
@@ -158,7 +165,7 @@ k_conv3x3_patch_h2(const float* __restrict__ x, const float* __restrict__ wimg, 
     const bool ok = pvalid && yi >= 0 && yi < H && xi >= 0 && xi < W;
     unit[t] = ok ? 2 * (wave * 32 + i + dy * W + dx) + h : 2 * kPatchMax + h;
   }
-  if (threadIdx.x < 8) {                           // the zero slot of both buffers and planes
+  if (threadIdx.x < 4 * NPB) {                     // the zero slot of every buffer and plane
     f16x8 z;
 #pragma unroll
     for (int e = 0; e < 8; ++e) z[e] = (_Float16)0;
@@ -166,10 +173,10 @@ k_conv3x3_patch_h2(const float* __restrict__ x, const float* __restrict__ wimg, 
   }
 
   auto issue_stage = [&](int st) {
-    const float* g = wimg + (size_t)st * kStageFloats;
-    float* dst = lds + (st % NB) * kStageFloats;
+    const float* g = wimg + (size_t)st * kStage;
+    float* dst = lds + (st % NB) * kStage;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);
+    for (int q = 0; q < KPS; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);
   };
   // patch block cb: thread t moves the float4 quarter (t & 3) of patch pixels (t >> 2) + 64 j, j = 0 .. 3 (always four
   // loads, clamped address: the vmcnt counts below rely on it)
@@ -216,28 +223,31 @@ k_conv3x3_patch_h2(const float* __restrict__ x, const float* __restrict__ wimg, 
   const f16x8* lw = nullptr;
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
+    const int pb = DBUF ? (cb & 1) : 0;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int ks = cb * 9 + t, st = ks / KPS, kk = ks % KPS;
       if (kk == 0) {
         // everything but this wave's pieces of stage st + 1 has landed: stage st, and any patch loads (conservative)
-        if (st + 1 < NST) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (st + 1 < NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // also publishes the patch written before it
         if (st + 2 < NST) issue_stage(st + 2);
-        lw = reinterpret_cast<const f16x8*>(lds + (st % NB) * kStageFloats) + lane;
+        lw = reinterpret_cast<const f16x8*>(lds + (st % NB) * kStage) + lane;
       } else if (t == 0) {
         __syncthreads();                           // patch block cb is in LDS
       }
-      const f16x8 ah = patch[cb & 1][0][unit[t]], al = patch[cb & 1][1][unit[t]];
+      const f16x8 ah = patch[pb][0][unit[t]], al = patch[pb][1][unit[t]];
 #pragma unroll
       for (int blk = 0; blk < NBLK; ++blk)
         mma3(acc[blk], ah, al, lw[((kk * NBLK + blk) * 2 + 0) * 64], lw[((kk * NBLK + blk) * 2 + 1) * 64]);
     }
-    // block cb + 1 (in registers since the start of block cb) goes to the other buffer: its last readers finished before
-    // the barrier that opened block cb; block cb + 2 is requested
+    // block cb + 1 (in registers since the start of block cb) goes to LDS - to the other buffer, whose last readers
+    // finished before the barrier that opened block cb, or, with one buffer, after a barrier that ends block cb - and
+    // block cb + 2 is requested
     if (cb + 1 < CB) {
-      store_patch((cb + 1) & 1, pv);
+      if (!DBUF) __syncthreads();
+      store_patch(DBUF ? ((cb + 1) & 1) : 0, pv);
       if (cb + 2 < CB) load_patch(cb + 2, pv);
     }
   }
@@ -280,8 +290,8 @@ hipError_t launch_bias_relu_nhwc(float* y, const float* bias, const float* resid
   return hipGetLastError();
 }
 
-static bool g_conv_patch = true;      // stride-1 3x3 shapes on the LDS-patch kernel when W <= 48 (else the gather kernel, same image)
-void set_conv_patch(bool v) { g_conv_patch = v; }
+static int g_conv_patch = 1;      // stride-1 3x3 shapes on the LDS-patch kernel when W <= 48 (else the gather kernel, same image): 1 = automatic, 2 = never the three-workgroup form, 0 = gather
+void set_conv_patch(int v) { g_conv_patch = v; }
 
 hipError_t launch_conv_nhwc_h2(const float* x, const float* wimg, const float* bias, const float* residual, float* y, int B,
                                int H, int W, int cin, int cout, int ks, int stride, int relu, hipStream_t s) {
@@ -292,8 +302,12 @@ hipError_t launch_conv_nhwc_h2(const float* x, const float* wimg, const float* b
 #define GMF_CONV(CI, CO, K, S) hipLaunchKernelGGL((k_conv_nhwc_h2<CI, CO, K, S>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, Ho, Wo, relu)
   // stride-1 3x3 shapes: activations staged through LDS (weight image in (channel block, tap) order); W <= 48
   if (g_conv_patch && ks == 3 && stride == 1 && W <= 48 && cin == cout && (cin == 64 || cin == 128)) {
-    if (cin == 64) hipLaunchKernelGGL((k_conv3x3_patch_h2<64, 64>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, relu);
-    else hipLaunchKernelGGL((k_conv3x3_patch_h2<128, 128>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, relu);
+    // grids between one round of 512 and one of 768 workgroup slots: the 49.5 KiB form (three workgroups per CU)
+    const long nwg = (long)grid.x * grid.y;
+    if (cin == 64 && W <= 40 && g_conv_patch == 1 && nwg > 512 && nwg <= 768)
+      hipLaunchKernelGGL((k_conv3x3_patch_h2<64, 64, 3, 40, false, 3>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, relu);
+    else if (cin == 64) hipLaunchKernelGGL((k_conv3x3_patch_h2<64, 64, 4, 48, true, 2>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, relu);
+    else hipLaunchKernelGGL((k_conv3x3_patch_h2<128, 128, 4, 48, true, 2>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, relu);
     return hipGetLastError();
   }
 #define GMF_CONV_CBT(CI, CO) hipLaunchKernelGGL((k_conv_nhwc_h2<CI, CO, 3, 1, true>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, Ho, Wo, relu)

@@ -82,7 +82,7 @@ hipError_t launch_transformation_loss(const float* trans, const float* gt_trans,
 
 // image encoder epilogue (row f-1): image_kernels.hip
 hipError_t launch_bias_relu_nhwc(float* y, const float* bias, const float* residual, long n_pixels, int C, hipStream_t s);
-void set_conv_patch(bool v);
+void set_conv_patch(int v);
 hipError_t launch_conv_nhwc_h2(const float* x, const float* wimg, const float* bias, const float* residual, float* y, int B,
                                int H, int W, int cin, int cout, int ks, int stride, int relu, hipStream_t s);
 

@@ -817,3 +817,29 @@ def test_conv_nhwc_matches_torch(cin, cout, ks, stride, H, W):
         err, floor = _maxerr(y.cpu().double(), want), _maxerr(f32, want)
         assert err < max(4.0 * floor, 4e-6), (err, floor)        # floor = error of torch's own fp32 convolution
     h.call("gmf_set_tuning", b"conv_lds_patch", 1)
+
+
+def test_conv_three_workgroup_form():
+    """The 49.5 KiB form of the 64 -> 64 convolution (three workgroups per CU; taken when the grid has between 513 and 768
+    workgroups - 56 ... 81 images of 30 x 40) against the two-workgroup form (bit-identical: same arithmetic in the same
+    order) and against torch's convolution."""
+    from gmf_amd import _lib, packing
+    h = _lib.handle_for(0)
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(56)
+    B, C, H, W = 56, 64, 30, 40
+    x = torch.randn(B, C, H, W, generator=gen)
+    Wt = torch.randn(C, C, 3, 3, generator=gen) / (C * 9) ** 0.5
+    b = torch.randn(C, generator=gen)
+    xg = _gpu(x).contiguous(memory_format=torch.channels_last)
+    wimg, bg = _gpu(packing.conv_image(Wt, 1)), _gpu(b)
+    outs = []
+    for knob in (1, 2):
+        h.call("gmf_set_tuning", b"conv_lds_patch", knob)
+        y = torch.empty((B, C, H, W), device=DEV).contiguous(memory_format=torch.channels_last)
+        h.call("gmf_conv_nhwc", xg.data_ptr(), wimg.data_ptr(), bg.data_ptr(), None, y.data_ptr(), B, H, W, C, C, 3, 1, 1, st)
+        outs.append(y)
+    h.call("gmf_set_tuning", b"conv_lds_patch", 1)
+    assert torch.equal(outs[0], outs[1])
+    want = torch.relu(torch.nn.functional.conv2d(_gpu(x), _gpu(Wt), bg, 1, 1))
+    assert _maxerr(outs[0].cpu(), want.cpu()) < 1e-5

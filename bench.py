@@ -1,6 +1,6 @@
 """bench.py - correspondences/second of the GMF multimodal-fusion hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--sweep]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -8,17 +8,24 @@ One "step" = one pass of the whole hot path (PointDSC.forward in test mode: Fusi
 spatial-consistency attention, Fusion-2 with LCPE}, classifier head, pose head with on-device SVD and
 refinement) over one batch of synthetic scene pairs already resident in HBM.  Workload at every N:
 BASELINE.json configs[1] per GPU (32 pairs x 5000 correspondences x 128-d, 196 image tokens), fp32 - weak
-scaling: pairs are independent, each rank owns its own 32 pairs, and the only exchange is one RCCL
-all-gather of the per-pair logits and poses per step (inside the timed region).
+scaling: pairs are independent, each rank owns its own 32 pairs, and the only exchange is ONE RCCL
+all-gather of the packed per-pair logits and poses per step (inside the timed region).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline     - the dominant kernel (the spatial-consistency attention) against the f16 MFMA peak / 3 partial products,
-                 timed in situ with HIP events on the stream it is launched on
-  cpu_baseline - the CPU oracle (a port of the reference's PyTorch CPU path) timed on this host's cores
+                 timed in situ with HIP events on the stream it is launched on; HBM traffic per launch from the committed
+                 rocprofv3 PMC summary ONLY when that summary was taken on this very source tree (hash match), else null
+  step         - the whole step against the same peak (SURVEY.md section 8d F_logits)
+  cpu_baseline - the CPU oracle (a port of the reference's PyTorch CPU path) timed on this host's cores, all cores and 1 thread
+  ranks        - per-rank step time and the all-gather's own time (multi-GPU diagnostics)
+  sweep        - with --sweep: N = 1000 / 10000, the KITTI shape and the B = 1 latency points (headline unchanged)
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -30,17 +37,74 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# /opt/skills/guides/MI355X_MICROARCH.md, "Chip-level parameters": dense MFMA peaks
-PEAK_FP32_MFMA_TFLOPS = 157.3
+# /opt/skills/guides/MI355X_MICROARCH.md, "Chip-level parameters": dense MFMA peaks, HBM
 PEAK_F16_MFMA_TFLOPS = 2500.0
-# MFMA products issued per algorithmic multiply-add by each form of the attention kernel (gmf_set_tuning "scattn_variant")
-PRODUCTS = {0: 1, 1: 1, 2: 1, 3: 6, 4: 6, 5: 6, 6: 6, 7: 6, 8: 6, 9: 3, 10: 3, 16: 3, 17: 3, 18: 3}
+PEAK_HBM_GBS = 8000.0
+PRODUCTS = 3            # MFMA products per algorithmic multiply-add: split-fp16 operands, hh + hl + lh
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_scattn_h2p_pmc.json")
 
 
 def scattn_flops_per_launch(B: int, N: int) -> float:
-    """Algorithmic FLOPs of one k_scattn launch: QK^T + PV = 512*N^2 and the fused
+    """Algorithmic FLOPs of one attention launch: QK^T + PV = 512*N^2 and the fused
     fc_message 128->64->64->128 = 40 960*N, per pair (2 FLOP per MAC; compat/softmax elementwise work excluded)."""
     return B * (512.0 * N * N + 40960.0 * N)
+
+
+def scattn_bytes_per_launch(B: int, N: int) -> float:
+    """Compulsory HBM bytes of one attention launch: Q', K, V, fusion2_out in and the block output (5 x 512 B per row;
+    K / V re-reads hit L2 by construction of the XCD-aware grid) - SURVEY.md section 8d.  The compat cache this build streams
+    on top of that (4 B per (i, j), padded to 32 x 32 tiles) is NOT algorithmic: it shows up in `traffic`."""
+    return B * N * 5 * 512.0
+
+
+def step_flops(B: int, N: int, T: int) -> float:
+    """F_logits(N, T) of SURVEY.md section 8d, per batch."""
+    per_pair = 12 * (598784.0 * N + 512.0 * N * N + 256.0 * N * T + 33536.0 * T) + 11840.0 * N + 458752.0 * T + 256.0 * T * T
+    return B * per_pair
+
+
+def csrc_sha16() -> str:
+    """Hash of the kernel sources and the ABI header: ties a committed PMC summary to the build it was taken on."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "gmf_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "gmf_amd", "csrc", "*.hpp")) +
+                   glob.glob(os.path.join(ROOT, "gmf_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "include", "gmf_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_model(dev, kind):
+    import gmf_amd
+    from gmf_amd import synthetic
+    sigma_d, tau = (0.10, 0.10) if kind == "3dmatch" else (1.2, 1.2)
+    sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7, sigma_d=sigma_d)
+    model = gmf_amd.PointDSC(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1,
+                             inlier_threshold=tau, sigma_d=sigma_d, k=40, nms_radius=tau)
+    model.load_state_dict(sd, strict=False)
+    return model.to(dev).eval(), sd, tau
+
+
+def make_batch(dev, seeds, N, T, kind):
+    from gmf_amd import synthetic
+    batch = synthetic.synthetic_batch(seeds, N=N, T=T, kind=kind)
+    data = {k: batch[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    return batch, data
+
+
+def time_steps(driver, data, steps, warmup):
+    for _ in range(warmup):
+        out = driver.step(data)
+    torch.cuda.synchronize()
+    driver.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = driver.step(data)
+    torch.cuda.synchronize()
+    driver.barrier()
+    return time.perf_counter() - t0, out
 
 
 def main():
@@ -53,6 +117,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=196)
     ap.add_argument("--kind", default="3dmatch", choices=["3dmatch", "kitti"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", action="store_true", help="append N = 1000 / 10000, KITTI-shape and B = 1 results (rank 0, N = 1 GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -67,23 +132,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    import gmf_amd
-    from gmf_amd import _lib, synthetic
+    from gmf_amd import _lib
     from gmf_amd.dist import ShardedBatchDriver
 
     B, N, T = args.pairs, args.ncorr, args.tokens
-    sigma_d, tau = (0.10, 0.10) if args.kind == "3dmatch" else (1.2, 1.2)
-    sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7, sigma_d=sigma_d)
-    model = gmf_amd.PointDSC(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1,
-                             inlier_threshold=tau, sigma_d=sigma_d, k=40, nms_radius=tau)
-    model.load_state_dict(sd, strict=False)
-    model = model.to(dev).eval()
-
+    model, sd, tau = build_model(dev, args.kind)
     driver = ShardedBatchDriver(model, world, rank, dev)
     seeds = [rank * B + i for i in range(B)]                 # every rank owns its own pairs (weak scaling)
-    batch = synthetic.synthetic_batch(seeds, N=N, T=T, kind=args.kind)
-    data = {k: batch[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
-    data["testing"] = True
+    batch, data = make_batch(dev, seeds, N, T, args.kind)
     torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -98,13 +154,20 @@ def main():
     for _ in range(args.steps):
         out = driver.step(data)
     torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
     driver.barrier()
     dt = time.perf_counter() - t0
-    import ctypes as C
     ms_total, launches = C.c_double(0.0), C.c_int(0)
     handle.call("gmf_profile_read", C.byref(ms_total), C.byref(launches))
     handle.call("gmf_profile_enable", 0)
     dt = driver.max_over_ranks(dt)
+    # diagnostics outside the timed region: per-rank step time, and one more step with the model / gather split timed by events
+    per_rank_ms = driver.gather_floats(t_local / args.steps * 1e3)
+    driver.time_steps = True
+    driver.step(data)
+    model_ms, gather_ms = driver.read_timings()
+    driver.time_steps = False
+    gather_all = driver.gather_floats(gather_ms if gather_ms is not None else 0.0)
 
     if rank != 0:
         driver.close()
@@ -112,39 +175,72 @@ def main():
 
     value = world * B * N * args.steps / dt
     avg_ms = ms_total.value / max(1, launches.value)
-    achieved = scattn_flops_per_launch(B, N) / (avg_ms * 1e-3) / 1e12
-    variant = int(os.environ.get("GMF_SCATTN", "18"))
-    nprod = PRODUCTS.get(variant, 3)
-    if nprod == 1:
-        peak, peak_note, dtype = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA dense peak", "f32"
-    else:
-        peak = PEAK_F16_MFMA_TFLOPS / nprod
-        peak_note = (f"f16/bf16 MFMA dense peak 2500 TFLOP/s / {nprod} partial products per algorithmic multiply-add "
-                     "(split-precision operands, fp32 accumulate, fp32-equivalent results)")
-        dtype = "f32 (split-fp16 MFMA operands, fp32 accumulate)" if nprod == 3 else "f32 (split-bf16 MFMA operands, fp32 accumulate)"
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_scattn_h2p_pmc.json")
-    if variant == 18 and (B, N, T) == (32, 5000, 196) and os.path.exists(pmc_file):
-        traffic = json.load(open(pmc_file))["derived"]["traffic_bytes_per_launch"]   # rocprofv3 PMC, see the file
+    flops = scattn_flops_per_launch(B, N)
+    achieved = flops / (avg_ms * 1e-3) / 1e12
+    peak = PEAK_F16_MFMA_TFLOPS / PRODUCTS
+    alg_bytes = scattn_bytes_per_launch(B, N)
+    traffic, traffic_note = None, "no PMC summary for this source tree (profiles/r02_scattn_h2p_pmc.json missing or taken on another build)"
+    sha = csrc_sha16()
+    if os.path.exists(PMC_SUMMARY):
+        pmc = json.load(open(PMC_SUMMARY))
+        wl = pmc.get("workload", {})
+        if pmc.get("csrc_sha16") == sha and (wl.get("pairs"), wl.get("n_corr"), wl.get("tokens")) == (B, N, T):
+            traffic = pmc["derived"]["traffic_bytes_per_launch"]
+            traffic_note = f"rocprofv3 FETCH_SIZE / WRITE_SIZE passes on this source tree (csrc_sha16 {sha}), profiles/r02_scattn_h2p_pmc.json"
+    step_ms = dt / args.steps * 1e3
+    step_tflops = step_flops(B, N, T) / (step_ms * 1e-3) / 1e12
     line = {
         "metric": "correspondences/sec (whole node)", "value": value, "unit": "correspondences/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (split-fp16 MFMA operands, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"synthetic {args.kind}-shape pairs, PointDSC.forward test mode (logits + R,t)",
                    "pairs_per_gpu": B, "global_pairs": world * B, "n_corr": N, "feat_dim": 128, "image_tokens": T,
-                   "layers": 12, "parallelism": f"pairs sharded over {world} GPU(s), RCCL all-gather of logits+poses"},
-        "roofline": {"bound": "mfma", "kernel": "k_scattn (spatial-consistency attention + fc_message)",
+                   "layers": 12, "parallelism": f"pairs sharded over {world} GPU(s), one RCCL all-gather of packed logits+poses"},
+        "roofline": {"bound": "mfma", "kernel": "k_scattn_h2p (spatial-consistency attention + fc_message)",
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": traffic, "peak_note": peak_note,
-                     "executed_mfma_tflops": achieved * nprod, "x_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
-                     "avg_launch_ms": avg_ms, "launches_timed": launches.value,
-                     "flops_per_launch": scattn_flops_per_launch(B, N)},
+                     "traffic": traffic, "traffic_note": traffic_note,
+                     "algorithmic_bytes": alg_bytes,
+                     "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                     "hbm_floor_ms": (traffic / (PEAK_HBM_GBS * 1e9) * 1e3) if traffic else None,
+                     "peak_note": (f"f16 MFMA dense peak {PEAK_F16_MFMA_TFLOPS:.0f} TFLOP/s / {PRODUCTS} partial products per algorithmic "
+                                   "multiply-add (split-fp16 operands, fp32 accumulate, fp32-equivalent results)"),
+                     "executed_mfma_tflops": achieved * PRODUCTS,
+                     "avg_launch_ms": avg_ms, "launches_timed": launches.value, "flops_per_launch": flops},
+        "step": {"algorithmic_tflops": step_tflops, "frac_of_peak": step_tflops / peak,
+                 "flops_per_step": step_flops(B, N, T), "note": "F_logits of SURVEY.md section 8d x pairs / step time"},
+        "ranks": {"per_rank_ms_per_step": per_rank_ms, "model_ms": model_ms, "all_gather_ms": gather_ms,
+                  "all_gather_ms_per_rank": gather_all,
+                  "note": "outside the timed region: one extra step with HIP events around the forward and around pack + all-gather"},
+        "csrc_sha16": sha,
     }
-
+    if args.sweep and world == 1:
+        line["sweep"] = sweep(dev)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"], line["parity"] = cpu_baseline(sd, batch, out, N, T, tau)
     print(json.dumps(line))
     driver.close()
+
+
+def sweep(dev):
+    """Other operating points of the same build: N in {1 k, 10 k}, the KITTI shape (config 3) and the
+    B = 1 latency points (the reference's evaluation mode).  Few steps each; the headline is not affected."""
+    from gmf_amd.dist import ShardedBatchDriver
+    rows = []
+    peak = PEAK_F16_MFMA_TFLOPS / PRODUCTS
+    for kind, B, N, steps in (("3dmatch", 32, 1000, 5), ("3dmatch", 32, 10000, 2), ("kitti", 16, 10000, 2),
+                              ("3dmatch", 1, 1000, 20), ("3dmatch", 1, 5000, 10), ("3dmatch", 1, 10000, 5)):
+        model, _, _ = build_model(dev, kind)
+        _, data = make_batch(dev, list(range(B)), N, 196, kind)
+        drv = ShardedBatchDriver(model, 1, 0, dev)
+        dt, _ = time_steps(drv, data, steps, 2)
+        ms = dt / steps * 1e3
+        tf = step_flops(B, N, 196) / (ms * 1e-3) / 1e12
+        rows.append({"workload": f"{kind} {B} pairs x {N}", "ms_per_step": ms, "value": B * N / (ms * 1e-3),
+                     "unit": "correspondences/s", "step_frac_of_peak": tf / peak})
+        del model, data
+        torch.cuda.empty_cache()
+    return rows
 
 
 def host_cpu_share() -> int:
@@ -159,9 +255,20 @@ def host_cpu_share() -> int:
     return n
 
 
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sd, batch, gpu_out, N, T, tau):
     """Time the CPU oracle (port of the reference's PyTorch CPU path) on a bounded sample: pair 0 of the same
-    batch, test mode, B=1 as the reference runs it; 1 warm-up + 5 repetitions (~12 s of CPU work), median.  Also report parity."""
+    batch, test mode, B=1 as the reference runs it; 1 warm-up + 5 repetitions on all cores (~12 s of CPU work), median,
+    then 1 repetition on ONE thread (~15 s; scaling context).  Also report parity."""
     from oracle import gmf_oracle as O
     import statistics
     one = {k: v[:1] for k, v in batch.items()}
@@ -174,10 +281,17 @@ def cpu_baseline(sd, batch, gpu_out, N, T, tau):
             t0 = time.perf_counter()
             ref = O.pointdsc_forward(sd, one, inlier_threshold=tau, nms_radius=tau, testing=True)
             ts.append(time.perf_counter() - t0)
+        torch.set_num_threads(1)
+        t0 = time.perf_counter()
+        O.pointdsc_forward(sd, one, inlier_threshold=tau, nms_radius=tau, testing=True)
+        t1 = time.perf_counter() - t0
+        torch.set_num_threads(cores)
     med = statistics.median(ts)
     base = {"value": N / med, "unit": "correspondences/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(), "value_1_thread": N / t1,
             "sample": f"1 pair x {N} correspondences x 128-d, {T} tokens, PointDSC.forward test mode, median of 5 "
-                      f"after 1 warm-up ({med:.2f} s per pair), torch {torch.__version__} CPU fp32"}
+                      f"after 1 warm-up on {cores} threads ({med:.2f} s per pair) + 1 run on 1 thread ({t1:.1f} s), "
+                      f"torch {torch.__version__} CPU fp32"}
     parity = {"max_abs_dlogit": float((gpu_out["logits"][:1].cpu() - ref["logits"]).abs().max()),
               "max_abs_dT": float((gpu_out["final_trans"][:1].cpu() - ref["final_trans"]).abs().max()),
               "vs": "CPU oracle on pair 0 of the timed batch"}

@@ -33,10 +33,9 @@ class EncoderWeights(C.Structure):
         ("tail_wst", _vp), ("tail_vec", _vp), ("tail_wst_stride", C.c_int), ("tail_vec_stride", C.c_int),
         ("head_wst", _vp), ("head_vec", _vp),
         ("sigma_d", C.c_float),
-        ("ff_wst_b3", _vp), ("ff_wst_b3_stride", C.c_int), ("f1_ff_wst_b3", _vp),
         ("front_wst_h2", _vp), ("ctx_wst_h2", _vp), ("attn_wst_h2", _vp), ("ff_wst_h2", _vp),
         ("f1_ctx_wst_h2", _vp), ("f1_attn_wst_h2", _vp), ("f1_ff_wst_h2", _vp),
-        ("tail_wst_h2", _vp), ("tail_wst_q16", _vp),
+        ("tail_wst_h2", _vp),
     ]
 
 
@@ -114,7 +113,7 @@ def load_library() -> C.CDLL:
             fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.gmf_abi_version() != 1:
+        if lib.gmf_abi_version() != 2:
             raise RuntimeError("gmf_amd: libgmf_hip.so ABI version mismatch")
         _lib = lib
         return lib

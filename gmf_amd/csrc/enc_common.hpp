@@ -46,21 +46,6 @@ GMF_DEVINL void store_block_timg(float* __restrict__ tile_base, int db, const f3
     p[q * 64] = make_float4(a[4 * q + 0] + bias, a[4 * q + 1] + bias, a[4 * q + 2] + bias, a[4 * q + 3] + bias);
 }
 
-// bf16x3 image of a 32 x 128 tile: 16-byte unit index ((plane*8 + slot)*64 + lane); slot = MFMA k-step.
-// Y^T block mb (rows on lanes) fills slots 2mb, 2mb+1; a T-layout block db fills slots 2db, 2db+1.
-GMF_DEVINL void store_block_b3(float* __restrict__ tile_base, int blk, const float (&t)[16], int lane) {
-  bf16x8* base = reinterpret_cast<bf16x8*>(tile_base);
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    bf16x8 hi, mi, lo;
-    split8(&t[8 * half], hi, mi, lo);
-    const int slot = 2 * blk + half;
-    base[(0 * 8 + slot) * 64 + lane] = hi;
-    base[(1 * 8 + slot) * 64 + lane] = mi;
-    base[(2 * 8 + slot) * 64 + lane] = lo;
-  }
-}
-
 // fp16x2 image of a 32 x 128 tile: 16-byte unit ((plane*8 + slot)*64 + lane), planes hi | lo.
 GMF_DEVINL void store_block_h2(float* __restrict__ tile_base, int blk, const float (&t)[16], int lane) {
   f16x8* base = reinterpret_cast<f16x8*>(tile_base);
@@ -71,26 +56,6 @@ GMF_DEVINL void store_block_h2(float* __restrict__ tile_base, int blk, const flo
     const int slot = 2 * blk + half;
     base[(0 * 8 + slot) * 64 + lane] = hi;
     base[(1 * 8 + slot) * 64 + lane] = lo;
-  }
-}
-
-// V tile image for the 16x16x32 attention kernel (k_scattn_h2q): 16-byte unit ((plane*8 + db16)*64 + 16 g + c) holds, for
-// feature d = 16 db16 + c, the 8 keys {4g .. 4g+3, 16+4g .. 16+4g+3} of the tile - the contraction order in which a lane
-// (g, c) of that kernel holds its probabilities.  `t` is a T-layout block of 32 features (feature on the lane, rows
-// 8(r>>2) + 4h + (r&3) in the registers): lane (h, i) owns the units g = h (registers 0-3, 8-11) and g = 2+h (4-7, 12-15).
-GMF_DEVINL void store_block_vq16(float* __restrict__ tile_base, int db32, const float (&t)[16], int lane) {
-  f16x8* base = reinterpret_cast<f16x8*>(tile_base);
-  const int h = lane >> 5, i = lane & 31;
-  const int db16 = 2 * db32 + (i >> 4), c = i & 15;
-#pragma unroll
-  for (int which = 0; which < 2; ++which) {
-    const float v8[8] = {t[4 * which], t[4 * which + 1], t[4 * which + 2], t[4 * which + 3],
-                         t[8 + 4 * which], t[8 + 4 * which + 1], t[8 + 4 * which + 2], t[8 + 4 * which + 3]};
-    f16x8 hi, lo;
-    split8h(v8, hi, lo);
-    const int g = 2 * which + h;
-    base[(0 * 8 + db16) * 64 + 16 * g + c] = hi;
-    base[(1 * 8 + db16) * 64 + 16 * g + c] = lo;
   }
 }
 

@@ -4,7 +4,7 @@
 // but 8 x 3 MFMAs of 32 cycles per 32 x 128 block instead of 64 MFMAs of 64 cycles.
 //   k_front_h2        PointDSC.py:88,104-109,56-58     [layer0] + PointCN + Q'/K/V projections -> fp16x2 images
 //   k_fusion_attn_h2  fusion_layer.py:119-121,44,84-94,190
-//   k_fusion_ff_h2    fusion_layer.py:54-69,191
+//   k_fusion_ff_h2p   fusion_layer.py:54-69,191
 //   k_ctx_prep_h2     fusion_layer.py:124-126,46-49,86-87
 #include <algorithm>
 #include <cstdlib>
@@ -23,8 +23,7 @@ constexpr int kRing = GMF_H2_RING;   // LDS ring depth of the weight / context s
 //   vecs (fp32): bp | bq' | bk | bv | b0 | W0 image (fp32, K=8: layer0 stays on the f32 MFMA, 4 MFMAs per block)
 //   outputs: f as fp32 P32 image; Q', K, V as fp16x2 plane images (16 KiB per tile).
 // =========================================================================================
-// VQ: V is written in the q16 tile layout (store_block_vq16) for the 16x16x32 attention kernel.
-template <int MODE, bool VQ>
+template <int MODE>
 __global__ void __launch_bounds__(256, 2)
 k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const float* __restrict__ vecs,
            float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out,
@@ -121,7 +120,7 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
     float t[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bv);
-    if (active) { if (VQ) store_block_vq16(v_out + toff, db, t, lane); else store_block_h2(v_out + toff, db, t, lane); }
+    if (active) store_block_h2(v_out + toff, db, t, lane);
   }
 }
 
@@ -317,77 +316,9 @@ k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_im
 }
 
 // =========================================================================================
-// k_fusion_ff_h2: stages (48 x 16 KiB): for c in 0..15: W1a_c | W1g_c | W2_c (4 blocks of 32 x 32: 2 planes x 2 steps)
-// =========================================================================================
-__global__ void __launch_bounds__(256, 2)
-k_fusion_ff_h2(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
-               float* __restrict__ x2_out, int tiles) {
-  __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
-  const int lane = threadIdx.x & 63, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = blockIdx.y;
-  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
-  const bool active = tile_raw < tiles;
-  const int tile = active ? tile_raw : tiles - 1;
-  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
-
-  StageRing<kRing> ss;
-  ss.init(lds, wave, lane, wst, 3 * (FFH / 32));
-  ss.prime();
-  FragH2<8> nx;
-  {
-    float x[CF], xn[CF];
-    load_frag_p32<CF>(x, x1 + toff, lane);
-    layernorm_frag<CF>(xn, x, vecs, vecs + C, h);
-    nx.set(xn);
-  }
-  f32x16 y[4];
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb) y[mb] = zero16();
-  const float* b1a = vecs + 2 * C;
-  const float* b1g = vecs + 2 * C + FFH;
-
-  for (int c = 0; c < FFH / 32; ++c) {
-    float ga[16];
-    {
-      const f16x8* lw = as_h2(ss.acquire());
-      f32x16 acc = zero16();
-      mma_wx_h2<8>(acc, lw, nx);
-      float b[16];
-      load_vec_block(b, b1a, c, h);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ga[r] = acc[r] + b[r];
-    }
-    {
-      const f16x8* lw = as_h2(ss.acquire());
-      f32x16 acc = zero16();
-      mma_wx_h2<8>(acc, lw, nx);
-      float b[16];
-      load_vec_block(b, b1g, c, h);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ga[r] *= gelu_erf_1r(acc[r] + b[r]);
-    }
-    {
-      FragH2<2> gx;
-      gx.set(ga);
-      const f16x8* lw = as_h2(ss.acquire());
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) mma_wx_h2<2>(y[mb], lw + mb * (2 * 2 * 64), gx);
-    }
-  }
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    float b[16], xr[16], t[16];
-    load_vec_block(b, vecs + 2 * C + 2 * FFH, mb, h);
-    load_block_p32(xr, x1 + toff, mb, lane);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = fmaf(y[mb][r], kH2Inv, b[r]) + xr[r];
-    if (active) store_block_p32(x2_out + toff, mb, t, lane);
-  }
-}
-
-// =========================================================================================
-// k_fusion_ff_h2p: k_fusion_ff_h2 with the chunk loop software-pipelined inside each wave.
+// k_fusion_ff_h2p: LayerNorm + Linear(128 -> 1024) + GEGLU + Linear(512 -> 128) + residual (fusion_layer.py:54-69,191) with
+//   the chunk loop software-pipelined inside each wave.
+//   stages (48 x 16 KiB): for c in 0..15: W1a_c | W1g_c | W2_c (4 blocks of 32 x 32: 2 planes x 2 steps)
 //   A GEGLU chunk is 48 MFMAs of W1 (value | gate, K = 128), 16 GELUs (~24 vector instructions each) and 24 MFMAs of
 //   W2; in program order they run back to back and the kernel costs matrix time PLUS vector time.  Here the W1 MFMAs
 //   of chunk c+1 are issued three at a time with one GELU of chunk c in their issue gaps (16 units), the fp16 split
@@ -396,8 +327,7 @@ k_fusion_ff_h2(const float* __restrict__ x1, const float* __restrict__ wst, cons
 //   A0 G0 | A1 G1 W2_0 | ... | A15 G15 W2_14 | W2_15 addressed into the unchanged blob; past the end the last stage is
 //   re-fetched into a free slot instead of branching), so a whole chunk is one basic block for the scheduler.
 // =========================================================================================
-// ABL (timing only, wrong results): 1 = one LDS-DMA piece per wave and stage instead of four, 2 = no GELU
-template <int ABL, bool SPLIT = false>
+template <bool SPLIT>
 __global__ void __launch_bounds__(256, 2)
 k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
                 float* __restrict__ x2_out, int tiles, float* __restrict__ part) {
@@ -428,12 +358,11 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
     const float* g = wst + (size_t)blob_stage(n_issued) * kStageFloats;
     float* dst = lds + (n_issued & (NB - 1)) * kStageFloats;
 #pragma unroll
-    for (int q = 0; q < (ABL == 1 ? 1 : 4); ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);
+    for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);
     ++n_issued;
   };
   auto acquire = [&]() {
-    if (ABL == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but this wave's pieces of the 2 younger stages have landed
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but this wave's pieces of the 2 younger stages have landed
     __syncthreads();
     const f16x8* cur = reinterpret_cast<const f16x8*>(lds + (n_used & (NB - 1)) * kStageFloats) + lane;
     ++n_used;
@@ -488,7 +417,7 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
           if (half == 0) mma3(a_nxt, wh, wl, nx.h[s], nx.l[s]);
           else mma3(g_nxt, wh, wl, nx.h[s], nx.l[s]);
           wh = wh_n; wl = wl_n;
-          a_cur[u] *= (ABL == 2) ? g_cur[u] : gelu_erf_1r(g_cur[u]);
+          a_cur[u] *= gelu_erf_1r(g_cur[u]);
           if (half == 1 && (s & 1)) { const int j = s - 1; split2h(a_cur[j], a_cur[j + 1], gx.h[0], gx.l[0], j); }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -576,20 +505,13 @@ k_ff_reduce(const float* __restrict__ part, const float* __restrict__ x1, const 
 // -----------------------------------------------------------------------------------------
 static inline dim3 tgrid(int tiles, int B, int sets = 1) { return dim3((tiles + kWavesPerWG - 1) / kWavesPerWG, B, sets); }
 
-static bool g_front_split = [] { const char* e = getenv("GMF_FRONT_SPLIT"); return e ? atoi(e) != 0 : true; }();
-void set_front_split(bool v) { g_front_split = v; }
-
-hipError_t launch_front_h2(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
-                           float* v, int B, int N, int tiles, hipStream_t s, bool v_q16) {
-  const bool vq = v_q16;
+hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
+                           float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s) {
   dim3 g = tgrid(tiles, B);
-  if (mode != 2 && g.x * B < 128 && g_front_split) g.z = 3;      // small grids: one workgroup per output (Q' + f | K | V)
-#define GMF_FRONT_H2(M) do { if (vq) hipLaunchKernelGGL((k_front_h2<M, true>), g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles); \
-                             else hipLaunchKernelGGL((k_front_h2<M, false>), g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles); } while (0)
-  if (mode == 1) GMF_FRONT_H2(1);
-  else if (mode == 2) GMF_FRONT_H2(2);
-  else GMF_FRONT_H2(0);
-#undef GMF_FRONT_H2
+  if (mode != 2 && g.x * B < 128 && tune.front_split) g.z = 3;      // small grids: one workgroup per output (Q' + f | K | V)
+  if (mode == 1) hipLaunchKernelGGL(k_front_h2<1>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  else if (mode == 2) hipLaunchKernelGGL(k_front_h2<2>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  else hipLaunchKernelGGL(k_front_h2<0>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
   return hipGetLastError();
 }
 
@@ -607,18 +529,13 @@ hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, 
   return hipGetLastError();
 }
 
-static int g_ff_split = [] { const char* e = getenv("GMF_FF_SPLIT"); return e ? atoi(e) : 0; }();
-void set_ff_split(int v) { g_ff_split = v; }
-
-hipError_t launch_fusion_ff_h2(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s,
-                               float* part, int max_parts) {
-  static const bool pipelined = [] { const char* e = getenv("GMF_FF_PIPE"); return e ? atoi(e) != 0 : true; }();
-  static const int abl = [] { const char* e = getenv("GMF_FF_ABL"); return e ? atoi(e) : 0; }();
-  const int force_hs = g_ff_split;   // 0 = automatic, 1 = off, 2 / 4 / 8 = forced
+hipError_t launch_fusion_ff_h2(const Tuning& tune, const float* x1, const float* wst, const float* vecs, float* x2, int B,
+                               int tiles, hipStream_t s, float* part, int max_parts) {
+  const int force_hs = tune.ff_split;   // 0 = automatic, 1 = off, 2 / 4 / 8 = forced
   const dim3 g = tgrid(tiles, B);
   // small grids: divide the 16 hidden chunks over 2 / 4 / 8 workgroups (deterministic two-pass sum)
   int hs = 1;
-  if (pipelined && abl == 0 && part && max_parts >= 2) {
+  if (part && max_parts >= 2) {
     const int base = g.x * B;
     if (force_hs > 0) hs = force_hs;
     else if (base < 256) hs = base <= 64 ? 8 : base <= 128 ? 4 : 2;
@@ -626,13 +543,10 @@ hipError_t launch_fusion_ff_h2(const float* x1, const float* wst, const float* v
     if (hs != 2 && hs != 4 && hs != 8) hs = 1;
   }
   if (hs > 1) {
-    hipLaunchKernelGGL((k_fusion_ff_h2p<0, true>), dim3(g.x, g.y, hs), dim3(256), 0, s, x1, wst, vecs, x2, tiles, part);
+    hipLaunchKernelGGL(k_fusion_ff_h2p<true>, dim3(g.x, g.y, hs), dim3(256), 0, s, x1, wst, vecs, x2, tiles, part);
     hipLaunchKernelGGL(k_ff_reduce, dim3(g.x, g.y, 4), dim3(256), 0, s, part, x1, vecs, x2, tiles, hs);
   }
-  else if (pipelined && abl == 1) hipLaunchKernelGGL(k_fusion_ff_h2p<1>, g, dim3(256), 0, s, x1, wst, vecs, x2, tiles, (float*)nullptr);
-  else if (pipelined && abl == 2) hipLaunchKernelGGL(k_fusion_ff_h2p<2>, g, dim3(256), 0, s, x1, wst, vecs, x2, tiles, (float*)nullptr);
-  else if (pipelined) hipLaunchKernelGGL(k_fusion_ff_h2p<0>, g, dim3(256), 0, s, x1, wst, vecs, x2, tiles, (float*)nullptr);
-  else hipLaunchKernelGGL(k_fusion_ff_h2, g, dim3(256), 0, s, x1, wst, vecs, x2, tiles);
+  else hipLaunchKernelGGL(k_fusion_ff_h2p<false>, g, dim3(256), 0, s, x1, wst, vecs, x2, tiles, (float*)nullptr);
   return hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
-// GMF correspondence encoder on gfx950: the fp32-MFMA kernels of every stage and every form of the spatial-consistency
-// attention kernel (the split-fp16 linear stages live in encoder_h2.hip).
+// GMF correspondence encoder on gfx950: the fp32-MFMA kernels of every stage and the spatial-consistency attention
+// kernels (the split-fp16 linear stages live in encoder_h2.hip).
 //
 // Replaces (file:line relative to /root/reference/GMF_PointDSC/):
 //   k_front      models/PointDSC.py:88,104-109,56-58   layer0 / PointCN conv1x1+BN+ReLU, Q/K/V conv1x1
@@ -14,9 +14,10 @@
 //   k_scattn_h2p  (18, DEFAULT) split-fp16 MFMA operands, c streamed from the compat cache, tile loop software-pipelined
 //                 inside each wave, split-fp16 fc_message epilogue; KSPLIT form + k_scattn_merge for small grids
 //   k_scattn_h2   (9)  split-fp16, c recomputed in-kernel or cached, not pipelined: fallback when the cache does not fit
-//   k_scattn_h2q  (19) the 16x16x32 MFMA form (own V / c / weight layouts); measured slower, kept for A/B
-//   k_scattn_b3, k_scattn_b3p (3..8) split-bf16 (3 planes, 6 products); k_scattn, k_scattn_pipe (0..2) fp32 MFMA;
-//   k_scattn_dense: the drop-in NonLocalBlock with a caller-supplied dense `attention` [B,N,N]
+//   k_scattn      (0)  fp32 MFMA on fp32 images: the single-stage entry point gmf_scattn_forward and, as k_scattn<true>,
+//                 the drop-in NonLocalBlock with a caller-supplied dense `attention` [B,N,N]
+// The measured-and-rejected forms of round 1 (split-bf16, 8-wave, rational compat, 16x16x32 MFMA, timing ablations) are
+// kept as source only in tools/ubench/archive/ and are not part of the library.
 //
 // Every kernel runs 4 waves per workgroup, each wave owning one 32-row tile ("rows on lanes",
 // see mfma_core.hpp).  Weights, K/V tiles and context tiles stream L2 -> LDS in 16 KiB stages by
@@ -33,9 +34,7 @@ namespace gmf {
 // =========================================================================================
 // MODE 0: in = feat image, PointCN applied.  MODE 1: in = corr_pos, layer0 then PointCN.
 // MODE 2: in = feat image used as-is (stand-alone NonLocalBlock whose caller already applied PointCN).
-// FMT 0: Q', K (P32) and V (T image) in fp32.  FMT 1: bf16x3 plane images (24 KiB per tile) for k_scattn_b3.
-// FMT 2: fp16x2 plane images (16 KiB per tile) for k_scattn_h2.
-template <int MODE, int FMT>
+template <int MODE>
 __global__ void __launch_bounds__(256, 2)
 k_front(const float* __restrict__ in, const float* __restrict__ wst, const float* __restrict__ vecs,
         float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out,
@@ -47,7 +46,6 @@ k_front(const float* __restrict__ in, const float* __restrict__ wst, const float
   const bool active = tile_raw < tiles;
   const int tile = active ? tile_raw : tiles - 1;
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
-  const size_t toff3 = ((size_t)pair * tiles + tile) * (size_t)(FMT == 1 ? kB3TileFloats : 32 * C);
 
   constexpr bool FIRST = (MODE == 1);
   StageStream ss;
@@ -100,7 +98,7 @@ k_front(const float* __restrict__ in, const float* __restrict__ wst, const float
 
 #pragma unroll
   for (int which = 0; which < 2; ++which) {   // Q', K
-    float* dst = (which == 0 ? q_out : k_out) + toff3;
+    float* dst = (which == 0 ? q_out : k_out) + toff;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       const float4* lw = ss.acquire();
@@ -110,11 +108,7 @@ k_front(const float* __restrict__ in, const float* __restrict__ wst, const float
       load_vec_block(b, vecs + (1 + which) * C, mb, h);
 #pragma unroll
       for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r];
-      if (active) {
-        if (FMT == 1) store_block_b3(dst, mb, t, lane);
-        else if (FMT == 2) store_block_h2(dst, mb, t, lane);
-        else store_block_p32(dst, mb, t, lane);
-      }
+      if (active) store_block_p32(dst, mb, t, lane);
     }
   }
 #pragma unroll
@@ -123,17 +117,7 @@ k_front(const float* __restrict__ in, const float* __restrict__ wst, const float
     f32x16 acc = zero16();
     mma_xw<CF>(acc, lw, f);
     const float bv = vecs[3 * C + 32 * db + i];
-    if (active) {
-      if (FMT != 0) {
-        float t[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t[r] = acc[r] + bv;
-        if (FMT == 1) store_block_b3(v_out + toff3, db, t, lane);
-        else store_block_h2(v_out + toff3, db, t, lane);
-      } else {
-        store_block_timg(v_out + toff3, db, acc, bv, lane);
-      }
-    }
+    if (active) store_block_timg(v_out + toff, db, acc, bv, lane);
   }
 }
 
@@ -306,15 +290,6 @@ k_scattn(const float* __restrict__ q_img, const float* __restrict__ k_img, const
   }
 }
 
-// =========================================================================================
-// k_scattn_pipe: software-pipelined form of k_scattn (same math, same images, same epilogue).
-//   Inside one wave the QK^T MFMA chain of tile t+1 is issued together with the compat/softmax VALU
-//   work of tile t (independent instruction streams in one basic block), so the matrix pipe does not
-//   idle while the vector pipe builds c_ij and the exponentials.  K tiles therefore run one tile
-//   ahead of V / pts8 tiles in the LDS double buffers.  The j < N mask exists only in the last tile
-//   and the O rescale is skipped when no row's running max moved.
-//   FASTSQRT: v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf expansion.
-// =========================================================================================
 // Correctly rounded square root for the squared distances (normal range or exactly 0): v_sqrt_f32 (1 ulp) plus
 // one FMA correction step, y' = y + (x - y*y) * (0.5 * rsq(x)).  Agrees with sqrtf bit for bit on 6.7e7 sampled
 // squared distances (tools/ubench/sqrt_check.hip; raw v_sqrt_f32 differs on 15 % of them) at 6 instructions
@@ -325,453 +300,41 @@ GMF_DEVINL float sqrt_cr(float x) {
   return fmaf(fmaf(-y, y, x), hr, y);
 }
 
-// d = ||a|| - ||b|| from the squared lengths.
-//   FASTSQRT = false: the reference's form, sqrt(a2) - sqrt(b2) with correctly rounded square roots (sqrt_cr),
-//                     i.e. the same roundings as torch.norm on the CPU.
-//   FASTSQRT = true : the rational form (a2 - b2) / (sqrt(a2) + sqrt(b2)).  The two lengths are nearly equal
-//                     exactly where c_ij > 0 matters, so the subtraction of two rounded square roots in the
-//                     reference form is where its error comes from; here the difference is taken on the
-//                     squared lengths and the square roots (v_sqrt_f32, 1 ulp) and the reciprocal
-//                     (v_rcp_f32) only enter through a well-conditioned denominator.  7 instructions.
-template <bool FASTSQRT>
-GMF_DEVINL float len_diff(float a2, float b2) {
-  if (FASTSQRT) {
-    const float den = fmaxf(__builtin_amdgcn_sqrtf(a2) + __builtin_amdgcn_sqrtf(b2), 1e-30f);
-    return (a2 - b2) * __builtin_amdgcn_rcpf(den);
-  }
-  return sqrt_cr(a2) - sqrt_cr(b2);
-}
+// d = ||a|| - ||b|| from the squared lengths in the reference's form, sqrt(a2) - sqrt(b2) with correctly rounded square
+// roots (sqrt_cr), i.e. the same roundings as torch.norm on the CPU (PointDSC.py:217-219).
+GMF_DEVINL float len_diff(float a2, float b2) { return sqrt_cr(a2) - sqrt_cr(b2); }
 
 // compat * score for one element; lp points at this lane-half's first key of the tile (pts8 rows)
-template <bool FASTSQRT>
 GMF_DEVINL float compat_times(const float4* lp, int jl, const float (&si)[3], const float (&ti)[3], float inv_sig2, float sc) {
   const float4 a = lp[2 * jl], b = lp[2 * jl + 1];
   const float ax = si[0] - a.x, ay = si[1] - a.y, az = si[2] - a.z;
   const float bx = ti[0] - b.x, by = ti[1] - b.y, bz = ti[2] - b.z;
-  const float d = len_diff<FASTSQRT>(fmaf(az, az, fmaf(ay, ay, ax * ax)), fmaf(bz, bz, fmaf(by, by, bx * bx)));
+  const float d = len_diff(fmaf(az, az, fmaf(ay, ay, ax * ax)), fmaf(bz, bz, fmaf(by, by, bx * bx)));
   return fmaxf(1.0f - d * d * inv_sig2, 0.f) * sc;
 }
 
-template <bool FASTSQRT>
-__global__ void __launch_bounds__(256, 2)
-k_scattn_pipe(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
-              const float* __restrict__ pts8, const float* __restrict__ fus, const float* __restrict__ wst,
-              const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2) {
-  // LDS: K slots [2][4096] | V slots [2][4096] | pts slots [2][256]
-  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats + 512];
-  float* const ldsK = lds;
-  float* const ldsV = lds + 2 * kStageFloats;
-  float* const ldsP = lds + 4 * kStageFloats;
-  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = blockIdx.y;
-  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
-  const bool active = tile_raw < tiles;
-  const int tile = active ? tile_raw : tiles - 1;
-  const size_t pbase = (size_t)pair * tiles;
-  const size_t toff = (pbase + tile) * (32 * C);
-
-  float qf[CF];
-  load_frag_p32<CF>(qf, q_img + toff, lane);
-  float si[3], ti[3];
-  {
-    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)tile * 32 + i) * 8);
-    const float4 a = pp[0], b = pp[1];
-    si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
-  }
-  const float* gk = k_img + pbase * (32 * C);
-  const float* gv = v_img + pbase * (32 * C);
-  const float* gp = pts8 + pbase * 32 * 8;
-
-  auto issueK = [&](int t) { dma_issue(gk + (size_t)t * kStageFloats, ldsK + (t & 1) * kStageFloats, 16, wave, kWavesPerWG, lane); };
-  auto issueV = [&](int t) {
-    dma_issue(gv + (size_t)t * kStageFloats, ldsV + (t & 1) * kStageFloats, 16, wave, kWavesPerWG, lane);
-    if (wave == (t & 3)) dma_piece_1k(gp + (size_t)t * 256, ldsP + (t & 1) * 256, lane);
-  };
-
-  f32x16 oacc[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
-  float m_run = -INFINITY, l_half = 0.f;
-
-  issueK(0);
-  if (tiles > 1) issueK(1);
-  issueV(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  f32x16 s_cur = zero16();
-  mma_wx<CF>(s_cur, reinterpret_cast<const float4*>(ldsK) + lane, qf);
-
-  for (int t = 0; t < tiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();            // K_{t+1}, V_t, pts_t landed; every wave is done with K_t, V_{t-1}, pts_{t-1}
-    if (t + 2 < tiles) issueK(t + 2);
-    if (t + 1 < tiles) issueV(t + 1);
-    const float4* lp = reinterpret_cast<const float4*>(ldsP + (t & 1) * 256) + 8 * h;
-    const float4* lv = reinterpret_cast<const float4*>(ldsV + (t & 1) * kStageFloats) + lane;
-    float x[16];
-    float mx = -INFINITY;
-    f32x16 s_next = zero16();
-    if (t + 1 < tiles) {
-      // ---- phase 1: S_{t+1} MFMA chain  ||  compat + scores of tile t (no key mask: tile t is full) ----
-      // Hand-placed interleave: unit u = one MFMA + a quarter of one element's VALU work, fenced by
-      // sched_barrier(0).  Left to itself hipcc emits the whole dependent MFMA chain in one run (the wave
-      // then waits 64 cycles in front of every MFMA with its VALU work queued behind), and
-      // sched_group_barrier pipelines were not honoured for this block (ROCm 7.2).
-      const float4* lk = reinterpret_cast<const float4*>(ldsK + ((t + 1) & 1) * kStageFloats) + lane;
-      float4 kf = lk[0], pa = lp[0], pb = lp[1];
-      float4 kf_n = kf, pa_n = pa, pb_n = pb;
-      float d2s = 0.f, d2t = 0.f, cc = 0.f;
-#pragma unroll
-      for (int u = 0; u < 64; ++u) {
-        const int g = u >> 2, e = u & 3;
-        if (e == 0 && g < 15) {
-          const int jn = 8 * ((g + 1) >> 2) + ((g + 1) & 3);
-          kf_n = lk[(g + 1) * 64]; pa_n = lp[2 * jn]; pb_n = lp[2 * jn + 1];
-        }
-        s_next = mfma32(e == 0 ? kf.x : e == 1 ? kf.y : e == 2 ? kf.z : kf.w, qf[u], s_next);
-        if (e == 0) {
-          const float ax = si[0] - pa.x, ay = si[1] - pa.y, az = si[2] - pa.z;
-          d2s = fmaf(az, az, fmaf(ay, ay, ax * ax));
-        } else if (e == 1) {
-          const float bx = ti[0] - pb.x, by = ti[1] - pb.y, bz = ti[2] - pb.z;
-          d2t = fmaf(bz, bz, fmaf(by, by, bx * bx));
-        } else if (e == 2) {
-          const float d = len_diff<FASTSQRT>(d2s, d2t);
-          cc = fmaxf(1.0f - d * d * inv_sig2, 0.f);
-        } else {
-          x[g] = cc * s_cur[g];
-          mx = fmaxf(mx, x[g]);
-          kf = kf_n; pa = pa_n; pb = pb_n;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      const int jbase = t * 32 + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int jl = 8 * (g >> 2) + (g & 3);
-        const float v = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, s_cur[g]);
-        x[g] = (jbase + jl < N) ? v : -INFINITY;
-        mx = fmaxf(mx, x[g]);
-      }
-    }
-    mx = xhalf_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const bool moved = m_new > m_run;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    if (__any(moved)) {
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-    }
-    // ---- phase 2: O^T += V_t^T P^T, with the exponentials of the next 4 keys under each run of 16 MFMAs ----
-    float ls = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { x[e] = __builtin_amdgcn_exp2f(x[e] - m_new); ls += x[e]; }
-    {
-      float4 vv = lv[0], vv_n = vv;
-#pragma unroll
-      for (int u = 0; u < 64; ++u) {
-        const int q = u >> 4, db = (u >> 2) & 3, e = u & 3;
-        if (e == 0 && u < 60) {
-          const int un = u + 4, qn = un >> 4, dbn = (un >> 2) & 3;
-          vv_n = lv[(dbn * 4 + qn) * 64];
-        }
-        oacc[db] = mfma32(e == 0 ? vv.x : e == 1 ? vv.y : e == 2 ? vv.z : vv.w, x[4 * q + e], oacc[db]);
-        if (db == 0 && q < 3) {
-          const int r = 4 * (q + 1) + e;
-          x[r] = __builtin_amdgcn_exp2f(x[r] - m_new);
-          ls += x[r];
-        }
-        if (e == 3) vv = vv_n;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    l_half = fmaf(l_half, alpha, ls);
-    s_cur = s_next;
-  }
-
-  // ---- epilogue: normalise, fc_message, add the Fusion-2 branch (identical to k_scattn) ----
-  float o[CF];
-  {
-    const float inv = 1.0f / xhalf_sum(l_half);
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
-  }
-  __syncthreads();
-  StageStream ss;
-  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, wst, 5);
-  ss.prime();
-  float m1[DHF], m2[DHF];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const float4* lw = ss.acquire();
-    f32x16 acc = zero16();
-    mma_wx<CF>(acc, lw, o);
-    float b[16];
-    load_vec_block(b, vecs, mb, h);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
-  }
-  {
-    const float4* lw = ss.acquire();
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      f32x16 acc = zero16();
-      mma_wx<DHF>(acc, lw + mb * (32 * DH / 4), m1);
-      float b[16];
-      load_vec_block(b, vecs + 64, mb, h);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
-    }
-  }
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    const float4* lw = ss.acquire();
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int mb = 2 * st + hb;
-      f32x16 acc = zero16();
-      mma_wx<DHF>(acc, lw + hb * (32 * DH / 4), m2);
-      float b[16], fz[16], t[16];
-      load_vec_block(b, vecs + 128, mb, h);
-      load_block_p32(fz, fus + toff, mb, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r] + fz[r];
-      if (active) store_block_p32(out + toff, mb, t, lane);
-    }
-  }
-}
-
 // =========================================================================================
-// k_scattn_b3: the attention loop on the bf16 MFMA with split-bf16 operands (fp32-equivalent accuracy).
-//   Same algorithm and epilogue as k_scattn; Q', K, V arrive as bf16x3 plane images from k_front<.,true>.
-//   8 waves per workgroup (256 queries), one workgroup per CU (100 KB LDS: two buffers of K|V|pts8), two
-//   waves per SIMD: one wave's MFMA runs under the other's compat/softmax VALU work.
-//   Per 32x32 tile and wave: 48 + 48 MFMAs of 32 cycles (vs 128 of 64 in fp32).
-// =========================================================================================
-constexpr int kB3Waves = 8;                       // k_scattn_b3p (double-buffered, 1 workgroup per CU)
-constexpr int kB3sWaves = 4;                      // k_scattn_b3  (single-buffered, 2 workgroups per CU)
-constexpr int kB3BufFloats = 2 * kB3TileFloats + 256;
-
-// Single-buffered K | V | pts8 (49 KB) so that TWO independent 4-wave workgroups fit on a CU: the two waves
-// that share a SIMD then belong to different workgroups, are not barrier-locked to each other, and one's
-// MFMA phase runs under the other's VALU phase.  Two barriers per tile: B1 after the QK^T phase (K_t is
-// free -> K_{t+1} streams in under the softmax and PV phases), B2 after the PV phase (V_t, pts_t are free
-// -> V_{t+1}, pts_{t+1} stream in under the next QK^T phase).
-// ABL (timing-only ablations, results wrong): 1 = no compat term, 2 = no compat and no exponentials,
-// 3 = K/V operands not re-read from LDS, 4 = no DMA of K/V tiles, 5 = no barriers B1/B2 (racy).
-template <bool FASTSQRT, int WAVES, int ABL = 0>
-__global__ void __launch_bounds__(64 * WAVES, 2)
-k_scattn_b3(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
-            const float* __restrict__ pts8, const float* __restrict__ fus, const float* __restrict__ wst,
-            const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2, int wgs_per_pair) {
-  __shared__ __attribute__((aligned(16))) float lds[kB3BufFloats];
-  float* const ldsK = lds;
-  float* const ldsV = lds + kB3TileFloats;
-  float* const ldsP = lds + 2 * kB3TileFloats;
-  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // XCD-aware work mapping: hardware deals workgroup L to XCD L % 8, so give XCD x one contiguous run of
-  // (pair, query-block) items.  All workgroups of a pair then stream the SAME K/V tiles through ONE L2 at
-  // about the same time (each tile is fetched from HBM/MALL once per pair instead of once per workgroup).
-  // Pure speed choice: any placement computes the same result.
-  int pair, qblock;
-  {
-    const int total = gridDim.x, L = blockIdx.x;
-    const int chunk = total >> 3, rem = total & 7, xcd = L & 7, kth = L >> 3;
-    const int start = (xcd < rem) ? xcd * (chunk + 1) : rem * (chunk + 1) + (xcd - rem) * chunk;
-    const int logical = start + kth;
-    pair = logical / wgs_per_pair;
-    qblock = logical - pair * wgs_per_pair;
-  }
-  const int tile_raw = qblock * WAVES + wave;
-  const bool active = tile_raw < tiles;
-  const int tile = active ? tile_raw : tiles - 1;
-  const size_t pbase = (size_t)pair * tiles;
-  const size_t toff = (pbase + tile) * (32 * C);
-
-  bf16x8 qh[8], qm[8], ql[8];
-  {
-    const bf16x8* qp = reinterpret_cast<const bf16x8*>(q_img + (pbase + tile) * (size_t)kB3TileFloats) + lane;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) { qh[s] = qp[(0 * 8 + s) * 64]; qm[s] = qp[(1 * 8 + s) * 64]; ql[s] = qp[(2 * 8 + s) * 64]; }
-  }
-  float si[3], ti[3];
-  {
-    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)tile * 32 + i) * 8);
-    const float4 a = pp[0], b = pp[1];
-    si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
-  }
-  const float* gk = k_img + pbase * (size_t)kB3TileFloats;
-  const float* gv = v_img + pbase * (size_t)kB3TileFloats;
-  const float* gp = pts8 + pbase * 32 * 8;
-  auto issueK = [&](int t) { if (ABL != 4) dma_issue(gk + (size_t)t * kB3TileFloats, ldsK, 24, wave, WAVES, lane); };
-  auto issueV = [&](int t) {
-    if (ABL != 4) dma_issue(gv + (size_t)t * kB3TileFloats, ldsV, 24, wave, WAVES, lane);
-    if (wave == (t & (WAVES - 1))) dma_piece_1k(gp + (size_t)t * 256, ldsP, lane);
-  };
-
-  f32x16 oacc[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
-  float m_run = -INFINITY, l_half = 0.f;
-  const bf16x8* lk = reinterpret_cast<const bf16x8*>(ldsK) + lane;
-  const bf16x8* lv = reinterpret_cast<const bf16x8*>(ldsV) + lane;
-  const float4* lp = reinterpret_cast<const float4*>(ldsP) + 8 * h;
-
-  issueK(0);
-  issueV(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int t = 0; t < tiles; ++t) {
-    // ---- S^T = K_t Q'^T : 8 k-steps x 6 partial products ----
-    f32x16 sacc = zero16();
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int ss_ = (ABL == 3) ? 0 : s;
-      const bf16x8 kh = lk[(0 * 8 + ss_) * 64], km = lk[(1 * 8 + ss_) * 64], kl = lk[(2 * 8 + ss_) * 64];
-      mma6(sacc, kh, km, kl, qh[s], qm[s], ql[s]);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V_t, pts_t (issued one phase ago) have landed
-    if (ABL != 5) __syncthreads();                     // B1: every wave is done reading K_t
-    if (t + 1 < tiles) issueK(t + 1);
-    // ---- compat, scores, online softmax ----
-    float x[16];
-    float mx = -INFINITY;
-    if (t + 1 < tiles) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int jl = 8 * (r >> 2) + (r & 3);
-        x[r] = (ABL == 1 || ABL == 2) ? sacc[r] : compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
-        mx = fmaxf(mx, x[r]);
-      }
-    } else {
-      const int jbase = t * 32 + 4 * h;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int jl = 8 * (r >> 2) + (r & 3);
-        const float v = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
-        x[r] = (jbase + jl < N) ? v : -INFINITY;
-        mx = fmaxf(mx, x[r]);
-      }
-    }
-    mx = xhalf_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const bool moved = m_new > m_run;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float ls = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { x[r] = (ABL == 2) ? (x[r] - m_new) : __builtin_amdgcn_exp2f(x[r] - m_new); ls += x[r]; }
-    l_half = fmaf(l_half, alpha, ls);
-    if (__any(moved)) {
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-    }
-    // ---- O^T += V_t^T P^T : P planes straight from the accumulator registers ----
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 ph, pm, pl;
-      split8(&x[8 * s2], ph, pm, pl);
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const int slot = (ABL == 3) ? 0 : 2 * db + s2;
-        const bf16x8 vh = lv[(0 * 8 + slot) * 64], vm = lv[(1 * 8 + slot) * 64], vl = lv[(2 * 8 + slot) * 64];
-        mma6(oacc[db], vh, vm, vl, ph, pm, pl);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K_{t+1} (issued two phases ago) has landed
-    if (ABL != 5) __syncthreads();                     // B2: every wave is done reading V_t, pts_t
-    if (t + 1 < tiles) issueV(t + 1);
-  }
-
-  // ---- epilogue: normalise, fc_message (fp32 MFMA), add the Fusion-2 branch ----
-  float o[CF];
-  {
-    const float inv = 1.0f / xhalf_sum(l_half);
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
-  }
-  __syncthreads();
-  StageStream ss;
-  ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5);
-  ss.prime();
-  float m1[DHF], m2[DHF];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const float4* lw = ss.acquire();
-    f32x16 acc = zero16();
-    mma_wx<CF>(acc, lw, o);
-    float b[16];
-    load_vec_block(b, vecs, mb, h);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
-  }
-  {
-    const float4* lw = ss.acquire();
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      f32x16 acc = zero16();
-      mma_wx<DHF>(acc, lw + mb * (32 * DH / 4), m1);
-      float b[16];
-      load_vec_block(b, vecs + 64, mb, h);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
-    }
-  }
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    const float4* lw = ss.acquire();
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int mb = 2 * st + hb;
-      f32x16 acc = zero16();
-      mma_wx<DHF>(acc, lw + hb * (32 * DH / 4), m2);
-      float b[16], fz[16], t[16];
-      load_vec_block(b, vecs + 128, mb, h);
-      load_block_p32(fz, fus + toff, mb, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r] + fz[r];
-      if (active) store_block_p32(out + toff, mb, t, lane);
-    }
-  }
-}
-
-// k_scattn_h2: k_scattn_b3 with split-fp16 operands (two planes, three partial products, 16 KiB tiles).
+// k_scattn_h2: the attention with split-fp16 operands (two planes, three partial products, 16 KiB tiles), c_ij
+// recomputed per (i, j) from the key points (cache-less fallback, `scattn_variant` 9) or streamed from the compat cache.
 // P is scaled by 2^10 (folded into the exponent; the row sum carries the same factor, so O/l is unchanged) to keep
 // its low plane out of the fp16 subnormal range.
-// Single-buffered K | V | pts8 (33 KB) so that TWO independent 4-wave workgroups fit on a CU: the two waves
-// that share a SIMD then belong to different workgroups, are not barrier-locked to each other, and one's
-// MFMA phase runs under the other's VALU phase.  Two barriers per tile: B1 after the QK^T phase (K_t is
-// free -> K_{t+1} streams in under the softmax and PV phases), B2 after the PV phase (V_t, pts_t are free
-// -> V_{t+1}, pts_{t+1} stream in under the next QK^T phase).
-// DBUF: K | V | pts8 double buffered (66 KB per workgroup, still two workgroups per CU) with ONE barrier per tile:
-// the split-fp16 QK^T phase (24 MFMAs) is too short to hide the V_t transfer of the single-buffered scheme.
-// ABL (timing-only ablations, results wrong): 1 = no compat term, 2 = no K/V tile DMA, 3 = no barrier,
-// 4 = no MFMA (VALU and LDS work only), 5 = no compat, no exponentials, no splits (MFMA + LDS + DMA only).
+// K | V | pts8 double buffered (66 KB per workgroup, two workgroups per CU: the two waves that share a SIMD belong to
+// different workgroups, are not barrier-locked to each other, and one's MFMA phase runs under the other's VALU phase),
+// ONE barrier per tile.
 // CACHED: c_ij does not depend on the layer, so k_compat_build evaluates it ONCE per batch and stores it in the element
 // order of this kernel (4 KiB per 32x32 tile: [q][lane][4 floats], registers r = 4q .. 4q+3 of each lane).  The 12
 // attention launches then stream it back with four coalesced, non-temporal 16-byte loads per lane and tile (prefetched
 // one tile ahead) instead of re-evaluating 2 square roots and ~20 more VALU instructions per element: 100 MB per pair
 // and layer at N = 5000 - HBM bandwidth this otherwise compute-bound kernel was not using.
-template <bool FASTSQRT, int WAVES, bool DBUF, int ABL = 0, bool CACHED = false>
-__global__ void __launch_bounds__(64 * WAVES, 2)
+template <bool CACHED>
+__global__ void __launch_bounds__(256, 2)
 k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
             const float* __restrict__ pts8, const float* __restrict__ fus, const float* __restrict__ wst,
             const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2, int wgs_per_pair,
             const float* __restrict__ c_dense) {
-  __shared__ __attribute__((aligned(16))) float lds[(DBUF ? 2 : 1) * (2 * kStageFloats + 256)];
+  constexpr int WAVES = 4;
   constexpr int kBuf = 2 * kStageFloats + 256;
+  __shared__ __attribute__((aligned(16))) float lds[2 * kBuf];
   float* const ldsK = lds;
   float* const ldsV = lds + kStageFloats;
   float* const ldsP = lds + 2 * kStageFloats;
@@ -822,10 +385,10 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
   const float* gk = k_img + pbase * (size_t)kStageFloats;
   const float* gv = v_img + pbase * (size_t)kStageFloats;
   const float* gp = pts8 + pbase * 32 * 8;
-  auto issueK = [&](int t) { if (ABL != 2) dma_issue(gk + (size_t)t * kStageFloats, ldsK + (DBUF ? (t & 1) * kBuf : 0), 16, wave, WAVES, lane); };
+  auto issueK = [&](int t) { dma_issue(gk + (size_t)t * kStageFloats, ldsK + (t & 1) * kBuf, 16, wave, WAVES, lane); };
   auto issueV = [&](int t) {
-    if (ABL != 2) dma_issue(gv + (size_t)t * kStageFloats, ldsV + (DBUF ? (t & 1) * kBuf : 0), 16, wave, WAVES, lane);
-    if (!CACHED && wave == (t & (WAVES - 1))) dma_piece_1k(gp + (size_t)t * 256, ldsP + (DBUF ? (t & 1) * kBuf : 0), lane);
+    dma_issue(gv + (size_t)t * kStageFloats, ldsV + (t & 1) * kBuf, 16, wave, WAVES, lane);
+    if (!CACHED && wave == (t & (WAVES - 1))) dma_piece_1k(gp + (size_t)t * 256, ldsP + (t & 1) * kBuf, lane);
   };
 
   f32x16 oacc[4];
@@ -839,33 +402,21 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
   issueK(0);
   issueV(0);
   if (CACHED) fetch_c(0, c_a);
-  if (!DBUF) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
   auto tile_step = [&](const int t, float (&c_cur)[16], float (&c_nxt)[16]) {
-    if (DBUF) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t (issued one whole tile ago) has landed
-      if (ABL != 3) __syncthreads();                     // ... for every wave; buffer (t+1)&1 is free again
-      if (t + 1 < tiles) { issueK(t + 1); issueV(t + 1); }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile t (issued one whole tile ago) has landed
+    __syncthreads();                                     // ... for every wave; buffer (t+1)&1 is free again
+    if (t + 1 < tiles) { issueK(t + 1); issueV(t + 1); }
     if (CACHED && t + 1 < tiles) fetch_c(t + 1, c_nxt);
-    const int boff = DBUF ? (t & 1) * (kBuf / 4) : 0;    // in 16-byte units
+    const int boff = (t & 1) * (kBuf / 4);               // in 16-byte units
     const f16x8* lk = lk0 + boff;
     const f16x8* lv = lv0 + boff;
     const float4* lp = lp0 + boff;
-    // ---- S^T = K_t Q'^T : 8 k-steps x 6 partial products ----
+    // ---- S^T = K_t Q'^T : 8 k-steps x 3 partial products ----
     f32x16 sacc = zero16();
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const f16x8 kh = lk[(0 * 8 + s) * 64], kl = lk[(1 * 8 + s) * 64];
-      if (ABL == 4) { sacc[s] += (float)kh[0] + (float)kl[1]; sacc[s + 8] += (float)qh[s][0] * (float)ql[s][1]; }
-      else mma3(sacc, kh, kl, qh[s], ql[s]);
-    }
-    if (!DBUF) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // V_t, pts_t (issued one phase ago) have landed
-      __syncthreads();                                   // B1: every wave is done reading K_t
-      if (t + 1 < tiles) issueK(t + 1);
+      mma3(sacc, kh, kl, qh[s], ql[s]);
     }
     // ---- compat, scores, online softmax ----
     float x[16];
@@ -874,7 +425,7 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int jl = 8 * (r >> 2) + (r & 3);
-        x[r] = (ABL == 1 || ABL == 5) ? sacc[r] : CACHED ? c_cur[r] * sacc[r] : compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
+        x[r] = CACHED ? c_cur[r] * sacc[r] : compat_times(lp, jl, si, ti, inv_sig2, sacc[r]);
         mx = fmaxf(mx, x[r]);
       }
     } else {
@@ -882,7 +433,7 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int jl = 8 * (r >> 2) + (r & 3);
-        const float v = CACHED ? c_cur[r] * sacc[r] : compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, sacc[r]);
+        const float v = CACHED ? c_cur[r] * sacc[r] : compat_times(lp, jl, si, ti, inv_sig2, sacc[r]);
         x[r] = (jbase + jl < N) ? v : -INFINITY;
         mx = fmaxf(mx, x[r]);
       }
@@ -895,7 +446,7 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
     float ls = 0.f;
     const float m_off = m_new - 10.0f;   // P' = 2^10 P
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { x[r] = (ABL == 5) ? (x[r] - m_off) : __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
+    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
     l_half = fmaf(l_half, alpha, ls);
     if (__any(moved)) {
 #pragma unroll
@@ -912,14 +463,8 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
       for (int db = 0; db < 4; ++db) {
         const int slot = 2 * db + s2;
         const f16x8 vh = lv[(0 * 8 + slot) * 64], vl = lv[(1 * 8 + slot) * 64];
-        if (ABL == 4) oacc[db][slot] += (float)vh[0] * (float)ph[1] + (float)vl[2] * (float)pl[3];
-        else mma3(oacc[db], vh, vl, ph, pl);
+        mma3(oacc[db], vh, vl, ph, pl);
       }
-    }
-    if (!DBUF) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K_{t+1} (issued two phases ago) has landed
-      __syncthreads();                                   // B2: every wave is done reading V_t, pts_t
-      if (t + 1 < tiles) issueV(t + 1);
     }
   };
   // two register sets for the cached c tile: tile t multiplies out of one while tile t+1 streams into the other
@@ -983,257 +528,6 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
 }
 
 // =========================================================================================
-// k_scattn_b3p: k_scattn_b3 with the tile loop software-pipelined inside each wave.
-//   K tiles run one tile ahead of V / pts8 in the LDS double buffers.  Phase 1 issues the 48 MFMAs of
-//   S_{t+1} = K_{t+1} Q'^T one per sched_barrier(0) unit, each unit carrying its share of tile t's
-//   compat / score / max work and then the first half of the exponentials and their bf16 split; phase 2
-//   issues the 48 MFMAs of O^T += V_t^T P^T with the second half of the exponentials underneath.
-//   (The bf16 MFMA co-executes with VALU work, so a wave overlaps its own matrix and vector streams; the
-//   barrier-locked waves of k_scattn_b3 do all their matrix work, then all their vector work, together.)
-// =========================================================================================
-GMF_DEVINL void split2(float x0, float x1, bf16x8& hi, bf16x8& mi, bf16x8& lo, int j) {
-  const f32x2 x = {x0, x1};
-  const bf16x2 hh = __builtin_convertvector(x, bf16x2);
-  const f32x2 r1 = x - __builtin_convertvector(hh, f32x2);
-  const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
-  const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
-  hi[j] = hh[0]; hi[j + 1] = hh[1];
-  mi[j] = mm[0]; mi[j + 1] = mm[1];
-  lo[j] = ll[0]; lo[j + 1] = ll[1];
-}
-
-// the u-th of the six partial products of one k-step (small terms first)
-GMF_DEVINL f32x16 mma6_part(int u, f32x16 acc, bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl) {
-  switch (u) {
-    case 0: return mfma_b16(al, bh, acc);
-    case 1: return mfma_b16(ah, bl, acc);
-    case 2: return mfma_b16(am, bm, acc);
-    case 3: return mfma_b16(am, bh, acc);
-    case 4: return mfma_b16(ah, bm, acc);
-    default: return mfma_b16(ah, bh, acc);
-  }
-}
-
-template <bool FASTSQRT>
-__global__ void __launch_bounds__(512, 2)
-k_scattn_b3p(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
-             const float* __restrict__ pts8, const float* __restrict__ fus, const float* __restrict__ wst,
-             const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, float inv_sig2) {
-  // LDS: K slots [2][6144] | V slots [2][6144] | pts slots [2][256]
-  __shared__ __attribute__((aligned(16))) float lds[4 * kB3TileFloats + 512];
-  float* const ldsK = lds;
-  float* const ldsV = lds + 2 * kB3TileFloats;
-  float* const ldsP = lds + 4 * kB3TileFloats;
-  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = blockIdx.y;
-  const int tile_raw = blockIdx.x * kB3Waves + wave;
-  const bool active = tile_raw < tiles;
-  const int tile = active ? tile_raw : tiles - 1;
-  const size_t pbase = (size_t)pair * tiles;
-  const size_t toff = (pbase + tile) * (32 * C);
-
-  bf16x8 qh[8], qm[8], ql[8];
-  {
-    const bf16x8* qp = reinterpret_cast<const bf16x8*>(q_img + (pbase + tile) * (size_t)kB3TileFloats) + lane;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) { qh[s] = qp[(0 * 8 + s) * 64]; qm[s] = qp[(1 * 8 + s) * 64]; ql[s] = qp[(2 * 8 + s) * 64]; }
-  }
-  float si[3], ti[3];
-  {
-    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)tile * 32 + i) * 8);
-    const float4 a = pp[0], b = pp[1];
-    si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
-  }
-  const float* gk = k_img + pbase * (size_t)kB3TileFloats;
-  const float* gv = v_img + pbase * (size_t)kB3TileFloats;
-  const float* gp = pts8 + pbase * 32 * 8;
-  auto issueK = [&](int t) { dma_issue(gk + (size_t)t * kB3TileFloats, ldsK + (t & 1) * kB3TileFloats, 24, wave, kB3Waves, lane); };
-  auto issueV = [&](int t) {
-    dma_issue(gv + (size_t)t * kB3TileFloats, ldsV + (t & 1) * kB3TileFloats, 24, wave, kB3Waves, lane);
-    if (wave == (t & 7)) dma_piece_1k(gp + (size_t)t * 256, ldsP + (t & 1) * 256, lane);
-  };
-
-  f32x16 oacc[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
-  float m_run = -INFINITY, l_half = 0.f;
-
-  issueK(0);
-  if (tiles > 1) issueK(1);
-  issueV(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  f32x16 s_cur = zero16();
-  {
-    const bf16x8* lk = reinterpret_cast<const bf16x8*>(ldsK) + lane;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) mma6(s_cur, lk[(0 * 8 + s) * 64], lk[(1 * 8 + s) * 64], lk[(2 * 8 + s) * 64], qh[s], qm[s], ql[s]);
-  }
-
-  for (int t = 0; t < tiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();            // K_{t+1}, V_t, pts_t landed; every wave is done with K_t, V_{t-1}, pts_{t-1}
-    if (t + 2 < tiles) issueK(t + 2);
-    if (t + 1 < tiles) issueV(t + 1);
-    const float4* lp = reinterpret_cast<const float4*>(ldsP + (t & 1) * 256) + 8 * h;
-    const bf16x8* lv = reinterpret_cast<const bf16x8*>(ldsV + (t & 1) * kB3TileFloats) + lane;
-    float x[16];
-    float mx = -INFINITY, m_new = 0.f, alpha = 1.f, ls = 0.f;
-    bool moved = false;
-    bf16x8 ph0, pm0, pl0;
-    f32x16 s_next = zero16();
-    if (t + 1 < tiles) {
-      const bf16x8* lk = reinterpret_cast<const bf16x8*>(ldsK + ((t + 1) & 1) * kB3TileFloats) + lane;
-      bf16x8 kh = lk[0], km = lk[8 * 64], kl = lk[16 * 64];
-      bf16x8 kh_n = kh, km_n = km, kl_n = kl;
-      float4 pa = lp[0], pb = lp[1];
-      float d2s = 0.f, d2t = 0.f, cc = 0.f;
-#pragma unroll
-      for (int u = 0; u < 48; ++u) {
-        const int s = u / 6, pr = u % 6;
-        if (pr == 0 && s < 7) { kh_n = lk[(0 * 8 + s + 1) * 64]; km_n = lk[(1 * 8 + s + 1) * 64]; kl_n = lk[(2 * 8 + s + 1) * 64]; }
-        s_next = mma6_part(pr, s_next, kh, km, kl, qh[s], qm[s], ql[s]);
-        if (pr == 5) { kh = kh_n; km = km_n; kl = kl_n; }
-        if (u < 32) {                       // two quarter-elements per unit: element g = u/2
-          const int g = u >> 1;
-          if ((u & 1) == 0) {
-            const float ax = si[0] - pa.x, ay = si[1] - pa.y, az = si[2] - pa.z;
-            d2s = fmaf(az, az, fmaf(ay, ay, ax * ax));
-            const float bx = ti[0] - pb.x, by = ti[1] - pb.y, bz = ti[2] - pb.z;
-            d2t = fmaf(bz, bz, fmaf(by, by, bx * bx));
-            if (g < 15) { const int jn = 8 * ((g + 1) >> 2) + ((g + 1) & 3); pa = lp[2 * jn]; pb = lp[2 * jn + 1]; }
-          } else {
-            const float d = len_diff<FASTSQRT>(d2s, d2t);
-            cc = fmaxf(1.0f - d * d * inv_sig2, 0.f);
-            x[g] = cc * s_cur[g];
-            mx = fmaxf(mx, x[g]);
-          }
-        } else if (u == 32) {
-          mx = xhalf_max(mx);
-          m_new = fmaxf(m_run, mx);
-          moved = m_new > m_run;
-          alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-          m_run = m_new;
-        } else if (u <= 40) {
-          const int r = u - 33;
-          x[r] = __builtin_amdgcn_exp2f(x[r] - m_new);
-          ls += x[r];
-        } else if (u <= 44) {
-          const int j = 2 * (u - 41);
-          split2(x[j], x[j + 1], ph0, pm0, pl0, j);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      const int jbase = t * 32 + 4 * h;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int jl = 8 * (g >> 2) + (g & 3);
-        const float v = compat_times<FASTSQRT>(lp, jl, si, ti, inv_sig2, s_cur[g]);
-        x[g] = (jbase + jl < N) ? v : -INFINITY;
-        mx = fmaxf(mx, x[g]);
-      }
-      mx = xhalf_max(mx);
-      m_new = fmaxf(m_run, mx);
-      moved = m_new > m_run;
-      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_new); ls += x[r]; }
-      split8(&x[0], ph0, pm0, pl0);
-    }
-    if (__any(moved)) {
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-    }
-    // ---- phase 2: O^T += V_t^T P^T ----
-    {
-      bf16x8 ph1, pm1, pl1;
-      bf16x8 vh = lv[0], vm = lv[8 * 64], vl = lv[16 * 64];
-      bf16x8 vh_n = vh, vm_n = vm, vl_n = vl;
-#pragma unroll
-      for (int u = 0; u < 48; ++u) {
-        const int s2 = u / 24, db = (u % 24) / 6, pr = u % 6;
-        if (pr == 0 && u < 42) {
-          const int un = u + 6, s2n = un / 24, dbn = (un % 24) / 6, slot = 2 * dbn + s2n;
-          vh_n = lv[(0 * 8 + slot) * 64]; vm_n = lv[(1 * 8 + slot) * 64]; vl_n = lv[(2 * 8 + slot) * 64];
-        }
-        oacc[db] = mma6_part(pr, oacc[db], vh, vm, vl, s2 ? ph1 : ph0, s2 ? pm1 : pm0, s2 ? pl1 : pl0);
-        if (pr == 5) { vh = vh_n; vm = vm_n; vl = vl_n; }
-        if (u < 8) {
-          const int r = 8 + u;
-          x[r] = __builtin_amdgcn_exp2f(x[r] - m_new);
-          ls += x[r];
-        } else if (u < 12) {
-          const int j = 2 * (u - 8);
-          split2(x[8 + j], x[8 + j + 1], ph1, pm1, pl1, j);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    l_half = fmaf(l_half, alpha, ls);
-    s_cur = s_next;
-  }
-
-  // ---- epilogue: normalise, fc_message (fp32 MFMA), add the Fusion-2 branch ----
-  float o[CF];
-  {
-    const float inv = 1.0f / xhalf_sum(l_half);
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
-  }
-  __syncthreads();
-  StageStream ss;
-  ss.init(lds, lds + kStageFloats, wave, kB3Waves, lane, wst, 5);
-  ss.prime();
-  float m1[DHF], m2[DHF];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const float4* lw = ss.acquire();
-    f32x16 acc = zero16();
-    mma_wx<CF>(acc, lw, o);
-    float b[16];
-    load_vec_block(b, vecs, mb, h);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
-  }
-  {
-    const float4* lw = ss.acquire();
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      f32x16 acc = zero16();
-      mma_wx<DHF>(acc, lw + mb * (32 * DH / 4), m1);
-      float b[16];
-      load_vec_block(b, vecs + 64, mb, h);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
-    }
-  }
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    const float4* lw = ss.acquire();
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int mb = 2 * st + hb;
-      f32x16 acc = zero16();
-      mma_wx<DHF>(acc, lw + hb * (32 * DH / 4), m2);
-      float b[16], fz[16], t[16];
-      load_vec_block(b, vecs + 128, mb, h);
-      load_block_p32(fz, fus + toff, mb, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = acc[r] + b[r] + fz[r];
-      if (active) store_block_p32(out + toff, mb, t, lane);
-    }
-  }
-}
-
-// =========================================================================================
 // k_compat_build: the spatial-consistency matrix c_ij = max(0, 1 - (||s_i-s_j|| - ||t_i-t_j||)^2 / sigma_d^2)
 // (PointDSC.py:216-221), evaluated once per batch with the reference's roundings and stored in the element order of the
 // attention kernels: for query tile I and key tile J, lane (h, i) register r is the pair
@@ -1242,42 +536,35 @@ k_scattn_b3p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
 // =========================================================================================
 constexpr int kJPerWave = 8;
 
-// Q16: element order of k_scattn_h2q - lane (g, c), float4 q4 = 2 ib + jb holds (query 32 I + 16 ib + c, keys 32 J + 16 jb + 4 g + r).
-// Default order: c is exactly symmetric (the squared differences do not see the sign of s_i - s_j), so only tiles J >= I are
+// c is exactly symmetric (the squared differences do not see the sign of s_i - s_j), so only tiles J >= I are
 // evaluated; a tile with J > I is also written as tile (J, I) after a 32 x 32 transpose through a per-wave LDS buffer
 // (16 ds_write_b32 + 16 ds_read_b32 instead of 16 x ~26 vector instructions with two correctly rounded square roots).
-template <bool Q16>
 __global__ void __launch_bounds__(256)
 k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int N, int tiles, float inv_sig2) {
-  __shared__ float tr[Q16 ? 1 : 4 * 32 * 33];
-  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31, g = lane >> 4, c16 = lane & 15;
+  __shared__ float tr[4 * 32 * 33];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.z, I = blockIdx.x;
   const size_t pbase = (size_t)pair * tiles;
-  float si[2][3], ti[2][3];
-#pragma unroll
-  for (int ib = 0; ib < (Q16 ? 2 : 1); ++ib) {
-    const int row = Q16 ? 16 * ib + c16 : i;
-    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)I * 32 + row) * 8);
+  float si[3], ti[3];
+  {
+    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)I * 32 + i) * 8);
     const float4 a = pp[0], b = pp[1];
-    si[ib][0] = a.x; si[ib][1] = a.y; si[ib][2] = a.z; ti[ib][0] = b.x; ti[ib][1] = b.y; ti[ib][2] = b.z;
+    si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
   }
   float4* const cbase = reinterpret_cast<float4*>(c_dense) + pbase * (size_t)tiles * 256 + lane;
   float4* const crow = cbase + (size_t)I * tiles * 256;
-  float* const mt = tr + (Q16 ? 0 : wave * 32 * 33);
+  float* const mt = tr + wave * 32 * 33;
   const int j0 = (blockIdx.y * 4 + wave) * kJPerWave;
-  for (int J = Q16 ? j0 : max(j0, I); J < min(tiles, j0 + kJPerWave); ++J) {
-    const float4* lp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)J * 32) * 8) + (Q16 ? 0 : 8 * h);
+  for (int J = max(j0, I); J < min(tiles, j0 + kJPerWave); ++J) {
+    const float4* lp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)J * 32) * 8) + 8 * h;
     float c[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (Q16) c[r] = compat_times<false>(lp, 16 * ((r >> 2) & 1) + 4 * g + (r & 3), si[r >> 3], ti[r >> 3], inv_sig2, 1.0f);
-      else c[r] = compat_times<false>(lp, 8 * (r >> 2) + (r & 3), si[0], ti[0], inv_sig2, 1.0f);
-    }
+    for (int r = 0; r < 16; ++r) c[r] = compat_times(lp, 8 * (r >> 2) + (r & 3), si, ti, inv_sig2, 1.0f);
     float4* ct = crow + (size_t)J * 256;
 #pragma unroll
     for (int q = 0; q < 4; ++q) ct[q * 64] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
-    if (!Q16 && J > I) {
+    if (J > I) {
       // tile (J, I): lane (h, i), register r = element (row i of J, column jl of I) = c(I: jl, J: i) = M[jl][i]
 #pragma unroll
       for (int r = 0; r < 16; ++r) mt[i * 33 + 8 * (r >> 2) + 4 * h + (r & 3)] = c[r];
@@ -1318,9 +605,8 @@ GMF_DEVINL float xhalf_max_swap(float v) {
   return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-// PLACE: where a tile's 8 LDS-DMA pieces are issued - 0 = at the top of the tile, 1 = one per unit of phase 1,
-// 2 = one per unit in the bare MFMA gaps of phase 2.
-// EPI_H2: fc_message epilogue on the f16 MFMA with split-fp16 weights (wst = tail_wst_h2) instead of the fp32 MFMA.
+// A tile's 8 LDS-DMA pieces are issued one per unit in the bare MFMA gaps of phase 2 (at the tile top / in phase 1
+// measured 1.19 / 1.17 ms against 1.16 ms per launch in round 1).
 // fc_message on the f16 MFMA (split-fp16 weights, tail_wst_h2) + bias + Fusion-2 branch for the 32 rows of one wave, given
 // the normalised attention output o (fragment order).  `ss` is primed on the 5 weight stages; every wave of the workgroup
 // calls this (padding waves with active = false keep their seat at the stage barriers).
@@ -1379,7 +665,7 @@ GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stag
 // KSPLIT (small grids: B x ceil(tiles/4) workgroups fill a fraction of the 512 slots, e.g. B = 1 - the reference's
 // evaluation mode): the keys of a query block are divided over `ksplits` workgroups, each writes its un-normalised partial
 // O (P32 tile image), row maximum and row sum; k_scattn_merge combines them and runs the epilogue.
-template <int PLACE, bool EPI_H2, bool KSPLIT = false>
+template <bool KSPLIT>
 __global__ void __launch_bounds__(256, 2)
 k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
              const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
@@ -1467,10 +753,6 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
       mx = __builtin_fmaxf(mx, __builtin_fmaxf(x[r], x[r + 1]));
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (PLACE == 0) {
-      if (t + 2 < t_end) issueK(t + 2);
-      if (t + 1 < t_end) issueV(t + 1);
-    }
     if (t + 1 < t_end) fetch_c(t + 1);
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -1523,7 +805,6 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
         if (pr == 0 && s < 7) { kh_n = lk[(0 * 8 + s + 1) * 64]; kl_n = lk[(1 * 8 + s + 1) * 64]; }
         s_next = mma3_part(pr, s_next, kh, kl, qh[s], ql[s]);
         if (pr == 2) { kh = kh_n; kl = kl_n; }
-        if (PLACE == 1 && u >= 2 && u < 10) issue_piece(t, u - 2);
         if (u < 2) {
           // (the row maximum and the accumulator rescale are settled before the phase: see below)
         } else if (u <= 11) {
@@ -1561,7 +842,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
           const int j = 4 + 2 * u;           // split pairs 6, 7 (needed from u = 12 on)
           split2h(x[8 + j], x[8 + j + 1], ph1, pl1, j);
         }
-        if (PLACE == 2 && u >= 3 && u < 11) issue_piece(t, u - 3);
+        if (u >= 3 && u < 11) issue_piece(t, u - 3);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -1609,11 +890,8 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (t + 1 < t_end) {
-        if (PLACE == 0) { if (t + 2 < t_end) issueK(t + 2); issueV(t + 1); }
-        else {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) issue_piece(t, q);
-        }
+        for (int q = 0; q < 8; ++q) issue_piece(t, q);
       }
     }
   } else {
@@ -1642,7 +920,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
     return;
   }
 
-  // ---- epilogue: normalise, fc_message (fp32 MFMA), add the Fusion-2 branch ----
+  // ---- epilogue: normalise, fc_message (split-fp16 MFMA), add the Fusion-2 branch ----
   float o[CF];
   {
     const float inv = 1.0f / xhalf_sum(l_half);
@@ -1655,49 +933,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   StageStream ss;
   ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5);
   ss.prime();
-  if (EPI_H2) {
-    scattn_epilogue_h2(o, active, ss, vecs, fus + toff, out + toff, lane, h);
-    return;
-  }
-  float m1[DHF], m2[DHF];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const float4* lw = ss.acquire();
-    f32x16 acc = zero16();
-    mma_wx<CF>(acc, lw, o);
-    float b[16];
-    load_vec_block(b, vecs, mb, h);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
-  }
-  {
-    const float4* lw = ss.acquire();
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      f32x16 acc = zero16();
-      mma_wx<DHF>(acc, lw + mb * (32 * DH / 4), m1);
-      float b[16];
-      load_vec_block(b, vecs + 64, mb, h);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
-    }
-  }
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    const float4* lw = ss.acquire();
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-      const int mb = 2 * st + hb;
-      f32x16 acc = zero16();
-      mma_wx<DHF>(acc, lw + hb * (32 * DH / 4), m2);
-      float b[16], fz[16], tt[16];
-      load_vec_block(b, vecs + 128, mb, h);
-      load_block_p32(fz, fus + toff, mb, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tt[r] = acc[r] + b[r] + fz[r];
-      if (active) store_block_p32(out + toff, mb, tt, lane);
-    }
-  }
+  scattn_epilogue_h2(o, active, ss, vecs, fus + toff, out + toff, lane, h);
 }
 
 // All five fc_message weight stages in LDS at once (80 KiB): for grids that do not fill the chip anyway (the merge step
@@ -1779,394 +1015,6 @@ k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_
 #pragma unroll
   for (int e = 0; e < CF; ++e) o[e] *= inv;
   scattn_epilogue_h2(o, active, ss, vecs, fus + toff, out + toff, lane, h);
-}
-
-// =========================================================================================
-// k_scattn_h2q: k_scattn_h2p on v_mfma_f32_16x16x32_f16 (scattn_variant 19).
-//   At equal cycles per FLOP the chip holds a ~13 % higher clock on the 16x16x32 shape than on 32x32x16
-//   (tools/ubench/mfma_shape.hip: 1690 vs 1494 TFLOP/s with operands re-read from LDS), and this kernel is
-//   clock-limited.  Lane l = (g = l >> 4, c = l & 15).  A wave still owns 32 queries (blocks ib = 0, 1 of 16) and a
-//   tile is still 32 keys (blocks jb):
-//     S^T block (jb, ib) = K_jb Q_ib^T: A = K rows 16 jb + c, B = Q rows 16 ib + c, both as d = 32 s' + 8 g .. + 7 -
-//       16-byte units of the UNCHANGED fp16x2 K / Q' images, gathered with per-lane addresses (conflict-free);
-//       D: lane (g, c) holds keys 16 jb + 4 g + r of query 16 ib + c.
-//     A lane therefore holds, for each of its two queries, 8 probabilities: exactly one B operand of the K = 32
-//       contraction O^T += V^T P^T, in the key order slot(g, e) -> key 16 (e >> 2) + 4 g + (e & 3).  The V image is
-//       written in that order by k_front_h2<.., VQ> (store_block_vq16), the cached c in the matching element order by
-//       k_compat_build<true>, and the fc_message weights by packing.p16_h2, so accumulators chain into operands with no
-//       data movement here either.
-//     O^T block (db16, ib): lane (g, c) holds features 16 db16 + 4 g + r of query 16 ib + c = one float4 of the P32 image.
-//   Row statistics are per (lane, ib); the row maximum crosses the four lane groups with v_permlane16_swap and
-//   v_permlane32_swap.  Software pipelining, LDS rings, the XCD-aware mapping and the DMA placement are those of k_scattn_h2p.
-// =========================================================================================
-GMF_DEVINL f32x4 mfma_q16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-GMF_DEVINL void mma3q(f32x4& acc, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
-  acc = mfma_q16(al, bh, acc);
-  acc = mfma_q16(ah, bl, acc);
-  acc = mfma_q16(ah, bh, acc);
-}
-GMF_DEVINL float vmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// max / sum over the four lane groups g (lanes 16 apart)
-GMF_DEVINL float xg_max(float v) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  const float m = vmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-  return vmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
-}
-GMF_DEVINL float xg_sum(float v) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  const float m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
-}
-
-// OCC: workgroups per CU (1 = one wave per SIMD with the whole 512-register file; 1280 workgroups = 5.0 rounds of 256 CUs).
-// PLACE: LDS-DMA pieces issued 0 = at the tile top (a full tile of lead: needed at one wave per SIMD), 2 = in phase 2.
-// LATEC: the c tile of tile t+1 is loaded in phase 2 of tile t (its registers are dead during phase 1) after an L2
-// touch-prefetch issued one tile earlier (one dword per 64-byte line: the whole 4 KiB tile in one instruction).
-template <int OCC, int PLACE, bool LATEC>
-__global__ void __launch_bounds__(256, OCC)
-k_scattn_h2q(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
-             const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
-             float* __restrict__ out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_dense) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
-  float* const ldsK = lds;
-  float* const ldsV = lds + 2 * kStageFloats;
-  constexpr int WAVES = 4;
-  const int lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int pair, qblock;
-  {
-    const int total = gridDim.x, L = blockIdx.x;
-    const int chunk = total >> 3, rem = total & 7, xcd = L & 7, kth = L >> 3;
-    const int start = (xcd < rem) ? xcd * (chunk + 1) : rem * (chunk + 1) + (xcd - rem) * chunk;
-    const int logical = start + kth;
-    pair = logical / wgs_per_pair;
-    qblock = logical - pair * wgs_per_pair;
-  }
-  const int tile_raw = qblock * WAVES + wave;
-  const bool active = tile_raw < tiles;
-  const int tile = active ? tile_raw : tiles - 1;
-  const size_t pbase = (size_t)pair * tiles;
-  const size_t toff = (pbase + tile) * (32 * C);
-  // unit of row (16 b + c16), d = 32 s' + 8 g .. +7 inside an fp16x2 tile image: (plane*8 + 2 s' + (g >> 1))*64 + 32 (g & 1) + 16 b + c16
-  const int goff = (g >> 1) * 64 + 32 * (g & 1) + c16;
-
-  f16x8 qh[2][4], ql[2][4];
-  {
-    const f16x8* qp = reinterpret_cast<const f16x8*>(q_img + (pbase + tile) * (size_t)kStageFloats) + goff;
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-      for (int sp = 0; sp < 4; ++sp) {
-        qh[ib][sp] = qp[(0 * 8 + 2 * sp) * 64 + 16 * ib];
-        ql[ib][sp] = qp[(1 * 8 + 2 * sp) * 64 + 16 * ib];
-      }
-  }
-  const f32x4* const crow = reinterpret_cast<const f32x4*>(c_dense) + ((pbase + tile) * (size_t)tiles) * 256 + lane;
-  float c[16];                    // c[8 ib + 4 jb + r]
-  auto fetch_c = [&](int t) {
-    const f32x4* ct = crow + (size_t)t * 256;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = __builtin_nontemporal_load(ct + q * 64);
-      c[4 * q + 0] = v[0]; c[4 * q + 1] = v[1]; c[4 * q + 2] = v[2]; c[4 * q + 3] = v[3];
-    }
-  };
-  auto touch_c = [&](int t) {       // brings tile t of this wave's c rows into L2: lane l reads one dword of 64-byte line l
-    unsigned dummy;
-    const float* a = reinterpret_cast<const float*>(crow - lane + (size_t)t * 256) + lane * 16;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(a) : "memory");
-  };
-  const float* gk = k_img + pbase * (size_t)kStageFloats;
-  const float* gv = v_img + pbase * (size_t)kStageFloats;
-  auto issue16k = [&](const float* gsrc, float* l) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dma_piece_1k(gsrc + (wave + WAVES * q) * 256, l + (wave + WAVES * q) * 256, lane);
-  };
-  auto issueK = [&](int t) { issue16k(gk + (size_t)t * kStageFloats, ldsK + (t & 1) * kStageFloats); };
-  auto issueV = [&](int t) { issue16k(gv + (size_t)t * kStageFloats, ldsV + (t & 1) * kStageFloats); };
-  auto issue_piece = [&](const int t, const int q) {
-    if (q < 4) {
-      if (t + 2 < tiles) dma_piece_1k(gk + (size_t)(t + 2) * kStageFloats + (wave + WAVES * q) * 256,
-                                      ldsK + (t & 1) * kStageFloats + (wave + WAVES * q) * 256, lane);
-    } else {
-      dma_piece_1k(gv + (size_t)(t + 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256,
-                   ldsV + ((t + 1) & 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256, lane);
-    }
-  };
-
-  f32x4 oacc[8][2];
-#pragma unroll
-  for (int db = 0; db < 8; ++db)
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) oacc[db][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
-
-  struct STile { f32x4 s[2][2]; };   // [jb][ib]
-  auto zero_s = [&](STile& st) {
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib) st.s[jb][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-
-  issueK(0);
-  if (tiles > 1) issueK(1);
-  issueV(0);
-  fetch_c(0);
-  if (LATEC && tiles > 1) touch_c(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  STile s_a, s_b;
-  zero_s(s_a);
-  {
-    const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK) + goff;
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int sp = 0; sp < 4; ++sp) {
-        const f16x8 kh = lk[(0 * 8 + 2 * sp) * 64 + 16 * jb], kl = lk[(1 * 8 + 2 * sp) * 64 + 16 * jb];
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) mma3q(s_a.s[jb][ib], kh, kl, qh[ib][sp], ql[ib][sp]);
-      }
-  }
-
-  // top of tile t (see k_scattn_h2p): scores first, then the c prefetch; x[8 ib + 4 jb + r]
-  auto tile_top = [&](const int t, const STile& s_cur, float (&x)[16], float (&mx)[2]) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[8 * ib + 4 * jb + r] = c[8 * ib + 4 * jb + r] * s_cur.s[jb][ib][r];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (PLACE == 0) {
-      if (t + 2 < tiles) issueK(t + 2);
-      if (t + 1 < tiles) issueV(t + 1);
-    }
-    if (LATEC) { if (t + 2 < tiles) touch_c(t + 2); }
-    else if (t + 1 < tiles) fetch_c(t + 1);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto row_max = [&](const float (&x)[16], float (&mx)[2]) {
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-      float m = x[8 * ib];
-#pragma unroll
-      for (int e = 1; e < 8; ++e) m = __builtin_fmaxf(m, x[8 * ib + e]);
-      mx[ib] = xg_max(m);
-    }
-  };
-  auto new_max = [&](const float (&mx)[2], float (&m_off)[2], float (&alpha)[2]) {
-    bool moved = false;
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-      const float m_new = __builtin_fmaxf(m_run[ib], mx[ib]);
-      moved = moved || (m_new > m_run[ib]);
-      alpha[ib] = __builtin_amdgcn_exp2f(m_run[ib] - m_new);
-      m_run[ib] = m_new;
-      m_off[ib] = m_new - 10.0f;            // P' = 2^10 P
-    }
-    if (__any(moved)) {
-#pragma unroll
-      for (int db = 0; db < 8; ++db)
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) oacc[db][ib][r] *= alpha[ib];
-    }
-  };
-
-  auto tile_step = [&](const int t, const STile& s_cur, STile& s_next) {
-    float x[16], mx[2], m_off[2], alpha[2], ls[2] = {0.f, 0.f};
-    tile_top(t, s_cur, x, mx);
-    row_max(x, mx);
-    new_max(mx, m_off, alpha);
-    const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV + (t & 1) * kStageFloats) + lane;
-    const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK + ((t + 1) & 1) * kStageFloats) + goff;
-    f16x8 ph[2], pl[2];
-    zero_s(s_next);
-    // ---- phase 1: S_{t+1}, 16 groups of 3 MFMAs (jb, s', ib); exponentials of x[u] and the fp16 splits in the gaps ----
-    {
-      f16x8 kh = lk[0], kl = lk[8 * 64];
-      f16x8 kh_n = kh, kl_n = kl;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int jb = u >> 3, sp = (u >> 1) & 3, ib = u & 1;
-        if (ib == 0 && u < 14) {
-          const int un = u + 2, jbn = un >> 3, spn = (un >> 1) & 3;
-          kh_n = lk[(0 * 8 + 2 * spn) * 64 + 16 * jbn]; kl_n = lk[(1 * 8 + 2 * spn) * 64 + 16 * jbn];
-        }
-        mma3q(s_next.s[jb][ib], kh, kl, qh[ib][sp], ql[ib][sp]);
-        if (ib == 1) { kh = kh_n; kl = kl_n; }
-        {
-          const int ibx = u >> 3;            // x[0..7] belong to query block 0, x[8..15] to block 1
-          x[u] = __builtin_amdgcn_exp2f(x[u] - m_off[ibx]);
-          ls[ibx] += x[u];
-        }
-        if (u >= 2 && (u & 1) == 0) {         // pair (u-2, u-1) is complete
-          const int p = u - 2, ibx = p >> 3, j = p & 7;
-          split2h(x[p], x[p + 1], ph[ibx], pl[ibx], j);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // ---- phase 2: O^T += V_t^T P^T, 16 groups of 3 MFMAs (db16, ib); the last split and the refills in the gaps ----
-    {
-      f16x8 vh = lv[0], vl = lv[8 * 64];
-      f16x8 vh_n = vh, vl_n = vl;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int db = u >> 1, ib = u & 1;
-        if (u == 0) split2h(x[14], x[15], ph[1], pl[1], 6);
-        if (LATEC && u == 1) fetch_c(t + 1);
-        if (ib == 0 && db < 7) { vh_n = lv[(0 * 8 + db + 1) * 64]; vl_n = lv[(1 * 8 + db + 1) * 64]; }
-        mma3q(oacc[db][ib], vh, vl, ph[ib], pl[ib]);
-        if (ib == 1) { vh = vh_n; vl = vl_n; }
-        if (PLACE == 2 && u >= 2 && u < 10) issue_piece(t, u - 2);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) l_part[ib] = fmaf(l_part[ib], alpha[ib], ls[ib]);
-  };
-  auto tile_last = [&](const int t, const STile& s_cur) {
-    float x[16], mx[2], m_off[2], alpha[2], ls[2] = {0.f, 0.f};
-    tile_top(t, s_cur, x, mx);
-    const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV + (t & 1) * kStageFloats) + lane;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int jb = (e >> 2) & 1, r = e & 3;
-      x[e] = (t * 32 + 16 * jb + 4 * g + r < N) ? x[e] : -INFINITY;
-    }
-    row_max(x, mx);
-    new_max(mx, m_off, alpha);
-    f16x8 ph[2], pl[2];
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { x[8 * ib + e] = __builtin_amdgcn_exp2f(x[8 * ib + e] - m_off[ib]); ls[ib] += x[8 * ib + e]; }
-      split8h(&x[8 * ib], ph[ib], pl[ib]);
-    }
-#pragma unroll
-    for (int db = 0; db < 8; ++db) {
-      const f16x8 vh = lv[(0 * 8 + db) * 64], vl = lv[(1 * 8 + db) * 64];
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib) mma3q(oacc[db][ib], vh, vl, ph[ib], pl[ib]);
-    }
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) l_part[ib] = fmaf(l_part[ib], alpha[ib], ls[ib]);
-  };
-  if (LATEC) {
-    for (int t = 0; t + 1 < tiles; ++t) {
-      tile_step(t, s_a, s_b);
-      s_a = s_b;                 // S_{t+1} finished a phase ago: 16 cheap moves, one loop body for the register allocator
-    }
-    tile_last(tiles - 1, s_a);
-  } else {
-    int t = 0;
-    for (; t + 2 < tiles; t += 2) {
-      tile_step(t, s_a, s_b);
-      tile_step(t + 1, s_b, s_a);
-    }
-    if (t + 1 < tiles) { tile_step(t, s_a, s_b); tile_last(t + 1, s_b); }
-    else tile_last(t, s_a);
-  }
-
-  // ---- epilogue: normalise, fc_message on 16x16x32 MFMAs (weights: packing.p16_h2), add the Fusion-2 branch ----
-  //   B operand of contraction step s for query block ib = the lane's accumulator blocks 2s and 2s+1 (8 values)
-  f16x8 oh[2][4], ol[2][4];
-#pragma unroll
-  for (int ib = 0; ib < 2; ++ib) {
-    const float inv = 1.0f / xg_sum(l_part[ib]);
-#pragma unroll
-    for (int sp = 0; sp < 4; ++sp) {
-      float v8[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { v8[r] = oacc[2 * sp][ib][r] * inv; v8[4 + r] = oacc[2 * sp + 1][ib][r] * inv; }
-      split8h(v8, oh[ib][sp], ol[ib][sp]);
-    }
-  }
-  __syncthreads();
-  StageStream ss;
-  ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5);
-  ss.prime();
-  const f32x4* bias4 = reinterpret_cast<const f32x4*>(vecs) + g;        // + 4 * block for features 16 block + 4 g ..
-  // layer a: 128 -> 64 (4 output blocks of 16; stages: blocks 0,1 | 2,3), ReLU
-  f16x8 m1h[2][2], m1l[2][2];
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    const f16x8* lw = as_h2(ss.acquire());
-    float keep[2][8];
-#pragma unroll
-    for (int mbl = 0; mbl < 2; ++mbl) {
-      const int mb = 2 * st + mbl;
-      const f32x4 b4 = bias4[4 * mb];
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp)
-          mma3q(acc, lw[((mbl * 4 + sp) * 2 + 0) * 64], lw[((mbl * 4 + sp) * 2 + 1) * 64], oh[ib][sp], ol[ib][sp]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) keep[ib][4 * mbl + r] = fmaxf(fmaf(acc[r], kH2Inv, b4[r]), 0.f);
-      }
-    }
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) split8h(keep[ib], m1h[ib][st], m1l[ib][st]);
-  }
-  // layer b: 64 -> 64 (one stage, 4 output blocks), ReLU
-  f16x8 m2h[2][2], m2l[2][2];
-  {
-    const f16x8* lw = as_h2(ss.acquire());
-#pragma unroll
-    for (int sp2 = 0; sp2 < 2; ++sp2) {
-      float keep[2][8];
-#pragma unroll
-      for (int mbl = 0; mbl < 2; ++mbl) {
-        const int mb = 2 * sp2 + mbl;
-        const f32x4 b4 = bias4[16 + 4 * mb];
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int sp = 0; sp < 2; ++sp)
-            mma3q(acc, lw[((mb * 2 + sp) * 2 + 0) * 64], lw[((mb * 2 + sp) * 2 + 1) * 64], m1h[ib][sp], m1l[ib][sp]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) keep[ib][4 * mbl + r] = fmaxf(fmaf(acc[r], kH2Inv, b4[r]), 0.f);
-        }
-      }
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib) split8h(keep[ib], m2h[ib][sp2], m2l[ib][sp2]);
-    }
-  }
-  // layer c: 64 -> 128 (8 output blocks; stages: blocks 0..3 | 4..7), + bias + Fusion-2 branch, stored as float4s of the
-  // P32 image: features 16 mb + 4 g .. +3 of row 16 ib + c16 = float4 index (2 mb + (g >> 1))*64 + 32 (g & 1) + 16 ib + c16
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    const f16x8* lw = as_h2(ss.acquire());
-#pragma unroll
-    for (int mbl = 0; mbl < 4; ++mbl) {
-      const int mb = 4 * st + mbl;
-      const f32x4 b4 = bias4[32 + 4 * mb];
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
-          mma3q(acc, lw[((mbl * 2 + sp) * 2 + 0) * 64], lw[((mbl * 2 + sp) * 2 + 1) * 64], m2h[ib][sp], m2l[ib][sp]);
-        const int f4 = (2 * mb + (g >> 1)) * 64 + 32 * (g & 1) + 16 * ib + c16;
-        const float4 fz = reinterpret_cast<const float4*>(fus + toff)[f4];
-        if (active)
-          reinterpret_cast<float4*>(out + toff)[f4] = make_float4(fmaf(acc[0], kH2Inv, b4[0]) + fz.x, fmaf(acc[1], kH2Inv, b4[1]) + fz.y,
-                                                                  fmaf(acc[2], kH2Inv, b4[2]) + fz.z, fmaf(acc[3], kH2Inv, b4[3]) + fz.w);
-      }
-    }
-  }
 }
 
 // =========================================================================================
@@ -2400,85 +1248,6 @@ k_fusion_ff(const float* __restrict__ x1, const float* __restrict__ wst, const f
 }
 
 // =========================================================================================
-// k_fusion_ff_b3: k_fusion_ff on the bf16 MFMA with split-bf16 operands (fp32-equivalent accuracy).
-//   Weights arrive pre-split (three bf16 planes per 32-output block, 24 KiB per stage); LayerNorm output and
-//   the GEGLU product are split in registers.  144 MFMAs of 32 cycles per 32-unit chunk instead of 192 of 64.
-//   stages (48 x 24 KiB): for c in 0..15: W1a_c | W1g_c | W2_c (4 blocks of 32 x 32)
-// =========================================================================================
-__global__ void __launch_bounds__(256, 2)
-k_fusion_ff_b3(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
-               float* __restrict__ x2_out, int tiles) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * kB3TileFloats];
-  const int lane = threadIdx.x & 63, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = blockIdx.y;
-  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
-  const bool active = tile_raw < tiles;
-  const int tile = active ? tile_raw : tiles - 1;
-  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
-
-  StageStream ss;
-  ss.stage_floats = kB3TileFloats;
-  ss.init(lds, lds + kB3TileFloats, wave, kWavesPerWG, lane, wst, 3 * (FFH / 32));
-  ss.prime();
-
-  bf16x8 xh[8], xm[8], xl[8];
-  {
-    float x[CF], xn[CF];
-    load_frag_p32<CF>(x, x1 + toff, lane);
-    layernorm_frag<CF>(xn, x, vecs, vecs + C, h);
-    split_frag<CF>(xn, xh, xm, xl);
-  }
-  f32x16 y[4];
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb) y[mb] = zero16();
-  const float* b1a = vecs + 2 * C;
-  const float* b1g = vecs + 2 * C + FFH;
-
-  for (int c = 0; c < FFH / 32; ++c) {
-    float ga[16];
-    {
-      const bf16x8* lw = reinterpret_cast<const bf16x8*>(ss.acquire());
-      f32x16 acc = zero16();
-      mma_wx_b3<8>(acc, lw, xh, xm, xl);
-      float b[16];
-      load_vec_block(b, b1a, c, h);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ga[r] = acc[r] + b[r];
-    }
-    {
-      const bf16x8* lw = reinterpret_cast<const bf16x8*>(ss.acquire());
-      f32x16 acc = zero16();
-      mma_wx_b3<8>(acc, lw, xh, xm, xl);
-      float b[16];
-      load_vec_block(b, b1g, c, h);
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {      // erff in groups of four: bounds the live temporaries (no spills)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ga[4 * r4 + e] *= gelu_erf(acc[4 * r4 + e] + b[4 * r4 + e]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    {
-      bf16x8 gh[2], gm[2], gl[2];
-      split_frag<16>(ga, gh, gm, gl);
-      const bf16x8* lw = reinterpret_cast<const bf16x8*>(ss.acquire());
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) mma_wx_b3<2>(y[mb], lw + mb * (3 * 2 * 64), gh, gm, gl);
-    }
-  }
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    float b[16], xr[16], t[16];
-    load_vec_block(b, vecs + 2 * C + 2 * FFH, mb, h);
-    load_block_p32(xr, x1 + toff, mb, lane);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = y[mb][r] + b[r] + xr[r];
-    if (active) store_block_p32(x2_out + toff, mb, t, lane);
-  }
-}
-
-// =========================================================================================
 // k_head: classifier 128->32 ReLU ->32 ReLU ->1 and row L2 normalisation.
 //   stages (2): Wc1 (32x128) | Wc2 (32x32, padded)     vecs: b1[32] | b2[32] | w3[32] | b3
 //   outputs (row-major, the layout the pose head and the caller consume):
@@ -2673,119 +1442,73 @@ __global__ void k_pack_pts8(const float* __restrict__ src, const float* __restri
 }  // namespace gmf
 
 // -----------------------------------------------------------------------------------------
+
+// -----------------------------------------------------------------------------------------
 // host-side launchers (C++ linkage inside the library; the C ABI in gmf_api.cpp calls these)
 // -----------------------------------------------------------------------------------------
 #include "launchers.hpp"
-#include <cstdlib>
 
 namespace gmf {
-
-static int g_scattn_variant = [] { const char* e = getenv("GMF_SCATTN"); return e ? atoi(e) : 18; }();
-static bool g_h2_dbuf = [] { const char* e = getenv("GMF_H2_DBUF"); return e ? atoi(e) != 0 : true; }();
-void set_h2_dbuf(bool v) { g_h2_dbuf = v; }
-static int g_key_splits = [] { const char* e = getenv("GMF_KEY_SPLITS"); return e ? atoi(e) : 0; }();   // 0 = automatic
-void set_key_splits(int v) { g_key_splits = v; }
-static bool g_use_cache = [] { const char* e = getenv("GMF_COMPAT_CACHE"); return e ? atoi(e) != 0 : true; }();
-void set_use_cache(bool v) { g_use_cache = v; }
-bool get_use_cache() { return g_use_cache; }
-static bool g_force_fp32_qkv = false;   // set while the dense-compat (drop-in NonLocalBlock) path runs
-void set_force_fp32_qkv(bool v) { g_force_fp32_qkv = v; }
-void set_scattn_variant(int v) { g_scattn_variant = v; }
-int get_scattn_variant() { return g_scattn_variant; }
 
 static inline dim3 tile_grid(int tiles, int B, int sets = 1) { return dim3((tiles + kWavesPerWG - 1) / kWavesPerWG, B, sets); }
 
 hipError_t launch_front(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
                         float* v, int B, int N, int tiles, hipStream_t s) {
-  const int fmt = g_force_fp32_qkv ? 0 : (g_scattn_variant >= 9) ? 2 : (g_scattn_variant >= 3) ? 1 : 0;
-#define GMF_LAUNCH_FRONT(M, F) hipLaunchKernelGGL((k_front<M, F>), tile_grid(tiles, B), dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles)
-  if (fmt == 1) { if (mode == 1) GMF_LAUNCH_FRONT(1, 1); else if (mode == 2) GMF_LAUNCH_FRONT(2, 1); else GMF_LAUNCH_FRONT(0, 1); }
-  else if (fmt == 2) { if (mode == 1) GMF_LAUNCH_FRONT(1, 2); else if (mode == 2) GMF_LAUNCH_FRONT(2, 2); else GMF_LAUNCH_FRONT(0, 2); }
-  else { if (mode == 1) GMF_LAUNCH_FRONT(1, 0); else if (mode == 2) GMF_LAUNCH_FRONT(2, 0); else GMF_LAUNCH_FRONT(0, 0); }
-#undef GMF_LAUNCH_FRONT
+  const dim3 g = tile_grid(tiles, B);
+  if (mode == 1) hipLaunchKernelGGL(k_front<1>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  else if (mode == 2) hipLaunchKernelGGL(k_front<2>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  else hipLaunchKernelGGL(k_front<0>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
   return hipGetLastError();
 }
 
-hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s,
-                               bool q16) {
+hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s) {
   const dim3 grid(tiles, (tiles + 4 * kJPerWave - 1) / (4 * kJPerWave), B);
-  if (q16) hipLaunchKernelGGL(k_compat_build<true>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, 1.0f / (sigma_d * sigma_d));
-  else hipLaunchKernelGGL(k_compat_build<false>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, 1.0f / (sigma_d * sigma_d));
+  hipLaunchKernelGGL(k_compat_build, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, 1.0f / (sigma_d * sigma_d));
   return hipGetLastError();
 }
 
-hipError_t launch_scattn(const float* q, const float* k, const float* v, const float* pts8, const float* fus,
-                         const float* wst, const float* vecs, float* out, int B, int N, int tiles, float sigma_d,
-                         hipStream_t s, const CompatCache* cc) {
-  // GMF_SCATTN / gmf_set_tuning("scattn_variant") selects the kernel form for A/B measurements:
-  // 0 = fp32 MFMA, two-phase loop; 1 = fp32 MFMA, software-pipelined; 2 = 1 with v_sqrt_f32;
-  // 3 = split-bf16 (3 planes, 6 products) MFMA; 4 = 3 with the rational compat form; 5/6 = 3/4 software-pipelined,
-  // 8 waves; 7/8 = 3/4 with 8-wave workgroups; 9 = split-fp16 (2 planes, 3 products) MFMA (default);
-  // 10 = 9 with the rational compat form; 11..15 = timing-only ablations of 9;
-  // 16/17/18 = 9 with the compat cache and the tile loop software-pipelined inside each wave (k_scattn_h2p), LDS-DMA
-  // pieces issued at the tile top / in phase 1 / in the bare MFMA gaps of phase 2 (18 = default; falls back to 9 when
-  // the cache is off or too large).
-  const int variant = g_scattn_variant;
+// fp32 images (P32 Q', K; T-image V), fp32 MFMA, c recomputed in-kernel: the single-stage entry point gmf_scattn_forward
+// and the whole-encoder path when no split-fp16 weight images were given (or `scattn_variant` 0).
+hipError_t launch_scattn_fp32(const float* q, const float* k, const float* v, const float* pts8, const float* fus,
+                              const float* wst, const float* vecs, float* out, int B, int N, int tiles, float sigma_d,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(k_scattn<false>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles,
+                     1.0f / (sigma_d * sigma_d));
+  return hipGetLastError();
+}
+
+// Split-fp16 plane images of Q', K, V (k_front_h2 / k_linear_h2).  tune.scattn_variant:
+//   18 (default) = k_scattn_h2p: c streamed from the compat cache, tile loop software-pipelined inside each wave, split-fp16
+//                  fc_message epilogue; on small grids the keys of a query block are divided over several workgroups
+//                  (KSPLIT form) and k_scattn_merge finishes.  Needs cc->dense and cc->tail_wst_h2; otherwise:
+//   9            = k_scattn_h2: not pipelined, c from the cache when there is one, else recomputed per (i, j) from pts8
+//                  (the fallback when the cache would not fit); fp32-MFMA fc_message epilogue (wst = fp32 images).
+hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, const float* v, const float* pts8,
+                            const float* fus, const float* wst, const float* vecs, float* out, int B, int N, int tiles,
+                            float sigma_d, hipStream_t s, const CompatCache* cc) {
   const float inv = 1.0f / (sigma_d * sigma_d);
-  if (variant >= 3) {
-    const dim3 grid((tiles + kB3Waves - 1) / kB3Waves, B);
-    const int wpp = (tiles + kB3sWaves - 1) / kB3sWaves;
-    const dim3 grid4(wpp * B);
-    const int wpp8 = (tiles + 7) / 8;
-    const dim3 grid8(wpp8 * B);
-    if (variant == 4) hipLaunchKernelGGL((k_scattn_b3<true, 4>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
-    else if (variant >= 11 && variant <= 15) {
-      switch (variant) {
-        case 11: hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 1>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr); break;
-        case 12: hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 2>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr); break;
-        case 13: hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 3>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr); break;
-        case 14: hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 4>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr); break;
-        default: hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 5>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr); break;
-      }
+  const int wpp = (tiles + 3) / 4;
+  const dim3 grid4(wpp * B);
+  const float* cd = (cc && tune.use_cache) ? cc->dense : nullptr;
+  if (tune.scattn_variant == 18 && cd && cc->tail_wst_h2) {
+    int ksplits = 1;
+    if (cc->part_o && cc->max_splits > 1) {
+      if (tune.key_splits > 0) ksplits = tune.key_splits;
+      else if (wpp * B < 256) ksplits = std::max(2, 512 / (wpp * B));   // one resident round of 512 workgroup slots, never more
+      else if (wpp * B < 384 && tiles >= 64) ksplits = 2;               // measured break-even
+      ksplits = std::min(std::min(ksplits, cc->max_splits), std::max(1, tiles / 4));
     }
-    else if (variant == 19 && cc && cc->q16 && cc->dense && cc->tail_wst_q16)
-      {
-      static const int q16_mode = [] { const char* e = getenv("GMF_Q16_MODE"); return e ? atoi(e) : 2; }();
-      if (q16_mode == 1) hipLaunchKernelGGL((k_scattn_h2q<1, 0, false>), grid4, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_q16, vecs, out, N, tiles, wpp, cc->dense);
-      else hipLaunchKernelGGL((k_scattn_h2q<2, 2, true>), grid4, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_q16, vecs, out, N, tiles, wpp, cc->dense);
-      }
-    else if (variant >= 16 && cc && g_use_cache && cc->dense) {
-      static const bool epi_h2 = [] { const char* e = getenv("GMF_EPI_H2"); return e ? atoi(e) != 0 : true; }();
-      // small grids: divide the keys of each query block over several workgroups (k_scattn_merge finishes)
-      int ksplits = 1;
-      if (variant == 18 && cc->tail_wst_h2 && epi_h2 && cc->part_o && cc->max_splits > 1) {
-        if (g_key_splits > 0) ksplits = g_key_splits;
-        else if (wpp * B < 256) ksplits = std::max(2, 512 / (wpp * B));   // one resident round of 512 workgroup slots, never more
-        else if (wpp * B < 384 && tiles >= 64) ksplits = 2;               // measured break-even
-        ksplits = std::min(std::min(ksplits, cc->max_splits), std::max(1, tiles / 4));
-      }
-      if (ksplits > 1) {
-        hipLaunchKernelGGL((k_scattn_h2p<2, true, true>), dim3(wpp * B * ksplits), dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out,
-                           N, tiles, wpp, cc->dense, ksplits, cc->part_o, cc->part_ml);
-        hipLaunchKernelGGL(k_scattn_merge, dim3(wpp, B), dim3(256), 0, s, cc->part_o, cc->part_ml, fus, cc->tail_wst_h2, vecs, out, tiles, ksplits);
-      }
-      else if (variant == 17) hipLaunchKernelGGL((k_scattn_h2p<1, false>), grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense, 1, (float*)nullptr, (float*)nullptr);
-      else if (variant == 18 && cc->tail_wst_h2 && epi_h2) hipLaunchKernelGGL((k_scattn_h2p<2, true>), grid4, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cc->dense, 1, (float*)nullptr, (float*)nullptr);
-      else if (variant == 18) hipLaunchKernelGGL((k_scattn_h2p<2, false>), grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense, 1, (float*)nullptr, (float*)nullptr);
-      else hipLaunchKernelGGL((k_scattn_h2p<0, false>), grid4, dim3(256), 0, s, q, k, v, fus, wst, vecs, out, N, tiles, wpp, cc->dense, 1, (float*)nullptr, (float*)nullptr);
+    if (ksplits > 1) {
+      hipLaunchKernelGGL(k_scattn_h2p<true>, dim3(wpp * B * ksplits), dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out,
+                         N, tiles, wpp, cd, ksplits, cc->part_o, cc->part_ml);
+      hipLaunchKernelGGL(k_scattn_merge, dim3(wpp, B), dim3(256), 0, s, cc->part_o, cc->part_ml, fus, cc->tail_wst_h2, vecs, out, tiles, ksplits);
+    } else {
+      hipLaunchKernelGGL(k_scattn_h2p<false>, grid4, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, 1,
+                         (float*)nullptr, (float*)nullptr);
     }
-    else if (variant == 9 || variant >= 16) {
-      const float* cd = (cc && g_use_cache) ? cc->dense : nullptr;
-      if (cd) hipLaunchKernelGGL((k_scattn_h2<false, 4, true, 0, true>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
-      else if (g_h2_dbuf) hipLaunchKernelGGL((k_scattn_h2<false, 4, true>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
-      else hipLaunchKernelGGL((k_scattn_h2<false, 4, false>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
-    }
-    else if (variant == 10) hipLaunchKernelGGL((k_scattn_h2<true, 4, true>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, (const float*)nullptr);
-    else if (variant == 7) hipLaunchKernelGGL((k_scattn_b3<false, 8>), grid8, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp8);
-    else if (variant == 8) hipLaunchKernelGGL((k_scattn_b3<true, 8>), grid8, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp8);
-    else if (variant == 5) hipLaunchKernelGGL(k_scattn_b3p<false>, grid, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
-    else if (variant == 6) hipLaunchKernelGGL(k_scattn_b3p<true>, grid, dim3(512), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
-    else hipLaunchKernelGGL((k_scattn_b3<false, 4>), grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp);
-    return hipGetLastError();
   }
-  if (variant == 0) hipLaunchKernelGGL(k_scattn<false>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
-  else if (variant == 2) hipLaunchKernelGGL(k_scattn_pipe<true>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
-  else hipLaunchKernelGGL(k_scattn_pipe<false>, tile_grid(tiles, B), dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv);
+  else if (cd) hipLaunchKernelGGL(k_scattn_h2<true>, grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
+  else hipLaunchKernelGGL(k_scattn_h2<false>, grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
   return hipGetLastError();
 }
 
@@ -2811,11 +1534,6 @@ hipError_t launch_fusion_attn(bool pe, const float* x, const float* ctx_img, con
 
 hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s) {
   hipLaunchKernelGGL(k_fusion_ff, tile_grid(tiles, B), dim3(256), 0, s, x1, wst, vecs, x2, tiles);
-  return hipGetLastError();
-}
-
-hipError_t launch_fusion_ff_b3(const float* x1, const float* wst_b3, const float* vecs, float* x2, int B, int tiles, hipStream_t s) {
-  hipLaunchKernelGGL(k_fusion_ff_b3, tile_grid(tiles, B), dim3(256), 0, s, x1, wst_b3, vecs, x2, tiles);
   return hipGetLastError();
 }
 

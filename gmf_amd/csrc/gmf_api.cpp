@@ -20,6 +20,7 @@ struct gmf_handle {
   void* arena = nullptr;
   size_t arena_bytes = 0;
   size_t arena_used = 0;
+  gmf::Tuning tune;   // per-handle knobs (gmf_set_tuning); no process-global state
   // optional in-situ timing of the dominant kernel (k_scattn): event pairs recorded on the caller's stream
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -112,46 +113,47 @@ int gmf_create(int device, gmf_handle** out) {
 
 int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
   GMF_REQUIRE(h && name, GMF_ERR_BAD_ARG, "set_tuning: null pointer");
+  gmf::Tuning& t = h->tune;
   if (std::strcmp(name, "scattn_variant") == 0) {
-    GMF_REQUIRE(value >= 0 && value <= 19, GMF_ERR_BAD_ARG, "set_tuning: scattn_variant out of range (0..19)");
-    gmf::set_scattn_variant(value);
+    GMF_REQUIRE(value == 0 || value == 9 || value == 18, GMF_ERR_BAD_ARG,
+                "set_tuning: scattn_variant must be 18 (cached, pipelined split-fp16; default), 9 (split-fp16, not pipelined) or 0 (fp32 MFMA)");
+    t.scattn_variant = value;
     return GMF_OK;
   }
   if (std::strcmp(name, "front_output_split") == 0) {  // 1 = small grids use one workgroup per output of k_front_h2 (default), 0 = never
-    gmf::set_front_split(value != 0);
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: front_output_split must be 0 or 1");
+    t.front_split = value != 0;
     return GMF_OK;
   }
   if (std::strcmp(name, "ff_hidden_splits") == 0) {    // 0 = automatic (small grids only), 1 = off, 2 / 4 / 8 = forced
     GMF_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, GMF_ERR_BAD_ARG,
                 "set_tuning: ff_hidden_splits must be 0, 1, 2, 4 or 8");
-    gmf::set_ff_split(value);
+    t.ff_split = value;
     return GMF_OK;
   }
   if (std::strcmp(name, "attn_key_splits") == 0) {     // 0 = automatic (small grids only), 1 = off, n = force n splits
     GMF_REQUIRE(value >= 0 && value <= 8, GMF_ERR_BAD_ARG, "set_tuning: attn_key_splits out of range (0..8)");
-    gmf::set_key_splits(value);
+    t.key_splits = value;
     return GMF_OK;
   }
   if (std::strcmp(name, "compat_cache") == 0) {
-    gmf::set_use_cache(value != 0);
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: compat_cache must be 0 or 1");
+    t.use_cache = value != 0;
     return GMF_OK;
   }
   if (std::strcmp(name, "conv_lds_patch") == 0) {      // 1 = stride-1 3x3 convolutions stage their activations through LDS (default), 2 = same without the three-workgroup form, 0 = gather form
     GMF_REQUIRE(value >= 0 && value <= 2, GMF_ERR_BAD_ARG, "set_tuning: conv_lds_patch must be 0, 1 or 2");
-    gmf::set_conv_patch(value);
+    t.conv_patch = value;
     return GMF_OK;
   }
   if (std::strcmp(name, "nms_binned") == 0) {          // 1 = grid-binned NMS candidates on large grids (default), 2 = always, 0 = all pairs
     GMF_REQUIRE(value >= 0 && value <= 2, GMF_ERR_BAD_ARG, "set_tuning: nms_binned must be 0, 1 or 2");
-    gmf::set_nms_binned(value);
+    t.nms_binned = value;
     return GMF_OK;
   }
   if (std::strcmp(name, "topk_select") == 0) {         // 1 = radix select of the S seeds (default), 0 = full bitonic sort
-    gmf::set_topk_select(value != 0);
-    return GMF_OK;
-  }
-  if (std::strcmp(name, "h2_double_buffer") == 0) {
-    gmf::set_h2_dbuf(value != 0);
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: topk_select must be 0 or 1");
+    t.topk_select = value != 0;
     return GMF_OK;
   }
   return fail(h, GMF_ERR_BAD_ARG, std::string("gmf: set_tuning: unknown knob ") + name);
@@ -238,7 +240,7 @@ int gmf_scattn_forward(gmf_handle* h, const float* q, const float* k, const floa
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "scattn_forward: empty input");
   GMF_REQUIRE(sigma_d > 0.f, GMF_ERR_BAD_ARG, "scattn_forward: sigma_d must be positive");
   SetDevice sd(h);
-  GMF_HIP(gmf::launch_scattn(q, k, v, pts8, fusion2_out, wst, vecs, out, B, N, tiles_of(N), sigma_d, S(stream)));
+  GMF_HIP(gmf::launch_scattn_fp32(q, k, v, pts8, fusion2_out, wst, vecs, out, B, N, tiles_of(N), sigma_d, S(stream)));
   return GMF_OK;
 }
 
@@ -296,9 +298,9 @@ static int check_weights(gmf_handle* h, const gmf_encoder_weights* w) {
   return GMF_OK;
 }
 
-static bool use_h2(const gmf_encoder_weights* w, bool dense) {
-  const int v = gmf::get_scattn_variant();
-  return !dense && v >= 9 && w->front_wst_h2 && w->ctx_wst_h2 && w->attn_wst_h2 && w->ff_wst_h2;
+// split-fp16 path: needs every split-fp16 weight image; the dense-`attention` drop-in and scattn_variant 0 run on fp32 images
+static bool use_h2(const gmf_handle* h, const gmf_encoder_weights* w, bool dense) {
+  return !dense && h->tune.scattn_variant >= 9 && w->front_wst_h2 && w->ctx_wst_h2 && w->attn_wst_h2 && w->ff_wst_h2 && w->tail_wst_h2;
 }
 
 // Runs Fusion-2 + the spatial-consistency block of layer `l` given f,q,k,v.
@@ -307,20 +309,16 @@ static int run_block_tail(gmf_handle* h, const gmf_encoder_weights* w, int l, co
                           float* out, int B, int N, int T, hipStream_t st, const float* dense_compat = nullptr,
                           const gmf::CompatCache* cc = nullptr) {
   const int tiles = tiles_of(N), tt = tiles_of(T);
-  const bool h2 = use_h2(w, dense_compat != nullptr);
+  const bool h2 = use_h2(h, w, dense_compat != nullptr);
   if (h2) {
     GMF_HIP(gmf::launch_fusion_attn_h2(true, f, ctx_l, w->attn_wst_h2 + (size_t)l * w->attn_wst_stride,
                                        w->attn_vec + (size_t)l * w->attn_vec_stride, x1, B, N, tiles, T, tt, st));
-    GMF_HIP(gmf::launch_fusion_ff_h2(x1, w->ff_wst_h2 + (size_t)l * w->ff_wst_stride,
+    GMF_HIP(gmf::launch_fusion_ff_h2(h->tune, x1, w->ff_wst_h2 + (size_t)l * w->ff_wst_stride,
                                      w->ff_vec + (size_t)l * w->ff_vec_stride, x2, B, tiles, st,
                                      cc ? cc->part_o : nullptr, cc ? cc->max_splits : 0));   // the attention's partial buffer is free here
   } else {
-  GMF_HIP(gmf::launch_fusion_attn(true, f, ctx_l, w->attn_wst + (size_t)l * w->attn_wst_stride,
-                                  w->attn_vec + (size_t)l * w->attn_vec_stride, x1, B, N, tiles, T, tt, st));
-  if (w->ff_wst_b3)
-    GMF_HIP(gmf::launch_fusion_ff_b3(x1, w->ff_wst_b3 + (size_t)l * w->ff_wst_b3_stride,
-                                     w->ff_vec + (size_t)l * w->ff_vec_stride, x2, B, tiles, st));
-  else
+    GMF_HIP(gmf::launch_fusion_attn(true, f, ctx_l, w->attn_wst + (size_t)l * w->attn_wst_stride,
+                                    w->attn_vec + (size_t)l * w->attn_vec_stride, x1, B, N, tiles, T, tt, st));
     GMF_HIP(gmf::launch_fusion_ff(x1, w->ff_wst + (size_t)l * w->ff_wst_stride, w->ff_vec + (size_t)l * w->ff_vec_stride,
                                   x2, B, tiles, st));
   }
@@ -340,9 +338,12 @@ static int run_block_tail(gmf_handle* h, const gmf_encoder_weights* w, int l, co
   if (dense_compat)
     GMF_HIP(gmf::launch_scattn_dense(q, k, v, dense_compat, x2, w->tail_wst + (size_t)l * w->tail_wst_stride,
                                      w->tail_vec + (size_t)l * w->tail_vec_stride, out, B, N, tiles, st));
+  else if (h2)
+    GMF_HIP(gmf::launch_scattn_h2(h->tune, q, k, v, pts8, x2, w->tail_wst + (size_t)l * w->tail_wst_stride,
+                                  w->tail_vec + (size_t)l * w->tail_vec_stride, out, B, N, tiles, w->sigma_d, st, cc));
   else
-    GMF_HIP(gmf::launch_scattn(q, k, v, pts8, x2, w->tail_wst + (size_t)l * w->tail_wst_stride,
-                               w->tail_vec + (size_t)l * w->tail_vec_stride, out, B, N, tiles, w->sigma_d, st, cc));
+    GMF_HIP(gmf::launch_scattn_fp32(q, k, v, pts8, x2, w->tail_wst + (size_t)l * w->tail_wst_stride,
+                                    w->tail_vec + (size_t)l * w->tail_vec_stride, out, B, N, tiles, w->sigma_d, st));
   if (ev1) GMF_HIP(hipEventRecord(ev1, st));
   return GMF_OK;
 }
@@ -361,27 +362,24 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   const int tiles = tiles_of(N), tt = tiles_of(T);
   const size_t act = (size_t)B * tiles * kTileFloats;
   const size_t tok = (size_t)B * tt * kTileFloats;
-  const size_t act3 = act + act / 2;   // Q', K, V may be bf16x3 plane images (24 KiB per tile)
   // compat cache (built once per batch, streamed by all L attention launches): 4 KiB per pair of 32-row tiles
   const size_t n_tt = (size_t)B * tiles * tiles;
-  const bool want_cache = (L > 1) && (gmf::get_scattn_variant() == 9 || gmf::get_scattn_variant() >= 16) && gmf::get_use_cache() &&
-                          n_tt * 4096 <= ((size_t)96 << 30);
+  const bool h2 = use_h2(h, w, false);
+  const bool want_cache = h2 && (L > 1) && h->tune.use_cache && n_tt * 4096 <= ((size_t)96 << 30);
   const size_t cache_need = want_cache ? arena_need(n_tt * 1024, 4) : 0;
-  // 16x16x32 form of the attention kernel: needs the cache, the split-fp16 path and the q16 fc_message images
-  const bool q16 = want_cache && gmf::get_scattn_variant() == 19 && w->tail_wst_q16 && use_h2(w, false);
   // key-split attention for small grids (fewer than 256 workgroups of 128 queries): partial-result workspace
   const int kMaxSplits = 8;
   const bool want_split = want_cache && ((tiles + 3) / 4) * B < 384 && tiles >= 8;
   const size_t split_need = want_split ? arena_need((size_t)kMaxSplits * act, 4) + arena_need((size_t)kMaxSplits * B * tiles * 64, 4) : 0;
-  const size_t need = 5 * arena_need(act, 4) + 3 * arena_need(act3, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +
+  const size_t need = 8 * arena_need(act, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +
                       5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4) + cache_need + split_need;
   if (int rc = arena_reserve(h, need)) return rc;
   float* featA = arena_take<float>(h, act);
   float* featB = arena_take<float>(h, act);
   float* f = arena_take<float>(h, act);
-  float* q = arena_take<float>(h, act3);
-  float* k = arena_take<float>(h, act3);
-  float* v = arena_take<float>(h, act3);
+  float* q = arena_take<float>(h, act);
+  float* k = arena_take<float>(h, act);
+  float* v = arena_take<float>(h, act);
   float* x1 = arena_take<float>(h, act);
   float* x2 = arena_take<float>(h, act);
   float* pts8 = arena_take<float>(h, (size_t)B * tiles * 32 * 8);
@@ -391,12 +389,11 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   float* x1t = arena_take<float>(h, tok);
   float* imgfeat = arena_take<float>(h, tok);
   float* ctxall = arena_take<float>(h, (size_t)(L > 0 ? L : 1) * tok);
-  gmf::CompatCache cc{nullptr, nullptr, nullptr};
+  gmf::CompatCache cc{nullptr, nullptr, nullptr, nullptr, 0};
   float* c_dense = nullptr;
   if (want_cache) {
     c_dense = arena_take<float>(h, n_tt * 1024);
     cc.dense = c_dense;
-    cc.q16 = q16;
   }
   if (want_split) {
     cc.part_o = arena_take<float>(h, (size_t)kMaxSplits * act);
@@ -407,17 +404,15 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   // Fusion-1: image_feat = FusionLayer(p_tok (context), queries = q_tok), pe = False (PointDSC.py:137)
   GMF_HIP(gmf::launch_pack_p32(p_tokens, pimg, B, T, kC, (long)T * kC, kC, 1, st));
   GMF_HIP(gmf::launch_pack_p32(q_tokens, qimg, B, T, kC, (long)T * kC, kC, 1, st));
-  const bool h2 = use_h2(w, false);
   if (h2 && w->f1_ctx_wst_h2 && w->f1_attn_wst_h2 && w->f1_ff_wst_h2) {
     GMF_HIP(gmf::launch_ctx_prep_h2(false, pimg, w->f1_ctx_wst_h2, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st));
     GMF_HIP(gmf::launch_fusion_attn_h2(false, qimg, f1ctx, w->f1_attn_wst_h2, w->f1_attn_vec, x1t, B, T, tt, T, tt, st));
-    GMF_HIP(gmf::launch_fusion_ff_h2(x1t, w->f1_ff_wst_h2, w->f1_ff_vec, imgfeat, B, tt, st,
+    GMF_HIP(gmf::launch_fusion_ff_h2(h->tune, x1t, w->f1_ff_wst_h2, w->f1_ff_vec, imgfeat, B, tt, st,
                                      tt <= tiles ? cc.part_o : nullptr, tt <= tiles ? cc.max_splits : 0));
   } else {
     GMF_HIP(gmf::launch_ctx_prep(false, pimg, w->f1_ctx_wst, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st));
     GMF_HIP(gmf::launch_fusion_attn(false, qimg, f1ctx, w->f1_attn_wst, w->f1_attn_vec, x1t, B, T, tt, T, tt, st));
-    if (w->f1_ff_wst_b3) GMF_HIP(gmf::launch_fusion_ff_b3(x1t, w->f1_ff_wst_b3, w->f1_ff_vec, imgfeat, B, tt, st));
-    else GMF_HIP(gmf::launch_fusion_ff(x1t, w->f1_ff_wst, w->f1_ff_vec, imgfeat, B, tt, st));
+    GMF_HIP(gmf::launch_fusion_ff(x1t, w->f1_ff_wst, w->f1_ff_vec, imgfeat, B, tt, st));
   }
   // context side of all L Fusion-2 layers in one launch
   if (L > 0) {
@@ -427,7 +422,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
                                       w->ctx_vec_stride, st));
   }
   GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st));
-  if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, st, q16));
+  if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, st));
 
   float* cur = featA;
   float* nxt = featB;
@@ -437,14 +432,13 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   }
   for (int l = 0; l < L; ++l) {
     const float* in = (l == 0) ? corr_pos : cur;
-    if (h2) GMF_HIP(gmf::launch_front_h2(l == 0 ? 1 : 0, in, w->front_wst_h2 + (size_t)l * w->front_wst_stride,
-                                         w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st, q16));
+    if (h2) GMF_HIP(gmf::launch_front_h2(h->tune, l == 0 ? 1 : 0, in, w->front_wst_h2 + (size_t)l * w->front_wst_stride,
+                                         w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
     else GMF_HIP(gmf::launch_front(l == 0 ? 1 : 0, in, w->front_wst + (size_t)l * w->front_wst_stride,
                                    w->front_vec + (size_t)l * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
     cc.tail_wst_h2 = w->tail_wst_h2 ? w->tail_wst_h2 + (size_t)l * w->tail_wst_stride : nullptr;
-    cc.tail_wst_q16 = w->tail_wst_q16 ? w->tail_wst_q16 + (size_t)l * w->tail_wst_stride : nullptr;
     if (int rc = run_block_tail(h, w, l, f, q, k, v, pts8, ctxall + (size_t)l * tok, x1, x2, nxt, B, N, T, st, nullptr,
-                                want_cache ? &cc : nullptr)) return rc;
+                                &cc)) return rc;
     float* t = cur; cur = nxt; nxt = t;
   }
   GMF_HIP(gmf::launch_head(cur, w->head_wst, w->head_vec, logits, feat_n, feat, B, N, tiles, st));
@@ -466,19 +460,17 @@ int gmf_nonlocal_block_forward(gmf_handle* h, const gmf_encoder_weights* w, int 
   const int tiles = tiles_of(N), tt = tiles_of(T);
   const size_t act = (size_t)B * tiles * kTileFloats;
   const size_t tok = (size_t)B * tt * kTileFloats;
-  const size_t act3 = act + act / 2;
-  if (int rc = arena_reserve(h, 3 * arena_need(act, 4) + 3 * arena_need(act3, 4) + arena_need(tok, 4))) return rc;
+  if (int rc = arena_reserve(h, 6 * arena_need(act, 4) + arena_need(tok, 4))) return rc;
   float* f = arena_take<float>(h, act);
-  float* q = arena_take<float>(h, act3);
-  float* k = arena_take<float>(h, act3);
-  float* v = arena_take<float>(h, act3);
-  gmf::set_force_fp32_qkv(attention != nullptr);   // the dense-compat kernel consumes fp32 images
+  float* q = arena_take<float>(h, act);
+  float* k = arena_take<float>(h, act);
+  float* v = arena_take<float>(h, act);
   float* x1 = arena_take<float>(h, act);
   float* x2 = arena_take<float>(h, act);
   float* ctx = arena_take<float>(h, tok);
   // apply_pointcn = 0: the caller's feat is already the block input (NonLocalBlock.forward, PointDSC.py:40-45)
-  if (use_h2(w, attention != nullptr)) {
-    GMF_HIP(gmf::launch_front_h2(apply_pointcn ? 0 : 2, feat_img, w->front_wst_h2 + (size_t)layer * w->front_wst_stride,
+  if (use_h2(h, w, attention != nullptr)) {   // (the dense-compat kernel consumes fp32 images: fp32 path)
+    GMF_HIP(gmf::launch_front_h2(h->tune, apply_pointcn ? 0 : 2, feat_img, w->front_wst_h2 + (size_t)layer * w->front_wst_stride,
                                  w->front_vec + (size_t)layer * w->front_vec_stride, f, q, k, v, B, N, tiles, st));
     GMF_HIP(gmf::launch_ctx_prep_h2(true, image_feat_img, w->ctx_wst_h2 + (size_t)layer * w->ctx_wst_stride,
                                     w->ctx_vec + (size_t)layer * w->ctx_vec_stride, ctx, B, T, tt, 1, 0, 0, st));
@@ -488,9 +480,8 @@ int gmf_nonlocal_block_forward(gmf_handle* h, const gmf_encoder_weights* w, int 
     GMF_HIP(gmf::launch_ctx_prep(true, image_feat_img, w->ctx_wst + (size_t)layer * w->ctx_wst_stride,
                                  w->ctx_vec + (size_t)layer * w->ctx_vec_stride, ctx, B, T, tt, 1, 0, 0, st));
   }
-  const int rc_tail = run_block_tail(h, w, layer, f, q, k, v, pts8, ctx, x1, x2, out_img, B, N, T, st, attention);
-  gmf::set_force_fp32_qkv(false);
-  return rc_tail;
+  gmf::CompatCache cc{nullptr, w->tail_wst_h2 ? w->tail_wst_h2 + (size_t)layer * w->tail_wst_stride : nullptr, nullptr, nullptr, 0};
+  return run_block_tail(h, w, layer, f, q, k, v, pts8, ctx, x1, x2, out_img, B, N, T, st, attention, &cc);
 }
 
 int gmf_fusion_layer_forward(gmf_handle* h, int pe, int latent_dim, int d_head, const float* ctx_wst, const float* ctx_vec,
@@ -521,7 +512,7 @@ int gmf_fusion_layer_forward(gmf_handle* h, int pe, int latent_dim, int d_head, 
   if (narrow) {
     GMF_HIP(gmf::launch_ctx_prep(pe != 0, cimg, ctx_wst, ctx_vec, ctx, B, T, tt, 1, 0, 0, st));
     GMF_HIP(gmf::launch_fusion_attn(pe != 0, xin, ctx, attn_wst, attn_vec, x1, B, N, tiles, T, tt, st));
-    if (ff_wst_h2) GMF_HIP(gmf::launch_fusion_ff_h2(x1, ff_wst_h2, ff_vec, x2, B, tiles, st));
+    if (ff_wst_h2) GMF_HIP(gmf::launch_fusion_ff_h2(h->tune, x1, ff_wst_h2, ff_vec, x2, B, tiles, st));
     else GMF_HIP(gmf::launch_fusion_ff(x1, ff_wst, ff_vec, x2, B, tiles, st));
   } else {
     GMF_HIP(gmf::launch_ctx_prep_w(pe != 0, cimg, ctx_wst, ctx_vec, ctx, B, T, tt, st));
@@ -547,10 +538,10 @@ int gmf_pick_seeds(gmf_handle* h, const float* src_keypts, const float* scores, 
     if (int rc = arena_reserve(h, arena_need((size_t)B * N, 4) + arena_need(n_scr, 4))) return rc;
     float* kbuf = arena_take<float>(h, (size_t)B * N);
     float* scr = arena_take<float>(h, n_scr);
-    GMF_HIP(gmf::launch_nms_keys(src_keypts, scores, kbuf, B, N, nms_radius, st, scr));
+    GMF_HIP(gmf::launch_nms_keys(h->tune, src_keypts, scores, kbuf, B, N, nms_radius, st, scr));
     keys = kbuf;
   }
-  GMF_HIP(gmf::launch_sort_topk(keys, seeds_out, B, N, num_seeds, st));
+  GMF_HIP(gmf::launch_sort_topk(h->tune, keys, seeds_out, B, N, num_seeds, st));
   return GMF_OK;
 }
 
@@ -598,10 +589,10 @@ int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, 
     if (p->use_nms) {
       // dmat is free until k_seed_dist: it doubles as the grid-binning scratch of the NMS when it is large enough
       float* scr = (BS * N >= gmf::nms_scratch_floats(B, N)) ? dmat : nullptr;
-      GMF_HIP(gmf::launch_nms_keys(src_keypts, logits, keys, B, N, p->nms_radius, st, scr));
+      GMF_HIP(gmf::launch_nms_keys(h->tune, src_keypts, logits, keys, B, N, p->nms_radius, st, scr));
       kk = keys;
     }
-    GMF_HIP(gmf::launch_sort_topk(kk, seeds, B, N, Sn, st));
+    GMF_HIP(gmf::launch_sort_topk(h->tune, kk, seeds, B, N, Sn, st));
     seeds_use = seeds;
   } else if (seeds_out) {
     GMF_HIP(hipMemcpyAsync(seeds_out, seeds_in, BS * sizeof(int), hipMemcpyDeviceToDevice, st));
@@ -776,7 +767,7 @@ int gmf_conv_nhwc(gmf_handle* h, const float* x, const float* wimg, const float*
   GMF_REQUIRE(known, GMF_ERR_UNSUPPORTED_SHAPE,
               "conv_nhwc: supported are the ResNet-34 layer1 / layer2 shapes (64->64 3x3 s1, 64->128 3x3 s2, 128->128 3x3 s1, 64->128 1x1 s2)");
   SetDevice sd(h);
-  GMF_HIP(gmf::launch_conv_nhwc_h2(x, wimg, bias, residual, y, B, H, W, cin, cout, ksize, stride, relu, S(stream)));
+  GMF_HIP(gmf::launch_conv_nhwc_h2(h->tune, x, wimg, bias, residual, y, B, H, W, cin, cout, ksize, stride, relu, S(stream)));
   return GMF_OK;
 }
 

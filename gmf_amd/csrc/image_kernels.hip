@@ -290,10 +290,8 @@ hipError_t launch_bias_relu_nhwc(float* y, const float* bias, const float* resid
   return hipGetLastError();
 }
 
-static int g_conv_patch = 1;      // stride-1 3x3 shapes on the LDS-patch kernel when W <= 48 (else the gather kernel, same image): 1 = automatic, 2 = never the three-workgroup form, 0 = gather
-void set_conv_patch(int v) { g_conv_patch = v; }
-
-hipError_t launch_conv_nhwc_h2(const float* x, const float* wimg, const float* bias, const float* residual, float* y, int B,
+// tune.conv_patch: stride-1 3x3 shapes on the LDS-patch kernel when W <= 48 (else the gather kernel, same image): 1 = automatic, 2 = never the three-workgroup form, 0 = gather
+hipError_t launch_conv_nhwc_h2(const Tuning& tune, const float* x, const float* wimg, const float* bias, const float* residual, float* y, int B,
                                int H, int W, int cin, int cout, int ks, int stride, int relu, hipStream_t s) {
   const int pad = ks / 2;
   const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
@@ -301,10 +299,10 @@ hipError_t launch_conv_nhwc_h2(const float* x, const float* wimg, const float* b
   const dim3 grid((unsigned)((P + 127) / 128), cout / 64);
 #define GMF_CONV(CI, CO, K, S) hipLaunchKernelGGL((k_conv_nhwc_h2<CI, CO, K, S>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, Ho, Wo, relu)
   // stride-1 3x3 shapes: activations staged through LDS (weight image in (channel block, tap) order); W <= 48
-  if (g_conv_patch && ks == 3 && stride == 1 && W <= 48 && cin == cout && (cin == 64 || cin == 128)) {
+  if (tune.conv_patch && ks == 3 && stride == 1 && W <= 48 && cin == cout && (cin == 64 || cin == 128)) {
     // grids between one round of 512 and one of 768 workgroup slots: the 49.5 KiB form (three workgroups per CU)
     const long nwg = (long)grid.x * grid.y;
-    if (cin == 64 && W <= 40 && g_conv_patch == 1 && nwg > 512 && nwg <= 768)
+    if (cin == 64 && W <= 40 && tune.conv_patch == 1 && nwg > 512 && nwg <= 768)
       hipLaunchKernelGGL((k_conv3x3_patch_h2<64, 64, 3, 40, false, 3>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, relu);
     else if (cin == 64) hipLaunchKernelGGL((k_conv3x3_patch_h2<64, 64, 4, 48, true, 2>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, relu);
     else hipLaunchKernelGGL((k_conv3x3_patch_h2<128, 128, 4, 48, true, 2>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, relu);

@@ -7,29 +7,35 @@ namespace gmf {
 // compat matrix built once per batch by launch_compat_build (see k_compat_build): [B, tiles, tiles, 1024] floats
 struct CompatCache {
   const float* dense;
-  const float* tail_wst_h2;   // this layer's fc_message weights as split-fp16 images, or nullptr (fp32-MFMA epilogue)
-  const float* tail_wst_q16;  // ... as 16x16x32 A-operand images (k_scattn_h2q)
-  bool q16;                   // scattn_variant 19 is active: the V images and `dense` are in k_scattn_h2q's element order
+  const float* tail_wst_h2;   // this layer's fc_message weights as split-fp16 images (epilogue of k_scattn_h2p)
   float* part_o;              // key-split workspace: [max_splits][B * tiles] P32 tile images (or nullptr)
   float* part_ml;             // ... [max_splits][B * tiles][32][2] row maximum, row sum
   int max_splits;
 };
-void set_use_cache(bool v);
-void set_key_splits(int v);
-void set_ff_split(int v);
-void set_front_split(bool v);
-bool get_use_cache();
-hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s,
-                               bool q16 = false);
-void set_scattn_variant(int v);
-void set_force_fp32_qkv(bool v);
-void set_h2_dbuf(bool v);
-int get_scattn_variant();
+
+// Per-handle tuning knobs (gmf_set_tuning).  Every value selects between forms that compute the same result up to
+// rounding; there is no process-global state and no environment variable behind any of them.
+struct Tuning {
+  int scattn_variant = 18;   // 18 = cached, software-pipelined split-fp16 attention; 9 = split-fp16 without the pipelining
+                             // (and without the cache when compat_cache = 0); 0 = fp32 MFMA path for every stage
+  bool use_cache = true;     // compat cache (built once per batch) for variants 9 / 18
+  int key_splits = 0;        // attention key splits on small grids: 0 = automatic, 1 = off, n = forced
+  int ff_split = 0;          // feed-forward hidden splits on small grids: 0 = automatic, 1 = off, 2 / 4 / 8 = forced
+  bool front_split = true;   // small grids: one workgroup per output (Q' + f | K | V) of k_front_h2
+  int conv_patch = 1;        // stride-1 3x3 convolutions: 1 = LDS patch kernel (automatic form), 2 = never three workgroups per CU, 0 = gather kernel
+  int nms_binned = 1;        // 1 = grid-binned NMS candidates on large grids, 2 = always, 0 = all pairs
+  bool topk_select = true;   // radix select of the S seeds (false = full bitonic sort)
+};
+
+hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s);
 hipError_t launch_front(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
                         float* v, int B, int N, int tiles, hipStream_t s);
-hipError_t launch_scattn(const float* q, const float* k, const float* v, const float* pts8, const float* fus,
-                         const float* wst, const float* vecs, float* out, int B, int N, int tiles, float sigma_d,
-                         hipStream_t s, const CompatCache* cc = nullptr);
+hipError_t launch_scattn_fp32(const float* q, const float* k, const float* v, const float* pts8, const float* fus,
+                              const float* wst, const float* vecs, float* out, int B, int N, int tiles, float sigma_d,
+                              hipStream_t s);
+hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, const float* v, const float* pts8,
+                            const float* fus, const float* wst, const float* vecs, float* out, int B, int N, int tiles,
+                            float sigma_d, hipStream_t s, const CompatCache* cc);
 hipError_t launch_scattn_dense(const float* q, const float* k, const float* v, const float* compat, const float* fus,
                                const float* wst, const float* vecs, float* out, int B, int N, int tiles, hipStream_t s);
 hipError_t launch_ctx_prep(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
@@ -37,7 +43,6 @@ hipError_t launch_ctx_prep(bool pe, const float* ctx, const float* wst, const fl
 hipError_t launch_fusion_attn(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
                               float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
 hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
-hipError_t launch_fusion_ff_b3(const float* x1, const float* wst_b3, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
 hipError_t launch_head(const float* feat_img, const float* wst, const float* vecs, float* logits, float* feat_n,
                        float* feat_rm, int B, int N, int tiles, hipStream_t s);
 hipError_t launch_ctx_prep_w(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
@@ -46,14 +51,14 @@ hipError_t launch_fusion_attn_w(bool pe, const float* x, const float* ctx_img, c
                                 float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
 hipError_t launch_fusion_ff_w(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
 hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
-hipError_t launch_front_h2(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
-                           float* v, int B, int N, int tiles, hipStream_t s, bool v_q16 = false);
+hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
+                           float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s);
 hipError_t launch_ctx_prep_h2(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
                               int ttiles, int sets, int wst_stride, int vec_stride, hipStream_t s);
 hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
                                  float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
-hipError_t launch_fusion_ff_h2(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s,
-                               float* part = nullptr, int max_parts = 0);
+hipError_t launch_fusion_ff_h2(const Tuning& tune, const float* x1, const float* wst, const float* vecs, float* x2, int B,
+                               int tiles, hipStream_t s, float* part = nullptr, int max_parts = 0);
 int padded_desc_width(int d);
 hipError_t launch_nn_match(const float* F0, const float* F1, float* f0_img, float* f1_img, float* norm2, int* idx,
                            float* dist, int N0, int N1, int d, int mode, hipStream_t s);
@@ -82,8 +87,7 @@ hipError_t launch_transformation_loss(const float* trans, const float* gt_trans,
 
 // image encoder epilogue (row f-1): image_kernels.hip
 hipError_t launch_bias_relu_nhwc(float* y, const float* bias, const float* residual, long n_pixels, int C, hipStream_t s);
-void set_conv_patch(int v);
-hipError_t launch_conv_nhwc_h2(const float* x, const float* wimg, const float* bias, const float* residual, float* y, int B,
+hipError_t launch_conv_nhwc_h2(const Tuning& tune, const float* x, const float* wimg, const float* bias, const float* residual, float* y, int B,
                                int H, int W, int cin, int cout, int ks, int stride, int relu, hipStream_t s);
 
 }  // namespace gmf

@@ -1,15 +1,14 @@
 // Internal C++ launch entry points of the pose-head kernels.  Public C ABI: include/gmf_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "launchers.hpp"
 
 namespace gmf {
 
-hipError_t launch_nms_keys(const float* src, const float* scores, float* keys, int B, int N, float R, hipStream_t s,
+hipError_t launch_nms_keys(const Tuning& tune, const float* src, const float* scores, float* keys, int B, int N, float R, hipStream_t s,
                            float* scratch = nullptr);     // scratch: nms_scratch_floats(B, N) floats, or null = all-pairs form
 size_t nms_scratch_floats(int B, int N);
-void set_nms_binned(int v);
-hipError_t launch_sort_topk(const float* keys, int* out_idx, int B, int N, int S, hipStream_t s);
-void set_topk_select(bool on);
+hipError_t launch_sort_topk(const Tuning& tune, const float* keys, int* out_idx, int B, int N, int S, hipStream_t s);
 hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* dist_in, int* knn_idx, int B, int N, int S,
                             int k, hipStream_t s);
 hipError_t launch_seed_power(const float* featn_img, const float* src, const float* tgt, const int* knn_idx, float* snaps,

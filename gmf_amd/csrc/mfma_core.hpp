@@ -43,67 +43,13 @@ GMF_DEVINL f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// ---- split-bf16 ("bf16x3") arithmetic -------------------------------------------------------------
-// An fp32 value is carried as three bf16 planes x = xh + xm + xl (exact to ~2^-25 relative); a product is
-// evaluated as the six partial products of weight >= 2^-16 (hh, hm, mh, hl, lh, mm) on the bf16 MFMA with
-// fp32 accumulation.  bf16 x bf16 products are exact in fp32, so the result carries the same ~1e-7 relative
-// error per term as an fp32 FMA chain, at 6/16 of the fp32-MFMA cycles - and, unlike v_mfma_f32_32x32x2_f32,
-// the bf16 MFMA co-executes with VALU work on gfx950.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-GMF_DEVINL f32x16 mfma_b16(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-// v[0..7] -> planes (round-to-nearest-even conversions; v_cvt_pk_bf16_f32 + shifts + v_pk_add_f32)
-GMF_DEVINL void split8(const float* v, bf16x8& hi, bf16x8& mi, bf16x8& lo) {
-#pragma unroll
-  for (int j = 0; j < 8; j += 2) {
-    const f32x2 x = {v[j], v[j + 1]};
-    const bf16x2 hh = __builtin_convertvector(x, bf16x2);
-    const f32x2 r1 = x - __builtin_convertvector(hh, f32x2);
-    const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
-    const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
-    const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
-    hi[j] = hh[0]; hi[j + 1] = hh[1];
-    mi[j] = mm[0]; mi[j + 1] = mm[1];
-    lo[j] = ll[0]; lo[j + 1] = ll[1];
-  }
-}
-
-// acc += A * B with A = (ah, am, al), B = (bh, bm, bl); small terms first
-GMF_DEVINL void mma6(f32x16& acc, bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl) {
-  acc = mfma_b16(al, bh, acc);
-  acc = mfma_b16(ah, bl, acc);
-  acc = mfma_b16(am, bm, acc);
-  acc = mfma_b16(am, bh, acc);
-  acc = mfma_b16(ah, bm, acc);
-  acc = mfma_b16(ah, bh, acc);
-}
-
-// a K-wide row fragment (K/2 floats) -> K/16 k-steps of three planes
-template <int KF>
-GMF_DEVINL void split_frag(const float (&x)[KF], bf16x8 (&hi)[KF / 8], bf16x8 (&mi)[KF / 8], bf16x8 (&lo)[KF / 8]) {
-#pragma unroll
-  for (int s = 0; s < KF / 8; ++s) split8(&x[8 * s], hi[s], mi[s], lo[s]);
-}
-
-// acc += Wb3(32 x K) * X^T with the weight block as a bf16x3 image in LDS: 16-byte unit ((plane*NS + s)*64 + lane)
-template <int NS>
-GMF_DEVINL void mma_wx_b3(f32x16& acc, const bf16x8* lw, const bf16x8 (&xh)[NS], const bf16x8 (&xm)[NS], const bf16x8 (&xl)[NS]) {
-#pragma unroll
-  for (int s = 0; s < NS; ++s)
-    mma6(acc, lw[(0 * NS + s) * 64], lw[(1 * NS + s) * 64], lw[(2 * NS + s) * 64], xh[s], xm[s], xl[s]);
-}
-
 // ---- split-fp16 ("fp16x2") arithmetic ------------------------------------------------------------
 // x = xh + xl with two fp16 planes (11 + 11 significant bits, round-to-nearest-even: |x - xh - xl| <= 2^-22 |x|)
 // and three partial products hh, hl, lh (the dropped l*l term is <= 2^-22 |ab|).  Per-term error ~2.4e-7 worst
 // case - below the fp32 accumulation noise of a 128-term dot product - at 3/16 of the fp32-MFMA cycles, with
 // operand images the size of the fp32 ones (4 B per element).  Ranges: |x| < 65504; low parts that fall into the
 // fp16 subnormal range keep an absolute error <= 3e-8.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
@@ -158,8 +104,6 @@ GMF_DEVINL void mma3(f32x16& acc, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
   acc = mfma_h16(ah, bl, acc);
   acc = mfma_h16(ah, bh, acc);
 }
-
-constexpr int kB3TileFloats = 3 * 8 * 64 * 4;   // one 32 x 128 tile as three bf16 planes = 24 KiB
 
 GMF_DEVINL f32x16 zero16() {
   f32x16 z;
@@ -305,7 +249,7 @@ GMF_DEVINL void dma_issue(const float* __restrict__ gsrc, float* lds_dst, int n_
 struct StageStream {
   const float* seg_ptr[3];
   int seg_end[3];   // cumulative stage counts
-  int stage_floats = kStageFloats;   // 4096 (16 KiB fp32 image) or kB3TileFloats (24 KiB bf16x3 image)
+  int stage_floats = kStageFloats;   // 16 KiB unless the user sets another stage size (match_kernels.hip)
   float* buf0;
   float* buf1;
   int issued;       // stages issued so far

@@ -1368,11 +1368,10 @@ k_global_registration(const float* __restrict__ X, const float* __restrict__ Y, 
 // =========================================================================================
 static inline int next_pow2(int n) { int m = 1; while (m < n) m <<= 1; return m; }
 
-static int g_nms_binned = 1;        // 1 = grid-binned candidates for N >= 1024 on grids of >= 128 workgroups (default), 2 = whenever N >= 1024, 0 = all pairs
-void set_nms_binned(int v) { g_nms_binned = v; }
 size_t nms_scratch_floats(int B, int N) { return (size_t)B * ((size_t)4 * N + kNmsHdr); }
 
-hipError_t launch_nms_keys(const float* src, const float* scores, float* keys, int B, int N, float R, hipStream_t s,
+// tune.nms_binned: 1 = grid-binned candidates for N >= 1024 on grids of >= 128 workgroups (default), 2 = whenever N >= 1024, 0 = all pairs
+hipError_t launch_nms_keys(const Tuning& tune, const float* src, const float* scores, float* keys, int B, int N, float R, hipStream_t s,
                            float* scratch) {
   // The reference tests sqrt(d2) >= R (PointDSC.py:283).  sqrtf is monotone, so that is d2 >= t for the smallest float t
   // with sqrtf(t) >= R; finding t on the host removes the square root from the N^2 loop without changing one decision.
@@ -1385,7 +1384,7 @@ hipError_t launch_nms_keys(const float* src, const float* scores, float* keys, i
   }
   const int nblk = (N + 255) / 256;
   // (on small grids - B = 1 - the two binned launches cost more latency than the candidate-split all-pairs kernel saves)
-  if (scratch && g_nms_binned && N >= 1024 && (nblk * B >= 128 || g_nms_binned == 2) && R > 0.f && std::isfinite(R)) {
+  if (scratch && tune.nms_binned && N >= 1024 && (nblk * B >= 128 || tune.nms_binned == 2) && R > 0.f && std::isfinite(R)) {
     const float inv_cell = 1.0f / (1.01f * R);
     hipLaunchKernelGGL(k_nms_bin, dim3(B), dim3(1024), 0, s, src, scores, scratch, N, inv_cell);
     hipLaunchKernelGGL(k_nms_keys_binned, dim3(nblk, B), dim3(256), 0, s, src, scores, scratch, keys, N, t, inv_cell);
@@ -1401,30 +1400,24 @@ hipError_t launch_nms_keys(const float* src, const float* scores, float* keys, i
   return hipGetLastError();
 }
 
-static int g_topk_select = 1;      // 1 = radix select + rank placement (default), 0 = full bitonic sort
-void set_topk_select(bool on) { g_topk_select = on ? 1 : 0; }
-
-hipError_t launch_sort_topk(const float* keys, int* out_idx, int B, int N, int S, hipStream_t s) {
+// tune.topk_select: radix select + rank placement (default) or the full bitonic sort
+hipError_t launch_sort_topk(const Tuning& tune, const float* keys, int* out_idx, int B, int N, int S, hipStream_t s) {
   const int M = next_pow2(N < 2 ? 2 : N);
   if (M > 16384) return hipErrorInvalidValue;
   constexpr size_t kSelectLds = 156 * 1024;        // dynamic LDS the select kernel may use (160 KiB minus its static arrays)
   const size_t need = (size_t)N * 4 + 8 + (size_t)S * 8;
-  if (g_topk_select && S >= 1 && S <= N && need <= kSelectLds) {
-    static bool attr2_set = false;
-    if (!attr2_set) {
+  if (tune.topk_select && S >= 1 && S <= N && need <= kSelectLds) {
+    {   // per device and cheap: no process-wide "already set" flag
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_topk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)kSelectLds);
       if (e != hipSuccess) return e;
-      attr2_set = true;
     }
     hipLaunchKernelGGL(k_select_topk, dim3(B), dim3(1024), need, s, keys, out_idx, N, S);
     return hipGetLastError();
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(k_sort_topk, dim3(B), dim3(1024), (size_t)M * 8, s, keys, out_idx, N, M, S);
   return hipGetLastError();
@@ -1433,11 +1426,9 @@ hipError_t launch_sort_topk(const float* keys, int* out_idx, int B, int N, int S
 hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* dist_in, int* knn_idx, int B, int N, int S,
                             int k, hipStream_t s) {
   if ((size_t)N * 4 > 150 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
+  {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_seeds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   if (dist_in && N <= 256 * 32) {
     hipLaunchKernelGGL(k_knn_select_fast<32>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k);

@@ -1,14 +1,19 @@
 """Data-parallel driver: scene pairs shard across the GPUs of one node, one process per GPU.
 
-Pairs are independent in eval mode, so the data path has exactly one exchange step:
-an all-gather of the per-pair inlier logits [B/G, N] and poses [B/G, 4, 4] (RCCL over xGMI through
-``torch.distributed`` backend "nccl"; "gloo" on CPU for the tests).  The reference has no counterpart - it
-is single-process, single-GPU (train_3DMatch.py:17).
+Pairs are independent in eval mode, so the data path has exactly ONE exchange step per
+batch: an all-gather of one packed buffer per rank - row p = [logits of pair p (N floats) | final_trans of pair p
+(16 floats)] - over RCCL/xGMI through ``torch.distributed`` backend "nccl" ("gloo" on CPU for the tests).  The
+reference has no counterpart - it is single-process, single-GPU (train_3DMatch.py:17).
+
+Uneven shards (B % world != 0) are padded to the largest shard inside the packed buffer and trimmed after the
+gather, so the collective always sees equal sizes; the shard sizes come from `shard_range` (pure arithmetic, the
+same on every rank - no size exchange).
 """
 from __future__ import annotations
 
 import os
-from typing import Callable, Dict, Tuple
+import time
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -21,6 +26,10 @@ def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_sizes(total: int, world: int) -> List[int]:
+    return [b - a for a, b in (shard_range(total, world, r) for r in range(world))]
+
+
 def shard_batch(data: Dict[str, torch.Tensor], world: int, rank: int) -> Dict[str, torch.Tensor]:
     """Slice every [B, ...] tensor of a global batch down to this rank's pairs (non-tensors pass through)."""
     B = next(v.shape[0] for v in data.values() if torch.is_tensor(v))
@@ -29,16 +38,27 @@ def shard_batch(data: Dict[str, torch.Tensor], world: int, rank: int) -> Dict[st
 
 
 class ShardedBatchDriver:
-    """Runs `model` on the local shard and all-gathers logits and poses.
+    """Runs `model` on the local shard and all-gathers logits and poses with ONE collective.
 
     model(data) must return a dict with "final_trans" [b,4,4] and expose the logits [b,N] either as
     `model.last_logits` or as result["logits"].
+
+    `step(local_data)` assumes every rank holds the same number of pairs (the weak-scaling benchmark) unless
+    `sizes` (pairs per rank, e.g. `shard_sizes(B, world)`) is given; `run(global_data)` shards a global batch and
+    passes the sizes itself.  With `always_collective=True` the exchange also runs at world size 1 when a process
+    group exists (a one-rank RCCL all-gather: the same code path the multi-GPU runs take).
     """
 
-    def __init__(self, model: Callable, world: int, rank: int, device: torch.device, backend: str = None):
+    def __init__(self, model: Callable, world: int, rank: int, device: torch.device, backend: str = None,
+                 always_collective: bool = False):
         self.model, self.world, self.rank, self.device = model, world, rank, device
         self.own_pg = False
-        if world > 1:
+        self.always_collective = always_collective
+        self.last_model_ms: Optional[float] = None      # device time of the local forward (cuda) / wall time (cpu)
+        self.last_gather_ms: Optional[float] = None     # ... of pack + all-gather + unpack
+        self.time_steps = False                         # record the two figures above (adds event records, no host sync)
+        self._events = None
+        if world > 1 or always_collective:
             if not dist.is_initialized():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29500")
@@ -47,23 +67,72 @@ class ShardedBatchDriver:
                 dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
                 self.own_pg = True
 
-    def step(self, data) -> Dict[str, torch.Tensor]:
+    # -- timing helpers (no host synchronisation inside step) -------------------------------------------------
+    def _mark(self, i: int):
+        if not self.time_steps:
+            return
+        if self.device.type == "cuda":
+            if self._events is None:
+                self._events = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            self._events[i].record(torch.cuda.current_stream(self.device))
+        else:
+            if self._events is None:
+                self._events = [0.0, 0.0, 0.0]
+            self._events[i] = time.perf_counter()
+
+    def read_timings(self) -> Tuple[Optional[float], Optional[float]]:
+        """(model ms, gather ms) of the last step; synchronises the device - call outside timed regions."""
+        if not self.time_steps or self._events is None:
+            return None, None
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+            e = self._events
+            return e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
+        e = self._events
+        return (e[1] - e[0]) * 1e3, (e[2] - e[1]) * 1e3
+
+    # -- the step ---------------------------------------------------------------------------------------------
+    def _collective(self) -> bool:
+        return (self.world > 1 or self.always_collective) and dist.is_initialized()
+
+    def step(self, data, sizes: Optional[List[int]] = None) -> Dict[str, torch.Tensor]:
+        self._mark(0)
         res = self.model(data)
         logits = res["logits"] if "logits" in res else self.model.last_logits
-        out = {"logits": logits, "final_trans": res["final_trans"], "final_labels": res.get("final_labels")}
-        if self.world > 1:
+        trans = res["final_trans"]
+        out = {"logits": logits, "final_trans": trans, "final_labels": res.get("final_labels")}
+        self._mark(1)
+        if self._collective():
             b, n = logits.shape
-            all_logits = torch.empty((self.world * b, n), device=logits.device, dtype=logits.dtype)
-            all_trans = torch.empty((self.world * b, 4, 4), device=logits.device, dtype=logits.dtype)
-            dist.all_gather_into_tensor(all_logits, logits.contiguous())
-            dist.all_gather_into_tensor(all_trans, res["final_trans"].contiguous())
-            out["all_logits"], out["all_trans"] = all_logits, all_trans
+            if sizes is None:
+                sizes = [b] * self.world
+            if len(sizes) != self.world or sizes[self.rank] != b:
+                raise RuntimeError(f"gmf_amd.dist: rank {self.rank} holds {b} pairs but the shard plan says {sizes}: every "
+                                   "rank must pass the same `sizes` (shard_sizes(B, world)), or equal shards without it")
+            bmax = max(sizes)
+            # one packed buffer per rank: [bmax, N + 16] = logits | pose, rows >= b are padding
+            buf = torch.zeros((bmax, n + 16), device=logits.device, dtype=logits.dtype) if bmax != b else \
+                torch.empty((bmax, n + 16), device=logits.device, dtype=logits.dtype)
+            buf[:b, :n] = logits
+            buf[:b, n:] = trans.reshape(b, 16)
+            gathered = torch.empty((self.world * bmax, n + 16), device=logits.device, dtype=logits.dtype)
+            dist.all_gather_into_tensor(gathered, buf)           # the ONE exchange step of the batch
+            if min(sizes) != bmax:
+                gathered = torch.cat([gathered[r * bmax:r * bmax + sizes[r]] for r in range(self.world)])
+            out["all_logits"] = gathered[:, :n]
+            out["all_trans"] = gathered[:, n:].reshape(-1, 4, 4)
         else:
-            out["all_logits"], out["all_trans"] = logits, res["final_trans"]
+            out["all_logits"], out["all_trans"] = logits, trans
+        self._mark(2)
         return out
 
+    def run(self, global_data) -> Dict[str, torch.Tensor]:
+        """Shard a global batch [B, ...] over the ranks (uneven allowed), run, gather."""
+        B = next(v.shape[0] for v in global_data.values() if torch.is_tensor(v))
+        return self.step(shard_batch(global_data, self.world, self.rank), sizes=shard_sizes(B, self.world))
+
     def barrier(self):
-        if self.world > 1:
+        if self.world > 1 and dist.is_initialized():
             dist.barrier()
 
     def max_over_ranks(self, seconds: float) -> float:
@@ -72,6 +141,15 @@ class ShardedBatchDriver:
         t = torch.tensor([seconds], dtype=torch.float64, device=self.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather_floats(self, value: float) -> List[float]:
+        """One float from every rank (diagnostics: per-rank step times)."""
+        if self.world == 1:
+            return [value]
+        t = torch.tensor([value], dtype=torch.float64, device=self.device)
+        allv = torch.empty(self.world, dtype=torch.float64, device=self.device)
+        dist.all_gather_into_tensor(allv, t)
+        return [float(v) for v in allv.cpu()]
 
     def close(self):
         if self.own_pg and dist.is_initialized():

@@ -81,7 +81,12 @@ class FusionLayer(nn.Module):
         if self._packed is None or self._packed_version != ver:
             sd = {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()}
             packed = packing.pack_fusion(sd, "", self.pe)
-            packed["ff_wst_h2"] = packing.pack_fusion(sd, "", self.pe, img=packing.p32_h2s)["ff_wst"]
+            try:
+                packed["ff_wst_h2"] = packing.pack_fusion(sd, "", self.pe, img=packing.p32_h2s)["ff_wst"]
+            except ValueError as e:          # a weight outside the fp16 range: feed-forward on the fp32 MFMA, said once per pack
+                import warnings
+                warnings.warn(f"{e}  The feed-forward of this FusionLayer runs on the fp32 MFMA.", RuntimeWarning)
+                packed["ff_wst_h2"] = None
             self._packed = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in packed.items()}
             self._packed_version = ver
         return self._packed
@@ -106,5 +111,5 @@ class FusionLayer(nn.Module):
                blobs["attn_vec"].data_ptr(), blobs["ff_wst"].data_ptr(), blobs["ff_vec"].data_ptr(),
                data.data_ptr(), x.data_ptr(), x.stride(0), x.stride(1), x.stride(2),
                out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), B, N, T, st,
-               blobs["ff_wst_h2"].data_ptr() if self.split_fp16_ff else None)
+               blobs["ff_wst_h2"].data_ptr() if (self.split_fp16_ff and blobs["ff_wst_h2"] is not None) else None)
         return out

@@ -43,7 +43,7 @@ def p32(W: torch.Tensor) -> torch.Tensor:
     return W.reshape(M // 32, 32, K // 8, 2, 4).permute(0, 2, 3, 1, 4).reshape(-1)
 
 
-def _b3_index(K: int, device):
+def _frag_index(K: int, device):
     """Feature index visited by (k-step s, K-half h, element j) of a K-wide fragment: f = 8s + j is the fragment
     index, feature = 32*(f >> 4) + 8*((f & 15) >> 2) + 4h + (f & 3)   (gmf_amd/csrc/mfma_core.hpp)."""
     s_ = torch.arange(K // 16, device=device)[:, None, None]
@@ -53,22 +53,23 @@ def _b3_index(K: int, device):
     return 32 * (f >> 4) + 8 * ((f & 15) >> 2) + 4 * h_ + (f & 3)          # [K/16, 2, 8]
 
 
-def p32_b3(W: torch.Tensor) -> torch.Tensor:
-    """[M, K] fp32 (M % 32 == 0, K % 16 == 0) -> flat split-bf16 image, returned as float32 words.
+FP16_MAX = 65504.0
 
-    Per 32-output block: [plane hi|mid|lo][k-step][lane = (h, i)][8 bf16]; W = hi + mid + lo with round-to-nearest-even
-    conversions (torch's .to(bfloat16) = v_cvt_pk_bf16_f32)."""
-    M, K = W.shape
-    assert M % 32 == 0 and K % 16 == 0, (M, K)
-    hi = W.to(torch.bfloat16)
-    r1 = W - hi.float()
-    mi = r1.to(torch.bfloat16)
-    lo = (r1 - mi.float()).to(torch.bfloat16)
-    idx = _b3_index(K, W.device)                                            # [S, 2, 8]
-    planes = torch.stack([hi, mi, lo])                                      # [3, M, K]
-    g = planes[:, :, idx]                                                   # [3, M, S, 2, 8]
-    g = g.reshape(3, M // 32, 32, K // 16, 2, 8).permute(1, 0, 3, 4, 2, 5)  # [mb, plane, S, h, i, 8]
-    return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
+
+def split_fp16(W: torch.Tensor, what: str):
+    """W -> (hi, lo) fp16 planes with W ~ hi + lo.  Raises when a value does not fit the fp16 range: the planes of a
+    weight with |w| > 65504 (|w| > 255.8 for the images stored as 256 w) would be inf / nan and so would every logit.
+    The reference is plain fp32 and has no such limit; a BatchNorm with a tiny running_var can fold to weights this large
+    (INTEGRATION.md, "Supported value range")."""
+    amax = float(W.abs().max()) if W.numel() else 0.0
+    if not (amax <= FP16_MAX):          # also catches nan / inf
+        raise ValueError(
+            f"gmf_amd.packing: {what} has max |value| = {amax:.6g} after folding/scaling, outside the fp16 range "
+            f"(65504; 255.8 for weights stored as 256 w) of the split-fp16 MFMA operands.  Rescale the checkpoint "
+            f"(e.g. BatchNorm running_var), or select the fp32-MFMA path with gmf_set_tuning('scattn_variant', 0).")
+    hi = W.to(torch.float16)
+    lo = (W - hi.float()).to(torch.float16)
+    return hi, lo
 
 
 def p32_h2(W: torch.Tensor) -> torch.Tensor:
@@ -77,9 +78,8 @@ def p32_h2(W: torch.Tensor) -> torch.Tensor:
     Per 32-output block: [plane hi|lo][k-step][lane = (h, i)][8 fp16]; W ~ hi + lo, both round-to-nearest-even."""
     M, K = W.shape
     assert M % 32 == 0 and K % 16 == 0, (M, K)
-    hi = W.to(torch.float16)
-    lo = (W - hi.float()).to(torch.float16)
-    idx = _b3_index(K, W.device)
+    hi, lo = split_fp16(W, "dense weight")
+    idx = _frag_index(K, W.device)
     g = torch.stack([hi, lo])[:, :, idx]                                    # [2, M, S, 2, 8]
     g = g.reshape(2, M // 32, 32, K // 16, 2, 8).permute(1, 0, 3, 4, 2, 5)  # [mb, plane, S, h, i, 8]
     return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
@@ -92,32 +92,6 @@ def p32_h2s(W: torch.Tensor) -> torch.Tensor:
     """p32_h2 of 256 W: the lo plane fp16(256 w - hi) stays a normal fp16 number for |w| >= 2^-11 instead of a subnormal
     (spacing 2^-24: an unscaled weight of 0.006 kept 16 significant bits).  The kernels fold 2^-8 into their bias add."""
     return p32_h2(W * H2_SCALE)
-
-
-def p16_h2s(W: torch.Tensor) -> torch.Tensor:
-    """p16_h2 of 256 W (see p32_h2s)."""
-    return p16_h2(W * H2_SCALE)
-
-
-def p16_h2(W: torch.Tensor) -> torch.Tensor:
-    """[M, K] fp32 (M % 16 == 0, K % 32 == 0) -> flat split-fp16 image for v_mfma_f32_16x16x32_f16 A-operands.
-
-    16-byte unit ((mb*S + s)*2 + plane)*64 + lane, lane = 16 g + c: the 8 halfs are W[16 mb + c][32 s + perm(g, e)],
-    perm(g, e) = 16 (e >> 2) + 4 g + (e & 3) - the contraction order in which a lane of the q16 attention kernel holds a
-    pair of 16x16 accumulator blocks (features 4g..4g+3 of blocks 2s and 2s+1), so accumulators chain into the next
-    layer's B operand with no data movement (gmf_amd/csrc/encoder_kernels.hip, k_scattn_h2q)."""
-    M, K = W.shape
-    assert M % 16 == 0 and K % 32 == 0, (M, K)
-    dev = W.device
-    s_ = torch.arange(K // 32, device=dev)[:, None, None]
-    g_ = torch.arange(4, device=dev)[None, :, None]
-    e_ = torch.arange(8, device=dev)[None, None, :]
-    idx = 32 * s_ + 16 * (e_ >> 2) + 4 * g_ + (e_ & 3)                       # [S, 4, 8]
-    hi = W.to(torch.float16)
-    lo = (W - hi.float()).to(torch.float16)
-    gth = torch.stack([hi, lo])[:, :, idx]                                    # [2, M, S, 4, 8]
-    gth = gth.reshape(2, M // 16, 16, K // 32, 4, 8).permute(1, 3, 0, 4, 2, 5)   # [mb, S, plane, g, c, 8]
-    return gth.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
 
 
 def conv_image(W: torch.Tensor, stride: int = 1) -> torch.Tensor:
@@ -134,25 +108,11 @@ def conv_image(W: torch.Tensor, stride: int = 1) -> torch.Tensor:
         Wk = Wt.reshape(co, 9, ci // 16, 16).permute(0, 2, 1, 3).reshape(co, 9 * ci)      # (channel block, tap, c)
     else:
         Wk = Wt.reshape(co, kh * kw * ci)                                   # (tap, cin)
-    hi = Wk.to(torch.float16)
-    lo = (Wk - hi.float()).to(torch.float16)
+    hi, lo = split_fp16(Wk, "BatchNorm-folded convolution weight (x 256)")
     nk = Wk.shape[1] // 16
     g = torch.stack([hi, lo]).reshape(2, co // 64, 2, 32, nk, 2, 8)         # [plane, half, blk, i, ks, h, e]
     g = g.permute(1, 4, 2, 0, 5, 3, 6)                                      # [half, ks, blk, plane, h, i, e]
     return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
-
-
-def pack_ff_b3(sd, prefix: str) -> torch.Tensor:
-    """GEGLU feed-forward weights of one FusionLayer (128-wide) as 48 bf16x3 stages of 24 KiB."""
-    f = prefix + "cross_attend_blocks.1."
-    W1, W2 = _f(sd[f + "fn.net.0.weight"]), _f(sd[f + "fn.net.2.weight"])
-    hid = W2.shape[1]
-    chunks = []
-    for c in range(hid // 32):
-        chunks += [p32_b3(W1[32 * c:32 * c + 32]), p32_b3(W1[hid + 32 * c:hid + 32 * c + 32]), p32_b3(W2[:, 32 * c:32 * c + 32])]
-    out = torch.cat(chunks)
-    assert out.numel() == 48 * 6144
-    return out.contiguous()
 
 
 def fold_bn(W, b, sd, p, eps=1e-5):
@@ -302,22 +262,28 @@ class PackedEncoder:
         if f1 is not None:
             for k, v in f1.items():
                 self.t["f1_" + k] = v
-            self.t["f1_ff_wst_b3"] = pack_ff_b3(sd, "encoder.fusion_layer_1.")
-            f1h = pack_fusion(sd, "encoder.fusion_layer_1.", pe=False, img=p32_h2s)
-            for k in ("ctx_wst", "attn_wst", "ff_wst"):
-                self.t["f1_" + k + "_h2"] = f1h[k]
-        if num_layers > 0:
-            f2h = [pack_fusion(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.", pe=True, img=p32_h2s) for i in range(num_layers)]
-            for k in ("ctx_wst", "attn_wst", "ff_wst"):
-                self.t[k + "_h2"] = torch.stack([f[k] for f in f2h]).contiguous()
-            self.t["front_wst_h2"] = torch.stack([pack_front(sd, i, with_layer0=(i == 0 and "encoder.layer0.weight" in sd),
+        # split-fp16 images of every dense weight.  A weight outside the fp16 range (|256 w| > 65504) cannot be split; the
+        # encoder then runs every stage on the fp32 MFMA (still the HIP path - slower, same results) and says so once.
+        self.split_fp16 = True
+        try:
+            h2 = {}
+            if f1 is not None:
+                f1h = pack_fusion(sd, "encoder.fusion_layer_1.", pe=False, img=p32_h2s)
+                for k in ("ctx_wst", "attn_wst", "ff_wst"):
+                    h2["f1_" + k + "_h2"] = f1h[k]
+            if num_layers > 0:
+                f2h = [pack_fusion(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.", pe=True, img=p32_h2s) for i in range(num_layers)]
+                for k in ("ctx_wst", "attn_wst", "ff_wst"):
+                    h2[k + "_h2"] = torch.stack([f[k] for f in f2h]).contiguous()
+                h2["front_wst_h2"] = torch.stack([pack_front(sd, i, with_layer0=(i == 0 and "encoder.layer0.weight" in sd),
                                                              identity_pointcn=standalone_block, img=p32_h2s)[0]
                                                   for i in range(num_layers)]).contiguous()
-            self.t["tail_wst_h2"] = torch.stack([pack_tail(sd, i, img=p32_h2s)[0] for i in range(num_layers)]).contiguous()
-            self.t["tail_wst_q16"] = torch.stack([pack_tail(sd, i, img=p16_h2s)[0] for i in range(num_layers)]).contiguous()
-        if num_layers > 0:
-            self.t["ff_wst_b3"] = torch.stack([pack_ff_b3(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.")
-                                               for i in range(num_layers)]).contiguous()
+                h2["tail_wst_h2"] = torch.stack([pack_tail(sd, i, img=p32_h2s)[0] for i in range(num_layers)]).contiguous()
+            self.t.update(h2)
+        except ValueError as e:
+            import warnings
+            warnings.warn(f"{e}  Falling back to the fp32-MFMA kernels for the whole encoder (about 3x slower).", RuntimeWarning)
+            self.split_fp16 = False
         if "classification.0.weight" in sd:
             self.t["head_wst"], self.t["head_vec"] = pack_head(sd)
         self.t = {k: v.to(device) for k, v in self.t.items() if torch.is_tensor(v)}
@@ -335,10 +301,7 @@ class PackedEncoder:
         w.front_wst_stride, w.front_vec_stride = FRONT_WST, FRONT_VEC
         w.tail_wst_stride, w.tail_vec_stride = TAIL_WST, TAIL_VEC
         w.sigma_d = self.sigma_d
-        w.ff_wst_b3 = self.t["ff_wst_b3"].data_ptr() if "ff_wst_b3" in self.t else None
-        w.ff_wst_b3_stride = 48 * 6144
-        w.f1_ff_wst_b3 = self.t["f1_ff_wst_b3"].data_ptr() if "f1_ff_wst_b3" in self.t else None
         for name in ("front_wst_h2", "ctx_wst_h2", "attn_wst_h2", "ff_wst_h2", "f1_ctx_wst_h2", "f1_attn_wst_h2", "f1_ff_wst_h2",
-                     "tail_wst_h2", "tail_wst_q16"):
+                     "tail_wst_h2"):
             setattr(w, name, self.t[name].data_ptr() if name in self.t else None)
         self.struct = w

@@ -73,7 +73,11 @@ class _FusedResNet:
             spec = {"w": w.contiguous(memory_format=cl), "b": b, "stride": conv.stride[0], "pad": conv.padding[0],
                     "cin": w.shape[1], "cout": w.shape[0], "ks": w.shape[2]}
             if native_convs and w.shape[1] % 16 == 0:
-                spec["img"] = packing.conv_image(w.cpu(), conv.stride[0]).to(w.device)
+                try:
+                    spec["img"] = packing.conv_image(w.cpu(), conv.stride[0]).to(w.device)
+                except ValueError as e:      # folded weight outside the fp16 range: this convolution stays on MIOpen (fp32)
+                    import warnings
+                    warnings.warn(f"{e}  This convolution runs on MIOpen's fp32 kernel instead.", RuntimeWarning)
             return spec
 
         self.stem = fold(bb.conv1, bb.bn1)
@@ -84,7 +88,20 @@ class _FusedResNet:
                 self.blocks.append((fold(blk.conv1, blk.bn1), fold(blk.conv2, blk.bn2), ds))
 
     @staticmethod
-    def _bias_relu(y, bias, residual=None):
+    def _nhwc(t, what):
+        """The HIP kernels read raw pointers as dense NHWC: anything else (an NCHW result because MIOpen's channels-last
+        path is off in this torch build, a strided view) is converted here instead of being misread."""
+        if not t.is_contiguous(memory_format=torch.channels_last):
+            t = t.contiguous(memory_format=torch.channels_last)
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"gmf_amd image encoder: {what} must be float32, got {t.dtype}")
+        return t
+
+    @classmethod
+    def _bias_relu(cls, y, bias, residual=None):
+        y = cls._nhwc(y, "convolution output")
+        if residual is not None:
+            residual = cls._nhwc(residual, "residual")
         B, C, H, W = y.shape
         h, st = handle_and_stream(y)
         h.call("gmf_bias_relu_nhwc", y.data_ptr(), bias.data_ptr(), None if residual is None else residual.data_ptr(),
@@ -99,6 +116,9 @@ class _FusedResNet:
         # the native kernel maps 128 output pixels to a workgroup: below ~128 workgroups (a few images) MIOpen's kernels,
         # which also split the output channels, fill the chip better
         if "img" in c and B * Ho * Wo >= self.min_native_pixels:
+            x = self._nhwc(x, "convolution input")
+            if residual is not None:
+                residual = self._nhwc(residual, "residual")
             y = torch.empty((B, c["cout"], Ho, Wo), device=x.device, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
             h, st = handle_and_stream(x)
             h.call("gmf_conv_nhwc", x.data_ptr(), c["img"].data_ptr(), c["b"].data_ptr(),
@@ -236,18 +256,27 @@ class NonLocalNet(nn.Module):
         cache = self.__dict__.setdefault("_img_graphs", {})
         ent = cache.get(key)
         if ent is None:
-            try:
-                static_in = image.detach().clone()
-                with torch.no_grad():
-                    for _ in range(2):                   # MIOpen picks its algorithms and workspaces outside the capture
-                        enc(static_in)
-                    torch.cuda.synchronize()
-                    g = torch.cuda.CUDAGraph()
+            static_in = image.detach().clone()
+            with torch.no_grad():
+                for _ in range(2):                       # MIOpen picks its algorithms and workspaces outside the capture
+                    enc(static_in)                       # (a kernel or shape error surfaces here, eagerly, as itself)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                try:
                     with torch.cuda.graph(g):
                         static_out = enc(static_in)
-                ent = (g, static_in, static_out)
-            except Exception:                            # capture unsupported for this shape / stack: stay eager
-                ent = False
+                    ent = (g, static_in, static_out)
+                except RuntimeError as e:
+                    # Only "this operation cannot be captured" (hipErrorStreamCapture*: a library call inside the pass that
+                    # allocates or synchronises) keeps the pass eager - said once per shape; anything else is a real error.
+                    msg = str(e)
+                    if "capture" not in msg.lower():
+                        raise
+                    import warnings
+                    warnings.warn(f"gmf_amd: HIP-graph capture of the image encoder failed for input {tuple(image.shape)} "
+                                  f"({msg.splitlines()[0]}); running it eagerly.", RuntimeWarning)
+                    torch.cuda.synchronize()
+                    ent = False
             if len(cache) > 8:
                 cache.clear()
             cache[key] = ent

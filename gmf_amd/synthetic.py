@@ -228,3 +228,9 @@ def dgr_scene(N: int, seed: int, inlier_ratio: float = 0.3, noise: float = 0.01,
     w = (1.0 / (1.0 + np.exp(-logit.astype(np.float64)))).astype(np.float32)
     w[w < clip] = 0
     return torch.from_numpy(X), torch.from_numpy(Y), torch.from_numpy(w)[:, None], Q.astype(np.float32), t.astype(np.float32)
+
+
+def seeded_images(n_images: int, H: int, W: int) -> torch.Tensor:
+    """[n,3,H,W] uniform [0,1) images, the inputs of golden F15 (oracle/gen_fixtures.py gen_f15 draws the same stream)."""
+    r = np.random.default_rng([115, n_images, H, W])
+    return torch.from_numpy(r.uniform(0, 1, (n_images, 3, H, W)).astype(np.float32))

@@ -38,7 +38,7 @@ enum {
   GMF_ERR_OOM = -5
 };
 
-#define GMF_ABI_VERSION 1
+#define GMF_ABI_VERSION 2
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 int gmf_abi_version(void);
@@ -49,14 +49,23 @@ const char* gmf_last_error_string(gmf_handle* h);
 /* Bytes of library-owned device workspace currently held by the handle. */
 long long gmf_workspace_bytes(gmf_handle* h);
 
-/* Process-wide tuning knobs for A/B measurements (results are identical up to rounding):
- *   "scattn_variant": 0 = fp32-MFMA attention, two-phase loop; 1 = fp32 MFMA, software-pipelined; 2 = 1 with the
- *                     rational form of the compatibility term; 3 = split-bf16 MFMA (3 planes, 6 products);
- *                     4 = 3 with the rational form; 5..8 = structural variants of 3/4 (pipelined, 8-wave);
- *                     9 = split-fp16 MFMA (2 planes, 3 products; default); 10 = 9 with the rational form;
- *                     11..15 = timing-only ablations (wrong results).
- *   With variants 3..8 gmf_front_forward writes Q', K, V as bf16x3 plane images of 24 KiB per 32-row tile (the
- *   q, k, v buffers must hold 1.5x the fp32 image size); with 9/10 as fp16x2 plane images of 16 KiB per tile. */
+/* Per-handle tuning knobs (state lives in the handle; no process globals, no environment variables).  Every setting
+ * computes the same result up to rounding - there is no timing-only or wrong-result mode in the library; unknown names
+ * and out-of-range values are rejected with GMF_ERR_BAD_ARG.
+ *   "scattn_variant"    : 18 = split-fp16 MFMA attention (2 planes, 3 products), compat matrix streamed from the per-batch
+ *                         cache, tile loop software-pipelined inside each wave (default); 9 = the same arithmetic without
+ *                         the pipelining; 0 = every encoder stage on the fp32 MFMA with fp32 images.
+ *   "compat_cache"      : 1 = build the compat matrix once per batch (default), 0 = recompute c_ij in the attention kernel
+ *                         (what the library does by itself when the cache would exceed 96 GB); 0 implies the
+ *                         non-pipelined kernel.
+ *   "attn_key_splits"   : 0 = automatic (small grids only), 1 = off, 2..8 = forced number of key splits.
+ *   "ff_hidden_splits"  : 0 = automatic (small grids only), 1 = off, 2 / 4 / 8 = forced.
+ *   "front_output_split": 1 = small grids use one workgroup per output of the front kernel (default), 0 = never.
+ *   "fused_linear"      : 1 = one kernel per layer for Q'/K/V + Fusion-2 (default), 0 = the three-kernel sequence.
+ *   "conv_lds_patch"    : 1 = stride-1 3x3 convolutions stage activations through LDS (default), 2 = same without the
+ *                         three-workgroup form, 0 = gather form.
+ *   "nms_binned"        : 1 = grid-binned NMS candidates on large grids (default), 2 = always, 0 = all pairs.
+ *   "topk_select"       : 1 = radix select of the S seeds (default), 0 = full bitonic sort. */
 int gmf_set_tuning(gmf_handle* h, const char* name, int value);
 
 /* In-situ timing of the dominant kernel (the spatial-consistency attention): while enabled, every
@@ -126,21 +135,15 @@ typedef struct gmf_encoder_weights {
   const float* tail_wst;    const float* tail_vec;  int tail_wst_stride,  tail_vec_stride;  /* fc_message */
   const float* head_wst;    const float* head_vec;
   float sigma_d;
-  /* optional split-bf16 (bf16x3) images of the GEGLU feed-forward weights: 48 stages of 24 KiB per layer.
-   * When non-NULL the feed-forward runs on the bf16 MFMA (fp32-equivalent accuracy, 2.7x fewer MFMA cycles). */
-  const float* ff_wst_b3;   int ff_wst_b3_stride;
-  const float* f1_ff_wst_b3;
   /* optional split-fp16 (fp16x2) images of every dense weight of the linear stages, same sizes and strides as the
-   * fp32 blobs.  When all are non-NULL and the attention variant is 9/10 (the default), [layer0]+PointCN+QKV, the
-   * context prepare, the cross-attention and the feed-forward run on the f16 MFMA (fp32-equivalent accuracy). */
+   * fp32 blobs.  When all are non-NULL (tail_wst_h2 included) and the attention variant is 9 / 18 (the default),
+   * [layer0]+PointCN+QKV, the context prepare, the cross-attention, the feed-forward and the attention run on the f16
+   * MFMA with split-fp16 operands (fp32-equivalent accuracy); otherwise every stage runs on the fp32 MFMA. */
   const float* front_wst_h2; const float* ctx_wst_h2; const float* attn_wst_h2; const float* ff_wst_h2;
   const float* f1_ctx_wst_h2; const float* f1_attn_wst_h2; const float* f1_ff_wst_h2;
   /* optional split-fp16 image of the fc_message weights (same size and stride as tail_wst): the epilogue of the cached,
    * software-pipelined attention kernel then runs on the f16 MFMA too. */
   const float* tail_wst_h2;
-  /* the same weights as split-fp16 images for v_mfma_f32_16x16x32_f16 A-operands (gmf_amd.packing.p16_h2), used by
-   * the 16x16x32 form of the attention kernel (scattn_variant 19). */
-  const float* tail_wst_q16;
 } gmf_encoder_weights;
 
 /* PointDSC.forward up to the logits (PointDSC.py:216-241) with image TOKENS as input:

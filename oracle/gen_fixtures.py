@@ -175,7 +175,78 @@ def gen_f14(pdsc):
     np.savez_compressed(os.path.join(GOLD, "f14_validation_step.npz"), **out)
 
 
+def gen_f15():
+    """F15: the image encoder at batch size (row f-1) - the reference's ImageEncoder (models/Img_Encoder.py:9-19,
+    models/resnet.py:195-216) on 64 seeded 120 x 160 images (32 pairs x 2: every layer1 / layer2 convolution of the HIP
+    encoder then takes its native kernel, and the 64 -> 64 shape its three-workgroups-per-CU form) and on 32 images of
+    96 x 128.  Stored: the tokens [B, H'W', 128] of every 8th image row-sampled (::7), plus fp64 sum and sum of squares
+    of every image's tokens."""
+    import models.Img_Encoder as ie
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    enc = ie.ImageEncoder().eval()
+    shapes_ie = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    enc.load_state_dict(O.seeded_state_dict(shapes_ie, seed=111, gain=1.0))
+    out = {"seed": 111}
+    for tag, nimg, H, W in (("64x120x160", 64, 120, 160), ("32x96x128", 32, 96, 128)):
+        r = np.random.default_rng([115, nimg, H, W])
+        img = torch.from_numpy(r.uniform(0, 1, (nimg, 3, H, W)).astype(np.float32))
+        feat = torch.cat([enc(img[i:i + 8]) for i in range(0, nimg, 8)])
+        tok = feat.view(nimg, 128, -1).permute(0, 2, 1)           # PointDSC.py:129-131
+        out[f"shape_{tag}"] = np.array([nimg, H, W])
+        out[f"rows_{tag}"] = _np(tok[::8, ::7]).astype(np.float32)
+        out[f"sum_{tag}"] = _np(tok.double().sum((1, 2)))
+        out[f"sumsq_{tag}"] = _np((tok.double() ** 2).sum((1, 2)))
+        print("F15", tag, tuple(tok.shape), float(tok.abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "f15_image_encoder_batch.npz"), **out)
+
+
+def gen_f16(pdsc):
+    """F16: the whole test-mode forward where the seed list runs into the zero-key tie group - N = 1500 / 3000 with the
+    UNMODIFIED seeded weights (mostly negative logits: fewer than S local maxima have a positive score, so
+    `argsort(scores * is_local_max, descending)[:S]` (PointDSC.py:284-286) is filled up from the suppressed points, whose
+    key is +-0, in whatever order this torch build's unstable CPU sort leaves them).  Stored per scene: the reference's
+    logits, seeds (captured from pick_seeds), final_trans, final_labels and the ground truth."""
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    model = build_ref_pointdsc(pdsc, O.seeded_state_dict(O.pointdsc_shapes(6, 12, 128), seed=7))
+    caps = {}
+    model.classification.register_forward_hook(lambda m, i, o: caps.__setitem__("logits", o))
+    orig_pick = model.pick_seeds
+
+    def pick(*a, **k):
+        caps["seeds"] = orig_pick(*a, **k)
+        return caps["seeds"]
+    model.pick_seeds = pick
+    out, cases = {}, []
+    for N, seeds in ((1500, [81, 82, 83]), (3000, [84, 85])):
+        for sd_ in seeds:
+            b = O.synthetic_batch([sd_], N=N, T=196)
+            data = {"corr_pos": b["corr_pos"], "src_keypts": b["src_keypts"], "tgt_keypts": b["tgt_keypts"],
+                    "p_image": _tok_to_image(b["p_tokens"]), "q_image": _tok_to_image(b["q_tokens"]), "testing": True}
+            res = model(data)
+            tag = f"{N}_{sd_}"
+            cases.append([N, sd_])
+            lg = caps["logits"].squeeze(1)
+            out[f"logits_{tag}"] = _np(lg)
+            out[f"seeds_{tag}"] = _np(caps["seeds"]).astype(np.int32)
+            out[f"final_trans_{tag}"] = _np(res["final_trans"])
+            out[f"final_labels_{tag}"] = _np(res["final_labels"]).astype(np.uint8)
+            out[f"gt_trans_{tag}"] = _np(b["gt_trans"])
+            err = float((res["final_trans"] - b["gt_trans"]).abs().max())
+            print("F16", tag, "positive logits:", int((lg > 0).sum()), "S:", N // 10, "max|T - T_gt|:", err)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(GOLD, "f16_pose_tie_scenes.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f15":
+        _import_reference()
+        gen_f15()
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f16":
+        gen_f16(_import_reference()[0])
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f14":
         gen_f14(_import_reference()[0])
         return

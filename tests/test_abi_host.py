@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gmf_hip.h but not exported"
     assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
-    assert lib.gmf_abi_version() == 1
+    assert lib.gmf_abi_version() == 2
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device error path")
@@ -151,6 +151,28 @@ def test_image_encoder_matches_reference(golden_dir):
     assert f.shape == (2, 128, 15, 20)
     tok = f.view(2, 128, -1).permute(0, 2, 1)
     assert np.abs(tok.numpy() - g["tokens"]).max() < 1e-4 * max(1.0, np.abs(g["tokens"]).max())
+
+
+@pytest.mark.parametrize("tag", ["64x120x160", "32x96x128"])
+def test_image_encoder_matches_reference_at_batch_size(golden_dir, tag):
+    """Golden F15: the reference's ImageEncoder on 64 images of 120 x 160 (32 pairs) and 32 of 96 x 128 - sampled token
+    rows and per-image fp64 checksums.  Here the stock module on the CPU; tests/test_gpu_parity.py holds the fused HIP
+    encoder to the same fixture."""
+    import gmf_amd
+    from gmf_amd import synthetic
+    g = np.load(os.path.join(golden_dir, "f15_image_encoder_batch.npz"))
+    enc = gmf_amd.ImageEncoder().eval()
+    shapes = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    enc.load_state_dict(synthetic.seeded_state_dict(shapes, seed=int(g["seed"]), gain=1.0))
+    nimg, H, W = (int(v) for v in g[f"shape_{tag}"])
+    img = synthetic.seeded_images(nimg, H, W)
+    with torch.no_grad():
+        f = torch.cat([enc(img[i:i + 8]) for i in range(0, nimg, 8)])
+    tok = f.view(nimg, 128, -1).permute(0, 2, 1)
+    scale = max(1.0, float(np.abs(g[f"rows_{tag}"]).max()))
+    assert np.abs(tok[::8, ::7].numpy() - g[f"rows_{tag}"]).max() < 1e-4 * scale
+    assert np.abs(tok.double().sum((1, 2)).numpy() / g[f"sum_{tag}"] - 1).max() < 1e-5
+    assert np.abs((tok.double() ** 2).sum((1, 2)).numpy() / g[f"sumsq_{tag}"] - 1).max() < 1e-5
 
 
 def test_oracle_is_only_reachable_from_the_checkers():

@@ -23,18 +23,34 @@ def _global_batch(B=5, N=37):
     return {"corr_pos": torch.randn(B, N, 6, generator=g), "src_keypts": torch.randn(B, N, 3, generator=g), "testing": True}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, B):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
     from gmf_amd.dist import ShardedBatchDriver, shard_batch
     drv = ShardedBatchDriver(_fake_model, world, rank, torch.device("cpu"), backend="gloo")
-    # 6 pairs over 2 ranks (all_gather_into_tensor needs equal shards)
-    data = shard_batch(_global_batch(B=6), world, rank)
-    out = drv.step(data)
+    drv.time_steps = True
+    calls = []
+    real = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    if B % world == 0:
+        out = drv.step(shard_batch(_global_batch(B=B), world, rank))      # equal shards: local data, no plan needed
+    else:
+        out = drv.run(_global_batch(B=B))                                   # uneven shards: padded inside the one buffer
+    n_collectives = len(calls)
+    ms = drv.read_timings()
+    bad = None
+    if B % world != 0:
+        try:                                                                # local data of unequal size WITHOUT a plan:
+            drv.step(shard_batch(_global_batch(B=B), world, rank), sizes=[1] * world)   # must raise, not hang
+        except RuntimeError as e:
+            bad = str(e)
+    dist.all_gather_into_tensor = real
     drv.barrier()
     t = drv.max_over_ranks(float(rank + 1))
-    q.put((rank, out["all_logits"].clone(), out["all_trans"].clone(), t))
+    per_rank = drv.gather_floats(float(10 + rank))
+    q.put((rank, out["all_logits"].clone(), out["all_trans"].clone(), t, n_collectives, bad, per_rank, ms))
     drv.close()
 
 
@@ -49,19 +65,37 @@ def test_shard_range_covers_batch():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_gloo_matches_single_process():
-    world, port = 2, 29731
+import pytest
+
+
+@pytest.mark.parametrize("B,port", [(6, 29731), (5, 29733)])
+def test_two_rank_gloo_matches_single_process(B, port):
+    """6 pairs over 2 ranks (equal shards) and 5 pairs over 2 ranks (3 + 2: padded to the larger shard inside the packed
+    buffer and trimmed after the gather): every rank ends with the single-process result bit for bit, after exactly ONE
+    collective per step."""
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, B)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    ref = _fake_model(_global_batch(B=6))
-    for rank, all_logits, all_trans, t in got:
+    ref = _fake_model(_global_batch(B=B))
+    for rank, all_logits, all_trans, t, n_coll, bad, per_rank, ms in got:
         assert torch.equal(all_logits, ref["logits"])
         assert torch.equal(all_trans, ref["final_trans"])
         assert t == 2.0          # MAX over ranks of (rank + 1)
+        assert n_coll == 1       # one all_gather_into_tensor per step (logits and poses packed together)
+        assert per_rank == [10.0, 11.0]
+        assert ms[0] is not None and ms[0] >= 0 and ms[1] >= 0
+        if B % world != 0:
+            assert bad is not None and "shard plan" in bad
+
+
+def test_shard_sizes_match_ranges():
+    from gmf_amd.dist import shard_range, shard_sizes
+    assert shard_sizes(5, 2) == [3, 2] and shard_sizes(256, 8) == [32] * 8 and shard_sizes(3, 4) == [1, 1, 1, 0]
+    assert sum(shard_sizes(257, 8)) == 257

@@ -230,3 +230,26 @@ def test_f14_metrics_corner_cases(golden_dir):
     bb = O.synthetic_batch(list(g["alone_seeds"]), N=pred.shape[1], T=12)
     tl = O.transformation_loss(T, bb["gt_trans"], bb["src_keypts"], bb["tgt_keypts"], pred)
     assert _rel(tl, g["alone_trans"]) < 1e-5
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_f16_oracle_in_tie_scenes(golden_dir, sd_full, case):
+    """Golden F16 (the reference at N = 1500 / 3000 with unmodified weights, seed list inside the zero-key tie group): the
+    oracle's logits are the reference's to 1e-4 and its seed list agrees wherever no tie is involved; inside the tie group
+    the order belongs to torch's unstable sort (same machine, same build here - but not a contract), so the pose is held
+    to "no worse against the ground truth than the reference's own"."""
+    g = np.load(os.path.join(golden_dir, "f16_pose_tie_scenes.npz"))
+    N, seed = (int(v) for v in g["cases"][case])
+    tag = f"{N}_{seed}"
+    b = O.synthetic_batch([seed], N=N, T=196)
+    ref = O.pointdsc_forward(sd_full, b, testing=True)
+    assert np.abs(ref["logits"].numpy() - g[f"logits_{tag}"]).max() < 1e-4
+    ref_seeds = g[f"seeds_{tag}"][0]
+    rl, src = torch.from_numpy(g[f"logits_{tag}"]), b["src_keypts"]
+    sdist = torch.norm(src[:, :, None, :] - src[:, None, :, :], dim=-1)
+    is_max = torch.all((rl[:, :, None] >= rl[:, None, :]) | (sdist >= 0.10), dim=-1).float()
+    n_pos = int(((rl * is_max)[0][torch.from_numpy(ref_seeds.astype(np.int64))] > 0).sum())
+    assert np.array_equal(ref["seeds"][0].numpy()[:n_pos], ref_seeds[:n_pos])
+    err_o = np.abs(ref["final_trans"].numpy() - g[f"gt_trans_{tag}"]).max()
+    err_r = np.abs(g[f"final_trans_{tag}"] - g[f"gt_trans_{tag}"]).max()
+    assert err_o <= err_r + 1e-4

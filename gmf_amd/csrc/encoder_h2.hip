@@ -37,12 +37,15 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
   const int tile = active ? tile_raw : tiles - 1;
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
 
-  // gridDim.z == 3 (small grids): workgroup z recomputes PointCN and produces ONE of Q' (z = 0, it also stores f), K, V -
-  // 8 weight stages instead of 16 per workgroup, three times the workgroups.
-  const bool zsplit = (MODE != 2) && gridDim.z == 3;
+  // gridDim.z == 3 (small grids): workgroup z recomputes PointCN (MODE 0 / 1) and produces ONE of Q' (z = 0, it also stores
+  // f), K, V - 8 (MODE 2: 4) weight stages instead of 16 (12) per workgroup, three times the workgroups.
+  // MODE 3: corr_pos -> layer0 -> PointCN -> f only (the first layer's f when the later PointCNs run in the attention epilogue).
+  const bool zsplit = (MODE != 3) && gridDim.z == 3;
   const int zsel = zsplit ? (int)blockIdx.z : -1;
   StageRing<kRing> ss;
-  if (MODE == 2) ss.init(lds, wave, lane, wst + 4 * kStageFloats, 12);
+  if (MODE == 3) ss.init(lds, wave, lane, wst, 4);
+  else if (MODE == 2 && zsplit) ss.init(lds, wave, lane, wst + (4 + 4 * zsel) * kStageFloats, 4);
+  else if (MODE == 2) ss.init(lds, wave, lane, wst + 4 * kStageFloats, 12);
   else if (zsplit) ss.init(lds, wave, lane, wst, 4, wst + (4 + 4 * zsel) * kStageFloats, 4);
   else ss.init(lds, wave, lane, wst, 16);
   ss.prime();
@@ -51,7 +54,7 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
   FragH2<8> fx;
   {
     float x[CF];
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 3) {
       const int row = tile * 32 + i;
       float pk[4];
 #pragma unroll
@@ -91,7 +94,8 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
       }
     }
   }
-  if (active && zsel <= 0) store_frag_p32<CF>(f_out + toff, f, lane);
+  if (active && zsel <= 0 && MODE != 2) store_frag_p32<CF>(f_out + toff, f, lane);
+  if (MODE == 3) return;
   fx.set(f);
 
 #pragma unroll
@@ -315,36 +319,15 @@ k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_im
   }
 }
 
-// =========================================================================================
-// k_fusion_ff_h2p: LayerNorm + Linear(128 -> 1024) + GEGLU + Linear(512 -> 128) + residual (fusion_layer.py:54-69,191) with
-//   the chunk loop software-pipelined inside each wave.
-//   stages (48 x 16 KiB): for c in 0..15: W1a_c | W1g_c | W2_c (4 blocks of 32 x 32: 2 planes x 2 steps)
-//   A GEGLU chunk is 48 MFMAs of W1 (value | gate, K = 128), 16 GELUs (~24 vector instructions each) and 24 MFMAs of
-//   W2; in program order they run back to back and the kernel costs matrix time PLUS vector time.  Here the W1 MFMAs
-//   of chunk c+1 are issued three at a time with one GELU of chunk c in their issue gaps (16 units), the fp16 split
-//   of the gated values rides in the later units, and only the 24 W2 MFMAs run bare.  The biases start the
-//   accumulators (no separate add), the stage ring is 4 deep and its acquire is branch-free (stage order
-//   A0 G0 | A1 G1 W2_0 | ... | A15 G15 W2_14 | W2_15 addressed into the unchanged blob; past the end the last stage is
-//   re-fetched into a free slot instead of branching), so a whole chunk is one basic block for the scheduler.
-// =========================================================================================
-template <bool SPLIT>
-__global__ void __launch_bounds__(256, 2)
-k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
-                float* __restrict__ x2_out, int tiles, float* __restrict__ part) {
-  // gridDim.z = HS > 1 (small grids, e.g. B = 1): workgroup z handles the hidden chunks [z, z+1) * 16 / HS and writes its
-  // partial Linear-2 output (no bias, no residual) to part[z]; k_ff_reduce adds the partials in a fixed order.
+// The GEGLU chunk loop of the feed-forward, software-pipelined inside the wave (shared by k_fusion_ff_h2p and k_linear_h2):
+//   y[mb] += W2[:, chunk] (value_c * GELU(gate_c)) for the hidden chunks [c_begin, c_begin + NCH), value / gate = W1 nx + b1.
+// `lds` is a ring of NB = 4 stages owned by the workgroup (the caller has made sure no wave still reads it); on return
+// every DMA piece this wave issued has landed.  Stage order A0 G0 | A1 G1 W2_0 | ... addressed into the unchanged blob
+// (16 x (A | G | W2)); past the end the last stage is re-fetched into a free slot instead of branching.
+GMF_DEVINL void ff_chunks(const FragH2<8>& nx, f32x16 (&y)[4], float* lds, const float* __restrict__ wst,
+                          const float* __restrict__ b1a, const float* __restrict__ b1g, const int wave, const int lane,
+                          const int h, const int c_begin, const int NCH) {
   constexpr int NB = 4;
-  // (compile-time trip counts for the common un-split form: a run-time chunk count costs it 9 %)
-  const int HS = SPLIT ? (int)gridDim.z : 1, NCH = SPLIT ? (FFH / 32) / HS : FFH / 32, c_begin = SPLIT ? (int)blockIdx.z * NCH : 0;
-  __shared__ __attribute__((aligned(16))) float lds[NB * kStageFloats];
-  const int lane = threadIdx.x & 63, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = blockIdx.y;
-  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
-  const bool active = tile_raw < tiles;
-  const int tile = active ? tile_raw : tiles - 1;
-  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
-
   // stage n of the consumption order -> stage index in the blob (16 x (A | G | W2))
   int n_issued = 0, n_used = 0;
   auto blob_stage = [&](int n) {
@@ -371,18 +354,6 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
   };
   issue_one(); issue_one(); issue_one();
 
-  FragH2<8> nx;
-  {
-    float x[CF], xn[CF];
-    load_frag_p32<CF>(x, x1 + toff, lane);
-    layernorm_frag<CF>(xn, x, vecs, vecs + C, h);
-    nx.set(xn);
-  }
-  f32x16 y[4];
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb) y[mb] = zero16();
-  const float* b1a = vecs + 2 * C;
-  const float* b1g = vecs + 2 * C + FFH;
   auto bias_acc = [&](const float* bvec, int c) {
     float b[16];
     load_vec_block(b, bvec, c, h);
@@ -449,6 +420,49 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
   chunk(c_begin + NCH - 2, a0, g0, a1, g1, true);
   chunk(c_begin + NCH - 1, a1, g1, a0, g0, false);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-fetched tail stages
+}
+
+// =========================================================================================
+// k_fusion_ff_h2p: LayerNorm + Linear(128 -> 1024) + GEGLU + Linear(512 -> 128) + residual (fusion_layer.py:54-69,191) with
+//   the chunk loop software-pipelined inside each wave.
+//   stages (48 x 16 KiB): for c in 0..15: W1a_c | W1g_c | W2_c (4 blocks of 32 x 32: 2 planes x 2 steps)
+//   A GEGLU chunk is 48 MFMAs of W1 (value | gate, K = 128), 16 GELUs (~24 vector instructions each) and 24 MFMAs of
+//   W2; in program order they run back to back and the kernel costs matrix time PLUS vector time.  Here the W1 MFMAs
+//   of chunk c+1 are issued three at a time with one GELU of chunk c in their issue gaps (16 units), the fp16 split
+//   of the gated values rides in the later units, and only the 24 W2 MFMAs run bare.  The biases start the
+//   accumulators (no separate add), the stage ring is 4 deep and its acquire is branch-free (stage order
+//   A0 G0 | A1 G1 W2_0 | ... | A15 G15 W2_14 | W2_15 addressed into the unchanged blob; past the end the last stage is
+//   re-fetched into a free slot instead of branching), so a whole chunk is one basic block for the scheduler.
+// =========================================================================================
+template <bool SPLIT>
+__global__ void __launch_bounds__(256, 2)
+k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
+                float* __restrict__ x2_out, int tiles, float* __restrict__ part) {
+  // gridDim.z = HS > 1 (small grids, e.g. B = 1): workgroup z handles the hidden chunks [z, z+1) * 16 / HS and writes its
+  // partial Linear-2 output (no bias, no residual) to part[z]; k_ff_reduce adds the partials in a fixed order.
+  constexpr int NB = 4;
+  // (compile-time trip counts for the common un-split form: a run-time chunk count costs it 9 %)
+  const int HS = SPLIT ? (int)gridDim.z : 1, NCH = SPLIT ? (FFH / 32) / HS : FFH / 32, c_begin = SPLIT ? (int)blockIdx.z * NCH : 0;
+  __shared__ __attribute__((aligned(16))) float lds[NB * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+
+  FragH2<8> nx;
+  {
+    float x[CF], xn[CF];
+    load_frag_p32<CF>(x, x1 + toff, lane);
+    layernorm_frag<CF>(xn, x, vecs, vecs + C, h);
+    nx.set(xn);
+  }
+  f32x16 y[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) y[mb] = zero16();
+  ff_chunks(nx, y, lds, wst, vecs + 2 * C, vecs + 2 * C + FFH, wave, lane, h, c_begin, NCH);
   if (HS > 1) {
     float* pt = part + ((size_t)blockIdx.z * gridDim.y * tiles + (size_t)pair * tiles + tile) * (32 * C);
 #pragma unroll
@@ -467,6 +481,210 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
     load_block_p32(xr, x1 + toff, mb, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = fmaf(y[mb][r], kH2Inv, b[r]) + xr[r];
+    if (active) store_block_p32(x2_out + toff, mb, t, lane);
+  }
+}
+
+// =========================================================================================
+// k_linear_h2: every linear stage of one encoder layer in ONE pass over f = ReLU(PointCN(feat)) [B, N, 128]
+// (PointDSC.py:56-58, fusion_layer.py:172-201):
+//     Q' = Wq' f + bq', K = Wk f + bk, V = Wv f + bv                          -> split-fp16 images for the attention kernel
+//     x' = LCPE(f) ; x1 = x' + Wo softmax(LN(x') Wq'' Kc^T) Vc + bo           (cross-attention over the T context tokens)
+//     x2 = x1 + W2 GEGLU(W1 LN(x1) + b1) + b2                                 -> fp32 image (the Fusion-2 branch of the block sum)
+// i.e. k_front_h2<2> + k_fusion_attn_h2<true> + k_fusion_ff_h2p with x' and x1 never leaving the registers: the residuals
+// START the accumulators of the following projection (256 (x' + bo), 256 (x1 + b2) - the weight images are 256 W), so they
+// cost no registers across the stage that follows, and the only HBM traffic of the layer's linear part is f (+ two LCPE
+// neighbour rows per tile) in and Q', K, V, x2 out (2.5 KB per row instead of 5 KB in the three-kernel form).
+//   stages: Wq' Wk Wv [12] | Wq'' [2] | context tiles [ttiles] | Wo [2] through a 2-slot ring, then the 48 feed-forward
+//   stages through the 4-slot ring of ff_chunks (the same 64 KiB of LDS; one workgroup barrier between the two).
+// =========================================================================================
+__global__ void __launch_bounds__(256, 2)
+k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst, const float* __restrict__ front_vec,
+            const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
+            const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
+            float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
+            int ttiles) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const float* pair_base = f_in + (size_t)pair * tiles * (32 * C);
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+
+  StageRing<2> ss;
+  ss.init(lds, wave, lane, front_wst + 4 * kStageFloats, 12, attn_wst, 2,
+          ctx_img + (size_t)pair * ttiles * kStageFloats, ttiles, attn_wst + 2 * kStageFloats, 2);
+  ss.prime();
+
+  // ---- Q', K, V from f ---------------------------------------------------------------------------------------------
+  {
+    FragH2<8> fx;
+    {
+      float f[CF];
+      load_frag_p32<CF>(f, f_in + toff, lane);
+      fx.set(f);
+    }
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {   // Q', K
+      float* dst = (which == 0 ? q_out : k_out) + toff;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        // the bias is requested BEFORE the acquire: a load issued after it would be younger than the stage's DMA pieces, and
+        // the compiler's wait for the bias would then wait for the next stage to land as well (no look-ahead left)
+        float b[16], t[16];
+        load_vec_block(b, front_vec + (1 + which) * C, mb, h);
+        const f16x8* lw = as_h2(ss.acquire());
+        f32x16 acc = zero16();
+        mma_wx_h2<8>(acc, lw, fx);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, b[r]);
+        if (active) store_block_h2(dst, mb, t, lane);
+      }
+    }
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {             // V (feature on lane)
+      const float bv = front_vec[3 * C + 32 * db + i];
+      const f16x8* lw = as_h2(ss.acquire());
+      f32x16 acc = zero16();
+      mma_xw_h2<8>(acc, lw, fx);
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bv);
+      if (active) store_block_h2(v_out + toff, db, t, lane);
+    }
+  }
+
+  // ---- cross-attention: x1 = x' + Wo softmax(q Kc^T) Vc + bo --------------------------------------------------------
+  f32x16 x1a[4];                                 // 256 x1, accumulator layout (block mb = features 32 mb .. 32 mb + 31)
+  {
+    FragH2<4> qx;
+    {
+      float xp[CF];
+      lcpe_frag(xp, pair_base, tile * 32 + i, N, attn_vec, h);
+      {
+        FragH2<8> nx;
+        {
+          float xn[CF];
+          layernorm_frag<CF>(xn, xp, attn_vec + 4 * C, attn_vec + 5 * C, h);
+          nx.set(xn);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const f16x8* lw = as_h2(ss.acquire());
+          f32x16 acc = zero16();
+          mma_wx_h2<8>(acc, lw, nx);
+          float t[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[r] = acc[r] * kH2Inv;
+          qx.set_block(mb, t);
+        }
+      }
+      // the residual and the output bias start the out-projection accumulators (Wo images are 256 W)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        float b[16];
+        load_vec_block(b, attn_vec + 6 * C, mb, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x1a[mb][r] = (xp[16 * mb + r] + b[r]) * 256.0f;
+      }
+    }
+    f32x16 oacc[2];
+    oacc[0] = zero16(); oacc[1] = zero16();
+    float m_run = -INFINITY, l_half = 0.f;
+    for (int t = 0; t < ttiles; ++t) {
+      const f16x8* lk = as_h2(ss.acquire());
+      const f16x8* lv = lk + 2 * 4 * 64;            // Vc image follows the Kc image (2 planes x 4 steps)
+      f32x16 sc = zero16();
+      mma_wx_h2<4>(sc, lk, qx);
+      float x[16];
+      float mx = -INFINITY;
+      if (t + 1 < ttiles) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { x[r] = sc[r]; mx = fmaxf(mx, sc[r]); }
+      } else {                                      // only the last context tile can hold tokens >= T
+        const int jbase = t * 32 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int jl = 8 * (r >> 2) + (r & 3);
+          x[r] = (jbase + jl < T) ? sc[r] : -INFINITY;
+          mx = fmaxf(mx, x[r]);
+        }
+      }
+      mx = xhalf_max(mx);
+      const float m_new = fmaxf(m_run, mx);
+      const bool moved = m_new > m_run;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      const float m_off = m_new - 10.0f;
+      float ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
+      l_half = fmaf(l_half, alpha, ls);
+      if (__any(moved)) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8 ph, pl;
+        split8h(&x[8 * s2], ph, pl);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int slot = 2 * db + s2;
+          mma3(oacc[db], lv[(0 * 4 + slot) * 64], lv[(1 * 4 + slot) * 64], ph, pl);
+        }
+      }
+    }
+    FragH2<4> ox;
+    {
+      const float inv = 1.0f / xhalf_sum(l_half);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = oacc[db][r] * inv;
+        ox.set_block(db, t);
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const f16x8* lw = as_h2(ss.acquire());
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) mma_wx_h2<4>(x1a[2 * st + hb], lw + hb * (2 * 4 * 64), ox);
+    }
+  }
+
+  // ---- feed-forward: x2 = x1 + W2 GEGLU(W1 LN(x1) + b1) + b2 --------------------------------------------------------
+  FragH2<8> nx;
+  f32x16 y[4];
+  {
+    float x1[CF], xn[CF];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x1[16 * mb + r] = x1a[mb][r] * kH2Inv;
+    layernorm_frag<CF>(xn, x1, ff_vec, ff_vec + C, h);
+    nx.set(xn);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      float b[16];
+      load_vec_block(b, ff_vec + 2 * C + 2 * FFH, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[mb][r] = (x1[16 * mb + r] + b[r]) * 256.0f;
+    }
+  }
+  __syncthreads();                               // every wave is done with the 2-slot ring: the 4-slot ring may overwrite it
+  ff_chunks(nx, y, lds, ff_wst, ff_vec + 2 * C, ff_vec + 2 * C + FFH, wave, lane, h, 0, FFH / 32);
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = y[mb][r] * kH2Inv;
     if (active) store_block_p32(x2_out + toff, mb, t, lane);
   }
 }
@@ -508,10 +726,19 @@ static inline dim3 tgrid(int tiles, int B, int sets = 1) { return dim3((tiles + 
 hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
                            float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s) {
   dim3 g = tgrid(tiles, B);
-  if (mode != 2 && g.x * B < 128 && tune.front_split) g.z = 3;      // small grids: one workgroup per output (Q' + f | K | V)
-  if (mode == 1) hipLaunchKernelGGL(k_front_h2<1>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  if (g.x * B < 128 && tune.front_split) g.z = 3;      // small grids: one workgroup per output (Q' + f | K | V)
+  if (mode == 3) { g.z = 1; hipLaunchKernelGGL(k_front_h2<3>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles); }
+  else if (mode == 1) hipLaunchKernelGGL(k_front_h2<1>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
   else if (mode == 2) hipLaunchKernelGGL(k_front_h2<2>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
   else hipLaunchKernelGGL(k_front_h2<0>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_linear_h2(const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
+                            const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec, float* q,
+                            float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_linear_h2, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
+                     ff_vec, q, k, v, x2, N, tiles, T, ttiles);
   return hipGetLastError();
 }
 

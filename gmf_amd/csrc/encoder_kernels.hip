@@ -610,11 +610,16 @@ GMF_DEVINL float xhalf_max_swap(float v) {
 // fc_message on the f16 MFMA (split-fp16 weights, tail_wst_h2) + bias + Fusion-2 branch for the 32 rows of one wave, given
 // the normalised attention output o (fragment order).  `ss` is primed on the 5 weight stages; every wave of the workgroup
 // calls this (padding waves with active = false keep their seat at the stage barriers).
-template <class Stages>
+// NEXT_PCN: the block output feat = msg + fusion2_out is not stored; the NEXT layer's PointCN (conv1x1 + folded BatchNorm +
+// ReLU, PointDSC.py:104-109,141) runs on it here - 4 more weight stages (front_wst_h2 of layer l+1, blocks Wp) - and
+// f_{l+1} = ReLU(Wp' feat + bp') is what goes to memory: the next layer's linear kernel needs f with its two LCPE neighbour
+// rows, and the raw feat of a middle layer has no other reader.
+template <bool NEXT_PCN, class Stages>
 GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stages& ss, const float* __restrict__ vecs,
-                                   const float* __restrict__ fus_tile, float* __restrict__ out_tile, const int lane, const int h) {
+                                   const float* __restrict__ fus_tile, float* __restrict__ out_tile, const int lane, const int h,
+                                   const float* __restrict__ next_bias = nullptr) {
     // stages (fp16x2 images, same sizes as the fp32 ones): Wa block 0 | Wa block 1 | Wb (2 blocks) | Wc 0,1 | Wc 2,3
-    FragH2<8> ox;
+    FragH2<8> ox, featx;
     FragH2<4> m1x, m2x;
     if (active) ox.set(o);
 #pragma unroll
@@ -657,20 +662,52 @@ GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stag
         load_block_p32(fz, fus_tile, mb, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) tt[r] = fmaf(acc[r], kH2Inv, b[r]) + fz[r];
-        if (active) store_block_p32(out_tile, mb, tt, lane);
+        if (NEXT_PCN) featx.set_block(mb, tt);
+        else if (active) store_block_p32(out_tile, mb, tt, lane);
+      }
+    }
+    if (NEXT_PCN) {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const f16x8* lw = as_h2(ss.acquire());
+        if (!active) continue;
+        f32x16 acc = zero16();
+        mma_wx_h2<8>(acc, lw, featx);
+        float b[16], tt[16];
+        load_vec_block(b, next_bias, mb, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tt[r] = fmaxf(fmaf(acc[r], kH2Inv, b[r]), 0.f);
+        store_block_p32(out_tile, mb, tt, lane);
       }
     }
 }
 
-// KSPLIT (small grids: B x ceil(tiles/4) workgroups fill a fraction of the 512 slots, e.g. B = 1 - the reference's
-// evaluation mode): the keys of a query block are divided over `ksplits` workgroups, each writes its un-normalised partial
-// O (P32 tile image), row maximum and row sum; k_scattn_merge combines them and runs the epilogue.
-template <bool KSPLIT>
+// Work mapping of the attention grid (k_scattn_h2p and k_scattn_merge).  The n_items = B * wgs_per_pair work items
+// (pair, block of 4 query tiles) are dealt to the 8 XCDs in contiguous runs (hardware sends workgroup L to XCD L % 8), so
+// that all workgroups of a pair stream the SAME K/V tiles through ONE L2 at about the same time.  Within an XCD's run the
+// first `n_full` items are WHOLE workgroups (all key tiles, epilogue in-kernel); each remaining item is SPLIT by key range
+// over `ksplits` workgroups that write un-normalised partial results for k_scattn_merge.  Two uses:
+//   * small grids (fewer items than the chip has workgroup slots, e.g. B = 1 - the reference's evaluation mode): n_full = 0;
+//   * the tail of a large grid: 32 pairs x 40 query blocks = 1280 items on 512 slots are 2.5 rounds, i.e. 3 rounds of
+//     wall time with half the chip idle in the last; with n_full = 2 rounds' worth and the last 256 items split in two,
+//     the tail is 512 half-length workgroups = one half round.
+struct AttnItem { int item, ks; bool split, valid; };
+GMF_DEVINL AttnItem attn_item(int L, int n_items, int n_full, int ksplits) {
+  const int chunk = n_items >> 3, rem = n_items & 7, xcd = L & 7, kth = L >> 3;
+  const int start = (xcd < rem) ? xcd * (chunk + 1) : rem * (chunk + 1) + (xcd - rem) * chunk;
+  const int items = chunk + (xcd < rem ? 1 : 0);
+  const int nf = min(n_full, items);
+  if (kth < nf) return AttnItem{start + kth, 0, false, true};
+  const int j = kth - nf, r = j / ksplits;
+  return AttnItem{start + nf + r, j - r * ksplits, true, nf + r < items};
+}
+
 __global__ void __launch_bounds__(256, 2)
 k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
              const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
              float* __restrict__ out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_dense,
-             int ksplits, float* __restrict__ part_o, float* __restrict__ part_ml) {
+             int n_items, int n_full, int ksplits, float* __restrict__ part_o, float* __restrict__ part_ml,
+             const float* __restrict__ next_wst, const float* __restrict__ next_bias) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
   float* const ldsK = lds;
   float* const ldsV = lds + 2 * kStageFloats;
@@ -678,19 +715,14 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned lane_off16 = lane * 16;
-  int pair, qblock, ks = 0;
-  {                                            // XCD-aware work mapping, as k_scattn_h2
-    const int total = gridDim.x, L = blockIdx.x;
-    const int chunk = total >> 3, rem = total & 7, xcd = L & 7, kth = L >> 3;
-    const int start = (xcd < rem) ? xcd * (chunk + 1) : rem * (chunk + 1) + (xcd - rem) * chunk;
-    int logical = start + kth;
-    if (KSPLIT) { ks = logical % ksplits; logical /= ksplits; }
-    pair = logical / wgs_per_pair;
-    qblock = logical - pair * wgs_per_pair;
-  }
+  const AttnItem it = attn_item(blockIdx.x, n_items, n_full, ksplits);
+  if (!it.valid) return;                       // grid padding of the split tail (uniform per workgroup)
+  const bool split = it.split;
+  const int ks = it.ks;
+  const int pair = it.item / wgs_per_pair, qblock = it.item - pair * wgs_per_pair;
   // key tiles [t_begin, t_end) of this workgroup
-  const int t_begin = KSPLIT ? (tiles * ks) / ksplits : 0;
-  const int t_end = KSPLIT ? (tiles * (ks + 1)) / ksplits : tiles;
+  const int t_begin = split ? (tiles * ks) / ksplits : 0;
+  const int t_end = split ? (tiles * (ks + 1)) / ksplits : tiles;
   const int tile_raw = qblock * WAVES + wave;
   const bool active = tile_raw < tiles;
   const int tile = active ? tile_raw : tiles - 1;
@@ -903,7 +935,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
     if (t + 1 < t_end) { tile_step(t, s_a, s_b); tile_last(t + 1, s_b); }
     else tile_last(t, s_a);
   }
-  if (KSPLIT) {
+  if (split) {
     // partial result of this key range: un-normalised O as a P32 tile image, row maximum and row sum
     if (active) {
       float of[CF];
@@ -911,7 +943,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
       for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) of[16 * db + r] = oacc[db][r];
-      const size_t n_tiles_all = (size_t)(gridDim.x / ksplits / wgs_per_pair) * tiles;     // B * tiles
+      const size_t n_tiles_all = (size_t)(n_items / wgs_per_pair) * tiles;     // B * tiles
       const size_t pt = (size_t)ks * n_tiles_all + pbase + tile;
       store_frag_p32<CF>(part_o + pt * (32 * C), of, lane);
       const float lsum = xhalf_sum(l_half);
@@ -931,9 +963,10 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   }
   __syncthreads();
   StageStream ss;
-  ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5);
+  ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5, next_wst, next_wst ? 4 : 0);
   ss.prime();
-  scattn_epilogue_h2(o, active, ss, vecs, fus + toff, out + toff, lane, h);
+  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, fus + toff, out + toff, lane, h, next_bias);
+  else scattn_epilogue_h2<false>(o, active, ss, vecs, fus + toff, out + toff, lane, h);
 }
 
 // All five fc_message weight stages in LDS at once (80 KiB): for grids that do not fill the chip anyway (the merge step
@@ -942,12 +975,18 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
 struct StagesPreloaded {
   const float* base;
   int used, lane;
-  GMF_DEVINL void init(float* lds, int wave, int lane_, const float* g, int n_stages) {
+  // n_stages of `g`, then (if given) 4 stages of `g2`
+  GMF_DEVINL void init(float* lds, int wave, int lane_, const float* g, int n_stages, const float* g2 = nullptr) {
     base = lds; used = 0; lane = lane_;
     for (int st = 0; st < n_stages; ++st)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         dma_piece_1k(g + (size_t)st * kStageFloats + (wave + 4 * q) * 256, lds + st * kStageFloats + (wave + 4 * q) * 256, lane_);
+    if (g2)
+      for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          dma_piece_1k(g2 + (size_t)st * kStageFloats + (wave + 4 * q) * 256, lds + (n_stages + st) * kStageFloats + (wave + 4 * q) * 256, lane_);
   }
   GMF_DEVINL const float4* acquire() {
     if (used == 0) {
@@ -962,22 +1001,29 @@ struct StagesPreloaded {
 
 // k_scattn_merge: combines the `ksplits` partial results of k_scattn_h2p<.., KSPLIT> per query tile - common maximum M,
 // O = sum_k O_k 2^(m_k - M), l = sum_k l_k 2^(m_k - M), splits added in index order - and runs the epilogue.
-// grid (ceil(tiles/4), B), block 256.  The partials are fetched four splits at a time (all loads of a group in flight).
+// One workgroup per SPLIT item of attn_item's mapping: grid 8 * (largest number of split items of an XCD), block 256.  The
+// partials are fetched four splits at a time (all loads of a group in flight).
 __global__ void __launch_bounds__(256, 1)
 k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_ml, const float* __restrict__ fus,
-               const float* __restrict__ wst, const float* __restrict__ vecs, float* __restrict__ out, int tiles, int ksplits) {
-  __shared__ __attribute__((aligned(16))) float lds[5 * kStageFloats];
+               const float* __restrict__ wst, const float* __restrict__ vecs, float* __restrict__ out, int tiles,
+               int wgs_per_pair, int n_items, int n_full, int ksplits, const float* __restrict__ next_wst,
+               const float* __restrict__ next_bias) {
+  __shared__ __attribute__((aligned(16))) float lds[9 * kStageFloats];
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = blockIdx.y;
-  const int tile_raw = blockIdx.x * 4 + wave;
+  // split item r of XCD x: the workgroup slot (x, n_full + r * 1) of a ksplits = 1 mapping
+  const AttnItem it = attn_item(blockIdx.x + 8 * min(n_full, (n_items >> 3) + ((int)(blockIdx.x & 7) < (n_items & 7) ? 1 : 0)),
+                                n_items, n_full, 1);
+  if (!it.valid) return;
+  const int pair = it.item / wgs_per_pair;
+  const int tile_raw = (it.item - pair * wgs_per_pair) * 4 + wave;
   const bool active = tile_raw < tiles;
   const int tile = active ? tile_raw : tiles - 1;
-  const size_t n_tiles_all = (size_t)gridDim.y * tiles;
+  const size_t n_tiles_all = (size_t)(n_items / wgs_per_pair) * tiles;
   const size_t pt0 = (size_t)pair * tiles + tile;
   const size_t toff = pt0 * (32 * C);
   StagesPreloaded ss;
-  ss.init(lds, wave, lane, wst, 5);
+  ss.init(lds, wave, lane, wst, 5, next_wst);
   float mk[8], lk[8];
   float M = -INFINITY;
 #pragma unroll
@@ -1014,7 +1060,8 @@ k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_
   const float inv = 1.0f / l;
 #pragma unroll
   for (int e = 0; e < CF; ++e) o[e] *= inv;
-  scattn_epilogue_h2(o, active, ss, vecs, fus + toff, out + toff, lane, h);
+  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, fus + toff, out + toff, lane, h, next_bias);
+  else scattn_epilogue_h2<false>(o, active, ss, vecs, fus + toff, out + toff, lane, h);
 }
 
 // =========================================================================================
@@ -1450,6 +1497,18 @@ __global__ void k_pack_pts8(const float* __restrict__ src, const float* __restri
 
 namespace gmf {
 
+// compute units of the current device (256 on MI355X); queried once per process and device
+static int cu_count() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  static int cached[16] = {0};
+  if (dev >= 0 && dev < 16 && cached[dev] > 0) return cached[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (dev >= 0 && dev < 16) cached[dev] = n;
+  return n;
+}
+
 static inline dim3 tile_grid(int tiles, int B, int sets = 1) { return dim3((tiles + kWavesPerWG - 1) / kWavesPerWG, B, sets); }
 
 hipError_t launch_front(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
@@ -1491,21 +1550,32 @@ hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, 
   const dim3 grid4(wpp * B);
   const float* cd = (cc && tune.use_cache) ? cc->dense : nullptr;
   if (tune.scattn_variant == 18 && cd && cc->tail_wst_h2) {
-    int ksplits = 1;
-    if (cc->part_o && cc->max_splits > 1) {
-      if (tune.key_splits > 0) ksplits = tune.key_splits;
-      else if (wpp * B < 256) ksplits = std::max(2, 512 / (wpp * B));   // one resident round of 512 workgroup slots, never more
-      else if (wpp * B < 384 && tiles >= 64) ksplits = 2;               // measured break-even
-      ksplits = std::min(std::min(ksplits, cc->max_splits), std::max(1, tiles / 4));
+    // Work split (attn_item): W items on `slots` resident workgroups (2 per CU).
+    const int W = wpp * B, slots = 2 * cu_count();
+    const int chunk = W >> 3, per_xcd = chunk + ((W & 7) ? 1 : 0);
+    int n_full = per_xcd, ksplits = 1;                                    // default: every item whole
+    const bool can_split = cc->part_o && cc->max_splits > 1 && tiles >= 8;
+    if (can_split) {
+      const int cap = std::min(cc->max_splits, std::max(1, tiles / 4));
+      if (tune.key_splits > 1) { n_full = 0; ksplits = std::min(tune.key_splits, cap); }             // forced: every item split
+      else if (tune.key_splits == 0) {
+        if (W < slots / 2) { n_full = 0; ksplits = std::min(std::max(2, slots / W), cap); }         // small grid: one resident round
+        else if (W < 3 * slots / 4 && tiles >= 64) { n_full = 0; ksplits = std::min(2, cap); }       // measured break-even
+        else if (W > slots && tune.tail_split) {
+          // large grid: whole rounds run whole; a last partial round of at most half the slots is split to fill them
+          const int full = (W / slots) * slots, rest = W - full;
+          if (rest > 0 && 2 * rest <= slots && tiles >= 16) { n_full = full / 8; ksplits = std::min(std::min(slots / rest, 4), cap); }
+        }
+      }
+      if (ksplits <= 1) { n_full = per_xcd; ksplits = 1; }
     }
-    if (ksplits > 1) {
-      hipLaunchKernelGGL(k_scattn_h2p<true>, dim3(wpp * B * ksplits), dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out,
-                         N, tiles, wpp, cd, ksplits, cc->part_o, cc->part_ml);
-      hipLaunchKernelGGL(k_scattn_merge, dim3(wpp, B), dim3(256), 0, s, cc->part_o, cc->part_ml, fus, cc->tail_wst_h2, vecs, out, tiles, ksplits);
-    } else {
-      hipLaunchKernelGGL(k_scattn_h2p<false>, grid4, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, 1,
-                         (float*)nullptr, (float*)nullptr);
-    }
+    const int max_tail = std::max(0, per_xcd - n_full);
+    const dim3 grid(8 * (std::min(n_full, per_xcd) + max_tail * ksplits));
+    hipLaunchKernelGGL(k_scattn_h2p, grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, W, n_full,
+                       ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias);
+    if (max_tail > 0)
+      hipLaunchKernelGGL(k_scattn_merge, dim3(8 * max_tail), dim3(256), 0, s, cc->part_o, cc->part_ml, fus, cc->tail_wst_h2, vecs, out,
+                         tiles, wpp, W, n_full, ksplits, cc->next_wst_h2, cc->next_bias);
   }
   else if (cd) hipLaunchKernelGGL(k_scattn_h2<true>, grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
   else hipLaunchKernelGGL(k_scattn_h2<false>, grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);

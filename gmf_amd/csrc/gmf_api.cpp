@@ -136,6 +136,16 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     t.key_splits = value;
     return GMF_OK;
   }
+  if (std::strcmp(name, "attn_tail_split") == 0) {     // 1 = split the last partial round of a large attention grid by keys (default 0)
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: attn_tail_split must be 0 or 1");
+    t.tail_split = value != 0;
+    return GMF_OK;
+  }
+  if (std::strcmp(name, "fused_linear") == 0) {        // 1 = two launches per layer (k_linear_h2 + attention with the next PointCN; default), 0 = four
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: fused_linear must be 0 or 1");
+    t.fused_linear = value != 0;
+    return GMF_OK;
+  }
   if (std::strcmp(name, "compat_cache") == 0) {
     GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: compat_cache must be 0 or 1");
     t.use_cache = value != 0;
@@ -303,6 +313,10 @@ static bool use_h2(const gmf_handle* h, const gmf_encoder_weights* w, bool dense
   return !dense && h->tune.scattn_variant >= 9 && w->front_wst_h2 && w->ctx_wst_h2 && w->attn_wst_h2 && w->ff_wst_h2 && w->tail_wst_h2;
 }
 
+static int run_scattn(gmf_handle* h, const gmf_encoder_weights* w, int l, const float* q, const float* k, const float* v,
+                      const float* pts8, const float* x2, float* out, int B, int N, hipStream_t st, const float* dense_compat,
+                      const gmf::CompatCache* cc);
+
 // Runs Fusion-2 + the spatial-consistency block of layer `l` given f,q,k,v.
 static int run_block_tail(gmf_handle* h, const gmf_encoder_weights* w, int l, const float* f, const float* q,
                           const float* k, const float* v, const float* pts8, const float* ctx_l, float* x1, float* x2,
@@ -322,6 +336,15 @@ static int run_block_tail(gmf_handle* h, const gmf_encoder_weights* w, int l, co
     GMF_HIP(gmf::launch_fusion_ff(x1, w->ff_wst + (size_t)l * w->ff_wst_stride, w->ff_vec + (size_t)l * w->ff_vec_stride,
                                   x2, B, tiles, st));
   }
+  return run_scattn(h, w, l, q, k, v, pts8, x2, out, B, N, st, dense_compat, cc);
+}
+
+// The attention launch of layer `l` (bracketed by the in-situ profiling events when enabled).
+static int run_scattn(gmf_handle* h, const gmf_encoder_weights* w, int l, const float* q, const float* k, const float* v,
+                      const float* pts8, const float* x2, float* out, int B, int N, hipStream_t st, const float* dense_compat,
+                      const gmf::CompatCache* cc) {
+  const int tiles = tiles_of(N);
+  const bool h2 = use_h2(h, w, dense_compat != nullptr);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (h->profile) {
     if (h->prof_used == h->prof_events.size()) {
@@ -368,8 +391,9 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   const bool want_cache = h2 && (L > 1) && h->tune.use_cache && n_tt * 4096 <= ((size_t)96 << 30);
   const size_t cache_need = want_cache ? arena_need(n_tt * 1024, 4) : 0;
   // key-split attention for small grids (fewer than 256 workgroups of 128 queries): partial-result workspace
-  const int kMaxSplits = 8;
-  const bool want_split = want_cache && ((tiles + 3) / 4) * B < 384 && tiles >= 8;
+  // (small grids: up to 8 splits of every query block; large grids: the last partial round of workgroups is split in 2..4)
+  const int kMaxSplits = ((tiles + 3) / 4) * B < 384 ? 8 : 4;
+  const bool want_split = want_cache && tiles >= 8;
   const size_t split_need = want_split ? arena_need((size_t)kMaxSplits * act, 4) + arena_need((size_t)kMaxSplits * B * tiles * 64, 4) : 0;
   const size_t need = 8 * arena_need(act, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +
                       5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4) + cache_need + split_need;
@@ -426,6 +450,38 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
 
   float* cur = featA;
   float* nxt = featB;
+  // Two launches per layer (default on the split-fp16 path with the cached, pipelined attention kernel): the layer's PointCN
+  // runs in the PREVIOUS layer's attention epilogue (layer 0: a small f-only kernel), so a layer is
+  //   k_linear_h2 : f -> Q', K, V (split-fp16 images) and x2 = Fusion-2(f)        (small grids: the three split-capable kernels)
+  //   k_scattn_h2p: Q', K, V, c, x2 -> f_{l+1} = ReLU(PointCN_{l+1}(fc_message(attention) + x2))   (last layer: the features)
+  const bool fuse = h2 && L > 0 && want_cache && h->tune.fused_linear && h->tune.scattn_variant == 18;
+  if (fuse) {
+    const bool one_kernel = ((tiles + 3) / 4) * B >= 256;      // below: key / hidden / output splits fill the chip better
+    GMF_HIP(gmf::launch_front_h2(h->tune, 3, corr_pos, w->front_wst_h2, w->front_vec, f, q, k, v, B, N, tiles, st));
+    for (int l = 0; l < L; ++l) {
+      const float* fw = w->front_wst_h2 + (size_t)l * w->front_wst_stride;
+      const float* fv = w->front_vec + (size_t)l * w->front_vec_stride;
+      const float* aw = w->attn_wst_h2 + (size_t)l * w->attn_wst_stride;
+      const float* av = w->attn_vec + (size_t)l * w->attn_vec_stride;
+      const float* ffw = w->ff_wst_h2 + (size_t)l * w->ff_wst_stride;
+      const float* ffv = w->ff_vec + (size_t)l * w->ff_vec_stride;
+      const float* ctx_l = ctxall + (size_t)l * tok;
+      if (one_kernel) {
+        GMF_HIP(gmf::launch_linear_h2(f, fw, fv, ctx_l, aw, av, ffw, ffv, q, k, v, x2, B, N, tiles, T, tt, st));
+      } else {
+        GMF_HIP(gmf::launch_front_h2(h->tune, 2, f, fw, fv, f, q, k, v, B, N, tiles, st));
+        GMF_HIP(gmf::launch_fusion_attn_h2(true, f, ctx_l, aw, av, x1, B, N, tiles, T, tt, st));
+        GMF_HIP(gmf::launch_fusion_ff_h2(h->tune, x1, ffw, ffv, x2, B, tiles, st, cc.part_o, cc.max_splits));
+      }
+      const bool last = (l + 1 == L);
+      cc.tail_wst_h2 = w->tail_wst_h2 + (size_t)l * w->tail_wst_stride;
+      cc.next_wst_h2 = last ? nullptr : w->front_wst_h2 + (size_t)(l + 1) * w->front_wst_stride;
+      cc.next_bias = last ? nullptr : w->front_vec + (size_t)(l + 1) * w->front_vec_stride;
+      if (int rc = run_scattn(h, w, l, q, k, v, pts8, x2, last ? cur : f, B, N, st, nullptr, &cc)) return rc;
+    }
+    GMF_HIP(gmf::launch_head(cur, w->head_wst, w->head_vec, logits, feat_n, feat, B, N, tiles, st));
+    return GMF_OK;
+  }
   if (L == 0) {
     // degenerate: features are layer0(corr_pos) only
     GMF_HIP(gmf::launch_front(1, corr_pos, w->front_wst, w->front_vec, cur, q, k, v, B, N, tiles, st));

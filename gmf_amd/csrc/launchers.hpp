@@ -11,6 +11,10 @@ struct CompatCache {
   float* part_o;              // key-split workspace: [max_splits][B * tiles] P32 tile images (or nullptr)
   float* part_ml;             // ... [max_splits][B * tiles][32][2] row maximum, row sum
   int max_splits;
+  // when non-null, the attention epilogue applies the NEXT layer's PointCN (4 split-fp16 weight stages + bias) to the block
+  // output and stores f_{l+1} instead of feat (k_scattn_h2p / k_scattn_merge only)
+  const float* next_wst_h2 = nullptr;
+  const float* next_bias = nullptr;
 };
 
 // Per-handle tuning knobs (gmf_set_tuning).  Every value selects between forms that compute the same result up to
@@ -19,9 +23,13 @@ struct Tuning {
   int scattn_variant = 18;   // 18 = cached, software-pipelined split-fp16 attention; 9 = split-fp16 without the pipelining
                              // (and without the cache when compat_cache = 0); 0 = fp32 MFMA path for every stage
   bool use_cache = true;     // compat cache (built once per batch) for variants 9 / 18
-  int key_splits = 0;        // attention key splits on small grids: 0 = automatic, 1 = off, n = forced
+  int key_splits = 0;        // attention key splits: 0 = automatic (small grids, and the tail of large ones), 1 = off, n = forced
+  bool tail_split = false;   // large grids: split the last partial round of attention workgroups by keys.  Off by default: a CU
+                             // left with one resident workgroup runs it almost twice as fast, so the "half-empty last round" costs
+                             // little (32 x 5000: 1.10 ms split vs 1.07 ms whole, measured)
   int ff_split = 0;          // feed-forward hidden splits on small grids: 0 = automatic, 1 = off, 2 / 4 / 8 = forced
   bool front_split = true;   // small grids: one workgroup per output (Q' + f | K | V) of k_front_h2
+  bool fused_linear = true;  // one kernel per layer for Q'/K/V + Fusion-2 (k_linear_h2) with the next PointCN in the attention epilogue
   int conv_patch = 1;        // stride-1 3x3 convolutions: 1 = LDS patch kernel (automatic form), 2 = never three workgroups per CU, 0 = gather kernel
   int nms_binned = 1;        // 1 = grid-binned NMS candidates on large grids, 2 = always, 0 = all pairs
   bool topk_select = true;   // radix select of the S seeds (false = full bitonic sort)
@@ -53,6 +61,10 @@ hipError_t launch_fusion_ff_w(const float* x1, const float* wst, const float* ve
 hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
 hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
                            float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s);
+// mode 3: corr_pos -> layer0 -> PointCN -> f only.  launch_linear_h2: all linear stages of one layer from f (k_linear_h2)
+hipError_t launch_linear_h2(const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
+                            const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec, float* q,
+                            float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
 hipError_t launch_ctx_prep_h2(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
                               int ttiles, int sets, int wst_stride, int vec_stride, hipStream_t s);
 hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,

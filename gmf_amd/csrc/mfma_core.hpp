@@ -296,17 +296,17 @@ struct StageStream {
 // younger vector-memory operations only make the wait more conservative).
 template <int NBUF>
 struct StageRing {
-  const float* seg_ptr[3];
-  int seg_end[3];
+  const float* seg_ptr[4];
+  int seg_end[4];
   float* base;
   int issued, consumed, total;
   int wave, lane;
 
   GMF_DEVINL void init(float* lds_base, int wave_, int lane_, const float* p0, int n0, const float* p1 = nullptr,
-                       int n1 = 0, const float* p2 = nullptr, int n2 = 0) {
-    seg_ptr[0] = p0; seg_ptr[1] = p1; seg_ptr[2] = p2;
-    seg_end[0] = n0; seg_end[1] = n0 + n1; seg_end[2] = n0 + n1 + n2;
-    total = seg_end[2];
+                       int n1 = 0, const float* p2 = nullptr, int n2 = 0, const float* p3 = nullptr, int n3 = 0) {
+    seg_ptr[0] = p0; seg_ptr[1] = p1; seg_ptr[2] = p2; seg_ptr[3] = p3;
+    seg_end[0] = n0; seg_end[1] = n0 + n1; seg_end[2] = n0 + n1 + n2; seg_end[3] = n0 + n1 + n2 + n3;
+    total = seg_end[3];
     base = lds_base; issued = 0; consumed = 0;
     wave = wave_; lane = lane_;
   }
@@ -315,7 +315,8 @@ struct StageRing {
       const float* g;
       if (issued < seg_end[0]) g = seg_ptr[0] + (size_t)issued * kStageFloats;
       else if (issued < seg_end[1]) g = seg_ptr[1] + (size_t)(issued - seg_end[0]) * kStageFloats;
-      else g = seg_ptr[2] + (size_t)(issued - seg_end[1]) * kStageFloats;
+      else if (issued < seg_end[2]) g = seg_ptr[2] + (size_t)(issued - seg_end[1]) * kStageFloats;
+      else g = seg_ptr[3] + (size_t)(issued - seg_end[2]) * kStageFloats;
       float* dst = base + (issued % NBUF) * kStageFloats;
 #pragma unroll
       for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);

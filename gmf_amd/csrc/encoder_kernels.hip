@@ -1559,7 +1559,9 @@ hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, 
       const int cap = std::min(cc->max_splits, std::max(1, tiles / 4));
       if (tune.key_splits > 1) { n_full = 0; ksplits = std::min(tune.key_splits, cap); }             // forced: every item split
       else if (tune.key_splits == 0) {
-        if (W < slots / 2) { n_full = 0; ksplits = std::min(std::max(2, slots / W), cap); }         // small grid: one resident round
+        // small grid: ONE workgroup per CU - a workgroup alone on its CU runs its tiles almost twice as fast as two
+        // co-resident ones (B = 1, N = 5000: 6 splits = 240 workgroups 1.64 ms per forward, 8 splits = 320 workgroups 1.75 ms)
+        if (W < slots / 2) { n_full = 0; ksplits = std::min(std::max(2, (slots / 2) / W), cap); }
         else if (W < 3 * slots / 4 && tiles >= 64) { n_full = 0; ksplits = std::min(2, cap); }       // measured break-even
         else if (W > slots && tune.tail_split) {
           // large grid: whole rounds run whole; a last partial round of at most half the slots is split to fill them

@@ -24,19 +24,29 @@ for k, v in knobs:
     _lib.handle_for(0).call("gmf_set_tuning", k.encode(), int(v))
 b = synthetic.synthetic_batch(list(range(B)), N=N, T=196)
 args = [b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")]
+data = {k: b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+data["testing"] = True
+if os.environ.get("FULL", "0") == "1":          # whole forward (encoder + pose head) instead of the encoder alone
+    class _M:
+        @staticmethod
+        def encode(*a):
+            return model(data)
+    run = _M
+else:
+    run = model
 for _ in range(2):
-    model.encode(*args)
+    run.encode(*args)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(reps):
-    model.encode(*args)
+    run.encode(*args)
 torch.cuda.synchronize()
 print(f"encode: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per pass (B={B}, N={N}, knobs={knobs})")
 from torch.profiler import profile, ProfilerActivity   # noqa: E402
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     for _ in range(reps):
-        model.encode(*args)
+        run.encode(*args)
     torch.cuda.synchronize()
-rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:12]
+rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:int(os.environ.get('ROWS', '12'))]
 for e in rows:
     print(f"{e.key[:70]:70s} n={e.count:4d} avg={e.device_time_total / e.count:9.1f} us total={e.device_time_total / reps / 1e3:7.3f} ms/pass")

@@ -816,6 +816,16 @@ int gmf_bias_relu_nhwc(gmf_handle* h, float* y, const float* bias, const float* 
   return GMF_OK;
 }
 
+int gmf_stem_forward(gmf_handle* h, const float* x, long long sb, long long sc, long long sh, long long sw, const float* wimg,
+                     const float* bias, float* y, int B, int H, int W, gmf_stream_t stream) {
+  GMF_REQUIRE(h && x && wimg && bias && y, GMF_ERR_BAD_ARG, "stem_forward: null pointer");
+  GMF_REQUIRE(B > 0 && H > 0 && W > 0, GMF_ERR_UNSUPPORTED_SHAPE, "stem_forward: empty input");
+  GMF_REQUIRE(B <= 65535, GMF_ERR_UNSUPPORTED_SHAPE, "stem_forward: at most 65535 images per call");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_stem_h2(x, (long)sb, (long)sc, (long)sh, (long)sw, wimg, bias, y, B, H, W, S(stream)));
+  return GMF_OK;
+}
+
 int gmf_conv_nhwc(gmf_handle* h, const float* x, const float* wimg, const float* bias, const float* residual, float* y,
                   int B, int H, int W, int cin, int cout, int ksize, int stride, int relu, gmf_stream_t stream) {
   GMF_REQUIRE(h && x && wimg && bias && y, GMF_ERR_BAD_ARG, "conv_nhwc: null pointer");

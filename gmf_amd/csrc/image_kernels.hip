@@ -284,6 +284,148 @@ k_bias_relu_nhwc(float* __restrict__ y, const float* __restrict__ bias, const fl
   reinterpret_cast<float4*>(y)[idx] = v;
 }
 
+// =========================================================================================
+// k_stem_h2: the ResNet stem in one kernel (GMF_PointDSC/models/resnet.py:198-204: conv1 7x7 stride 2 pad 3, 3 -> 64
+// channels, BatchNorm (folded into the weights / bias), ReLU, max-pool 3x3 stride 2 pad 1).
+//   input  x [B, 3, H, W] with arbitrary element strides (NCHW as the reference hands it over, or a channels-last view)
+//   output y [B, Hp, Wp, 64] NHWC fp32, Hc = (H - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1 (same for W)
+// A workgroup produces an 8 x 8 tile of pooled pixels x 64 channels:
+//   1. the 39 x 39 x 3 input patch behind the 17 x 17 convolution outputs the tile's pool windows touch is loaded to LDS,
+//      pixel-major ([y][x][c], zeros outside the image), coalesced along x;
+//   2. the convolution is an implicit GEMM on the f16 MFMA with split-fp16 operands (three products per multiply-add, fp32
+//      accumulate; weights as an image of 256 W): M = 289 convolution pixels in 10 tiles of 32 (wave w owns tiles w, w + 4,
+//      w + 8), N = 64 channels (2 blocks), K = 7 kernel rows x 24 (21 = 7 taps x 3 channels + 3 zero weights) = 168, padded
+//      to 11 k-steps of 16.  A k-step's 8 values of a lane are 8 CONSECUTIVE floats of one patch row (the kernel row's 21
+//      values are contiguous in the pixel-major patch), read with four ds_read_b64 and split to fp16 hi / lo in registers;
+//      the weight fragments of a k-step are loaded from global memory (L2-resident: 44 KiB) once per wave and k-step and
+//      serve its three pixel tiles;
+//   3. the convolution tile goes to LDS (over the patch), and the pool + bias + ReLU pass (max commutes with the monotone
+//      bias + ReLU) writes 64-channel rows.
+// Weight image (packing.stem_image): 16-byte unit ((ks * 2 + blk) * 2 + plane) * 64 + lane, lane (h, j) holding
+// W'[32 blk + j][k = 16 ks + 8 h .. + 7], k = 24 ky + 3 kx + c.
+// =========================================================================================
+constexpr int kStemPT = 8;                          // pooled tile edge
+constexpr int kStemCT = 2 * kStemPT + 1;            // convolution tile edge (17)
+constexpr int kStemIT = 2 * kStemCT + 5;            // input patch edge (39)
+constexpr int kStemRow = kStemIT * 3 + 3;           // patch row stride in floats (120: even, so 8-byte reads stay aligned)
+constexpr int kStemRows = kStemIT + 1;              // + one zero row: the padded k-steps (ky = 7) read below the patch
+constexpr int kStemCS = 68;                         // convolution tile row stride in floats (64 channels + 4)
+constexpr int kStemKS = 11;
+
+__global__ void __launch_bounds__(256, 2)
+k_stem_h2(const float* __restrict__ x, long sb, long sc, long sh, long sw, const float* __restrict__ wimg,
+          const float* __restrict__ bias, float* __restrict__ y, int H, int W, int Hc, int Wc, int Hp, int Wp) {
+  __shared__ __attribute__((aligned(16))) float lds[kStemCT * kStemCT * kStemCS];      // 19 652 floats >= the 4 800 of the patch
+  static_assert(kStemRows * kStemRow <= kStemCT * kStemCT * kStemCS, "the patch fits under the convolution tile");
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int img = blockIdx.z;
+  const int py0 = blockIdx.y * kStemPT, px0 = blockIdx.x * kStemPT;     // first pooled pixel of the tile
+  const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;                       // first convolution pixel (may be -1)
+  const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;                       // first input pixel
+  // ---- 1. input patch -> LDS --------------------------------------------------------------------------------------
+  const float* xi = x + (size_t)img * sb;
+  for (int e = threadIdx.x; e < kStemRows * kStemRow; e += 256) {
+    const int r = e / kStemRow, q = e - r * kStemRow;
+    const int px = q / 3, c = q - 3 * px;
+    const int yy = iy0 + r, xx = ix0 + px;
+    float v = 0.f;
+    if (r < kStemIT && px < kStemIT && yy >= 0 && yy < H && xx >= 0 && xx < W) v = xi[(size_t)c * sc + (size_t)yy * sh + (size_t)xx * sw];
+    lds[e] = v;
+  }
+  __syncthreads();
+  // ---- 2. implicit GEMM ---------------------------------------------------------------------------------------------
+  constexpr int NPIX = kStemCT * kStemCT;          // 289
+  int aoff[3];                                     // patch offset (floats) of the window origin of this lane's pixel, per tile
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int p = min(32 * (wave + 4 * t) + i, NPIX - 1);
+    const int cy = p / kStemCT, cx = p - cy * kStemCT;
+    aoff[t] = (2 * cy) * kStemRow + (2 * cx) * 3;
+  }
+  const int n_tiles = (wave + 8 < (NPIX + 31) / 32) ? 3 : 2;      // 10 tiles: waves 0, 1 own three
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) { acc[t][0] = zero16(); acc[t][1] = zero16(); }
+  const f16x8* wp = reinterpret_cast<const f16x8*>(wimg) + lane;
+  f16x8 wcur[2][2], wnxt[2][2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) { wcur[blk][0] = wp[(blk * 2 + 0) * 64]; wcur[blk][1] = wp[(blk * 2 + 1) * 64]; }
+#pragma unroll
+  for (int ks = 0; ks < kStemKS; ++ks) {
+    if (ks + 1 < kStemKS) {
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        wnxt[blk][0] = wp[(((ks + 1) * 2 + blk) * 2 + 0) * 64];
+        wnxt[blk][1] = wp[(((ks + 1) * 2 + blk) * 2 + 1) * 64];
+      }
+    }
+    const int k0 = 16 * ks + 8 * h, ky = k0 / 24, ko = k0 - 24 * ky;       // per K-half: one kernel row, offset 0 / 8 / 16
+    const int koff = ky * kStemRow + ko;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (t < n_tiles) {
+        const float2* ap = reinterpret_cast<const float2*>(lds + aoff[t] + koff);
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float2 v = ap[j]; a[2 * j] = v.x; a[2 * j + 1] = v.y; }
+        f16x8 ah, al;
+        split8h(a, ah, al);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) mma3(acc[t][blk], ah, al, wcur[blk][0], wcur[blk][1]);
+      }
+    }
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) { wcur[blk][0] = wnxt[blk][0]; wcur[blk][1] = wnxt[blk][1]; }
+  }
+  __syncthreads();                                 // every wave is done reading the patch
+  // ---- 3. convolution tile -> LDS: D = mfma(A = pixels, B = weights) has the CHANNEL on the lane (32 blk + i) and the
+  //         pixels 8 (r >> 2) + 4 h + (r & 3) of the tile in the registers
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    if (t < n_tiles) {
+      const int pbase = 32 * (wave + 4 * t);
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = pbase + 8 * (r >> 2) + 4 * h + (r & 3);
+          if (p < NPIX) lds[p * kStemCS + 32 * blk + i] = acc[t][blk][r] * (1.0f / 256.0f);
+        }
+    }
+  }
+  __syncthreads();
+  // ---- pool 3x3 stride 2 pad 1 + bias + ReLU ------------------------------------------------------------------------
+  for (int e = threadIdx.x; e < kStemPT * kStemPT * 16; e += 256) {
+    const int c4 = e & 15, pp = e >> 4;
+    const int ty = pp / kStemPT, tx = pp - ty * kStemPT;
+    const int py = py0 + ty, px = px0 + tx;
+    if (py >= Hp || px >= Wp) continue;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ly = 2 * ty + dy, lx = 2 * tx + dx;          // tile-local convolution pixel
+        const int cy = cy0 + ly, cx = cx0 + lx;
+        if (cy < 0 || cy >= Hc || cx < 0 || cx >= Wc) continue;
+        const float4 v = *reinterpret_cast<const float4*>(lds + (ly * kStemCT + lx) * kStemCS + 4 * c4);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    const float4 b = reinterpret_cast<const float4*>(bias)[c4];
+    float4 o = make_float4(fmaxf(m.x + b.x, 0.f), fmaxf(m.y + b.y, 0.f), fmaxf(m.z + b.z, 0.f), fmaxf(m.w + b.w, 0.f));
+    reinterpret_cast<float4*>(y + (((size_t)img * Hp + py) * Wp + px) * 64)[c4] = o;
+  }
+}
+
+hipError_t launch_stem_h2(const float* x, long sb, long sc, long sh, long sw, const float* wimg, const float* bias, float* y,
+                          int B, int H, int W, hipStream_t s) {
+  const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;
+  const dim3 grid((Wp + kStemPT - 1) / kStemPT, (Hp + kStemPT - 1) / kStemPT, B);
+  hipLaunchKernelGGL(k_stem_h2, grid, dim3(256), 0, s, x, sb, sc, sh, sw, wimg, bias, y, H, W, Hc, Wc, Hp, Wp);
+  return hipGetLastError();
+}
+
 hipError_t launch_bias_relu_nhwc(float* y, const float* bias, const float* residual, long n_pixels, int C, hipStream_t s) {
   const long total4 = n_pixels * (C / 4);
   hipLaunchKernelGGL(k_bias_relu_nhwc, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, y, bias, residual, total4, C / 4);

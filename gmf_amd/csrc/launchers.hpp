@@ -98,6 +98,8 @@ hipError_t launch_transformation_loss(const float* trans, const float* gt_trans,
                                       float* out, hipStream_t s);
 
 // image encoder epilogue (row f-1): image_kernels.hip
+hipError_t launch_stem_h2(const float* x, long sb, long sc, long sh, long sw, const float* wimg, const float* bias, float* y,
+                          int B, int H, int W, hipStream_t s);
 hipError_t launch_bias_relu_nhwc(float* y, const float* bias, const float* residual, long n_pixels, int C, hipStream_t s);
 hipError_t launch_conv_nhwc_h2(const Tuning& tune, const float* x, const float* wimg, const float* bias, const float* residual, float* y, int B,
                                int H, int W, int cin, int cout, int ks, int stride, int relu, hipStream_t s);

@@ -115,6 +115,21 @@ def conv_image(W: torch.Tensor, stride: int = 1) -> torch.Tensor:
     return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
 
 
+def stem_image(W: torch.Tensor) -> torch.Tensor:
+    """[64, 3, 7, 7] fp32 (BatchNorm folded) -> split-fp16 image of 256 W for k_stem_h2 (image_kernels.hip).
+
+    K = 7 kernel rows x 24 (k = 24 ky + 3 kx + c; the 3 slots behind each row's 21 taps are zero) padded to 176 = 11 k-steps;
+    16-byte unit ((ks * 2 + blk) * 2 + plane) * 64 + lane, lane = 32 h + j holding W[32 blk + j][16 ks + 8 h .. + 7]."""
+    co, ci, kh, kw = W.shape
+    assert (co, ci, kh, kw) == (64, 3, 7, 7), W.shape
+    Wk = torch.zeros(64, 176, dtype=torch.float32, device=W.device)
+    Wk[:, :168].view(64, 7, 24)[:, :, :21] = (W.float() * H2_SCALE).permute(0, 2, 3, 1).reshape(64, 7, 21)   # [co, ky, (kx, c)]
+    hi, lo = split_fp16(Wk, "BatchNorm-folded stem weight (x 256)")
+    g = torch.stack([hi, lo]).reshape(2, 2, 32, 11, 2, 8)                    # [plane, blk, j, ks, h, e]
+    g = g.permute(3, 1, 0, 4, 2, 5)                                          # [ks, blk, plane, h, j, e]
+    return g.contiguous().view(torch.int16).reshape(-1).view(torch.float32)
+
+
 def fold_bn(W, b, sd, p, eps=1e-5):
     """conv1x1 (W [out,in], b) followed by eval BatchNorm `p` -> equivalent (W', b')."""
     scale = sd[p + "weight"] * torch.rsqrt(sd[p + "running_var"] + eps)

@@ -81,6 +81,12 @@ class _FusedResNet:
             return spec
 
         self.stem = fold(bb.conv1, bb.bn1)
+        if native_convs:
+            try:
+                self.stem["img"] = packing.stem_image(self.stem["w"].cpu()).to(self.stem["w"].device)
+            except ValueError as e:          # folded weight outside the fp16 range: the stem stays on MIOpen (fp32)
+                import warnings
+                warnings.warn(f"{e}  The stem convolution runs on MIOpen's fp32 kernel instead.", RuntimeWarning)
         self.blocks = []
         for layer in (bb.layer1, bb.layer2):
             for blk in layer:
@@ -131,8 +137,25 @@ class _FusedResNet:
         y = y + c["b"][None, :, None, None]
         return y if residual is None else y + residual
 
+    def _stem(self, x):
+        """conv1 7x7/2 + folded BatchNorm + ReLU + max-pool 3x3/2 (resnet.py:198-204) in one HIP kernel; reads the image
+        through its strides (NCHW as the reference passes it, or any view), writes NHWC."""
+        if "img" not in self.stem:
+            return F.max_pool2d(self._conv(x.contiguous(memory_format=torch.channels_last), self.stem), 3, 2, 1)
+        if x.dtype != torch.float32:
+            raise RuntimeError(f"gmf_amd image encoder: images must be float32, got {x.dtype}")
+        B, _, H, W = x.shape
+        Hp, Wp = ((H - 1) // 2) // 2 + 1, ((W - 1) // 2) // 2 + 1
+        y = torch.empty((B, 64, Hp, Wp), device=x.device, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+        h, st = handle_and_stream(x)
+        for b0 in range(0, B, 65535):
+            xb, yb = x[b0:b0 + 65535], y[b0:b0 + 65535]
+            h.call("gmf_stem_forward", xb.data_ptr(), xb.stride(0), xb.stride(1), xb.stride(2), xb.stride(3),
+                   self.stem["img"].data_ptr(), self.stem["b"].data_ptr(), yb.data_ptr(), xb.shape[0], H, W, st)
+        return y
+
     def __call__(self, x):
-        x = F.max_pool2d(self._conv(x, self.stem), 3, 2, 1)
+        x = self._stem(x)
         for c1, c2, ds in self.blocks:
             idt = x if ds is None else self._conv(x, ds, relu=False)
             x = self._conv(self._conv(x, c1), c2, residual=idt)
@@ -245,14 +268,13 @@ class NonLocalNet(nn.Module):
             f = self.image_encoder(image)
         else:
             enc = self._fused_image_encoder()
-            image = image.contiguous(memory_format=torch.channels_last)
             f = self._graphed_encoder(enc, image) if self.graph_image_encoder else enc(image)
         return f.flatten(2).permute(0, 2, 1).contiguous()
 
     graph_image_encoder = True
 
     def _graphed_encoder(self, enc, image):
-        key = (tuple(image.shape), image.device, self._img_fused_version)
+        key = (tuple(image.shape), tuple(image.stride()), image.device, self._img_fused_version)
         cache = self.__dict__.setdefault("_img_graphs", {})
         ent = cache.get(key)
         if ent is None:

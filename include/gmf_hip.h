@@ -287,6 +287,14 @@ int gmf_transformation_loss(gmf_handle* h, const float* trans, const float* gt_t
 int gmf_bias_relu_nhwc(gmf_handle* h, float* y, const float* bias, const float* residual, long long n_pixels, int C,
                        gmf_stream_t stream);
 
+/* The ResNet stem in one kernel (GMF_PointDSC/models/resnet.py:198-204): conv1 7x7 stride 2 pad 3 (3 -> 64 channels) with
+ * the BatchNorm folded in, ReLU and max-pool 3x3 stride 2 pad 1.  x [B,3,H,W] fp32 with element strides (sb, sc, sh, sw) -
+ * NCHW as the reference passes it, or any view; y [B,Hp,Wp,64] NHWC fp32 with Hc = (H-1)/2+1, Hp = (Hc-1)/2+1 (same for W).
+ * wimg: the folded weights as a split-fp16 image of 256 W (gmf_amd/packing.py: stem_image), bias [64].  Implicit GEMM on the
+ * f16 MFMA with split-fp16 operands, fp32 accumulate; the pooled tile is written once. */
+int gmf_stem_forward(gmf_handle* h, const float* x, long long sb, long long sc, long long sh, long long sw, const float* wimg,
+                     const float* bias, float* y, int B, int H, int W, gmf_stream_t stream);
+
 /* Convolution of the ResNet-34 layer1 / layer2 shapes (GMF_PointDSC/models/resnet.py:36-75, 144-170) as an implicit GEMM on
  * the f16 MFMA with split-fp16 operands: x [B,H,W,cin] NHWC fp32 -> y [B,Ho,Wo,cout] NHWC fp32 (pad = ksize / 2),
  *   y = conv(x, W) + bias (+ residual [B,Ho,Wo,cout]) -> ReLU if relu != 0.

@@ -514,10 +514,15 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
   const float* pair_base = f_in + (size_t)pair * tiles * (32 * C);
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
 
-  StageRing<2> ss;
+  // 4-slot ring, three stages in flight.  The waits are COUNTED (vmcnt counts loads, LDS-DMA pieces and stores alike, in
+  // issue order): during the Q'/K/V stages a wave has, behind the pieces of the stage it acquires, the pieces of the next two
+  // stages and the 4 stores of each of the last three stages - vmcnt(20) in steady state - so neither the younger stages nor
+  // the stores (whose acknowledgement takes a memory round trip) are waited for at a stage barrier.  For the counts to hold
+  // on every wave, the padding waves of a pair's last workgroup store too: they recompute the pair's last tile and write the
+  // same bits to the same place as the wave that owns it.
+  StageRing<4> ss;
   ss.init(lds, wave, lane, front_wst + 4 * kStageFloats, 12, attn_wst, 2,
           ctx_img + (size_t)pair * ttiles * kStageFloats, ttiles, attn_wst + 2 * kStageFloats, 2);
-  ss.prime();
 
   // ---- Q', K, V from f ---------------------------------------------------------------------------------------------
   {
@@ -527,33 +532,40 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
       load_frag_p32<CF>(f, f_in + toff, lane);
       fx.set(f);
     }
+    // every bias of the phase is loaded up front: a load inside the stage loop would sit between the DMA pieces in the
+    // vmcnt queue and the compiler's wait for it would drain the stages in flight
+    float bqk[2][CF], bvv[4];
+    load_vec_frag<CF>(bqk[0], front_vec + 1 * C, h);
+    load_vec_frag<CF>(bqk[1], front_vec + 2 * C, h);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) bvv[db] = front_vec[3 * C + 32 * db + i];
+    ss.prime();                                  // AFTER the loads above: their wait then leaves the three primed stages in flight
 #pragma unroll
     for (int which = 0; which < 2; ++which) {   // Q', K
       float* dst = (which == 0 ? q_out : k_out) + toff;
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
-        // the bias is requested BEFORE the acquire: a load issued after it would be younger than the stage's DMA pieces, and
-        // the compiler's wait for the bias would then wait for the next stage to land as well (no look-ahead left)
-        float b[16], t[16];
-        load_vec_block(b, front_vec + (1 + which) * C, mb, h);
-        const f16x8* lw = as_h2(ss.acquire());
+        constexpr int kYounger[4] = {8, 12, 16, 20};
+        const int sidx = 4 * which + mb;                       // stage index (compile-time: the loops are unrolled)
+        const f16x8* lw = as_h2(sidx == 0 ? ss.acquire_counted<kYounger[0]>() : sidx == 1 ? ss.acquire_counted<kYounger[1]>()
+                                : sidx == 2 ? ss.acquire_counted<kYounger[2]>() : ss.acquire_counted<kYounger[3]>());
         f32x16 acc = zero16();
         mma_wx_h2<8>(acc, lw, fx);
+        float t[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, b[r]);
-        if (active) store_block_h2(dst, mb, t, lane);
+        for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bqk[which][16 * mb + r]);
+        store_block_h2(dst, mb, t, lane);
       }
     }
 #pragma unroll
     for (int db = 0; db < 4; ++db) {             // V (feature on lane)
-      const float bv = front_vec[3 * C + 32 * db + i];
-      const f16x8* lw = as_h2(ss.acquire());
+      const f16x8* lw = as_h2(ss.acquire_counted<20>());
       f32x16 acc = zero16();
       mma_xw_h2<8>(acc, lw, fx);
       float t[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bv);
-      if (active) store_block_h2(v_out + toff, db, t, lane);
+      for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bvv[db]);
+      store_block_h2(v_out + toff, db, t, lane);
     }
   }
 

@@ -327,6 +327,18 @@ struct StageRing {
 #pragma unroll
     for (int k = 0; k < NBUF - 1; ++k) issue_one();
   }
+  // acquire with a caller-counted wait: YOUNGER is a lower bound of the vector-memory operations (DMA pieces of later stages,
+  // loads, stores - vmcnt counts them all, in issue order) this wave has issued after the pieces of the stage being acquired.
+  // Lets stores and later stages stay in flight across the stage barrier.
+  template <int YOUNGER>
+  GMF_DEVINL const float4* acquire_counted() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+    __syncthreads();
+    const float* cur = base + (consumed % NBUF) * kStageFloats;
+    ++consumed;
+    issue_one();
+    return reinterpret_cast<const float4*>(cur) + lane;
+  }
   GMF_DEVINL const float4* acquire() {
     if (issued - consumed == NBUF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NBUF - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

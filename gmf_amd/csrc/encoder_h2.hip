@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "enc_common.hpp"
+#include "enc_ff.hpp"
 #include "launchers.hpp"
 
 namespace gmf {
@@ -23,16 +24,15 @@ constexpr int kRing = GMF_H2_RING;   // LDS ring depth of the weight / context s
 //   vecs (fp32): bp | bq' | bk | bv | b0 | W0 image (fp32, K=8: layer0 stays on the f32 MFMA, 4 MFMAs per block)
 //   outputs: f as fp32 P32 image; Q', K, V as fp16x2 plane images (16 KiB per tile).
 // =========================================================================================
+// (bx, pair): the workgroup's row block and pair; zsel = -1 (all outputs) or the ONE output (0 = Q' (+ f), 1 = K, 2 = V) it
+// produces.  `lds`: kRing * 16 KiB owned by the workgroup.
 template <int MODE>
-__global__ void __launch_bounds__(256, 2)
-k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const float* __restrict__ vecs,
-           float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out,
-           float* __restrict__ v_out, int N, int tiles) {
-  __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
+GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const int zsel_in, const float* __restrict__ in,
+                              const float* __restrict__ wst, const float* __restrict__ vecs, float* __restrict__ f_out,
+                              float* __restrict__ q_out, float* __restrict__ k_out, float* __restrict__ v_out, int N, int tiles) {
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = blockIdx.y;
-  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const int tile_raw = bx * kWavesPerWG + wave;
   const bool active = tile_raw < tiles;
   const int tile = active ? tile_raw : tiles - 1;
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
@@ -40,8 +40,8 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
   // gridDim.z == 3 (small grids): workgroup z recomputes PointCN (MODE 0 / 1) and produces ONE of Q' (z = 0, it also stores
   // f), K, V - 8 (MODE 2: 4) weight stages instead of 16 (12) per workgroup, three times the workgroups.
   // MODE 3: corr_pos -> layer0 -> PointCN -> f only (the first layer's f when the later PointCNs run in the attention epilogue).
-  const bool zsplit = (MODE != 3) && gridDim.z == 3;
-  const int zsel = zsplit ? (int)blockIdx.z : -1;
+  const bool zsplit = (MODE != 3) && zsel_in >= 0;
+  const int zsel = zsplit ? zsel_in : -1;
   StageRing<kRing> ss;
   if (MODE == 3) ss.init(lds, wave, lane, wst, 4);
   else if (MODE == 2 && zsplit) ss.init(lds, wave, lane, wst + (4 + 4 * zsel) * kStageFloats, 4);
@@ -128,6 +128,16 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
   }
 }
 
+template <int MODE>
+__global__ void __launch_bounds__(256, 2)
+k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const float* __restrict__ vecs,
+           float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out,
+           float* __restrict__ v_out, int N, int tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
+  front_h2_body<MODE>(lds, blockIdx.x, blockIdx.y, gridDim.z == 3 ? (int)blockIdx.z : -1, in, wst, vecs, f_out, q_out, k_out, v_out,
+                      N, tiles);
+}
+
 // =========================================================================================
 // k_ctx_prep_h2: output per token tile (4096 floats): Kc | Vc as fp16x2 images for d_head = 64:
 //   Kc: unit ((plane*4 + s)*64 + lane), 2 planes x 4 k-steps = 2048 floats ; Vc: unit ((plane*4 + slot)*64 + lane),
@@ -207,14 +217,12 @@ k_ctx_prep_h2(const float* __restrict__ ctx, const float* __restrict__ wst, cons
 //   vecs: query taps | gamma | beta | bo (fp32).  P is scaled by 2^10 as in k_scattn_h2.
 // =========================================================================================
 template <bool PE>
-__global__ void __launch_bounds__(256, 2)
-k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_img, const float* __restrict__ wst,
-                 const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
-  __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
+GMF_DEVINL void fusion_attn_h2_body(float* lds, const int bx, const int pair, const float* __restrict__ xin,
+                                    const float* __restrict__ ctx_img, const float* __restrict__ wst,
+                                    const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = blockIdx.y;
-  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const int tile_raw = bx * kWavesPerWG + wave;
   const bool active = tile_raw < tiles;
   const int tile = active ? tile_raw : tiles - 1;
   const float* pair_base = xin + (size_t)pair * tiles * (32 * C);
@@ -319,107 +327,28 @@ k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_im
   }
 }
 
-// The GEGLU chunk loop of the feed-forward, software-pipelined inside the wave (shared by k_fusion_ff_h2p and k_linear_h2):
-//   y[mb] += W2[:, chunk] (value_c * GELU(gate_c)) for the hidden chunks [c_begin, c_begin + NCH), value / gate = W1 nx + b1.
-// `lds` is a ring of NB = 4 stages owned by the workgroup (the caller has made sure no wave still reads it); on return
-// every DMA piece this wave issued has landed.  Stage order A0 G0 | A1 G1 W2_0 | ... addressed into the unchanged blob
-// (16 x (A | G | W2)); past the end the last stage is re-fetched into a free slot instead of branching.
-GMF_DEVINL void ff_chunks(const FragH2<8>& nx, f32x16 (&y)[4], float* lds, const float* __restrict__ wst,
-                          const float* __restrict__ b1a, const float* __restrict__ b1g, const int wave, const int lane,
-                          const int h, const int c_begin, const int NCH) {
-  constexpr int NB = 4;
-  // stage n of the consumption order -> stage index in the blob (16 x (A | G | W2))
-  int n_issued = 0, n_used = 0;
-  auto blob_stage = [&](int n) {
-    n = min(n, 3 * NCH - 1);
-    if (n < 2) return 3 * c_begin + n;
-    if (n == 3 * NCH - 1) return 3 * c_begin + n;
-    const int m = n - 2, c = m / 3, k = m - 3 * c;
-    return 3 * c_begin + ((k == 2) ? 3 * c + 2 : 3 * c + 3 + k);
-  };
-  auto issue_one = [&]() {
-    const float* g = wst + (size_t)blob_stage(n_issued) * kStageFloats;
-    float* dst = lds + (n_issued & (NB - 1)) * kStageFloats;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);
-    ++n_issued;
-  };
-  auto acquire = [&]() {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but this wave's pieces of the 2 younger stages have landed
-    __syncthreads();
-    const f16x8* cur = reinterpret_cast<const f16x8*>(lds + (n_used & (NB - 1)) * kStageFloats) + lane;
-    ++n_used;
-    issue_one();
-    return cur;
-  };
-  issue_one(); issue_one(); issue_one();
+template <bool PE>
+__global__ void __launch_bounds__(256, 2)
+k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_img, const float* __restrict__ wst,
+                 const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
+  __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
+  fusion_attn_h2_body<PE>(lds, blockIdx.x, blockIdx.y, xin, ctx_img, wst, vecs, x1_out, N, tiles, T, ttiles);
+}
 
-  auto bias_acc = [&](const float* bvec, int c) {
-    float b[16];
-    load_vec_block(b, bvec, c, h);
-    f32x16 a;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = b[r];
-    return a;
-  };
-
-  f32x16 a0 = bias_acc(b1a, c_begin), g0 = bias_acc(b1g, c_begin), a1, g1;
-  {
-    const f16x8* lw = acquire();
-    mma_wx_h2<8>(a0, lw, nx);
-    lw = acquire();
-    mma_wx_h2<8>(g0, lw, nx);
-  }
-  // chunk c: gated values from (a_cur, g_cur); W1 of chunk c+1 accumulates into (a_nxt, g_nxt) meanwhile
-  auto chunk = [&](const int c, f32x16& a_cur, const f32x16& g_cur, f32x16& a_nxt, f32x16& g_nxt, const bool has_next) {
-    FragH2<2> gx;
-    if (has_next) {
-      a_nxt = bias_acc(b1a, c + 1);
-      g_nxt = bias_acc(b1g, c + 1);
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const f16x8* lw = acquire();
-        f16x8 wh = lw[0], wl = lw[8 * 64];
-        f16x8 wh_n = wh, wl_n = wl;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const int u = 8 * half + s;
-          if (s < 7) { wh_n = lw[(0 * 8 + s + 1) * 64]; wl_n = lw[(1 * 8 + s + 1) * 64]; }
-          if (half == 0) mma3(a_nxt, wh, wl, nx.h[s], nx.l[s]);
-          else mma3(g_nxt, wh, wl, nx.h[s], nx.l[s]);
-          wh = wh_n; wl = wl_n;
-          a_cur[u] *= gelu_erf_1r(g_cur[u]);
-          if (half == 1 && (s & 1)) { const int j = s - 1; split2h(a_cur[j], a_cur[j + 1], gx.h[0], gx.l[0], j); }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) a_cur[u] *= gelu_erf_1r(g_cur[u]);
-#pragma unroll
-      for (int j = 0; j < 8; j += 2) split2h(a_cur[j], a_cur[j + 1], gx.h[0], gx.l[0], j);
-    }
-    {
-      const f16x8* lw = acquire();
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-          const f16x8* lb = lw + mb * (2 * 2 * 64);
-          mma3(y[mb], lb[(0 * 2 + s) * 64], lb[(1 * 2 + s) * 64], gx.h[s], gx.l[s]);
-          if (s == 0) { const int j = 2 * mb; split2h(a_cur[8 + j], a_cur[8 + j + 1], gx.h[1], gx.l[1], j); }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-  };
-  for (int c = c_begin; c + 2 < c_begin + NCH; c += 2) {
-    chunk(c, a0, g0, a1, g1, true);
-    chunk(c + 1, a1, g1, a0, g0, true);
-  }
-  chunk(c_begin + NCH - 2, a0, g0, a1, g1, true);
-  chunk(c_begin + NCH - 1, a1, g1, a0, g0, false);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-fetched tail stages
+// k_small_front_fattn: small grids (e.g. B = 1, the reference's evaluation mode) - the first of the three launches of a layer:
+// workgroups z = 0, 1, 2 project Q', K, V from f (front_h2_body<2>, one output each), workgroups z = 3 run LCPE + LayerNorm +
+// cross-attention -> x1 (fusion_attn_h2_body).  The two are independent given f; as separate launches on these latency-
+// bound grids they cost their sum (8.7 + 18.6 us per layer at B = 1, N = 5000), in one launch the longer of the two.
+__global__ void __launch_bounds__(256, 2)
+k_small_front_fattn(const float* __restrict__ f_in, const float* __restrict__ front_wst, const float* __restrict__ front_vec,
+                    const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
+                    float* __restrict__ q_out, float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x1_out,
+                    int N, int tiles, int T, int ttiles) {
+  __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
+  if (blockIdx.z < 3)
+    front_h2_body<2>(lds, blockIdx.x, blockIdx.y, blockIdx.z, f_in, front_wst, front_vec, nullptr, q_out, k_out, v_out, N, tiles);
+  else
+    fusion_attn_h2_body<true>(lds, blockIdx.x, blockIdx.y, f_in, ctx_img, attn_wst, attn_vec, x1_out, N, tiles, T, ttiles);
 }
 
 // =========================================================================================
@@ -438,51 +367,8 @@ template <bool SPLIT>
 __global__ void __launch_bounds__(256, 2)
 k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
                 float* __restrict__ x2_out, int tiles, float* __restrict__ part) {
-  // gridDim.z = HS > 1 (small grids, e.g. B = 1): workgroup z handles the hidden chunks [z, z+1) * 16 / HS and writes its
-  // partial Linear-2 output (no bias, no residual) to part[z]; k_ff_reduce adds the partials in a fixed order.
-  constexpr int NB = 4;
-  // (compile-time trip counts for the common un-split form: a run-time chunk count costs it 9 %)
-  const int HS = SPLIT ? (int)gridDim.z : 1, NCH = SPLIT ? (FFH / 32) / HS : FFH / 32, c_begin = SPLIT ? (int)blockIdx.z * NCH : 0;
-  __shared__ __attribute__((aligned(16))) float lds[NB * kStageFloats];
-  const int lane = threadIdx.x & 63, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = blockIdx.y;
-  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
-  const bool active = tile_raw < tiles;
-  const int tile = active ? tile_raw : tiles - 1;
-  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
-
-  FragH2<8> nx;
-  {
-    float x[CF], xn[CF];
-    load_frag_p32<CF>(x, x1 + toff, lane);
-    layernorm_frag<CF>(xn, x, vecs, vecs + C, h);
-    nx.set(xn);
-  }
-  f32x16 y[4];
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb) y[mb] = zero16();
-  ff_chunks(nx, y, lds, wst, vecs + 2 * C, vecs + 2 * C + FFH, wave, lane, h, c_begin, NCH);
-  if (HS > 1) {
-    float* pt = part + ((size_t)blockIdx.z * gridDim.y * tiles + (size_t)pair * tiles + tile) * (32 * C);
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      float t[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = y[mb][r];
-      if (active) store_block_p32(pt, mb, t, lane);
-    }
-    return;
-  }
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    float b[16], xr[16], t[16];
-    load_vec_block(b, vecs + 2 * C + 2 * FFH, mb, h);
-    load_block_p32(xr, x1 + toff, mb, lane);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = fmaf(y[mb][r], kH2Inv, b[r]) + xr[r];
-    if (active) store_block_p32(x2_out + toff, mb, t, lane);
-  }
+  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+  fusion_ff_h2p_body<SPLIT>(lds, blockIdx.x, blockIdx.y, gridDim.y, blockIdx.z, gridDim.z, x1, wst, vecs, x2_out, tiles, part);
 }
 
 // =========================================================================================
@@ -768,19 +654,31 @@ hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, 
   return hipGetLastError();
 }
 
-hipError_t launch_fusion_ff_h2(const Tuning& tune, const float* x1, const float* wst, const float* vecs, float* x2, int B,
-                               int tiles, hipStream_t s, float* part, int max_parts) {
-  const int force_hs = tune.ff_split;   // 0 = automatic, 1 = off, 2 / 4 / 8 = forced
-  const dim3 g = tgrid(tiles, B);
-  // small grids: divide the 16 hidden chunks over 2 / 4 / 8 workgroups (deterministic two-pass sum)
+// hidden splits of the feed-forward on a grid of `base` workgroups (tune.ff_split: 0 = automatic, 1 = off, 2 / 4 / 8 = forced)
+int plan_ff_split(const Tuning& tune, int base, int max_parts) {
   int hs = 1;
-  if (part && max_parts >= 2) {
-    const int base = g.x * B;
-    if (force_hs > 0) hs = force_hs;
+  if (max_parts >= 2) {
+    if (tune.ff_split > 0) hs = tune.ff_split;
     else if (base < 256) hs = base <= 64 ? 8 : base <= 128 ? 4 : 2;
     hs = std::min(hs, max_parts);
     if (hs != 2 && hs != 4 && hs != 8) hs = 1;
   }
+  return hs;
+}
+
+hipError_t launch_small_front_fattn(const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
+                                    const float* attn_wst, const float* attn_vec, float* q, float* k, float* v, float* x1, int B,
+                                    int N, int tiles, int T, int ttiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_small_front_fattn, tgrid(tiles, B, 4), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec,
+                     q, k, v, x1, N, tiles, T, ttiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_fusion_ff_h2(const Tuning& tune, const float* x1, const float* wst, const float* vecs, float* x2, int B,
+                               int tiles, hipStream_t s, float* part, int max_parts) {
+  const dim3 g = tgrid(tiles, B);
+  // small grids: divide the 16 hidden chunks over 2 / 4 / 8 workgroups (deterministic two-pass sum)
+  const int hs = part ? plan_ff_split(tune, g.x * B, max_parts) : 1;
   if (hs > 1) {
     hipLaunchKernelGGL(k_fusion_ff_h2p<true>, dim3(g.x, g.y, hs), dim3(256), 0, s, x1, wst, vecs, x2, tiles, part);
     hipLaunchKernelGGL(k_ff_reduce, dim3(g.x, g.y, 4), dim3(256), 0, s, part, x1, vecs, x2, tiles, hs);

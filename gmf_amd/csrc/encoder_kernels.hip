@@ -24,6 +24,7 @@
 // LDS-DMA; activations chain from one MFMA's accumulators into the next MFMA's operand registers.
 #include <algorithm>
 #include "enc_common.hpp"
+#include "enc_ff.hpp"
 
 namespace gmf {
 
@@ -614,9 +615,42 @@ GMF_DEVINL float xhalf_max_swap(float v) {
 // ReLU, PointDSC.py:104-109,141) runs on it here - 4 more weight stages (front_wst_h2 of layer l+1, blocks Wp) - and
 // f_{l+1} = ReLU(Wp' feat + bp') is what goes to memory: the next layer's linear kernel needs f with its two LCPE neighbour
 // rows, and the raw feat of a middle layer has no other reader.
-template <bool NEXT_PCN, class Stages>
+// The Fusion-2 branch x2 of the block sum, per 32-feature block of this wave's tile: read from the x2 image (FusTile), or -
+// small grids - formed here from the hidden-split feed-forward partials, x2 = (sum_z part[z]) / 256 + b2 + x1 with the
+// partials added in index order (FusFromParts: bit-identical to k_ff_reduce, which this replaces).
+struct FusTile {
+  const float* tile;
+  GMF_DEVINL void load(float (&fz)[16], int mb, int lane, int h) const { load_block_p32(fz, tile, mb, lane); }
+};
+struct FusFromParts {
+  const float* part_tile;   // this tile in part[0]
+  size_t split_stride;      // floats between part[z] and part[z + 1]
+  const float* x1_tile;
+  const float* b2;
+  int hs;
+  GMF_DEVINL void load(float (&fz)[16], int mb, int lane, int h) const {
+    float b[16], xr[16], p[8][16];
+    load_vec_block(b, b2, mb, h);
+#pragma unroll
+    for (int z = 0; z < 8; ++z)
+      if (z < hs) load_block_p32(p[z], part_tile + (size_t)z * split_stride, mb, lane);
+    load_block_p32(xr, x1_tile, mb, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fz[r] = p[0][r];
+#pragma unroll
+    for (int z = 1; z < 8; ++z)
+      if (z < hs) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fz[r] += p[z][r];
+      }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fz[r] = fmaf(fz[r], kH2Inv, b[r]) + xr[r];
+  }
+};
+
+template <bool NEXT_PCN, class Stages, class Fus>
 GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stages& ss, const float* __restrict__ vecs,
-                                   const float* __restrict__ fus_tile, float* __restrict__ out_tile, const int lane, const int h,
+                                   const Fus& fus_tile, float* __restrict__ out_tile, const int lane, const int h,
                                    const float* __restrict__ next_bias = nullptr) {
     // stages (fp16x2 images, same sizes as the fp32 ones): Wa block 0 | Wa block 1 | Wb (2 blocks) | Wc 0,1 | Wc 2,3
     FragH2<8> ox, featx;
@@ -659,7 +693,7 @@ GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stag
         mma_wx_h2<4>(acc, lw + hb * (2 * 4 * 64), m2x);
         float b[16], fz[16], tt[16];
         load_vec_block(b, vecs + 128, mb, h);
-        load_block_p32(fz, fus_tile, mb, lane);
+        fus_tile.load(fz, mb, lane, h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) tt[r] = fmaf(acc[r], kH2Inv, b[r]) + fz[r];
         if (NEXT_PCN) featx.set_block(mb, tt);
@@ -702,20 +736,20 @@ GMF_DEVINL AttnItem attn_item(int L, int n_items, int n_full, int ksplits) {
   return AttnItem{start + nf + r, j - r * ksplits, true, nf + r < items};
 }
 
-__global__ void __launch_bounds__(256, 2)
-k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
-             const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
-             float* __restrict__ out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_dense,
-             int n_items, int n_full, int ksplits, float* __restrict__ part_o, float* __restrict__ part_ml,
-             const float* __restrict__ next_wst, const float* __restrict__ next_bias) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+// `bid`: the workgroup's index in the attention grid; `lds`: 64 KiB owned by the workgroup.
+GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restrict__ q_img, const float* __restrict__ k_img,
+                                const float* __restrict__ v_img, const float* __restrict__ fus, const float* __restrict__ wst,
+                                const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, int wgs_per_pair,
+                                const float* __restrict__ c_dense, int n_items, int n_full, int ksplits,
+                                float* __restrict__ part_o, float* __restrict__ part_ml, const float* __restrict__ next_wst,
+                                const float* __restrict__ next_bias) {
   float* const ldsK = lds;
   float* const ldsV = lds + 2 * kStageFloats;
   constexpr int WAVES = 4;
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned lane_off16 = lane * 16;
-  const AttnItem it = attn_item(blockIdx.x, n_items, n_full, ksplits);
+  const AttnItem it = attn_item(bid, n_items, n_full, ksplits);
   if (!it.valid) return;                       // grid padding of the split tail (uniform per workgroup)
   const bool split = it.split;
   const int ks = it.ks;
@@ -965,8 +999,46 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
   StageStream ss;
   ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5, next_wst, next_wst ? 4 : 0);
   ss.prime();
-  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, fus + toff, out + toff, lane, h, next_bias);
-  else scattn_epilogue_h2<false>(o, active, ss, vecs, fus + toff, out + toff, lane, h);
+  const FusTile ft{fus + toff};
+  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, ft, out + toff, lane, h, next_bias);
+  else scattn_epilogue_h2<false>(o, active, ss, vecs, ft, out + toff, lane, h);
+}
+
+__global__ void __launch_bounds__(256, 2)
+k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
+             const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
+             float* __restrict__ out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_dense,
+             int n_items, int n_full, int ksplits, float* __restrict__ part_o, float* __restrict__ part_ml,
+             const float* __restrict__ next_wst, const float* __restrict__ next_bias) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+  scattn_h2p_body(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items, n_full,
+                  ksplits, part_o, part_ml, next_wst, next_bias);
+}
+
+// k_small_attn_ff: small grids, the second of the three launches of a layer - the first n_attn workgroups are the key-split
+// attention workgroups (every item split: n_full = 0; they need only Q', K, V and c), the remaining ones the hidden-split
+// feed-forward workgroups (they need only x1).  Both write partial results; k_scattn_merge adds them up.  As separate
+// launches the two cost their sum on these latency-bound grids (B = 1, N = 5000: 44 + 18 us per layer); the attention
+// workgroups are one per CU (attn_item), so the feed-forward workgroups find a second slot on every CU.
+__global__ void __launch_bounds__(256, 2)
+k_small_attn_ff(const int n_attn, const float* __restrict__ q_img, const float* __restrict__ k_img,
+                const float* __restrict__ v_img, const float* __restrict__ tail_wst, const float* __restrict__ tail_vecs, int N,
+                int tiles, int wgs_per_pair, const float* __restrict__ c_dense, int n_items, int ksplits,
+                float* __restrict__ part_o, float* __restrict__ part_ml, const float* __restrict__ x1,
+                const float* __restrict__ ff_wst, const float* __restrict__ ff_vecs, float* __restrict__ ff_part, int n_pairs,
+                int ff_hs) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+  if ((int)blockIdx.x < n_attn) {
+    // (n_full = 0: every item is split and leaves through the partial-result branch; `fus` / `out` of the whole-item epilogue
+    // are never touched - they get valid pointers all the same, a literal null there crashes this compiler's optimiser)
+    scattn_h2p_body(lds, blockIdx.x, q_img, k_img, v_img, x1, tail_wst, tail_vecs, ff_part, N, tiles, wgs_per_pair, c_dense,
+                    n_items, 0, ksplits, part_o, part_ml, nullptr, nullptr);
+  } else {
+    const int id = (int)blockIdx.x - n_attn;           // (bx, pair, z) with z fastest: the splits of a row block start together
+    const int z = id % ff_hs, r = id / ff_hs;
+    const int pair = r / wgs_per_pair, bx = r - pair * wgs_per_pair;
+    fusion_ff_h2p_body<true>(lds, bx, pair, n_pairs, z, ff_hs, x1, ff_wst, ff_vecs, ff_part, tiles, ff_part);   // (x2_out unused: hs > 1)
+  }
 }
 
 // All five fc_message weight stages in LDS at once (80 KiB): for grids that do not fill the chip anyway (the merge step
@@ -1007,7 +1079,8 @@ __global__ void __launch_bounds__(256, 1)
 k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_ml, const float* __restrict__ fus,
                const float* __restrict__ wst, const float* __restrict__ vecs, float* __restrict__ out, int tiles,
                int wgs_per_pair, int n_items, int n_full, int ksplits, const float* __restrict__ next_wst,
-               const float* __restrict__ next_bias) {
+               const float* __restrict__ next_bias, const float* __restrict__ ff_part, int ff_hs, const float* __restrict__ x1,
+               const float* __restrict__ ff_b2) {
   __shared__ __attribute__((aligned(16))) float lds[9 * kStageFloats];
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1060,8 +1133,15 @@ k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_
   const float inv = 1.0f / l;
 #pragma unroll
   for (int e = 0; e < CF; ++e) o[e] *= inv;
-  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, fus + toff, out + toff, lane, h, next_bias);
-  else scattn_epilogue_h2<false>(o, active, ss, vecs, fus + toff, out + toff, lane, h);
+  if (ff_part) {                                 // small grids: the Fusion-2 branch arrives as hidden-split partials (k_small_attn_ff)
+    const FusFromParts fp{ff_part + toff, n_tiles_all * (32 * C), x1 + toff, ff_b2, ff_hs};
+    if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, fp, out + toff, lane, h, next_bias);
+    else scattn_epilogue_h2<false>(o, active, ss, vecs, fp, out + toff, lane, h);
+    return;
+  }
+  const FusTile ft{fus + toff};
+  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, ft, out + toff, lane, h, next_bias);
+  else scattn_epilogue_h2<false>(o, active, ss, vecs, ft, out + toff, lane, h);
 }
 
 // =========================================================================================
@@ -1536,6 +1616,49 @@ hipError_t launch_scattn_fp32(const float* q, const float* k, const float* v, co
   return hipGetLastError();
 }
 
+// Work split of the attention grid (attn_item): W items on `slots` resident workgroups (2 per CU).  n_full = items per XCD
+// that run whole; the rest are split `ksplits` ways by key range (ksplits = 1: none).
+void plan_attn_split(const Tuning& tune, int W, int tiles, int max_splits, int* n_full_out, int* ksplits_out) {
+  const int slots = 2 * cu_count();
+  const int per_xcd = (W >> 3) + ((W & 7) ? 1 : 0);
+  int n_full = per_xcd, ksplits = 1;                                    // default: every item whole
+  if (max_splits > 1 && tiles >= 8) {
+    const int cap = std::min(max_splits, std::max(1, tiles / 4));
+    if (tune.key_splits > 1) { n_full = 0; ksplits = std::min(tune.key_splits, cap); }             // forced: every item split
+    else if (tune.key_splits == 0) {
+      // small grid: ONE workgroup per CU - a workgroup alone on its CU runs its tiles almost twice as fast as two
+      // co-resident ones (B = 1, N = 5000: 6 splits = 240 workgroups 1.64 ms per forward, 8 splits = 320 workgroups 1.75 ms)
+      if (W < slots / 2) { n_full = 0; ksplits = std::min(std::max(2, (slots / 2) / W), cap); }
+      else if (W < 3 * slots / 4 && tiles >= 64) { n_full = 0; ksplits = std::min(2, cap); }       // measured break-even
+      else if (W > slots && tune.tail_split) {
+        // large grid: whole rounds run whole; a last partial round of at most half the slots is split to fill them
+        const int full = (W / slots) * slots, rest = W - full;
+        if (rest > 0 && 2 * rest <= slots && tiles >= 16) { n_full = full / 8; ksplits = std::min(std::min(slots / rest, 4), cap); }
+      }
+    }
+    if (ksplits <= 1) { n_full = per_xcd; ksplits = 1; }
+  }
+  *n_full_out = n_full;
+  *ksplits_out = ksplits;
+}
+
+// Small grids, launches two and three of a layer (after k_small_front_fattn): key-split attention workgroups beside the
+// hidden-split feed-forward workgroups, then the merge kernel (partials of both -> block output / next layer's f).
+// Preconditions (checked by the caller with plan_attn_split / plan_ff_split): every attention item is split, ff_hs > 1.
+hipError_t launch_small_attn_ff_merge(const float* q, const float* k, const float* v, const float* x1, const float* ff_wst,
+                                      const float* ff_vecs, float* ff_part, int ff_hs, const float* tail_vecs, float* out, int B,
+                                      int N, int tiles, int ksplits, hipStream_t s, const CompatCache* cc) {
+  const int wpp = (tiles + 3) / 4, W = wpp * B;
+  const int per_xcd = (W >> 3) + ((W & 7) ? 1 : 0);
+  const int n_attn = 8 * per_xcd * ksplits, n_ff = W * ff_hs;
+  hipLaunchKernelGGL(k_small_attn_ff, dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
+                     cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs);
+  hipLaunchKernelGGL(k_scattn_merge, dim3(8 * per_xcd), dim3(256), 0, s, cc->part_o, cc->part_ml, x1, cc->tail_wst_h2, tail_vecs, out,
+                     tiles, wpp, W, 0, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)ff_part, ff_hs, x1,
+                     ff_vecs + 2 * C + 2 * FFH);
+  return hipGetLastError();
+}
+
 // Split-fp16 plane images of Q', K, V (k_front_h2 / k_linear_h2).  tune.scattn_variant:
 //   18 (default) = k_scattn_h2p: c streamed from the compat cache, tile loop software-pipelined inside each wave, split-fp16
 //                  fc_message epilogue; on small grids the keys of a query block are divided over several workgroups
@@ -1550,34 +1673,18 @@ hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, 
   const dim3 grid4(wpp * B);
   const float* cd = (cc && tune.use_cache) ? cc->dense : nullptr;
   if (tune.scattn_variant == 18 && cd && cc->tail_wst_h2) {
-    // Work split (attn_item): W items on `slots` resident workgroups (2 per CU).
-    const int W = wpp * B, slots = 2 * cu_count();
-    const int chunk = W >> 3, per_xcd = chunk + ((W & 7) ? 1 : 0);
-    int n_full = per_xcd, ksplits = 1;                                    // default: every item whole
-    const bool can_split = cc->part_o && cc->max_splits > 1 && tiles >= 8;
-    if (can_split) {
-      const int cap = std::min(cc->max_splits, std::max(1, tiles / 4));
-      if (tune.key_splits > 1) { n_full = 0; ksplits = std::min(tune.key_splits, cap); }             // forced: every item split
-      else if (tune.key_splits == 0) {
-        // small grid: ONE workgroup per CU - a workgroup alone on its CU runs its tiles almost twice as fast as two
-        // co-resident ones (B = 1, N = 5000: 6 splits = 240 workgroups 1.64 ms per forward, 8 splits = 320 workgroups 1.75 ms)
-        if (W < slots / 2) { n_full = 0; ksplits = std::min(std::max(2, (slots / 2) / W), cap); }
-        else if (W < 3 * slots / 4 && tiles >= 64) { n_full = 0; ksplits = std::min(2, cap); }       // measured break-even
-        else if (W > slots && tune.tail_split) {
-          // large grid: whole rounds run whole; a last partial round of at most half the slots is split to fill them
-          const int full = (W / slots) * slots, rest = W - full;
-          if (rest > 0 && 2 * rest <= slots && tiles >= 16) { n_full = full / 8; ksplits = std::min(std::min(slots / rest, 4), cap); }
-        }
-      }
-      if (ksplits <= 1) { n_full = per_xcd; ksplits = 1; }
-    }
+    const int W = wpp * B;
+    const int per_xcd = (W >> 3) + ((W & 7) ? 1 : 0);
+    int n_full, ksplits;
+    plan_attn_split(tune, W, tiles, cc->part_o ? cc->max_splits : 0, &n_full, &ksplits);
     const int max_tail = std::max(0, per_xcd - n_full);
     const dim3 grid(8 * (std::min(n_full, per_xcd) + max_tail * ksplits));
     hipLaunchKernelGGL(k_scattn_h2p, grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, W, n_full,
                        ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias);
     if (max_tail > 0)
       hipLaunchKernelGGL(k_scattn_merge, dim3(8 * max_tail), dim3(256), 0, s, cc->part_o, cc->part_ml, fus, cc->tail_wst_h2, vecs, out,
-                         tiles, wpp, W, n_full, ksplits, cc->next_wst_h2, cc->next_bias);
+                         tiles, wpp, W, n_full, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)nullptr, 0,
+                         (const float*)nullptr, (const float*)nullptr);
   }
   else if (cd) hipLaunchKernelGGL(k_scattn_h2<true>, grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
   else hipLaunchKernelGGL(k_scattn_h2<false>, grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);

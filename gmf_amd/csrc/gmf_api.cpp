@@ -141,6 +141,11 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     t.tail_split = value != 0;
     return GMF_OK;
   }
+  if (std::strcmp(name, "small_grid_roles") == 0) {    // 1 = small grids: three launches per layer with mixed workgroup roles (default), 0 = one kernel per stage
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: small_grid_roles must be 0 or 1");
+    t.small_roles = value != 0;
+    return GMF_OK;
+  }
   if (std::strcmp(name, "fused_linear") == 0) {        // 1 = two launches per layer (k_linear_h2 + attention with the next PointCN; default), 0 = four
     GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: fused_linear must be 0 or 1");
     t.fused_linear = value != 0;
@@ -339,6 +344,23 @@ static int run_block_tail(gmf_handle* h, const gmf_encoder_weights* w, int l, co
   return run_scattn(h, w, l, q, k, v, pts8, x2, out, B, N, st, dense_compat, cc);
 }
 
+// in-situ profiling: an event pair around the attention launch(es) of a layer, recorded on the caller's stream
+static int prof_begin(gmf_handle* h, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1) {
+  *ev0 = *ev1 = nullptr;
+  if (!h->profile) return GMF_OK;
+  if (h->prof_used == h->prof_events.size()) {
+    hipEvent_t a, b;
+    GMF_HIP(hipEventCreate(&a));
+    GMF_HIP(hipEventCreate(&b));
+    h->prof_events.emplace_back(a, b);
+  }
+  *ev0 = h->prof_events[h->prof_used].first;
+  *ev1 = h->prof_events[h->prof_used].second;
+  ++h->prof_used;
+  GMF_HIP(hipEventRecord(*ev0, st));
+  return GMF_OK;
+}
+
 // The attention launch of layer `l` (bracketed by the in-situ profiling events when enabled).
 static int run_scattn(gmf_handle* h, const gmf_encoder_weights* w, int l, const float* q, const float* k, const float* v,
                       const float* pts8, const float* x2, float* out, int B, int N, hipStream_t st, const float* dense_compat,
@@ -346,18 +368,7 @@ static int run_scattn(gmf_handle* h, const gmf_encoder_weights* w, int l, const 
   const int tiles = tiles_of(N);
   const bool h2 = use_h2(h, w, dense_compat != nullptr);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (h->profile) {
-    if (h->prof_used == h->prof_events.size()) {
-      hipEvent_t a, b;
-      GMF_HIP(hipEventCreate(&a));
-      GMF_HIP(hipEventCreate(&b));
-      h->prof_events.emplace_back(a, b);
-    }
-    ev0 = h->prof_events[h->prof_used].first;
-    ev1 = h->prof_events[h->prof_used].second;
-    ++h->prof_used;
-    GMF_HIP(hipEventRecord(ev0, st));
-  }
+  if (int rc = prof_begin(h, st, &ev0, &ev1)) return rc;
   if (dense_compat)
     GMF_HIP(gmf::launch_scattn_dense(q, k, v, dense_compat, x2, w->tail_wst + (size_t)l * w->tail_wst_stride,
                                      w->tail_vec + (size_t)l * w->tail_vec_stride, out, B, N, tiles, st));
@@ -394,7 +405,8 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   // (small grids: up to 8 splits of every query block; large grids: the last partial round of workgroups is split in 2..4)
   const int kMaxSplits = ((tiles + 3) / 4) * B < 384 ? 8 : 4;
   const bool want_split = want_cache && tiles >= 8;
-  const size_t split_need = want_split ? arena_need((size_t)kMaxSplits * act, 4) + arena_need((size_t)kMaxSplits * B * tiles * 64, 4) : 0;
+  const size_t split_need = want_split ? arena_need((size_t)kMaxSplits * act, 4) + arena_need((size_t)kMaxSplits * B * tiles * 64, 4) +
+                                             (kMaxSplits == 8 ? arena_need((size_t)8 * act, 4) : 0) : 0;
   const size_t need = 8 * arena_need(act, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +
                       5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4) + cache_need + split_need;
   if (int rc = arena_reserve(h, need)) return rc;
@@ -419,6 +431,8 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
     c_dense = arena_take<float>(h, n_tt * 1024);
     cc.dense = c_dense;
   }
+  float* ff_part = nullptr;
+  if (want_split && kMaxSplits == 8) ff_part = arena_take<float>(h, (size_t)8 * act);   // small grids: feed-forward partials beside the attention's
   if (want_split) {
     cc.part_o = arena_take<float>(h, (size_t)kMaxSplits * act);
     cc.part_ml = arena_take<float>(h, (size_t)kMaxSplits * B * tiles * 64);
@@ -456,7 +470,13 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   //   k_scattn_h2p: Q', K, V, c, x2 -> f_{l+1} = ReLU(PointCN_{l+1}(fc_message(attention) + x2))   (last layer: the features)
   const bool fuse = h2 && L > 0 && want_cache && h->tune.fused_linear && h->tune.scattn_variant == 18;
   if (fuse) {
-    const bool one_kernel = ((tiles + 3) / 4) * B >= 256;      // below: key / hidden / output splits fill the chip better
+    const int Wg = ((tiles + 3) / 4) * B;
+    const bool one_kernel = Wg >= 256;      // below: key / hidden / output splits fill the chip better
+    // small grids: when both the attention and the feed-forward are split anyway, their workgroups share launches
+    int small_nf = 1, small_ks = 1;
+    gmf::plan_attn_split(h->tune, Wg, tiles, cc.part_o ? cc.max_splits : 0, &small_nf, &small_ks);
+    const int ff_hs = cc.part_o ? gmf::plan_ff_split(h->tune, Wg, cc.max_splits) : 1;
+    const bool small3 = !one_kernel && h->tune.small_roles && small_nf == 0 && small_ks > 1 && ff_hs > 1 && ff_part;
     GMF_HIP(gmf::launch_front_h2(h->tune, 3, corr_pos, w->front_wst_h2, w->front_vec, f, q, k, v, B, N, tiles, st));
     for (int l = 0; l < L; ++l) {
       const float* fw = w->front_wst_h2 + (size_t)l * w->front_wst_stride;
@@ -468,6 +488,19 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
       const float* ctx_l = ctxall + (size_t)l * tok;
       if (one_kernel) {
         GMF_HIP(gmf::launch_linear_h2(f, fw, fv, ctx_l, aw, av, ffw, ffv, q, k, v, x2, B, N, tiles, T, tt, st));
+      } else if (small3) {
+        // three launches: {Q' | K | V | cross-attention} -> {key-split attention | hidden-split feed-forward} -> merge
+        GMF_HIP(gmf::launch_small_front_fattn(f, fw, fv, ctx_l, aw, av, q, k, v, x1, B, N, tiles, T, tt, st));
+        const bool last3 = (l + 1 == L);
+        cc.tail_wst_h2 = w->tail_wst_h2 + (size_t)l * w->tail_wst_stride;
+        cc.next_wst_h2 = last3 ? nullptr : w->front_wst_h2 + (size_t)(l + 1) * w->front_wst_stride;
+        cc.next_bias = last3 ? nullptr : w->front_vec + (size_t)(l + 1) * w->front_vec_stride;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (int rc = prof_begin(h, st, &e0, &e1)) return rc;
+        GMF_HIP(gmf::launch_small_attn_ff_merge(q, k, v, x1, ffw, ffv, ff_part, ff_hs, w->tail_vec + (size_t)l * w->tail_vec_stride,
+                                                last3 ? cur : f, B, N, tiles, small_ks, st, &cc));
+        if (e1) GMF_HIP(hipEventRecord(e1, st));
+        continue;
       } else {
         // (projecting Q'/K/V on a side stream beside the Fusion-2 kernels, forked and joined with events, was measured at
         // B = 1: 1.62 vs 1.58 ms at N = 5000, 1.08 vs 1.00 ms at N = 1000 - the event round trips cost more than the overlap gives)

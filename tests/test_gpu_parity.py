@@ -584,6 +584,28 @@ def test_two_launch_layers_match_oracle(sd_full, model, fused, B, N, T):
         assert _maxerr(feat_n[p:p + 1].cpu(), fn) < 1e-4
 
 
+@pytest.mark.parametrize("roles", [1, 0])
+@pytest.mark.parametrize("N", [64, 257, 1000])
+def test_small_grid_three_launch_layers(golden_dir, model, roles, N):
+    """Small grids (the reference's B = 1 evaluation mode): a layer is three launches whose workgroups play different roles -
+    {Q' | K | V | LCPE + cross-attention}, {key-split attention | hidden-split feed-forward}, merge (attention partials +
+    feed-forward partials + fc_message + next PointCN) - or, with `small_grid_roles` = 0, one kernel per stage.  Both give
+    the reference's golden logits and pose (F4 / F10; N = 64 is too small to split: it takes the per-stage path either way)."""
+    from gmf_amd import _lib
+    g = _load(golden_dir, "f4_f10_pointdsc.npz")
+    h = _lib.handle_for(0)
+    b = synthetic.synthetic_batch(list(g[f"pair_seeds_N{N}"]), N=N, T=196)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    try:
+        h.call("gmf_set_tuning", b"small_grid_roles", roles)
+        res = model(data)
+    finally:
+        h.call("gmf_set_tuning", b"small_grid_roles", 1)
+    assert _maxerr(model.last_logits.cpu(), g[f"logits_N{N}"]) < 1e-4
+    assert _maxerr(res["final_trans"].cpu(), g[f"final_trans_N{N}"]) < 1e-4
+
+
 def test_tuning_rejects_unknown_and_removed_settings():
     """The round-1 timing-only ablations (scattn_variant 11..15: wrong results) and the measured-and-rejected forms are no
     longer part of the library: gmf_set_tuning refuses them, out-of-range values and unknown knobs with GMF_ERR_BAD_ARG (-1)

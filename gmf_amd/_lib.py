@@ -88,6 +88,7 @@ SIGNATURES = {
     "gmf_similarity_matrix": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp]),
     "gmf_spectral_matching_loss": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "gmf_spectral_matching_loss_fused": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp]),
+    "gmf_spectral_matching_backward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp, _vp]),
     "gmf_classification_loss": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "gmf_stem_forward": (C.c_int, [_vp, _vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "gmf_conv_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),

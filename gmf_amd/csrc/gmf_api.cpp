@@ -813,6 +813,23 @@ int gmf_spectral_matching_loss_fused(gmf_handle* h, const float* feat_n, const f
   return GMF_OK;
 }
 
+int gmf_spectral_matching_backward(gmf_handle* h, const float* feat_n, const float* gt_labels, int B, int N, float sigma,
+                                   int balanced, float* d_feat_n, float* d_sigma, gmf_stream_t stream) {
+  GMF_REQUIRE(h && feat_n && gt_labels && d_feat_n && d_sigma, GMF_ERR_BAD_ARG, "spectral_matching_backward: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "spectral_matching_backward: empty input");
+  GMF_REQUIRE(sigma != 0.f, GMF_ERR_BAD_ARG, "spectral_matching_backward: sigma must be non-zero");
+  SetDevice sd(h);
+  const size_t n_img = gmf::similarity_image_floats(B, N);
+  const size_t n_part = (size_t)gmf::sm_backward_parts(B, N);
+  if (int rc = arena_reserve(h, 2 * arena_need(n_img, 4) + arena_need((size_t)4 * B, 4) + arena_need(n_part, 8))) return rc;
+  float* img = arena_take<float>(h, n_img);
+  float* timg = arena_take<float>(h, n_img);
+  float* consts = arena_take<float>(h, (size_t)4 * B);
+  double* part = arena_take<double>(h, n_part);
+  GMF_HIP(gmf::launch_sm_backward(feat_n, gt_labels, img, timg, consts, part, B, N, sigma, balanced, d_feat_n, d_sigma, S(stream)));
+  return GMF_OK;
+}
+
 int gmf_classification_loss(gmf_handle* h, const float* pred, const float* gt, const float* weight, int B, int N,
                             int balanced, float* out6, gmf_stream_t stream) {
   GMF_REQUIRE(h && pred && gt && out6, GMF_ERR_BAD_ARG, "classification_loss: null pointer");

@@ -101,6 +101,9 @@ hipError_t launch_sm_loss_fused(const float* feat_n, const float* gt, float* img
                                 int N, float sigma, int balanced, float* out, hipStream_t s);
 hipError_t launch_sm_loss(const float* M, int ldm, const float* gt, double* part, double* pair_loss, int B, int N,
                           int balanced, float* out, hipStream_t s);
+int sm_backward_parts(int B, int N);
+hipError_t launch_sm_backward(const float* feat_n, const float* gt, float* img, float* timg, float* consts, double* dsig_part,
+                              int B, int N, float sigma, int balanced, float* dF, float* dsigma, hipStream_t s);
 hipError_t launch_classification_loss(const float* pred, const float* gt, const float* weight, double* part, int B, int N,
                                       int balanced, float* out, hipStream_t s);
 hipError_t launch_transformation_loss(const float* trans, const float* gt_trans, const float* src, const float* tgt,

@@ -438,6 +438,175 @@ k_transformation_final(const float* __restrict__ trans, const float* __restrict_
   }
 }
 
+// =========================================================================================
+// Training path, first backward slice: gradient of the spectral-matching loss through the
+// feature-similarity matrix,
+//     M = clamp(1 - (1 - Fn Fn^T) / sigma^2, 0, 1), zero diagonal            GMF_PointDSC/models/PointDSC.py:231-234
+//     loss = SpectralMatchingLoss(M, gt_labels)                              GMF_PointDSC/libs/loss.py:116-140
+// with respect to the unit features Fn [B, N, 128] and the learned bandwidth sigma (PointDSC.py:164) - what
+// `loss.backward()` in libs/trainer.py:158 pushes into the encoder through this term.  As in the forward, M never exists:
+//     dL/dM_ij = gtM_ij (M_ij - 1) cP + (1 - gtM_ij) M_ij cN       cP = 1 / (B Dp), cN = 1 / (B Dn)   (balanced form;
+//                                                                  MSE form: cP = cN = 2 / (B N^2))
+//     G_ij     = dL/dM_ij [0 <= u_ij <= 1] / sigma^2               u = 1 - (1 - s) / sigma^2, s = <f_i, f_j>  (clamp's gradient mask)
+//     dL/dFn   = (G + G^T) Fn = 2 G Fn                             (G is symmetric)
+//     dL/dsigma = sum_ij dL/dM_ij [0 <= u_ij <= 1] 2 (1 - s_ij) / sigma^3
+// i.e. the structure of the attention kernel with K = V = Fn and P = G: per 32 x 32 tile S^T = F_J F_I^T and
+// dF_I^T += F_J^T G^T on the f16 MFMA with split-fp16 operands; G is scaled by a power of two per pair so that its fp16
+// planes stay in the normal range.  One launch: 1 024 N^2 MFMA flops per pair, the size of one attention launch.
+// =========================================================================================
+// T image of the features for the second product: unit ((plane * 8 + slot) * 64 + lane), slot = 2 db + s2, lane (h, d): the 8
+// halves are Fn[32 t + 16 s2 + 4 h + e][32 db + d] (e < 4) followed by Fn[32 t + 16 s2 + 8 + 4 h + e][32 db + d] - the key order
+// in which a lane of the kernel below holds its 16 values of G.
+__global__ void k_pack_rows_t_h2(const float* __restrict__ feat, float* __restrict__ img, int N, int tiles, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63, slot = (idx >> 6) & 7;
+  const long bt = idx >> 9;
+  const int tile = bt % tiles;
+  const long b = bt / tiles;
+  const int h = lane >> 5, d = 32 * (slot >> 1) + (lane & 31), s2 = slot & 1;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int row = 32 * tile + 16 * s2 + 8 * (e >> 2) + 4 * h + (e & 3);
+    v[e] = row < N ? feat[((size_t)b * N + row) * kFeat + d] : 0.f;
+  }
+  f16x8 hi, lo;
+  split8h(v, hi, lo);
+  f16x8* o = reinterpret_cast<f16x8*>(img + (size_t)bt * kTileFloats);
+  o[(0 * 8 + slot) * 64 + lane] = hi;
+  o[(1 * 8 + slot) * 64 + lane] = lo;
+}
+
+// per pair: cP, cN (see above), and the power-of-two scale of G; consts[b] = {cP, cN, scale, 1 / scale}
+__global__ void __launch_bounds__(256)
+k_sm_bwd_prep(const float* __restrict__ gt, float* __restrict__ consts, int B, int N, int balanced, float inv_sig2) {
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  double n1 = 0.0;
+  for (int i = threadIdx.x; i < N; i += 256) n1 += (gt[(size_t)b * N + i] == 1.0f) ? 1.0 : 0.0;
+  n1 = block_sum(n1, red);
+  if (threadIdx.x == 0) {
+    const double np = n1 * n1 - n1, nn = (double)N * N - np;       // entries of gt_M that are 1 / 0 (the diagonal is 0)
+    double cP, cN;
+    if (balanced) { cP = 1.0 / ((double)B * (fmax(np - 1.0, 0.0) + 1.0)); cN = 1.0 / ((double)B * (fmax(nn - 1.0, 0.0) + 1.0)); }
+    else cP = cN = 2.0 / ((double)B * (double)N * (double)N);
+    const double gmax = fmax(cP, cN) * inv_sig2;                   // |G| <= gmax
+    int e;
+    frexp(gmax, &e);                                               // gmax = m 2^e, m in [0.5, 1)
+    const float scale = ldexpf(1.0f, 8 - e);                       // scaled |G| <= 256
+    consts[4 * b + 0] = (float)cP; consts[4 * b + 1] = (float)cN; consts[4 * b + 2] = scale; consts[4 * b + 3] = 1.0f / scale;
+  }
+}
+
+// grid (ceil(tiles / 4), B), block 256: a wave owns 32 rows i of pair b and sweeps all key tiles.
+// dsig_part[b * gridDim.x + blockIdx.x] = this workgroup's part of dL/dsigma (fp64).
+__global__ void __launch_bounds__(256, 2)
+k_sm_backward(const float* __restrict__ img, const float* __restrict__ timg, const float* __restrict__ gt,
+              const float* __restrict__ consts, float* __restrict__ dF, double* __restrict__ dsig_part, int N, int tiles,
+              float inv_sig2, float two_inv_sig3) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * kTileFloats];      // K ring [2] | V ring [2]
+  __shared__ double red[4];
+  float* const ldsK = lds;
+  float* const ldsV = lds + 2 * kTileFloats;
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * 4 + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t pbase = (size_t)pair * tiles;
+  const float cP = consts[4 * pair + 0], cN = consts[4 * pair + 1], scale = consts[4 * pair + 2], inv_scale = consts[4 * pair + 3];
+  const int row_i = 32 * tile + i;
+  const float* gtp = gt + (size_t)pair * N;
+  const float gt_i = row_i < N ? gtp[row_i] : 0.f;
+
+  f16x8 qh[8], ql[8];
+  {
+    const f16x8* qp = reinterpret_cast<const f16x8*>(img + (pbase + tile) * (size_t)kTileFloats) + lane;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { qh[s] = qp[(0 * 8 + s) * 64]; ql[s] = qp[(1 * 8 + s) * 64]; }
+  }
+  const float* gk = img + pbase * (size_t)kTileFloats;
+  const float* gv = timg + pbase * (size_t)kTileFloats;
+  auto issue = [&](int t) {
+    dma_issue(gk + (size_t)t * kTileFloats, ldsK + (t & 1) * kTileFloats, 16, wave, 4, lane);
+    dma_issue(gv + (size_t)t * kTileFloats, ldsV + (t & 1) * kTileFloats, 16, wave, 4, lane);
+  };
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
+  double dsig = 0.0;
+  issue(0);
+  for (int t = 0; t < tiles; ++t) {
+    // the labels of this lane's 16 keys are requested BEFORE the stage wait (a load after it would queue behind the next
+    // tile's DMA pieces)
+    float gtj[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
+      gtj[r] = j < N ? gtp[j] : 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < tiles) issue(t + 1);
+    const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK + (t & 1) * kTileFloats) + lane;
+    const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV + (t & 1) * kTileFloats) + lane;
+    f32x16 sacc = zero16();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) mma3(sacc, lk[(0 * 8 + s) * 64], lk[(1 * 8 + s) * 64], qh[s], ql[s]);
+    float g[16];
+    float ds_local = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
+      const float sv = sacc[r];
+      const float u = 1.0f - (1.0f - sv) * inv_sig2;
+      const bool diag = (j == row_i);
+      const float M = diag ? 0.f : fminf(fmaxf(u, 0.f), 1.f);
+      const bool both = (gt_i == 1.0f) && (gtj[r] == 1.0f) && !diag;
+      const float dM = both ? (M - 1.0f) * cP : M * cN;
+      const bool inside = (u >= 0.f) && (u <= 1.f) && !diag && (j < N) && (row_i < N);
+      const float gm = inside ? dM : 0.f;
+      g[r] = gm * inv_sig2 * scale;
+      ds_local = fmaf(gm, (1.0f - sv) * two_inv_sig3, ds_local);
+    }
+    dsig += (double)ds_local;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f16x8 ph, pl;
+      split8h(&g[8 * s2], ph, pl);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int slot = 2 * db + s2;
+        mma3(oacc[db], lv[(0 * 8 + slot) * 64], lv[(1 * 8 + slot) * 64], ph, pl);
+      }
+    }
+  }
+  // dF_i = 2 G F: lane (h, i) register r of block db is feature 32 db + 8 (r >> 2) + 4 h + (r & 3) of row i
+  if (active && row_i < N) {
+    float4* o = reinterpret_cast<float4*>(dF + ((size_t)pair * N + row_i) * kFeat);
+    const float c2 = 2.0f * inv_scale;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        o[8 * db + 2 * q + h] = make_float4(oacc[db][4 * q] * c2, oacc[db][4 * q + 1] * c2, oacc[db][4 * q + 2] * c2, oacc[db][4 * q + 3] * c2);
+  }
+  if (!active) dsig = 0.0;
+  const double tot = block_sum(dsig, red);
+  if (threadIdx.x == 0) dsig_part[(size_t)pair * gridDim.x + blockIdx.x] = tot;
+}
+
+// dsigma = sum of the partials in index order (deterministic)
+__global__ void k_sm_bwd_dsigma(const double* __restrict__ part, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) s += part[k];
+    out[0] = (float)s;
+  }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------------------
 static void similarity_grid(int B, int tiles, dim3& grid, int& chunk) {
   const int rg = (tiles + 3) / 4;
@@ -513,6 +682,23 @@ hipError_t launch_transformation_loss(const float* trans, const float* gt_trans,
   const int S = transformation_slices(B, N);
   hipLaunchKernelGGL(k_transformation_partial, dim3(S, B), dim3(256), 0, s, trans, src, tgt, probs, B, N, part);
   hipLaunchKernelGGL(k_transformation_final, dim3(1), dim3(256), 0, s, trans, gt_trans, part, B, N, S, re_thre, te_thre, out);
+  return hipGetLastError();
+}
+
+int sm_backward_parts(int B, int N) { return B * ((((N + 31) / 32) + 3) / 4); }
+
+hipError_t launch_sm_backward(const float* feat_n, const float* gt, float* img, float* timg, float* consts, double* dsig_part,
+                              int B, int N, float sigma, int balanced, float* dF, float* dsigma, hipStream_t s) {
+  const int tiles = (N + 31) / 32;
+  const long total = (long)B * tiles * 512;
+  const float inv_sig2 = 1.0f / (sigma * sigma);
+  hipLaunchKernelGGL(k_pack_rows_h2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat_n, img, N, tiles, total);
+  hipLaunchKernelGGL(k_pack_rows_t_h2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat_n, timg, N, tiles, total);
+  hipLaunchKernelGGL(k_sm_bwd_prep, dim3(B), dim3(256), 0, s, gt, consts, B, N, balanced, inv_sig2);
+  const dim3 grid((tiles + 3) / 4, B);
+  hipLaunchKernelGGL(k_sm_backward, grid, dim3(256), 0, s, img, timg, gt, consts, dF, dsig_part, N, tiles, inv_sig2,
+                     2.0f / (sigma * sigma * sigma));
+  hipLaunchKernelGGL(k_sm_bwd_dsigma, dim3(1), dim3(64), 0, s, dsig_part, (int)(grid.x * grid.y), dsigma);
   return hipGetLastError();
 }
 

@@ -1,8 +1,10 @@
 """Validation metrics of the PointDSC plugin surface (reference: GMF_PointDSC/libs/loss.py; caller
 libs/trainer.py:194-262, evaluate()).  Forward only: the three modules the reference's `evaluate_metric` dict holds,
 with its class names, constructor arguments, call signatures and return values, each one launch sequence of
-libgmf_hip.so over the C ABI.  Backward (the training half of SURVEY section 8 row f-4) is not built: the modules
-raise if an input requires grad."""
+libgmf_hip.so over the C ABI.  Backward (the training half of SURVEY section 8 row f-4): the first slice is built -
+`SpectralMatchingLoss.from_features` is differentiable with respect to the unit features and the bandwidth sigma
+(`_SpectralMatchingFromFeatures`, one HIP launch for the whole N x N x 128 backward); every other module is forward
+only and raises if an input requires grad."""
 from __future__ import annotations
 
 import torch
@@ -61,6 +63,34 @@ class ClassificationLoss(nn.Module):
                 "logit_true": float(host[4]), "logit_false": float(host[5])}
 
 
+class _SpectralMatchingFromFeatures(torch.autograd.Function):
+    """loss = SpectralMatchingLoss(M(feat_n, sigma), gt) with M = clamp(1 - (1 - Fn Fn^T)/sigma^2, 0, 1), zero diagonal
+    (PointDSC.py:231-234, libs/loss.py:116-140).  forward: gmf_spectral_matching_loss_fused; backward:
+    gmf_spectral_matching_backward (d loss / d feat_n [B,N,128], d loss / d sigma) - M is written in neither."""
+
+    @staticmethod
+    def forward(ctx, feat_n, sigma, gt, balanced):
+        f = require_cuda_f32(feat_n, "feat_n").contiguous()
+        out = torch.empty(1, device=f.device, dtype=torch.float32)
+        sig = float(sigma)                       # one host read of the scalar parameter (the reference's `self.sigma ** 2`)
+        h, st = handle_and_stream(f)
+        h.call("gmf_spectral_matching_loss_fused", f.data_ptr(), gt.data_ptr(), f.shape[0], f.shape[1], sig,
+               1 if balanced else 0, out.data_ptr(), st)
+        ctx.save_for_backward(f, gt)
+        ctx.sig, ctx.balanced, ctx.sigma_is_tensor = sig, balanced, torch.is_tensor(sigma)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        f, gt = ctx.saved_tensors
+        dF = torch.empty_like(f)
+        dsig = torch.empty(1, device=f.device, dtype=torch.float32)
+        h, st = handle_and_stream(f)
+        h.call("gmf_spectral_matching_backward", f.data_ptr(), gt.data_ptr(), f.shape[0], f.shape[1], ctx.sig,
+               1 if ctx.balanced else 0, dF.data_ptr(), dsig.data_ptr(), st)
+        return grad_out * dF, (grad_out * dsig).reshape(1) if ctx.sigma_is_tensor else None, None, None
+
+
 class SpectralMatchingLoss(nn.Module):
     """libs/loss.py:116-140.  forward(M [bs,N,N], gt_labels [bs,N]) -> 0-dim device tensor.
 
@@ -87,11 +117,18 @@ class SpectralMatchingLoss(nn.Module):
         return out[0]
 
     def from_features(self, feat_n, sigma, gt_labels):
-        _no_grad(feat_n)
-        f = require_cuda_f32(feat_n, "feat_n").contiguous()
+        """Differentiable: with grad enabled and `feat_n` (or a tensor `sigma` of one element, e.g. PointDSC.sigma) requiring
+        grad, the result carries the backward of the whole M + loss computation (one HIP launch, M never written)."""
+        f = require_cuda_f32(feat_n, "feat_n")
         gt = gt_labels.to(device=f.device, dtype=torch.float32).contiguous()
         if f.dim() != 3 or f.shape[2] != 128 or gt.shape != f.shape[:2]:
             raise RuntimeError("gmf_amd.SpectralMatchingLoss.from_features: expected feat_n [bs,N,128] and gt_labels [bs,N]")
+        needs_grad = torch.is_grad_enabled() and (f.requires_grad or (torch.is_tensor(sigma) and sigma.requires_grad))
+        if needs_grad:
+            if torch.is_tensor(sigma) and sigma.numel() != 1:
+                raise RuntimeError("gmf_amd.SpectralMatchingLoss.from_features: sigma must be a scalar or a one-element tensor")
+            return _SpectralMatchingFromFeatures.apply(f, sigma, gt, self.balanced)
+        f = f.contiguous()
         out = torch.empty(1, device=f.device, dtype=torch.float32)
         h, st = handle_and_stream(f)
         h.call("gmf_spectral_matching_loss_fused", f.data_ptr(), gt.data_ptr(), f.shape[0], f.shape[1], float(sigma),

@@ -266,6 +266,14 @@ int gmf_spectral_matching_loss(gmf_handle* h, const float* M, int ldm, const flo
 int gmf_spectral_matching_loss_fused(gmf_handle* h, const float* feat_n, const float* gt_labels, int B, int N, float sigma,
                                      int balanced, float* loss_out, gmf_stream_t stream);
 
+/* Backward of gmf_spectral_matching_loss_fused (first slice of the training path, libs/trainer.py:158): the gradient of
+ * SpectralMatchingLoss(M(feat_n, sigma), gt_labels) (PointDSC.py:231-234, libs/loss.py:116-140) for an upstream gradient
+ * of 1, with respect to feat_n -> d_feat_n [B,N,128] and to the bandwidth sigma -> d_sigma [1] (both device, fp32).  M and
+ * dL/dM are never written: S = Fn Fn^T tile by tile, dL/dFn = 2 G Fn with G = dL/dM * [0 <= u <= 1] / sigma^2 (clamp's
+ * gradient mask), split-fp16 MFMA products with fp32 accumulation, dsigma summed in fp64 in a fixed order. */
+int gmf_spectral_matching_backward(gmf_handle* h, const float* feat_n, const float* gt_labels, int B, int N, float sigma,
+                                   int balanced, float* d_feat_n, float* d_sigma, gmf_stream_t stream);
+
 /* ClassificationLoss.forward(pred, gt, weight) (GMF_PointDSC/libs/loss.py:67-113): pred [B,N] logits, gt [B,N] float
  * 0/1, weight [B,N] or NULL -> out [6] (device) = loss, precision, recall, f1 (pair 0, as loss.py:99-101), mean logit of
  * the inliers, mean logit of the outliers. */

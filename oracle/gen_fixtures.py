@@ -239,7 +239,48 @@ def gen_f16(pdsc):
     np.savez_compressed(os.path.join(GOLD, "f16_pose_tie_scenes.npz"), **out)
 
 
+def gen_f17(pdsc):
+    """F17: first backward slice of the training path (row f-4) - the reference's own autograd through
+    M = clamp(1 - (1 - Fn Fn^T) / sigma^2, 0, 1) (PointDSC.py:229-234, inside its non-test forward) and
+    libs/loss.py SpectralMatchingLoss: gradients with respect to the encoder output `corr_features` (i.e. through
+    F.normalize as well) and to the learned `sigma`.  The encoder output is captured by a hook and stored, so the HIP
+    slice is driven from the same features; sigma is set to 0.8 so that the clamp has both active bounds."""
+    import libs.loss as L
+    torch.manual_seed(0)
+    sd = O.seeded_state_dict(O.pointdsc_shapes(6, 12, 128), seed=7)
+    sd["sigma"] = torch.tensor([0.8])
+    model = build_ref_pointdsc(pdsc, sd)
+    caps = {}
+
+    def hook(m, i, o):
+        o.retain_grad()
+        caps["enc_out"] = o
+    model.encoder.register_forward_hook(hook)
+    out = {"sigma": np.float32(0.8)}
+    with torch.enable_grad():
+        for N, seeds, balanced in ((96, [91, 92], True), (150, [93, 94], True), (150, [93, 94], False)):
+            b = O.synthetic_batch(seeds, N=N, T=196)
+            data = {"corr_pos": b["corr_pos"], "src_keypts": b["src_keypts"], "tgt_keypts": b["tgt_keypts"],
+                    "p_image": _tok_to_image(b["p_tokens"]), "q_image": _tok_to_image(b["q_tokens"])}
+            model.zero_grad()
+            res = model(data)
+            loss = L.SpectralMatchingLoss(balanced=balanced)(res["M"], b["gt_labels"])
+            loss.backward()
+            tag = f"N{N}_{'bal' if balanced else 'mse'}"
+            feat = caps["enc_out"].permute(0, 2, 1)                       # [B,N,128] = corr_features (PointDSC.py:223-228)
+            out[f"pair_seeds_{tag}"] = np.array(seeds)
+            out[f"corr_features_N{N}"] = _np(feat)                       # (the same for both forms of the loss)
+            out[f"d_corr_features_{tag}"] = _np(caps["enc_out"].grad.permute(0, 2, 1))
+            out[f"d_sigma_{tag}"] = _np(model.sigma.grad)
+            out[f"loss_{tag}"] = np.float32(float(loss))
+            print("F17", tag, "loss", float(loss), "|dF|max", float(caps["enc_out"].grad.abs().max()), "dsigma", float(model.sigma.grad))
+    np.savez_compressed(os.path.join(GOLD, "f17_sm_loss_backward.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f17":
+        gen_f17(_import_reference()[0])
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f15":
         _import_reference()
         gen_f15()

@@ -494,6 +494,25 @@ def spectral_matching_loss(M, gt_labels, balanced: bool = True):
     return float(((M - gt_M) ** 2).mean())
 
 
+def sm_loss_from_features(corr_features, sigma, gt_labels, balanced: bool = True):
+    """Differentiable restatement (tensors in, 0-dim tensor out) of PointDSC.py:229-234 followed by libs/loss.py:116-140:
+    F.normalize -> M = clamp(1 - (1 - Fn Fn^T) / sigma^2, 0, 1) with the diagonal set to zero in place -> the loss.
+    torch autograd over it is the CPU checker of the HIP backward slice (golden F17 pins it to the reference's gradients)."""
+    fn = F.normalize(corr_features, p=2, dim=-1)
+    M = torch.matmul(fn, fn.permute(0, 2, 1))
+    M = torch.clamp(1 - (1 - M) / sigma ** 2, min=0, max=1)
+    idx = torch.arange(M.shape[1])
+    M[:, idx, idx] = 0
+    gt = gt_labels.float()
+    gt_M = ((gt[:, None, :] + gt[:, :, None]) == 2).float()
+    gt_M[:, idx, idx] = 0
+    if balanced:
+        lp = ((M - 1) ** 2 * gt_M).sum((-1, -2)) / (torch.relu(gt_M.sum((-1, -2)) - 1.0) + 1.0)
+        ln = (M ** 2 * (1 - gt_M)).sum((-1, -2)) / (torch.relu((1 - gt_M).sum((-1, -2)) - 1.0) + 1.0)
+        return torch.mean(lp * 0.5 + ln * 0.5)
+    return ((M - gt_M) ** 2).mean()
+
+
 def transformation_loss(trans, gt_trans, src_keypts, tgt_keypts, probs, re_thre: float = 15.0, te_thre: float = 30.0):
     """libs/loss.py:12-64 (TransformationLoss).  As the reference, pair i's warped source points are compared with the
     target points of EVERY pair of the batch (`warp_src_keypts - tgt_keypts` broadcasts [N,3] against [bs,N,3],

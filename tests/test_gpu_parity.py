@@ -954,6 +954,56 @@ def test_similarity_matrix_sizes(B, N):
             assert abs(float(sm.from_features(_gpu(f), sigma, _gpu(gt))) - ref) < 1e-5 * max(1.0, abs(ref))
 
 
+@pytest.mark.parametrize("tag", ["N96_bal", "N150_bal", "N150_mse"])
+def test_f17_sm_loss_backward(golden_dir, tag):
+    """Golden F17: the reference's autograd gradients of SpectralMatchingLoss(M(F.normalize(corr_features), sigma), gt) with
+    respect to the encoder output and to sigma.  Here: torch's F.normalize on the device, then ONE HIP backward launch for
+    the whole N x N x 128 part (gmf_spectral_matching_backward; M and dL/dM are never written).  Tolerance: 2e-5 of the
+    largest gradient entry (split-fp16 products, fp32 accumulation), dsigma 1e-4 relative."""
+    g = _load(golden_dir, "f17_sm_loss_backward.npz")
+    N = int(tag[1:].split("_")[0])
+    feat = _gpu(torch.from_numpy(g[f"corr_features_N{N}"])).requires_grad_(True)
+    sigma = torch.tensor([float(g["sigma"])], device=DEV, requires_grad=True)
+    gt = _gpu(synthetic.synthetic_batch(list(g[f"pair_seeds_{tag}"]), N=N, T=196)["gt_labels"])
+    fn = torch.nn.functional.normalize(feat, p=2, dim=-1)
+    loss = gmf_amd.SpectralMatchingLoss(balanced=tag.endswith("bal")).from_features(fn, sigma, gt)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g[f"loss_{tag}"])) < 1e-5 * abs(float(g[f"loss_{tag}"]))
+    ref = g[f"d_corr_features_{tag}"]
+    assert _maxerr(feat.grad.cpu(), ref) < 2e-5 * np.abs(ref).max()
+    assert abs(float(sigma.grad) - float(g[f"d_sigma_{tag}"][0])) < 1e-4 * abs(float(g[f"d_sigma_{tag}"][0]))
+
+
+def test_sm_loss_backward_full_size():
+    """32 pairs x 5000 (the benchmark shape): the HIP backward against torch autograd on the device over the dense
+    formulation for one pair (M materialised: 100 MB), and a finite, symmetric-consistent result for all."""
+    B, N = 4, 5000
+    b = synthetic.synthetic_batch([900 + i for i in range(B)], N=N, T=12)
+    g = torch.Generator().manual_seed(3)
+    feat = torch.randn(B, N, 128, generator=g)
+    feat[b["gt_labels"] > 0] += 1.5 * torch.randn(1, 128, generator=g)
+    fn = torch.nn.functional.normalize(_gpu(feat), p=2, dim=-1).requires_grad_(True)
+    sigma = torch.tensor([0.8], device=DEV, requires_grad=True)
+    gt = _gpu(b["gt_labels"])
+    loss = gmf_amd.SpectralMatchingLoss().from_features(fn, sigma, gt)
+    loss.backward()
+    assert torch.isfinite(fn.grad).all() and torch.isfinite(sigma.grad).all()
+    fr = fn.detach().clone().requires_grad_(True)
+    sr = sigma.detach().clone().requires_grad_(True)
+    M = torch.clamp(1 - (1 - fr @ fr.permute(0, 2, 1)) / sr ** 2, min=0, max=1)
+    idx = torch.arange(N, device=DEV)
+    M[:, idx, idx] = 0
+    gtM = ((gt[:, None, :] + gt[:, :, None]) == 2).float()
+    gtM[:, idx, idx] = 0
+    lp = ((M - 1) ** 2 * gtM).sum((-1, -2)) / (torch.relu(gtM.sum((-1, -2)) - 1.0) + 1.0)
+    ln = (M ** 2 * (1 - gtM)).sum((-1, -2)) / (torch.relu((1 - gtM).sum((-1, -2)) - 1.0) + 1.0)
+    ref = torch.mean(lp * 0.5 + ln * 0.5)
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-5 * abs(float(ref.detach()))
+    assert _maxerr(fn.grad.cpu(), fr.grad.cpu()) < 5e-5 * float(fr.grad.abs().max())
+    assert abs(float(sigma.grad) - float(sr.grad)) < 1e-4 * abs(float(sr.grad))
+
+
 def test_validation_modules_are_forward_only():
     x = torch.zeros(1, 8, device=DEV, requires_grad=True)
     with pytest.raises(RuntimeError, match="forward-only"):

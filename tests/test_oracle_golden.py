@@ -253,3 +253,21 @@ def test_f16_oracle_in_tie_scenes(golden_dir, sd_full, case):
     err_o = np.abs(ref["final_trans"].numpy() - g[f"gt_trans_{tag}"]).max()
     err_r = np.abs(g[f"final_trans_{tag}"] - g[f"gt_trans_{tag}"]).max()
     assert err_o <= err_r + 1e-4
+
+
+@pytest.mark.parametrize("tag", ["N96_bal", "N150_bal", "N150_mse"])
+def test_f17_oracle_sm_loss_backward(golden_dir, tag):
+    """Golden F17 (the reference's autograd through M and SpectralMatchingLoss): torch autograd over the ORACLE's restatement
+    of the same two functions, from the stored encoder output, gives the reference's gradients (feature gradient to 1e-5 of
+    its largest entry, dsigma to 1e-5 relative) - the checker the HIP backward is held to on the GPU."""
+    g = np.load(os.path.join(golden_dir, "f17_sm_loss_backward.npz"))
+    N = int(tag[1:].split("_")[0])
+    feat = torch.from_numpy(g[f"corr_features_N{N}"]).requires_grad_(True)
+    sigma = torch.tensor([float(g["sigma"])], requires_grad=True)
+    gt = O.synthetic_batch(list(g[f"pair_seeds_{tag}"]), N=N, T=196)["gt_labels"]
+    loss = O.sm_loss_from_features(feat, sigma, gt, balanced=tag.endswith("bal"))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g[f"loss_{tag}"])) < 1e-6
+    ref = g[f"d_corr_features_{tag}"]
+    assert np.abs(feat.grad.numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+    assert abs(float(sigma.grad) - float(g[f"d_sigma_{tag}"][0])) < 1e-5 * abs(float(g[f"d_sigma_{tag}"][0]))

@@ -57,6 +57,28 @@ def main():
         ln = ((Mt - 0) ** 2 * (1 - gt_M)).sum(-1).sum(-1) / (torch.relu((1 - gt_M).sum(-1).sum(-1) - 1.0) + 1.0)
         return torch.mean(lp * 0.5 + ln * 0.5)
 
+    # first backward slice of the training path: forward + backward of the loss from the features (M never written)
+    fg = f.detach().clone().requires_grad_(True)
+    sg = torch.tensor([float(sigma)], device=dev, requires_grad=True)
+
+    def fwd_bwd():
+        fg.grad = None
+        sg.grad = None
+        sm.from_features(fg, sg, gt).backward()
+    t = timed(fwd_bwd)
+    print(f"from_features forward + backward (HIP)       {t:8.3f} ms   (backward alone ~ {t - timed(lambda: sm.from_features(f, sigma, gt)):.3f} ms; "
+          f"{B * 1024.0 * N * N / 1e12:.2f} TFLOP of algorithmic MFMA work)")
+
+    def torch_fwd_bwd():
+        fr = f.detach().clone().requires_grad_(True)
+        sr = sg.detach().clone().requires_grad_(True)
+        Mt = torch.clamp(1 - (1 - fr @ fr.permute(0, 2, 1)) / sr ** 2, min=0, max=1)
+        idx = torch.arange(N, device=dev)
+        Mt[:, idx, idx] = 0
+        torch_sm(Mt).backward()
+    if B * N * N * 4 * 12 < 200e9:
+        print(f"eager torch forward + backward               {timed(torch_fwd_bwd, 2):8.3f} ms")
+
     if B * N * N * 4 * 6 < 200e9:
         t = timed(torch_M, 3)
         print(f"eager torch M (rocBLAS fp32 + 3 passes)      {t:8.3f} ms")

@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import gc
 import glob
 import hashlib
 import json
@@ -233,7 +234,11 @@ def sweep(dev):
         model, _, _ = build_model(dev, kind)
         _, data = make_batch(dev, list(range(B)), N, 196, kind)
         drv = ShardedBatchDriver(model, 1, 0, dev)
-        dt, _ = time_steps(drv, data, steps, 2)
+        gc.collect()
+        torch.cuda.synchronize()
+        # best of three timed batches of steps: the loop also frees the previous configuration's model (Python GC, hipFree of
+        # its blobs), which can land as one ~70 ms stall anywhere in a batch of sub-millisecond steps
+        dt = min(time_steps(drv, data, steps, 2)[0] for _ in range(3))
         ms = dt / steps * 1e3
         tf = step_flops(B, N, 196) / (ms * 1e-3) / 1e12
         rows.append({"workload": f"{kind} {B} pairs x {N}", "ms_per_step": ms, "value": B * N / (ms * 1e-3),

@@ -2,8 +2,9 @@
 
 Same constructor arguments, ``forward(data, mask=None, queries_encoder=None)`` signature and
 ``state_dict`` keys as the reference class.  The sub-modules below only HOLD parameters under the
-reference's names; the forward pass is three HIP kernels (context prepare, cross-attention,
-GEGLU feed-forward) behind ``gmf_fusion_layer_forward``.
+reference's names; the eval-mode forward pass is three HIP kernels (context prepare, cross-attention,
+GEGLU feed-forward) behind ``gmf_fusion_layer_forward``; in train() mode with autograd enabled the forward
+is the differentiable composition of HIP training primitives in ``gmf_amd/train.py``.
 """
 from __future__ import annotations
 
@@ -95,6 +96,11 @@ class FusionLayer(nn.Module):
         """data [B,T,dim] context tokens; queries_encoder [B,N,latent_dim] (any strides) -> [B,N,latent_dim].
 
         `mask` is accepted and ignored, exactly as in the reference (fusion_layer.py:82)."""
+        if self.training and torch.is_grad_enabled():
+            # train() mode with autograd on: the differentiable path (gmf_amd/train.py - HIP training primitives behind a
+            # torch.autograd.Function; gradients to data, queries and every parameter).  eval() keeps the fused inference kernels.
+            from .train import fusion_layer_train
+            return fusion_layer_train(self, data, queries_encoder)
         x = require_cuda_f32(queries_encoder, "queries_encoder")
         data = require_cuda_f32(data, "data").contiguous()
         B, N, Cq = x.shape

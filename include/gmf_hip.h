@@ -288,6 +288,39 @@ int gmf_transformation_loss(gmf_handle* h, const float* trans, const float* gt_t
                             const float* tgt_keypts, const float* probs, int B, int N, float re_thre, float te_thre,
                             float* out5, gmf_stream_t stream);
 
+/* ---- training primitives (row f-4, second backward slice) -----------------------------------------------------------
+ * What forward + backward of one FusionLayer / PerceiverIO (fusion_layer.py:32-128,172-201) are made of, on plain row-major
+ * fp32 tensors; gmf_amd/train.py composes them into a torch.autograd.Function.  Contractions run on the fp32 MFMA (exact
+ * fp32 products; gradients of magnitude 1e-8 need no operand scaling), every cross-row sum is taken in a fixed order. */
+
+/* C[b] = alpha * op(A[b]) op(B[b]) (+ bias[col]) (+ residual[b]) for b < batch; op(X) = X^T when trans_x != 0.  op(A) is
+ * M x K, op(B) is K x N; lda / ldb / ldc are row strides and stride_* batch strides, in floats (residual shares C's layout).
+ * Few output tiles with a long contraction (weight gradients: K = every row of the batch) are split over K into partials
+ * that are added in index order. */
+int gmf_gemm_f32(gmf_handle* h, int trans_a, int trans_b, const float* A, const float* B, float* C, const float* bias,
+                 const float* residual, int M, int N, int K, long long lda, long long ldb, long long ldc, long long stride_a,
+                 long long stride_b, long long stride_c, int batch, float alpha, gmf_stream_t stream);
+/* LCPE (fusion_layer.py:118-128) on x [rows, C] = sequences of L rows: forward y = x + bias + depthwise conv3(x) with taps
+ * w [C,1,3]; backward (x := dy, y := dx, bias unused) the transposed taps: dx[l] = dy[l] (1 + w1) + w0 dy[l+1] + w2 dy[l-1]. */
+int gmf_lcpe(gmf_handle* h, int backward, const float* x, const float* w, const float* bias, float* y, int rows, int L, int C,
+             gmf_stream_t stream);
+/* nn.LayerNorm over the last dim (eps 1e-5): y, and mean / rstd [rows] for the backward.  Backward: dx = the input gradient
+ * (+ dx_add when non-NULL: the residual branch's gradient). */
+int gmf_layernorm_forward(gmf_handle* h, const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                          long long rows, int C, gmf_stream_t stream);
+int gmf_layernorm_backward(gmf_handle* h, const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                           const float* dx_add, float* dx, long long rows, int C, gmf_stream_t stream);
+/* forward: out = softmax(scale * a) per row of length T; backward: a = P, b = dP -> out = dS = scale * P * (dP - <dP, P>). */
+int gmf_softmax_rows(gmf_handle* h, int backward, const float* a, const float* b, float* out, long long rows, int T, float scale,
+                     gmf_stream_t stream);
+/* GEGLU (fusion_layer.py:54-57): hdn [rows, 2H] -> out [rows, H] = x * gelu_erf(gates); backward: dg [rows, H] -> out = dhdn [rows, 2H]. */
+int gmf_geglu(gmf_handle* h, int backward, const float* hdn, const float* dg, float* out, long long rows, int H,
+              gmf_stream_t stream);
+/* out[c] = sum over rows r of x[r][c] * y'[r + shift][c] with y' = 1 (y NULL), y, or (y - mean) * rstd (LayerNorm's xhat);
+ * rows r + shift outside r's sequence of L rows contribute 0.  Bias, LayerNorm-parameter and LCPE-tap gradients. */
+int gmf_colsum(gmf_handle* h, const float* x, const float* y, const float* mean, const float* rstd, int shift, int L, long long rows,
+               int C, float* out, gmf_stream_t stream);
+
 /* ---- image encoder epilogue (ResNet BasicBlock, GMF_PointDSC/models/resnet.py:59-75) ------------------------------- */
 
 /* y = max(y + bias[c] (+ residual), 0) in place on an NHWC fp32 tensor of n_pixels x C (C % 4 == 0): the folded

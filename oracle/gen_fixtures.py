@@ -277,7 +277,45 @@ def gen_f17(pdsc):
     np.savez_compressed(os.path.join(GOLD, "f17_sm_loss_backward.npz"), **out)
 
 
+def gen_f18(fl, pio):
+    """F18: second backward slice (row f-4) - the reference's own autograd through one FusionLayer (Fusion-2 form: pe = True,
+    128 / 128 / head 64, fusion_layer.py:131-201) and through the DGR bottleneck PerceiverIO (latent 256, head 128): for seeded
+    weights, inputs and upstream gradient, the output and the gradients with respect to the queries, the context and EVERY
+    parameter.  Inputs and weights are regenerated from the seeds; the fixture stores outputs and gradients."""
+    out = {}
+    with torch.enable_grad():
+        for tag, mod, lat, dh, N, T, B in (("fl128", fl.FusionLayer, 128, 64, 150, 40, 2), ("pio256", pio.PerceiverIO, 256, 128, 70, 45, 1)):
+            torch.manual_seed(0)
+            kw = dict(depth=0, dim=128, latent_dim=lat, cross_heads=1, latent_heads=8, cross_dim_head=dh, latent_dim_head=dh, pe=True)
+            ref = mod(**kw).train()
+            shapes = O.fusion_layer_shapes("", 128, lat, dh, pe=True, out_to_query=(tag == "pio256"))
+            ref.load_state_dict(O.seeded_state_dict(shapes, seed=118))
+            r = np.random.default_rng([118, N, T])
+            x = torch.from_numpy(r.normal(0, 1, (B, N, lat)).astype(np.float32)).requires_grad_(True)
+            ctxt = torch.from_numpy(r.normal(0, 1, (B, T, 128)).astype(np.float32)).requires_grad_(True)
+            up = torch.from_numpy(r.normal(0, 1, (B, N, lat)).astype(np.float32))
+            y = ref(ctxt, queries_encoder=x)
+            y.backward(up)
+            out[f"{tag}_dims"] = np.array([B, N, T, lat, dh])
+            out[f"{tag}_out"] = _np(y)
+            out[f"{tag}_dx"], out[f"{tag}_dctx"] = _np(x.grad), _np(ctxt.grad)
+            for name, p in ref.named_parameters():
+                gr = _np(p.grad)
+                if gr.size > 40000:          # the wide feed-forward matrices: every 8th row + fp64 checksums
+                    out[f"{tag}_gradrows::{name}"] = gr[::8]
+                    out[f"{tag}_gradsum::{name}"] = np.array([gr.astype(np.float64).sum(), (gr.astype(np.float64) ** 2).sum()])
+                else:
+                    out[f"{tag}_grad::{name}"] = gr
+            print("F18", tag, "|out|max", float(y.detach().abs().max()), "|dx|max", float(x.grad.abs().max()),
+                  "params", len(list(ref.named_parameters())))
+    np.savez_compressed(os.path.join(GOLD, "f18_fusion_layer_backward.npz"), seed=118, **out)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f18":
+        r_ = _import_reference()
+        gen_f18(r_[1], r_[3])
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f17":
         gen_f17(_import_reference()[0])
         return

@@ -974,6 +974,81 @@ def test_f17_sm_loss_backward(golden_dir, tag):
     assert abs(float(sigma.grad) - float(g[f"d_sigma_{tag}"][0])) < 1e-4 * abs(float(g[f"d_sigma_{tag}"][0]))
 
 
+@pytest.mark.parametrize("tag", ["fl128", "pio256"])
+def test_f18_fusion_layer_backward(golden_dir, tag):
+    """Golden F18: the reference's autograd through one FusionLayer (pe = True, 128 / 128 / head 64 - the Fusion-2 form) and the
+    DGR bottleneck PerceiverIO (256 / head 128).  gmf_amd's module in train() mode runs the HIP training primitives behind a
+    torch.autograd.Function: output, d queries, d context and all 18 parameter gradients within 2e-5 of each tensor's largest
+    entry (fp32 MFMA products; sums in another order than the reference's)."""
+    g = _load(golden_dir, "f18_fusion_layer_backward.npz")
+    B, N, T, lat, dh = (int(v) for v in g[f"{tag}_dims"])
+    cls = gmf_amd.PerceiverIO if tag == "pio256" else gmf_amd.FusionLayer
+    m = cls(depth=0, dim=128, latent_dim=lat, cross_heads=1, latent_heads=8, cross_dim_head=dh, latent_dim_head=dh, pe=True)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(synthetic.seeded_state_dict(shapes, seed=int(g["seed"])))
+    m = m.to(DEV).train()
+    r = np.random.default_rng([118, N, T])
+    x = _gpu(torch.from_numpy(r.normal(0, 1, (B, N, lat)).astype(np.float32))).requires_grad_(True)
+    ctx = _gpu(torch.from_numpy(r.normal(0, 1, (B, T, 128)).astype(np.float32))).requires_grad_(True)
+    up = _gpu(torch.from_numpy(r.normal(0, 1, (B, N, lat)).astype(np.float32)))
+    y = m(ctx, queries_encoder=x)
+    y.backward(up)
+
+    def close(a, b, what):
+        err, ref = _maxerr(a.detach().cpu(), b), float(np.abs(b).max())
+        assert err < 2e-5 * max(ref, 1e-12), (what, err, ref)
+    close(y, g[f"{tag}_out"], "out")
+    close(x.grad, g[f"{tag}_dx"], "dx")
+    close(ctx.grad, g[f"{tag}_dctx"], "dctx")
+    checked = 0
+    for name, p in m.named_parameters():
+        if f"{tag}_grad::{name}" in g.files:
+            close(p.grad, g[f"{tag}_grad::{name}"], name)
+        else:
+            close(p.grad[::8], g[f"{tag}_gradrows::{name}"], name)
+            s = g[f"{tag}_gradsum::{name}"]
+            assert abs(float(p.grad.double().sum()) - s[0]) < 1e-4 * np.sqrt(s[1]), name
+        checked += 1
+    assert checked == 18
+    # eval() mode keeps the fused inference kernels and agrees with the training forward
+    with torch.no_grad():
+        ye = m.eval()(ctx, queries_encoder=x)
+    assert _maxerr(ye.cpu(), y.detach().cpu()) < 1e-4
+
+
+def test_training_primitives_against_torch():
+    """Each HIP training primitive on odd sizes against torch on the device: gmf_gemm_f32 in its four transpose forms, as a
+    batched sub-matrix product and with a long contraction (split-K path), LCPE, LayerNorm, softmax, GEGLU, column sums."""
+    from gmf_amd import train as T_
+    gen = torch.Generator().manual_seed(11)
+    rn = lambda *s: _gpu(torch.randn(*s, generator=gen))
+    A, Bm = rn(70, 45), rn(45, 133)
+    assert _maxerr(T_.gemm(A, Bm).cpu(), (A @ Bm).cpu()) < 1e-4
+    assert _maxerr(T_.gemm(A.t().contiguous(), Bm, ta=True).cpu(), (A @ Bm).cpu()) < 1e-4
+    assert _maxerr(T_.gemm(A, Bm.t().contiguous(), tb=True).cpu(), (A @ Bm).cpu()) < 1e-4
+    assert _maxerr(T_.gemm(A.t().contiguous(), Bm.t().contiguous(), ta=True, tb=True).cpu(), (A @ Bm).cpu()) < 1e-4
+    bias, R = rn(133), rn(70, 133)
+    assert _maxerr(T_.gemm(A, Bm, bias=bias, residual=R, alpha=0.5).cpu(), (0.5 * (A @ Bm) + bias + R).cpu()) < 1e-4
+    X, Y = rn(20000, 96), rn(20000, 160)                       # K = 20000 rows: split-K
+    ref = (X.double().t() @ Y.double()).float()
+    assert _maxerr(T_.gemm(X, Y, ta=True).cpu(), ref.cpu()) < 2e-5 * float(ref.abs().max())
+    x = rn(3 * 37, 64)
+    w, b = rn(64, 1, 3), rn(64)
+    ref = torch.nn.functional.conv1d(x.reshape(3, 37, 64).permute(0, 2, 1), w, b, padding=1, groups=64).permute(0, 2, 1) + x.reshape(3, 37, 64)
+    assert _maxerr(T_.lcpe_fwd(x, w, b, 37).cpu(), ref.reshape(-1, 64).cpu()) < 1e-5
+    gam, bet = rn(64), rn(64)
+    y, mu, rs = T_.layernorm_fwd(x, gam, bet)
+    assert _maxerr(y.cpu(), torch.nn.functional.layer_norm(x, (64,), gam, bet).cpu()) < 1e-5
+    S = rn(50, 196)
+    assert _maxerr(T_.softmax_rows(S, 0.3).cpu(), torch.softmax(S * 0.3, -1).cpu()) < 1e-6
+    hd = rn(33, 256)
+    assert _maxerr(T_.geglu_fwd(hd).cpu(), (hd[:, :128] * torch.nn.functional.gelu(hd[:, 128:])).cpu()) < 1e-5
+    assert _maxerr(T_.colsum(x).cpu(), x.sum(0).cpu()) < 1e-4
+    xs = x.reshape(3, 37, 64)
+    ref = (xs[:, 1:] * xs[:, :-1]).sum((0, 1))               # sum_l x[l] * x[l - 1] within each sequence
+    assert _maxerr(T_.colsum(x, y=x, shift=-1, L=37).cpu(), ref.cpu()) < 1e-4
+
+
 def test_sm_loss_backward_full_size():
     """32 pairs x 5000 (the benchmark shape): the HIP backward against torch autograd on the device over the dense
     formulation for one pair (M materialised: 100 MB), and a finite, symmetric-consistent result for all."""

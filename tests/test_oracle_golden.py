@@ -271,3 +271,34 @@ def test_f17_oracle_sm_loss_backward(golden_dir, tag):
     ref = g[f"d_corr_features_{tag}"]
     assert np.abs(feat.grad.numpy() - ref).max() < 1e-5 * np.abs(ref).max()
     assert abs(float(sigma.grad) - float(g[f"d_sigma_{tag}"][0])) < 1e-5 * abs(float(g[f"d_sigma_{tag}"][0]))
+
+
+@pytest.mark.parametrize("tag", ["fl128", "pio256"])
+def test_f18_oracle_fusion_layer_backward(golden_dir, tag):
+    """Golden F18 (the reference's autograd through one FusionLayer / PerceiverIO): torch autograd over the ORACLE's
+    fusion_layer restatement gives the reference's output and gradients (queries, context, every parameter) - each tensor to
+    1e-5 of its largest entry."""
+    g = np.load(os.path.join(golden_dir, "f18_fusion_layer_backward.npz"))
+    B, N, T, lat, dh = (int(v) for v in g[f"{tag}_dims"])
+    shapes = O.fusion_layer_shapes("", 128, lat, dh, pe=True, out_to_query=(tag == "pio256"))
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.seeded_state_dict(shapes, seed=int(g["seed"])).items()}
+    r = np.random.default_rng([118, N, T])
+    x = torch.from_numpy(r.normal(0, 1, (B, N, lat)).astype(np.float32)).requires_grad_(True)
+    ctx = torch.from_numpy(r.normal(0, 1, (B, T, 128)).astype(np.float32)).requires_grad_(True)
+    up = torch.from_numpy(r.normal(0, 1, (B, N, lat)).astype(np.float32))
+    y = O.fusion_layer(sd, "", ctx, x, pe=True)
+    y.backward(up)
+
+    def close(a, b):
+        return np.abs(np.asarray(a) - b).max() < 1e-5 * max(1e-12, np.abs(b).max())
+    assert close(y.detach().numpy(), g[f"{tag}_out"])
+    assert close(x.grad.numpy(), g[f"{tag}_dx"]) and close(ctx.grad.numpy(), g[f"{tag}_dctx"])
+    checked = 0
+    for k, v in sd.items():
+        if f"{tag}_grad::{k}" in g.files:
+            assert close(v.grad.numpy(), g[f"{tag}_grad::{k}"]), k
+        else:
+            assert close(v.grad.numpy()[::8], g[f"{tag}_gradrows::{k}"]), k
+            assert abs(float(v.grad.double().sum()) - g[f"{tag}_gradsum::{k}"][0]) < 1e-4 * np.sqrt(g[f"{tag}_gradsum::{k}"][1]), k
+        checked += 1
+    assert checked == 18

@@ -65,13 +65,12 @@ def step_flops(B: int, N: int, T: int) -> float:
 
 
 def csrc_sha16() -> str:
-    """Hash of the kernel sources and the ABI header: ties a committed PMC summary to the build it was taken on."""
+    """Hash of the encoder kernel sources (the attention and linear-stage kernels and their shared headers): ties a committed
+    PMC summary to the kernels it was taken on."""
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(ROOT, "gmf_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "gmf_amd", "csrc", "*.hpp")) +
-                   glob.glob(os.path.join(ROOT, "gmf_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "include", "gmf_hip.h")])
-    for f in files:
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for name in ("encoder_kernels.hip", "encoder_h2.hip", "enc_common.hpp", "enc_ff.hpp", "mfma_core.hpp"):
+        h.update(name.encode())
+        h.update(open(os.path.join(ROOT, "gmf_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -91,13 +91,20 @@ SIGNATURES = {
     "gmf_spectral_matching_backward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp, _vp]),
     "gmf_classification_loss": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "gmf_stem_forward": (C.c_int, [_vp, _vp, _ll, _ll, _ll, _ll, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
-    "gmf_gemm_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int] + [_ll] * 6 + [C.c_int, C.c_float, _vp]),
+    "gmf_gemm_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int] + [_ll] * 6 + [C.c_int, C.c_float, C.c_int, _vp]),
     "gmf_lcpe": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "gmf_layernorm_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, C.c_int, _vp]),
     "gmf_layernorm_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, C.c_int, _vp]),
-    "gmf_softmax_rows": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _ll, C.c_int, C.c_float, _vp]),
+    "gmf_softmax_rows": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _ll, C.c_int, C.c_float, _vp]),
     "gmf_geglu": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _ll, C.c_int, _vp]),
-    "gmf_colsum": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _ll, C.c_int, _vp, _vp]),
+    "gmf_colsum": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _ll, C.c_int, _vp, _vp]),
+    "gmf_batchnorm_train_forward": (C.c_int, [_vp] * 9 + [_ll, C.c_int, C.c_float, C.c_float, C.c_int, _vp]),
+    "gmf_batchnorm_train_backward": (C.c_int, [_vp] * 10 + [_ll, C.c_int, _vp]),
+    "gmf_normalize_rows": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _ll, C.c_int, _vp]),
+    "gmf_relu_backward": (C.c_int, [_vp, _vp, _vp, _vp, _ll, _vp]),
+    "gmf_classification_backward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "gmf_spectral_matching_dense_backward": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "gmf_similarity_backward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp]),
     "gmf_conv_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
     "gmf_bias_relu_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, C.c_int, _vp]),
     "gmf_transformation_loss": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float, _vp, _vp]),

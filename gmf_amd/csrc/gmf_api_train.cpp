@@ -7,7 +7,7 @@ extern "C" {
 
 int gmf_gemm_f32(gmf_handle* h, int trans_a, int trans_b, const float* A, const float* B, float* C, const float* bias,
                  const float* residual, int M, int N, int K, long long lda, long long ldb, long long ldc, long long stride_a,
-                 long long stride_b, long long stride_c, int batch, float alpha, gmf_stream_t stream) {
+                 long long stride_b, long long stride_c, int batch, float alpha, int relu, gmf_stream_t stream) {
   GMF_REQUIRE(h && A && B && C, GMF_ERR_BAD_ARG, "gemm_f32: null pointer");
   GMF_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, GMF_ERR_UNSUPPORTED_SHAPE, "gemm_f32: empty problem");
   GMF_REQUIRE((long long)batch * ((M + 127) / 128) <= 2000000 , GMF_ERR_UNSUPPORTED_SHAPE, "gemm_f32: grid too large");
@@ -19,7 +19,7 @@ int gmf_gemm_f32(gmf_handle* h, int trans_a, int trans_b, const float* A, const 
     part = arena_take<float>(h, (size_t)batch * ksplits * M * N);
   }
   GMF_HIP(gmf::launch_gemm_f32(trans_a != 0, trans_b != 0, A, B, C, bias, residual, M, N, K, (long)lda, (long)ldb, (long)ldc,
-                               (long)stride_a, (long)stride_b, (long)stride_c, batch, alpha, part, ksplits, S(stream)));
+                               (long)stride_a, (long)stride_b, (long)stride_c, batch, alpha, part, ksplits, relu ? 1 : 0, S(stream)));
   return GMF_OK;
 }
 
@@ -50,12 +50,12 @@ int gmf_layernorm_backward(gmf_handle* h, const float* dy, const float* x, const
   return GMF_OK;
 }
 
-int gmf_softmax_rows(gmf_handle* h, int backward, const float* a, const float* b, float* out, long long rows, int T, float scale,
-                     gmf_stream_t stream) {
+int gmf_softmax_rows(gmf_handle* h, int backward, const float* a, const float* b, const float* mul, float* out, long long rows, int T,
+                     float scale, gmf_stream_t stream) {
   GMF_REQUIRE(h && a && out && (!backward || b), GMF_ERR_BAD_ARG, "softmax_rows: null pointer");
   GMF_REQUIRE(rows > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "softmax_rows: empty input");
   SetDevice sd(h);
-  GMF_HIP(gmf::launch_softmax(backward != 0, a, b, out, (long)rows, T, scale, S(stream)));
+  GMF_HIP(gmf::launch_softmax(backward != 0, a, b, mul, out, (long)rows, T, scale, S(stream)));
   return GMF_OK;
 }
 
@@ -68,8 +68,8 @@ int gmf_geglu(gmf_handle* h, int backward, const float* hdn, const float* dg, fl
   return GMF_OK;
 }
 
-int gmf_colsum(gmf_handle* h, const float* x, const float* y, const float* mean, const float* rstd, int shift, int L, long long rows,
-               int C, float* out, gmf_stream_t stream) {
+int gmf_colsum(gmf_handle* h, const float* x, const float* y, const float* mean, const float* rstd, const float* cmean,
+               const float* crstd, int center_x, int shift, int L, long long rows, int C, float* out, gmf_stream_t stream) {
   GMF_REQUIRE(h && x && out, GMF_ERR_BAD_ARG, "colsum: null pointer");
   GMF_REQUIRE((mean == nullptr) == (rstd == nullptr) && (!mean || y), GMF_ERR_BAD_ARG, "colsum: mean and rstd come together, with y");
   GMF_REQUIRE(rows > 0 && C > 0 && L > 0 && rows % L == 0, GMF_ERR_UNSUPPORTED_SHAPE, "colsum: rows must be a positive multiple of L");
@@ -78,7 +78,116 @@ int gmf_colsum(gmf_handle* h, const float* x, const float* y, const float* mean,
   const size_t n_part = (size_t)gmf::colsum_chunks((long)rows) * C;
   if (int rc = arena_reserve(h, arena_need(n_part, 4))) return rc;
   float* part = arena_take<float>(h, n_part);
-  GMF_HIP(gmf::launch_colsum(x, y, mean, rstd, shift, L, (long)rows, C, part, out, S(stream)));
+  GMF_REQUIRE(!center_x || cmean, GMF_ERR_BAD_ARG, "colsum: center_x needs cmean");
+  GMF_HIP(gmf::launch_colsum(x, y, mean, rstd, cmean, crstd, center_x ? 1 : 0, shift, L, (long)rows, C, part, out, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_batchnorm_train_forward(gmf_handle* h, const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                float* rstd, float* running_mean, float* running_var, long long rows, int C, float eps,
+                                float momentum, int relu, gmf_stream_t stream) {
+  GMF_REQUIRE(h && x && gamma && beta && y && mean && rstd, GMF_ERR_BAD_ARG, "batchnorm_train_forward: null pointer");
+  GMF_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GMF_ERR_BAD_ARG, "batchnorm_train_forward: running stats come together");
+  GMF_REQUIRE(rows > 1 && C > 0, GMF_ERR_UNSUPPORTED_SHAPE, "batchnorm_train_forward: need more than one row");
+  SetDevice sd(h);
+  const size_t n_part = (size_t)gmf::colsum_chunks((long)rows) * C;
+  if (int rc = arena_reserve(h, arena_need(n_part, 4) + 2 * arena_need((size_t)C, 4))) return rc;
+  float* part = arena_take<float>(h, n_part);
+  float* sum = arena_take<float>(h, (size_t)C);
+  float* sumsq = arena_take<float>(h, (size_t)C);
+  hipStream_t st = S(stream);
+  GMF_HIP(gmf::launch_colsum(x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, (int)rows, (long)rows, C, part, sum, st));
+  GMF_HIP(gmf::launch_bn_finish(sum, nullptr, mean, rstd, nullptr, nullptr, C, (long)rows, eps, momentum, st));
+  // sum of squared deviations: x' = x - mean (centred), y' = (x - mean) * 1
+  GMF_HIP(gmf::launch_colsum(x, x, nullptr, nullptr, mean, nullptr, 1, 0, (int)rows, (long)rows, C, part, sumsq, st));
+  GMF_HIP(gmf::launch_bn_finish(sum, sumsq, mean, rstd, running_mean, running_var, C, (long)rows, eps, momentum, st));
+  GMF_HIP(gmf::launch_bn_apply(x, mean, rstd, gamma, beta, y, (long)rows, C, relu ? 1 : 0, st));
+  return GMF_OK;
+}
+
+int gmf_batchnorm_train_backward(gmf_handle* h, const float* dy, const float* x, const float* y_relu, const float* mean,
+                                 const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta, long long rows, int C,
+                                 gmf_stream_t stream) {
+  GMF_REQUIRE(h && dy && x && mean && rstd && gamma && dx && dgamma && dbeta, GMF_ERR_BAD_ARG, "batchnorm_train_backward: null pointer");
+  GMF_REQUIRE(rows > 1 && C > 0, GMF_ERR_UNSUPPORTED_SHAPE, "batchnorm_train_backward: need more than one row");
+  SetDevice sd(h);
+  const size_t n_part = (size_t)gmf::colsum_chunks((long)rows) * C;
+  const size_t n_el = (size_t)rows * C;
+  if (int rc = arena_reserve(h, arena_need(n_part, 4) + (y_relu ? arena_need(n_el, 4) : 0))) return rc;
+  float* part = arena_take<float>(h, n_part);
+  hipStream_t st = S(stream);
+  const float* g = dy;
+  if (y_relu) {                                   // the ReLU that followed the BatchNorm: mask the incoming gradient by its output
+    float* gm = arena_take<float>(h, n_el);
+    GMF_HIP(gmf::launch_relu_bwd(dy, y_relu, gm, (long)n_el, st));
+    g = gm;
+  }
+  GMF_HIP(gmf::launch_colsum(g, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, (int)rows, (long)rows, C, part, dbeta, st));
+  GMF_HIP(gmf::launch_colsum(g, x, nullptr, nullptr, mean, rstd, 0, 0, (int)rows, (long)rows, C, part, dgamma, st));
+  GMF_HIP(gmf::launch_bn_bwd(g, x, mean, rstd, gamma, dbeta, dgamma, dx, (long)rows, C, st));
+  return GMF_OK;
+}
+
+int gmf_normalize_rows(gmf_handle* h, int backward, const float* a, const float* dy, float* nrm, float* out, long long rows, int C,
+                       gmf_stream_t stream) {
+  GMF_REQUIRE(h && a && nrm && out && (!backward || dy), GMF_ERR_BAD_ARG, "normalize_rows: null pointer");
+  GMF_REQUIRE(rows > 0 && C > 0, GMF_ERR_UNSUPPORTED_SHAPE, "normalize_rows: empty input");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_normalize(backward != 0, a, dy, nrm, out, (long)rows, C, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_relu_backward(gmf_handle* h, const float* dy, const float* y, float* out, long long total, gmf_stream_t stream) {
+  GMF_REQUIRE(h && dy && y && out, GMF_ERR_BAD_ARG, "relu_backward: null pointer");
+  GMF_REQUIRE(total > 0, GMF_ERR_UNSUPPORTED_SHAPE, "relu_backward: empty input");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_relu_bwd(dy, y, out, (long)total, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_classification_backward(gmf_handle* h, const float* pred, const float* gt, const float* weight, int B, int N, int balanced,
+                                float* d_pred, gmf_stream_t stream) {
+  GMF_REQUIRE(h && pred && gt && d_pred, GMF_ERR_BAD_ARG, "classification_backward: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "classification_backward: empty input");
+  SetDevice sd(h);
+  if (int rc = arena_reserve(h, arena_need(1, 4))) return rc;
+  float* pw = arena_take<float>(h, 1);
+  GMF_HIP(gmf::launch_bce_bwd(pred, gt, weight, d_pred, pw, balanced, (long)B * N, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_spectral_matching_dense_backward(gmf_handle* h, const float* M, int ldm, const float* gt_labels, int B, int N, int balanced,
+                                         float* dM, gmf_stream_t stream) {
+  GMF_REQUIRE(h && M && gt_labels && dM, GMF_ERR_BAD_ARG, "spectral_matching_dense_backward: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0 && ldm >= N, GMF_ERR_UNSUPPORTED_SHAPE, "spectral_matching_dense_backward: need ldm >= N > 0");
+  SetDevice sd(h);
+  if (int rc = arena_reserve(h, arena_need((size_t)4 * B, 4))) return rc;
+  float* consts = arena_take<float>(h, (size_t)4 * B);
+  GMF_HIP(gmf::launch_sm_dense_bwd(M, ldm, gt_labels, consts, dM, B, N, balanced, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_similarity_backward(gmf_handle* h, const float* feat_n, const float* dM, int B, int N, float sigma, float* d_feat_n,
+                            float* d_sigma, gmf_stream_t stream) {
+  GMF_REQUIRE(h && feat_n && dM && d_feat_n && d_sigma, GMF_ERR_BAD_ARG, "similarity_backward: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "similarity_backward: empty input");
+  GMF_REQUIRE(sigma != 0.f, GMF_ERR_BAD_ARG, "similarity_backward: sigma must be non-zero");
+  SetDevice sd(h);
+  const size_t nn = (size_t)B * N * N, rows = (size_t)B * N;
+  const size_t n_part = (size_t)gmf::colsum_chunks((long)rows);
+  if (int rc = arena_reserve(h, 2 * arena_need(nn, 4) + arena_need(rows, 4) + arena_need(n_part, 4))) return rc;
+  float* Sm = arena_take<float>(h, nn);
+  float* G = arena_take<float>(h, nn);
+  float* rowdsig = arena_take<float>(h, rows);
+  float* part = arena_take<float>(h, n_part);
+  hipStream_t st = S(stream);
+  const long ld = 128, sF = (long)N * 128, sN = (long)N * N;
+  // S = Fn Fn^T per pair, G = dM * [0 <= u <= 1] / sigma^2, dFn = G Fn + G^T Fn, dsigma = sum of the row partials
+  GMF_HIP(gmf::launch_gemm_f32(false, true, feat_n, feat_n, Sm, nullptr, nullptr, N, N, 128, ld, ld, N, sF, sF, sN, B, 1.0f, nullptr, 1, 0, st));
+  GMF_HIP(gmf::launch_sim_bwd_G(Sm, dM, G, rowdsig, B, N, sigma, st));
+  GMF_HIP(gmf::launch_gemm_f32(false, false, G, feat_n, d_feat_n, nullptr, nullptr, N, 128, N, N, ld, ld, sN, sF, sF, B, 1.0f, nullptr, 1, 0, st));
+  GMF_HIP(gmf::launch_gemm_f32(true, false, G, feat_n, d_feat_n, nullptr, d_feat_n, N, 128, N, N, ld, ld, sN, sF, sF, B, 1.0f, nullptr, 1, 0, st));
+  GMF_HIP(gmf::launch_colsum(rowdsig, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, (int)rows, (long)rows, 1, part, d_sigma, st));
   return GMF_OK;
 }
 

@@ -110,21 +110,35 @@ hipError_t launch_transformation_loss(const float* trans, const float* gt_trans,
                                       const float* probs, double* part, int B, int N, float re_thre, float te_thre,
                                       float* out, hipStream_t s);
 
-// training primitives (row f-4, second backward slice): train_kernels.hip
+// training primitives (row f-4): train_kernels.hip
 int gemm_ksplits(int M, int N, int K, int batch);
 hipError_t launch_gemm_f32(bool ta, bool tb, const float* A, const float* B, float* C, const float* bias, const float* R, int M, int N,
                            int K, long lda, long ldb, long ldc, long sA, long sB, long sC, int batch, float alpha, float* part,
-                           int ksplits, hipStream_t s);
+                           int ksplits, int relu, hipStream_t s);
 hipError_t launch_lcpe(bool backward, const float* x, const float* w, const float* bias, float* y, int rows, int L, int C, hipStream_t s);
 hipError_t launch_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long rows, int C,
                          hipStream_t s);
 hipError_t launch_ln_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dx_add,
                          float* dx, long rows, int C, hipStream_t s);
-hipError_t launch_softmax(bool backward, const float* a, const float* b, float* out, long rows, int T, float scale, hipStream_t s);
+hipError_t launch_softmax(bool backward, const float* a, const float* b, const float* mul, float* out, long rows, int T, float scale,
+                          hipStream_t s);
 hipError_t launch_geglu(bool backward, const float* hdn, const float* dg, float* out, long rows, int H, hipStream_t s);
 int colsum_chunks(long rows);
-hipError_t launch_colsum(const float* x, const float* y, const float* mean, const float* rstd, int shift, int L, long rows, int C,
-                         float* part, float* out, hipStream_t s);
+hipError_t launch_colsum(const float* x, const float* y, const float* mean, const float* rstd, const float* cmean, const float* crstd,
+                         int center_x, int shift, int L, long rows, int C, float* part, float* out, hipStream_t s);
+hipError_t launch_bn_finish(const float* sum, const float* sumsq, float* mean, float* rstd, float* run_mean, float* run_var, int C,
+                            long rows, float eps, float momentum, hipStream_t s);
+hipError_t launch_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
+                           long rows, int C, int relu, hipStream_t s);
+hipError_t launch_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* sdy,
+                         const float* sdyx, float* dx, long rows, int C, hipStream_t s);
+hipError_t launch_relu_bwd(const float* dy, const float* y, float* out, long total, hipStream_t s);
+hipError_t launch_bce_bwd(const float* pred, const float* gt, const float* weight, float* dpred, float* pw_scratch, int balanced,
+                          long total, hipStream_t s);
+hipError_t launch_sm_dense_bwd(const float* M, long ldm, const float* gt, float* consts, float* dM, int B, int N, int balanced,
+                               hipStream_t s);
+hipError_t launch_normalize(bool backward, const float* a, const float* dy, float* nrm, float* out, long rows, int C, hipStream_t s);
+hipError_t launch_sim_bwd_G(const float* S, const float* dM, float* G, float* rowdsig, int B, int N, float sigma, hipStream_t s);
 
 // image encoder epilogue (row f-1): image_kernels.hip
 hipError_t launch_stem_h2(const float* x, long sb, long sc, long sh, long sw, const float* wimg, const float* bias, float* y,

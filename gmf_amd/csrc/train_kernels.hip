@@ -34,7 +34,7 @@ template <bool TA, bool TB>
 __global__ void __launch_bounds__(256)
 k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C, const float* __restrict__ bias,
            const float* __restrict__ R, int M, int N, int K, long lda, long ldb, long ldc, long sA, long sB, long sC,
-           int ksplits, int kchunk, float alpha, float* __restrict__ part) {
+           int ksplits, int kchunk, float alpha, float* __restrict__ part, int relu) {
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
   const int b = blockIdx.z / ksplits, ks = blockIdx.z - b * ksplits;
@@ -93,7 +93,7 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
           float v = alpha * acc[rb][cb][r];
           if (bias) v += bias[col];
           if (R) v += R[(size_t)b * sC + (size_t)row * ldc + col];
-          C[(size_t)b * sC + (size_t)row * ldc + col] = v;
+          C[(size_t)b * sC + (size_t)row * ldc + col] = relu ? fmaxf(v, 0.f) : v;
         }
       }
     }
@@ -101,7 +101,7 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
 
 __global__ void __launch_bounds__(256)
 k_gemm_reduce(const float* __restrict__ part, float* __restrict__ C, const float* __restrict__ bias, const float* __restrict__ R,
-              int M, int N, long ldc, long sC, int ksplits, float alpha, long total) {
+              int M, int N, long ldc, long sC, int ksplits, float alpha, long total, int relu) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const long mn = (long)M * N;
@@ -113,7 +113,7 @@ k_gemm_reduce(const float* __restrict__ part, float* __restrict__ C, const float
   float v = alpha * s;
   if (bias) v += bias[col];
   if (R) v += R[(size_t)b * sC + (size_t)row * ldc + col];
-  C[(size_t)b * sC + (size_t)row * ldc + col] = v;
+  C[(size_t)b * sC + (size_t)row * ldc + col] = relu ? fmaxf(v, 0.f) : v;
 }
 
 // =========================================================================================
@@ -201,29 +201,34 @@ k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float*
 // Row softmax of scale * S (T <= 4096, one wave per row) and its backward dS = scale * P * (dP - sum_j dP_j P_j).
 // =========================================================================================
 __global__ void __launch_bounds__(256)
-k_softmax_fwd(const float* __restrict__ S, float* __restrict__ P, long rows, int T, float scale) {
+k_softmax_fwd(const float* __restrict__ S, const float* __restrict__ mul, float* __restrict__ P, long rows, int T, float scale) {
+  // mul (optional, same shape as S): the logits are mul * (S * scale) - the spatial-consistency attention's
+  // softmax(compat * QK^T / sqrt(C)) (PointDSC.py:60-62)
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* s = S + row * T;
+  const float* m = mul ? mul + row * T : nullptr;
   float mx = -INFINITY;
-  for (int j = lane; j < T; j += 64) mx = fmaxf(mx, s[j] * scale);
+  for (int j = lane; j < T; j += 64) mx = fmaxf(mx, m ? m[j] * (s[j] * scale) : s[j] * scale);
   mx = wave_max_f(mx);
   float sum = 0.f;
-  for (int j = lane; j < T; j += 64) sum += expf(s[j] * scale - mx);
+  for (int j = lane; j < T; j += 64) sum += expf((m ? m[j] * (s[j] * scale) : s[j] * scale) - mx);
   const float inv = 1.0f / wave_sum_f(sum);
-  for (int j = lane; j < T; j += 64) P[row * T + j] = expf(s[j] * scale - mx) * inv;
+  for (int j = lane; j < T; j += 64) P[row * T + j] = expf((m ? m[j] * (s[j] * scale) : s[j] * scale) - mx) * inv;
 }
 
 __global__ void __launch_bounds__(256)
-k_softmax_bwd(const float* __restrict__ P, const float* __restrict__ dP, float* __restrict__ dS, long rows, int T, float scale) {
+k_softmax_bwd(const float* __restrict__ P, const float* __restrict__ dP, const float* __restrict__ mul, float* __restrict__ dS,
+              long rows, int T, float scale) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   float dot = 0.f;
   for (int j = lane; j < T; j += 64) dot = fmaf(P[row * T + j], dP[row * T + j], dot);
   dot = wave_sum_f(dot);
-  for (int j = lane; j < T; j += 64) dS[row * T + j] = scale * P[row * T + j] * (dP[row * T + j] - dot);
+  for (int j = lane; j < T; j += 64)
+    dS[row * T + j] = scale * (mul ? mul[row * T + j] : 1.0f) * P[row * T + j] * (dP[row * T + j] - dot);
 }
 
 // =========================================================================================
@@ -262,18 +267,23 @@ k_geglu_bwd(const float* __restrict__ hdn, const float* __restrict__ dg, float* 
 // =========================================================================================
 __global__ void __launch_bounds__(256)
 k_colsum_partial(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ mean,
-                 const float* __restrict__ rstd, int shift, int L, long rows, int C, int rows_per_chunk, float* __restrict__ part) {
+                 const float* __restrict__ rstd, const float* __restrict__ cmean, const float* __restrict__ crstd, int center_x,
+                 int shift, int L, long rows, int C, int rows_per_chunk, float* __restrict__ part) {
+  // cmean / crstd (per COLUMN: BatchNorm's statistics): y' = (y - cmean[c]) * crstd[c]; center_x: x' = x - cmean[c]
   const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + (long)rows_per_chunk);
   for (int c = threadIdx.x; c < C; c += 256) {
+    const float cm = cmean ? cmean[c] : 0.f, cr = crstd ? crstd[c] : 1.f;
     float s = 0.f;
     for (long r = r0; r < r1; ++r) {
       float v = x[r * C + c];
+      if (center_x) v -= cm;
       if (y) {
         const int l = (int)(r % L) + shift;
         if (l < 0 || l >= L) continue;
         const long ry = r + shift;
         float yv = y[ry * C + c];
         if (mean) yv = (yv - mean[ry]) * rstd[ry];
+        if (cmean) yv = (yv - cm) * cr;
         v *= yv;
       }
       s += v;
@@ -291,6 +301,176 @@ k_colsum_final(const float* __restrict__ part, int chunks, int C, float* __restr
   out[c] = s;
 }
 
+// =========================================================================================
+// F.normalize(x, p = 2, dim = -1) (PointDSC.py:229): y = x / max(||x||, 1e-12), one wave per row; the norm is saved.
+// Backward from the saved OUTPUT: dx = (dy - y <dy, y>) / max(||x||, 1e-12).
+// =========================================================================================
+__global__ void __launch_bounds__(256)
+k_normalize_fwd(const float* __restrict__ x, float* __restrict__ nrm, float* __restrict__ y, long rows, int C) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) { const float v = x[row * C + c]; s = fmaf(v, v, s); }
+  const float n = fmaxf(sqrtf(wave_sum_f(s)), 1e-12f);
+  for (int c = lane; c < C; c += 64) y[row * C + c] = x[row * C + c] / n;
+  if (lane == 0) nrm[row] = n;
+}
+
+__global__ void __launch_bounds__(256)
+k_normalize_bwd(const float* __restrict__ y, const float* __restrict__ dy, const float* __restrict__ nrm, float* __restrict__ dx,
+                long rows, int C) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float d = 0.f;
+  for (int c = lane; c < C; c += 64) d = fmaf(dy[row * C + c], y[row * C + c], d);
+  d = wave_sum_f(d);
+  const float inv = 1.0f / nrm[row];
+  for (int c = lane; c < C; c += 64) dx[row * C + c] = (dy[row * C + c] - y[row * C + c] * d) * inv;
+}
+
+// =========================================================================================
+// BatchNorm1d in TRAINING mode over the rows of x [rows, C] (the reference's BatchNorm1d on [B, C, N], PointDSC.py:13-21,
+// 104-109: statistics per channel over batch and positions): the column statistics come from k_colsum_*; here the
+// element-wise halves.  forward: y = (x - mean[c]) * rstd[c] * gamma[c] + beta[c] (-> ReLU).
+// backward (dy already masked by the ReLU): dx = gamma rstd (dy - sdy / R - xhat sdyx / R), sdy = sum_r dy, sdyx = sum_r dy xhat.
+// =========================================================================================
+__global__ void __launch_bounds__(256)
+k_bn_apply(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+           const float* __restrict__ beta, float* __restrict__ y, int C, int relu, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const float v = fmaf((x[idx] - mean[c]) * rstd[c], gamma[c], beta[c]);
+  y[idx] = relu ? fmaxf(v, 0.f) : v;
+}
+
+__global__ void __launch_bounds__(256)
+k_bn_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+         const float* __restrict__ gamma, const float* __restrict__ sdy, const float* __restrict__ sdyx, float* __restrict__ dx, int C,
+         float inv_rows, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const float xh = (x[idx] - mean[c]) * rstd[c];
+  dx[idx] = gamma[c] * rstd[c] * (dy[idx] - sdy[c] * inv_rows - xh * sdyx[c] * inv_rows);
+}
+
+// mean[c] = s[c] / rows ; rstd[c] = rsqrt(ss[c] / rows + eps) ; running statistics as torch updates them (momentum, unbiased var)
+__global__ void k_bn_finish(const float* __restrict__ s, const float* __restrict__ ss, float* __restrict__ mean, float* __restrict__ rstd,
+                            float* __restrict__ run_mean, float* __restrict__ run_var, int C, float rows, float eps, float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  if (ss == nullptr) { mean[c] = s[c] / rows; return; }
+  const float var = ss[c] / rows;
+  rstd[c] = rsqrtf(var + eps);
+  if (run_mean) {
+    run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean[c];
+    run_var[c] = (1.0f - momentum) * run_var[c] + momentum * var * (rows / fmaxf(rows - 1.0f, 1.0f));
+  }
+}
+
+// out = y > 0 ? dy : 0   (ReLU backward from the saved OUTPUT)
+__global__ void __launch_bounds__(256)
+k_relu_bwd(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  out[idx] = y[idx] > 0.f ? dy[idx] : 0.f;
+}
+
+// =========================================================================================
+// Loss backward halves (libs/loss.py) for an upstream gradient of 1.
+//   k_bce_bwd: d/dpred of mean BCE-with-logits with pos_weight pw (pw = 1: the unbalanced form; weight: optional per-element):
+//              (sigmoid(x) (1 - gt + pw gt) - pw gt) * w / count                                        loss.py:85-93
+//   k_sm_dense_bwd: dL/dM of SpectralMatchingLoss(M, gt) with the per-pair constants cP, cN of k_sm_bwd_prep (consts[b] = {cP, cN, ..}):
+//              gtM (M - 1) cP + (1 - gtM) M cN, zero on the diagonal                                     loss.py:116-140
+//   k_sim_bwd_G: from S = Fn Fn^T and an upstream dM: G = dM [0 <= u <= 1] / sigma^2 off the diagonal (clamp's gradient mask,
+//              u = 1 - (1 - S) / sigma^2), and rowdsig[r] = sum_j dM [..] 2 (1 - S) / sigma^3            PointDSC.py:231-234
+// =========================================================================================
+// pw[0] = (relu(sum(1 - gt) - 1) + 1) / (relu(sum(gt) - 1) + 1) over the whole batch (loss.py:85-86,93), one workgroup
+__global__ void __launch_bounds__(1024)
+k_bce_posweight(const float* __restrict__ gt, long total, float* __restrict__ pw) {
+  __shared__ float red[16];
+  float n1 = 0.f;
+  for (long i = threadIdx.x; i < total; i += 1024) n1 += gt[i];
+  n1 = wave_sum_f(n1);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    const double pos = fmax(s - 1.0, 0.0) + 1.0, neg = fmax((double)total - s - 1.0, 0.0) + 1.0;
+    pw[0] = (float)(neg / pos);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_bce_bwd(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ weight, float* __restrict__ dpred,
+          const float* __restrict__ pw_dev, float inv_count, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const float pos_weight = pw_dev ? pw_dev[0] : 1.0f;
+  const float x = pred[idx], g = gt[idx];
+  const float sg = 1.0f / (1.0f + expf(-x));
+  float d = sg * (1.0f - g + pos_weight * g) - pos_weight * g;
+  if (weight) d *= weight[idx];
+  dpred[idx] = d * inv_count;
+}
+
+__global__ void __launch_bounds__(256)
+k_sm_dense_bwd(const float* __restrict__ M, long ldm, const float* __restrict__ gt, const float* __restrict__ consts,
+               float* __restrict__ dM, int N, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const long nn = (long)N * N;
+  const int b = (int)(idx / nn);
+  const long rem = idx - (long)b * nn;
+  const int i = (int)(rem / N), j = (int)(rem - (long)i * N);
+  const float m = M[((size_t)b * N + i) * ldm + j];
+  const bool both = (i != j) && gt[(size_t)b * N + i] == 1.0f && gt[(size_t)b * N + j] == 1.0f;
+  dM[idx] = (i == j) ? 0.f : (both ? (m - 1.0f) * consts[4 * b] : m * consts[4 * b + 1]);
+}
+
+__global__ void __launch_bounds__(256)
+k_sim_bwd_G(const float* __restrict__ S, const float* __restrict__ dM, float* __restrict__ G, float* __restrict__ rowdsig, int N,
+            float inv_sig2, float two_inv_sig3, long rows) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int i = (int)(row % N);
+  float ds = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    const float s = S[row * N + j], u = 1.0f - (1.0f - s) * inv_sig2;
+    const bool inside = (u >= 0.f) && (u <= 1.f) && (j != i);
+    const float d = inside ? dM[row * N + j] : 0.f;
+    G[row * N + j] = d * inv_sig2;
+    ds = fmaf(d, (1.0f - s) * two_inv_sig3, ds);
+  }
+  ds = wave_sum_f(ds);
+  if (lane == 0) rowdsig[row] = ds;
+}
+
+// per pair consts {cP, cN, 0, 0} of the spectral-matching loss (the balanced form or the MSE form), as k_sm_bwd_prep
+__global__ void __launch_bounds__(256)
+k_sm_consts(const float* __restrict__ gt, float* __restrict__ consts, int B, int N, int balanced) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float n1 = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) n1 += (gt[(size_t)b * N + i] == 1.0f) ? 1.f : 0.f;
+  n1 = wave_sum_f(n1);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double n = (double)red[0] + red[1] + red[2] + red[3];
+    const double np = n * n - n, nn = (double)N * N - np;
+    double cP, cN;
+    if (balanced) { cP = 1.0 / ((double)B * (fmax(np - 1.0, 0.0) + 1.0)); cN = 1.0 / ((double)B * (fmax(nn - 1.0, 0.0) + 1.0)); }
+    else cP = cN = 2.0 / ((double)B * (double)N * (double)N);
+    consts[4 * b] = (float)cP; consts[4 * b + 1] = (float)cN; consts[4 * b + 2] = 0.f; consts[4 * b + 3] = 0.f;
+  }
+}
+
 // -----------------------------------------------------------------------------------------
 static inline unsigned blocks_of(long total) { return (unsigned)((total + 255) / 256); }
 
@@ -305,13 +485,13 @@ int gemm_ksplits(int M, int N, int K, int batch) {
 
 hipError_t launch_gemm_f32(bool ta, bool tb, const float* A, const float* B, float* C, const float* bias, const float* R, int M, int N,
                            int K, long lda, long ldb, long ldc, long sA, long sB, long sC, int batch, float alpha, float* part,
-                           int ksplits, hipStream_t s) {
+                           int ksplits, int relu, hipStream_t s) {
   if (!part) ksplits = 1;
   int kchunk = (K + ksplits - 1) / ksplits;
   kchunk = (kchunk + 15) / 16 * 16;
   ksplits = (K + kchunk - 1) / kchunk;
   const dim3 grid((N + 127) / 128, (M + 127) / 128, batch * ksplits);
-#define GMF_GEMM(TA, TB) hipLaunchKernelGGL((k_gemm_f32<TA, TB>), grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA, sB, sC, ksplits, kchunk, alpha, part)
+#define GMF_GEMM(TA, TB) hipLaunchKernelGGL((k_gemm_f32<TA, TB>), grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA, sB, sC, ksplits, kchunk, alpha, part, relu)
   if (ta && tb) GMF_GEMM(true, true);
   else if (ta) GMF_GEMM(true, false);
   else if (tb) GMF_GEMM(false, true);
@@ -319,7 +499,7 @@ hipError_t launch_gemm_f32(bool ta, bool tb, const float* A, const float* B, flo
 #undef GMF_GEMM
   if (ksplits > 1) {
     const long total = (long)batch * M * N;
-    hipLaunchKernelGGL(k_gemm_reduce, dim3(blocks_of(total)), dim3(256), 0, s, part, C, bias, R, M, N, ldc, sC, ksplits, alpha, total);
+    hipLaunchKernelGGL(k_gemm_reduce, dim3(blocks_of(total)), dim3(256), 0, s, part, C, bias, R, M, N, ldc, sC, ksplits, alpha, total, relu);
   }
   return hipGetLastError();
 }
@@ -343,10 +523,11 @@ hipError_t launch_ln_bwd(const float* dy, const float* x, const float* gamma, co
   return hipGetLastError();
 }
 
-hipError_t launch_softmax(bool backward, const float* a, const float* b, float* out, long rows, int T, float scale, hipStream_t s) {
+hipError_t launch_softmax(bool backward, const float* a, const float* b, const float* mul, float* out, long rows, int T, float scale,
+                          hipStream_t s) {
   const dim3 grid((unsigned)((rows + 3) / 4));
-  if (backward) hipLaunchKernelGGL(k_softmax_bwd, grid, dim3(256), 0, s, a, b, out, rows, T, scale);
-  else hipLaunchKernelGGL(k_softmax_fwd, grid, dim3(256), 0, s, a, out, rows, T, scale);
+  if (backward) hipLaunchKernelGGL(k_softmax_bwd, grid, dim3(256), 0, s, a, b, mul, out, rows, T, scale);
+  else hipLaunchKernelGGL(k_softmax_fwd, grid, dim3(256), 0, s, a, mul, out, rows, T, scale);
   return hipGetLastError();
 }
 
@@ -359,13 +540,70 @@ hipError_t launch_geglu(bool backward, const float* hdn, const float* dg, float*
 
 int colsum_chunks(long rows) { return (int)std::max<long>(1, std::min<long>(1024, (rows + 63) / 64)); }
 
-hipError_t launch_colsum(const float* x, const float* y, const float* mean, const float* rstd, int shift, int L, long rows, int C,
-                         float* part, float* out, hipStream_t s) {
+hipError_t launch_colsum(const float* x, const float* y, const float* mean, const float* rstd, const float* cmean, const float* crstd,
+                         int center_x, int shift, int L, long rows, int C, float* part, float* out, hipStream_t s) {
   const int chunks = colsum_chunks(rows);
   const int rpc = (int)((rows + chunks - 1) / chunks);
   const int used = (int)((rows + rpc - 1) / rpc);
-  hipLaunchKernelGGL(k_colsum_partial, dim3(used), dim3(256), 0, s, x, y, mean, rstd, shift, L, rows, C, rpc, part);
+  hipLaunchKernelGGL(k_colsum_partial, dim3(used), dim3(256), 0, s, x, y, mean, rstd, cmean, crstd, center_x, shift, L, rows, C, rpc, part);
   hipLaunchKernelGGL(k_colsum_final, dim3((C + 255) / 256), dim3(256), 0, s, part, used, C, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_bn_finish(const float* sum, const float* sumsq, float* mean, float* rstd, float* run_mean, float* run_var, int C,
+                            long rows, float eps, float momentum, hipStream_t s) {
+  hipLaunchKernelGGL(k_bn_finish, dim3((C + 255) / 256), dim3(256), 0, s, sum, sumsq, mean, rstd, run_mean, run_var, C, (float)rows, eps,
+                     momentum);
+  return hipGetLastError();
+}
+
+hipError_t launch_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
+                           long rows, int C, int relu, hipStream_t s) {
+  const long total = rows * C;
+  hipLaunchKernelGGL(k_bn_apply, dim3(blocks_of(total)), dim3(256), 0, s, x, mean, rstd, gamma, beta, y, C, relu, total);
+  return hipGetLastError();
+}
+
+hipError_t launch_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* sdy,
+                         const float* sdyx, float* dx, long rows, int C, hipStream_t s) {
+  const long total = rows * C;
+  hipLaunchKernelGGL(k_bn_bwd, dim3(blocks_of(total)), dim3(256), 0, s, dy, x, mean, rstd, gamma, sdy, sdyx, dx, C, 1.0f / (float)rows, total);
+  return hipGetLastError();
+}
+
+hipError_t launch_relu_bwd(const float* dy, const float* y, float* out, long total, hipStream_t s) {
+  hipLaunchKernelGGL(k_relu_bwd, dim3(blocks_of(total)), dim3(256), 0, s, dy, y, out, total);
+  return hipGetLastError();
+}
+
+hipError_t launch_bce_bwd(const float* pred, const float* gt, const float* weight, float* dpred, float* pw_scratch, int balanced,
+                          long total, hipStream_t s) {
+  const bool use_pw = balanced && !weight;            // (a per-element weight replaces the balancing, loss.py:87-89)
+  if (use_pw) hipLaunchKernelGGL(k_bce_posweight, dim3(1), dim3(1024), 0, s, gt, total, pw_scratch);
+  hipLaunchKernelGGL(k_bce_bwd, dim3(blocks_of(total)), dim3(256), 0, s, pred, gt, weight, dpred, use_pw ? pw_scratch : (float*)nullptr,
+                     1.0f / (float)total, total);
+  return hipGetLastError();
+}
+
+hipError_t launch_sm_dense_bwd(const float* M, long ldm, const float* gt, float* consts, float* dM, int B, int N, int balanced,
+                               hipStream_t s) {
+  hipLaunchKernelGGL(k_sm_consts, dim3(B), dim3(256), 0, s, gt, consts, B, N, balanced);
+  const long total = (long)B * N * N;
+  hipLaunchKernelGGL(k_sm_dense_bwd, dim3(blocks_of(total)), dim3(256), 0, s, M, ldm, gt, consts, dM, N, total);
+  return hipGetLastError();
+}
+
+hipError_t launch_sim_bwd_G(const float* S, const float* dM, float* G, float* rowdsig, int B, int N, float sigma, hipStream_t s) {
+  const long rows = (long)B * N;
+  hipLaunchKernelGGL(k_sim_bwd_G, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, dM, G, rowdsig, N, 1.0f / (sigma * sigma),
+                     2.0f / (sigma * sigma * sigma), rows);
+  return hipGetLastError();
+}
+
+hipError_t launch_normalize(bool backward, const float* a, const float* dy, float* nrm, float* out, long rows, int C, hipStream_t s) {
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (backward) hipLaunchKernelGGL(k_normalize_bwd, grid, dim3(256), 0, s, a, dy, nrm, out, rows, C);
+  else hipLaunchKernelGGL(k_normalize_fwd, grid, dim3(256), 0, s, a, nrm, out, rows, C);
   return hipGetLastError();
 }
 

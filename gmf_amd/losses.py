@@ -3,8 +3,9 @@ libs/trainer.py:194-262, evaluate()).  Forward only: the three modules the refer
 with its class names, constructor arguments, call signatures and return values, each one launch sequence of
 libgmf_hip.so over the C ABI.  Backward (the training half of SURVEY section 8 row f-4): the first slice is built -
 `SpectralMatchingLoss.from_features` is differentiable with respect to the unit features and the bandwidth sigma
-(`_SpectralMatchingFromFeatures`, one HIP launch for the whole N x N x 128 backward); every other module is forward
-only and raises if an input requires grad."""
+(`_SpectralMatchingFromFeatures`, one HIP launch for the whole N x N x 128 backward), and `ClassificationLoss(pred, gt)` /
+`SpectralMatchingLoss(M, gt)` carry their gradients when the logits / M require grad (the two losses the reference trains
+with by default); `TransformationLoss` is forward only and raises if an input requires grad."""
 from __future__ import annotations
 
 import torch
@@ -46,7 +47,7 @@ class ClassificationLoss(nn.Module):
         self.balanced = balanced
 
     def forward(self, pred, gt, weight=None):
-        _no_grad(pred, weight)
+        _no_grad(weight)
         pred = require_cuda_f32(pred, "pred").contiguous()
         gt = gt.to(device=pred.device, dtype=torch.float32).contiguous()
         if pred.dim() != 2 or gt.shape != pred.shape:
@@ -54,6 +55,12 @@ class ClassificationLoss(nn.Module):
         w = None
         if weight is not None:
             w = require_cuda_f32(weight, "weight").expand_as(pred).contiguous()
+        if pred.requires_grad and torch.is_grad_enabled():      # training: the loss carries d loss / d logits (libs/trainer.py:134)
+            from .train import classification_loss_train
+            loss, out = classification_loss_train(pred, gt, w, self.balanced)
+            host = out.cpu()
+            return {"loss": loss, "precision": float(host[1]), "recall": float(host[2]), "f1": float(host[3]),
+                    "logit_true": float(host[4]), "logit_false": float(host[5])}
         out = torch.empty(6, device=pred.device, dtype=torch.float32)
         h, st = handle_and_stream(pred)
         h.call("gmf_classification_loss", pred.data_ptr(), gt.data_ptr(), None if w is None else w.data_ptr(),
@@ -102,11 +109,13 @@ class SpectralMatchingLoss(nn.Module):
         self.balanced = balanced
 
     def forward(self, M, gt_labels):
-        _no_grad(M)
         M = require_cuda_f32(M, "M")
         if M.dim() != 3 or M.shape[1] != M.shape[2] or tuple(gt_labels.shape) != tuple(M.shape[:2]):
             raise RuntimeError("gmf_amd.SpectralMatchingLoss: expected M [bs,N,N] and gt_labels [bs,N]")
         N = M.shape[1]
+        if M.requires_grad and torch.is_grad_enabled():         # training: the loss carries dL/dM (libs/trainer.py:137)
+            from .train import spectral_matching_loss_train
+            return spectral_matching_loss_train(M, gt_labels.to(device=M.device, dtype=torch.float32).contiguous(), self.balanced)
         if not (M.stride(2) == 1 and M.stride(1) >= N and M.stride(0) == N * M.stride(1)):   # row-padded views pass
             M = M.contiguous()
         gt = gt_labels.to(device=M.device, dtype=torch.float32).contiguous()

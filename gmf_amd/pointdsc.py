@@ -428,7 +428,44 @@ class PointDSC(nn.Module):
         aux["seeds"] = seeds_out
         return final_T, labels, aux
 
+    def _forward_train(self, data):
+        """train() mode with autograd enabled (libs/trainer.py:131): the differentiable forward - HIP training primitives
+        behind torch.autograd.Functions (gmf_amd/train.py), BatchNorm in training mode (batch statistics, running statistics
+        updated).  Returns what the reference's non-test forward returns: `final_labels` = the inlier logits and `M` carry the
+        autograd graph (the two losses the reference trains with by default, config_3DMatch.py:50-52); `final_trans` comes
+        from the inference pose head and is detached (the reference's default `weight_transformation` is 0: its gradient is
+        never used; `TransformationLoss` raises if asked to differentiate)."""
+        from . import train as T
+        corr_pos = require_cuda_f32(data["corr_pos"], "corr_pos")
+        src = require_cuda_f32(data["src_keypts"], "src_keypts").contiguous()
+        tgt = require_cuda_f32(data["tgt_keypts"], "tgt_keypts").contiguous()
+        if "p_tokens" in data:
+            p_tok, q_tok = data["p_tokens"], data["q_tokens"]
+        else:       # the ResNet image encoder trains as a stock torch module (MIOpen convolutions, torch autograd)
+            enc = self.encoder.image_encoder
+            p_tok = enc(data["p_image"]).flatten(2).permute(0, 2, 1).contiguous()
+            q_tok = enc(data["q_image"]).flatten(2).permute(0, 2, 1).contiguous()
+        B, N, _ = corr_pos.shape
+        with torch.no_grad():                                   # PointDSC.py:216-221 (the reference computes it under no_grad)
+            # compat [B, N, N] dense: the trainable path materialises N x N tensors as the reference does (N = 1000 when training)
+            sd_ = torch.norm(src[:, :, None, :] - src[:, None, :, :], dim=-1)
+            td_ = torch.norm(tgt[:, :, None, :] - tgt[:, None, :, :], dim=-1)
+            compat = torch.clamp(1.0 - (sd_ - td_) ** 2 / float(self.sigma_spat) ** 2, min=0)
+        feat = T.encoder_train(self.encoder, corr_pos, compat, p_tok, q_tok)           # [B, N, C]
+        feat_n = T.normalize_rows(feat.reshape(B * N, -1)).reshape(B, N, -1)           # PointDSC.py:229
+        M = T.similarity_matrix_train(feat_n, self.sigma)                              # PointDSC.py:231-234
+        logits = T.classifier_train(self.classification, feat)                         # PointDSC.py:241
+        self.last_logits, self.last_features = logits, feat_n
+        with torch.no_grad():
+            final_trans, _, _ = self.pose_head(feat_n.detach().contiguous(), src, tgt, logits.detach().contiguous(), False)
+        return {"final_trans": final_trans, "final_labels": logits, "M": M}
+
     def forward(self, data):
+        if self.training and torch.is_grad_enabled():
+            if "testing" in data.keys():
+                raise RuntimeError("gmf_amd.PointDSC: test mode (`testing` key) in train() mode with autograd enabled - call eval() "
+                                   "or torch.no_grad() for inference")
+            return self._forward_train(data)
         corr_pos, src_keypts, tgt_keypts = data["corr_pos"], data["src_keypts"], data["tgt_keypts"]
         testing = "testing" in data.keys()
         if "p_tokens" in data:

@@ -20,7 +20,7 @@ def _p(t, off=0):
 
 
 def gemm(a, b, ta=False, tb=False, bias=None, residual=None, alpha=1.0, out=None, m=None, n=None, k=None, lda=None, ldb=None,
-         ldc=None, a_off=0, b_off=0, c_off=0, batch=1, sa=0, sb=0, sc=0):
+         ldc=None, a_off=0, b_off=0, c_off=0, batch=1, sa=0, sb=0, sc=0, relu=False):
     """out = alpha * op(a) op(b) (+ bias) (+ residual) through gmf_gemm_f32.  With the keyword geometry left out, `a` and `b`
     are dense 2-D row-major matrices; with it, any sub-matrix / batch of a larger buffer (offsets and strides in floats)."""
     if m is None:
@@ -33,7 +33,7 @@ def gemm(a, b, ta=False, tb=False, bias=None, residual=None, alpha=1.0, out=None
     h, st = handle_and_stream(a)
     h.call("gmf_gemm_f32", 1 if ta else 0, 1 if tb else 0, _p(a, a_off), _p(b, b_off), _p(out, c_off),
            None if bias is None else bias.data_ptr(), None if residual is None else _p(residual, c_off), m, n, k, lda, ldb,
-           ldc, sa, sb, sc, batch, float(alpha), st)
+           ldc, sa, sb, sc, batch, float(alpha), 1 if relu else 0, st)
     return out
 
 
@@ -43,7 +43,8 @@ def colsum(x, y=None, mean=None, rstd=None, shift=0, L=None):
     out = torch.empty(C, device=x.device, dtype=torch.float32)
     h, st = handle_and_stream(x)
     h.call("gmf_colsum", x.data_ptr(), None if y is None else y.data_ptr(), None if mean is None else mean.data_ptr(),
-           None if rstd is None else rstd.data_ptr(), int(shift), int(L if L is not None else rows), rows, C, out.data_ptr(), st)
+           None if rstd is None else rstd.data_ptr(), None, None, 0, int(shift), int(L if L is not None else rows), rows, C,
+           out.data_ptr(), st)
     return out
 
 
@@ -81,17 +82,19 @@ def lcpe_bwd(dy2d, w, L):
     return dx
 
 
-def softmax_rows(S2d, scale):
+def softmax_rows(S2d, scale, mul=None):
     P = torch.empty_like(S2d)
     h, st = handle_and_stream(S2d)
-    h.call("gmf_softmax_rows", 0, S2d.data_ptr(), None, P.data_ptr(), S2d.shape[0], S2d.shape[1], float(scale), st)
+    h.call("gmf_softmax_rows", 0, S2d.data_ptr(), None, None if mul is None else mul.data_ptr(), P.data_ptr(), S2d.shape[0],
+           S2d.shape[1], float(scale), st)
     return P
 
 
-def softmax_rows_bwd(P2d, dP2d, scale):
+def softmax_rows_bwd(P2d, dP2d, scale, mul=None):
     dS = torch.empty_like(P2d)
     h, st = handle_and_stream(P2d)
-    h.call("gmf_softmax_rows", 1, P2d.data_ptr(), dP2d.data_ptr(), dS.data_ptr(), P2d.shape[0], P2d.shape[1], float(scale), st)
+    h.call("gmf_softmax_rows", 1, P2d.data_ptr(), dP2d.data_ptr(), None if mul is None else mul.data_ptr(), dS.data_ptr(),
+           P2d.shape[0], P2d.shape[1], float(scale), st)
     return dS
 
 
@@ -224,3 +227,280 @@ def fusion_layer_train(layer, data, queries):
     """Differentiable FusionLayer / PerceiverIO forward (depth = 0, one cross head): gradients flow to `data`, `queries`
     and every parameter of `layer`."""
     return _FusionLayerTrain.apply(data, queries, bool(layer.pe), *_param_list(layer))
+
+
+# =====================================================================================================================
+# The rest of the encoder in training mode (PointDSC.py:10-74,77-143,175-181 with TRAIN-mode BatchNorm) and the two losses
+# the reference trains with by default (libs/loss.py:67-140; config_3DMatch.py:50-52: weight_transformation = 0).
+# Activations are token-major [B * N, C] rows (the reference's [B, C, N] transposed; BatchNorm1d over (B, N) per channel =
+# per column over all rows).
+# =====================================================================================================================
+class _Linear(torch.autograd.Function):
+    """y = relu?(x W^T + b (+ residual)); x [rows, in], W [out, in] (a Conv1d k = 1 weight squeezed), residual [rows, out]."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, residual, relu):
+        x = x.contiguous()
+        W2 = W.detach().reshape(W.shape[0], -1).contiguous()
+        y = gemm(x, W2, tb=True, bias=None if b is None else b.detach(), residual=None if residual is None else residual.contiguous(),
+                 relu=relu)
+        ctx.relu, ctx.has_b, ctx.has_r, ctx.wshape = relu, b is not None, residual is not None, W.shape
+        ctx.save_for_backward(x, W2, y if relu else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W2, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.relu:
+            g = torch.empty_like(dy)
+            h, st = handle_and_stream(dy)
+            h.call("gmf_relu_backward", dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), st)
+            dy = g
+        dW = gemm(dy, x, ta=True).reshape(ctx.wshape)
+        db = colsum(dy) if ctx.has_b else None
+        dx = gemm(dy, W2)
+        return dx, dW, db, (dy if ctx.has_r else None), None
+
+
+def linear(x, W, b=None, residual=None, relu=False):
+    return _Linear.apply(x, W, b, residual, relu)
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    """nn.BatchNorm1d in training mode on rows [rows, C] (+ fused ReLU); updates running_mean / running_var in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        x = x.contiguous()
+        rows, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        h, st = handle_and_stream(x)
+        h.call("gmf_batchnorm_train_forward", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+               rstd.data_ptr(), None if running_mean is None else running_mean.data_ptr(),
+               None if running_var is None else running_var.data_ptr(), rows, C, float(eps), float(momentum), 1 if relu else 0, st)
+        ctx.relu = relu
+        ctx.save_for_backward(x, gamma.detach(), mean, rstd, y if relu else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows, C = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, device=x.device, dtype=torch.float32)
+        db = torch.empty(C, device=x.device, dtype=torch.float32)
+        h, st = handle_and_stream(x)
+        h.call("gmf_batchnorm_train_backward", dy.data_ptr(), x.data_ptr(), y.data_ptr() if ctx.relu else None, mean.data_ptr(),
+               rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, C, st)
+        return dx, dg, db, None, None, None, None, None
+
+
+def batchnorm_train(x, bn, relu=False):
+    """`bn`: an nn.BatchNorm1d whose parameters and running statistics are used / updated exactly as torch would in train()."""
+    if bn.momentum is None:
+        raise NotImplementedError("gmf_amd.train: BatchNorm with cumulative moving average (momentum=None) is not used by GMF")
+    y = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                              bn.running_var if bn.track_running_stats else None, bn.eps, bn.momentum, relu)
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return y
+
+
+class _SCAttention(torch.autograd.Function):
+    """message = softmax_j(compat_ij * <q_i, k_j> / sqrt(C)) V per pair (PointDSC.py:56-64); q, k, v [B, N, C] token-major,
+    compat [B, N, N] (no gradient: the reference computes it under no_grad, PointDSC.py:216-221)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, compat):
+        q, k, v, compat = q.contiguous(), k.contiguous(), v.contiguous(), compat.contiguous()
+        B, N, Cc = q.shape
+        scale = 1.0 / (Cc ** 0.5)
+        S = torch.empty((B, N, N), device=q.device, dtype=torch.float32)
+        gemm(q, k, tb=True, out=S, m=N, n=N, k=Cc, lda=Cc, ldb=Cc, ldc=N, batch=B, sa=N * Cc, sb=N * Cc, sc=N * N)
+        P = softmax_rows(S.reshape(B * N, N), scale, mul=compat.reshape(B * N, N))
+        msg = torch.empty((B, N, Cc), device=q.device, dtype=torch.float32)
+        gemm(P, v, out=msg, m=N, n=Cc, k=N, lda=N, ldb=Cc, ldc=Cc, batch=B, sa=N * N, sb=N * Cc, sc=N * Cc)
+        ctx.scale = scale
+        ctx.save_for_backward(q, k, v, compat, P)
+        return msg
+
+    @staticmethod
+    def backward(ctx, dmsg):
+        q, k, v, compat, P = ctx.saved_tensors
+        dmsg = dmsg.contiguous()
+        B, N, Cc = q.shape
+        dev = q.device
+        dP = torch.empty((B * N, N), device=dev, dtype=torch.float32)
+        gemm(dmsg, v, tb=True, out=dP, m=N, n=N, k=Cc, lda=Cc, ldb=Cc, ldc=N, batch=B, sa=N * Cc, sb=N * Cc, sc=N * N)
+        dv = torch.empty_like(v)
+        gemm(P, dmsg, ta=True, out=dv, m=N, n=Cc, k=N, lda=N, ldb=Cc, ldc=Cc, batch=B, sa=N * N, sb=N * Cc, sc=N * Cc)
+        dS = softmax_rows_bwd(P, dP, ctx.scale, mul=compat.reshape(B * N, N))
+        dq = torch.empty_like(q)
+        gemm(dS, k, out=dq, m=N, n=Cc, k=N, lda=N, ldb=Cc, ldc=Cc, batch=B, sa=N * N, sb=N * Cc, sc=N * Cc)
+        dk = torch.empty_like(k)
+        gemm(dS, q, ta=True, out=dk, m=N, n=Cc, k=N, lda=N, ldb=Cc, ldc=Cc, batch=B, sa=N * N, sb=N * Cc, sc=N * Cc)
+        return dq, dk, dv, None
+
+
+def sc_attention(q, k, v, compat):
+    return _SCAttention.apply(q, k, v, compat)
+
+
+def nonlocal_block_train(block, feat, compat, image_feat, B, N):
+    """NonLocalBlock.forward (PointDSC.py:40-74) on token-major rows feat [B * N, C]; returns [B * N, C]."""
+    C = feat.shape[1]
+    q = linear(feat, block.projection_q.weight, block.projection_q.bias)
+    k = linear(feat, block.projection_k.weight, block.projection_k.bias)
+    v = linear(feat, block.projection_v.weight, block.projection_v.bias)
+    msg = sc_attention(q.reshape(B, N, C), k.reshape(B, N, C), v.reshape(B, N, C), compat).reshape(B * N, C)
+    fm = block.fc_message
+    m1 = batchnorm_train(linear(msg, fm[0].weight, fm[0].bias), fm[1], relu=True)
+    m2 = batchnorm_train(linear(m1, fm[3].weight, fm[3].bias), fm[4], relu=True)
+    fused = fusion_layer_train(block.fusion_layer_2, image_feat, feat.reshape(B, N, C)).reshape(B * N, C)
+    return linear(m2, fm[6].weight, fm[6].bias, residual=fused)           # message + image_feat (PointDSC.py:73)
+
+
+def encoder_train(net, corr_pos, compat, p_tokens, q_tokens):
+    """NonLocalNet.forward (PointDSC.py:114-143) from image TOKENS; returns corr_features [B, N, C] (= the reference's
+    encoder output permuted to token-major, PointDSC.py:223-228)."""
+    B, N, D = corr_pos.shape
+    image_feat = fusion_layer_train(net.fusion_layer_1, p_tokens, q_tokens)            # PointDSC.py:137
+    feat = linear(corr_pos.reshape(B * N, D).contiguous(), net.layer0.weight, net.layer0.bias)
+    for i in range(net.num_layers):
+        pc = net.blocks[f"PointCN_layer_{i}"]
+        feat = batchnorm_train(linear(feat, pc[0].weight, pc[0].bias), pc[1], relu=True)
+        feat = nonlocal_block_train(net.blocks[f"NonLocal_layer_{i}"], feat, compat, image_feat, B, N)
+    return feat.reshape(B, N, -1)
+
+
+def classifier_train(cls, feat):
+    """PointDSC.classification (PointDSC.py:175-181,241): [B, N, C] -> logits [B, N]."""
+    B, N, C = feat.shape
+    h1 = linear(feat.reshape(B * N, C), cls[0].weight, cls[0].bias, relu=True)
+    h2 = linear(h1, cls[2].weight, cls[2].bias, relu=True)
+    return linear(h2, cls[4].weight, cls[4].bias).reshape(B, N)
+
+
+class _Normalize(torch.autograd.Function):
+    """F.normalize(x, p=2, dim=-1) (PointDSC.py:229) on rows [rows, C]: LayerNorm-free row scaling, done with the primitives:
+    y = x / max(||x||, 1e-12); dx = (dy - y <dy, y>) / ||x||."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        nrm = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+        y = torch.empty_like(x)
+        h, st = handle_and_stream(x)
+        h.call("gmf_normalize_rows", 0, x.data_ptr(), None, nrm.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], st)
+        ctx.save_for_backward(y, nrm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, nrm = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        h, st = handle_and_stream(y)
+        h.call("gmf_normalize_rows", 1, y.data_ptr(), dy.data_ptr(), nrm.data_ptr(), dx.data_ptr(), y.shape[0], y.shape[1], st)
+        return dx
+
+
+def normalize_rows(x):
+    return _Normalize.apply(x)
+
+
+class _SimilarityMatrix(torch.autograd.Function):
+    """M = clamp(1 - (1 - Fn Fn^T) / sigma^2, 0, 1), zero diagonal (PointDSC.py:231-234), dense [B, N, N], differentiable with
+    respect to Fn and sigma for any upstream gradient (gmf_similarity_backward)."""
+
+    @staticmethod
+    def forward(ctx, feat_n, sigma):
+        f = feat_n.contiguous()
+        B, N, _ = f.shape
+        sig = float(sigma)
+        M = torch.empty((B, N, N), device=f.device, dtype=torch.float32)
+        h, st = handle_and_stream(f)
+        h.call("gmf_similarity_matrix", f.data_ptr(), B, N, sig, M.data_ptr(), N, st)
+        ctx.sig, ctx.sigma_is_tensor = sig, torch.is_tensor(sigma)
+        ctx.save_for_backward(f)
+        return M
+
+    @staticmethod
+    def backward(ctx, dM):
+        (f,) = ctx.saved_tensors
+        B, N, _ = f.shape
+        dM = dM.contiguous()
+        dF = torch.empty_like(f)
+        dsig = torch.empty(1, device=f.device, dtype=torch.float32)
+        h, st = handle_and_stream(f)
+        h.call("gmf_similarity_backward", f.data_ptr(), dM.data_ptr(), B, N, ctx.sig, dF.data_ptr(), dsig.data_ptr(), st)
+        return dF, dsig if ctx.sigma_is_tensor else None
+
+
+def similarity_matrix_train(feat_n, sigma):
+    return _SimilarityMatrix.apply(feat_n, sigma)
+
+
+class _ClassificationLossFn(torch.autograd.Function):
+    """The loss value of ClassificationLoss (libs/loss.py:67-93) with its gradient with respect to the logits."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, weight, balanced):
+        pred = pred.contiguous()
+        out = torch.empty(6, device=pred.device, dtype=torch.float32)
+        h, st = handle_and_stream(pred)
+        h.call("gmf_classification_loss", pred.data_ptr(), gt.data_ptr(), None if weight is None else weight.data_ptr(),
+               pred.shape[0], pred.shape[1], 1 if balanced else 0, out.data_ptr(), st)
+        ctx.balanced = balanced
+        ctx.save_for_backward(pred, gt, weight if weight is not None else pred.new_empty(0))
+        ctx.has_w = weight is not None
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, dloss, _dstats):
+        pred, gt, weight = ctx.saved_tensors
+        d = torch.empty_like(pred)
+        h, st = handle_and_stream(pred)
+        h.call("gmf_classification_backward", pred.data_ptr(), gt.data_ptr(), weight.data_ptr() if ctx.has_w else None,
+               pred.shape[0], pred.shape[1], 1 if ctx.balanced else 0, d.data_ptr(), st)
+        return dloss * d, None, None, None
+
+
+def classification_loss_train(pred, gt, weight, balanced):
+    return _ClassificationLossFn.apply(pred, gt, weight, balanced)
+
+
+class _SpectralMatchingDense(torch.autograd.Function):
+    """SpectralMatchingLoss(M, gt) (libs/loss.py:116-140) on a dense M with its gradient dL/dM."""
+
+    @staticmethod
+    def forward(ctx, M, gt, balanced):
+        N = M.shape[1]
+        if not (M.stride(2) == 1 and M.stride(1) >= N and M.stride(0) == N * M.stride(1)):
+            M = M.contiguous()
+        out = torch.empty(1, device=M.device, dtype=torch.float32)
+        h, st = handle_and_stream(M)
+        h.call("gmf_spectral_matching_loss", M.data_ptr(), M.stride(1), gt.data_ptr(), M.shape[0], N, 1 if balanced else 0,
+               out.data_ptr(), st)
+        ctx.balanced = balanced
+        ctx.save_for_backward(M, gt)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        M, gt = ctx.saved_tensors
+        B, N = M.shape[0], M.shape[1]
+        dM = torch.empty((B, N, N), device=M.device, dtype=torch.float32)
+        h, st = handle_and_stream(M)
+        h.call("gmf_spectral_matching_dense_backward", M.data_ptr(), M.stride(1), gt.data_ptr(), B, N, 1 if ctx.balanced else 0,
+               dM.data_ptr(), st)
+        return dloss * dM, None, None
+
+
+def spectral_matching_loss_train(M, gt, balanced):
+    return _SpectralMatchingDense.apply(M, gt, balanced)

@@ -288,18 +288,20 @@ int gmf_transformation_loss(gmf_handle* h, const float* trans, const float* gt_t
                             const float* tgt_keypts, const float* probs, int B, int N, float re_thre, float te_thre,
                             float* out5, gmf_stream_t stream);
 
-/* ---- training primitives (row f-4, second backward slice) -----------------------------------------------------------
- * What forward + backward of one FusionLayer / PerceiverIO (fusion_layer.py:32-128,172-201) are made of, on plain row-major
- * fp32 tensors; gmf_amd/train.py composes them into a torch.autograd.Function.  Contractions run on the fp32 MFMA (exact
+/* ---- training primitives (row f-4) -----------------------------------------------------------------------------------
+ * What the training forward + backward of the encoder are made of (FusionLayer / PerceiverIO fusion_layer.py:32-128,172-201;
+ * PointCN, NonLocalBlock and classifier PointDSC.py:10-74,104-109,175-181 with TRAIN-mode BatchNorm; the two losses the
+ * reference trains with by default, libs/loss.py:67-140, config_3DMatch.py:50-52), on plain row-major fp32 tensors;
+ * gmf_amd/train.py composes them into torch.autograd.Functions.  Contractions run on the fp32 MFMA (exact
  * fp32 products; gradients of magnitude 1e-8 need no operand scaling), every cross-row sum is taken in a fixed order. */
 
-/* C[b] = alpha * op(A[b]) op(B[b]) (+ bias[col]) (+ residual[b]) for b < batch; op(X) = X^T when trans_x != 0.  op(A) is
+/* C[b] = alpha * op(A[b]) op(B[b]) (+ bias[col]) (+ residual[b]) (-> ReLU if relu != 0) for b < batch; op(X) = X^T when trans_x != 0.  op(A) is
  * M x K, op(B) is K x N; lda / ldb / ldc are row strides and stride_* batch strides, in floats (residual shares C's layout).
  * Few output tiles with a long contraction (weight gradients: K = every row of the batch) are split over K into partials
  * that are added in index order. */
 int gmf_gemm_f32(gmf_handle* h, int trans_a, int trans_b, const float* A, const float* B, float* C, const float* bias,
                  const float* residual, int M, int N, int K, long long lda, long long ldb, long long ldc, long long stride_a,
-                 long long stride_b, long long stride_c, int batch, float alpha, gmf_stream_t stream);
+                 long long stride_b, long long stride_c, int batch, float alpha, int relu, gmf_stream_t stream);
 /* LCPE (fusion_layer.py:118-128) on x [rows, C] = sequences of L rows: forward y = x + bias + depthwise conv3(x) with taps
  * w [C,1,3]; backward (x := dy, y := dx, bias unused) the transposed taps: dx[l] = dy[l] (1 + w1) + w0 dy[l+1] + w2 dy[l-1]. */
 int gmf_lcpe(gmf_handle* h, int backward, const float* x, const float* w, const float* bias, float* y, int rows, int L, int C,
@@ -310,16 +312,46 @@ int gmf_layernorm_forward(gmf_handle* h, const float* x, const float* gamma, con
                           long long rows, int C, gmf_stream_t stream);
 int gmf_layernorm_backward(gmf_handle* h, const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                            const float* dx_add, float* dx, long long rows, int C, gmf_stream_t stream);
-/* forward: out = softmax(scale * a) per row of length T; backward: a = P, b = dP -> out = dS = scale * P * (dP - <dP, P>). */
-int gmf_softmax_rows(gmf_handle* h, int backward, const float* a, const float* b, float* out, long long rows, int T, float scale,
-                     gmf_stream_t stream);
+/* forward: out = softmax(mul * scale * a) per row of length T (mul: optional element-wise multiplier of the logits, the
+ * compat matrix of the spatial-consistency attention, PointDSC.py:60-62); backward: a = P, b = dP -> out = dS =
+ * scale * mul * P * (dP - <dP, P>). */
+int gmf_softmax_rows(gmf_handle* h, int backward, const float* a, const float* b, const float* mul, float* out, long long rows, int T,
+                     float scale, gmf_stream_t stream);
 /* GEGLU (fusion_layer.py:54-57): hdn [rows, 2H] -> out [rows, H] = x * gelu_erf(gates); backward: dg [rows, H] -> out = dhdn [rows, 2H]. */
 int gmf_geglu(gmf_handle* h, int backward, const float* hdn, const float* dg, float* out, long long rows, int H,
               gmf_stream_t stream);
-/* out[c] = sum over rows r of x[r][c] * y'[r + shift][c] with y' = 1 (y NULL), y, or (y - mean) * rstd (LayerNorm's xhat);
- * rows r + shift outside r's sequence of L rows contribute 0.  Bias, LayerNorm-parameter and LCPE-tap gradients. */
-int gmf_colsum(gmf_handle* h, const float* x, const float* y, const float* mean, const float* rstd, int shift, int L, long long rows,
-               int C, float* out, gmf_stream_t stream);
+/* out[c] = sum over rows r of x'[r][c] * y'[r + shift][c] with y' = 1 (y NULL), y, (y - mean[r]) * rstd[r] (LayerNorm's xhat)
+ * or (y - cmean[c]) * crstd[c] (BatchNorm's; crstd NULL = 1), x' = x or x - cmean[c] (center_x); rows r + shift outside r's
+ * sequence of L rows contribute 0.  Bias, LayerNorm / BatchNorm parameter and LCPE-tap gradients, BatchNorm statistics. */
+int gmf_colsum(gmf_handle* h, const float* x, const float* y, const float* mean, const float* rstd, const float* cmean,
+               const float* crstd, int center_x, int shift, int L, long long rows, int C, float* out, gmf_stream_t stream);
+/* nn.BatchNorm1d in TRAINING mode over the rows of x [rows, C] (= BatchNorm1d on [B, C, N]): batch statistics (mean / rstd [C]
+ * returned for the backward), running statistics updated as torch does (momentum, unbiased variance; may be NULL), optional
+ * fused ReLU.  Backward: dx, dgamma, dbeta; y_relu (the saved output) masks dy when the forward applied the ReLU, else NULL. */
+int gmf_batchnorm_train_forward(gmf_handle* h, const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                float* rstd, float* running_mean, float* running_var, long long rows, int C, float eps,
+                                float momentum, int relu, gmf_stream_t stream);
+int gmf_batchnorm_train_backward(gmf_handle* h, const float* dy, const float* x, const float* y_relu, const float* mean,
+                                 const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta, long long rows, int C,
+                                 gmf_stream_t stream);
+/* F.normalize(x, p=2, dim=-1) (PointDSC.py:229) on rows [rows, C]: forward a = x -> out = y, nrm [rows] = max(||x||, 1e-12);
+ * backward a = y (the saved output), dy, nrm -> out = dx = (dy - y <dy, y>) / nrm. */
+int gmf_normalize_rows(gmf_handle* h, int backward, const float* a, const float* dy, float* nrm, float* out, long long rows, int C,
+                       gmf_stream_t stream);
+/* out = y > 0 ? dy : 0 (ReLU backward from the saved output). */
+int gmf_relu_backward(gmf_handle* h, const float* dy, const float* y, float* out, long long total, gmf_stream_t stream);
+/* d loss / d pred of ClassificationLoss (libs/loss.py:67-93) for an upstream gradient of 1: mean BCE-with-logits, balanced
+ * (pos_weight = num_neg / num_pos over the batch) or not, or weighted per element (weight non-NULL). */
+int gmf_classification_backward(gmf_handle* h, const float* pred, const float* gt, const float* weight, int B, int N, int balanced,
+                                float* d_pred, gmf_stream_t stream);
+/* dL/dM [B,N,N] (dense) of SpectralMatchingLoss(M, gt_labels) (libs/loss.py:116-140), M with row stride ldm. */
+int gmf_spectral_matching_dense_backward(gmf_handle* h, const float* M, int ldm, const float* gt_labels, int B, int N, int balanced,
+                                         float* dM, gmf_stream_t stream);
+/* Backward of gmf_similarity_matrix for an arbitrary upstream dM [B,N,N] (dense): d_feat_n [B,N,128] and d_sigma [1]
+ * (PointDSC.py:231-234: matmul, clamp with its gradient mask, zero diagonal).  S and G are materialised in the workspace
+ * (training sizes: N ~ 1000); the loss-specific fused form without them is gmf_spectral_matching_backward. */
+int gmf_similarity_backward(gmf_handle* h, const float* feat_n, const float* dM, int B, int N, float sigma, float* d_feat_n,
+                            float* d_sigma, gmf_stream_t stream);
 
 /* ---- image encoder epilogue (ResNet BasicBlock, GMF_PointDSC/models/resnet.py:59-75) ------------------------------- */
 

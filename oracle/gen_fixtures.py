@@ -311,7 +311,65 @@ def gen_f18(fl, pio):
     np.savez_compressed(os.path.join(GOLD, "f18_fusion_layer_backward.npz"), seed=118, **out)
 
 
+def gen_f19(pdsc):
+    """F19: one training step of the reference in its DEFAULT configuration (libs/trainer.py:121-166; config_3DMatch.py:49-52:
+    balanced = False, weights 1 / 1 / 0): the model in train() mode (BatchNorm batch statistics), the non-test forward, loss =
+    ClassificationLoss + SpectralMatchingLoss, loss.backward().  Stored: logits, loss values, checksums + samples of M, the
+    BatchNorm running statistics after the forward, and for EVERY parameter the gradient's fp64 sum, L2 norm, max and first 16
+    entries; a second case uses the balanced losses.  Inputs and weights are regenerated from the seeds.
+
+    The model has THREE layers (the class takes num_layers; GMF configures 12): with train-mode BatchNorm (division by the batch
+    standard deviation of every channel) and the seeded weights, the 12-layer reference is chaotic - its own fp32 and fp64
+    evaluations differ by 0.31 on the logits, the feature error growing 1.6-10x per layer - so its gradients pin nothing.  At
+    three layers the fp32 noise on the logits is 8e-5 and every kind of module and gradient is still exercised."""
+    import libs.loss as L
+    out = {}
+    for tag, balanced, N, seeds in (("def", False, 200, [121, 122]), ("bal", True, 150, [123, 124, 125])):
+        torch.manual_seed(0)
+        sd = O.seeded_state_dict(O.pointdsc_shapes(6, 3, 128), seed=7)
+        model = build_ref_pointdsc(pdsc, sd, num_layers=3).train()
+        b = O.synthetic_batch(seeds, N=N, T=40)
+        data = {"corr_pos": b["corr_pos"], "src_keypts": b["src_keypts"], "tgt_keypts": b["tgt_keypts"],
+                "p_image": _tok_to_image(b["p_tokens"]), "q_image": _tok_to_image(b["q_tokens"])}
+        with torch.enable_grad():
+            res = model(data)
+            cl = L.ClassificationLoss(balanced=balanced)(res["final_labels"], b["gt_labels"])
+            sm = L.SpectralMatchingLoss(balanced=balanced)(res["M"], b["gt_labels"])
+            loss = 1.0 * cl["loss"] + 1.0 * sm
+            loss.backward()
+        M = res["M"].detach()
+        out[f"{tag}_cfg"] = np.array([int(balanced), N] + seeds)
+        out[f"{tag}_logits"] = _np(res["final_labels"])
+        out[f"{tag}_losses"] = np.array([float(cl["loss"]), float(sm)])
+        out[f"{tag}_M_sum"] = _np(M.double().sum((1, 2)))
+        out[f"{tag}_M_sumsq"] = _np((M.double() ** 2).sum((1, 2)))
+        out[f"{tag}_M_rows"] = _np(M[:, ::25])
+        names, stats, heads = [], [], []
+        for name, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad.double().reshape(-1)
+            names.append(name)
+            stats.append([float(g.sum()), float(g.norm()), float(g.abs().max())])
+            hd = np.zeros(16)
+            hd[:min(16, g.numel())] = g[:16].numpy()
+            heads.append(hd)
+        out[f"{tag}_grad_names"] = np.array(names)
+        out[f"{tag}_grad_stats"] = np.array(stats)
+        out[f"{tag}_grad_heads"] = np.array(heads, dtype=np.float32)
+        bn = model.encoder.blocks["NonLocal_layer_2"].fc_message[1]
+        out[f"{tag}_bn_running"] = np.stack([_np(bn.running_mean), _np(bn.running_var)])
+        pc = model.encoder.blocks["PointCN_layer_0"][1]
+        out[f"{tag}_pcn_running"] = np.stack([_np(pc.running_mean), _np(pc.running_var)])
+        print("F19", tag, "losses", out[f"{tag}_losses"], "params with grad", len(names),
+              "max |grad|", float(np.array(stats)[:, 2].max()))
+    np.savez_compressed(os.path.join(GOLD, "f19_training_step.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f19":
+        gen_f19(_import_reference()[0])
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f18":
         r_ = _import_reference()
         gen_f18(r_[1], r_[3])

@@ -112,7 +112,14 @@ def _lin(x, w, b):  # conv1x1 on token-major rows: x [B,N,Cin], w [Cout,Cin,1]
     return x @ w[:, :, 0].t() + b
 
 
+_BN_TRAIN = [False]      # True inside training_losses(): BatchNorm1d in train() mode = statistics of the batch (all rows), biased variance
+
+
 def _bn_eval(x, sd, p, eps: float = 1e-5):
+    if _BN_TRAIN[0]:
+        xf = x.reshape(-1, x.shape[-1])
+        mu, var = xf.mean(0), xf.var(0, unbiased=False)
+        return (x - mu) * torch.rsqrt(var + eps) * sd[p + "weight"] + sd[p + "bias"]
     return (x - sd[p + "running_mean"]) * torch.rsqrt(sd[p + "running_var"] + eps) * sd[p + "weight"] + sd[p + "bias"]
 
 
@@ -511,6 +518,43 @@ def sm_loss_from_features(corr_features, sigma, gt_labels, balanced: bool = True
         ln = (M ** 2 * (1 - gt_M)).sum((-1, -2)) / (torch.relu((1 - gt_M).sum((-1, -2)) - 1.0) + 1.0)
         return torch.mean(lp * 0.5 + ln * 0.5)
     return ((M - gt_M) ** 2).mean()
+
+
+def training_losses(sd: SD, data: dict, num_layers: int, balanced: bool):
+    """Differentiable restatement of the reference's default training objective (libs/trainer.py:131-141 with
+    config_3DMatch.py:49-52): the model in train() mode (BatchNorm batch statistics) and its non-test forward
+    (PointDSC.py:216-241), ClassificationLoss (loss.py:85-93) + SpectralMatchingLoss (loss.py:116-140).  Tensors in `sd` may
+    require grad; returns (logits, M, class_loss, sm_loss) as tensors.  Golden F19 pins it to the reference's gradients."""
+    src, tgt = data["src_keypts"], data["tgt_keypts"]
+    with torch.no_grad():
+        compat, _ = compat_matrix(src, tgt, float(sd["sigma_spat"]))
+    _BN_TRAIN[0] = True
+    try:
+        feat = encoder(sd, data["corr_pos"], compat, data["p_tokens"], data["q_tokens"], num_layers)
+        logits = classifier(sd, feat)
+    finally:
+        _BN_TRAIN[0] = False
+    fn = F.normalize(feat, p=2, dim=-1)
+    M = torch.matmul(fn, fn.permute(0, 2, 1))
+    M = torch.clamp(1 - (1 - M) / sd["sigma"] ** 2, min=0, max=1)
+    idx = torch.arange(M.shape[1])
+    M[:, idx, idx] = 0
+    gt = data["gt_labels"].float()
+    num_pos = torch.relu(gt.sum() - 1) + 1
+    num_neg = torch.relu((1 - gt).sum() - 1) + 1
+    if balanced:
+        cl = F.binary_cross_entropy_with_logits(logits, gt, pos_weight=num_neg / num_pos)
+    else:
+        cl = F.binary_cross_entropy_with_logits(logits, gt)
+    gt_M = ((gt[:, None, :] + gt[:, :, None]) == 2).float()
+    gt_M[:, idx, idx] = 0
+    if balanced:
+        lp = ((M - 1) ** 2 * gt_M).sum((-1, -2)) / (torch.relu(gt_M.sum((-1, -2)) - 1.0) + 1.0)
+        ln = (M ** 2 * (1 - gt_M)).sum((-1, -2)) / (torch.relu((1 - gt_M).sum((-1, -2)) - 1.0) + 1.0)
+        sm = torch.mean(lp * 0.5 + ln * 0.5)
+    else:
+        sm = ((M - gt_M) ** 2).mean()
+    return logits, M, cl, sm
 
 
 def transformation_loss(trans, gt_trans, src_keypts, tgt_keypts, probs, re_thre: float = 15.0, te_thre: float = 30.0):

@@ -1045,6 +1045,63 @@ def test_f18_fusion_layer_backward(golden_dir, tag):
     assert _maxerr(ye.cpu(), y.detach().cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("tag", ["def", "bal"])
+def test_f19_training_step(golden_dir, tag):
+    """Golden F19: one training step of the reference in its default configuration (libs/trainer.py:121-166: train() mode with
+    BatchNorm batch statistics, non-test forward, ClassificationLoss + SpectralMatchingLoss, loss.backward(); the MSE / plain-BCE
+    forms of config_3DMatch.py:49 and the balanced ones) on a 3-layer model (the 12-layer reference is chaotic in train mode
+    with seeded weights - see gen_f19).  gmf_amd's PointDSC in train() mode runs HIP training primitives behind
+    torch.autograd.Functions: logits within 3e-4 (fp32 noise of the reference itself: 8e-5), both losses to 1e-5 relative, M
+    checksums, the BatchNorm running statistics, and the gradient of EVERY parameter (137 tensors): each within
+    2e-4 of its own largest entry + 3e-6 of the largest gradient in the model (the biases in front of a BatchNorm have
+    mathematically zero gradients: the reference's and ours are both rounding noise there)."""
+    g = _load(golden_dir, "f19_training_step.npz")
+    cfg = g[f"{tag}_cfg"]
+    balanced, N, seeds = bool(cfg[0]), int(cfg[1]), [int(v) for v in cfg[2:]]
+    sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 3, 128), seed=7)
+    m = gmf_amd.PointDSC(in_dim=6, num_layers=3, num_channels=128, num_iterations=10, ratio=0.1, inlier_threshold=0.10,
+                         sigma_d=0.10, k=40, nms_radius=0.10)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(DEV).train()
+    b = synthetic.synthetic_batch(seeds, N=N, T=40)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    gt = _gpu(b["gt_labels"])
+    res = m(data)
+    cl = gmf_amd.ClassificationLoss(balanced=balanced)(res["final_labels"], gt)
+    sm = gmf_amd.SpectralMatchingLoss(balanced=balanced)(res["M"], gt)
+    loss = 1.0 * cl["loss"] + 1.0 * sm
+    loss.backward()
+    assert _maxerr(res["final_labels"].detach().cpu(), g[f"{tag}_logits"]) < 3e-4
+    ref_losses = g[f"{tag}_losses"]
+    assert abs(float(cl["loss"].detach()) - ref_losses[0]) < 1e-5 * ref_losses[0]
+    assert abs(float(sm.detach()) - ref_losses[1]) < 1e-5 * ref_losses[1]
+    M = res["M"].detach()
+    assert np.abs(M.double().sum((1, 2)).cpu().numpy() / g[f"{tag}_M_sum"] - 1).max() < 1e-5
+    assert _maxerr(M[:, ::25].cpu(), g[f"{tag}_M_rows"]) < 1e-4
+    assert res["final_trans"].shape == (len(seeds), 4, 4) and not res["final_trans"].requires_grad
+    bn = m.encoder.blocks["NonLocal_layer_2"].fc_message[1]
+    assert _maxerr(torch.stack([bn.running_mean, bn.running_var]).cpu(), g[f"{tag}_bn_running"]) < 1e-5
+    pc = m.encoder.blocks["PointCN_layer_0"][1]
+    assert _maxerr(torch.stack([pc.running_mean, pc.running_var]).cpu(), g[f"{tag}_pcn_running"]) < 1e-5
+    names, stats, heads = list(g[f"{tag}_grad_names"]), g[f"{tag}_grad_stats"], g[f"{tag}_grad_heads"]
+    params = dict(m.named_parameters())
+    gmax = float(stats[:, 2].max())
+    assert len(names) == 137
+    for i, n in enumerate(names):
+        gr = params[n].grad
+        assert gr is not None, n
+        gr = gr.double().reshape(-1).cpu()
+        k = min(16, gr.numel())
+        tol = 2e-4 * stats[i, 2] + 3e-6 * gmax
+        assert np.abs(gr[:k].numpy() - heads[i, :k]).max() < tol, (n, stats[i])
+        assert abs(float(gr.norm()) - stats[i, 1]) < 2e-4 * stats[i, 1] + 3e-6 * gmax * np.sqrt(gr.numel()), (n, stats[i])
+    # an optimiser step on the module's own parameters works as with the reference (torch.optim over nn.Parameters)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-6)
+    before = m.classification[0].weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, m.classification[0].weight.detach())
+
+
 def test_training_primitives_against_torch():
     """Each HIP training primitive on odd sizes against torch on the device: gmf_gemm_f32 in its four transpose forms, as a
     batched sub-matrix product and with a long contraction (split-K path), LCPE, LayerNorm, softmax, GEGLU, column sums."""
@@ -1108,10 +1165,51 @@ def test_sm_loss_backward_full_size():
     assert abs(float(sigma.grad) - float(sr.grad)) < 1e-4 * abs(float(sr.grad))
 
 
-def test_validation_modules_are_forward_only():
-    x = torch.zeros(1, 8, device=DEV, requires_grad=True)
+def test_loss_modules_gradients_and_forward_only_rest():
+    """ClassificationLoss and SpectralMatchingLoss(M, gt) carry their gradients (checked against torch autograd over the same
+    formulas, balanced and not, with a per-element weight); TransformationLoss is forward only and says so; inputs on the CPU
+    are refused."""
+    gen = torch.Generator().manual_seed(5)
+    pred = _gpu(torch.randn(3, 50, generator=gen)).requires_grad_(True)
+    gt = _gpu((torch.rand(3, 50, generator=gen) < 0.3).float())
+    w = _gpu(torch.rand(3, 50, generator=gen))
+    for balanced, weight in ((True, None), (False, None), (True, w)):
+        pred.grad = None
+        out = gmf_amd.ClassificationLoss(balanced=balanced)(pred, gt, weight)
+        out["loss"].backward()
+        pr = pred.detach().clone().requires_grad_(True)
+        num_pos, num_neg = torch.relu(gt.sum() - 1) + 1, torch.relu((1 - gt).sum() - 1) + 1
+        if weight is not None:
+            ref = (torch.nn.functional.binary_cross_entropy_with_logits(pr, gt, reduction="none") * weight).mean()
+        elif balanced:
+            ref = torch.nn.functional.binary_cross_entropy_with_logits(pr, gt, pos_weight=num_neg / num_pos)
+        else:
+            ref = torch.nn.functional.binary_cross_entropy_with_logits(pr, gt)
+        ref.backward()
+        assert abs(float(out["loss"].detach()) - float(ref.detach())) < 1e-5
+        assert _maxerr(pred.grad.cpu(), pr.grad.cpu()) < 1e-6
+    f = torch.nn.functional.normalize(_gpu(torch.randn(2, 70, 128, generator=gen)), dim=-1)
+    for balanced in (True, False):
+        M = gmf_amd.similarity_matrix(f, 0.9, contiguous=True).requires_grad_(True)
+        gt2 = _gpu((torch.rand(2, 70, generator=gen) < 0.4).float())
+        loss = gmf_amd.SpectralMatchingLoss(balanced=balanced)(M, gt2)
+        loss.backward()
+        Mr = M.detach().clone().requires_grad_(True)
+        gtM = ((gt2[:, None, :] + gt2[:, :, None]) == 2).float()
+        idx = torch.arange(70, device=DEV)
+        gtM[:, idx, idx] = 0
+        if balanced:
+            lp = ((Mr - 1) ** 2 * gtM).sum((-1, -2)) / (torch.relu(gtM.sum((-1, -2)) - 1.0) + 1.0)
+            ln = (Mr ** 2 * (1 - gtM)).sum((-1, -2)) / (torch.relu((1 - gtM).sum((-1, -2)) - 1.0) + 1.0)
+            ref = torch.mean(lp * 0.5 + ln * 0.5)
+        else:
+            ref = ((Mr - gtM) ** 2).mean()
+        ref.backward()
+        assert abs(float(loss.detach()) - float(ref.detach())) < 1e-6
+        assert _maxerr(M.grad.cpu(), Mr.grad.cpu()) < 1e-5 * float(Mr.grad.abs().max())
+    T = torch.eye(4, device=DEV).repeat(1, 1, 1).requires_grad_(True)
     with pytest.raises(RuntimeError, match="forward-only"):
-        gmf_amd.ClassificationLoss()(x, torch.zeros(1, 8, device=DEV))
+        gmf_amd.TransformationLoss()(T, T.detach(), _gpu(torch.rand(1, 8, 3)), _gpu(torch.rand(1, 8, 3)), _gpu(torch.rand(1, 8)))
     with pytest.raises(RuntimeError, match="HIP device"):
         gmf_amd.ClassificationLoss()(torch.zeros(1, 8), torch.zeros(1, 8))
 

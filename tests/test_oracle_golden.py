@@ -302,3 +302,26 @@ def test_f18_oracle_fusion_layer_backward(golden_dir, tag):
             assert abs(float(v.grad.double().sum()) - g[f"{tag}_gradsum::{k}"][0]) < 1e-4 * np.sqrt(g[f"{tag}_gradsum::{k}"][1]), k
         checked += 1
     assert checked == 18
+
+
+@pytest.mark.parametrize("tag", ["def", "bal"])
+def test_f19_oracle_training_step(golden_dir, tag):
+    """Golden F19 (one default training step of the reference, 3-layer model, train-mode BatchNorm): torch autograd over the
+    oracle's restatement `training_losses` reproduces the reference's logits (3e-4; its own fp32 noise is 8e-5), losses and the
+    gradient of every parameter (2e-4 of each tensor's largest entry + 3e-6 of the model's largest gradient)."""
+    g = np.load(os.path.join(golden_dir, "f19_training_step.npz"))
+    cfg = g[f"{tag}_cfg"]
+    balanced, N, seeds = bool(cfg[0]), int(cfg[1]), [int(v) for v in cfg[2:]]
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and k != "sigma_spat" and "running" not in k else v)
+          for k, v in O.seeded_state_dict(O.pointdsc_shapes(6, 3, 128), seed=7).items()}
+    b = O.synthetic_batch(seeds, N=N, T=40)
+    logits, M, cl, sm = O.training_losses(sd, b, 3, balanced)
+    (cl + sm).backward()
+    assert np.abs(logits.detach().numpy() - g[f"{tag}_logits"]).max() < 3e-4
+    assert abs(float(cl.detach()) - g[f"{tag}_losses"][0]) < 1e-5 and abs(float(sm.detach()) - g[f"{tag}_losses"][1]) < 1e-5
+    names, stats, heads = list(g[f"{tag}_grad_names"]), g[f"{tag}_grad_stats"], g[f"{tag}_grad_heads"]
+    gmax = float(stats[:, 2].max())
+    for i, n in enumerate(names):
+        gr = sd[n].grad.double().reshape(-1)
+        k = min(16, gr.numel())
+        assert np.abs(gr[:k].numpy() - heads[i, :k]).max() < 2e-4 * stats[i, 2] + 3e-6 * gmax, n

@@ -47,27 +47,48 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = zero16();
+  // 16-byte loads for the operand whose contraction index is contiguous in memory (A when !TA, B when TB), when every
+  // address is aligned; full k-steps take them, the ragged last one falls back to the masked scalar form
+  const bool vecA = !TA && (lda % 4 == 0) && (sA % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool vecB = TB && (ldb % 4 == 0) && (sB % 4 == 0) && ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
   for (int k0 = kbeg; k0 < kend; k0 += 16) {
     const int kk = k0 + 8 * h;
+    const bool fullk = (k0 + 16 <= kend);
     float a[2][8], bf[2][8];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
       const int r = m0 + 32 * rb + i;
+      if (vecA && fullk) {
+        const float4* p = reinterpret_cast<const float4*>(A + (size_t)min(r, M - 1) * lda + kk);
+        const float4 u = p[0], w = p[1];
+        const float z = (r < M) ? 1.f : 0.f;
+        a[rb][0] = u.x * z; a[rb][1] = u.y * z; a[rb][2] = u.z * z; a[rb][3] = u.w * z;
+        a[rb][4] = w.x * z; a[rb][5] = w.y * z; a[rb][6] = w.z * z; a[rb][7] = w.w * z;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = kk + e;
-        const bool ok = (r < M) && (k < kend);
-        a[rb][e] = ok ? (TA ? A[(size_t)k * lda + r] : A[(size_t)r * lda + k]) : 0.f;
+        for (int e = 0; e < 8; ++e) {
+          const int k = kk + e;
+          const bool ok = (r < M) && (k < kend);
+          a[rb][e] = ok ? (TA ? A[(size_t)k * lda + r] : A[(size_t)r * lda + k]) : 0.f;
+        }
       }
     }
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       const int c = n0 + 32 * cb + i;
+      if (vecB && fullk) {
+        const float4* p = reinterpret_cast<const float4*>(Bm + (size_t)min(c, N - 1) * ldb + kk);
+        const float4 u = p[0], w = p[1];
+        const float z = (c < N) ? 1.f : 0.f;
+        bf[cb][0] = u.x * z; bf[cb][1] = u.y * z; bf[cb][2] = u.z * z; bf[cb][3] = u.w * z;
+        bf[cb][4] = w.x * z; bf[cb][5] = w.y * z; bf[cb][6] = w.z * z; bf[cb][7] = w.w * z;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = kk + e;
-        const bool ok = (c < N) && (k < kend);
-        bf[cb][e] = ok ? (TB ? Bm[(size_t)c * ldb + k] : Bm[(size_t)k * ldb + c]) : 0.f;
+        for (int e = 0; e < 8; ++e) {
+          const int k = kk + e;
+          const bool ok = (c < N) && (k < kend);
+          bf[cb][e] = ok ? (TB ? Bm[(size_t)c * ldb + k] : Bm[(size_t)k * ldb + c]) : 0.f;
+        }
       }
     }
 #pragma unroll
@@ -270,11 +291,16 @@ k_colsum_partial(const float* __restrict__ x, const float* __restrict__ y, const
                  const float* __restrict__ rstd, const float* __restrict__ cmean, const float* __restrict__ crstd, int center_x,
                  int shift, int L, long rows, int C, int rows_per_chunk, float* __restrict__ part) {
   // cmean / crstd (per COLUMN: BatchNorm's statistics): y' = (y - cmean[c]) * crstd[c]; center_x: x' = x - cmean[c]
+  // block: 4 waves; lane = column within the 64-column block blockIdx.y, wave w takes rows r0 + w, r0 + w + 4, ...;
+  // the four wave sums are added in wave order through LDS
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lane;
   const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + (long)rows_per_chunk);
-  for (int c = threadIdx.x; c < C; c += 256) {
+  float s = 0.f;
+  if (c < C) {
     const float cm = cmean ? cmean[c] : 0.f, cr = crstd ? crstd[c] : 1.f;
-    float s = 0.f;
-    for (long r = r0; r < r1; ++r) {
+    for (long r = r0 + wave; r < r1; r += 4) {
       float v = x[r * C + c];
       if (center_x) v -= cm;
       if (y) {
@@ -288,17 +314,21 @@ k_colsum_partial(const float* __restrict__ x, const float* __restrict__ y, const
       }
       s += v;
     }
-    part[(size_t)blockIdx.x * C + c] = s;
   }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < C) part[(size_t)blockIdx.x * C + c] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
+// one wave per column: lane l adds chunks l, l + 64, ... in order, then a fixed butterfly over the lanes (deterministic)
 __global__ void __launch_bounds__(256)
 k_colsum_final(const float* __restrict__ part, int chunks, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   float s = 0.f;
-  for (int k = 0; k < chunks; ++k) s += part[(size_t)k * C + c];
-  out[c] = s;
+  for (int k = lane; k < chunks; k += 64) s += part[(size_t)k * C + c];
+  s = wave_sum_f(s);
+  if (lane == 0) out[c] = s;
 }
 
 // =========================================================================================
@@ -545,8 +575,9 @@ hipError_t launch_colsum(const float* x, const float* y, const float* mean, cons
   const int chunks = colsum_chunks(rows);
   const int rpc = (int)((rows + chunks - 1) / chunks);
   const int used = (int)((rows + rpc - 1) / rpc);
-  hipLaunchKernelGGL(k_colsum_partial, dim3(used), dim3(256), 0, s, x, y, mean, rstd, cmean, crstd, center_x, shift, L, rows, C, rpc, part);
-  hipLaunchKernelGGL(k_colsum_final, dim3((C + 255) / 256), dim3(256), 0, s, part, used, C, out);
+  hipLaunchKernelGGL(k_colsum_partial, dim3(used, (C + 63) / 64), dim3(256), 0, s, x, y, mean, rstd, cmean, crstd, center_x, shift, L,
+                     rows, C, rpc, part);
+  hipLaunchKernelGGL(k_colsum_final, dim3((C + 3) / 4), dim3(256), 0, s, part, used, C, out);
   return hipGetLastError();
 }
 

@@ -418,10 +418,10 @@ class _SimilarityMatrix(torch.autograd.Function):
     respect to Fn and sigma for any upstream gradient (gmf_similarity_backward)."""
 
     @staticmethod
-    def forward(ctx, feat_n, sigma):
+    def forward(ctx, feat_n, sigma, sigma_value):
         f = feat_n.contiguous()
         B, N, _ = f.shape
-        sig = float(sigma)
+        sig = float(sigma) if sigma_value is None else float(sigma_value)     # (a caller that already read the scalar passes it)
         M = torch.empty((B, N, N), device=f.device, dtype=torch.float32)
         h, st = handle_and_stream(f)
         h.call("gmf_similarity_matrix", f.data_ptr(), B, N, sig, M.data_ptr(), N, st)
@@ -438,11 +438,11 @@ class _SimilarityMatrix(torch.autograd.Function):
         dsig = torch.empty(1, device=f.device, dtype=torch.float32)
         h, st = handle_and_stream(f)
         h.call("gmf_similarity_backward", f.data_ptr(), dM.data_ptr(), B, N, ctx.sig, dF.data_ptr(), dsig.data_ptr(), st)
-        return dF, dsig if ctx.sigma_is_tensor else None
+        return dF, dsig if ctx.sigma_is_tensor else None, None
 
 
-def similarity_matrix_train(feat_n, sigma):
-    return _SimilarityMatrix.apply(feat_n, sigma)
+def similarity_matrix_train(feat_n, sigma, sigma_value=None):
+    return _SimilarityMatrix.apply(feat_n, sigma, sigma_value)
 
 
 class _ClassificationLossFn(torch.autograd.Function):

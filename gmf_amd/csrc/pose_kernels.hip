@@ -21,96 +21,11 @@
 
 #include "launchers_pose.hpp"
 #include "mfma_core.hpp"
+#include "kabsch.hpp"
 
 namespace gmf {
 
 #define GMF_DEVINL __device__ __forceinline__
-
-// ---------------------------------------------------------------------------------------
-// 3x3 SVD -> rotation.  H = U S V^T.  Returns  R = V diag(1,1,det(V U^T)) U^T  (Kabsch, common.py:43-45)
-// in the determinant-free form  R = v1 u1^T + v2 u2^T + (v1 x v2)(u1 x u2)^T  over the two dominant
-// singular pairs, which equals the reference's formula for any sign convention of the SVD and stays
-// well defined when the smallest singular value is 0 (planar neighbourhoods).
-// ---------------------------------------------------------------------------------------
-GMF_DEVINL void cross3(const double* a, const double* b, double* c) {
-  c[0] = a[1] * b[2] - a[2] * b[1];
-  c[1] = a[2] * b[0] - a[0] * b[2];
-  c[2] = a[0] * b[1] - a[1] * b[0];
-}
-
-GMF_DEVINL void any_perp(const double* a, double* p) {
-  // unit vector perpendicular to unit a
-  double ax = fabs(a[0]), ay = fabs(a[1]), az = fabs(a[2]);
-  double e[3] = {0, 0, 0};
-  if (ax <= ay && ax <= az) e[0] = 1; else if (ay <= az) e[1] = 1; else e[2] = 1;
-  cross3(a, e, p);
-  const double n = rsqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
-  p[0] *= n; p[1] *= n; p[2] *= n;
-}
-
-// A: row-major 3x3 H.  R (row-major) = V D U^T.
-GMF_DEVINL void kabsch_rotation_from_H(const double* Hin, double* R) {
-  double A[3][3], V[3][3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { A[r][c] = Hin[3 * r + c]; V[r][c] = (r == c) ? 1.0 : 0.0; }
-  for (int sweep = 0; sweep < 30; ++sweep) {
-    double off = 0.0;
-#pragma unroll
-    for (int pq = 0; pq < 3; ++pq) {
-      const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
-      double al = 0, be = 0, ga = 0;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) { al += A[r][p] * A[r][p]; be += A[r][q] * A[r][q]; ga += A[r][p] * A[r][q]; }
-      const double lim = 1e-15 * sqrt(al * be);
-      if (fabs(ga) > lim && ga != 0.0) {
-        off = fmax(off, fabs(ga) / fmax(sqrt(al * be), 1e-300));
-        const double zeta = (be - al) / (2.0 * ga);
-        const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double cs = rsqrt(1.0 + t * t), sn = cs * t;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const double ap = A[r][p], aq = A[r][q];
-          A[r][p] = cs * ap - sn * aq; A[r][q] = sn * ap + cs * aq;
-          const double vp = V[r][p], vq = V[r][q];
-          V[r][p] = cs * vp - sn * vq; V[r][q] = sn * vp + cs * vq;
-        }
-      }
-    }
-    if (off < 1e-15) break;
-  }
-  double sg[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) sg[c] = sqrt(A[0][c] * A[0][c] + A[1][c] * A[1][c] + A[2][c] * A[2][c]);
-  int j1 = 0;
-  if (sg[1] > sg[j1]) j1 = 1;
-  if (sg[2] > sg[j1]) j1 = 2;
-  int j2 = (j1 == 0) ? 1 : 0;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) if (c != j1 && sg[c] > sg[j2]) j2 = c;
-  double u1[3], u2[3], v1[3], v2[3], u3[3], v3[3];
-  if (!(sg[j1] > 0.0)) {           // H == 0 (or NaN): identity
-#pragma unroll
-    for (int r = 0; r < 9; ++r) R[r] = (r % 4 == 0) ? 1.0 : 0.0;
-    return;
-  }
-#pragma unroll
-  for (int r = 0; r < 3; ++r) { u1[r] = A[r][j1] / sg[j1]; v1[r] = V[r][j1]; }
-  if (sg[j2] > 1e-14 * sg[j1]) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r) { u2[r] = A[r][j2] / sg[j2]; v2[r] = V[r][j2]; }
-  } else {                           // rank 1: any completion (LAPACK's choice is arbitrary too)
-    any_perp(u1, u2);
-    any_perp(v1, v2);
-  }
-  cross3(u1, u2, u3);
-  cross3(v1, v2, v3);
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) R[3 * r + c] = v1[r] * u1[c] + v2[r] * u2[c] + v3[r] * u3[c];
-}
 
 // T (row-major 4x4 fp32) from R (double) and centroids:  t = cB - R cA   (common.py:46-50)
 GMF_DEVINL void write_T(float* T, const double* R, const double* ca, const double* cb) {

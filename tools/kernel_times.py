@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gmf_amd                                   # noqa: E402
 from gmf_amd import _lib, synthetic              # noqa: E402
 
+if os.environ.get("GMF_LIB"):                    # tools/ubench/ablate_h2p.py: time an ablated (wrong-result) build
+    _lib.LIB_PATH = os.environ["GMF_LIB"]
+
 pos = [a for a in sys.argv[1:] if "=" not in a]
 knobs = [a.split("=") for a in sys.argv[1:] if "=" in a]
 B = int(pos[0]) if len(pos) > 0 else 32

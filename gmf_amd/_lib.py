@@ -108,6 +108,10 @@ SIGNATURES = {
     "gmf_conv_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
     "gmf_bias_relu_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, C.c_longlong, C.c_int, _vp]),
     "gmf_transformation_loss": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float, _vp, _vp]),
+    "gmf_compat_dense": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp]),
+    "gmf_transformation_loss_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "gmf_pose_head_backward": (C.c_int, [_vp, C.POINTER(PoseParams), _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "gmf_weighted_procrustes_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_float, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

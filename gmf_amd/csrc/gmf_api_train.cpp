@@ -2,6 +2,7 @@
 // workspaces around the kernels of train_kernels.hip.  Kept apart from gmf_api.cpp so that the inference launch sequences
 // (and the source hash bench.py ties its profile to) do not move when the training path grows.
 #include "api_common.hpp"
+#include "launchers_pose.hpp"
 
 extern "C" {
 
@@ -188,6 +189,62 @@ int gmf_similarity_backward(gmf_handle* h, const float* feat_n, const float* dM,
   GMF_HIP(gmf::launch_gemm_f32(false, false, G, feat_n, d_feat_n, nullptr, nullptr, N, 128, N, N, ld, ld, sN, sF, sF, B, 1.0f, nullptr, 1, 0, st));
   GMF_HIP(gmf::launch_gemm_f32(true, false, G, feat_n, d_feat_n, nullptr, d_feat_n, N, 128, N, N, ld, ld, sN, sF, sF, B, 1.0f, nullptr, 1, 0, st));
   GMF_HIP(gmf::launch_colsum(rowdsig, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, (int)rows, (long)rows, 1, part, d_sigma, st));
+  return GMF_OK;
+}
+
+int gmf_compat_dense(gmf_handle* h, const float* src_keypts, const float* tgt_keypts, int B, int N, float sigma_d, float* out,
+                     gmf_stream_t stream) {
+  GMF_REQUIRE(h && src_keypts && tgt_keypts && out, GMF_ERR_BAD_ARG, "compat_dense: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0 && N <= 65535 && B <= 65535, GMF_ERR_UNSUPPORTED_SHAPE, "compat_dense: need 0 < B, N <= 65535");
+  GMF_REQUIRE(sigma_d > 0.f, GMF_ERR_BAD_ARG, "compat_dense: sigma_d must be positive");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_compat_dense(src_keypts, tgt_keypts, out, B, N, sigma_d, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_transformation_loss_backward(gmf_handle* h, const float* trans, const float* src_keypts, const float* tgt_keypts,
+                                     const float* probs, int B, int N, float* d_trans, gmf_stream_t stream) {
+  GMF_REQUIRE(h && trans && src_keypts && tgt_keypts && probs && d_trans, GMF_ERR_BAD_ARG, "transformation_loss_backward: null pointer");
+  GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "transformation_loss_backward: empty input");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_tl_backward(trans, src_keypts, tgt_keypts, probs, d_trans, B, N, S(stream)));
+  return GMF_OK;
+}
+
+int gmf_pose_head_backward(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, const float* src_keypts,
+                           const float* tgt_keypts, const int* knn_idx, const float* fitness, const float* d_final_trans, int B,
+                           int N, float* d_feat_n, float* d_sigma, gmf_stream_t stream) {
+  GMF_REQUIRE(h && p && feat_n && src_keypts && tgt_keypts && knn_idx && fitness && d_final_trans && d_feat_n && d_sigma,
+              GMF_ERR_BAD_ARG, "pose_head_backward: null pointer");
+  const int Sn = p->num_seeds, k = p->k, iters = p->num_iterations;
+  GMF_REQUIRE(B > 0 && N > 1 && Sn > 0 && Sn <= N, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head_backward: need N > 1, 0 < num_seeds <= N");
+  GMF_REQUIRE(k > 0 && k <= 64 && k <= N - 1, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head_backward: need 0 < k <= min(64, N-1)");
+  GMF_REQUIRE(iters > 0 && iters <= 64, GMF_ERR_BAD_ARG, "pose_head_backward: bad num_iterations");
+  GMF_REQUIRE(p->refine_iters == 0, GMF_ERR_BAD_ARG, "pose_head_backward: the post-refinement (test mode) is not differentiable");
+  GMF_REQUIRE(p->sigma > 0.f && p->sigma_d > 0.f, GMF_ERR_BAD_ARG, "pose_head_backward: sigma, sigma_d must be positive");
+  SetDevice sd(h);
+  hipStream_t st = S(stream);
+  const size_t BS = (size_t)B * Sn;
+  const size_t n_img = (size_t)B * tiles_of(N) * kTileFloats;
+  if (int rc = arena_reserve(h, arena_need(n_img, 4) + arena_need(BS * iters * k, 4) + arena_need(BS * iters, 1))) return rc;
+  float* fimg = arena_take<float>(h, n_img);
+  float* snaps = arena_take<float>(h, BS * iters * k);
+  unsigned char* conv = arena_take<unsigned char>(h, BS * iters);
+  // the forward's iterates and convergence flags of every seed (the stop iteration is a property of all seeds of a pair)
+  GMF_HIP(gmf::launch_pack_p32(feat_n, fimg, B, N, kC, (long)N * kC, kC, 1, st));
+  GMF_HIP(gmf::launch_seed_power(fimg, src_keypts, tgt_keypts, knn_idx, snaps, conv, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));
+  GMF_HIP(hipMemsetAsync(d_feat_n, 0, (size_t)B * N * kC * sizeof(float), st));
+  GMF_HIP(gmf::launch_pose_best_backward(feat_n, src_keypts, tgt_keypts, knn_idx, fitness, snaps, conv, d_final_trans, d_feat_n,
+                                         d_sigma, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));
+  return GMF_OK;
+}
+
+int gmf_weighted_procrustes_backward(gmf_handle* h, const float* X, const float* Y, const float* w, const int* offsets, int B,
+                                     float eps, const float* d_R, const float* d_t, float* d_w, gmf_stream_t stream) {
+  GMF_REQUIRE(h && X && Y && w && offsets && d_R && d_t && d_w, GMF_ERR_BAD_ARG, "weighted_procrustes_backward: null pointer");
+  GMF_REQUIRE(B > 0, GMF_ERR_UNSUPPORTED_SHAPE, "weighted_procrustes_backward: empty batch");
+  SetDevice sd(h);
+  GMF_HIP(gmf::launch_wp_backward(X, Y, w, offsets, B, eps, d_R, d_t, d_w, S(stream)));
   return GMF_OK;
 }
 

@@ -138,6 +138,7 @@ hipError_t launch_bce_bwd(const float* pred, const float* gt, const float* weigh
 hipError_t launch_sm_dense_bwd(const float* M, long ldm, const float* gt, float* consts, float* dM, int B, int N, int balanced,
                                hipStream_t s);
 hipError_t launch_normalize(bool backward, const float* a, const float* dy, float* nrm, float* out, long rows, int C, hipStream_t s);
+hipError_t launch_compat_dense(const float* src, const float* tgt, float* out, int B, int N, float sigma_d, hipStream_t s);
 hipError_t launch_sim_bwd_G(const float* S, const float* dM, float* G, float* rowdsig, int B, int N, float sigma, hipStream_t s);
 
 // image encoder epilogue (row f-1): image_kernels.hip

@@ -31,4 +31,14 @@ hipError_t launch_global_registration(const float* X, const float* Y, const floa
                                       float qsize, int max_iter, int max_break, double ratio, float* R, float* t,
                                       float* stats, int max_n, hipStream_t s);
 
+// backward of the pose head (pose_backward.hip)
+hipError_t launch_tl_backward(const float* trans, const float* src, const float* tgt, const float* probs, float* g_trans,
+                              int B, int N, hipStream_t s);
+hipError_t launch_pose_best_backward(const float* feat_n, const float* src, const float* tgt, const int* knn_idx,
+                                     const float* fitness, const float* snaps, const unsigned char* conv, const float* g_T,
+                                     float* g_feat, float* g_sigma, int B, int N, int S, int k, int iters, float sigma,
+                                     float sigma_d, hipStream_t s);
+hipError_t launch_wp_backward(const float* X, const float* Y, const float* w, const int* offsets, int B, float eps,
+                              const float* g_R, const float* g_t, float* g_w, hipStream_t s);
+
 }  // namespace gmf

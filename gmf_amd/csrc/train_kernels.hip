@@ -602,6 +602,24 @@ hipError_t launch_bn_bwd(const float* dy, const float* x, const float* mean, con
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// Dense spatial-consistency matrix for the trainable path (PointDSC.py:216-221, computed under no_grad by the reference):
+//   c[b,i,j] = clamp(1 - (|p_i - p_j| - |q_i - q_j|)^2 / sigma_d^2, min = 0),  row-major [B,N,N].
+// (The inference path never materialises it row-major: k_compat_build writes it in the attention kernel's fragment order.)
+// grid (ceil(N/256), N, B), block 256: one row i per blockIdx.y, coalesced stores.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_compat_dense(const float* __restrict__ src, const float* __restrict__ tgt, float* __restrict__ out, int N, float inv_sigmad2) {
+  const int b = blockIdx.z, i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  const float* ps = src + (size_t)b * N * 3;
+  const float* pt = tgt + (size_t)b * N * 3;
+  const float ax = ps[3 * i] - ps[3 * j], ay = ps[3 * i + 1] - ps[3 * j + 1], az = ps[3 * i + 2] - ps[3 * j + 2];
+  const float bx = pt[3 * i] - pt[3 * j], by = pt[3 * i + 1] - pt[3 * j + 1], bz = pt[3 * i + 2] - pt[3 * j + 2];
+  const float d = sqrtf(ax * ax + ay * ay + az * az) - sqrtf(bx * bx + by * by + bz * bz);
+  out[((size_t)b * N + i) * N + j] = fmaxf(1.0f - d * d * inv_sigmad2, 0.f);
+}
+
 hipError_t launch_relu_bwd(const float* dy, const float* y, float* out, long total, hipStream_t s) {
   hipLaunchKernelGGL(k_relu_bwd, dim3(blocks_of(total)), dim3(256), 0, s, dy, y, out, total);
   return hipGetLastError();
@@ -628,6 +646,11 @@ hipError_t launch_sim_bwd_G(const float* S, const float* dM, float* G, float* ro
   const long rows = (long)B * N;
   hipLaunchKernelGGL(k_sim_bwd_G, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, dM, G, rowdsig, N, 1.0f / (sigma * sigma),
                      2.0f / (sigma * sigma * sigma), rows);
+  return hipGetLastError();
+}
+
+hipError_t launch_compat_dense(const float* src, const float* tgt, float* out, int B, int N, float sigma_d, hipStream_t s) {
+  hipLaunchKernelGGL(k_compat_dense, dim3((N + 255) / 256, N, B), dim3(256), 0, s, src, tgt, out, N, 1.0f / (sigma_d * sigma_d));
   return hipGetLastError();
 }
 

@@ -145,6 +145,32 @@ class SpectralMatchingLoss(nn.Module):
         return out[0]
 
 
+class _TransformationLossFn(torch.autograd.Function):
+    """The five outputs of TransformationLoss (gmf_transformation_loss); element 0, the loss, carries its gradient with
+    respect to `trans` (gmf_transformation_loss_backward)."""
+
+    @staticmethod
+    def forward(ctx, trans, gt_trans, src, tgt, probs, re_thre, te_thre):
+        trans = trans.contiguous()
+        bs, N = probs.shape
+        out = torch.empty(5, device=trans.device, dtype=torch.float32)
+        h, st = handle_and_stream(trans)
+        h.call("gmf_transformation_loss", trans.data_ptr(), gt_trans.data_ptr(), src.data_ptr(), tgt.data_ptr(),
+               probs.data_ptr(), bs, N, re_thre, te_thre, out.data_ptr(), st)
+        ctx.save_for_backward(trans, src, tgt, probs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        trans, src, tgt, probs = ctx.saved_tensors
+        bs, N = probs.shape
+        g = torch.empty_like(trans)
+        h, st = handle_and_stream(trans)
+        h.call("gmf_transformation_loss_backward", trans.data_ptr(), src.data_ptr(), tgt.data_ptr(), probs.data_ptr(), bs, N,
+               g.data_ptr(), st)
+        return g * dout[0], None, None, None, None, None, None
+
+
 class TransformationLoss(nn.Module):
     """libs/loss.py:12-64.  forward(trans, gt_trans [bs,4,4], src_keypts, tgt_keypts [bs,N,3], probs [bs,N]) ->
     (loss, recall %, RE deg, TE cm, RMSE); loss, RE, TE, RMSE are 0-dim device tensors, recall a float, as the
@@ -156,18 +182,14 @@ class TransformationLoss(nn.Module):
         self.te_thre = te_thre
 
     def forward(self, trans, gt_trans, src_keypts, tgt_keypts, probs):
-        _no_grad(trans, probs)
-        trans = require_cuda_f32(trans, "trans").contiguous()
+        trans = require_cuda_f32(trans, "trans")
         dev = trans.device
         gt_trans = gt_trans.to(device=dev, dtype=torch.float32).contiguous()
         src = require_cuda_f32(src_keypts, "src_keypts").contiguous()
         tgt = require_cuda_f32(tgt_keypts, "tgt_keypts").contiguous()
-        probs = require_cuda_f32(probs, "probs").contiguous()
+        probs = require_cuda_f32(probs, "probs").detach().contiguous()       # (used as a mask only: probs > 0, loss.py:57)
         bs, N = probs.shape
         if trans.shape != (bs, 4, 4) or gt_trans.shape != (bs, 4, 4) or src.shape != (bs, N, 3) or tgt.shape != (bs, N, 3):
             raise RuntimeError("gmf_amd.TransformationLoss: expected trans, gt_trans [bs,4,4], keypts [bs,N,3], probs [bs,N]")
-        out = torch.empty(5, device=dev, dtype=torch.float32)
-        h, st = handle_and_stream(trans)
-        h.call("gmf_transformation_loss", trans.data_ptr(), gt_trans.data_ptr(), src.data_ptr(), tgt.data_ptr(),
-               probs.data_ptr(), bs, N, float(self.re_thre), float(self.te_thre), out.data_ptr(), st)
-        return out[0], float(out[1]), out[2], out[3], out[4]
+        out = _TransformationLossFn.apply(trans, gt_trans, src, tgt, probs, float(self.re_thre), float(self.te_thre))
+        return out[0], float(out[1]), out[2].detach(), out[3].detach(), out[4].detach()

@@ -400,8 +400,7 @@ class PointDSC(nn.Module):
         return logits, feat_n, feat
 
     # -- pose head --------------------------------------------------------------------------------
-    def pose_head(self, feat_n, src_keypts, tgt_keypts, logits, testing, seeds=None, return_aux=False, sigmas=None):
-        B, N, _ = feat_n.shape
+    def _pose_params(self, N, testing, sigmas=None, device=None):
         S = int(N * self.ratio)
         k = min(self.k, N - 1)
         pp = _lib.PoseParams()
@@ -409,11 +408,16 @@ class PointDSC(nn.Module):
         pp.use_nms = 1 if testing else 0
         pp.refine_iters = 20 if testing else 0
         if sigmas is None:
-            pw = self._weights(feat_n.device)       # sigma / sigma_spat were read when the weights were packed
+            pw = self._weights(device)              # sigma / sigma_spat were read when the weights were packed
             sigmas = (pw.sigma, pw.sigma_d)
         pp.sigma, pp.sigma_d = sigmas               # (the training path passes them: its weights change every step, no packing)
         pp.inlier_threshold, pp.nms_radius = float(self.inlier_threshold), float(self.nms_radius)
         pp.refine_threshold = 0.10 if self.inlier_threshold == 0.10 else 1.2      # PointDSC.py:505-508
+        return pp, S, k
+
+    def pose_head(self, feat_n, src_keypts, tgt_keypts, logits, testing, seeds=None, return_aux=False, sigmas=None):
+        B, N, _ = feat_n.shape
+        pp, S, k = self._pose_params(N, testing, sigmas, feat_n.device)
         dev = feat_n.device
         final_T = torch.empty((B, 4, 4), device=dev)
         labels = torch.empty((B, N), device=dev)
@@ -435,9 +439,9 @@ class PointDSC(nn.Module):
         """train() mode with autograd enabled (libs/trainer.py:131): the differentiable forward - HIP training primitives
         behind torch.autograd.Functions (gmf_amd/train.py), BatchNorm in training mode (batch statistics, running statistics
         updated).  Returns what the reference's non-test forward returns: `final_labels` = the inlier logits and `M` carry the
-        autograd graph (the two losses the reference trains with by default, config_3DMatch.py:50-52); `final_trans` comes
-        from the inference pose head and is detached (the reference's default `weight_transformation` is 0: its gradient is
-        never used; `TransformationLoss` raises if asked to differentiate)."""
+        autograd graph (the two losses the reference trains with by default, config_3DMatch.py:50-52), and so does `final_trans`
+        (the best seed's hypothesis: gmf_pose_head forward, gmf_pose_head_backward to the features and sigma) for
+        `TransformationLoss` (weight 0 in the reference's default configuration)."""
         from . import train as T
         corr_pos = require_cuda_f32(data["corr_pos"], "corr_pos")
         src = require_cuda_f32(data["src_keypts"], "src_keypts").contiguous()
@@ -449,20 +453,15 @@ class PointDSC(nn.Module):
             p_tok = enc(data["p_image"]).flatten(2).permute(0, 2, 1).contiguous()
             q_tok = enc(data["q_image"]).flatten(2).permute(0, 2, 1).contiguous()
         B, N, _ = corr_pos.shape
-        sigma, sigma_d = float(self.sigma), float(self.sigma_spat)      # the step's one host read of the two scalars
-        with torch.no_grad():                                   # PointDSC.py:216-221 (the reference computes it under no_grad)
-            # compat [B, N, N] dense: the trainable path materialises N x N tensors as the reference does (N = 1000 when training)
-            sd_ = torch.norm(src[:, :, None, :] - src[:, None, :, :], dim=-1)
-            td_ = torch.norm(tgt[:, :, None, :] - tgt[:, None, :, :], dim=-1)
-            compat = torch.clamp(1.0 - (sd_ - td_) ** 2 / sigma_d ** 2, min=0)
+        sigma, sigma_d = float(self.sigma.detach()), float(self.sigma_spat)      # the step's one host read of the two scalars
+        compat = T.compat_dense(src, tgt, sigma_d)              # PointDSC.py:216-221 (under no_grad in the reference too)
         feat = T.encoder_train(self.encoder, corr_pos, compat, p_tok, q_tok)           # [B, N, C]
         feat_n = T.normalize_rows(feat.reshape(B * N, -1)).reshape(B, N, -1)           # PointDSC.py:229
         M = T.similarity_matrix_train(feat_n, self.sigma, sigma)                       # PointDSC.py:231-234
         logits = T.classifier_train(self.classification, feat)                         # PointDSC.py:241
         self.last_logits, self.last_features = logits, feat_n
-        with torch.no_grad():
-            final_trans, _, _ = self.pose_head(feat_n.detach().contiguous(), src, tgt, logits.detach().contiguous(), False,
-                                               sigmas=(sigma, sigma_d))
+        # PointDSC.py:246-252: top-S seeds, per-seed hypotheses, the best one - differentiable with respect to the features and sigma
+        final_trans = T.pose_head_train(self, feat_n, self.sigma, src, tgt, logits.detach().contiguous(), (sigma, sigma_d))
         return {"final_trans": final_trans, "final_labels": logits, "M": M}
 
     def forward(self, data):

@@ -9,24 +9,52 @@ import torch
 from ._util import handle_and_stream, require_cuda_f32
 
 
+class _WeightedProcrustes(torch.autograd.Function):
+    """(R, t) of the batched solve, differentiable with respect to the weights (gmf_weighted_procrustes_backward: the DGR
+    trainer back-propagates its pose losses through this solve into the inlier network, core/trainer.py:594-614)."""
+
+    @staticmethod
+    def forward(ctx, w, X, Y, off, eps):
+        B = off.numel() - 1
+        R = torch.empty((B, 3, 3), device=X.device, dtype=torch.float32)
+        t = torch.empty((B, 3), device=X.device, dtype=torch.float32)
+        h, st = handle_and_stream(X)
+        h.call("gmf_weighted_procrustes", X.data_ptr(), Y.data_ptr(), w.data_ptr(), off.data_ptr(), B, float(eps),
+               R.data_ptr(), t.data_ptr(), st)
+        ctx.eps = float(eps)
+        ctx.save_for_backward(w, X, Y, off)
+        return R, t
+
+    @staticmethod
+    def backward(ctx, dR, dt):
+        w, X, Y, off = ctx.saved_tensors
+        B = off.numel() - 1
+        dR = torch.zeros((B, 3, 3), device=X.device) if dR is None else dR.contiguous()
+        dt = torch.zeros((B, 3), device=X.device) if dt is None else dt.contiguous()
+        dw = torch.empty_like(w)
+        h, st = handle_and_stream(X)
+        h.call("gmf_weighted_procrustes_backward", X.data_ptr(), Y.data_ptr(), w.data_ptr(), off.data_ptr(), B, ctx.eps,
+               dR.data_ptr(), dt.data_ptr(), dw.data_ptr(), st)
+        return dw, None, None, None, None
+
+
 def weighted_procrustes_batched(X, Y, w, offsets: Sequence[int], eps):
-    """B ragged problems in one launch: X,Y [sum N,3], w [sum N] or [sum N,1], offsets (B+1 ints) -> R [B,3,3], t [B,3]."""
+    """B ragged problems in one launch: X,Y [sum N,3], w [sum N] or [sum N,1], offsets (B+1 ints) -> R [B,3,3], t [B,3].
+    With autograd enabled and `w` requiring grad the result carries the gradient with respect to w (X, Y: none, as in the
+    DGR trainer, which sets requires_grad = False on them)."""
     X = require_cuda_f32(X, "X").contiguous()
     Y = require_cuda_f32(Y, "Y").contiguous()
     w = require_cuda_f32(w, "w").contiguous().reshape(-1)
     if X.shape != Y.shape or X.dim() != 2 or X.shape[1] != 3 or w.numel() != X.shape[0]:
         raise RuntimeError("gmf_amd.weighted_procrustes: expected X,Y [N,3] and w [N]")
+    if torch.is_grad_enabled() and (X.requires_grad or Y.requires_grad):
+        raise RuntimeError("gmf_amd.weighted_procrustes: gradients with respect to X / Y are not implemented (only w)")
     off = torch.as_tensor(list(offsets), dtype=torch.int32)
     B = off.numel() - 1
     if B < 1 or int(off[0]) != 0 or int(off[-1]) != X.shape[0] or bool((off[1:] <= off[:-1]).any()):
         raise RuntimeError("gmf_amd.weighted_procrustes: offsets must be increasing, start at 0 and end at N")
     off = off.to(X.device)
-    R = torch.empty((B, 3, 3), device=X.device, dtype=torch.float32)
-    t = torch.empty((B, 3), device=X.device, dtype=torch.float32)
-    h, st = handle_and_stream(X)
-    h.call("gmf_weighted_procrustes", X.data_ptr(), Y.data_ptr(), w.data_ptr(), off.data_ptr(), B, float(eps),
-           R.data_ptr(), t.data_ptr(), st)
-    return R, t
+    return _WeightedProcrustes.apply(w, X.detach(), Y.detach(), off, eps)
 
 
 def weighted_procrustes(X, Y, w, eps):

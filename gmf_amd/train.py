@@ -504,3 +504,44 @@ class _SpectralMatchingDense(torch.autograd.Function):
 
 def spectral_matching_loss_train(M, gt, balanced):
     return _SpectralMatchingDense.apply(M, gt, balanced)
+
+
+def compat_dense(src, tgt, sigma_d):
+    """[B, N, N] spatial-consistency matrix of PointDSC.py:216-221 (no gradient, as in the reference)."""
+    B, N, _ = src.shape
+    out = torch.empty((B, N, N), device=src.device, dtype=torch.float32)
+    h, st = handle_and_stream(src)
+    h.call("gmf_compat_dense", src.data_ptr(), tgt.data_ptr(), B, N, float(sigma_d), out.data_ptr(), st)
+    return out
+
+
+class _PoseHeadTrain(torch.autograd.Function):
+    """final_trans of the non-test forward (PointDSC.py:246-252,304-425): top-S seeds by confidence, kNN in feature space,
+    compatibility matrix + power iteration + weighted Kabsch per seed, the hypothesis with most inliers.  Forward =
+    gmf_pose_head; backward = gmf_pose_head_backward (only the best seed of each pair carries gradient: to the k neighbour
+    rows of the unit features and to sigma)."""
+
+    @staticmethod
+    def forward(ctx, feat_n, sigma, model, src, tgt, logits, sigmas):
+        f = feat_n.contiguous()
+        final_T, _, aux = model.pose_head(f, src, tgt, logits, False, return_aux=True, sigmas=sigmas)
+        ctx.model, ctx.sigmas, ctx.sigma_is_tensor = model, sigmas, torch.is_tensor(sigma)
+        ctx.save_for_backward(f, src, tgt, aux["knn_idx"], aux["fitness"])
+        return final_T
+
+    @staticmethod
+    def backward(ctx, dT):
+        f, src, tgt, knn_idx, fitness = ctx.saved_tensors
+        B, N, _ = f.shape
+        pp, _, _ = ctx.model._pose_params(N, False, ctx.sigmas)
+        dT = dT.contiguous()
+        dF = torch.empty_like(f)
+        dsig = torch.empty(B, device=f.device, dtype=torch.float32)
+        h, st = handle_and_stream(f)
+        h.call("gmf_pose_head_backward", pp, f.data_ptr(), src.data_ptr(), tgt.data_ptr(), knn_idx.data_ptr(), fitness.data_ptr(),
+               dT.data_ptr(), B, N, dF.data_ptr(), dsig.data_ptr(), st)
+        return dF, (dsig.sum().reshape(1) if ctx.sigma_is_tensor else None), None, None, None, None, None
+
+
+def pose_head_train(model, feat_n, sigma, src, tgt, logits, sigmas):
+    return _PoseHeadTrain.apply(feat_n, sigma, model, src, tgt, logits, sigmas)

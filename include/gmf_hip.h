@@ -352,6 +352,26 @@ int gmf_spectral_matching_dense_backward(gmf_handle* h, const float* M, int ldm,
  * (training sizes: N ~ 1000); the loss-specific fused form without them is gmf_spectral_matching_backward. */
 int gmf_similarity_backward(gmf_handle* h, const float* feat_n, const float* dM, int B, int N, float sigma, float* d_feat_n,
                             float* d_sigma, gmf_stream_t stream);
+/* Dense compat matrix [B,N,N] row-major, c_ij = clamp(1 - (|p_i-p_j| - |q_i-q_j|)^2 / sigma_d^2, min=0) (PointDSC.py:216-221;
+ * the trainable path materialises it as the reference does; the inference path streams it in kernel order instead). */
+int gmf_compat_dense(gmf_handle* h, const float* src_keypts, const float* tgt_keypts, int B, int N, float sigma_d, float* out,
+                     gmf_stream_t stream);
+/* d loss / d trans [B,4,4] of TransformationLoss (libs/loss.py:35-64) for an upstream gradient of 1:
+ * loss = (1/B) sum_i [any(probs_i > 0)] mean_{b,n} |R_i p_in + t_i - q_bn|^2 (the reference's broadcast over the batch). */
+int gmf_transformation_loss_backward(gmf_handle* h, const float* trans, const float* src_keypts, const float* tgt_keypts,
+                                     const float* probs, int B, int N, float* d_trans, gmf_stream_t stream);
+/* Backward of gmf_pose_head in train mode (use_nms = 0, refine_iters = 0; PointDSC.py:246,252,330-425): final_trans is the
+ * hypothesis of the best seed of each pair, so d_final_trans [B,4,4] flows through that seed's weighted Kabsch solve
+ * (closed-form derivative of the 3x3 SVD), its weights, the power iterations in reverse and the feature compatibility
+ * matrix to the k neighbour rows of feat_n and to sigma.  knn_idx [B,S,k] and fitness [B,S] are gmf_pose_head's outputs for
+ * the same inputs.  d_feat_n [B,N,128] is written whole (zero outside the neighbour rows), d_sigma [B] per pair. */
+int gmf_pose_head_backward(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, const float* src_keypts,
+                           const float* tgt_keypts, const int* knn_idx, const float* fitness, const float* d_final_trans, int B,
+                           int N, float* d_feat_n, float* d_sigma, gmf_stream_t stream);
+/* Backward of gmf_weighted_procrustes with respect to the weights (DGR trains its inlier network through this solve,
+ * core/trainer.py:594-614; X and Y carry no gradient there): d_R [B,3,3], d_t [B,3] -> d_w (ragged like w). */
+int gmf_weighted_procrustes_backward(gmf_handle* h, const float* X, const float* Y, const float* w, const int* offsets, int B,
+                                     float eps, const float* d_R, const float* d_t, float* d_w, gmf_stream_t stream);
 
 /* ---- image encoder epilogue (ResNet BasicBlock, GMF_PointDSC/models/resnet.py:59-75) ------------------------------- */
 

@@ -366,7 +366,121 @@ def gen_f19(pdsc):
     np.savez_compressed(os.path.join(GOLD, "f19_training_step.npz"), **out)
 
 
+def gen_f20(pdsc):
+    """F20: the rest of the backward (row f-4) - the reference's own autograd through its pose head in the non-test forward
+    (PointDSC.py:246-252,304-425: top-S seeds, kNN, feature compatibility, power iteration, weighted SVD of the best seed) and
+    libs/loss.py TransformationLoss.
+
+    Part A (slice): the 12-layer model in eval() mode with autograd enabled; loss = TransformationLoss alone.  Stored: the
+    encoder output (captured by a hook, so the HIP slice is driven from the same features), the logits, final_trans, the
+    loss, d loss / d encoder output (only the best seed's k neighbour rows are non-zero) and d loss / d sigma.
+    Part B (whole step): the 3-layer model of F19 in train() mode, loss = Classification + SpectralMatching + 1.0 *
+    Transformation (config weight_transformation = 1): the gradient statistics of every parameter."""
+    import libs.loss as L
+    out = {}
+    torch.manual_seed(0)
+    sd = O.seeded_state_dict(O.pointdsc_shapes(6, 12, 128), seed=7)
+    sd["sigma"] = torch.tensor([0.8])
+    model = build_ref_pointdsc(pdsc, sd)
+    caps = {}
+
+    def hook(m, i, o):
+        o.retain_grad()
+        caps["enc_out"] = o
+    model.encoder.register_forward_hook(hook)
+    out["sigma"] = np.float32(0.8)
+    with torch.enable_grad():
+        for N, seeds in ((200, [131, 132]), (150, [133, 134, 135])):
+            b = O.synthetic_batch(seeds, N=N, T=196)
+            data = {"corr_pos": b["corr_pos"], "src_keypts": b["src_keypts"], "tgt_keypts": b["tgt_keypts"],
+                    "p_image": _tok_to_image(b["p_tokens"]), "q_image": _tok_to_image(b["q_tokens"])}
+            model.zero_grad()
+            res = model(data)
+            tl = L.TransformationLoss(re_thre=15, te_thre=30)(res["final_trans"], b["gt_trans"], b["src_keypts"], b["tgt_keypts"],
+                                                              res["final_labels"])
+            tl[0].backward()
+            tag = f"N{N}"
+            g = caps["enc_out"].grad.permute(0, 2, 1)                     # [B,N,128]
+            out[f"pair_seeds_{tag}"] = np.array(seeds)
+            out[f"corr_features_{tag}"] = _np(caps["enc_out"].permute(0, 2, 1))
+            out[f"logits_{tag}"] = _np(res["final_labels"])
+            out[f"final_trans_{tag}"] = _np(res["final_trans"])
+            out[f"loss_{tag}"] = np.array([float(tl[0]), float(tl[1]), float(tl[2]), float(tl[3]), float(tl[4])], dtype=np.float32)
+            out[f"d_corr_features_{tag}"] = _np(g)
+            out[f"d_sigma_{tag}"] = _np(model.sigma.grad)
+            print("F20", tag, "loss", float(tl[0]), "|dF|max", float(g.abs().max()), "rows with grad",
+                  [int((g[i].abs().sum(-1) > 0).sum()) for i in range(g.shape[0])], "dsigma", float(model.sigma.grad))
+    # part B
+    torch.manual_seed(0)
+    sd = O.seeded_state_dict(O.pointdsc_shapes(6, 3, 128), seed=7)
+    model = build_ref_pointdsc(pdsc, sd, num_layers=3).train()
+    seeds, N = [121, 122], 200
+    b = O.synthetic_batch(seeds, N=N, T=40)
+    data = {"corr_pos": b["corr_pos"], "src_keypts": b["src_keypts"], "tgt_keypts": b["tgt_keypts"],
+            "p_image": _tok_to_image(b["p_tokens"]), "q_image": _tok_to_image(b["q_tokens"])}
+    with torch.enable_grad():
+        res = model(data)
+        cl = L.ClassificationLoss(balanced=False)(res["final_labels"], b["gt_labels"])
+        sm = L.SpectralMatchingLoss(balanced=False)(res["M"], b["gt_labels"])
+        tl = L.TransformationLoss(re_thre=15, te_thre=30)(res["final_trans"], b["gt_trans"], b["src_keypts"], b["tgt_keypts"],
+                                                          res["final_labels"])
+        loss = 1.0 * cl["loss"] + 1.0 * sm + 1.0 * tl[0]
+        loss.backward()
+    out["step_cfg"] = np.array([N] + seeds)
+    out["step_losses"] = np.array([float(cl["loss"]), float(sm), float(tl[0])])
+    out["step_final_trans"] = _np(res["final_trans"])
+    names, stats, heads = [], [], []
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.double().reshape(-1)
+        names.append(name)
+        stats.append([float(g.sum()), float(g.norm()), float(g.abs().max())])
+        hd = np.zeros(16)
+        hd[:min(16, g.numel())] = g[:16].numpy()
+        heads.append(hd)
+    out["step_grad_names"] = np.array(names)
+    out["step_grad_stats"] = np.array(stats)
+    out["step_grad_heads"] = np.array(heads, dtype=np.float32)
+    print("F20 step losses", out["step_losses"], "params with grad", len(names), "max |grad|", float(np.array(stats)[:, 2].max()))
+    np.savez_compressed(os.path.join(GOLD, "f20_pose_head_backward.npz"), **out)
+
+
+def gen_f21(reg):
+    """F21: DGR's weighted_procrustes (core/registration.py:91-113) differentiated by the reference's own autograd with respect
+    to the weights, as its trainer does (core/trainer.py:594-614): L = sum(gR * R) + sum(gt * t) for seeded gR, gt."""
+    out = {}
+    g = torch.Generator().manual_seed(2100)
+    for tag, n, neg in (("n10", 10, False), ("n1000", 1000, False), ("n8000", 8000, True)):
+        X = torch.randn(n, 3, generator=g)
+        A = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+        if torch.det(A) < 0:
+            A[:, 0] = -A[:, 0]
+        Y = X @ A.t() + torch.randn(1, 3, generator=g) + 0.05 * torch.randn(n, 3, generator=g)
+        n_out = n // 3
+        Y[:n_out] = torch.randn(n_out, 3, generator=g) * 2.0              # outliers
+        w = torch.rand(n, 1, generator=g)
+        if neg:
+            w[::17] = -0.1 * w[::17]                                      # (|w| in the normaliser: the sign term of the gradient)
+        w.requires_grad_(True)
+        gR, gt = torch.randn(3, 3, generator=g), torch.randn(3, generator=g)
+        with torch.enable_grad():
+            R, t = reg.weighted_procrustes(X, Y, w, np.finfo(np.float32).eps)
+            ((gR * R).sum() + (gt * t).sum()).backward()
+        out[f"X_{tag}"], out[f"Y_{tag}"], out[f"w_{tag}"] = _np(X), _np(Y), _np(w)
+        out[f"gR_{tag}"], out[f"gt_{tag}"] = _np(gR), _np(gt)
+        out[f"R_{tag}"], out[f"t_{tag}"], out[f"dw_{tag}"] = _np(R), _np(t), _np(w.grad)
+        print("F21", tag, "|dw|max", float(w.grad.abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "f21_weighted_procrustes_backward.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f20":
+        gen_f20(_import_reference()[0])
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f21":
+        gen_f21(_import_reference()[4])
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f19":
         gen_f19(_import_reference()[0])
         return

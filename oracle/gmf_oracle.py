@@ -575,3 +575,22 @@ def transformation_loss(trans, gt_trans, src_keypts, tgt_keypts, probs, re_thre:
         if int((probs[i] > 0).sum()) >= 1:
             loss += float((diff ** 2).sum(-1).mean())
     return loss / bs, recall * 100.0 / bs, RE / bs, TE / bs, RMSE / bs
+
+
+def pose_loss_from_features(corr_features, sigma, logits, src, tgt, sigma_d: float, ratio: float = 0.1, k: int = 40,
+                            iters: int = 10, tau: float = 0.10):
+    """Differentiable restatement (tensors in, 0-dim tensor out) of the non-test forward's pose head followed by the loss term
+    of TransformationLoss: F.normalize (PointDSC.py:229) -> top-S seeds by confidence (:246) -> cal_seed_trans (:303-427) ->
+    final_trans -> (1/bs) sum_i [any(probs_i > 0)] mean |warp_i - tgt|^2 with the reference's broadcast over the batch
+    (libs/loss.py:57-62).  torch autograd over it is the CPU checker of gmf_pose_head_backward +
+    gmf_transformation_loss_backward (golden F20 pins it to the reference's gradients).  Returns (loss, final_trans)."""
+    fn = F.normalize(corr_features, p=2, dim=-1)
+    bs, N, _ = fn.shape
+    seeds = torch.argsort(logits, dim=1, descending=True)[:, :int(N * ratio)]
+    _, _, final_T, _, _ = cal_seed_trans(fn, src, tgt, seeds, sigma, sigma_d, k, iters, tau)
+    loss = torch.zeros((), dtype=fn.dtype)
+    for i in range(bs):
+        if int((logits[i] > 0).sum()) >= 1:
+            warp = src[i] @ final_T[i, :3, :3].T + final_T[i, :3, 3]
+            loss = loss + ((warp[None] - tgt) ** 2).sum(-1).mean()
+    return loss / bs, final_T

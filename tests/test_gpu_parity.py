@@ -1078,7 +1078,7 @@ def test_f19_training_step(golden_dir, tag):
     M = res["M"].detach()
     assert np.abs(M.double().sum((1, 2)).cpu().numpy() / g[f"{tag}_M_sum"] - 1).max() < 1e-5
     assert _maxerr(M[:, ::25].cpu(), g[f"{tag}_M_rows"]) < 1e-4
-    assert res["final_trans"].shape == (len(seeds), 4, 4) and not res["final_trans"].requires_grad
+    assert res["final_trans"].shape == (len(seeds), 4, 4) and res["final_trans"].requires_grad
     bn = m.encoder.blocks["NonLocal_layer_2"].fc_message[1]
     assert _maxerr(torch.stack([bn.running_mean, bn.running_var]).cpu(), g[f"{tag}_bn_running"]) < 1e-5
     pc = m.encoder.blocks["PointCN_layer_0"][1]
@@ -1100,6 +1100,115 @@ def test_f19_training_step(golden_dir, tag):
     before = m.classification[0].weight.detach().clone()
     opt.step()
     assert not torch.equal(before, m.classification[0].weight.detach())
+
+
+@pytest.mark.parametrize("tag", ["N200", "N150"])
+def test_f20_pose_head_backward(golden_dir, tag):
+    """Golden F20, part A: the reference's autograd through its pose head in the non-test forward (top-S seeds, kNN, feature
+    compatibility + power iteration + weighted SVD of every seed, the best hypothesis; PointDSC.py:246-252,304-425) and
+    TransformationLoss, from the encoder output.  HIP: gmf_normalize_rows -> gmf_pose_head (forward) ->
+    gmf_transformation_loss, then gmf_transformation_loss_backward -> gmf_pose_head_backward (closed-form derivative of the 3x3
+    SVD, the power iterations in reverse) -> normalize backward: final_trans 1e-4, the five loss outputs, and the gradients
+    with respect to the encoder output (the same k neighbour rows non-zero) and sigma within 2e-3 of their largest entry."""
+    from gmf_amd import train as T_
+    g = _load(golden_dir, "f20_pose_head_backward.npz")
+    seeds = [int(v) for v in g[f"pair_seeds_{tag}"]]
+    N = int(tag[1:])
+    b = synthetic.synthetic_batch(seeds, N=N, T=196)
+    m = gmf_amd.PointDSC(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1, inlier_threshold=0.10,
+                         sigma_d=0.10, k=40, nms_radius=0.10).to(DEV)
+    with torch.no_grad():
+        m.sigma.fill_(float(g["sigma"]))
+    cf = _gpu(torch.from_numpy(g[f"corr_features_{tag}"])).requires_grad_(True)
+    logits = _gpu(torch.from_numpy(g[f"logits_{tag}"]))
+    src, tgt = _gpu(b["src_keypts"]), _gpu(b["tgt_keypts"])
+    B = len(seeds)
+    feat_n = T_.normalize_rows(cf.reshape(B * N, -1)).reshape(B, N, -1)
+    final_T = T_.pose_head_train(m, feat_n, m.sigma, src, tgt, logits, (float(g["sigma"]), 0.10))
+    tl = gmf_amd.TransformationLoss(re_thre=15, te_thre=30)(final_T, _gpu(b["gt_trans"]), src, tgt, logits)
+    tl[0].backward()
+    assert _maxerr(final_T.detach().cpu(), g[f"final_trans_{tag}"]) < 1e-4
+    ref_l = g[f"loss_{tag}"]
+    got_l = np.array([float(tl[0].detach()), float(tl[1]), float(tl[2]), float(tl[3]), float(tl[4])])
+    assert np.abs(got_l - ref_l).max() < 1e-3 * max(1.0, float(np.abs(ref_l).max())), (got_l, ref_l)
+    ref = g[f"d_corr_features_{tag}"]
+    got = cf.grad.cpu().numpy()
+    assert ((np.abs(ref).sum(-1) > 0) == (np.abs(got).sum(-1) > 0)).all()
+    assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
+    ds = float(g[f"d_sigma_{tag}"].reshape(-1)[0])
+    assert abs(float(m.sigma.grad) - ds) < 2e-3 * abs(ds) + 1e-9, (float(m.sigma.grad), ds)
+
+
+def test_f20_training_step_with_transformation_loss(golden_dir):
+    """Golden F20, part B: the training step of F19 with weight_transformation = 1 (loss = Classification + SpectralMatching +
+    Transformation, libs/trainer.py:141-143): the gradient through the pose head joins the other two at the encoder output.
+    Every parameter's gradient within 5e-4 of its largest entry + 1e-5 of the model's largest gradient."""
+    g = _load(golden_dir, "f20_pose_head_backward.npz")
+    cfg = g["step_cfg"]
+    N, seeds = int(cfg[0]), [int(v) for v in cfg[1:]]
+    sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 3, 128), seed=7)
+    m = gmf_amd.PointDSC(in_dim=6, num_layers=3, num_channels=128, num_iterations=10, ratio=0.1, inlier_threshold=0.10,
+                         sigma_d=0.10, k=40, nms_radius=0.10)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(DEV).train()
+    b = synthetic.synthetic_batch(seeds, N=N, T=40)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    gt = _gpu(b["gt_labels"])
+    res = m(data)
+    cl = gmf_amd.ClassificationLoss(balanced=False)(res["final_labels"], gt)
+    sm = gmf_amd.SpectralMatchingLoss(balanced=False)(res["M"], gt)
+    tl = gmf_amd.TransformationLoss(re_thre=15, te_thre=30)(res["final_trans"], _gpu(b["gt_trans"]), data["src_keypts"],
+                                                            data["tgt_keypts"], res["final_labels"])
+    (1.0 * cl["loss"] + 1.0 * sm + 1.0 * tl[0]).backward()
+    ref_losses = g["step_losses"]
+    got = [float(cl["loss"].detach()), float(sm.detach()), float(tl[0].detach())]
+    assert np.abs(np.array(got) / ref_losses - 1).max() < 1e-4, (got, ref_losses)
+    assert _maxerr(res["final_trans"].detach().cpu(), g["step_final_trans"]) < 1e-4
+    names, stats, heads = list(g["step_grad_names"]), g["step_grad_stats"], g["step_grad_heads"]
+    params = dict(m.named_parameters())
+    gmax = float(stats[:, 2].max())
+    assert len(names) == 137
+    for i, n in enumerate(names):
+        gr = params[n].grad
+        assert gr is not None, n
+        gr = gr.double().reshape(-1).cpu()
+        k = min(16, gr.numel())
+        tol = 5e-4 * stats[i, 2] + 1e-5 * gmax
+        assert np.abs(gr[:k].numpy() - heads[i, :k]).max() < tol, (n, stats[i])
+        assert abs(float(gr.norm()) - stats[i, 1]) < 5e-4 * stats[i, 1] + 1e-5 * gmax * np.sqrt(gr.numel()), (n, stats[i])
+
+
+@pytest.mark.parametrize("tag", ["n10", "n1000", "n8000"])
+def test_f21_weighted_procrustes_backward(golden_dir, tag):
+    """Golden F21: DGR's weighted_procrustes differentiated with respect to the weights by the reference's own autograd
+    (core/registration.py:91-113; the DGR trainer trains its inlier network through this solve, core/trainer.py:594-614).
+    gmf_amd.weighted_procrustes carries the same gradient (gmf_weighted_procrustes_backward)."""
+    g = _load(golden_dir, "f21_weighted_procrustes_backward.npz")
+    X, Y = _gpu(torch.from_numpy(g[f"X_{tag}"])), _gpu(torch.from_numpy(g[f"Y_{tag}"]))
+    w = _gpu(torch.from_numpy(g[f"w_{tag}"])).requires_grad_(True)
+    R, t = gmf_amd.weighted_procrustes(X, Y, w, float(np.finfo(np.float32).eps))
+    ((_gpu(torch.from_numpy(g[f"gR_{tag}"])) * R).sum() + (_gpu(torch.from_numpy(g[f"gt_{tag}"])) * t).sum()).backward()
+    assert _maxerr(R.detach().cpu(), g[f"R_{tag}"]) < 1e-5 and _maxerr(t.detach().cpu(), g[f"t_{tag}"]) < 1e-5
+    ref = g[f"dw_{tag}"]
+    assert w.grad.shape == w.shape
+    assert np.abs(w.grad.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
+    # no gradient asked for: the plain forward, and X / Y requiring grad is refused
+    with torch.no_grad():
+        R2, _ = gmf_amd.weighted_procrustes(X, Y, w, float(np.finfo(np.float32).eps))
+    assert torch.equal(R2, R.detach())
+    with pytest.raises(RuntimeError):
+        gmf_amd.weighted_procrustes(X.clone().requires_grad_(True), Y, w, 1e-7)
+
+
+def test_compat_dense_matches_formula():
+    """gmf_compat_dense (the trainable path's [B,N,N] compat matrix, PointDSC.py:216-221) against the formula in torch."""
+    from gmf_amd import train as T_
+    b = synthetic.synthetic_batch([5, 6], N=333, T=8)
+    src, tgt = _gpu(b["src_keypts"]), _gpu(b["tgt_keypts"])
+    c = T_.compat_dense(src, tgt, 0.1)
+    d = torch.norm(src[:, :, None] - src[:, None], dim=-1) - torch.norm(tgt[:, :, None] - tgt[:, None], dim=-1)
+    ref = torch.clamp(1.0 - d ** 2 / 0.1 ** 2, min=0)
+    assert (c - ref).abs().max() < 2e-5 and torch.equal(c, c.transpose(1, 2))
 
 
 def test_training_primitives_against_torch():
@@ -1166,9 +1275,9 @@ def test_sm_loss_backward_full_size():
 
 
 def test_loss_modules_gradients_and_forward_only_rest():
-    """ClassificationLoss and SpectralMatchingLoss(M, gt) carry their gradients (checked against torch autograd over the same
-    formulas, balanced and not, with a per-element weight); TransformationLoss is forward only and says so; inputs on the CPU
-    are refused."""
+    """ClassificationLoss, SpectralMatchingLoss(M, gt) and TransformationLoss carry their gradients (checked against torch
+    autograd over the same formulas: balanced and not, with a per-element weight; the transformation loss with the reference's
+    broadcast over the batch and a pair without positive logits); inputs on the CPU are refused."""
     gen = torch.Generator().manual_seed(5)
     pred = _gpu(torch.randn(3, 50, generator=gen)).requires_grad_(True)
     gt = _gpu((torch.rand(3, 50, generator=gen) < 0.3).float())
@@ -1207,9 +1316,24 @@ def test_loss_modules_gradients_and_forward_only_rest():
         ref.backward()
         assert abs(float(loss.detach()) - float(ref.detach())) < 1e-6
         assert _maxerr(M.grad.cpu(), Mr.grad.cpu()) < 1e-5 * float(Mr.grad.abs().max())
-    T = torch.eye(4, device=DEV).repeat(1, 1, 1).requires_grad_(True)
-    with pytest.raises(RuntimeError, match="forward-only"):
-        gmf_amd.TransformationLoss()(T, T.detach(), _gpu(torch.rand(1, 8, 3)), _gpu(torch.rand(1, 8, 3)), _gpu(torch.rand(1, 8)))
+    bs, n = 3, 41
+    T = torch.eye(4).repeat(bs, 1, 1)
+    T[:, :3, :] += 0.1 * torch.randn(bs, 3, 4, generator=gen)
+    T = _gpu(T).requires_grad_(True)
+    src3, tgt3 = _gpu(torch.rand(bs, n, 3, generator=gen)), _gpu(torch.rand(bs, n, 3, generator=gen))
+    probs = _gpu(torch.randn(bs, n, generator=gen))
+    probs[1] = -probs[1].abs()                           # pair 1: no positive logit -> contributes nothing (loss.py:57-59)
+    out = gmf_amd.TransformationLoss()(T, T.detach(), src3, tgt3, probs)
+    (2.5 * out[0]).backward()
+    Tr = T.detach().clone().requires_grad_(True)
+    ref = 0
+    for i in (0, 2):
+        warp = src3[i] @ Tr[i, :3, :3].T + Tr[i, :3, 3]
+        ref = ref + ((warp[None] - tgt3) ** 2).sum(-1).mean()
+    (2.5 * ref / bs).backward()
+    assert abs(float(out[0].detach()) - float(ref.detach() / bs)) < 1e-6 * float(ref.detach())
+    assert _maxerr(T.grad.cpu(), Tr.grad.cpu()) < 1e-5 * float(Tr.grad.abs().max())
+    assert float(T.grad[1].abs().max()) == 0.0 and float(T.grad[:, 3].abs().max()) == 0.0
     with pytest.raises(RuntimeError, match="HIP device"):
         gmf_amd.ClassificationLoss()(torch.zeros(1, 8), torch.zeros(1, 8))
 

@@ -325,3 +325,39 @@ def test_f19_oracle_training_step(golden_dir, tag):
         gr = sd[n].grad.double().reshape(-1)
         k = min(16, gr.numel())
         assert np.abs(gr[:k].numpy() - heads[i, :k]).max() < 2e-4 * stats[i, 2] + 3e-6 * gmax, n
+
+
+@pytest.mark.parametrize("tag", ["N200", "N150"])
+def test_f20_oracle_pose_head_backward(golden_dir, tag):
+    """Golden F20, part A (the reference's autograd through its pose head and TransformationLoss, from the encoder output):
+    torch autograd over the oracle's restatement `pose_loss_from_features` reproduces final_trans, the loss and the gradients
+    with respect to the encoder output and sigma."""
+    g = np.load(os.path.join(golden_dir, "f20_pose_head_backward.npz"))
+    seeds = [int(v) for v in g[f"pair_seeds_{tag}"]]
+    N = int(tag[1:])
+    b = O.synthetic_batch(seeds, N=N, T=196)
+    cf = torch.from_numpy(g[f"corr_features_{tag}"]).clone().requires_grad_(True)
+    sigma = torch.tensor([float(g["sigma"])], requires_grad=True)
+    logits = torch.from_numpy(g[f"logits_{tag}"])
+    loss, final_T = O.pose_loss_from_features(cf, sigma, logits, b["src_keypts"], b["tgt_keypts"], sigma_d=0.1)
+    loss.backward()
+    assert np.abs(final_T.detach().numpy() - g[f"final_trans_{tag}"]).max() < 1e-4
+    assert abs(float(loss.detach()) - float(g[f"loss_{tag}"][0])) < 1e-4 * max(1.0, float(g[f"loss_{tag}"][0]))
+    ref = g[f"d_corr_features_{tag}"]
+    assert np.abs(cf.grad.numpy() - ref).max() < 2e-3 * np.abs(ref).max()
+    assert ((np.abs(ref).sum(-1) > 0) == (np.abs(cf.grad.numpy()).sum(-1) > 0)).all()      # the same neighbour rows
+    assert abs(float(sigma.grad) - float(g[f"d_sigma_{tag}"])) < 2e-3 * abs(float(g[f"d_sigma_{tag}"])) + 1e-9
+
+
+@pytest.mark.parametrize("tag", ["n10", "n1000", "n8000"])
+def test_f21_oracle_weighted_procrustes_backward(golden_dir, tag):
+    """Golden F21 (DGR weighted_procrustes differentiated by the reference's autograd with respect to the weights): torch
+    autograd over the oracle's restatement gives the same gradient."""
+    g = np.load(os.path.join(golden_dir, "f21_weighted_procrustes_backward.npz"))
+    X, Y = torch.from_numpy(g[f"X_{tag}"]), torch.from_numpy(g[f"Y_{tag}"])
+    w = torch.from_numpy(g[f"w_{tag}"]).clone().requires_grad_(True)
+    R, t = O.weighted_procrustes(X, Y, w, float(np.finfo(np.float32).eps))
+    ((torch.from_numpy(g[f"gR_{tag}"]) * R).sum() + (torch.from_numpy(g[f"gt_{tag}"]) * t).sum()).backward()
+    assert np.abs(R.detach().numpy() - g[f"R_{tag}"]).max() < 1e-5 and np.abs(t.detach().numpy() - g[f"t_{tag}"]).max() < 1e-5
+    ref = g[f"dw_{tag}"]
+    assert np.abs(w.grad.numpy() - ref).max() < 1e-4 * np.abs(ref).max()

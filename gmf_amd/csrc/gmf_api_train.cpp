@@ -232,7 +232,7 @@ int gmf_pose_head_backward(gmf_handle* h, const gmf_pose_params* p, const float*
   unsigned char* conv = arena_take<unsigned char>(h, BS * iters);
   // the forward's iterates and convergence flags of every seed (the stop iteration is a property of all seeds of a pair)
   GMF_HIP(gmf::launch_pack_p32(feat_n, fimg, B, N, kC, (long)N * kC, kC, 1, st));
-  GMF_HIP(gmf::launch_seed_power(fimg, src_keypts, tgt_keypts, knn_idx, snaps, conv, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));
+  GMF_HIP(gmf::launch_seed_power(fimg, src_keypts, tgt_keypts, knn_idx, snaps, conv, nullptr, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));
   GMF_HIP(hipMemsetAsync(d_feat_n, 0, (size_t)B * N * kC * sizeof(float), st));
   GMF_HIP(gmf::launch_pose_best_backward(feat_n, src_keypts, tgt_keypts, knn_idx, fitness, snaps, conv, d_final_trans, d_feat_n,
                                          d_sigma, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));

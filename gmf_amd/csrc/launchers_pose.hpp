@@ -11,11 +11,15 @@ size_t nms_scratch_floats(int B, int N);
 hipError_t launch_sort_topk(const Tuning& tune, const float* keys, int* out_idx, int B, int N, int S, hipStream_t s);
 hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* dist_in, int* knn_idx, int B, int N, int S,
                             int k, hipStream_t s);
+// hsum non-null ([B,S,15] doubles): the centroids and H of the weighted Kabsch problem of the LAST power iterate are summed
+// in the same kernel; launch_seed_kabsch given the same buffer then only runs the SVD (and redoes the sums of pairs whose
+// iteration stopped earlier)
 hipError_t launch_seed_power(const float* featn_img, const float* src, const float* tgt, const int* knn_idx, float* snaps,
-                             unsigned char* conv, int B, int N, int S, int k, int iters, float sigma, float sigma_d,
-                             hipStream_t s);
+                             unsigned char* conv, double* hsum, int B, int N, int S, int k, int iters, float sigma,
+                             float sigma_d, hipStream_t s);
 hipError_t launch_seed_kabsch(const float* src, const float* tgt, const int* knn_idx, const float* snaps,
-                              const unsigned char* conv, float* seed_T, int B, int N, int S, int k, int iters, hipStream_t s);
+                              const unsigned char* conv, float* seed_T, int B, int N, int S, int k, int iters,
+                              const double* hsum, hipStream_t s);
 hipError_t launch_score_hyp(const float* src, const float* tgt, const float* seed_T, int* counts, int B, int N, int S,
                             float tau, hipStream_t s);
 hipError_t launch_finalize_pose(const float* src, const float* tgt, const float* seed_T, const int* counts, float* fitness,

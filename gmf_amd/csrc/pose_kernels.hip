@@ -603,7 +603,7 @@ constexpr int kKMax = 64;
 __global__ void __launch_bounds__(64)
 k_seed_power(const float* __restrict__ featn_img, const float* __restrict__ src, const float* __restrict__ tgt,
              const int* __restrict__ knn_idx, float* __restrict__ snaps, unsigned char* __restrict__ conv,
-             int N, int tiles, int S, int k, int iters, float inv_sigma2, float inv_sigmad2) {
+             double* __restrict__ hsum, int N, int tiles, int S, int k, int iters, float inv_sigma2, float inv_sigmad2) {
   __shared__ float Mx[kKMax * (kKMax + 1)];
   __shared__ float P[kKMax * 8];
   __shared__ float vec[kKMax];
@@ -689,6 +689,38 @@ k_seed_power(const float* __restrict__ featn_img, const float* __restrict__ src,
     last = v;
     __syncthreads();
   }
+  if (!hsum) return;
+  // Weights w = v / (sum v + 1e-6) (PointDSC.py:364-365) and the sums of the weighted Kabsch problem (common.py:10-50:
+  // centroids and H) for the LAST iterate, wave-parallel over the k neighbours: hsum [B,S,15] = ca, cb, H.  k_seed_kabsch
+  // (one lane per seed) then only runs the 3x3 SVD - unless every seed of the pair passed allclose earlier, in which case it
+  // redoes the pair's sums from the iterate the reference stopped at.
+  {
+    float sv = 0.f;
+    for (int r = 0; r < k; ++r) sv += vec[r];            // (the order of k_seed_kabsch's sum)
+    const float inv = 1.0f / (sv + 1e-6f);
+    float wf = (a < k) ? last * inv : 0.f;
+    wf = (wf < 0.f) ? 0.f : wf;                          // weights[weights < 0] = 0 (common.py:24)
+    const double w = wf;
+    double pa[3], pb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { pa[c] = (a < k) ? P[a * 8 + c] : 0.0; pb[c] = (a < k) ? P[a * 8 + 4 + c] : 0.0; }
+    const double sw = wave_sum(w);
+    double ca[3], cb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { ca[c] = wave_sum(w * pa[c]) / (sw + 1e-6); cb[c] = wave_sum(w * pb[c]) / (sw + 1e-6); }
+    double H[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) H[3 * r + c] = wave_sum(w * (pa[r] - ca[r]) * (pb[c] - cb[c]));
+    if (a < 15) {
+      double* o = hsum + ((size_t)pair * S + s) * 15;
+      double val = 0.0;
+#pragma unroll
+      for (int e = 0; e < 15; ++e) if (a == e) val = (e < 3) ? ca[e] : (e < 6) ? cb[e - 3] : H[e - 6];
+      o[a] = val;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -699,7 +731,7 @@ k_seed_power(const float* __restrict__ featn_img, const float* __restrict__ src,
 __global__ void __launch_bounds__(64)
 k_seed_kabsch(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ knn_idx,
               const float* __restrict__ snaps, const unsigned char* __restrict__ conv, float* __restrict__ seed_T,
-              int N, int S, int k, int iters) {
+              int N, int S, int k, int iters, const double* __restrict__ hsum) {
   __shared__ int stop_it;
   const int pair = blockIdx.y;
   // global early exit: first iteration at which EVERY seed of the pair passed allclose (PointDSC.py:444)
@@ -718,6 +750,17 @@ k_seed_kabsch(const float* __restrict__ src, const float* __restrict__ tgt, cons
   __syncthreads();
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= S) return;
+  if (hsum && stop_it == iters - 1) {                // k_seed_power already summed the last iterate: only the SVD is left
+    const double* hs = hsum + ((size_t)pair * S + s) * 15;
+    double ca[3], cb[3], H[9], R[9];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { ca[e] = hs[e]; cb[e] = hs[3 + e]; }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) H[e] = hs[6 + e];
+    kabsch_rotation_from_H(H, R);
+    write_T(seed_T + ((size_t)pair * S + s) * 16, R, ca, cb);
+    return;
+  }
   const int* nb = knn_idx + ((size_t)pair * S + s) * k;
   const float* v = snaps + (((size_t)pair * S + s) * iters + stop_it) * k;
   float sv = 0.f;
@@ -850,6 +893,65 @@ GMF_DEVINL void block_kabsch(const float* ps, const float* pt, int N, const floa
 }
 
 // ---------------------------------------------------------------------------------------
+// post_refinement (PointDSC.py:493-528) by a whole workgroup: up to `iters` IRLS steps from the transform in Tcur (shared),
+// with the reference's exit on an unchanged inlier count.  ONE pass over the points and ONE block reduction per step: the
+// inlier count and the weighted sums W, sum w a, sum w b, sum w a b^T (fp64) come from the same sweep, and
+//   H = sum w (a - ca)(b - cb)^T = Sab - ca Sb^T - Sa cb^T + W ca cb^T,   ca = Sa / (W + 1e-6), cb = Sb / (W + 1e-6)
+// (exact algebra of common.py:25-37; the step used to take a count pass, a centroid pass and an H pass, each with its own
+// reduction).  sh: >= 17 * 17 doubles.
+// ---------------------------------------------------------------------------------------
+GMF_DEVINL void irls_refine(const float* ps, const float* pt, int N, float* Tcur /*shared, 16*/, float thr, int iters,
+                            double* sh) {
+  int prev = 0;
+  for (int it = 0; it < iters; ++it) {
+    __syncthreads();
+    float Tl[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) Tl[e] = Tcur[e];
+    double acc[17];
+#pragma unroll
+    for (int e = 0; e < 17; ++e) acc[e] = 0.0;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      const float x = ps[3 * j], y = ps[3 * j + 1], z = ps[3 * j + 2];
+      const float u = pt[3 * j], v = pt[3 * j + 1], q = pt[3 * j + 2];
+      const float dx = (Tl[0] * x + Tl[1] * y + Tl[2] * z) + Tl[3] - u;
+      const float dy = (Tl[4] * x + Tl[5] * y + Tl[6] * z) + Tl[7] - v;
+      const float dz = (Tl[8] * x + Tl[9] * y + Tl[10] * z) + Tl[11] - q;
+      const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+      if (d < thr) {
+        const float r = d / thr;
+        const double w = 1.0f / (1.0f + r * r);
+        const double wx = w * x, wy = w * y, wz = w * z;
+        acc[0] += 1.0; acc[1] += w;
+        acc[2] += wx; acc[3] += wy; acc[4] += wz;
+        acc[5] += w * u; acc[6] += w * v; acc[7] += w * q;
+        acc[8] += wx * u; acc[9] += wx * v; acc[10] += wx * q;
+        acc[11] += wy * u; acc[12] += wy * v; acc[13] += wy * q;
+        acc[14] += wz * u; acc[15] += wz * v; acc[16] += wz * q;
+      }
+    }
+    block_sum_tree<17>(acc, sh);
+    const int n_inl = (int)acc[0];
+    if (abs(n_inl - prev) < 1) break;
+    prev = n_inl;
+    if (threadIdx.x == 0) {
+      const double den = acc[1] + 1e-6;
+      const double ca[3] = {acc[2] / den, acc[3] / den, acc[4] / den};
+      const double cb[3] = {acc[5] / den, acc[6] / den, acc[7] / den};
+      double H[9], R[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          H[3 * r + c] = acc[8 + 3 * r + c] - ca[r] * acc[5 + c] - acc[2 + r] * cb[c] + acc[1] * ca[r] * cb[c];
+      kabsch_rotation_from_H(H, R);
+      write_T(Tcur, R, ca, cb);
+    }
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
 // Per pair: best hypothesis (first argmax of the inlier count), its inlier labels, and the
 // reference's <=20-step IRLS refinement with early exit on an unchanged inlier count.
 // grid (B), block 1024.
@@ -859,9 +961,9 @@ k_finalize_pose(const float* __restrict__ src, const float* __restrict__ tgt, co
                 const int* __restrict__ counts, float* __restrict__ fitness, float* __restrict__ final_T,
                 float* __restrict__ labels, int* __restrict__ best_out, int N, int S, float tau, float refine_thr,
                 int refine_iters) {
-  __shared__ double sh[9 * 16];
+  __shared__ double sh[17 * 17];
   __shared__ float Tcur[16];
-  __shared__ int s_best, s_cnt;
+  __shared__ int s_best;
   __shared__ int red_c[16], red_i[16];
   const int pair = blockIdx.x;
   const float* ps = src + (size_t)pair * N * 3;
@@ -901,37 +1003,7 @@ k_finalize_pose(const float* __restrict__ src, const float* __restrict__ tgt, co
       labels[(size_t)pair * N + j] = (sqrtf(dx * dx + dy * dy + dz * dz) < tau) ? 1.f : 0.f;
     }
   }
-  int prev = 0;
-  for (int it = 0; it < refine_iters; ++it) {
-    __syncthreads();
-    float Tl[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) Tl[e] = Tcur[e];
-    int cnt = 0;
-    for (int j = threadIdx.x; j < N; j += blockDim.x) {
-      const float x = ps[3 * j], y = ps[3 * j + 1], z = ps[3 * j + 2];
-      const float dx = (Tl[0] * x + Tl[1] * y + Tl[2] * z) + Tl[3] - pt[3 * j];
-      const float dy = (Tl[4] * x + Tl[5] * y + Tl[6] * z) + Tl[7] - pt[3 * j + 1];
-      const float dz = (Tl[8] * x + Tl[9] * y + Tl[10] * z) + Tl[11] - pt[3 * j + 2];
-      cnt += (sqrtf(dx * dx + dy * dy + dz * dz) < refine_thr) ? 1 : 0;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red_c[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int c = 0;
-      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) c += red_c[w];
-      s_cnt = c;
-    }
-    __syncthreads();
-    const int n_inl = s_cnt;
-    if (abs(n_inl - prev) < 1) break;
-    prev = n_inl;
-    block_kabsch(ps, pt, N, Tl, refine_thr, true, Tcur, sh);
-  }
-  __syncthreads();
+  irls_refine(ps, pt, N, Tcur, refine_thr, refine_iters, sh);
   if (threadIdx.x < 16) final_T[(size_t)pair * 16 + threadIdx.x] = Tcur[threadIdx.x];
 }
 
@@ -941,45 +1013,13 @@ k_finalize_pose(const float* __restrict__ src, const float* __restrict__ tgt, co
 __global__ void __launch_bounds__(1024)
 k_post_refine(const float* __restrict__ T_in, const float* __restrict__ src, const float* __restrict__ tgt,
               float* __restrict__ T_out, int N, float thr, int iters) {
-  __shared__ double sh[9 * 16];
+  __shared__ double sh[17 * 17];
   __shared__ float Tcur[16];
-  __shared__ int s_cnt;
-  __shared__ int red_c[16];
   const int pair = blockIdx.x;
   const float* ps = src + (size_t)pair * N * 3;
   const float* pt = tgt + (size_t)pair * N * 3;
   if (threadIdx.x < 16) Tcur[threadIdx.x] = T_in[(size_t)pair * 16 + threadIdx.x];
-  int prev = 0;
-  for (int it = 0; it < iters; ++it) {
-    __syncthreads();
-    float Tl[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) Tl[e] = Tcur[e];
-    int cnt = 0;
-    for (int j = threadIdx.x; j < N; j += blockDim.x) {
-      const float x = ps[3 * j], y = ps[3 * j + 1], z = ps[3 * j + 2];
-      const float dx = (Tl[0] * x + Tl[1] * y + Tl[2] * z) + Tl[3] - pt[3 * j];
-      const float dy = (Tl[4] * x + Tl[5] * y + Tl[6] * z) + Tl[7] - pt[3 * j + 1];
-      const float dz = (Tl[8] * x + Tl[9] * y + Tl[10] * z) + Tl[11] - pt[3 * j + 2];
-      cnt += (sqrtf(dx * dx + dy * dy + dz * dz) < thr) ? 1 : 0;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red_c[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int c = 0;
-      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) c += red_c[w];
-      s_cnt = c;
-    }
-    __syncthreads();
-    const int n_inl = s_cnt;
-    if (abs(n_inl - prev) < 1) break;
-    prev = n_inl;
-    block_kabsch(ps, pt, N, Tl, thr, true, Tcur, sh);
-  }
-  __syncthreads();
+  irls_refine(ps, pt, N, Tcur, thr, iters, sh);
   if (threadIdx.x < 16) T_out[(size_t)pair * 16 + threadIdx.x] = Tcur[threadIdx.x];
 }
 
@@ -1358,17 +1398,19 @@ hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* 
 }
 
 hipError_t launch_seed_power(const float* featn_img, const float* src, const float* tgt, const int* knn_idx, float* snaps,
-                             unsigned char* conv, int B, int N, int S, int k, int iters, float sigma, float sigma_d,
-                             hipStream_t s) {
+                             unsigned char* conv, double* hsum, int B, int N, int S, int k, int iters, float sigma,
+                             float sigma_d, hipStream_t s) {
   if (k > kKMax) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_seed_power, dim3(S, B), dim3(64), 0, s, featn_img, src, tgt, knn_idx, snaps, conv, N, (N + 31) / 32, S, k,
+  hipLaunchKernelGGL(k_seed_power, dim3(S, B), dim3(64), 0, s, featn_img, src, tgt, knn_idx, snaps, conv, hsum, N, (N + 31) / 32, S, k,
                      iters, 1.0f / (sigma * sigma), 1.0f / (sigma_d * sigma_d));
   return hipGetLastError();
 }
 
 hipError_t launch_seed_kabsch(const float* src, const float* tgt, const int* knn_idx, const float* snaps,
-                              const unsigned char* conv, float* seed_T, int B, int N, int S, int k, int iters, hipStream_t s) {
-  hipLaunchKernelGGL(k_seed_kabsch, dim3((S + 63) / 64, B), dim3(64), 0, s, src, tgt, knn_idx, snaps, conv, seed_T, N, S, k, iters);
+                              const unsigned char* conv, float* seed_T, int B, int N, int S, int k, int iters,
+                              const double* hsum, hipStream_t s) {
+  hipLaunchKernelGGL(k_seed_kabsch, dim3((S + 63) / 64, B), dim3(64), 0, s, src, tgt, knn_idx, snaps, conv, seed_T, N, S, k, iters,
+                     hsum);
   return hipGetLastError();
 }
 
@@ -1389,14 +1431,14 @@ hipError_t launch_score_hyp(const float* src, const float* tgt, const float* see
 hipError_t launch_finalize_pose(const float* src, const float* tgt, const float* seed_T, const int* counts, float* fitness,
                                 float* final_T, float* labels, int* best, int B, int N, int S, float tau, float refine_thr,
                                 int refine_iters, hipStream_t s) {
-  hipLaunchKernelGGL(k_finalize_pose, dim3(B), dim3(1024), 0, s, src, tgt, seed_T, counts, fitness, final_T, labels, best, N, S,
+  hipLaunchKernelGGL(k_finalize_pose, dim3(B), dim3(N <= 2048 ? 256 : 1024), 0, s, src, tgt, seed_T, counts, fitness, final_T, labels, best, N, S,
                      tau, refine_thr, refine_iters);
   return hipGetLastError();
 }
 
 hipError_t launch_post_refine(const float* T_in, const float* src, const float* tgt, float* T_out, int B, int N, float thr,
                               int iters, hipStream_t s) {
-  hipLaunchKernelGGL(k_post_refine, dim3(B), dim3(1024), 0, s, T_in, src, tgt, T_out, N, thr, iters);
+  hipLaunchKernelGGL(k_post_refine, dim3(B), dim3(N <= 2048 ? 256 : 1024), 0, s, T_in, src, tgt, T_out, N, thr, iters);
   return hipGetLastError();
 }
 

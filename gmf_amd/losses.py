@@ -192,4 +192,5 @@ class TransformationLoss(nn.Module):
         if trans.shape != (bs, 4, 4) or gt_trans.shape != (bs, 4, 4) or src.shape != (bs, N, 3) or tgt.shape != (bs, N, 3):
             raise RuntimeError("gmf_amd.TransformationLoss: expected trans, gt_trans [bs,4,4], keypts [bs,N,3], probs [bs,N]")
         out = _TransformationLossFn.apply(trans, gt_trans, src, tgt, probs, float(self.re_thre), float(self.te_thre))
-        return out[0], float(out[1]), out[2].detach(), out[3].detach(), out[4].detach()
+        o = out.detach()
+        return out[0], float(o[1]), o[2], o[3], o[4]

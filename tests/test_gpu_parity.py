@@ -208,6 +208,54 @@ def test_f5_f7_pose_head(golden_dir, model):
     assert _maxerr(ref.cpu(), g["refined"]) < 1e-4
 
 
+def test_power_iteration_early_exit_is_resolved_per_pair(model):
+    """PointDSC.py:444: the power iteration stops as soon as EVERY seed passes allclose.  k_seed_power sums the weighted Kabsch
+    problem of the last iterate itself; when the pair stopped earlier, k_seed_kabsch redoes the seeds from the iterate the
+    reference stopped at.  A scene of exact inliers with near-identical features (M close to all-ones: convergence in a few
+    steps) takes the early path; the same kind of scene with noise and 3 iterations allowed runs them all.  Both match the
+    oracle's seed_weights + rigid_transform_3d (the oracle's power iteration has the same exit)."""
+    gen = torch.Generator().manual_seed(77)
+    N, k = 200, 40
+    sigma, sigma_d = float(model.sigma.detach()), float(model.sigma_spat)
+    iters_default = model.num_iterations
+    try:
+        for early in (True, False):
+            model.num_iterations = iters_default if early else 3
+            src = torch.rand(1, N, 3, generator=gen) * 2
+            A = torch.linalg.qr(torch.randn(3, 3, generator=gen))[0]
+            A = A * torch.sign(torch.det(A))
+            tgt = src @ A.T + torch.tensor([0.3, -0.2, 0.1])
+            u = torch.randn(1, 1, 128, generator=gen)
+            if not early:
+                tgt[:, ::3] += 0.5 * torch.randn(1, (N + 2) // 3, 3, generator=gen)
+            feat_n = torch.nn.functional.normalize(u + (0.02 if early else 0.6) * torch.randn(1, N, 128, generator=gen), dim=-1)
+            logits = torch.randn(1, N, generator=gen)
+            fT, _, aux = model.pose_head(_gpu(feat_n), _gpu(src), _gpu(tgt), _gpu(logits), testing=False, return_aux=True)
+            knn_idx = aux["knn_idx"].cpu().long()
+            w, sk, tk = O.seed_weights(feat_n, src, tgt, knn_idx, sigma, sigma_d, model.num_iterations)
+            Ts = O.rigid_transform_3d(sk, tk, w).reshape(1, -1, 4, 4)
+            assert _maxerr(aux["seed_trans"].cpu(), Ts) < 1e-4
+            # which path ran: replay the oracle's iteration and note where it stops
+            bi = torch.arange(1)[:, None, None]
+            f = feat_n[bi, knn_idx]
+            Mf = torch.clamp(1 - (1 - f @ f.transpose(2, 3)) / sigma ** 2, min=0)
+            d = torch.cdist(src[bi, knn_idx], src[bi, knn_idx]) - torch.cdist(tgt[bi, knn_idx], tgt[bi, knn_idx])
+            M = (Mf * torch.clamp(1 - d * d / sigma_d ** 2, min=0)).reshape(-1, k, k).clone()
+            M[:, torch.arange(k), torch.arange(k)] = 0
+            v = torch.ones(M.shape[0], k, 1)
+            stop = model.num_iterations - 1
+            for it in range(model.num_iterations):
+                nv = torch.bmm(M, v)
+                nv = nv / (torch.norm(nv, dim=1, keepdim=True) + 1e-6)
+                if torch.allclose(nv, v):
+                    stop = it
+                    break
+                v = nv
+            assert (stop < model.num_iterations - 1) == early, stop
+    finally:
+        model.num_iterations = iters_default
+
+
 def test_f6_rigid_transform(golden_dir):
     g = _load(golden_dir, "f6_rigid_transform.npz")
     A, B, w = (_gpu(torch.from_numpy(g[k])) for k in ("A", "B", "w"))

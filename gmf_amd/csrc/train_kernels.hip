@@ -30,33 +30,35 @@ namespace gmf {
 //   part[(b * ksplits + ks)][M][N]; k_gemm_reduce adds them in index order and applies alpha / bias / R.
 //   grid (ceil(N / 128), ceil(M / 128), batch * ksplits), block 256.
 // =========================================================================================
-template <bool TA, bool TB>
+template <bool TA, bool TB, int RB>
 __global__ void __launch_bounds__(256)
 k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C, const float* __restrict__ bias,
            const float* __restrict__ R, int M, int N, int K, long lda, long ldb, long ldc, long sA, long sB, long sC,
            int ksplits, int kchunk, float alpha, float* __restrict__ part, int relu) {
+  // RB = 2: 128 x 128 workgroup tile (a wave: 64 x 64); RB = 1: 64 x 128 (a wave: 32 x 64) - for tall-skinny products whose
+  // 128-row tiling leaves half the chip without a workgroup
+  constexpr int BM = 64 * RB;
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
   const int b = blockIdx.z / ksplits, ks = blockIdx.z - b * ksplits;
   const int kbeg = ks * kchunk, kend = min(K, kbeg + kchunk);
-  const int m0 = blockIdx.y * 128 + 64 * wr, n0 = blockIdx.x * 128 + 64 * wc;
+  const int m0 = blockIdx.y * BM + 32 * RB * wr, n0 = blockIdx.x * 128 + 64 * wc;
   A += (size_t)b * sA;
   Bm += (size_t)b * sB;
-  f32x16 acc[2][2];
+  f32x16 acc[RB][2];
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = zero16();
   // 16-byte loads for the operand whose contraction index is contiguous in memory (A when !TA, B when TB), when every
   // address is aligned; full k-steps take them, the ragged last one falls back to the masked scalar form
   const bool vecA = !TA && (lda % 4 == 0) && (sA % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   const bool vecB = TB && (ldb % 4 == 0) && (sB % 4 == 0) && ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+  auto load_step = [&](const int k0, float (&a)[RB][8], float (&bf)[2][8]) {
     const int kk = k0 + 8 * h;
     const bool fullk = (k0 + 16 <= kend);
-    float a[2][8], bf[2][8];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < RB; ++rb) {
       const int r = m0 + 32 * rb + i;
       if (vecA && fullk) {
         const float4* p = reinterpret_cast<const float4*>(A + (size_t)min(r, M - 1) * lda + kk);
@@ -91,15 +93,29 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
         }
       }
     }
+  };
+  auto mma_step = [&](const float (&a)[RB][8], const float (&bf)[2][8]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e)
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma32(a[rb][e], bf[cb][e], acc[rb][cb]);
+  };
+  // register double buffering: the loads of k-step t + 1 are in flight while the MFMAs of k-step t run (a wave that first
+  // waits for its operands and then multiplies leaves the matrix pipe idle for a memory round trip per step)
+  float a0[RB][8], b0[2][8], a1[RB][8], b1[2][8];
+  if (kbeg < kend) load_step(kbeg, a0, b0);
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    if (k0 + 16 < kend) load_step(k0 + 16, a1, b1);
+    mma_step(a0, b0);
+    if (k0 + 16 < kend) {
+      if (k0 + 32 < kend) load_step(k0 + 32, a0, b0);
+      mma_step(a1, b1);
+    }
   }
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       const int col = n0 + 32 * cb + i;
@@ -120,18 +136,29 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
     }
 }
 
-__global__ void __launch_bounds__(256)
+// Sum of the split-K partial tiles in a FIXED order (the result does not depend on scheduling): 64 outputs per workgroup,
+// G = blockDim.x / 64 wave-groups (1 for a few splits of a large output, up to 16 for the ~100 splits of a weight gradient);
+// group g adds the splits z = g, g + G, ... in increasing z, the G group sums are added in index order.
+__global__ void __launch_bounds__(1024)
 k_gemm_reduce(const float* __restrict__ part, float* __restrict__ C, const float* __restrict__ bias, const float* __restrict__ R,
               int M, int N, long ldc, long sC, int ksplits, float alpha, long total, int relu) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
+  __shared__ float red[16][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6, G = blockDim.x >> 6;
+  const long idx = (long)blockIdx.x * 64 + o;
   const long mn = (long)M * N;
-  const int b = (int)(idx / mn);
-  const long rem = idx - (long)b * mn;
-  const int row = (int)(rem / N), col = (int)(rem - (long)row * N);
+  const bool ok = idx < total;
+  const int b = ok ? (int)(idx / mn) : 0;
+  const long rem = ok ? idx - (long)b * mn : 0;
   float s = 0.f;
-  for (int z = 0; z < ksplits; ++z) s += part[((size_t)(b * ksplits + z)) * mn + rem];
-  float v = alpha * s;
+  if (ok)
+    for (int z = g; z < ksplits; z += G) s += part[((size_t)b * ksplits + z) * mn + rem];
+  red[g][o] = s;
+  __syncthreads();
+  if (g != 0 || !ok) return;
+  float t = red[0][o];
+  for (int q = 1; q < G; ++q) t += red[q][o];
+  const int row = (int)(rem / N), col = (int)(rem - (long)row * N);
+  float v = alpha * t;
   if (bias) v += bias[col];
   if (R) v += R[(size_t)b * sC + (size_t)row * ldc + col];
   C[(size_t)b * sC + (size_t)row * ldc + col] = relu ? fmaxf(v, 0.f) : v;
@@ -504,13 +531,22 @@ k_sm_consts(const float* __restrict__ gt, float* __restrict__ consts, int B, int
 // -----------------------------------------------------------------------------------------
 static inline unsigned blocks_of(long total) { return (unsigned)((total + 255) / 256); }
 
+// 64-row workgroup tiles when the 128-row tiling gives fewer workgroups than the chip has CUs
+static inline bool gemm_small_tile(int M, int N, int batch) {
+  return (long)((M + 127) / 128) * ((N + 127) / 128) * batch < 256 && M > 64;
+}
+
 int gemm_ksplits(int M, int N, int K, int batch) {
-  // few output tiles and a long contraction (weight gradients: K = every row of the batch): split K so that the launch
-  // has ~1000 workgroups; each split at least 512 deep
-  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-  if (tiles >= 256 || K < 2048) return 1;
-  int s = (int)std::min<long>((1024 + tiles - 1) / tiles, K / 512);
-  return std::max(1, std::min(s, 256));
+  // few output tiles and a long contraction (weight gradients: K = every row of the batch; the P V products of the
+  // attention): split K so that the launch has ~768 workgroups, each split at least 64 deep, the partial tiles at most
+  // ~48 MB (they are written and read once by k_gemm_reduce)
+  const int bm = gemm_small_tile(M, N, batch) ? 64 : 128;
+  const long tiles = (long)((M + bm - 1) / bm) * ((N + 127) / 128) * batch;
+  if (tiles >= 384 || K < 256) return 1;
+  long s = std::min<long>((768 + tiles - 1) / tiles, K / 64);
+  const long out_bytes = (long)M * N * batch * 4;
+  s = std::min<long>(s, std::max<long>(1, (48L << 20) / out_bytes));
+  return (int)std::max<long>(1, std::min<long>(s, 128));
 }
 
 hipError_t launch_gemm_f32(bool ta, bool tb, const float* A, const float* B, float* C, const float* bias, const float* R, int M, int N,
@@ -520,8 +556,15 @@ hipError_t launch_gemm_f32(bool ta, bool tb, const float* A, const float* B, flo
   int kchunk = (K + ksplits - 1) / ksplits;
   kchunk = (kchunk + 15) / 16 * 16;
   ksplits = (K + kchunk - 1) / kchunk;
-  const dim3 grid((N + 127) / 128, (M + 127) / 128, batch * ksplits);
-#define GMF_GEMM(TA, TB) hipLaunchKernelGGL((k_gemm_f32<TA, TB>), grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA, sB, sC, ksplits, kchunk, alpha, part, relu)
+  const bool small = gemm_small_tile(M, N, batch);
+  const dim3 grid((N + 127) / 128, small ? (M + 63) / 64 : (M + 127) / 128, batch * ksplits);
+#define GMF_GEMM(TA, TB)                                                                                                         \
+  do {                                                                                                                           \
+    if (small) hipLaunchKernelGGL((k_gemm_f32<TA, TB, 1>), grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA,   \
+                                  sB, sC, ksplits, kchunk, alpha, part, relu);                                                  \
+    else hipLaunchKernelGGL((k_gemm_f32<TA, TB, 2>), grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA, sB,    \
+                            sC, ksplits, kchunk, alpha, part, relu);                                                            \
+  } while (0)
   if (ta && tb) GMF_GEMM(true, true);
   else if (ta) GMF_GEMM(true, false);
   else if (tb) GMF_GEMM(false, true);
@@ -529,7 +572,8 @@ hipError_t launch_gemm_f32(bool ta, bool tb, const float* A, const float* B, flo
 #undef GMF_GEMM
   if (ksplits > 1) {
     const long total = (long)batch * M * N;
-    hipLaunchKernelGGL(k_gemm_reduce, dim3(blocks_of(total)), dim3(256), 0, s, part, C, bias, R, M, N, ldc, sC, ksplits, alpha, total, relu);
+    const int groups = ksplits > 64 ? 16 : ksplits > 32 ? 8 : ksplits > 16 ? 4 : ksplits > 8 ? 2 : 1;
+    hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((total + 63) / 64)), dim3(64 * groups), 0, s, part, C, bias, R, M, N, ldc, sC, ksplits, alpha, total, relu);
   }
   return hipGetLastError();
 }

@@ -31,7 +31,7 @@ namespace gmf {
 //   grid (ceil(N / 128), ceil(M / 128), batch * ksplits), block 256.
 // =========================================================================================
 template <bool TA, bool TB, int RB>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C, const float* __restrict__ bias,
            const float* __restrict__ R, int M, int N, int K, long lda, long ldb, long ldc, long sA, long sB, long sC,
            int ksplits, int kchunk, float alpha, float* __restrict__ part, int relu) {
@@ -102,17 +102,71 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma32(a[rb][e], bf[cb][e], acc[rb][cb]);
   };
+  // Full k-steps take the fast loader: per-lane base pointers computed once (rows / columns past the edge are CLAMPED, not
+  // masked - what they contribute lands in output rows / columns that are never stored), the k-dependent part of every
+  // address uniform.  Only a ragged last k-step (K % 16 != 0) goes through the masked loader above.
+  const float* pa[RB];
+  const float* pb[2];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int r = min(m0 + 32 * rb + i, M - 1);
+    pa[rb] = TA ? A + r + (size_t)(8 * h) * lda : A + (size_t)r * lda + 8 * h;
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int c = min(n0 + 32 * cb + i, N - 1);
+    pb[cb] = TB ? Bm + (size_t)c * ldb + 8 * h : Bm + c + (size_t)(8 * h) * ldb;
+  }
+  auto load_fast = [&](const int k0, float (&a)[RB][8], float (&bf)[2][8]) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      if (TA) {
+        const float* q = pa[rb] + (size_t)k0 * lda;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[rb][e] = q[(size_t)e * lda];
+      } else if (vecA) {
+        const float4* q = reinterpret_cast<const float4*>(pa[rb] + k0);
+        const float4 u = q[0], w = q[1];
+        a[rb][0] = u.x; a[rb][1] = u.y; a[rb][2] = u.z; a[rb][3] = u.w;
+        a[rb][4] = w.x; a[rb][5] = w.y; a[rb][6] = w.z; a[rb][7] = w.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[rb][e] = pa[rb][k0 + e];
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      if (!TB) {
+        const float* q = pb[cb] + (size_t)k0 * ldb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bf[cb][e] = q[(size_t)e * ldb];
+      } else if (vecB) {
+        const float4* q = reinterpret_cast<const float4*>(pb[cb] + k0);
+        const float4 u = q[0], w = q[1];
+        bf[cb][0] = u.x; bf[cb][1] = u.y; bf[cb][2] = u.z; bf[cb][3] = u.w;
+        bf[cb][4] = w.x; bf[cb][5] = w.y; bf[cb][6] = w.z; bf[cb][7] = w.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bf[cb][e] = pb[cb][k0 + e];
+      }
+    }
+  };
   // register double buffering: the loads of k-step t + 1 are in flight while the MFMAs of k-step t run (a wave that first
   // waits for its operands and then multiplies leaves the matrix pipe idle for a memory round trip per step)
+  const int kfull = kbeg + ((kend - kbeg) / 16) * 16;      // end of the full k-steps
   float a0[RB][8], b0[2][8], a1[RB][8], b1[2][8];
-  if (kbeg < kend) load_step(kbeg, a0, b0);
-  for (int k0 = kbeg; k0 < kend; k0 += 32) {
-    if (k0 + 16 < kend) load_step(k0 + 16, a1, b1);
+  if (kbeg < kfull) load_fast(kbeg, a0, b0);
+  for (int k0 = kbeg; k0 < kfull; k0 += 32) {
+    if (k0 + 16 < kfull) load_fast(k0 + 16, a1, b1);
     mma_step(a0, b0);
-    if (k0 + 16 < kend) {
-      if (k0 + 32 < kend) load_step(k0 + 32, a0, b0);
+    if (k0 + 16 < kfull) {
+      if (k0 + 32 < kfull) load_fast(k0 + 32, a0, b0);
       mma_step(a1, b1);
     }
+  }
+  if (kfull < kend) {
+    load_step(kfull, a0, b0);
+    mma_step(a0, b0);
   }
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
@@ -123,6 +177,158 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + 32 * rb + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (row >= M) continue;
+        if (ksplits > 1) {
+          part[((size_t)blockIdx.z * M + row) * N + col] = acc[rb][cb][r];
+        } else {
+          float v = alpha * acc[rb][cb][r];
+          if (bias) v += bias[col];
+          if (R) v += R[(size_t)b * sC + (size_t)row * ldc + col];
+          C[(size_t)b * sC + (size_t)row * ldc + col] = relu ? fmaxf(v, 0.f) : v;
+        }
+      }
+    }
+}
+
+// =========================================================================================
+// k_gemm_lds: the same product as k_gemm_f32 for operands whose contiguous dimension is 16-byte friendly (see
+// gemm_lds_ok): both 128 x 16 operand tiles of a k-step go global -> registers -> LDS with coalesced 16-byte loads
+// (k_gemm_f32's lanes each read their own row: 64 cache lines per load instruction), double buffered, one barrier per
+// k-step; the four waves read their MFMA fragments from the LDS (rows padded to 20 floats: conflict-free b128 reads).
+//   LDS per stage: A_s [128][20] | B_s [128][20] floats (k contiguous per row / column), two stages = 40 KiB.
+//   grid (ceil(N / 128), ceil(M / 128), batch * ksplits), block 256.
+// =========================================================================================
+constexpr int kGemmLd = 20;                          // floats per LDS row (16 + 4 of padding)
+constexpr int kGemmStage = 2 * 128 * kGemmLd;        // floats per stage (A then B)
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256, 2)
+k_gemm_lds(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C, const float* __restrict__ bias,
+           const float* __restrict__ R, int M, int N, int K, long lda, long ldb, long ldc, long sA, long sB, long sC,
+           int ksplits, int kchunk, float alpha, float* __restrict__ part, int relu) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kGemmStage];
+  const int t = threadIdx.x, lane = t & 63, h = lane >> 5, i = lane & 31;
+  const int wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+  const int b = blockIdx.z / ksplits, ks = blockIdx.z - b * ksplits;
+  const int kbeg = ks * kchunk, kend = min(K, kbeg + kchunk);
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  A += (size_t)b * sA;
+  Bm += (size_t)b * sB;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = zero16();
+
+  // global -> registers: two 16-byte pieces per thread and operand.
+  //   k-contiguous operand (A when !TA, B when TB): piece p covers row (t >> 2) + 64 p, k = k0 + 4 (t & 3) .. + 3
+  //   row-contiguous operand (A when TA, B when !TB): piece p covers k = k0 + (t >> 5) + 8 p, rows 4 (t & 31) .. + 3
+  // Every fetch ISSUES its loads, whatever k0 (addresses past the end are clamped into the matrix and the values replaced by
+  // zeros): a load under a branch would make the compiler's s_waitcnt vmcnt conservative at the join - it would wait for
+  // the loads just issued instead of only for the ones of the previous step.
+  auto fetch = [&](const float* base, long ld, bool kcontig, int r0, int rmax, int k0, float4 (&v)[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (kcontig) {
+        const int row = min(r0 + (t >> 2) + 64 * p, rmax - 1), k = k0 + 4 * (t & 3);
+        const float4 x = *reinterpret_cast<const float4*>(base + (size_t)row * ld + min(k, K - 4));
+        const bool ok = k < kend;       // (component-wise selects: a select between two float4 OBJECTS goes through scratch)
+        v[p].x = ok ? x.x : 0.f; v[p].y = ok ? x.y : 0.f; v[p].z = ok ? x.z : 0.f; v[p].w = ok ? x.w : 0.f;
+      } else {
+        const int k = k0 + (t >> 5) + 8 * p, row = r0 + 4 * (t & 31);
+        const float4 x = *reinterpret_cast<const float4*>(base + (size_t)min(k, K - 1) * ld + min(row, rmax - 4));
+        const bool ok = k < kend && row < rmax;
+        v[p].x = ok ? x.x : 0.f; v[p].y = ok ? x.y : 0.f; v[p].z = ok ? x.z : 0.f; v[p].w = ok ? x.w : 0.f;
+      }
+    }
+  };
+  auto stash = [&](float* dst, bool kcontig, const float4 (&v)[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (kcontig) {
+        *reinterpret_cast<float4*>(dst + ((t >> 2) + 64 * p) * kGemmLd + 4 * (t & 3)) = v[p];
+      } else {
+        float* q = dst + (4 * (t & 31)) * kGemmLd + (t >> 5) + 8 * p;
+        q[0] = v[p].x; q[kGemmLd] = v[p].y; q[2 * kGemmLd] = v[p].z; q[3 * kGemmLd] = v[p].w;
+      }
+    }
+  };
+  auto mma_stage = [&](const int stage) {
+    const float* As = lds + stage * kGemmStage + (64 * wr + i) * kGemmLd + 8 * h;
+    const float* Bs = lds + stage * kGemmStage + 128 * kGemmLd + (64 * wc + i) * kGemmLd + 8 * h;
+    float a[2][8], bf[2][8];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const float4 u = *reinterpret_cast<const float4*>(As + 32 * rb * kGemmLd);
+      const float4 w = *reinterpret_cast<const float4*>(As + 32 * rb * kGemmLd + 4);
+      a[rb][0] = u.x; a[rb][1] = u.y; a[rb][2] = u.z; a[rb][3] = u.w; a[rb][4] = w.x; a[rb][5] = w.y; a[rb][6] = w.z; a[rb][7] = w.w;
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const float4 u = *reinterpret_cast<const float4*>(Bs + 32 * cb * kGemmLd);
+      const float4 w = *reinterpret_cast<const float4*>(Bs + 32 * cb * kGemmLd + 4);
+      bf[cb][0] = u.x; bf[cb][1] = u.y; bf[cb][2] = u.z; bf[cb][3] = u.w; bf[cb][4] = w.x; bf[cb][5] = w.y; bf[cb][6] = w.z; bf[cb][7] = w.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma32(a[rb][e], bf[cb][e], acc[rb][cb]);
+  };
+  // Prefetch distance TWO k-steps through two register sets: the operands of k-step t + 2 are requested at the top of
+  // step t, held in registers across step t + 1's MFMAs and written to the LDS at its end - a full k-step (2048 matrix-pipe
+  // cycles) plus a barrier more than one memory round trip.  One barrier per k-step, two LDS stages.
+  float4 va0[2], vb0[2], va1[2], vb1[2];
+  fetch(A, lda, !TA, m0, M, kbeg, va0);
+  fetch(Bm, ldb, TB, n0, N, kbeg, vb0);
+  fetch(A, lda, !TA, m0, M, kbeg + 16, va1);
+  fetch(Bm, ldb, TB, n0, N, kbeg + 16, vb1);
+  stash(lds, !TA, va0);
+  stash(lds + 128 * kGemmLd, TB, vb0);
+  __syncthreads();
+  // invariant at the top of a pair of steps: LDS stage 0 holds k0, register set 1 holds k0 + 16
+  int k0 = kbeg;
+  for (; k0 + 48 < kend; k0 += 32) {           // steady state: both fetches of the pair are needed - no branch around a load
+    fetch(A, lda, !TA, m0, M, k0 + 32, va0);
+    fetch(Bm, ldb, TB, n0, N, k0 + 32, vb0);
+    mma_stage(0);
+    stash(lds + kGemmStage, !TA, va1);
+    stash(lds + kGemmStage + 128 * kGemmLd, TB, vb1);
+    __syncthreads();
+    fetch(A, lda, !TA, m0, M, k0 + 48, va1);
+    fetch(Bm, ldb, TB, n0, N, k0 + 48, vb1);
+    mma_stage(1);
+    stash(lds, !TA, va0);
+    stash(lds + 128 * kGemmLd, TB, vb0);
+    __syncthreads();
+  }
+  for (; k0 < kend; k0 += 32) {                // the last (at most three) steps: nothing fetched that is not used
+    if (k0 + 32 < kend) {
+      fetch(A, lda, !TA, m0, M, k0 + 32, va0);
+      fetch(Bm, ldb, TB, n0, N, k0 + 32, vb0);
+    }
+    mma_stage(0);
+    if (k0 + 16 >= kend) break;
+    stash(lds + kGemmStage, !TA, va1);
+    stash(lds + kGemmStage + 128 * kGemmLd, TB, vb1);
+    __syncthreads();
+    mma_stage(1);
+    if (k0 + 32 < kend) {
+      stash(lds, !TA, va0);
+      stash(lds + 128 * kGemmLd, TB, vb0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int col = n0 + 64 * wc + 32 * cb + i;
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 64 * wr + 32 * rb + 8 * (r >> 2) + 4 * h + (r & 3);
         if (row >= M) continue;
         if (ksplits > 1) {
           part[((size_t)blockIdx.z * M + row) * N + col] = acc[rb][cb][r];
@@ -531,16 +737,18 @@ k_sm_consts(const float* __restrict__ gt, float* __restrict__ consts, int B, int
 // -----------------------------------------------------------------------------------------
 static inline unsigned blocks_of(long total) { return (unsigned)((total + 255) / 256); }
 
-// 64-row workgroup tiles when the 128-row tiling gives fewer workgroups than the chip has CUs
-static inline bool gemm_small_tile(int M, int N, int batch) {
-  return (long)((M + 127) / 128) * ((N + 127) / 128) * batch < 256 && M > 64;
+// 64-row workgroup tiles (the register-direct kernel) when the 128-row tiling gives fewer workgroups than the chip has CUs
+// and the contraction is too short to split; long contractions keep the 128-row tiles and split K instead
+static inline bool gemm_small_tile(int M, int N, int K, int batch) {
+  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  return tiles < 256 && M > 64 && (K < 256 || tiles < 4);      // (one or two tiles: even 128 splits leave CUs without work)
 }
 
 int gemm_ksplits(int M, int N, int K, int batch) {
   // few output tiles and a long contraction (weight gradients: K = every row of the batch; the P V products of the
   // attention): split K so that the launch has ~768 workgroups, each split at least 64 deep, the partial tiles at most
   // ~48 MB (they are written and read once by k_gemm_reduce)
-  const int bm = gemm_small_tile(M, N, batch) ? 64 : 128;
+  const int bm = gemm_small_tile(M, N, K, batch) ? 64 : 128;
   const long tiles = (long)((M + bm - 1) / bm) * ((N + 127) / 128) * batch;
   if (tiles >= 384 || K < 256) return 1;
   long s = std::min<long>((768 + tiles - 1) / tiles, K / 64);
@@ -556,7 +764,20 @@ hipError_t launch_gemm_f32(bool ta, bool tb, const float* A, const float* B, flo
   int kchunk = (K + ksplits - 1) / ksplits;
   kchunk = (kchunk + 15) / 16 * 16;
   ksplits = (K + kchunk - 1) / kchunk;
-  const bool small = gemm_small_tile(M, N, batch);
+  // the LDS-staged kernel needs 16-byte pieces along each operand's contiguous dimension
+  const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool a_ok = al16(A) && lda % 4 == 0 && sA % 4 == 0 && (ta ? M % 4 == 0 : K % 4 == 0);
+  const bool b_ok = al16(B) && ldb % 4 == 0 && sB % 4 == 0 && (tb ? K % 4 == 0 : N % 4 == 0);
+  const bool small = gemm_small_tile(M, N, K, batch);
+  if (a_ok && b_ok && !small) {
+    const dim3 grid((N + 127) / 128, (M + 127) / 128, batch * ksplits);
+#define GMF_GEMM_LDS(TA, TB) hipLaunchKernelGGL((k_gemm_lds<TA, TB>), grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA, sB, sC, ksplits, kchunk, alpha, part, relu)
+    if (ta && tb) GMF_GEMM_LDS(true, true);
+    else if (ta) GMF_GEMM_LDS(true, false);
+    else if (tb) GMF_GEMM_LDS(false, true);
+    else GMF_GEMM_LDS(false, false);
+#undef GMF_GEMM_LDS
+  } else {
   const dim3 grid((N + 127) / 128, small ? (M + 63) / 64 : (M + 127) / 128, batch * ksplits);
 #define GMF_GEMM(TA, TB)                                                                                                         \
   do {                                                                                                                           \
@@ -570,6 +791,7 @@ hipError_t launch_gemm_f32(bool ta, bool tb, const float* A, const float* B, flo
   else if (tb) GMF_GEMM(false, true);
   else GMF_GEMM(false, false);
 #undef GMF_GEMM
+  }
   if (ksplits > 1) {
     const long total = (long)batch * M * N;
     const int groups = ksplits > 64 ? 16 : ksplits > 32 ? 8 : ksplits > 16 ? 4 : ksplits > 8 ? 2 : 1;

@@ -1,9 +1,10 @@
-"""Timing-only ablations of the attention kernel k_scattn_h2p (results WRONG by construction; never part of the library).
-Each ablation is a textual patch applied to a scratch COPY of gmf_amd/csrc/encoder_kernels.hip; the patched object is
-linked with the product's other objects into tools/_ab/libgmf_hip_<name>.so (git-ignored, travels with gpurun).
+"""Timing-only ablations of the two per-layer kernels, k_scattn_h2p and k_linear_h2 (results WRONG by construction; never
+part of the library).  Each ablation is a set of textual patches applied to a scratch COPY of gmf_amd/csrc; the objects
+whose sources changed are rebuilt and linked with the product's other objects into tools/_ab/libgmf_hip_<name>.so
+(git-ignored, travels with gpurun).
 
     python tools/ubench/ablate_h2p.py build            # here (cross-compiles)
-    python tools/ubench/ablate_h2p.py run [B] [N]      # GPU box: ms per attention launch for every variant
+    python tools/ubench/ablate_h2p.py run [B] [N]      # GPU box: ms per launch of both kernels for every variant
 
 What each one removes tells what that resource costs the shipped kernel:
     half_lds   K / V fragments re-read from the LDS for every second k-step only (the LDS traffic of a 64-query wave)
@@ -11,6 +12,12 @@ What each one removes tells what that resource costs the shipped kernel:
     no_exp     v_exp_f32 replaced by a subtraction
     no_dma     the in-loop K / V tile refills are not issued (stale tiles)
     no_split   probabilities not split into two fp16 planes (one conversion)
+and for k_linear_h2 (prefix lin_):
+    lin_no_gelu     GELU of the feed-forward replaced by the identity
+    lin_no_barrier  the stage barriers removed (racy)
+    lin_no_dma      the weight / context stages not fetched (stale LDS)
+    lin_no_exp      the cross-attention's exponentials replaced by a subtraction
+    lin_dma_same    every stage fetched from the same 16 KiB (same DMA count and waits, no L2 traffic)
 """
 import os
 import shutil
@@ -21,72 +28,108 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CSRC = os.path.join(ROOT, "gmf_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "_ab")
 
+EK, EH, FF, MC = "encoder_kernels.hip", "encoder_h2.hip", "enc_ff.hpp", "mfma_core.hpp"
 PATCHES = {
     "base": [],
     "half_lds": [
-        ("if (pr == 0 && s < 7) { kh_n", "if (pr == 0 && s < 7 && (s & 1)) { kh_n"),
-        ("if (pr == 0 && u < 21) {\n", "if (pr == 0 && u < 21 && ((u / 3) & 1)) {\n"),
+        (EK, "if (pr == 0 && s < 7) { kh_n", "if (pr == 0 && s < 7 && (s & 1)) { kh_n"),
+        (EK, "if (pr == 0 && u < 21) {\n", "if (pr == 0 && u < 21 && ((u / 3) & 1)) {\n"),
     ],
     "no_c": [
-        ("const f32x4 v = __builtin_nontemporal_load(ct + q * 64);", "const f32x4 v = {1.f, 1.f, 1.f, 1.f}; (void)ct;"),
+        (EK, "const f32x4 v = __builtin_nontemporal_load(ct + q * 64);", "const f32x4 v = {1.f, 1.f, 1.f, 1.f}; (void)ct;"),
     ],
     "no_exp": [
-        ("          x[r] = __builtin_amdgcn_exp2f(x[r] - m_off);\n          ls += x[r];",
+        (EK, "          x[r] = __builtin_amdgcn_exp2f(x[r] - m_off);\n          ls += x[r];",
          "          x[r] = x[r] - m_off;\n          ls += x[r];"),
     ],
     "no_dma": [
-        ("        if (u >= 3 && u < 11) issue_piece(t, u - 3);\n", ""),
+        (EK, "        if (u >= 3 && u < 11) issue_piece(t, u - 3);\n", ""),
     ],
     "no_split": [
-        ("          split2h(x[j], x[j + 1], ph0, pl0, j);", "          ph0[j] = (_Float16)x[j]; ph0[j + 1] = (_Float16)x[j + 1];"),
-        ("          split2h(x[8 + j], x[8 + j + 1], ph1, pl1, j);", "          ph1[j] = (_Float16)x[8 + j]; ph1[j + 1] = (_Float16)x[8 + j + 1];"),
+        (EK, "          split2h(x[j], x[j + 1], ph0, pl0, j);", "          ph0[j] = (_Float16)x[j]; ph0[j + 1] = (_Float16)x[j + 1];"),
+        (EK, "          split2h(x[8 + j], x[8 + j + 1], ph1, pl1, j);", "          ph1[j] = (_Float16)x[8 + j]; ph1[j + 1] = (_Float16)x[8 + j + 1];"),
+    ],
+    "lin_no_gelu": [
+        (FF, "a_cur[u] *= gelu_erf_1r(g_cur[u]);", "a_cur[u] *= g_cur[u];"),
+    ],
+    "lin_no_barrier": [
+        (MC, "    asm volatile(\"s_waitcnt vmcnt(%0)\" ::\"n\"(YOUNGER) : \"memory\");\n    __syncthreads();", "    asm volatile(\"s_waitcnt vmcnt(%0)\" ::\"n\"(YOUNGER) : \"memory\");"),
+        (MC, "    __syncthreads();            // everyone's pieces of this stage landed; the slot of the previous stage is free\n", ""),
+        (FF, "    asm volatile(\"s_waitcnt vmcnt(8)\" ::: \"memory\");   // all but this wave's pieces of the 2 younger stages have landed\n    __syncthreads();",
+         "    asm volatile(\"s_waitcnt vmcnt(8)\" ::: \"memory\");"),
+    ],
+    "lin_no_dma": [
+        (MC, "      for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);\n      ++issued;", "      for (int q = 0; q < 1; ++q) { (void)g; (void)dst; }\n      ++issued;"),
+        (FF, "    for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);\n    ++n_issued;", "    for (int q = 0; q < 1; ++q) { (void)g; (void)dst; }\n    ++n_issued;"),
+    ],
+    "lin_dma_same": [      # every stage is fetched from the SAME 16 KiB of global memory (hot in the L1): same DMA count, no L2 traffic
+        (MC, "      float* dst = base + (issued % NBUF) * kStageFloats;\n#pragma unroll\n      for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256,",
+         "      float* dst = base + (issued % NBUF) * kStageFloats;\n      g = seg_ptr[0];\n#pragma unroll\n      for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256,"),
+        (FF, "    const float* g = wst + (size_t)blob_stage(n_issued) * kStageFloats;", "    const float* g = wst;"),
+    ],
+    "lin_dma_once": [      # only the first ring-full of stages is fetched (the LDS holds real data, later stages reuse it)
+        (MC, "      for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);\n      ++issued;",
+         "      for (int q = 0; q < 4; ++q) if (issued < NBUF) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);\n      ++issued;"),
+        (FF, "    for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);\n    ++n_issued;",
+         "    for (int q = 0; q < 4; ++q) if (n_issued < NB) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);\n    ++n_issued;"),
+    ],
+    "lin_no_exp": [
+        (EH, "      for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }\n      l_half = fmaf(l_half, alpha, ls);\n      if (__any(moved)) {\n#pragma unroll\n        for (int db = 0; db < 2; ++db)",
+         "      for (int r = 0; r < 16; ++r) { x[r] = x[r] - m_off; ls += x[r]; }\n      l_half = fmaf(l_half, alpha, ls);\n      if (__any(moved)) {\n#pragma unroll\n        for (int db = 0; db < 2; ++db)"),
     ],
 }
+OBJ_OF = {EK: ["encoder_kernels"], EH: ["encoder_h2"], FF: ["encoder_kernels", "encoder_h2"], MC: ["encoder_kernels", "encoder_h2"]}
 
 
-def build():
+def build(only=None):
     os.makedirs(OUT, exist_ok=True)
     subprocess.check_call(["make", "-C", CSRC, "-j4"])
-    src = open(os.path.join(CSRC, "encoder_kernels.hip")).read()
-    objs = [o for o in os.listdir(CSRC) if o.endswith(".o") and o != "encoder_kernels.o"]
     for name, patches in PATCHES.items():
-        text = src
-        for old, new in patches:
-            n = text.count(old)
-            if n < 1:
-                raise SystemExit(f"{name}: pattern not found: {old[:50]!r}")
-            text = text.replace(old, new)
+        if only and name not in only:
+            continue
         work = os.path.join(OUT, "src_" + name)
         shutil.rmtree(work, ignore_errors=True)
         os.makedirs(work)
         for f in os.listdir(CSRC):
-            if f.endswith(".hpp"):
+            if f.endswith((".hpp", ".hip")):
                 shutil.copy(os.path.join(CSRC, f), work)
-        open(os.path.join(work, "encoder_kernels.hip"), "w").write(text)
-        obj = os.path.join(work, "encoder_kernels.o")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
-                               "-fno-slp-vectorize", "-c", os.path.join(work, "encoder_kernels.hip"), "-o", obj])
+        rebuild = set() if patches else {"encoder_kernels"}
+        for fname, old, new in patches:
+            path = os.path.join(work, fname)
+            text = open(path).read()
+            if text.count(old) < 1:
+                raise SystemExit(f"{name}: pattern not found in {fname}: {old[:50]!r}")
+            open(path, "w").write(text.replace(old, new))
+            rebuild.update(OBJ_OF[fname])
+        objs = []
+        for o in sorted(rebuild):
+            obj = os.path.join(work, o + ".o")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+                                   "-fno-slp-vectorize", "-c", os.path.join(work, o + ".hip"), "-o", obj])
+            objs.append(obj)
+        rest = [os.path.join(CSRC, o) for o in os.listdir(CSRC) if o.endswith(".o") and o[:-2] not in rebuild]
         lib = os.path.join(OUT, f"libgmf_hip_{name}.so")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", obj]
-                              + [os.path.join(CSRC, o) for o in objs] + ["-o", lib])
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950"] + objs + rest + ["-o", lib])
         shutil.rmtree(work)
         print("built", lib, flush=True)
 
 
 def run(argv):
-    for name in PATCHES:
+    names = [a for a in argv if a in PATCHES] or list(PATCHES)
+    argv = [a for a in argv if a not in PATCHES]
+    for name in names:
         lib = os.path.join(OUT, f"libgmf_hip_{name}.so")
-        env = dict(os.environ, GMF_LIB=lib, ROWS="2")
+        env = dict(os.environ, GMF_LIB=lib, ROWS="3")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_times.py")] + argv, env=env,
                            capture_output=True, text=True)
         print(f"== {name}", flush=True)
-        print("\n".join(l for l in r.stdout.splitlines() if "scattn" in l or "encode:" in l), flush=True)
+        print("\n".join(l for l in r.stdout.splitlines() if "scattn" in l or "k_linear" in l or "encode:" in l), flush=True)
         if r.returncode:
             print(r.stderr[-1500:])
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "build":
-        build()
+        build(sys.argv[2:] or None)
     else:
         run(sys.argv[2:])

@@ -540,6 +540,9 @@ constexpr int kJPerWave = 8;
 // c is exactly symmetric (the squared differences do not see the sign of s_i - s_j), so only tiles J >= I are
 // evaluated; a tile with J > I is also written as tile (J, I) after a 32 x 32 transpose through a per-wave LDS buffer
 // (16 ds_write_b32 + 16 ds_read_b32 instead of 16 x ~26 vector instructions with two correctly rounded square roots).
+// HALF (the throughput numerics mode, gmf_set_tuning "precision" = 1): c is stored as fp16, 2 KiB per tile
+// ([q2][lane][8 halves], registers r = 8 q2 .. 8 q2 + 7) - half the stream of the 12 attention launches.
+template <bool HALF>
 __global__ void __launch_bounds__(256)
 k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int N, int tiles, float inv_sig2) {
   __shared__ float tr[4 * 32 * 33];
@@ -553,8 +556,23 @@ k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int 
     const float4 a = pp[0], b = pp[1];
     si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
   }
-  float4* const cbase = reinterpret_cast<float4*>(c_dense) + pbase * (size_t)tiles * 256 + lane;
-  float4* const crow = cbase + (size_t)I * tiles * 256;
+  constexpr int kTile16 = HALF ? 128 : 256;          // 16-byte pieces per tile
+  float4* const cbase = reinterpret_cast<float4*>(c_dense) + pbase * (size_t)tiles * kTile16 + lane;
+  float4* const crow = cbase + (size_t)I * tiles * kTile16;
+  auto store_tile = [&](float4* ct, const float (&c)[16]) {
+    if (HALF) {
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        f16x8 hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hv[e] = (_Float16)c[8 * q2 + e];
+        ct[q2 * 64] = __builtin_bit_cast(float4, hv);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ct[q * 64] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+    }
+  };
   float* const mt = tr + wave * 32 * 33;
   const int j0 = (blockIdx.y * 4 + wave) * kJPerWave;
   for (int J = max(j0, I); J < min(tiles, j0 + kJPerWave); ++J) {
@@ -562,9 +580,7 @@ k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int 
     float c[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) c[r] = compat_times(lp, 8 * (r >> 2) + (r & 3), si, ti, inv_sig2, 1.0f);
-    float4* ct = crow + (size_t)J * 256;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ct[q * 64] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+    store_tile(crow + (size_t)J * kTile16, c);
     if (J > I) {
       // tile (J, I): lane (h, i), register r = element (row i of J, column jl of I) = c(I: jl, J: i) = M[jl][i]
 #pragma unroll
@@ -573,9 +589,7 @@ k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int 
       float d[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) d[r] = mt[(8 * (r >> 2) + 4 * h + (r & 3)) * 33 + i];
-      float4* dt = cbase + ((size_t)J * tiles + I) * 256;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) dt[q * 64] = make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+      store_tile(cbase + ((size_t)J * tiles + I) * kTile16, d);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
@@ -737,6 +751,11 @@ GMF_DEVINL AttnItem attn_item(int L, int n_items, int n_full, int ksplits) {
 }
 
 // `bid`: the workgroup's index in the attention grid; `lds`: 64 KiB owned by the workgroup.
+// NPROD = 3, CH = false: the parity form (split-fp16 operands, three partial products, c as fp32).
+// NPROD = 1, CH = true: the THROUGHPUT numerics mode (gmf_set_tuning "precision" = 1): only the high
+// fp16 planes of Q', K, V and of the probabilities are multiplied (one product, fp32 accumulation; the softmax statistics,
+// the compat product and the epilogue stay as they are) and c is streamed as fp16 - NOT within the 1e-4 parity gate.
+template <int NPROD = 3, bool CH = false>
 GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restrict__ q_img, const float* __restrict__ k_img,
                                 const float* __restrict__ v_img, const float* __restrict__ fus, const float* __restrict__ wst,
                                 const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, int wgs_per_pair,
@@ -767,23 +786,46 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   {
     const f16x8* qp = reinterpret_cast<const f16x8*>(q_img + (pbase + tile) * (size_t)kStageFloats) + lane;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { qh[s] = qp[(0 * 8 + s) * 64]; ql[s] = qp[(1 * 8 + s) * 64]; }
+    for (int s = 0; s < 8; ++s) {
+      qh[s] = qp[(0 * 8 + s) * 64];
+      if (NPROD == 3) ql[s] = qp[(1 * 8 + s) * 64];
+    }
   }
-  const f32x4* const crow = reinterpret_cast<const f32x4*>(c_dense) + ((pbase + tile) * (size_t)tiles) * 256 + lane;
+  constexpr int kCTile16 = CH ? 128 : 256;             // 16-byte pieces per c tile
+  const f32x4* const crow = reinterpret_cast<const f32x4*>(c_dense) + ((pbase + tile) * (size_t)tiles) * kCTile16 + lane;
   float c[16];
   auto fetch_c = [&](int t) {
-    const f32x4* ct = crow + (size_t)t * 256;
+    const f32x4* ct = crow + (size_t)t * kCTile16;
+    if (CH) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = __builtin_nontemporal_load(ct + q * 64);
-      c[4 * q + 0] = v[0]; c[4 * q + 1] = v[1]; c[4 * q + 2] = v[2]; c[4 * q + 3] = v[3];
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const f16x8 hv = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(ct + q2 * 64));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c[8 * q2 + e] = (float)hv[e];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = __builtin_nontemporal_load(ct + q * 64);
+        c[4 * q + 0] = v[0]; c[4 * q + 1] = v[1]; c[4 * q + 2] = v[2]; c[4 * q + 3] = v[3];
+      }
     }
+  };
+  // one product (hi x hi) or the three of the split-fp16 scheme
+  auto mma_n = [&](f32x16& acc, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
+    if (NPROD == 3) mma3(acc, ah, al, bh, bl);
+    else acc = mfma_h16(ah, bh, acc);
+  };
+  auto to_planes2 = [&](float x0, float x1, f16x8& hi, f16x8& lo, int j) {
+    if (NPROD == 3) split2h(x0, x1, hi, lo, j);
+    else { const f32x2 xx = {x0, x1}; const f16x2 hh = __builtin_convertvector(xx, f16x2); hi[j] = hh[0]; hi[j + 1] = hh[1]; }
   };
   const float* gk = k_img + pbase * (size_t)kStageFloats;
   const float* gv = v_img + pbase * (size_t)kStageFloats;
+  constexpr int kPiecesPerWave = (NPROD == 3) ? 4 : 2;   // one product: only the high plane (the first 8 KiB) of a tile is used
   auto issue16k = [&](const float* g, float* l) {      // this wave's 4 of the 16 KiB-pieces of one tile
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + WAVES * q) * 256, l + (wave + WAVES * q) * 256, lane_off16);
+    for (int q = 0; q < kPiecesPerWave; ++q) dma_piece_1k_s(g + (wave + WAVES * q) * 256, l + (wave + WAVES * q) * 256, lane_off16);
   };
   auto issueK = [&](int t) { issue16k(gk + (size_t)t * kStageFloats, ldsK + (t & 1) * kStageFloats); };
   auto issueV = [&](int t) { issue16k(gv + (size_t)t * kStageFloats, ldsV + (t & 1) * kStageFloats); };
@@ -803,7 +845,7 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   if (active) {
     const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK + (t_begin & 1) * kStageFloats) + lane;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) mma3(s_a, lk[(0 * 8 + s) * 64], lk[(1 * 8 + s) * 64], qh[s], ql[s]);
+    for (int s = 0; s < 8; ++s) mma_n(s_a, lk[(0 * 8 + s) * 64], lk[(1 * 8 + s) * 64], qh[s], ql[s]);
   }
 
   // top of tile t: K_{t+1}, V_t, c_t have landed and every wave is done with K_t and V_{t-1}.  The scores x = c_t * s_t
@@ -824,6 +866,7 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   };
   // piece q (0..3 of K_{t+2}, 4..7 of V_{t+1}) of this wave's share of the refills
   auto issue_piece = [&](const int t, const int q) {
+    if ((q & 3) >= kPiecesPerWave) return;
     if (q < 4) {
       if (t + 2 < t_end) dma_piece_1k_s(gk + (size_t)(t + 2) * kStageFloats + (wave + WAVES * q) * 256,
                                         ldsK + (t & 1) * kStageFloats + (wave + WAVES * q) * 256, lane_off16);
@@ -863,13 +906,14 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
     s_next = zero16();
     // ---- phase 1: S_{t+1} on the matrix pipe, tile t's scores / max / first exponentials in its issue gaps ----
     {
-      f16x8 kh = lk[0], kl = lk[8 * 64];
+      f16x8 kh = lk[0], kl = kh;
+      if (NPROD == 3) kl = lk[8 * 64];
       f16x8 kh_n = kh, kl_n = kl;
 #pragma unroll
       for (int u = 0; u < 24; ++u) {
         const int s = u / 3, pr = u % 3;
-        if (pr == 0 && s < 7) { kh_n = lk[(0 * 8 + s + 1) * 64]; kl_n = lk[(1 * 8 + s + 1) * 64]; }
-        s_next = mma3_part(pr, s_next, kh, kl, qh[s], ql[s]);
+        if (pr == 0 && s < 7) { kh_n = lk[(0 * 8 + s + 1) * 64]; if (NPROD == 3) kl_n = lk[(1 * 8 + s + 1) * 64]; }
+        if (NPROD == 3 || pr == 2) s_next = mma3_part(pr, s_next, kh, kl, qh[s], ql[s]);
         if (pr == 2) { kh = kh_n; kl = kl_n; }
         if (u < 2) {
           // (the row maximum and the accumulator rescale are settled before the phase: see below)
@@ -879,34 +923,35 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
           ls += x[r];
         } else if (u <= 15) {
           const int j = 2 * (u - 12);        // split pairs 0..3: the first 8 keys
-          split2h(x[j], x[j + 1], ph0, pl0, j);
+          to_planes2(x[j], x[j + 1], ph0, pl0, j);
         } else if (u <= 21) {
           const int r = u - 6;               // exponentials 10..15
           x[r] = __builtin_amdgcn_exp2f(x[r] - m_off);
           ls += x[r];
         } else {
           const int j = 2 * (u - 22);        // split pairs 4, 5
-          split2h(x[8 + j], x[8 + j + 1], ph1, pl1, j);
+          to_planes2(x[8 + j], x[8 + j + 1], ph1, pl1, j);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- phase 2: O^T += V_t^T P^T, the remaining exponentials and the second split in its issue gaps ----
     {
-      f16x8 vh = lv[0], vl = lv[8 * 64];
+      f16x8 vh = lv[0], vl = vh;
+      if (NPROD == 3) vl = lv[8 * 64];
       f16x8 vh_n = vh, vl_n = vl;
 #pragma unroll
       for (int u = 0; u < 24; ++u) {
         const int s2 = u / 12, db = (u % 12) / 3, pr = u % 3;
         if (pr == 0 && u < 21) {
           const int un = u + 3, slot = 2 * ((un % 12) / 3) + un / 12;
-          vh_n = lv[(0 * 8 + slot) * 64]; vl_n = lv[(1 * 8 + slot) * 64];
+          vh_n = lv[(0 * 8 + slot) * 64]; if (NPROD == 3) vl_n = lv[(1 * 8 + slot) * 64];
         }
-        oacc[db] = mma3_part(pr, oacc[db], vh, vl, s2 ? ph1 : ph0, s2 ? pl1 : pl0);
+        if (NPROD == 3 || pr == 2) oacc[db] = mma3_part(pr, oacc[db], vh, vl, s2 ? ph1 : ph0, s2 ? pl1 : pl0);
         if (pr == 2) { vh = vh_n; vl = vl_n; }
         if (u < 2) {
           const int j = 4 + 2 * u;           // split pairs 6, 7 (needed from u = 12 on)
-          split2h(x[8 + j], x[8 + j + 1], ph1, pl1, j);
+          to_planes2(x[8 + j], x[8 + j + 1], ph1, pl1, j);
         }
         if (u >= 3 && u < 11) issue_piece(t, u - 3);
         __builtin_amdgcn_sched_barrier(0);
@@ -944,7 +989,7 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         const int slot = 2 * db + s2;
-        mma3(oacc[db], lv[(0 * 8 + slot) * 64], lv[(1 * 8 + slot) * 64], ph, pl);
+        mma_n(oacc[db], lv[(0 * 8 + slot) * 64], lv[(1 * 8 + slot) * 64], ph, pl);
       }
     }
     l_half = fmaf(l_half, alpha, ls);
@@ -1004,6 +1049,7 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   else scattn_epilogue_h2<false>(o, active, ss, vecs, ft, out + toff, lane, h);
 }
 
+template <int NPROD, bool CH>
 __global__ void __launch_bounds__(256, 2)
 k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
              const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
@@ -1011,8 +1057,8 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
              int n_items, int n_full, int ksplits, float* __restrict__ part_o, float* __restrict__ part_ml,
              const float* __restrict__ next_wst, const float* __restrict__ next_bias) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
-  scattn_h2p_body(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items, n_full,
-                  ksplits, part_o, part_ml, next_wst, next_bias);
+  scattn_h2p_body<NPROD, CH>(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items,
+                             n_full, ksplits, part_o, part_ml, next_wst, next_bias);
 }
 
 // k_small_attn_ff: small grids, the second of the three launches of a layer - the first n_attn workgroups are the key-split
@@ -1600,9 +1646,10 @@ hipError_t launch_front(int mode, const float* in, const float* wst, const float
   return hipGetLastError();
 }
 
-hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s) {
+hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, bool half, hipStream_t s) {
   const dim3 grid(tiles, (tiles + 4 * kJPerWave - 1) / (4 * kJPerWave), B);
-  hipLaunchKernelGGL(k_compat_build, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, 1.0f / (sigma_d * sigma_d));
+  if (half) hipLaunchKernelGGL(k_compat_build<true>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, 1.0f / (sigma_d * sigma_d));
+  else hipLaunchKernelGGL(k_compat_build<false>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, 1.0f / (sigma_d * sigma_d));
   return hipGetLastError();
 }
 
@@ -1679,8 +1726,12 @@ hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, 
     plan_attn_split(tune, W, tiles, cc->part_o ? cc->max_splits : 0, &n_full, &ksplits);
     const int max_tail = std::max(0, per_xcd - n_full);
     const dim3 grid(8 * (std::min(n_full, per_xcd) + max_tail * ksplits));
-    hipLaunchKernelGGL(k_scattn_h2p, grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, W, n_full,
-                       ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias);
+    if (cc->half)       // throughput numerics mode: one fp16 product, c streamed as fp16 (the cache was built that way)
+      hipLaunchKernelGGL((k_scattn_h2p<1, true>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, W,
+                         n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias);
+    else
+      hipLaunchKernelGGL((k_scattn_h2p<3, false>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias);
     if (max_tail > 0)
       hipLaunchKernelGGL(k_scattn_merge, dim3(8 * max_tail), dim3(256), 0, s, cc->part_o, cc->part_ml, fus, cc->tail_wst_h2, vecs, out,
                          tiles, wpp, W, n_full, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)nullptr, 0,

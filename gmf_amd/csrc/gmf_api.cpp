@@ -91,6 +91,11 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     t.topk_select = value != 0;
     return GMF_OK;
   }
+  if (std::strcmp(name, "precision") == 0) {           // 0 = parity numerics (default), 1 = throughput numerics (NOT within 1e-4)
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: precision must be 0 (parity) or 1 (throughput)");
+    t.precision = value;
+    return GMF_OK;
+  }
   return fail(h, GMF_ERR_BAD_ARG, std::string("gmf: set_tuning: unknown knob ") + name);
 }
 
@@ -380,7 +385,11 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
                                       w->ctx_vec_stride, st));
   }
   GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st));
-  if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, st));
+  // throughput numerics mode ("precision" = 1): on the two-launch path of large grids the attention multiplies one fp16
+  // product and streams the compat matrix as fp16; every other path keeps the parity numerics
+  cc.half = h->tune.precision == 1 && h2 && L > 0 && want_cache && h->tune.fused_linear && h->tune.scattn_variant == 18 &&
+            ((tiles + 3) / 4) * B >= 256;
+  if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, cc.half, st));
 
   float* cur = featA;
   float* nxt = featB;

@@ -15,6 +15,8 @@ struct CompatCache {
   // output and stores f_{l+1} instead of feat (k_scattn_h2p / k_scattn_merge only)
   const float* next_wst_h2 = nullptr;
   const float* next_bias = nullptr;
+  bool half = false;          // `dense` holds fp16 tiles (2 KiB each) and the attention multiplies one fp16 product: the
+                              // throughput numerics mode (Tuning::precision = 1), large grids only
 };
 
 // Per-handle tuning knobs (gmf_set_tuning).  Every value selects between forms that compute the same result up to
@@ -34,9 +36,12 @@ struct Tuning {
   int conv_patch = 1;        // stride-1 3x3 convolutions: 1 = LDS patch kernel (automatic form), 2 = never three workgroups per CU, 0 = gather kernel
   int nms_binned = 1;        // 1 = grid-binned NMS candidates on large grids, 2 = always, 0 = all pairs
   bool topk_select = true;   // radix select of the S seeds (false = full bitonic sort)
+  int precision = 0;         // NOT rounding-equivalent: 0 = parity numerics (fp32-equivalent split-fp16 products, the default);
+                             // 1 = throughput numerics: the spatial-consistency attention multiplies plain
+                             // fp16 operands (one product, fp32 accumulation) and streams c as fp16 - outside the 1e-4 gate
 };
 
-hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, hipStream_t s);
+hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, bool half, hipStream_t s);
 hipError_t launch_front(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
                         float* v, int B, int N, int tiles, hipStream_t s);
 hipError_t launch_scattn_fp32(const float* q, const float* k, const float* v, const float* pts8, const float* fus,

@@ -62,6 +62,7 @@ class ShardedBatchDriver:
             if not dist.is_initialized():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29500")
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL's peer buffers
                 backend = backend or ("nccl" if device.type == "cuda" else "gloo")
                 kw = {"device_id": device} if device.type == "cuda" else {}
                 dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)

@@ -20,6 +20,8 @@ model = model.to(dev).eval()
 b = synthetic.synthetic_batch(list(range(B)), N=N, T=196)
 args = [b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")]
 _lib.handle_for(0).call("gmf_set_tuning", b"scattn_variant", v)
+if os.environ.get("GMF_PRECISION"):                  # the throughput numerics mode (tools only: the library reads no environment)
+    _lib.handle_for(0).call("gmf_set_tuning", b"precision", int(os.environ["GMF_PRECISION"]))
 for _ in range(2):
     model.encode(*args)
 torch.cuda.synchronize()

@@ -23,6 +23,7 @@
 // see mfma_core.hpp).  Weights, K/V tiles and context tiles stream L2 -> LDS in 16 KiB stages by
 // LDS-DMA; activations chain from one MFMA's accumulators into the next MFMA's operand registers.
 #include <algorithm>
+#include <type_traits>
 #include "enc_common.hpp"
 #include "enc_ff.hpp"
 
@@ -1061,6 +1062,170 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
                              n_full, ksplits, part_o, part_ml, next_wst, next_bias);
 }
 
+// =========================================================================================
+// k_scattn_fast: the attention of the THROUGHPUT numerics mode (gmf_set_tuning "precision" = 1) on large grids.  With one
+// fp16 product instead of three a key tile is 16 MFMAs (512 matrix-pipe cycles): shorter than one memory round trip, so
+// the one-tile-ahead streams of k_scattn_h2p leave its waves waiting (measured: 58 % of their cycles).  This form keeps
+// every stream TWO tiles ahead, and lands all of them in the LDS (nothing is in flight towards a register, so the
+// compiler's register allocation cannot interfere with data that has not arrived yet):
+//   LDS (72 KiB, two workgroups per CU): K ring [3][8 KiB] | V ring [3][8 KiB] (high planes only) | c ring [wave][3][2 KiB]
+//   (fp16 compat tiles, each wave its own query tile's);
+//   per tile and wave 6 LDS-DMA pieces in a fixed order (2 of K_{t+2}, 2 of V_{t+2}, 2 of c_{t+2}), all issued
+//   unconditionally (past the end: the last tile again, into slots nobody reads) and all outside the compiler's s_waitcnt
+//   bookkeeping - so ONE counted wait, s_waitcnt vmcnt(6) at the tile top, guarantees everything issued two tiles ago or
+//   earlier while the six pieces of the previous tile stay in flight.
+// No intra-wave MFMA / VALU interleaving: two workgroups per CU overlap each other.  Same work mapping (whole items only),
+// same epilogue (fc_message + Fusion-2 branch + next PointCN, parity arithmetic) as k_scattn_h2p.
+// =========================================================================================
+__global__ void __launch_bounds__(256, 2)
+k_scattn_fast(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
+              const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
+              float* __restrict__ out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_half, int n_items,
+              const float* __restrict__ next_wst, const float* __restrict__ next_bias) {
+  constexpr int WAVES = 4;
+  constexpr int kHiFloats = kStageFloats / 2;          // the high plane of a tile image: 8 KiB
+  constexpr int kCFloats = 512;                        // one fp16 compat tile: 2 KiB
+  __shared__ __attribute__((aligned(16))) float lds[6 * kHiFloats + WAVES * 3 * kCFloats];
+  float* const ldsK = lds;
+  float* const ldsV = lds + 3 * kHiFloats;
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* const ldsC = lds + 6 * kHiFloats + wave * 3 * kCFloats;
+  const unsigned lane_off16 = lane * 16;
+  const AttnItem it = attn_item(blockIdx.x, n_items, 0x7fffffff, 1);
+  if (!it.valid) return;
+  const int pair = it.item / wgs_per_pair, qblock = it.item - pair * wgs_per_pair;
+  const int tile_raw = qblock * WAVES + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const size_t pbase = (size_t)pair * tiles;
+  const size_t toff = (pbase + tile) * (32 * C);
+
+  f16x8 qh[8];
+  {
+    const f16x8* qp = reinterpret_cast<const f16x8*>(q_img + (pbase + tile) * (size_t)kStageFloats) + lane;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qh[s] = qp[s * 64];
+  }
+  const float* gc = c_half + ((pbase + tile) * (size_t)tiles) * kCFloats;       // this wave's row of compat tiles
+  const float* gk = k_img + pbase * (size_t)kStageFloats;
+  const float* gv = v_img + pbase * (size_t)kStageFloats;
+  // the 6 pieces of tile t (clamped to the last one) into ring slot `slot`: this wave's 2 of the 8 KiB-pieces of the K and
+  // of the V high plane, and the 2 KiB of its own compat tile
+  auto issue_tile = [&](int t, const int slot) {
+    t = min(t, tiles - 1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      dma_piece_1k_s(gk + (size_t)t * kStageFloats + (wave + WAVES * q) * 256, ldsK + slot * kHiFloats + (wave + WAVES * q) * 256, lane_off16);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      dma_piece_1k_s(gv + (size_t)t * kStageFloats + (wave + WAVES * q) * 256, ldsV + slot * kHiFloats + (wave + WAVES * q) * 256, lane_off16);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      dma_piece_1k_s(gc + (size_t)t * kCFloats + q * 256, ldsC + slot * kCFloats + q * 256, lane_off16);
+  };
+  // x = c * s with c one half of a 32-bit LDS word
+  auto cmul = [&](const float cdw, const float sv, const bool hi) {
+    const f16x2 hv = __builtin_bit_cast(f16x2, cdw);
+    return (float)(hi ? hv[1] : hv[0]) * sv;
+  };
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
+  float m_run = -INFINITY, l_half = 0.f;
+
+  auto tile_step = [&](auto last_tag, const int t, const int slot) {
+    constexpr bool LAST = decltype(last_tag)::value;       // only the last key tile can hold keys >= N
+    // everything issued two tiles ago or earlier has landed (tile t's K, V, c among it); the previous tile's 6 stay in flight
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __syncthreads();                                   // ... for every wave; and every wave is done with tile t - 1's slots
+    issue_tile(t + 2, slot == 0 ? 2 : slot - 1);       // -> slot (t + 2) % 3 = tile t - 1's
+    if (!active) return;
+    const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK + slot * kHiFloats) + lane;
+    const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV + slot * kHiFloats) + lane;
+    const f32x4* lc = reinterpret_cast<const f32x4*>(ldsC + slot * kCFloats) + lane;
+    const f32x4 c0a = lc[0], c0b = lc[64];
+    f32x16 sc = zero16();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) sc = mfma_h16(lk[s * 64], qh[s], sc);
+    float x[16];
+    float mx = -INFINITY;
+    const int jbase = t * 32 + 4 * h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float cdw = (r < 8) ? c0a[r >> 1] : c0b[(r - 8) >> 1];
+      x[r] = cmul(cdw, sc[r], (r & 1) != 0);
+      if (LAST) {
+        const int jl = 8 * (r >> 2) + (r & 3);
+        x[r] = (jbase + jl < N) ? x[r] : -INFINITY;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(mx, __builtin_fmaxf(x[r], x[r + 1]));
+    mx = xhalf_max_swap(mx);
+    const float m_new = __builtin_fmaxf(m_run, mx);
+    const bool moved = m_new > m_run;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    const float m_off = m_new - 10.0f;                 // P' = 2^10 P
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
+    l_half = fmaf(l_half, alpha, ls);
+    if (__any(moved)) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f16x8 ph;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const f32x2 xx = {x[8 * s2 + j], x[8 * s2 + j + 1]};
+        const f16x2 hh = __builtin_convertvector(xx, f16x2);
+        ph[j] = hh[0]; ph[j + 1] = hh[1];
+      }
+#pragma unroll
+      for (int db = 0; db < 4; ++db) oacc[db] = mfma_h16(lv[(2 * db + s2) * 64], ph, oacc[db]);
+    }
+  };
+
+  // prologue: tiles 0 and 1 (past-the-end tiles clamp to the last one)
+  issue_tile(0, 0);
+  issue_tile(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    const std::false_type body;
+    const std::true_type tail;
+    int slot = 0;
+    for (int t = 0; t + 1 < tiles; ++t) {
+      tile_step(body, t, slot);
+      slot = (slot == 2) ? 0 : slot + 1;
+    }
+    tile_step(tail, tiles - 1, slot);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped refills of the last tiles: nothing may land after the epilogue starts
+  // ---- epilogue: normalise, fc_message, Fusion-2 branch, next PointCN (parity arithmetic) ----
+  float o[CF];
+  {
+    const float inv = 1.0f / xhalf_sum(l_half);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
+  }
+  __syncthreads();
+  StageStream ss;
+  ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5, next_wst, next_wst ? 4 : 0);
+  ss.prime();
+  const FusTile ft{fus + toff};
+  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, ft, out + toff, lane, h, next_bias);
+  else scattn_epilogue_h2<false>(o, active, ss, vecs, ft, out + toff, lane, h);
+}
+
 // k_small_attn_ff: small grids, the second of the three launches of a layer - the first n_attn workgroups are the key-split
 // attention workgroups (every item split: n_full = 0; they need only Q', K, V and c), the remaining ones the hidden-split
 // feed-forward workgroups (they need only x1).  Both write partial results; k_scattn_merge adds them up.  As separate
@@ -1726,7 +1891,10 @@ hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, 
     plan_attn_split(tune, W, tiles, cc->part_o ? cc->max_splits : 0, &n_full, &ksplits);
     const int max_tail = std::max(0, per_xcd - n_full);
     const dim3 grid(8 * (std::min(n_full, per_xcd) + max_tail * ksplits));
-    if (cc->half)       // throughput numerics mode: one fp16 product, c streamed as fp16 (the cache was built that way)
+    if (cc->half && max_tail == 0)   // throughput numerics mode, whole items only: the three-tiles-in-flight form
+      hipLaunchKernelGGL(k_scattn_fast, dim3(8 * per_xcd), dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, W,
+                         cc->next_wst_h2, cc->next_bias);
+    else if (cc->half)  // ... with a split tail: one fp16 product, c streamed as fp16 (the cache was built that way)
       hipLaunchKernelGGL((k_scattn_h2p<1, true>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, W,
                          n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias);
     else

@@ -374,7 +374,7 @@ class PointDSC(nn.Module):
         """Numerics of the eval-mode encoder on this module's device: "parity" (default - fp32-equivalent split-fp16 products,
         logits within 1e-4 of the reference) or "throughput" (on large grids the spatial-consistency
         attention multiplies plain fp16 operands and streams the compat matrix as fp16; measured deviation from the parity
-        mode at 32 x 5000: logits 1e-3, identical inlier labels 99.999 %, 1.3-1.5x the throughput).  The setting lives in the
+        mode at 32 x 5000: logits 1e-3, identical inlier labels 99.999 %, 1.4-1.6x the throughput).  The setting lives in the
         device's library handle (gmf_set_tuning "precision"), i.e. it applies to every module on that device."""
         if mode not in ("parity", "throughput"):
             raise ValueError("gmf_amd.PointDSC.set_precision: mode must be 'parity' or 'throughput'")

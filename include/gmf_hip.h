@@ -59,7 +59,7 @@ long long gmf_workspace_bytes(gmf_handle* h);
  *                         operands (ONE product, fp32 accumulation) and streams the compat matrix as fp16; softmax
  *                         statistics, LayerNorm, GELU, the linear stages and the pose head are unchanged.  NOT within the
  *                         1e-4 gate: measured against the parity mode at 32 x 5000: max |d logit| 1.1e-3, 99.999 % identical
- *                         inlier labels, 1.3x (N = 5000) to 1.5x (N = 10000) the throughput.
+ *                         inlier labels, 1.4x (N = 5000) to 1.6x (N = 10000) the throughput.
  *   "scattn_variant"    : 18 = split-fp16 MFMA attention (2 planes, 3 products), compat matrix streamed from the per-batch
  *                         cache, tile loop software-pipelined inside each wave (default); 9 = the same arithmetic without
  *                         the pipelining; 0 = every encoder stage on the fp32 MFMA with fp32 images.

@@ -730,6 +730,43 @@ def test_tuning_rejects_unknown_and_removed_settings():
     assert h.lib.gmf_set_tuning(h.h, b"scattn_variant", 18) == 0
 
 
+def test_backward_entry_points_reject_bad_arguments():
+    """The round-2 training entry points validate their arguments like the rest of the C ABI: null pointers, empty shapes, a
+    test-mode parameter block (the post-refinement is not differentiable) and non-positive bandwidths return an error code and
+    a message instead of launching."""
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    L = h.lib
+    x = torch.zeros(2, 64, 128, device=DEV)
+    pts = torch.zeros(2, 64, 3, device=DEV)
+    knn = torch.zeros(2, 6, 40, device=DEV, dtype=torch.int32)
+    fit = torch.zeros(2, 6, device=DEV)
+    gT = torch.zeros(2, 4, 4, device=DEV)
+    dF, ds = torch.zeros_like(x), torch.zeros(2, device=DEV)
+    pp = _lib.PoseParams()
+    pp.num_seeds, pp.k, pp.num_iterations, pp.use_nms, pp.refine_iters = 6, 40, 10, 0, 0
+    pp.sigma, pp.sigma_d, pp.inlier_threshold, pp.nms_radius, pp.refine_threshold = 1.0, 0.1, 0.1, 0.1, 0.1
+    args = [x.data_ptr(), pts.data_ptr(), pts.data_ptr(), knn.data_ptr(), fit.data_ptr(), gT.data_ptr(), 2, 64, dF.data_ptr(),
+            ds.data_ptr(), None]
+    assert L.gmf_pose_head_backward(h.h, pp, *args) == 0
+    bad = list(args); bad[3] = None
+    assert L.gmf_pose_head_backward(h.h, pp, *bad) == -1 and b"null" in L.gmf_last_error_string(h.h)
+    pp.refine_iters = 20
+    assert L.gmf_pose_head_backward(h.h, pp, *args) == -1 and b"not differentiable" in L.gmf_last_error_string(h.h)
+    pp.refine_iters, pp.sigma = 0, 0.0
+    assert L.gmf_pose_head_backward(h.h, pp, *args) != 0
+    pp.sigma, pp.k = 1.0, 65
+    assert L.gmf_pose_head_backward(h.h, pp, *args) != 0
+    assert L.gmf_transformation_loss_backward(h.h, gT.data_ptr(), pts.data_ptr(), pts.data_ptr(), fit.data_ptr(), 0, 64,
+                                              gT.data_ptr(), None) != 0
+    assert L.gmf_transformation_loss_backward(h.h, None, pts.data_ptr(), pts.data_ptr(), fit.data_ptr(), 2, 64, gT.data_ptr(),
+                                              None) == -1
+    assert L.gmf_compat_dense(h.h, pts.data_ptr(), pts.data_ptr(), 2, 64, 0.0, x.data_ptr(), None) == -1
+    assert L.gmf_weighted_procrustes_backward(h.h, pts.data_ptr(), pts.data_ptr(), fit.data_ptr(), None, 1, 1e-7, gT.data_ptr(),
+                                              gT.data_ptr(), fit.data_ptr(), None) == -1
+    torch.cuda.synchronize()
+
+
 def test_tuning_is_per_handle(golden_dir, model):
     """Tuning state lives in the handle: a second handle on the same device set to the fp32 path does not change what the
     first one runs (bitwise identical logits before and after)."""

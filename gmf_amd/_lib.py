@@ -97,7 +97,7 @@ SIGNATURES = {
     "gmf_layernorm_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, C.c_int, _vp]),
     "gmf_softmax_rows": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _ll, C.c_int, C.c_float, _vp]),
     "gmf_geglu": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _ll, C.c_int, _vp]),
-    "gmf_colsum": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _ll, C.c_int, _vp, _vp]),
+    "gmf_colsum": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _ll, C.c_int, _vp, C.c_int, _vp, _vp]),
     "gmf_batchnorm_train_forward": (C.c_int, [_vp] * 9 + [_ll, C.c_int, C.c_float, C.c_float, C.c_int, _vp]),
     "gmf_batchnorm_train_backward": (C.c_int, [_vp] * 10 + [_ll, C.c_int, _vp]),
     "gmf_normalize_rows": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _ll, C.c_int, _vp]),

@@ -70,17 +70,20 @@ int gmf_geglu(gmf_handle* h, int backward, const float* hdn, const float* dg, fl
 }
 
 int gmf_colsum(gmf_handle* h, const float* x, const float* y, const float* mean, const float* rstd, const float* cmean,
-               const float* crstd, int center_x, int shift, int L, long long rows, int C, float* out, gmf_stream_t stream) {
+               const float* crstd, int center_x, int shift, int L, long long rows, int C, const float* relu_y, int dual, float* out,
+               gmf_stream_t stream) {
   GMF_REQUIRE(h && x && out, GMF_ERR_BAD_ARG, "colsum: null pointer");
   GMF_REQUIRE((mean == nullptr) == (rstd == nullptr) && (!mean || y), GMF_ERR_BAD_ARG, "colsum: mean and rstd come together, with y");
   GMF_REQUIRE(rows > 0 && C > 0 && L > 0 && rows % L == 0, GMF_ERR_UNSUPPORTED_SHAPE, "colsum: rows must be a positive multiple of L");
   GMF_REQUIRE(shift >= -1 && shift <= 1, GMF_ERR_BAD_ARG, "colsum: shift must be -1, 0 or 1");
   SetDevice sd(h);
-  const size_t n_part = (size_t)gmf::colsum_chunks((long)rows) * C;
+  GMF_REQUIRE(!dual || y, GMF_ERR_BAD_ARG, "colsum: dual needs y (without y both sums are the same)");
+  const size_t n_part = (size_t)gmf::colsum_chunks((long)rows) * C * (dual ? 2 : 1);
   if (int rc = arena_reserve(h, arena_need(n_part, 4))) return rc;
   float* part = arena_take<float>(h, n_part);
   GMF_REQUIRE(!center_x || cmean, GMF_ERR_BAD_ARG, "colsum: center_x needs cmean");
-  GMF_HIP(gmf::launch_colsum(x, y, mean, rstd, cmean, crstd, center_x ? 1 : 0, shift, L, (long)rows, C, part, out, S(stream)));
+  GMF_HIP(gmf::launch_colsum(x, y, mean, rstd, cmean, crstd, center_x ? 1 : 0, shift, L, (long)rows, C, part, out, S(stream), relu_y,
+                             dual != 0));
   return GMF_OK;
 }
 
@@ -112,20 +115,13 @@ int gmf_batchnorm_train_backward(gmf_handle* h, const float* dy, const float* x,
   GMF_REQUIRE(h && dy && x && mean && rstd && gamma && dx && dgamma && dbeta, GMF_ERR_BAD_ARG, "batchnorm_train_backward: null pointer");
   GMF_REQUIRE(rows > 1 && C > 0, GMF_ERR_UNSUPPORTED_SHAPE, "batchnorm_train_backward: need more than one row");
   SetDevice sd(h);
-  const size_t n_part = (size_t)gmf::colsum_chunks((long)rows) * C;
-  const size_t n_el = (size_t)rows * C;
-  if (int rc = arena_reserve(h, arena_need(n_part, 4) + (y_relu ? arena_need(n_el, 4) : 0))) return rc;
+  const size_t n_part = (size_t)gmf::colsum_chunks((long)rows) * C * 2;
+  if (int rc = arena_reserve(h, arena_need(n_part, 4))) return rc;
   float* part = arena_take<float>(h, n_part);
   hipStream_t st = S(stream);
-  const float* g = dy;
-  if (y_relu) {                                   // the ReLU that followed the BatchNorm: mask the incoming gradient by its output
-    float* gm = arena_take<float>(h, n_el);
-    GMF_HIP(gmf::launch_relu_bwd(dy, y_relu, gm, (long)n_el, st));
-    g = gm;
-  }
-  GMF_HIP(gmf::launch_colsum(g, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, (int)rows, (long)rows, C, part, dbeta, st));
-  GMF_HIP(gmf::launch_colsum(g, x, nullptr, nullptr, mean, rstd, 0, 0, (int)rows, (long)rows, C, part, dgamma, st));
-  GMF_HIP(gmf::launch_bn_bwd(g, x, mean, rstd, gamma, dbeta, dgamma, dx, (long)rows, C, st));
+  // ONE pass over dy: dgamma = sum g xhat, dbeta = sum g, with g = dy masked by the output of the ReLU that followed
+  GMF_HIP(gmf::launch_colsum(dy, x, nullptr, nullptr, mean, rstd, 0, 0, (int)rows, (long)rows, C, part, dgamma, st, y_relu, true, dbeta));
+  GMF_HIP(gmf::launch_bn_bwd(dy, x, mean, rstd, gamma, dbeta, dgamma, dx, (long)rows, C, st, y_relu));
   return GMF_OK;
 }
 

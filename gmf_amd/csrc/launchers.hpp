@@ -130,13 +130,14 @@ hipError_t launch_softmax(bool backward, const float* a, const float* b, const f
 hipError_t launch_geglu(bool backward, const float* hdn, const float* dg, float* out, long rows, int H, hipStream_t s);
 int colsum_chunks(long rows);
 hipError_t launch_colsum(const float* x, const float* y, const float* mean, const float* rstd, const float* cmean, const float* crstd,
-                         int center_x, int shift, int L, long rows, int C, float* part, float* out, hipStream_t s);
+                         int center_x, int shift, int L, long rows, int C, float* part, float* out, hipStream_t s,
+                         const float* relu_y = nullptr, bool dual = false, float* out2 = nullptr);
 hipError_t launch_bn_finish(const float* sum, const float* sumsq, float* mean, float* rstd, float* run_mean, float* run_var, int C,
                             long rows, float eps, float momentum, hipStream_t s);
 hipError_t launch_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* y,
                            long rows, int C, int relu, hipStream_t s);
 hipError_t launch_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* sdy,
-                         const float* sdyx, float* dx, long rows, int C, hipStream_t s);
+                         const float* sdyx, float* dx, long rows, int C, hipStream_t s, const float* relu_y = nullptr);
 hipError_t launch_relu_bwd(const float* dy, const float* y, float* out, long total, hipStream_t s);
 hipError_t launch_bce_bwd(const float* pred, const float* gt, const float* weight, float* dpred, float* pw_scratch, int balanced,
                           long total, hipStream_t s);

@@ -522,20 +522,27 @@ k_geglu_bwd(const float* __restrict__ hdn, const float* __restrict__ dg, float* 
 __global__ void __launch_bounds__(256)
 k_colsum_partial(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ mean,
                  const float* __restrict__ rstd, const float* __restrict__ cmean, const float* __restrict__ crstd, int center_x,
-                 int shift, int L, long rows, int C, int rows_per_chunk, float* __restrict__ part) {
+                 int shift, int L, long rows, int C, int rows_per_chunk, float* __restrict__ part,
+                 const float* __restrict__ relu_y, int dual) {
+  // relu_y: x is masked by the saved output of a ReLU (x' = x where relu_y > 0, else 0: the gradient entering a fused
+  // Linear / BatchNorm + ReLU).  dual: the plain column sums of x' are produced too, as columns C .. 2C - 1 of the
+  // partial rows (which are then 2C wide): sum x' y' and sum x' in ONE pass over x (a LayerNorm's dgamma / dbeta, a
+  // BatchNorm's, an LCPE tap with its bias).
   // cmean / crstd (per COLUMN: BatchNorm's statistics): y' = (y - cmean[c]) * crstd[c]; center_x: x' = x - cmean[c]
   // block: 4 waves; lane = column within the 64-column block blockIdx.y, wave w takes rows r0 + w, r0 + w + 4, ...;
   // the four wave sums are added in wave order through LDS
-  __shared__ float red[4][64];
+  __shared__ float red[2][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + lane;
   const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + (long)rows_per_chunk);
-  float s = 0.f;
+  float s = 0.f, s1 = 0.f;
   if (c < C) {
     const float cm = cmean ? cmean[c] : 0.f, cr = crstd ? crstd[c] : 1.f;
     for (long r = r0 + wave; r < r1; r += 4) {
       float v = x[r * C + c];
+      if (relu_y && !(relu_y[r * C + c] > 0.f)) v = 0.f;
       if (center_x) v -= cm;
+      s1 += v;
       if (y) {
         const int l = (int)(r % L) + shift;
         if (l < 0 || l >= L) continue;
@@ -548,20 +555,28 @@ k_colsum_partial(const float* __restrict__ x, const float* __restrict__ y, const
       s += v;
     }
   }
-  red[wave][lane] = s;
+  red[0][wave][lane] = s;
+  red[1][wave][lane] = s1;
   __syncthreads();
-  if (wave == 0 && c < C) part[(size_t)blockIdx.x * C + c] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  const int Cw = dual ? 2 * C : C;
+  if (wave == 0 && c < C) part[(size_t)blockIdx.x * Cw + c] = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
+  if (dual && wave == 1 && c < C)
+    part[(size_t)blockIdx.x * Cw + C + c] = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
 }
 
 // one wave per column: lane l adds chunks l, l + 64, ... in order, then a fixed butterfly over the lanes (deterministic)
 __global__ void __launch_bounds__(256)
-k_colsum_final(const float* __restrict__ part, int chunks, int C, float* __restrict__ out) {
+k_colsum_final(const float* __restrict__ part, int chunks, int C, float* __restrict__ out, float* __restrict__ out2, int c_split) {
+  // columns c_split .. C - 1 go to out2 (the plain sums of a dual pass) when it is given
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   float s = 0.f;
   for (int k = lane; k < chunks; k += 64) s += part[(size_t)k * C + c];
   s = wave_sum_f(s);
-  if (lane == 0) out[c] = s;
+  if (lane == 0) {
+    if (out2 && c >= c_split) out2[c - c_split] = s;
+    else out[c] = s;
+  }
 }
 
 // =========================================================================================
@@ -612,12 +627,13 @@ k_bn_apply(const float* __restrict__ x, const float* __restrict__ mean, const fl
 __global__ void __launch_bounds__(256)
 k_bn_bwd(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
          const float* __restrict__ gamma, const float* __restrict__ sdy, const float* __restrict__ sdyx, float* __restrict__ dx, int C,
-         float inv_rows, long total) {
+         float inv_rows, long total, const float* __restrict__ relu_y) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int c = (int)(idx % C);
   const float xh = (x[idx] - mean[c]) * rstd[c];
-  dx[idx] = gamma[c] * rstd[c] * (dy[idx] - sdy[c] * inv_rows - xh * sdyx[c] * inv_rows);
+  const float g = (relu_y && !(relu_y[idx] > 0.f)) ? 0.f : dy[idx];      // the ReLU that followed the BatchNorm
+  dx[idx] = gamma[c] * rstd[c] * (g - sdy[c] * inv_rows - xh * sdyx[c] * inv_rows);
 }
 
 // mean[c] = s[c] / rows ; rstd[c] = rsqrt(ss[c] / rows + eps) ; running statistics as torch updates them (momentum, unbiased var)
@@ -837,13 +853,15 @@ hipError_t launch_geglu(bool backward, const float* hdn, const float* dg, float*
 int colsum_chunks(long rows) { return (int)std::max<long>(1, std::min<long>(1024, (rows + 63) / 64)); }
 
 hipError_t launch_colsum(const float* x, const float* y, const float* mean, const float* rstd, const float* cmean, const float* crstd,
-                         int center_x, int shift, int L, long rows, int C, float* part, float* out, hipStream_t s) {
+                         int center_x, int shift, int L, long rows, int C, float* part, float* out, hipStream_t s,
+                         const float* relu_y, bool dual, float* out2) {
   const int chunks = colsum_chunks(rows);
   const int rpc = (int)((rows + chunks - 1) / chunks);
   const int used = (int)((rows + rpc - 1) / rpc);
   hipLaunchKernelGGL(k_colsum_partial, dim3(used, (C + 63) / 64), dim3(256), 0, s, x, y, mean, rstd, cmean, crstd, center_x, shift, L,
-                     rows, C, rpc, part);
-  hipLaunchKernelGGL(k_colsum_final, dim3((C + 3) / 4), dim3(256), 0, s, part, used, C, out);
+                     rows, C, rpc, part, relu_y, dual ? 1 : 0);
+  const int Cw = dual ? 2 * C : C;                  // out: [sum x' y' (C) | sum x' (C)] when dual
+  hipLaunchKernelGGL(k_colsum_final, dim3((Cw + 3) / 4), dim3(256), 0, s, part, used, Cw, out, dual ? out2 : (float*)nullptr, C);
   return hipGetLastError();
 }
 
@@ -862,9 +880,10 @@ hipError_t launch_bn_apply(const float* x, const float* mean, const float* rstd,
 }
 
 hipError_t launch_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* sdy,
-                         const float* sdyx, float* dx, long rows, int C, hipStream_t s) {
+                         const float* sdyx, float* dx, long rows, int C, hipStream_t s, const float* relu_y) {
   const long total = rows * C;
-  hipLaunchKernelGGL(k_bn_bwd, dim3(blocks_of(total)), dim3(256), 0, s, dy, x, mean, rstd, gamma, sdy, sdyx, dx, C, 1.0f / (float)rows, total);
+  hipLaunchKernelGGL(k_bn_bwd, dim3(blocks_of(total)), dim3(256), 0, s, dy, x, mean, rstd, gamma, sdy, sdyx, dx, C, 1.0f / (float)rows, total,
+                     relu_y);
   return hipGetLastError();
 }
 

@@ -37,15 +37,16 @@ def gemm(a, b, ta=False, tb=False, bias=None, residual=None, alpha=1.0, out=None
     return out
 
 
-def colsum(x, y=None, mean=None, rstd=None, shift=0, L=None):
-    """[rows, C] -> [C]: sum_r x[r] * y'[r + shift] (see gmf_colsum)."""
+def colsum(x, y=None, mean=None, rstd=None, shift=0, L=None, dual=False, relu_y=None):
+    """[rows, C] -> [C]: sum_r x[r] * y'[r + shift] (see gmf_colsum).  dual: ([C] that sum, [C] the plain column sums of x)
+    from ONE pass; relu_y: x is masked by the saved output of a ReLU first."""
     rows, C = x.shape
-    out = torch.empty(C, device=x.device, dtype=torch.float32)
+    out = torch.empty(2 * C if dual else C, device=x.device, dtype=torch.float32)
     h, st = handle_and_stream(x)
     h.call("gmf_colsum", x.data_ptr(), None if y is None else y.data_ptr(), None if mean is None else mean.data_ptr(),
            None if rstd is None else rstd.data_ptr(), None, None, 0, int(shift), int(L if L is not None else rows), rows, C,
-           out.data_ptr(), st)
-    return out
+           None if relu_y is None else relu_y.data_ptr(), 1 if dual else 0, out.data_ptr(), st)
+    return (out[:C], out[C:]) if dual else out
 
 
 def layernorm_fwd(x, gamma, beta):
@@ -173,8 +174,7 @@ class _FusionLayerTrain(torch.autograd.Function):
         dW1 = gemm(dhd, xn2, ta=True)                               # [2 H, lat]
         db1 = colsum(dhd)
         dxn2 = gemm(dhd, W1)                                        # [BN, lat]
-        dg2 = colsum(dxn2, y=x1, mean=mu2, rstd=rs2)
-        dbn2 = colsum(dxn2)
+        dg2, dbn2 = colsum(dxn2, y=x1, mean=mu2, rstd=rs2, dual=True)
         dx1 = layernorm_bwd(dxn2, x1, g2, mu2, rs2, dx_add=d2)
         # ---- cross-attention (fusion_layer.py:71-94,190) ----
         dWo = gemm(dx1, a, ta=True)                                 # [lat, dh]
@@ -192,20 +192,20 @@ class _FusionLayerTrain(torch.autograd.Function):
         dxn = gemm(dq, Wq)                                          # [BN, lat]
         dWkv = gemm(dkv, cn, ta=True)                               # [2 dh, dim]
         dcn = gemm(dkv, Wkv)                                        # [BT, dim]
-        dg1 = colsum(dxn, y=xp, mean=mu1, rstd=rs1)
-        dbn1 = colsum(dxn)
+        dg1, dbn1 = colsum(dxn, y=xp, mean=mu1, rstd=rs1, dual=True)
         dxp = layernorm_bwd(dxn, xp, g1, mu1, rs1, dx_add=dx1)
-        dgc = colsum(dcn, y=cp, mean=muc, rstd=rsc)
-        dbnc = colsum(dcn)
+        dgc, dbnc = colsum(dcn, y=cp, mean=muc, rstd=rsc, dual=True)
         dcp = layernorm_bwd(dcn, cp, gc, muc, rsc)
         grads = []
         if pe:
             # ---- LCPE (fusion_layer.py:118-128) ----
             dx = lcpe_bwd(dxp, wq_t, N)
             dc = lcpe_bwd(dcp, wc_t, T)
-            dwq = torch.stack([colsum(dxp, y=x2, shift=s, L=N) for s in (-1, 0, 1)], dim=1).reshape(wq_t.shape)
-            dwc = torch.stack([colsum(dcp, y=c2, shift=s, L=T) for s in (-1, 0, 1)], dim=1).reshape(wc_t.shape)
-            grads += [dwq, colsum(dxp), dwc, colsum(dcp)]
+            tq0, dbq = colsum(dxp, y=x2, shift=0, L=N, dual=True)        # the centre tap and the bias from one pass
+            tc0, dbc = colsum(dcp, y=c2, shift=0, L=T, dual=True)
+            dwq = torch.stack([colsum(dxp, y=x2, shift=-1, L=N), tq0, colsum(dxp, y=x2, shift=1, L=N)], dim=1).reshape(wq_t.shape)
+            dwc = torch.stack([colsum(dcp, y=c2, shift=-1, L=T), tc0, colsum(dcp, y=c2, shift=1, L=T)], dim=1).reshape(wc_t.shape)
+            grads += [dwq, dbq, dwc, dbc]
         else:
             dx, dc = dxp, dcp
         grads += [dg1, dbn1, dgc, dbnc, dWq, dWkv, dWo, dbo, dg2, dbn2, dW1, db1, dW2, db2]

@@ -330,9 +330,12 @@ int gmf_geglu(gmf_handle* h, int backward, const float* hdn, const float* dg, fl
               gmf_stream_t stream);
 /* out[c] = sum over rows r of x'[r][c] * y'[r + shift][c] with y' = 1 (y NULL), y, (y - mean[r]) * rstd[r] (LayerNorm's xhat)
  * or (y - cmean[c]) * crstd[c] (BatchNorm's; crstd NULL = 1), x' = x or x - cmean[c] (center_x); rows r + shift outside r's
- * sequence of L rows contribute 0.  Bias, LayerNorm / BatchNorm parameter and LCPE-tap gradients, BatchNorm statistics. */
+ * sequence of L rows contribute 0.  Bias, LayerNorm / BatchNorm parameter and LCPE-tap gradients, BatchNorm statistics.
+ * relu_y (optional): x is first masked by the saved output of a ReLU (x where relu_y > 0, else 0).  dual != 0 (needs y): out
+ * holds 2C values, [sum x' y' | sum x'] - a normalisation's dgamma and dbeta, or an LCPE tap and its bias, in one pass. */
 int gmf_colsum(gmf_handle* h, const float* x, const float* y, const float* mean, const float* rstd, const float* cmean,
-               const float* crstd, int center_x, int shift, int L, long long rows, int C, float* out, gmf_stream_t stream);
+               const float* crstd, int center_x, int shift, int L, long long rows, int C, const float* relu_y, int dual, float* out,
+               gmf_stream_t stream);
 /* nn.BatchNorm1d in TRAINING mode over the rows of x [rows, C] (= BatchNorm1d on [B, C, N]): batch statistics (mean / rstd [C]
  * returned for the backward), running statistics updated as torch does (momentum, unbiased variance; may be NULL), optional
  * fused ReLU.  Backward: dx, dgamma, dbeta; y_relu (the saved output) masks dy when the forward applied the ReLU, else NULL. */

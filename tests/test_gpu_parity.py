@@ -1344,6 +1344,27 @@ def test_training_primitives_against_torch():
     X, Y = rn(20000, 96), rn(20000, 160)                       # K = 20000 rows: split-K
     ref = (X.double().t() @ Y.double()).float()
     assert _maxerr(T_.gemm(X, Y, ta=True).cpu(), ref.cpu()) < 2e-5 * float(ref.abs().max())
+    # 16-byte friendly sizes take the LDS-staged kernel (k_gemm_lds): ragged tiles (260 = 2 x 128 + 4 rows, 132 columns), a
+    # contraction that is not a multiple of the 16-deep k-step, all four transpose forms, bias + residual + ReLU, a batch
+    A2, B2 = rn(260, 200), rn(200, 132)
+    ref2 = (A2.double() @ B2.double()).float()
+    tol2 = 2e-5 * float(ref2.abs().max())
+    assert _maxerr(T_.gemm(A2, B2).cpu(), ref2.cpu()) < tol2
+    assert _maxerr(T_.gemm(A2.t().contiguous(), B2, ta=True).cpu(), ref2.cpu()) < tol2
+    assert _maxerr(T_.gemm(A2, B2.t().contiguous(), tb=True).cpu(), ref2.cpu()) < tol2
+    assert _maxerr(T_.gemm(A2.t().contiguous(), B2.t().contiguous(), ta=True, tb=True).cpu(), ref2.cpu()) < tol2
+    bias2, R2 = rn(132), rn(260, 132)
+    assert _maxerr(T_.gemm(A2, B2, bias=bias2, residual=R2, relu=True).cpu(), torch.relu(ref2 + bias2 + R2).cpu()) < tol2
+    A3, B3 = rn(5, 300, 64), rn(5, 264, 64)                    # batched Q K^T shape
+    out3 = torch.empty(5, 300, 264, device=DEV)
+    T_.gemm(A3, B3, tb=True, out=out3, m=300, n=264, k=64, lda=64, ldb=64, ldc=264, batch=5, sa=300 * 64, sb=264 * 64, sc=300 * 264)
+    assert _maxerr(out3.cpu(), torch.matmul(A3, B3.transpose(1, 2)).cpu()) < 1e-4
+    P3 = rn(3, 1000, 1000)                                     # long contraction with few tiles: split-K through the LDS kernel
+    V3 = rn(3, 1000, 128)
+    out4 = torch.empty(3, 1000, 128, device=DEV)
+    T_.gemm(P3, V3, out=out4, m=1000, n=128, k=1000, lda=1000, ldb=128, ldc=128, batch=3, sa=10 ** 6, sb=128000, sc=128000)
+    ref4 = torch.matmul(P3.double(), V3.double()).float()
+    assert _maxerr(out4.cpu(), ref4.cpu()) < 2e-5 * float(ref4.abs().max())
     x = rn(3 * 37, 64)
     w, b = rn(64, 1, 3), rn(64)
     ref = torch.nn.functional.conv1d(x.reshape(3, 37, 64).permute(0, 2, 1), w, b, padding=1, groups=64).permute(0, 2, 1) + x.reshape(3, 37, 64)
@@ -1359,6 +1380,14 @@ def test_training_primitives_against_torch():
     xs = x.reshape(3, 37, 64)
     ref = (xs[:, 1:] * xs[:, :-1]).sum((0, 1))               # sum_l x[l] * x[l - 1] within each sequence
     assert _maxerr(T_.colsum(x, y=x, shift=-1, L=37).cpu(), ref.cpu()) < 1e-4
+    # one pass, two sums (a LayerNorm's dgamma / dbeta), with the gradient masked by a ReLU output
+    yr = rn(111, 64)
+    prod, plain = T_.colsum(x, y=y, mean=None, rstd=None, dual=True, relu_y=yr)
+    xm = x * (yr > 0)
+    assert _maxerr(prod.cpu(), (xm * y).sum(0).cpu()) < 1e-4 and _maxerr(plain.cpu(), xm.sum(0).cpu()) < 1e-4
+    xh = (x - mu[:, None]) * rs[:, None]
+    dg, db = T_.colsum(y, y=x, mean=mu, rstd=rs, dual=True)
+    assert _maxerr(dg.cpu(), (y * xh).sum(0).cpu()) < 1e-4 and _maxerr(db.cpu(), y.sum(0).cpu()) < 1e-4
 
 
 def test_sm_loss_backward_full_size():

@@ -58,6 +58,8 @@ class ShardedBatchDriver:
         self.last_gather_ms: Optional[float] = None     # ... of pack + all-gather + unpack
         self.time_steps = False                         # record the two figures above (adds event records, no host sync)
         self._events = None
+        # a gloo group with the model on a HIP device (a multi-process rehearsal on one GPU): collectives go through the host
+        self.stage_host = False
         if world > 1 or always_collective:
             if not dist.is_initialized():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -65,8 +67,11 @@ class ShardedBatchDriver:
                 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL's peer buffers
                 backend = backend or ("nccl" if device.type == "cuda" else "gloo")
                 kw = {"device_id": device} if device.type == "cuda" else {}
+                if backend == "gloo":
+                    kw = {}
                 dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
                 self.own_pg = True
+            self.stage_host = device.type == "cuda" and dist.get_backend() == "gloo"
 
     # -- timing helpers (no host synchronisation inside step) -------------------------------------------------
     def _mark(self, i: int):
@@ -116,8 +121,13 @@ class ShardedBatchDriver:
                 torch.empty((bmax, n + 16), device=logits.device, dtype=logits.dtype)
             buf[:b, :n] = logits
             buf[:b, n:] = trans.reshape(b, 16)
-            gathered = torch.empty((self.world * bmax, n + 16), device=logits.device, dtype=logits.dtype)
-            dist.all_gather_into_tensor(gathered, buf)           # the ONE exchange step of the batch
+            if self.stage_host:
+                g_host = torch.empty((self.world * bmax, n + 16), dtype=logits.dtype)
+                dist.all_gather_into_tensor(g_host, buf.cpu())
+                gathered = g_host.to(logits.device)
+            else:
+                gathered = torch.empty((self.world * bmax, n + 16), device=logits.device, dtype=logits.dtype)
+                dist.all_gather_into_tensor(gathered, buf)       # the ONE exchange step of the batch
             if min(sizes) != bmax:
                 gathered = torch.cat([gathered[r * bmax:r * bmax + sizes[r]] for r in range(self.world)])
             out["all_logits"] = gathered[:, :n]
@@ -139,7 +149,7 @@ class ShardedBatchDriver:
     def max_over_ranks(self, seconds: float) -> float:
         if self.world == 1:
             return seconds
-        t = torch.tensor([seconds], dtype=torch.float64, device=self.device)
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if self.stage_host else self.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -147,8 +157,9 @@ class ShardedBatchDriver:
         """One float from every rank (diagnostics: per-rank step times)."""
         if self.world == 1:
             return [value]
-        t = torch.tensor([value], dtype=torch.float64, device=self.device)
-        allv = torch.empty(self.world, dtype=torch.float64, device=self.device)
+        dev = "cpu" if self.stage_host else self.device
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        allv = torch.empty(self.world, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(allv, t)
         return [float(v) for v in allv.cpu()]
 

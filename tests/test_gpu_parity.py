@@ -944,6 +944,61 @@ def test_sharded_driver_one_rank_rccl(model):
         drv.close()
 
 
+def _two_rank_worker(rank, world, port, q):
+    """One of two processes sharing GPU 0: the real PointDSC on its shard of a 5-pair batch, gloo gather through the host."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch as _t
+    import gmf_amd as _g
+    from gmf_amd import synthetic as _s
+    from gmf_amd.dist import ShardedBatchDriver
+    dev = _t.device("cuda:0")
+    m = _g.PointDSC(num_layers=12)
+    m.load_state_dict(_s.seeded_state_dict(_s.pointdsc_shapes(6, 12, 128), seed=7), strict=False)
+    m = m.to(dev).eval()
+    b = _s.synthetic_batch([11, 12, 13, 14, 15], N=257, T=40)
+    data = {k: b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    drv = ShardedBatchDriver(m, world, rank, dev, backend="gloo")
+    out = drv.run(data)                                   # 3 + 2 pairs: padded inside the one packed buffer
+    drv.barrier()
+    t = drv.max_over_ranks(float(rank + 1))
+    q.put((rank, out["all_logits"].cpu(), out["all_trans"].cpu(), out["logits"].shape[0], t))
+    drv.close()
+
+
+def test_two_process_sharded_forward_on_one_gpu(model):
+    """The N > 1 step rehearsed on the one GPU there is: TWO processes, each with its own library handle and the real PointDSC
+    on its shard (3 + 2 pairs of a 5-pair batch), exchanging the packed logits | poses with one collective (gloo through the
+    host here - the RCCL form of the same call runs in test_sharded_driver_one_rank_rccl).  Every rank ends with all five
+    pairs, equal to the single-process forward of the whole batch (5e-5: the shard sizes take different small-grid splits)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, 29763, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    b = synthetic.synthetic_batch([11, 12, 13, 14, 15], N=257, T=40)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    ref = model(data)
+    ref_logits, ref_T = model.last_logits.cpu(), ref["final_trans"].cpu()
+    sizes = {}
+    for rank, all_logits, all_trans, local_b, t in got:
+        sizes[rank] = local_b
+        assert all_logits.shape == (5, 257) and all_trans.shape == (5, 4, 4)
+        assert _maxerr(all_logits, ref_logits) < 5e-5
+        assert _maxerr(all_trans, ref_T) < 1e-4
+        assert t == 2.0
+    assert sizes == {0: 3, 1: 2}
+    assert torch.equal(got[0][1], got[1][1]) and torch.equal(got[0][2], got[1][2])      # both ranks hold the same gathered result
+
+
 def _f16_cases(g):
     return [(int(n), int(s)) for n, s in g["cases"]]
 

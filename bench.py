@@ -120,6 +120,10 @@ def main():
     ap.add_argument("--kind", default="3dmatch", choices=["3dmatch", "kitti"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="append N = 1000 / 10000, KITTI-shape and B = 1 results (rank 0, N = 1 GPU)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="N > 1 ranks on a box with fewer GPUs: ranks share the devices (local_rank %% device_count) and exchange "
+                         "through gloo staged over the host.  Exercises the launch line, the sharded step and the JSON line; the "
+                         "numbers are NOT a measurement (the line says so)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,15 +135,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the HIP path is mandatory, there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if args.rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from gmf_amd import _lib
     from gmf_amd.dist import ShardedBatchDriver
 
     B, N, T = args.pairs, args.ncorr, args.tokens
     model, sd, tau = build_model(dev, args.kind)
-    driver = ShardedBatchDriver(model, world, rank, dev)
+    driver = ShardedBatchDriver(model, world, rank, dev, backend="gloo" if args.rehearsal else None)
     seeds = [rank * B + i for i in range(B)]                 # every rank owns its own pairs (weak scaling)
     batch, data = make_batch(dev, seeds, N, T, args.kind)
     torch.cuda.synchronize()
@@ -148,7 +153,7 @@ def main():
         out = driver.step(data)
     torch.cuda.synchronize()
 
-    handle = _lib.handle_for(local_rank)
+    handle = _lib.handle_for(dev_index)
     handle.call("gmf_profile_enable", 1)
     driver.barrier()
     torch.cuda.synchronize()
@@ -216,6 +221,8 @@ def main():
                   "note": "outside the timed region: one extra step with HIP events around the forward and around pack + all-gather"},
         "csrc_sha16": sha,
     }
+    if args.rehearsal:
+        line["rehearsal"] = "ranks share the GPU(s) and exchange through gloo over the host: NOT a measurement"
     if args.sweep and world == 1:
         line["sweep"] = sweep(dev)
     if world == 1 and not args.no_cpu_baseline:

@@ -584,7 +584,7 @@ int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, 
   const size_t BS = (size_t)B * Sn;
   const size_t need = arena_need((size_t)B * N, 4) + arena_need(BS, 4) + arena_need(BS * k, 4) +
                       arena_need(BS * iters * k, 4) + arena_need(BS * iters, 1) + arena_need(BS * 16, 4) +
-                      arena_need(BS, 4) + arena_need(BS, 4) + arena_need(B, 4) + arena_need(BS * 15, 8) +
+                      arena_need(BS, 4) + arena_need(BS, 4) + arena_need(B, 4) + arena_need(BS * 15, 8) + arena_need(1, 4) +
                       arena_need((size_t)B * tiles_of(N) * kTileFloats, 4) + arena_need(BS * N, 4);
   if (int rc = arena_reserve(h, need)) return rc;
   float* fimg = arena_take<float>(h, (size_t)B * tiles_of(N) * kTileFloats);
@@ -599,6 +599,7 @@ int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, 
   float* fit = arena_take<float>(h, BS);
   int* best = arena_take<int>(h, B);
   double* hsum = arena_take<double>(h, BS * 15);
+  int* stop_it = arena_take<int>(h, 1);
   if (seeds_out) seeds = seeds_out;
   if (knn_out) knn = knn_out;
   if (seed_trans) sT = seed_trans;
@@ -623,7 +624,7 @@ int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, 
   GMF_HIP(gmf::launch_seed_dist(fimg, seeds_use, dmat, B, N, Sn, st));
   GMF_HIP(gmf::launch_knn_seeds(feat_n, seeds_use, dmat, knn, B, N, Sn, k, st));
   GMF_HIP(gmf::launch_seed_power(fimg, src_keypts, tgt_keypts, knn, snaps, conv, hsum, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));
-  GMF_HIP(gmf::launch_seed_kabsch(src_keypts, tgt_keypts, knn, snaps, conv, sT, B, N, Sn, k, iters, hsum, st));
+  GMF_HIP(gmf::launch_seed_kabsch(src_keypts, tgt_keypts, knn, snaps, conv, sT, B, N, Sn, k, iters, hsum, stop_it, st));
   GMF_HIP(gmf::launch_score_hyp(src_keypts, tgt_keypts, sT, counts, B, N, Sn, p->inlier_threshold, st));
   GMF_HIP(gmf::launch_finalize_pose(src_keypts, tgt_keypts, sT, counts, fit, final_trans, final_labels, best, B, N, Sn,
                                     p->inlier_threshold, p->refine_threshold, p->refine_iters, st));

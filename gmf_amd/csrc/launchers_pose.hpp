@@ -19,7 +19,9 @@ hipError_t launch_seed_power(const float* featn_img, const float* src, const flo
                              float sigma_d, hipStream_t s);
 hipError_t launch_seed_kabsch(const float* src, const float* tgt, const int* knn_idx, const float* snaps,
                               const unsigned char* conv, float* seed_T, int B, int N, int S, int k, int iters,
-                              const double* hsum, hipStream_t s);
+                              const double* hsum, int* stop_scratch, hipStream_t s);   // stop_scratch: 1 int (batches: the
+                                                                                       // batch-wide stop iteration lands there)
+hipError_t launch_stop_iteration(const unsigned char* conv, int B, int S, int iters, int* stop_out, hipStream_t s);
 hipError_t launch_score_hyp(const float* src, const float* tgt, const float* seed_T, int* counts, int B, int N, int S,
                             float tau, hipStream_t s);
 hipError_t launch_finalize_pose(const float* src, const float* tgt, const float* seed_T, const int* counts, float* fitness,
@@ -41,7 +43,7 @@ hipError_t launch_tl_backward(const float* trans, const float* src, const float*
 hipError_t launch_pose_best_backward(const float* feat_n, const float* src, const float* tgt, const int* knn_idx,
                                      const float* fitness, const float* snaps, const unsigned char* conv, const float* g_T,
                                      float* g_feat, float* g_sigma, int B, int N, int S, int k, int iters, float sigma,
-                                     float sigma_d, hipStream_t s);
+                                     float sigma_d, const int* stop_batch, hipStream_t s);
 hipError_t launch_wp_backward(const float* X, const float* Y, const float* w, const int* offsets, int B, float eps,
                               const float* g_R, const float* g_t, float* g_w, hipStream_t s);
 

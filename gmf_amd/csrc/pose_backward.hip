@@ -110,7 +110,8 @@ __global__ void __launch_bounds__(64)
 k_pose_best_backward(const float* __restrict__ feat_n, const float* __restrict__ src, const float* __restrict__ tgt,
                      const int* __restrict__ knn_idx, const float* __restrict__ fitness, const float* __restrict__ snaps,
                      const unsigned char* __restrict__ conv, const float* __restrict__ g_T, float* __restrict__ g_feat,
-                     float* __restrict__ g_sigma, int N, int S, int k, int iters, float sigma, float inv_sigmad2) {
+                     float* __restrict__ g_sigma, int N, int S, int k, int iters, float sigma, float inv_sigmad2,
+                     const int* __restrict__ stop_batch) {
   extern __shared__ float dyn[];
   float* const F = dyn;                              // [64][129]
   float* const Cx = F + kKMax * (kCF + 1);           // [64][65]
@@ -136,7 +137,9 @@ k_pose_best_backward(const float* __restrict__ feat_n, const float* __restrict__
     best = bi;
   }
   int stop_it = iters - 1;
-  {
+  if (stop_batch) {                                  // batches: the stop iteration of the whole batch (k_stop_iteration)
+    stop_it = *stop_batch;
+  } else {
     const unsigned char* cv = conv + (size_t)pair * S * iters;
     for (int it = 0; it < iters - 1; ++it) {
       bool ok = true;
@@ -387,13 +390,13 @@ hipError_t launch_tl_backward(const float* trans, const float* src, const float*
 hipError_t launch_pose_best_backward(const float* feat_n, const float* src, const float* tgt, const int* knn_idx,
                                      const float* fitness, const float* snaps, const unsigned char* conv, const float* g_T,
                                      float* g_feat, float* g_sigma, int B, int N, int S, int k, int iters, float sigma,
-                                     float sigma_d, hipStream_t s) {
+                                     float sigma_d, const int* stop_batch, hipStream_t s) {
   const size_t lds = ((size_t)kKMax * (kCF + 1) + (size_t)kKMax * (kKMax + 1) + (size_t)(iters + 1) * kKMax + kKMax) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_best_backward),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_pose_best_backward, dim3(B), dim3(64), lds, s, feat_n, src, tgt, knn_idx, fitness, snaps, conv, g_T,
-                     g_feat, g_sigma, N, S, k, iters, sigma, 1.0f / (sigma_d * sigma_d));
+                     g_feat, g_sigma, N, S, k, iters, sigma, 1.0f / (sigma_d * sigma_d), stop_batch);
   return hipGetLastError();
 }
 

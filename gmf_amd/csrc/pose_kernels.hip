@@ -728,16 +728,45 @@ k_seed_power(const float* __restrict__ featn_img, const float* __restrict__ src,
 // w = v/(sum v + 1e-6) (PointDSC.py:364-365) and solve the weighted Kabsch problem on the k neighbours.
 // One thread per seed.  grid (ceil(S/64), B), block 64.  seed_T [B,S,16]
 // ---------------------------------------------------------------------------------------
+// The iteration at which the reference's power iteration stops (PointDSC.py:444): the first at which EVERY seed of EVERY pair
+// of the batch passed allclose (the test is over the whole [bs * S, k] tensor), else the last.  One workgroup; only launched
+// for batches (for one pair k_seed_kabsch finds it itself).
+__global__ void __launch_bounds__(1024)
+k_stop_iteration(const unsigned char* __restrict__ conv, int total_seeds, int iters, int* __restrict__ stop_out) {
+  __shared__ unsigned long long red[16];
+  // bit `it` of the mask: this thread's seeds all passed at iteration `it`
+  unsigned long long mask = ~0ull;
+  for (int s = threadIdx.x; s < total_seeds; s += blockDim.x) {
+    unsigned long long m = 0;
+    for (int it = 0; it < iters; ++it) m |= (unsigned long long)(conv[(size_t)s * iters + it] != 0) << it;
+    mask &= m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mask &= __shfl_xor(mask, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mask;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mask &= red[w];
+    int first = iters - 1;
+    for (int it = 0; it < iters - 1; ++it)
+      if ((mask >> it) & 1ull) { first = it; break; }
+    *stop_out = first;
+  }
+}
+
 __global__ void __launch_bounds__(64)
 k_seed_kabsch(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ knn_idx,
               const float* __restrict__ snaps, const unsigned char* __restrict__ conv, float* __restrict__ seed_T,
-              int N, int S, int k, int iters, const double* __restrict__ hsum) {
+              int N, int S, int k, int iters, const double* __restrict__ hsum, const int* __restrict__ stop_batch) {
   __shared__ int stop_it;
   const int pair = blockIdx.y;
-  // global early exit: first iteration at which EVERY seed of the pair passed allclose (PointDSC.py:444)
+  // global early exit: first iteration at which EVERY seed passed allclose (PointDSC.py:444) - of the whole batch
+  // (stop_batch, from k_stop_iteration) or, for a single pair, found here
   if (threadIdx.x == 0) stop_it = iters - 1;
   __syncthreads();
-  {
+  if (stop_batch) {
+    if (threadIdx.x == 0) stop_it = *stop_batch;
+  } else {
     const unsigned char* cv = conv + (size_t)pair * S * iters;
     int first = iters - 1;
     for (int it = 0; it < iters - 1; ++it) {
@@ -1408,9 +1437,19 @@ hipError_t launch_seed_power(const float* featn_img, const float* src, const flo
 
 hipError_t launch_seed_kabsch(const float* src, const float* tgt, const int* knn_idx, const float* snaps,
                               const unsigned char* conv, float* seed_T, int B, int N, int S, int k, int iters,
-                              const double* hsum, hipStream_t s) {
+                              const double* hsum, int* stop_scratch, hipStream_t s) {
+  const int* stop_batch = nullptr;
+  if (B > 1 && stop_scratch) {          // the reference's allclose spans the batch
+    hipLaunchKernelGGL(k_stop_iteration, dim3(1), dim3(1024), 0, s, conv, B * S, iters, stop_scratch);
+    stop_batch = stop_scratch;
+  }
   hipLaunchKernelGGL(k_seed_kabsch, dim3((S + 63) / 64, B), dim3(64), 0, s, src, tgt, knn_idx, snaps, conv, seed_T, N, S, k, iters,
-                     hsum);
+                     hsum, stop_batch);
+  return hipGetLastError();
+}
+
+hipError_t launch_stop_iteration(const unsigned char* conv, int B, int S, int iters, int* stop_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_stop_iteration, dim3(1), dim3(1024), 0, s, conv, B * S, iters, stop_out);
   return hipGetLastError();
 }
 

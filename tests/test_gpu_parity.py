@@ -288,6 +288,38 @@ def test_throughput_precision_mode(model):
     assert torch.equal(model(small)["final_trans"], rs1)      # the small grid never left the parity numerics
 
 
+def test_power_iteration_exit_spans_the_batch(model):
+    """PointDSC.py:444 tests allclose over the whole [bs * S, k] tensor: in a batch, a pair whose seeds have all converged keeps
+    iterating until every pair has.  A fast-converging pair next to a slow one: the batch result matches the oracle run on the
+    batch (which has the reference's exit), and the fast pair's hypotheses differ - within the allclose tolerance, but not
+    bitwise - from what the same pair gives alone, where it stops early."""
+    gen = torch.Generator().manual_seed(91)
+    N = 200
+    src, tgt, feat = [], [], []
+    for early in (True, False):
+        s_ = torch.rand(N, 3, generator=gen) * 2
+        A = torch.linalg.qr(torch.randn(3, 3, generator=gen))[0]
+        A = A * torch.sign(torch.det(A))
+        t_ = s_ @ A.T + torch.tensor([0.3, -0.2, 0.1])
+        if not early:
+            t_[::3] += 0.5 * torch.randn((N + 2) // 3, 3, generator=gen)
+        u = torch.randn(1, 128, generator=gen)
+        feat.append(torch.nn.functional.normalize(u + (0.02 if early else 0.6) * torch.randn(N, 128, generator=gen), dim=-1))
+        src.append(s_); tgt.append(t_)
+    src, tgt, feat = torch.stack(src), torch.stack(tgt), torch.stack(feat)
+    logits = torch.randn(2, N, generator=gen)
+    sigma, sigma_d = float(model.sigma.detach()), float(model.sigma_spat)
+    _, _, aux = model.pose_head(_gpu(feat), _gpu(src), _gpu(tgt), _gpu(logits), testing=False, return_aux=True)
+    knn_idx = aux["knn_idx"].cpu().long()
+    w, sk, tk = O.seed_weights(feat, src, tgt, knn_idx, sigma, sigma_d, model.num_iterations)      # the exit spans both pairs
+    Ts = O.rigid_transform_3d(sk, tk, w).reshape(2, -1, 4, 4)
+    assert _maxerr(aux["seed_trans"].cpu(), Ts) < 1e-4
+    _, _, alone = model.pose_head(_gpu(feat[:1]), _gpu(src[:1]), _gpu(tgt[:1]), _gpu(logits[:1]), testing=False, return_aux=True)
+    assert torch.equal(alone["knn_idx"], aux["knn_idx"][:1])
+    d = (alone["seed_trans"] - aux["seed_trans"][:1]).abs().max()
+    assert 0.0 < float(d) < 1e-4, float(d)
+
+
 def test_f6_rigid_transform(golden_dir):
     g = _load(golden_dir, "f6_rigid_transform.npz")
     A, B, w = (_gpu(torch.from_numpy(g[k])) for k in ("A", "B", "w"))

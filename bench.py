@@ -112,8 +112,8 @@ def time_steps(driver, data, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=32, help="scene pairs per GPU per step")
     ap.add_argument("--ncorr", type=int, default=5000)
     ap.add_argument("--tokens", type=int, default=196)

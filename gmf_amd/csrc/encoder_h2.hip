@@ -659,7 +659,7 @@ int plan_ff_split(const Tuning& tune, int base, int max_parts) {
   int hs = 1;
   if (max_parts >= 2) {
     if (tune.ff_split > 0) hs = tune.ff_split;
-    else if (base < 256) hs = base <= 64 ? 8 : base <= 128 ? 4 : 2;
+    else if (base < 256) hs = base <= 32 ? 8 : base <= 64 ? 4 : 2;   // (measured at B = 1 .. 4: the merge reads every partial)
     hs = std::min(hs, max_parts);
     if (hs != 2 && hs != 4 && hs != 8) hs = 1;
   }

@@ -1,11 +1,10 @@
-"""Validation metrics of the PointDSC plugin surface (reference: GMF_PointDSC/libs/loss.py; caller
-libs/trainer.py:194-262, evaluate()).  Forward only: the three modules the reference's `evaluate_metric` dict holds,
-with its class names, constructor arguments, call signatures and return values, each one launch sequence of
-libgmf_hip.so over the C ABI.  Backward (the training half of SURVEY section 8 row f-4): the first slice is built -
-`SpectralMatchingLoss.from_features` is differentiable with respect to the unit features and the bandwidth sigma
-(`_SpectralMatchingFromFeatures`, one HIP launch for the whole N x N x 128 backward), and `ClassificationLoss(pred, gt)` /
-`SpectralMatchingLoss(M, gt)` carry their gradients when the logits / M require grad (the two losses the reference trains
-with by default); `TransformationLoss` is forward only and raises if an input requires grad."""
+"""The three loss / metric modules of the PointDSC plugin surface (reference: GMF_PointDSC/libs/loss.py; callers
+libs/trainer.py:131-143 - the training step - and :194-262, evaluate()): the reference's class names, constructor arguments,
+call signatures and return values, each one launch sequence of libgmf_hip.so over the C ABI.  All three carry their
+gradients: `ClassificationLoss(pred, gt)` with respect to the logits, `SpectralMatchingLoss(M, gt)`
+with respect to M (and `SpectralMatchingLoss.from_features` - the fused similarity matrix + loss, one launch each way - with
+respect to the unit features and sigma), `TransformationLoss` with respect to `trans`.  The per-element `weight` of
+ClassificationLoss is a constant and must not require grad."""
 from __future__ import annotations
 
 import torch
@@ -17,8 +16,8 @@ from ._util import handle_and_stream, require_cuda_f32
 def _no_grad(*tensors):
     for t in tensors:
         if t is not None and t.requires_grad and torch.is_grad_enabled():
-            raise RuntimeError("gmf_amd.losses: forward-only metrics (validation); call under torch.no_grad() - "
-                               "the backward pass is not implemented")
+            raise RuntimeError("gmf_amd.losses: this argument is a constant of the loss (no gradient is defined for it); "
+                               "detach it or call under torch.no_grad()")
 
 
 def similarity_matrix(feat_n: torch.Tensor, sigma: float, contiguous: bool = False) -> torch.Tensor:

@@ -384,13 +384,16 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
 //   stages: Wq' Wk Wv [12] | Wq'' [2] | context tiles [ttiles] | Wo [2] through a 2-slot ring, then the 48 feed-forward
 //   stages through the 4-slot ring of ff_chunks (the same 64 KiB of LDS; one workgroup barrier between the two).
 // =========================================================================================
-__global__ void __launch_bounds__(256, 2)
-k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst, const float* __restrict__ front_vec,
-            const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
-            const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
-            float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
-            int ttiles) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+// PART 0: the whole kernel.  PART 1 / PART 2: its two independent halves as workgroup ROLES of one launch (k_linear_roles, grids
+// of 256 .. ~300 workgroups: one workgroup per CU cannot hide the 71-stage chain of a wave, two roles per row block shorten
+// it to its longer half) - 1 = the Q'/K/V projections, 2 = Fusion-2 (LCPE + cross-attention + feed-forward).
+template <int PART>
+GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const float* __restrict__ front_wst,
+                               const float* __restrict__ front_vec, const float* __restrict__ ctx_img,
+                               const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
+                               const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
+                               float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles,
+                               int T, int ttiles) {
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y;
@@ -407,11 +410,13 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
   // on every wave, the padding waves of a pair's last workgroup store too: they recompute the pair's last tile and write the
   // same bits to the same place as the wave that owns it.
   StageRing<4> ss;
-  ss.init(lds, wave, lane, front_wst + 4 * kStageFloats, 12, attn_wst, 2,
-          ctx_img + (size_t)pair * ttiles * kStageFloats, ttiles, attn_wst + 2 * kStageFloats, 2);
+  if (PART == 0) ss.init(lds, wave, lane, front_wst + 4 * kStageFloats, 12, attn_wst, 2,
+                         ctx_img + (size_t)pair * ttiles * kStageFloats, ttiles, attn_wst + 2 * kStageFloats, 2);
+  else if (PART == 1) ss.init(lds, wave, lane, front_wst + 4 * kStageFloats, 12);
+  else ss.init(lds, wave, lane, attn_wst, 2, ctx_img + (size_t)pair * ttiles * kStageFloats, ttiles, attn_wst + 2 * kStageFloats, 2);
 
   // ---- Q', K, V from f ---------------------------------------------------------------------------------------------
-  {
+  if (PART != 2) {
     FragH2<8> fx;
     {
       float f[CF];
@@ -433,7 +438,9 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
       for (int mb = 0; mb < 4; ++mb) {
         constexpr int kYounger[4] = {8, 12, 16, 20};
         const int sidx = 4 * which + mb;                       // stage index (compile-time: the loops are unrolled)
-        const f16x8* lw = as_h2(sidx == 0 ? ss.acquire_counted<kYounger[0]>() : sidx == 1 ? ss.acquire_counted<kYounger[1]>()
+        // (role 1 has no stages behind its last ones, so the counts of the steady state do not hold there: plain acquire)
+        const f16x8* lw = as_h2(PART == 1 ? ss.acquire()
+                                : sidx == 0 ? ss.acquire_counted<kYounger[0]>() : sidx == 1 ? ss.acquire_counted<kYounger[1]>()
                                 : sidx == 2 ? ss.acquire_counted<kYounger[2]>() : ss.acquire_counted<kYounger[3]>());
         f32x16 acc = zero16();
         mma_wx_h2<8>(acc, lw, fx);
@@ -445,7 +452,7 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
     }
 #pragma unroll
     for (int db = 0; db < 4; ++db) {             // V (feature on lane)
-      const f16x8* lw = as_h2(ss.acquire_counted<20>());
+      const f16x8* lw = as_h2(PART == 1 ? ss.acquire() : ss.acquire_counted<20>());
       f32x16 acc = zero16();
       mma_xw_h2<8>(acc, lw, fx);
       float t[16];
@@ -455,6 +462,11 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
     }
   }
 
+  if (PART == 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  if (PART == 2) ss.prime();
   // ---- cross-attention: x1 = x' + Wo softmax(q Kc^T) Vc + bo --------------------------------------------------------
   f32x16 x1a[4];                                 // 256 x1, accumulator layout (block mb = features 32 mb .. 32 mb + 31)
   {
@@ -587,6 +599,33 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
   }
 }
 
+__global__ void __launch_bounds__(256, 2)
+k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst, const float* __restrict__ front_vec,
+            const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
+            const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
+            float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
+            int ttiles) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+  linear_h2_body<0>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N, tiles,
+                    T, ttiles);
+}
+
+// grid (ceil(tiles / 4), B, 2): blockIdx.z = 0 the Q'/K/V role, 1 the Fusion-2 role of the same 128 rows
+__global__ void __launch_bounds__(256, 2)
+k_linear_roles(const float* __restrict__ f_in, const float* __restrict__ front_wst, const float* __restrict__ front_vec,
+               const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
+               const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
+               float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
+               int ttiles) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+  if (blockIdx.z == 0)
+    linear_h2_body<1>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
+                      tiles, T, ttiles);
+  else
+    linear_h2_body<2>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
+                      tiles, T, ttiles);
+}
+
 // k_ff_reduce: x2 = sum_z part[z] + b2 + x1 (z in index order) for the hidden-split form of k_fusion_ff_h2p.
 // grid (ceil(tiles/4), B, 4): a wave adds one 32 x 32 block; all hs partial blocks are requested before the first add.
 __global__ void __launch_bounds__(256)
@@ -632,11 +671,17 @@ hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const 
   return hipGetLastError();
 }
 
-hipError_t launch_linear_h2(const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
+hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                             const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec, float* q,
                             float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s) {
-  hipLaunchKernelGGL(k_linear_h2, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
-                     ff_vec, q, k, v, x2, N, tiles, T, ttiles);
+  // grids that give a CU about one workgroup: two roles per row block (the Q'/K/V projections | Fusion-2) in one launch
+  const int W = ((tiles + 3) / 4) * B;
+  if (tune.mid_grid_roles > 0 && W < tune.mid_grid_roles)
+    hipLaunchKernelGGL(k_linear_roles, tgrid(tiles, B, 2), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec,
+                       ff_wst, ff_vec, q, k, v, x2, N, tiles, T, ttiles);
+  else
+    hipLaunchKernelGGL(k_linear_h2, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
+                       ff_vec, q, k, v, x2, N, tiles, T, ttiles);
   return hipGetLastError();
 }
 

@@ -91,6 +91,11 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     t.topk_select = value != 0;
     return GMF_OK;
   }
+  if (std::strcmp(name, "mid_grid_roles") == 0) {      // two-launch form below this many base workgroups: linear kernel as two roles (0 = never)
+    GMF_REQUIRE(value >= 0 && value <= 4096, GMF_ERR_BAD_ARG, "set_tuning: mid_grid_roles out of range (0..4096)");
+    t.mid_grid_roles = value;
+    return GMF_OK;
+  }
   if (std::strcmp(name, "precision") == 0) {           // 0 = parity numerics (default), 1 = throughput numerics (NOT within 1e-4)
     GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: precision must be 0 (parity) or 1 (throughput)");
     t.precision = value;
@@ -416,7 +421,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
       const float* ffv = w->ff_vec + (size_t)l * w->ff_vec_stride;
       const float* ctx_l = ctxall + (size_t)l * tok;
       if (one_kernel) {
-        GMF_HIP(gmf::launch_linear_h2(f, fw, fv, ctx_l, aw, av, ffw, ffv, q, k, v, x2, B, N, tiles, T, tt, st));
+        GMF_HIP(gmf::launch_linear_h2(h->tune, f, fw, fv, ctx_l, aw, av, ffw, ffv, q, k, v, x2, B, N, tiles, T, tt, st));
       } else if (small3) {
         // three launches: {Q' | K | V | cross-attention} -> {key-split attention | hidden-split feed-forward} -> merge
         GMF_HIP(gmf::launch_small_front_fattn(f, fw, fv, ctx_l, aw, av, q, k, v, x1, B, N, tiles, T, tt, st));

@@ -36,6 +36,8 @@ struct Tuning {
   int conv_patch = 1;        // stride-1 3x3 convolutions: 1 = LDS patch kernel (automatic form), 2 = never three workgroups per CU, 0 = gather kernel
   int nms_binned = 1;        // 1 = grid-binned NMS candidates on large grids, 2 = always, 0 = all pairs
   bool topk_select = true;   // radix select of the S seeds (false = full bitonic sort)
+  int mid_grid_roles = 512;  // two-launch form on grids below this many base workgroups (>= 256): the linear kernel runs as two
+                             // workgroup roles per row block (Q'/K/V | Fusion-2); 0 = never
   int precision = 0;         // NOT rounding-equivalent: 0 = parity numerics (fp32-equivalent split-fp16 products, the default);
                              // 1 = throughput numerics: the spatial-consistency attention multiplies plain
                              // fp16 operands (one product, fp32 accumulation) and streams c as fp16 - outside the 1e-4 gate
@@ -68,7 +70,7 @@ hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const flo
 hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
                            float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s);
 // mode 3: corr_pos -> layer0 -> PointCN -> f only.  launch_linear_h2: all linear stages of one layer from f (k_linear_h2)
-hipError_t launch_linear_h2(const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
+hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                             const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec, float* q,
                             float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
 // small grids: three launches per layer (k_small_front_fattn | k_small_attn_ff | k_scattn_merge)

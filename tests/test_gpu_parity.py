@@ -799,6 +799,30 @@ def test_backward_entry_points_reject_bad_arguments():
     torch.cuda.synchronize()
 
 
+def test_mid_grid_linear_roles_are_bit_identical(model):
+    """Grids of 256 .. 511 base workgroups run the fused linear kernel as two workgroup roles per row block (Q'/K/V |
+    Fusion-2: the two independent halves of k_linear_h2's body, `mid_grid_roles`).  Same arithmetic in the same order: logits
+    and poses bitwise equal to the single-kernel form."""
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    b = synthetic.synthetic_batch(list(range(200, 233)), N=1000, T=196)        # 33 pairs x 8 row blocks = 264 workgroups
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    try:
+        h.call("gmf_set_tuning", b"mid_grid_roles", 0)
+        r0 = model(data)
+        lg0, T0 = model.last_logits.clone(), r0["final_trans"].clone()
+        h.call("gmf_set_tuning", b"mid_grid_roles", 512)
+        r1 = model(data)
+        assert torch.equal(model.last_logits, lg0) and torch.equal(r1["final_trans"], T0)
+        assert h.lib.gmf_set_tuning(h.h, b"mid_grid_roles", -1) == -1
+    finally:
+        h.call("gmf_set_tuning", b"mid_grid_roles", 512)
+    ref = O.pointdsc_forward(synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7),
+                             synthetic.synthetic_batch([200], N=1000, T=196), testing=True)
+    assert _maxerr(lg0[:1].cpu(), ref["logits"]) < 1e-4
+
+
 def test_tuning_is_per_handle(golden_dir, model):
     """Tuning state lives in the handle: a second handle on the same device set to the fp32 path does not change what the
     first one runs (bitwise identical logits before and after)."""

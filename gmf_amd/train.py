@@ -311,52 +311,58 @@ def batchnorm_train(x, bn, relu=False):
 
 
 class _SCAttention(torch.autograd.Function):
-    """message = softmax_j(compat_ij * <q_i, k_j> / sqrt(C)) V per pair (PointDSC.py:56-64); q, k, v [B, N, C] token-major,
-    compat [B, N, N] (no gradient: the reference computes it under no_grad, PointDSC.py:216-221)."""
+    """message = softmax_j(compat_ij * <q_i, k_j> / sqrt(C)) V per pair (PointDSC.py:56-64).  qkv [B, N, 3C] token-major holds
+    Q | K | V side by side (ONE projection GEMM produces them, one GEMM each takes their gradients back: the products below
+    address the three column blocks through leading dimensions and offsets); compat [B, N, N] has no gradient (the reference
+    computes it under no_grad, PointDSC.py:216-221)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, compat):
-        q, k, v, compat = q.contiguous(), k.contiguous(), v.contiguous(), compat.contiguous()
-        B, N, Cc = q.shape
+    def forward(ctx, qkv, compat):
+        qkv, compat = qkv.contiguous(), compat.contiguous()
+        B, N, C3 = qkv.shape
+        Cc = C3 // 3
         scale = 1.0 / (Cc ** 0.5)
-        S = torch.empty((B, N, N), device=q.device, dtype=torch.float32)
-        gemm(q, k, tb=True, out=S, m=N, n=N, k=Cc, lda=Cc, ldb=Cc, ldc=N, batch=B, sa=N * Cc, sb=N * Cc, sc=N * N)
+        S = torch.empty((B, N, N), device=qkv.device, dtype=torch.float32)
+        gemm(qkv, qkv, tb=True, out=S, m=N, n=N, k=Cc, lda=C3, ldb=C3, ldc=N, b_off=Cc, batch=B, sa=N * C3, sb=N * C3, sc=N * N)
         P = softmax_rows(S.reshape(B * N, N), scale, mul=compat.reshape(B * N, N))
-        msg = torch.empty((B, N, Cc), device=q.device, dtype=torch.float32)
-        gemm(P, v, out=msg, m=N, n=Cc, k=N, lda=N, ldb=Cc, ldc=Cc, batch=B, sa=N * N, sb=N * Cc, sc=N * Cc)
+        msg = torch.empty((B, N, Cc), device=qkv.device, dtype=torch.float32)
+        gemm(P, qkv, out=msg, m=N, n=Cc, k=N, lda=N, ldb=C3, ldc=Cc, b_off=2 * Cc, batch=B, sa=N * N, sb=N * C3, sc=N * Cc)
         ctx.scale = scale
-        ctx.save_for_backward(q, k, v, compat, P)
+        ctx.save_for_backward(qkv, compat, P)
         return msg
 
     @staticmethod
     def backward(ctx, dmsg):
-        q, k, v, compat, P = ctx.saved_tensors
+        qkv, compat, P = ctx.saved_tensors
         dmsg = dmsg.contiguous()
-        B, N, Cc = q.shape
-        dev = q.device
+        B, N, C3 = qkv.shape
+        Cc = C3 // 3
+        dev = qkv.device
+        dqkv = torch.empty_like(qkv)
         dP = torch.empty((B * N, N), device=dev, dtype=torch.float32)
-        gemm(dmsg, v, tb=True, out=dP, m=N, n=N, k=Cc, lda=Cc, ldb=Cc, ldc=N, batch=B, sa=N * Cc, sb=N * Cc, sc=N * N)
-        dv = torch.empty_like(v)
-        gemm(P, dmsg, ta=True, out=dv, m=N, n=Cc, k=N, lda=N, ldb=Cc, ldc=Cc, batch=B, sa=N * N, sb=N * Cc, sc=N * Cc)
+        gemm(dmsg, qkv, tb=True, out=dP, m=N, n=N, k=Cc, lda=Cc, ldb=C3, ldc=N, b_off=2 * Cc, batch=B, sa=N * Cc, sb=N * C3, sc=N * N)
+        gemm(P, dmsg, ta=True, out=dqkv, m=N, n=Cc, k=N, lda=N, ldb=Cc, ldc=C3, c_off=2 * Cc, batch=B, sa=N * N, sb=N * Cc,
+             sc=N * C3)                                                                              # dV
         dS = softmax_rows_bwd(P, dP, ctx.scale, mul=compat.reshape(B * N, N))
-        dq = torch.empty_like(q)
-        gemm(dS, k, out=dq, m=N, n=Cc, k=N, lda=N, ldb=Cc, ldc=Cc, batch=B, sa=N * N, sb=N * Cc, sc=N * Cc)
-        dk = torch.empty_like(k)
-        gemm(dS, q, ta=True, out=dk, m=N, n=Cc, k=N, lda=N, ldb=Cc, ldc=Cc, batch=B, sa=N * N, sb=N * Cc, sc=N * Cc)
-        return dq, dk, dv, None
+        gemm(dS, qkv, out=dqkv, m=N, n=Cc, k=N, lda=N, ldb=C3, ldc=C3, b_off=Cc, batch=B, sa=N * N, sb=N * C3, sc=N * C3)     # dQ = dS K
+        gemm(dS, qkv, ta=True, out=dqkv, m=N, n=Cc, k=N, lda=N, ldb=C3, ldc=C3, c_off=Cc, batch=B, sa=N * N, sb=N * C3,
+             sc=N * C3)                                                                              # dK = dS^T Q
+        return dqkv, None
 
 
-def sc_attention(q, k, v, compat):
-    return _SCAttention.apply(q, k, v, compat)
+def sc_attention(qkv, compat):
+    return _SCAttention.apply(qkv, compat)
 
 
 def nonlocal_block_train(block, feat, compat, image_feat, B, N):
     """NonLocalBlock.forward (PointDSC.py:40-74) on token-major rows feat [B * N, C]; returns [B * N, C]."""
     C = feat.shape[1]
-    q = linear(feat, block.projection_q.weight, block.projection_q.bias)
-    k = linear(feat, block.projection_k.weight, block.projection_k.bias)
-    v = linear(feat, block.projection_v.weight, block.projection_v.bias)
-    msg = sc_attention(q.reshape(B, N, C), k.reshape(B, N, C), v.reshape(B, N, C), compat).reshape(B * N, C)
+    # Q | K | V from ONE product (the concatenation is a view-free torch.cat of three small parameters; autograd hands each its
+    # slice of the joint gradient)
+    Wqkv = torch.cat([block.projection_q.weight, block.projection_k.weight, block.projection_v.weight], dim=0)
+    bqkv = torch.cat([block.projection_q.bias, block.projection_k.bias, block.projection_v.bias], dim=0)
+    qkv = linear(feat, Wqkv, bqkv)
+    msg = sc_attention(qkv.reshape(B, N, 3 * C), compat).reshape(B * N, C)
     fm = block.fc_message
     m1 = batchnorm_train(linear(msg, fm[0].weight, fm[0].bias), fm[1], relu=True)
     m2 = batchnorm_train(linear(m1, fm[3].weight, fm[3].bias), fm[4], relu=True)

@@ -210,6 +210,8 @@ def main():
                      "algorithmic_bytes": alg_bytes,
                      "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                      "hbm_floor_ms": (traffic / (PEAK_HBM_GBS * 1e9) * 1e3) if traffic else None,
+                     "hbm_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+                     "hbm_frac_of_peak": (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None,
                      "peak_note": (f"f16 MFMA dense peak {PEAK_F16_MFMA_TFLOPS:.0f} TFLOP/s / {PRODUCTS} partial products per algorithmic "
                                    "multiply-add (split-fp16 operands, fp32 accumulate, fp32-equivalent results)"),
                      "executed_mfma_tflops": achieved * PRODUCTS,

@@ -13,6 +13,7 @@
 // which 288 GB make a non-issue) and the contractions run on the fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products, no
 // operand-range caveats for gradients of magnitude 1e-8) - a first, correct, device-resident training slice.
 #include <algorithm>
+#include <type_traits>
 
 #include "mfma_core.hpp"
 #include "launchers.hpp"
@@ -199,66 +200,74 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
 //   grid (ceil(N / 128), ceil(M / 128), batch * ksplits), block 256.
 // =========================================================================================
 constexpr int kGemmLd = 20;                          // floats per LDS row (16 + 4 of padding)
-constexpr int kGemmStage = 2 * 128 * kGemmLd;        // floats per stage (A then B)
 
-template <bool TA, bool TB>
+// RB = 2: 128 x 128 workgroup tile; RB = 1: 64 x 128 (tall-skinny products: twice the workgroups, half the splits)
+template <bool TA, bool TB, int RB>
 __global__ void __launch_bounds__(256, 2)
 k_gemm_lds(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C, const float* __restrict__ bias,
            const float* __restrict__ R, int M, int N, int K, long lda, long ldb, long ldc, long sA, long sB, long sC,
            int ksplits, int kchunk, float alpha, float* __restrict__ part, int relu) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * kGemmStage];
+  constexpr int BM = 64 * RB;
+  constexpr int kStage = (BM + 128) * kGemmLd;       // floats per stage: A_s [BM][20] | B_s [128][20]
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5, i = lane & 31;
   const int wave = t >> 6, wr = wave >> 1, wc = wave & 1;
   const int b = blockIdx.z / ksplits, ks = blockIdx.z - b * ksplits;
   const int kbeg = ks * kchunk, kend = min(K, kbeg + kchunk);
-  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * 128;
   A += (size_t)b * sA;
   Bm += (size_t)b * sB;
-  f32x16 acc[2][2];
+  f32x16 acc[RB][2];
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = zero16();
 
-  // global -> registers: two 16-byte pieces per thread and operand.
+  // global -> registers in 16-byte pieces, ROWS = rows (columns) of the operand tile, ROWS / 64 pieces per thread:
   //   k-contiguous operand (A when !TA, B when TB): piece p covers row (t >> 2) + 64 p, k = k0 + 4 (t & 3) .. + 3
-  //   row-contiguous operand (A when TA, B when !TB): piece p covers k = k0 + (t >> 5) + 8 p, rows 4 (t & 31) .. + 3
+  //   row-contiguous operand (A when TA, B when !TB), 128 rows: piece p covers k = k0 + (t >> 5) + 8 p, rows 4 (t & 31) .. + 3;
+  //                                                    64 rows: the one piece covers k = k0 + (t >> 4), rows 4 (t & 15) .. + 3
   // Every fetch ISSUES its loads, whatever k0 (addresses past the end are clamped into the matrix and the values replaced by
   // zeros): a load under a branch would make the compiler's s_waitcnt vmcnt conservative at the join - it would wait for
   // the loads just issued instead of only for the ones of the previous step.
-  auto fetch = [&](const float* base, long ld, bool kcontig, int r0, int rmax, int k0, float4 (&v)[2]) {
+  auto fetch = [&](auto rows_tag, const float* base, long ld, bool kcontig, int r0, int rmax, int k0, float4 (&v)[2]) {
+    constexpr int ROWS = decltype(rows_tag)::value, NP = ROWS / 64;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
       if (kcontig) {
         const int row = min(r0 + (t >> 2) + 64 * p, rmax - 1), k = k0 + 4 * (t & 3);
         const float4 x = *reinterpret_cast<const float4*>(base + (size_t)row * ld + min(k, K - 4));
         const bool ok = k < kend;       // (component-wise selects: a select between two float4 OBJECTS goes through scratch)
         v[p].x = ok ? x.x : 0.f; v[p].y = ok ? x.y : 0.f; v[p].z = ok ? x.z : 0.f; v[p].w = ok ? x.w : 0.f;
       } else {
-        const int k = k0 + (t >> 5) + 8 * p, row = r0 + 4 * (t & 31);
+        const int k = (ROWS == 128) ? k0 + (t >> 5) + 8 * p : k0 + (t >> 4);
+        const int row = r0 + 4 * ((ROWS == 128) ? (t & 31) : (t & 15));
         const float4 x = *reinterpret_cast<const float4*>(base + (size_t)min(k, K - 1) * ld + min(row, rmax - 4));
         const bool ok = k < kend && row < rmax;
         v[p].x = ok ? x.x : 0.f; v[p].y = ok ? x.y : 0.f; v[p].z = ok ? x.z : 0.f; v[p].w = ok ? x.w : 0.f;
       }
     }
   };
-  auto stash = [&](float* dst, bool kcontig, const float4 (&v)[2]) {
+  auto stash = [&](auto rows_tag, float* dst, bool kcontig, const float4 (&v)[2]) {
+    constexpr int ROWS = decltype(rows_tag)::value, NP = ROWS / 64;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
       if (kcontig) {
         *reinterpret_cast<float4*>(dst + ((t >> 2) + 64 * p) * kGemmLd + 4 * (t & 3)) = v[p];
       } else {
-        float* q = dst + (4 * (t & 31)) * kGemmLd + (t >> 5) + 8 * p;
+        float* q = (ROWS == 128) ? dst + (4 * (t & 31)) * kGemmLd + (t >> 5) + 8 * p : dst + (4 * (t & 15)) * kGemmLd + (t >> 4);
         q[0] = v[p].x; q[kGemmLd] = v[p].y; q[2 * kGemmLd] = v[p].z; q[3 * kGemmLd] = v[p].w;
       }
     }
   };
+  const std::integral_constant<int, BM> rowsA;
+  const std::integral_constant<int, 128> rowsB;
   auto mma_stage = [&](const int stage) {
-    const float* As = lds + stage * kGemmStage + (64 * wr + i) * kGemmLd + 8 * h;
-    const float* Bs = lds + stage * kGemmStage + 128 * kGemmLd + (64 * wc + i) * kGemmLd + 8 * h;
-    float a[2][8], bf[2][8];
+    const float* As = lds + stage * kStage + (32 * RB * wr + i) * kGemmLd + 8 * h;
+    const float* Bs = lds + stage * kStage + BM * kGemmLd + (64 * wc + i) * kGemmLd + 8 * h;
+    float a[RB][8], bf[2][8];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < RB; ++rb) {
       const float4 u = *reinterpret_cast<const float4*>(As + 32 * rb * kGemmLd);
       const float4 w = *reinterpret_cast<const float4*>(As + 32 * rb * kGemmLd + 4);
       a[rb][0] = u.x; a[rb][1] = u.y; a[rb][2] = u.z; a[rb][3] = u.w; a[rb][4] = w.x; a[rb][5] = w.y; a[rb][6] = w.z; a[rb][7] = w.w;
@@ -272,7 +281,7 @@ k_gemm_lds(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
 #pragma unroll
     for (int e = 0; e < 8; ++e)
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma32(a[rb][e], bf[cb][e], acc[rb][cb]);
   };
@@ -280,55 +289,59 @@ k_gemm_lds(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
   // step t, held in registers across step t + 1's MFMAs and written to the LDS at its end - a full k-step (2048 matrix-pipe
   // cycles) plus a barrier more than one memory round trip.  One barrier per k-step, two LDS stages.
   float4 va0[2], vb0[2], va1[2], vb1[2];
-  fetch(A, lda, !TA, m0, M, kbeg, va0);
-  fetch(Bm, ldb, TB, n0, N, kbeg, vb0);
-  fetch(A, lda, !TA, m0, M, kbeg + 16, va1);
-  fetch(Bm, ldb, TB, n0, N, kbeg + 16, vb1);
-  stash(lds, !TA, va0);
-  stash(lds + 128 * kGemmLd, TB, vb0);
+  float* const A0 = lds;
+  float* const B0 = lds + BM * kGemmLd;
+  float* const A1 = lds + kStage;
+  float* const B1 = lds + kStage + BM * kGemmLd;
+  fetch(rowsA, A, lda, !TA, m0, M, kbeg, va0);
+  fetch(rowsB, Bm, ldb, TB, n0, N, kbeg, vb0);
+  fetch(rowsA, A, lda, !TA, m0, M, kbeg + 16, va1);
+  fetch(rowsB, Bm, ldb, TB, n0, N, kbeg + 16, vb1);
+  stash(rowsA, A0, !TA, va0);
+  stash(rowsB, B0, TB, vb0);
   __syncthreads();
   // invariant at the top of a pair of steps: LDS stage 0 holds k0, register set 1 holds k0 + 16
   int k0 = kbeg;
   for (; k0 + 48 < kend; k0 += 32) {           // steady state: both fetches of the pair are needed - no branch around a load
-    fetch(A, lda, !TA, m0, M, k0 + 32, va0);
-    fetch(Bm, ldb, TB, n0, N, k0 + 32, vb0);
+    fetch(rowsA, A, lda, !TA, m0, M, k0 + 32, va0);
+    fetch(rowsB, Bm, ldb, TB, n0, N, k0 + 32, vb0);
     mma_stage(0);
-    stash(lds + kGemmStage, !TA, va1);
-    stash(lds + kGemmStage + 128 * kGemmLd, TB, vb1);
+    stash(rowsA, A1, !TA, va1);
+    stash(rowsB, B1, TB, vb1);
     __syncthreads();
-    fetch(A, lda, !TA, m0, M, k0 + 48, va1);
-    fetch(Bm, ldb, TB, n0, N, k0 + 48, vb1);
+    fetch(rowsA, A, lda, !TA, m0, M, k0 + 48, va1);
+    fetch(rowsB, Bm, ldb, TB, n0, N, k0 + 48, vb1);
     mma_stage(1);
-    stash(lds, !TA, va0);
-    stash(lds + 128 * kGemmLd, TB, vb0);
+    stash(rowsA, A0, !TA, va0);
+    stash(rowsB, B0, TB, vb0);
     __syncthreads();
   }
   for (; k0 < kend; k0 += 32) {                // the last (at most three) steps: nothing fetched that is not used
     if (k0 + 32 < kend) {
-      fetch(A, lda, !TA, m0, M, k0 + 32, va0);
-      fetch(Bm, ldb, TB, n0, N, k0 + 32, vb0);
+      fetch(rowsA, A, lda, !TA, m0, M, k0 + 32, va0);
+      fetch(rowsB, Bm, ldb, TB, n0, N, k0 + 32, vb0);
     }
     mma_stage(0);
     if (k0 + 16 >= kend) break;
-    stash(lds + kGemmStage, !TA, va1);
-    stash(lds + kGemmStage + 128 * kGemmLd, TB, vb1);
+    stash(rowsA, A1, !TA, va1);
+    stash(rowsB, B1, TB, vb1);
     __syncthreads();
     mma_stage(1);
     if (k0 + 32 < kend) {
-      stash(lds, !TA, va0);
-      stash(lds + 128 * kGemmLd, TB, vb0);
+      stash(rowsA, A0, !TA, va0);
+      stash(rowsB, B0, TB, vb0);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       const int col = n0 + 64 * wc + 32 * cb + i;
       if (col >= N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + 64 * wr + 32 * rb + 8 * (r >> 2) + 4 * h + (r & 3);
+        const int row = m0 + 32 * RB * wr + 32 * rb + 8 * (r >> 2) + 4 * h + (r & 3);
         if (row >= M) continue;
         if (ksplits > 1) {
           part[((size_t)blockIdx.z * M + row) * N + col] = acc[rb][cb][r];
@@ -753,18 +766,18 @@ k_sm_consts(const float* __restrict__ gt, float* __restrict__ consts, int B, int
 // -----------------------------------------------------------------------------------------
 static inline unsigned blocks_of(long total) { return (unsigned)((total + 255) / 256); }
 
-// 64-row workgroup tiles (the register-direct kernel) when the 128-row tiling gives fewer workgroups than the chip has CUs
-// and the contraction is too short to split; long contractions keep the 128-row tiles and split K instead
-static inline bool gemm_small_tile(int M, int N, int K, int batch) {
+// 64-row workgroup tiles when the 128-row tiling gives the chip fewer than two workgroups per CU (tall-skinny products:
+// activations x a 128-column weight): twice the workgroups, half the K splits and half the partial traffic
+static inline int gemm_tile_rows(int M, int N, int batch) {
   const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-  return tiles < 256 && M > 64 && (K < 256 || tiles < 4);      // (one or two tiles: even 128 splits leave CUs without work)
+  return (tiles < 512 && M > 64) ? 64 : 128;
 }
 
 int gemm_ksplits(int M, int N, int K, int batch) {
   // few output tiles and a long contraction (weight gradients: K = every row of the batch; the P V products of the
   // attention): split K so that the launch has ~768 workgroups, each split at least 64 deep, the partial tiles at most
   // ~48 MB (they are written and read once by k_gemm_reduce)
-  const int bm = gemm_small_tile(M, N, K, batch) ? 64 : 128;
+  const int bm = gemm_tile_rows(M, N, batch);
   const long tiles = (long)((M + bm - 1) / bm) * ((N + 127) / 128) * batch;
   if (tiles >= 384 || K < 256) return 1;
   long s = std::min<long>((768 + tiles - 1) / tiles, K / 64);
@@ -780,34 +793,33 @@ hipError_t launch_gemm_f32(bool ta, bool tb, const float* A, const float* B, flo
   int kchunk = (K + ksplits - 1) / ksplits;
   kchunk = (kchunk + 15) / 16 * 16;
   ksplits = (K + kchunk - 1) / kchunk;
-  // the LDS-staged kernel needs 16-byte pieces along each operand's contiguous dimension
+  // the LDS-staged kernel needs 16-byte pieces along each operand's contiguous dimension; anything else takes the
+  // register-direct kernel
   const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool a_ok = al16(A) && lda % 4 == 0 && sA % 4 == 0 && (ta ? M % 4 == 0 : K % 4 == 0);
   const bool b_ok = al16(B) && ldb % 4 == 0 && sB % 4 == 0 && (tb ? K % 4 == 0 : N % 4 == 0);
-  const bool small = gemm_small_tile(M, N, K, batch);
-  if (a_ok && b_ok && !small) {
-    const dim3 grid((N + 127) / 128, (M + 127) / 128, batch * ksplits);
-#define GMF_GEMM_LDS(TA, TB) hipLaunchKernelGGL((k_gemm_lds<TA, TB>), grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA, sB, sC, ksplits, kchunk, alpha, part, relu)
-    if (ta && tb) GMF_GEMM_LDS(true, true);
-    else if (ta) GMF_GEMM_LDS(true, false);
-    else if (tb) GMF_GEMM_LDS(false, true);
-    else GMF_GEMM_LDS(false, false);
-#undef GMF_GEMM_LDS
-  } else {
+  const bool lds_ok = a_ok && b_ok && K >= 4 && M >= 4 && N >= 4;
+  const bool small = gemm_tile_rows(M, N, batch) == 64;
   const dim3 grid((N + 127) / 128, small ? (M + 63) / 64 : (M + 127) / 128, batch * ksplits);
-#define GMF_GEMM(TA, TB)                                                                                                         \
+#define GMF_GEMM(KERNEL, TA, TB)                                                                                                 \
   do {                                                                                                                           \
-    if (small) hipLaunchKernelGGL((k_gemm_f32<TA, TB, 1>), grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA,   \
-                                  sB, sC, ksplits, kchunk, alpha, part, relu);                                                  \
-    else hipLaunchKernelGGL((k_gemm_f32<TA, TB, 2>), grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA, sB,    \
-                            sC, ksplits, kchunk, alpha, part, relu);                                                            \
+    if (small) hipLaunchKernelGGL((KERNEL<TA, TB, 1>), grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA, sB,   \
+                                  sC, ksplits, kchunk, alpha, part, relu);                                                      \
+    else hipLaunchKernelGGL((KERNEL<TA, TB, 2>), grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA, sB, sC,    \
+                            ksplits, kchunk, alpha, part, relu);                                                                \
   } while (0)
-  if (ta && tb) GMF_GEMM(true, true);
-  else if (ta) GMF_GEMM(true, false);
-  else if (tb) GMF_GEMM(false, true);
-  else GMF_GEMM(false, false);
-#undef GMF_GEMM
+  if (lds_ok) {
+    if (ta && tb) GMF_GEMM(k_gemm_lds, true, true);
+    else if (ta) GMF_GEMM(k_gemm_lds, true, false);
+    else if (tb) GMF_GEMM(k_gemm_lds, false, true);
+    else GMF_GEMM(k_gemm_lds, false, false);
+  } else {
+    if (ta && tb) GMF_GEMM(k_gemm_f32, true, true);
+    else if (ta) GMF_GEMM(k_gemm_f32, true, false);
+    else if (tb) GMF_GEMM(k_gemm_f32, false, true);
+    else GMF_GEMM(k_gemm_f32, false, false);
   }
+#undef GMF_GEMM
   if (ksplits > 1) {
     const long total = (long)batch * M * N;
     const int groups = ksplits > 64 ? 16 : ksplits > 32 ? 8 : ksplits > 16 ? 4 : ksplits > 8 ? 2 : 1;

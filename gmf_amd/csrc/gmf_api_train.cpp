@@ -13,7 +13,7 @@ int gmf_gemm_f32(gmf_handle* h, int trans_a, int trans_b, const float* A, const 
   GMF_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, GMF_ERR_UNSUPPORTED_SHAPE, "gemm_f32: empty problem");
   GMF_REQUIRE((long long)batch * ((M + 127) / 128) <= 2000000 , GMF_ERR_UNSUPPORTED_SHAPE, "gemm_f32: grid too large");
   SetDevice sd(h);
-  const int ksplits = gmf::gemm_ksplits(M, N, K, batch);
+  const int ksplits = gmf::gemm_ksplits(trans_a != 0, trans_b != 0, A, B, M, N, K, (long)lda, (long)ldb, (long)stride_a, (long)stride_b, batch);
   float* part = nullptr;
   if (ksplits > 1) {
     if (int rc = arena_reserve(h, arena_need((size_t)batch * ksplits * M * N, 4))) return rc;

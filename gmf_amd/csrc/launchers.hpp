@@ -118,7 +118,8 @@ hipError_t launch_transformation_loss(const float* trans, const float* gt_trans,
                                       float* out, hipStream_t s);
 
 // training primitives (row f-4): train_kernels.hip
-int gemm_ksplits(int M, int N, int K, int batch);
+int gemm_ksplits(bool ta, bool tb, const float* A, const float* B, int M, int N, int K, long lda, long ldb, long sA, long sB,
+                 int batch);
 hipError_t launch_gemm_f32(bool ta, bool tb, const float* A, const float* B, float* C, const float* bias, const float* R, int M, int N,
                            int K, long lda, long ldb, long ldc, long sA, long sB, long sC, int batch, float alpha, float* part,
                            int ksplits, int relu, hipStream_t s);

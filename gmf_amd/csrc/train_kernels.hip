@@ -201,27 +201,29 @@ k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
 // =========================================================================================
 constexpr int kGemmLd = 20;                          // floats per LDS row (16 + 4 of padding)
 
-// RB = 2: 128 x 128 workgroup tile; RB = 1: 64 x 128 (tall-skinny products: twice the workgroups, half the splits)
-template <bool TA, bool TB, int RB>
+// Workgroup tile (64 RB) x (64 CB), a wave (32 RB) x (32 CB): 128 x 128 for large products, 64 x 128 and 64 x 64 for the
+// tall-skinny ones (activations x a 128-column weight, the P V products): enough workgroups WITHOUT splitting K, i.e. without
+// the partial tiles and their reduction.
+template <bool TA, bool TB, int RB, int CB>
 __global__ void __launch_bounds__(256, 2)
 k_gemm_lds(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C, const float* __restrict__ bias,
            const float* __restrict__ R, int M, int N, int K, long lda, long ldb, long ldc, long sA, long sB, long sC,
            int ksplits, int kchunk, float alpha, float* __restrict__ part, int relu) {
-  constexpr int BM = 64 * RB;
-  constexpr int kStage = (BM + 128) * kGemmLd;       // floats per stage: A_s [BM][20] | B_s [128][20]
+  constexpr int BM = 64 * RB, BN = 64 * CB;
+  constexpr int kStage = (BM + BN) * kGemmLd;        // floats per stage: A_s [BM][20] | B_s [BN][20]
   __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
   const int t = threadIdx.x, lane = t & 63, h = lane >> 5, i = lane & 31;
   const int wave = t >> 6, wr = wave >> 1, wc = wave & 1;
   const int b = blockIdx.z / ksplits, ks = blockIdx.z - b * ksplits;
   const int kbeg = ks * kchunk, kend = min(K, kbeg + kchunk);
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * 128;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   A += (size_t)b * sA;
   Bm += (size_t)b * sB;
-  f32x16 acc[RB][2];
+  f32x16 acc[RB][CB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = zero16();
+    for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = zero16();
 
   // global -> registers in 16-byte pieces, ROWS = rows (columns) of the operand tile, ROWS / 64 pieces per thread:
   //   k-contiguous operand (A when !TA, B when TB): piece p covers row (t >> 2) + 64 p, k = k0 + 4 (t & 3) .. + 3
@@ -261,11 +263,11 @@ k_gemm_lds(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
     }
   };
   const std::integral_constant<int, BM> rowsA;
-  const std::integral_constant<int, 128> rowsB;
+  const std::integral_constant<int, BN> rowsB;
   auto mma_stage = [&](const int stage) {
     const float* As = lds + stage * kStage + (32 * RB * wr + i) * kGemmLd + 8 * h;
-    const float* Bs = lds + stage * kStage + BM * kGemmLd + (64 * wc + i) * kGemmLd + 8 * h;
-    float a[RB][8], bf[2][8];
+    const float* Bs = lds + stage * kStage + BM * kGemmLd + (32 * CB * wc + i) * kGemmLd + 8 * h;
+    float a[RB][8], bf[CB][8];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       const float4 u = *reinterpret_cast<const float4*>(As + 32 * rb * kGemmLd);
@@ -273,7 +275,7 @@ k_gemm_lds(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
       a[rb][0] = u.x; a[rb][1] = u.y; a[rb][2] = u.z; a[rb][3] = u.w; a[rb][4] = w.x; a[rb][5] = w.y; a[rb][6] = w.z; a[rb][7] = w.w;
     }
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < CB; ++cb) {
       const float4 u = *reinterpret_cast<const float4*>(Bs + 32 * cb * kGemmLd);
       const float4 w = *reinterpret_cast<const float4*>(Bs + 32 * cb * kGemmLd + 4);
       bf[cb][0] = u.x; bf[cb][1] = u.y; bf[cb][2] = u.z; bf[cb][3] = u.w; bf[cb][4] = w.x; bf[cb][5] = w.y; bf[cb][6] = w.z; bf[cb][7] = w.w;
@@ -283,7 +285,7 @@ k_gemm_lds(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma32(a[rb][e], bf[cb][e], acc[rb][cb]);
+        for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = mfma32(a[rb][e], bf[cb][e], acc[rb][cb]);
   };
   // Prefetch distance TWO k-steps through two register sets: the operands of k-step t + 2 are requested at the top of
   // step t, held in registers across step t + 1's MFMAs and written to the LDS at its end - a full k-step (2048 matrix-pipe
@@ -336,8 +338,8 @@ k_gemm_lds(const float* __restrict__ A, const float* __restrict__ Bm, float* __r
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const int col = n0 + 64 * wc + 32 * cb + i;
+    for (int cb = 0; cb < CB; ++cb) {
+      const int col = n0 + 32 * CB * wc + 32 * cb + i;
       if (col >= N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -766,19 +768,32 @@ k_sm_consts(const float* __restrict__ gt, float* __restrict__ consts, int B, int
 // -----------------------------------------------------------------------------------------
 static inline unsigned blocks_of(long total) { return (unsigned)((total + 255) / 256); }
 
-// 64-row workgroup tiles when the 128-row tiling gives the chip fewer than two workgroups per CU (tall-skinny products:
-// activations x a 128-column weight): twice the workgroups, half the K splits and half the partial traffic
-static inline int gemm_tile_rows(int M, int N, int batch) {
-  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-  return (tiles < 512 && M > 64) ? 64 : 128;
+// Workgroup tile of a product: 128 x 128 when that alone gives the chip two workgroups per CU; else 64-row tiles, and 64-column
+// tiles too (LDS-staged kernel only) when the 64 x 128 tiling would still have to split a contraction it can do whole
+static inline void gemm_tile(int M, int N, int K, int batch, bool lds_ok, int* bm, int* bn) {
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  *bm = (t128 < 512 && M > 64) ? 64 : 128;
+  *bn = 128;
+  const long t64 = (long)((M + *bm - 1) / *bm) * ((N + 127) / 128) * batch;
+  if (lds_ok && *bm == 64 && t64 < 384 && K >= 256 && N > 64) *bn = 64;
 }
 
-int gemm_ksplits(int M, int N, int K, int batch) {
-  // few output tiles and a long contraction (weight gradients: K = every row of the batch; the P V products of the
-  // attention): split K so that the launch has ~768 workgroups, each split at least 64 deep, the partial tiles at most
-  // ~48 MB (they are written and read once by k_gemm_reduce)
-  const int bm = gemm_tile_rows(M, N, batch);
-  const long tiles = (long)((M + bm - 1) / bm) * ((N + 127) / 128) * batch;
+static inline bool gemm_lds_ok(bool ta, bool tb, const float* A, const float* B, int M, int N, int K, long lda, long ldb, long sA,
+                               long sB) {
+  // the LDS-staged kernel needs 16-byte pieces along each operand's contiguous dimension
+  const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool a_ok = al16(A) && lda % 4 == 0 && sA % 4 == 0 && (ta ? M % 4 == 0 : K % 4 == 0);
+  const bool b_ok = al16(B) && ldb % 4 == 0 && sB % 4 == 0 && (tb ? K % 4 == 0 : N % 4 == 0);
+  return a_ok && b_ok && K >= 4 && M >= 4 && N >= 4;
+}
+
+int gemm_ksplits(bool ta, bool tb, const float* A, const float* B, int M, int N, int K, long lda, long ldb, long sA, long sB,
+                 int batch) {
+  // few output tiles and a long contraction (weight gradients: K = every row of the batch): split K so that the launch has
+  // ~768 workgroups, each split at least 64 deep, the partial tiles at most ~48 MB (written and read once by k_gemm_reduce)
+  int bm, bn;
+  gemm_tile(M, N, K, batch, gemm_lds_ok(ta, tb, A, B, M, N, K, lda, ldb, sA, sB), &bm, &bn);
+  const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
   if (tiles >= 384 || K < 256) return 1;
   long s = std::min<long>((768 + tiles - 1) / tiles, K / 64);
   const long out_bytes = (long)M * N * batch * 4;
@@ -793,33 +808,36 @@ hipError_t launch_gemm_f32(bool ta, bool tb, const float* A, const float* B, flo
   int kchunk = (K + ksplits - 1) / ksplits;
   kchunk = (kchunk + 15) / 16 * 16;
   ksplits = (K + kchunk - 1) / kchunk;
-  // the LDS-staged kernel needs 16-byte pieces along each operand's contiguous dimension; anything else takes the
-  // register-direct kernel
-  const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  const bool a_ok = al16(A) && lda % 4 == 0 && sA % 4 == 0 && (ta ? M % 4 == 0 : K % 4 == 0);
-  const bool b_ok = al16(B) && ldb % 4 == 0 && sB % 4 == 0 && (tb ? K % 4 == 0 : N % 4 == 0);
-  const bool lds_ok = a_ok && b_ok && K >= 4 && M >= 4 && N >= 4;
-  const bool small = gemm_tile_rows(M, N, batch) == 64;
-  const dim3 grid((N + 127) / 128, small ? (M + 63) / 64 : (M + 127) / 128, batch * ksplits);
-#define GMF_GEMM(KERNEL, TA, TB)                                                                                                 \
-  do {                                                                                                                           \
-    if (small) hipLaunchKernelGGL((KERNEL<TA, TB, 1>), grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA, sB,   \
-                                  sC, ksplits, kchunk, alpha, part, relu);                                                      \
-    else hipLaunchKernelGGL((KERNEL<TA, TB, 2>), grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA, sB, sC,    \
-                            ksplits, kchunk, alpha, part, relu);                                                                \
+  const bool lds_ok = gemm_lds_ok(ta, tb, A, B, M, N, K, lda, ldb, sA, sB);    // anything else takes the register-direct kernel
+  int bm, bn;
+  gemm_tile(M, N, K, batch, lds_ok, &bm, &bn);
+  const dim3 grid((N + bn - 1) / bn, (M + bm - 1) / bm, batch * ksplits);
+#define GMF_GEMM_ARGS grid, dim3(256), 0, s, A, B, C, bias, R, M, N, K, lda, ldb, ldc, sA, sB, sC, ksplits, kchunk, alpha, part, relu
+#define GMF_GEMM_LDS(TA, TB)                                                                         \
+  do {                                                                                               \
+    if (bm == 64 && bn == 64) hipLaunchKernelGGL((k_gemm_lds<TA, TB, 1, 1>), GMF_GEMM_ARGS);         \
+    else if (bm == 64) hipLaunchKernelGGL((k_gemm_lds<TA, TB, 1, 2>), GMF_GEMM_ARGS);                \
+    else hipLaunchKernelGGL((k_gemm_lds<TA, TB, 2, 2>), GMF_GEMM_ARGS);                              \
+  } while (0)
+#define GMF_GEMM_DIRECT(TA, TB)                                                                      \
+  do {                                                                                               \
+    if (bm == 64) hipLaunchKernelGGL((k_gemm_f32<TA, TB, 1>), GMF_GEMM_ARGS);                        \
+    else hipLaunchKernelGGL((k_gemm_f32<TA, TB, 2>), GMF_GEMM_ARGS);                                 \
   } while (0)
   if (lds_ok) {
-    if (ta && tb) GMF_GEMM(k_gemm_lds, true, true);
-    else if (ta) GMF_GEMM(k_gemm_lds, true, false);
-    else if (tb) GMF_GEMM(k_gemm_lds, false, true);
-    else GMF_GEMM(k_gemm_lds, false, false);
+    if (ta && tb) GMF_GEMM_LDS(true, true);
+    else if (ta) GMF_GEMM_LDS(true, false);
+    else if (tb) GMF_GEMM_LDS(false, true);
+    else GMF_GEMM_LDS(false, false);
   } else {
-    if (ta && tb) GMF_GEMM(k_gemm_f32, true, true);
-    else if (ta) GMF_GEMM(k_gemm_f32, true, false);
-    else if (tb) GMF_GEMM(k_gemm_f32, false, true);
-    else GMF_GEMM(k_gemm_f32, false, false);
+    if (ta && tb) GMF_GEMM_DIRECT(true, true);
+    else if (ta) GMF_GEMM_DIRECT(true, false);
+    else if (tb) GMF_GEMM_DIRECT(false, true);
+    else GMF_GEMM_DIRECT(false, false);
   }
-#undef GMF_GEMM
+#undef GMF_GEMM_LDS
+#undef GMF_GEMM_DIRECT
+#undef GMF_GEMM_ARGS
   if (ksplits > 1) {
     const long total = (long)batch * M * N;
     const int groups = ksplits > 64 ? 16 : ksplits > 32 ? 8 : ksplits > 16 ? 4 : ksplits > 8 ? 2 : 1;

@@ -68,12 +68,20 @@ def test_shard_range_covers_batch():
 import pytest
 
 
-@pytest.mark.parametrize("B,port", [(6, 29731), (5, 29733)])
-def test_two_rank_gloo_matches_single_process(B, port):
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+@pytest.mark.parametrize("B", [6, 5])
+def test_two_rank_gloo_matches_single_process(B):
     """6 pairs over 2 ranks (equal shards) and 5 pairs over 2 ranks (3 + 2: padded to the larger shard inside the packed
     buffer and trimmed after the gather): every rank ends with the single-process result bit for bit, after exactly ONE
     collective per step."""
     world = 2
+    port = _free_port()                  # (a fixed port can still be held by a previous run)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, B)) for r in range(world)]

@@ -979,8 +979,8 @@ def test_sharded_driver_one_rank_rccl(model):
     (The 2-rank logic, uneven shards included, is covered on gloo in tests/test_dist_gloo.py.)"""
     import torch.distributed as dist
     from gmf_amd.dist import ShardedBatchDriver
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29741")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
     b = synthetic.synthetic_batch([5, 6, 7], N=300, T=40)
     data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
     data["testing"] = True
@@ -998,6 +998,13 @@ def test_sharded_driver_one_rank_rccl(model):
         assert torch.equal(out2["all_logits"], out["all_logits"])
     finally:
         drv.close()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def _two_rank_worker(rank, world, port, q):
@@ -1032,7 +1039,8 @@ def test_two_process_sharded_forward_on_one_gpu(model):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, 29763, q)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(2)]

@@ -238,6 +238,8 @@ class NonLocalNet(nn.Module):
         super().__init__()
         if num_channels != 128:
             raise NotImplementedError("gmf_amd.NonLocalNet: HIP kernels are built for num_channels=128")
+        if not 1 <= in_dim <= 8:
+            raise NotImplementedError("gmf_amd.NonLocalNet: the layer0 kernel takes 1 <= in_dim <= 8 (GMF uses 6)")
         self.num_layers = num_layers
         self.blocks = nn.ModuleDict()
         self.layer0 = nn.Conv1d(in_dim, num_channels, 1, bias=True)
@@ -323,6 +325,10 @@ class PointDSC(nn.Module):
     def __init__(self, in_dim=6, num_layers=6, num_channels=128, num_iterations=10, ratio=0.1,
                  inlier_threshold=0.10, sigma_d=0.10, k=40, nms_radius=0.10):
         super().__init__()
+        if not 1 <= k <= 64:
+            raise NotImplementedError("gmf_amd.PointDSC: the seed kernels hold one neighbour per lane: 1 <= k <= 64 (GMF uses 40)")
+        if not 1 <= num_iterations <= 64:
+            raise NotImplementedError("gmf_amd.PointDSC: 1 <= num_iterations <= 64 (GMF uses 10)")
         self.num_iterations = num_iterations
         self.ratio = ratio
         self.num_channels = num_channels

@@ -191,3 +191,14 @@ def test_oracle_is_only_reachable_from_the_checkers():
                     if pat.search(open(p, errors="ignore").read()):
                         offenders.append(os.path.relpath(p, root))
     assert offenders == []
+
+
+def test_unsupported_configurations_are_refused_at_construction():
+    """Configurations the kernels are not built for raise NotImplementedError when the module is constructed (on any
+    host), not an assertion somewhere inside a forward."""
+    import pytest
+    import gmf_amd
+    for kw in (dict(num_channels=64), dict(in_dim=12), dict(k=100), dict(num_iterations=0)):
+        with pytest.raises(NotImplementedError):
+            gmf_amd.PointDSC(**kw)
+    gmf_amd.PointDSC(in_dim=6, num_layers=3, k=40)        # what GMF instantiates (with 12 layers) constructs anywhere

@@ -1,0 +1,56 @@
+"""Soak test (GPU box): the same forward many times over - every result must be bitwise equal to the first (a missed wait or
+a racing refill in a hand-scheduled kernel shows up as a flipped bit sooner or later).  Both numerics modes, large, mid-size
+and small grids, and a training step's gradients.
+    python tools/soak_determinism.py [repeats]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gmf_amd                                   # noqa: E402
+from gmf_amd import synthetic                    # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+dev = torch.device("cuda:0")
+sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7)
+model = gmf_amd.PointDSC(num_layers=12)
+model.load_state_dict(sd, strict=False)
+model = model.to(dev).eval()
+bad = 0
+for B, N, mode, n in ((32, 5000, "parity", reps // 4), (32, 5000, "throughput", reps // 4), (33, 1000, "parity", reps), (1, 5000, "parity", reps),
+                      (1, 1000, "parity", reps), (3, 3001, "parity", reps // 2), (16, 10000, "throughput", reps // 8)):
+    model.set_precision(mode)
+    b = synthetic.synthetic_batch(list(range(B)), N=N, T=196)
+    data = {k: b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    ref = model(data)
+    lg0, T0 = model.last_logits.clone(), ref["final_trans"].clone()
+    diff = 0
+    for _ in range(max(n, 2)):
+        out = model(data)
+        if not (torch.equal(model.last_logits, lg0) and torch.equal(out["final_trans"], T0)):
+            diff += 1
+    bad += diff
+    print(f"B={B} N={N} {mode}: {max(n, 2)} repeats, {diff} differ", flush=True)
+model.set_precision("parity")
+# training step: the gradients of two identical steps from identical weights
+m = gmf_amd.PointDSC(num_layers=3)
+m.load_state_dict(synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 3, 128), seed=7), strict=False)
+m = m.to(dev).train()
+b = synthetic.synthetic_batch([1, 2, 3, 4], N=500, T=40)
+data = {k: b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+gt = b["gt_labels"].to(dev)
+state = {k: v.clone() for k, v in m.state_dict().items()}
+grads = []
+for _ in range(max(reps // 20, 3)):
+    m.load_state_dict(state)
+    m.zero_grad()
+    res = m(data)
+    loss = gmf_amd.ClassificationLoss(balanced=False)(res["final_labels"], gt)["loss"] + gmf_amd.SpectralMatchingLoss(balanced=False)(res["M"], gt)
+    loss.backward()
+    grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None]).clone())
+d = sum(int(not torch.equal(g, grads[0])) for g in grads[1:])
+bad += d
+print(f"training step: {len(grads)} repeats, {d} differ", flush=True)
+print("DETERMINISTIC" if bad == 0 else f"NON-DETERMINISTIC: {bad}")

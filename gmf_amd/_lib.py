@@ -74,7 +74,7 @@ SIGNATURES = {
     "gmf_nonlocal_block_forward": (C.c_int, [_vp, C.POINTER(EncoderWeights), C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp,
                                              C.c_int, C.c_int, C.c_int, _vp]),
     "gmf_fusion_layer_forward": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll,
-                                           _ll, _vp, _ll, _ll, _ll, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+                                           _ll, _vp, _ll, _ll, _ll, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "gmf_pose_head": (C.c_int, [_vp, C.POINTER(PoseParams), _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
     "gmf_pick_seeds": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _vp, _vp]),

@@ -23,6 +23,10 @@ constexpr int DHW = 128;       // head width
 constexpr int DHWF = DHW / 2;
 constexpr int FFHW = 4 * LAT;  // GEGLU hidden width (value half)
 constexpr int kWaves = 4;
+#ifndef GMF_RING_W
+#define GMF_RING_W 4
+#endif
+constexpr int kRingW = GMF_RING_W;   // LDS ring depth of the split-fp16 kernels' stage streams (8 measured no faster: the stages are not what these kernels wait for)
 
 GMF_DEVINL void load_vec16(float (&v)[16], const float* __restrict__ vec, int mb, int h) {
   const float4* p = reinterpret_cast<const float4*>(vec + 32 * mb) + h;
@@ -330,11 +334,13 @@ k_fusion_ff_w(const float* __restrict__ x1, const float* __restrict__ wst, const
 //   lo-plane stage al*xh).  Single-range GELU (enc_common.hpp).  One wave per SIMD: x (128 VGPRs as two fp16 planes) and
 //   the eight output accumulators (128) stay in registers.
 // ---------------------------------------------------------------------------------------------
+// Small grids (M < ~6000 voxels is the usual size of the DGR bottleneck): gridDim.z = hs workgroups per row block take
+// 32 / hs hidden chunks each and store their raw partial sums to part[z]; k_ff_reduce_w adds them in index order.
 __global__ void __launch_bounds__(256, 1)
 k_fusion_ff_w_h2(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
-                 float* __restrict__ x2_out, int tiles) {
+                 float* __restrict__ x2_out, int tiles, float* __restrict__ part) {
   using namespace wide;
-  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kRingW * kStageFloats];
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y;
@@ -343,8 +349,9 @@ k_fusion_ff_w_h2(const float* __restrict__ x1, const float* __restrict__ wst, co
   const int tile = active ? tile_raw : tiles - 1;
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * LAT);
 
-  StageRing<4> ss;
-  ss.init(lds, wave, lane, wst, 6 * (FFHW / 32));
+  const int hs = gridDim.z, n_chunks = (FFHW / 32) / hs, c0 = blockIdx.z * n_chunks;
+  StageRing<kRingW> ss;
+  ss.init(lds, wave, lane, wst + (size_t)c0 * 6 * kStageFloats, 6 * n_chunks);
   ss.prime();
   FragH2<16> nx;
   {
@@ -368,7 +375,7 @@ k_fusion_ff_w_h2(const float* __restrict__ x1, const float* __restrict__ wst, co
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = mfma_h16(lw[s * 64], nx.h[s], acc);
   };
-  for (int c = 0; c < FFHW / 32; ++c) {
+  for (int c = c0; c < c0 + n_chunks; ++c) {
     float ga[16];
     {
       float b[16];
@@ -399,6 +406,13 @@ k_fusion_ff_w_h2(const float* __restrict__ x1, const float* __restrict__ wst, co
       for (int m4 = 0; m4 < 4; ++m4) mma_wx_h2<2>(y[4 * half + m4], lw + m4 * (2 * 2 * 64), gx);
     }
   }
+  if (hs > 1) {
+    float* dst = part + (size_t)blockIdx.z * ((size_t)gridDim.y * tiles * (32 * LAT)) + toff;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+      if (active) store_timg(dst, mb, y[mb], lane);          // (same 16-byte units as store_blk)
+    return;
+  }
 #pragma unroll
   for (int mb = 0; mb < 8; ++mb) {
     float b[16], xr[16], t[16];
@@ -407,6 +421,210 @@ k_fusion_ff_w_h2(const float* __restrict__ x1, const float* __restrict__ wst, co
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = fmaf(y[mb][r], kH2Inv, b[r]) + xr[r];
     if (active) store_blk<LAT>(x2_out + toff, mb, t, lane);
+  }
+}
+
+// x2 = sum_z part[z] * 2^-8 + b2 + x1 (z in index order).  grid (ceil(tiles/4), B, 8): a wave adds one 32 x 32 block.
+__global__ void __launch_bounds__(256)
+k_ff_reduce_w(const float* __restrict__ part, const float* __restrict__ x1, const float* __restrict__ vecs,
+              float* __restrict__ x2_out, int tiles, int hs) {
+  using namespace wide;
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int tile = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (tile >= tiles) return;
+  const int mb = blockIdx.z;
+  const size_t n_all = (size_t)gridDim.y * tiles * (32 * LAT);
+  const size_t toff = ((size_t)blockIdx.y * tiles + tile) * (32 * LAT);
+  float b[16], xr[16], p[8][16];
+  load_vec16(b, vecs + 2 * LAT + 2 * FFHW, mb, h);
+#pragma unroll
+  for (int z = 0; z < 8; ++z)
+    if (z < hs) load_blk<LAT>(p[z], part + (size_t)z * n_all + toff, mb, lane);
+  load_blk<LAT>(xr, x1 + toff, mb, lane);
+  float t[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[r] = p[0][r];
+#pragma unroll
+  for (int z = 1; z < 8; ++z)
+    if (z < hs) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] += p[z][r];
+    }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[r] = fmaf(t[r], kH2Inv, b[r]) + xr[r];
+  store_blk<LAT>(x2_out + toff, mb, t, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ctx_prep_w_h2 / k_fusion_attn_w_h2: the context preparation and the cross-attention of the 256-wide layer on the f16 MFMA
+// with split-fp16 operands, like its feed-forward above (same arithmetic as k_ctx_prep_h2 / k_fusion_attn_h2 of the
+// 128-wide layer, encoder_h2.hip; 5.3x fewer matrix cycles than k_ctx_prep_w / k_fusion_attn_w).  Weight images from
+// packing.p32_h2s (256 W; 2^-8 folded into the epilogues), same blob sizes and stage counts as the fp32 images:
+//   ctx : Wk[4] | Wv[4]                     a 32 x 128 block is one stage [plane][8 k-steps][lane][8 halfs]
+//   attn: Wq''[4 x (hi plane | lo plane)]   a 32 x 256 block is two stages [16 k-steps][lane][8 halfs] (hi: wh*xl + wh*xh, lo: wl*xh)
+//         | Wo[8]                           32 x 128 blocks
+// Context image per token tile (2 stages, as before): Kc | Vc as fp16x2 images for d_head = 128:
+//   Kc unit ((plane*8 + s)*64 + lane), Vc unit ((plane*8 + slot)*64 + lane), slot = 2*db + s2.
+// ---------------------------------------------------------------------------------------------
+template <bool PE>
+__global__ void __launch_bounds__(256, 1)
+k_ctx_prep_w_h2(const float* __restrict__ ctx, const float* __restrict__ wst, const float* __restrict__ vecs,
+                float* __restrict__ out, int T, int ttiles) {
+  __shared__ __attribute__((aligned(16))) float lds[kRingW * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWaves + wave;
+  const bool active = tile_raw < ttiles;
+  const int tile = active ? tile_raw : ttiles - 1;
+  const float* pair_base = ctx + (size_t)pair * ttiles * (32 * CX);
+  float* dst = out + ((size_t)pair * ttiles + tile) * (2 * kStageFloats);
+
+  StageRing<kRingW> ss;
+  ss.init(lds, wave, lane, wst, 8);
+  ss.prime();
+  FragH2<8> cx;
+  {
+    float x[CXF], cn[CXF];
+    if (PE) lcpe_w<CXF>(x, pair_base, tile * 32 + i, T, vecs, h);
+    else load_frag_p32<CXF>(x, pair_base + (size_t)tile * (32 * CX), lane);
+    layernorm_frag<CXF>(cn, x, vecs + 4 * CX, vecs + 5 * CX, h);
+    cx.set(cn);
+  }
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const f16x8* lw = as_h2(ss.acquire());
+    f32x16 acc = zero16();
+    mma_wx_h2<8>(acc, lw, cx);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = acc[r] * kH2Inv;
+    if (active) store_block_h2(dst, mb, t, lane);
+  }
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const f16x8* lw = as_h2(ss.acquire());
+    f32x16 acc = zero16();
+    mma_xw_h2<8>(acc, lw, cx);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = acc[r] * kH2Inv;
+    if (active) store_block_h2(dst + kStageFloats, db, t, lane);
+  }
+}
+
+template <bool PE>
+__global__ void __launch_bounds__(256, 1)
+k_fusion_attn_w_h2(const float* __restrict__ xin, const float* __restrict__ ctx_img, const float* __restrict__ wst,
+                   const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
+  __shared__ __attribute__((aligned(16))) float lds[kRingW * kStageFloats];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int tile_raw = blockIdx.x * kWaves + wave;
+  const bool active = tile_raw < tiles;
+  const int tile = active ? tile_raw : tiles - 1;
+  const float* pair_base = xin + (size_t)pair * tiles * (32 * LAT);
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * LAT);
+
+  StageRing<kRingW> ss;
+  ss.init(lds, wave, lane, wst, 8, ctx_img + (size_t)pair * ttiles * (2 * kStageFloats), 2 * ttiles, wst + 8 * kStageFloats, 8);
+  ss.prime();
+
+  // one wave per SIMD (512 VGPRs): x' (128), its two fp16 planes (128) and the Q fragment (64) are live together
+  float xp[LATF];
+  if (PE) lcpe_w<LATF>(xp, pair_base, tile * 32 + i, N, vecs, h);
+  else load_frag_p32<LATF>(xp, pair_base + (size_t)tile * (32 * LAT), lane);
+  FragH2<8> qx;
+  {
+    FragH2<16> nx;
+    {
+      float xn[LATF];
+      layernorm_frag<LATF>(xn, xp, vecs + 4 * LAT, vecs + 5 * LAT, h);
+      nx.set(xn);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      f32x16 acc = zero16();
+      const f16x8* lw = as_h2(ss.acquire());              // hi plane, 16 k-steps
+#pragma unroll
+      for (int s = 0; s < 16; ++s) { const f16x8 wh = lw[s * 64]; acc = mfma_h16(wh, nx.l[s], acc); acc = mfma_h16(wh, nx.h[s], acc); }
+      lw = as_h2(ss.acquire());                           // lo plane
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = mfma_h16(lw[s * 64], nx.h[s], acc);
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = acc[r] * kH2Inv;
+      qx.set_block(mb, t);
+    }
+  }
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
+  float m_run = -INFINITY, l_half = 0.f;
+  for (int t = 0; t < ttiles; ++t) {
+    f32x16 s = zero16();
+    {
+      const f16x8* lk = as_h2(ss.acquire());
+      mma_wx_h2<8>(s, lk, qx);
+    }
+    float x[16];
+    float mx = -INFINITY;
+    const int jbase = t * 32 + 4 * h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jl = 8 * (r >> 2) + (r & 3);
+      const float v = (jbase + jl < T) ? s[r] : -INFINITY;
+      x[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    const float m_off = m_new - 10.0f;                    // P' = 2^10 P: its lo plane stays a normal fp16 number
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
+    l_half = fmaf(l_half, alpha, ls);
+    const f16x8* lv = as_h2(ss.acquire());
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f16x8 ph, pl;
+      split8h(&x[8 * s2], ph, pl);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int slot = 2 * db + s2;
+        mma3(oacc[db], lv[(0 * 8 + slot) * 64], lv[(1 * 8 + slot) * 64], ph, pl);
+      }
+    }
+  }
+  FragH2<8> ox;
+  {
+    const float inv = 1.0f / xhalf_sum(l_half);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = oacc[db][r] * inv;
+      ox.set_block(db, t);
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const f16x8* lw = as_h2(ss.acquire());
+    f32x16 acc = zero16();
+    mma_wx_h2<8>(acc, lw, ox);
+    float b[16], t[16];
+    load_vec16(b, vecs + 6 * LAT, mb, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, b[r]) + xp[16 * mb + r];
+    if (active) store_blk<LAT>(x1_out + toff, mb, t, lane);
   }
 }
 
@@ -427,8 +645,36 @@ hipError_t launch_fusion_attn_w(bool pe, const float* x, const float* ctx_img, c
   return hipGetLastError();
 }
 
-hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const float* vecs, float* x2, int B, int tiles, hipStream_t s) {
-  hipLaunchKernelGGL(k_fusion_ff_w_h2, wgrid(tiles, B), dim3(256), 0, s, x1, wst_h2, vecs, x2, tiles);
+hipError_t launch_ctx_prep_w_h2(bool pe, const float* ctx, const float* wst_h2, const float* vecs, float* out, int B, int T,
+                                int ttiles, hipStream_t s) {
+  if (pe) hipLaunchKernelGGL(k_ctx_prep_w_h2<true>, wgrid(ttiles, B), dim3(256), 0, s, ctx, wst_h2, vecs, out, T, ttiles);
+  else hipLaunchKernelGGL(k_ctx_prep_w_h2<false>, wgrid(ttiles, B), dim3(256), 0, s, ctx, wst_h2, vecs, out, T, ttiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_fusion_attn_w_h2(bool pe, const float* x, const float* ctx_img, const float* wst_h2, const float* vecs,
+                                   float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s) {
+  if (pe) hipLaunchKernelGGL(k_fusion_attn_w_h2<true>, wgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst_h2, vecs, x1, N, tiles, T, ttiles);
+  else hipLaunchKernelGGL(k_fusion_attn_w_h2<false>, wgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst_h2, vecs, x1, N, tiles, T, ttiles);
+  return hipGetLastError();
+}
+
+// hidden splits of the wide feed-forward: one workgroup per CU, so as many as keep the grid within the 256 CUs
+int plan_ff_split_w(int base_wgs) {
+  int hs = 1;
+  while (hs < 8 && base_wgs * hs * 2 <= 256) hs *= 2;
+  return hs;
+}
+
+hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const float* vecs, float* x2, int B, int tiles, hipStream_t s,
+                                 float* part, int hs) {
+  const dim3 g = wgrid(tiles, B);
+  if (part && hs > 1) {
+    hipLaunchKernelGGL(k_fusion_ff_w_h2, dim3(g.x, g.y, hs), dim3(256), 0, s, x1, wst_h2, vecs, x2, tiles, part);
+    hipLaunchKernelGGL(k_ff_reduce_w, dim3(g.x, g.y, 8), dim3(256), 0, s, part, x1, vecs, x2, tiles, hs);
+  } else {
+    hipLaunchKernelGGL(k_fusion_ff_w_h2, g, dim3(256), 0, s, x1, wst_h2, vecs, x2, tiles, (float*)nullptr);
+  }
   return hipGetLastError();
 }
 

@@ -513,9 +513,12 @@ int gmf_fusion_layer_forward(gmf_handle* h, int pe, int latent_dim, int d_head, 
                              const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec,
                              const float* data, const float* queries, long long q_sb, long long q_sr, long long q_sk,
                              float* out, long long o_sb, long long o_sr, long long o_sk, int B, int N, int T,
-                             gmf_stream_t stream, const float* ff_wst_h2) {
+                             gmf_stream_t stream, const float* ff_wst_h2, const float* ctx_wst_h2, const float* attn_wst_h2) {
   GMF_REQUIRE(h && ctx_wst && ctx_vec && attn_wst && attn_vec && ff_wst && ff_vec && data && queries && out,
               GMF_ERR_BAD_ARG, "fusion_layer_forward: null pointer");
+  GMF_REQUIRE((ctx_wst_h2 == nullptr) == (attn_wst_h2 == nullptr), GMF_ERR_BAD_ARG,
+              "fusion_layer_forward: ctx_wst_h2 and attn_wst_h2 go together (the attention reads the context image the "
+              "context kernel of the same kind writes)");
   GMF_REQUIRE(B > 0 && N > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "fusion_layer_forward: empty input");
   const bool narrow = (latent_dim == 128 && d_head == 64), wide = (latent_dim == 256 && d_head == 128);
   GMF_REQUIRE(narrow || wide, GMF_ERR_UNSUPPORTED_SHAPE,
@@ -526,23 +529,38 @@ int gmf_fusion_layer_forward(gmf_handle* h, int pe, int latent_dim, int d_head, 
   const size_t act = (size_t)B * tiles * 32 * latent_dim;
   const size_t tok = (size_t)B * tt * kTileFloats;
   const size_t ctxsz = wide ? 2 * tok : tok;
-  if (int rc = arena_reserve(h, 3 * arena_need(act, 4) + arena_need(tok, 4) + arena_need(ctxsz, 4))) return rc;
+  // small grids of the wide layer: the feed-forward's hidden chunks are split over hs workgroups per row block
+  const int ff_hs_w = (wide && ff_wst_h2 && h->tune.ff_split != 1) ?
+                          (h->tune.ff_split > 1 ? h->tune.ff_split : gmf::plan_ff_split_w(((tiles + 3) / 4) * B)) : 1;
+  if (int rc = arena_reserve(h, 3 * arena_need(act, 4) + arena_need(tok, 4) + arena_need(ctxsz, 4) +
+                                    (ff_hs_w > 1 ? arena_need((size_t)ff_hs_w * act, 4) : 0))) return rc;
   float* xin = arena_take<float>(h, act);
   float* x1 = arena_take<float>(h, act);
   float* x2 = arena_take<float>(h, act);
   float* cimg = arena_take<float>(h, tok);
   float* ctx = arena_take<float>(h, ctxsz);
+  float* ff_part_w = ff_hs_w > 1 ? arena_take<float>(h, (size_t)ff_hs_w * act) : nullptr;
   GMF_HIP(gmf::launch_pack_p32(data, cimg, B, T, kC, (long)T * kC, kC, 1, st));
   GMF_HIP(gmf::launch_pack_p32(queries, xin, B, N, latent_dim, q_sb, q_sr, q_sk, st));
   if (narrow) {
-    GMF_HIP(gmf::launch_ctx_prep(pe != 0, cimg, ctx_wst, ctx_vec, ctx, B, T, tt, 1, 0, 0, st));
-    GMF_HIP(gmf::launch_fusion_attn(pe != 0, xin, ctx, attn_wst, attn_vec, x1, B, N, tiles, T, tt, st));
+    if (attn_wst_h2) {
+      GMF_HIP(gmf::launch_ctx_prep_h2(pe != 0, cimg, ctx_wst_h2, ctx_vec, ctx, B, T, tt, 1, 0, 0, st));
+      GMF_HIP(gmf::launch_fusion_attn_h2(pe != 0, xin, ctx, attn_wst_h2, attn_vec, x1, B, N, tiles, T, tt, st));
+    } else {
+      GMF_HIP(gmf::launch_ctx_prep(pe != 0, cimg, ctx_wst, ctx_vec, ctx, B, T, tt, 1, 0, 0, st));
+      GMF_HIP(gmf::launch_fusion_attn(pe != 0, xin, ctx, attn_wst, attn_vec, x1, B, N, tiles, T, tt, st));
+    }
     if (ff_wst_h2) GMF_HIP(gmf::launch_fusion_ff_h2(h->tune, x1, ff_wst_h2, ff_vec, x2, B, tiles, st));
     else GMF_HIP(gmf::launch_fusion_ff(x1, ff_wst, ff_vec, x2, B, tiles, st));
   } else {
-    GMF_HIP(gmf::launch_ctx_prep_w(pe != 0, cimg, ctx_wst, ctx_vec, ctx, B, T, tt, st));
-    GMF_HIP(gmf::launch_fusion_attn_w(pe != 0, xin, ctx, attn_wst, attn_vec, x1, B, N, tiles, T, tt, st));
-    if (ff_wst_h2) GMF_HIP(gmf::launch_fusion_ff_w_h2(x1, ff_wst_h2, ff_vec, x2, B, tiles, st));
+    if (attn_wst_h2) {
+      GMF_HIP(gmf::launch_ctx_prep_w_h2(pe != 0, cimg, ctx_wst_h2, ctx_vec, ctx, B, T, tt, st));
+      GMF_HIP(gmf::launch_fusion_attn_w_h2(pe != 0, xin, ctx, attn_wst_h2, attn_vec, x1, B, N, tiles, T, tt, st));
+    } else {
+      GMF_HIP(gmf::launch_ctx_prep_w(pe != 0, cimg, ctx_wst, ctx_vec, ctx, B, T, tt, st));
+      GMF_HIP(gmf::launch_fusion_attn_w(pe != 0, xin, ctx, attn_wst, attn_vec, x1, B, N, tiles, T, tt, st));
+    }
+    if (ff_wst_h2) GMF_HIP(gmf::launch_fusion_ff_w_h2(x1, ff_wst_h2, ff_vec, x2, B, tiles, st, ff_part_w, ff_hs_w));
     else GMF_HIP(gmf::launch_fusion_ff_w(x1, ff_wst, ff_vec, x2, B, tiles, st));
   }
   GMF_HIP(gmf::launch_unpack_p32(x2, out, B, N, latent_dim, o_sb, o_sr, o_sk, st));

@@ -66,7 +66,13 @@ hipError_t launch_ctx_prep_w(bool pe, const float* ctx, const float* wst, const 
 hipError_t launch_fusion_attn_w(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
                                 float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
 hipError_t launch_fusion_ff_w(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
-hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
+hipError_t launch_ctx_prep_w_h2(bool pe, const float* ctx, const float* wst_h2, const float* vecs, float* out, int B, int T,
+                                int ttiles, hipStream_t s);
+hipError_t launch_fusion_attn_w_h2(bool pe, const float* x, const float* ctx_img, const float* wst_h2, const float* vecs,
+                                   float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
+hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const float* vecs, float* x2, int B, int tiles, hipStream_t s,
+                                 float* part = nullptr, int hs = 1);
+int plan_ff_split_w(int base_wgs);
 hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
                            float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s);
 // mode 3: corr_pos -> layer0 -> PointCN -> f only.  launch_linear_h2: all linear stages of one layer from f (k_linear_h2)

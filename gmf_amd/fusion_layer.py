@@ -76,6 +76,7 @@ class FusionLayer(nn.Module):
         self._packed = None
         self._packed_version = None
         self.split_fp16_ff = True      # feed-forward on the f16 MFMA with split-fp16 operands (False: fp32 MFMA, for A/B runs)
+        self.split_fp16_attn = True    # context preparation + cross-attention likewise
 
     def _blobs(self, device):
         ver = (params_version(self), str(device))
@@ -83,11 +84,12 @@ class FusionLayer(nn.Module):
             sd = {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()}
             packed = packing.pack_fusion(sd, "", self.pe)
             try:
-                packed["ff_wst_h2"] = packing.pack_fusion(sd, "", self.pe, img=packing.p32_h2s)["ff_wst"]
-            except ValueError as e:          # a weight outside the fp16 range: feed-forward on the fp32 MFMA, said once per pack
+                h2 = packing.pack_fusion(sd, "", self.pe, img=packing.p32_h2s)
+                packed["ff_wst_h2"], packed["ctx_wst_h2"], packed["attn_wst_h2"] = h2["ff_wst"], h2["ctx_wst"], h2["attn_wst"]
+            except ValueError as e:          # a weight outside the fp16 range: the layer on the fp32 MFMA, said once per pack
                 import warnings
-                warnings.warn(f"{e}  The feed-forward of this FusionLayer runs on the fp32 MFMA.", RuntimeWarning)
-                packed["ff_wst_h2"] = None
+                warnings.warn(f"{e}  This FusionLayer runs on the fp32 MFMA.", RuntimeWarning)
+                packed["ff_wst_h2"] = packed["ctx_wst_h2"] = packed["attn_wst_h2"] = None
             self._packed = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in packed.items()}
             self._packed_version = ver
         return self._packed
@@ -117,5 +119,7 @@ class FusionLayer(nn.Module):
                blobs["attn_vec"].data_ptr(), blobs["ff_wst"].data_ptr(), blobs["ff_vec"].data_ptr(),
                data.data_ptr(), x.data_ptr(), x.stride(0), x.stride(1), x.stride(2),
                out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), B, N, T, st,
-               blobs["ff_wst_h2"].data_ptr() if (self.split_fp16_ff and blobs["ff_wst_h2"] is not None) else None)
+               blobs["ff_wst_h2"].data_ptr() if (self.split_fp16_ff and blobs["ff_wst_h2"] is not None) else None,
+               *((blobs["ctx_wst_h2"].data_ptr(), blobs["attn_wst_h2"].data_ptr())
+                 if (self.split_fp16_attn and blobs["attn_wst_h2"] is not None) else (None, None)))
         return out

@@ -176,12 +176,14 @@ int gmf_nonlocal_block_forward(gmf_handle* h, const gmf_encoder_weights* w, int 
  * image_fusion (resunet_new.py:618-626); (256, 128) is the DGR bottleneck instance (resunet_new.py:516-525)
  * whose to_out maps the head back to the 256-wide query.  Weight blobs: gmf_amd/packing.py.
  * ff_wst_h2 (may be NULL): the feed-forward weights as split-fp16 images (packing.p32_h2, same size as ff_wst); when
- * given, the GEGLU feed-forward - 96 % of this layer's FLOPs - runs on the f16 MFMA with fp32-equivalent accuracy. */
+ * given, the GEGLU feed-forward - 96 % of this layer's FLOPs - runs on the f16 MFMA with fp32-equivalent accuracy.
+ * ctx_wst_h2 / attn_wst_h2 (both or neither): the context and attention weights as
+ * split-fp16 images (packing.p32_h2s, same sizes) - context preparation and cross-attention on the f16 MFMA as well. */
 int gmf_fusion_layer_forward(gmf_handle* h, int pe, int latent_dim, int d_head, const float* ctx_wst, const float* ctx_vec,
                              const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec,
                              const float* data, const float* queries, long long q_sb, long long q_sr, long long q_sk,
                              float* out, long long o_sb, long long o_sr, long long o_sk, int B, int N, int T,
-                             gmf_stream_t stream, const float* ff_wst_h2);
+                             gmf_stream_t stream, const float* ff_wst_h2, const float* ctx_wst_h2, const float* attn_wst_h2);
 
 /* ---- pose head ------------------------------------------------------------------------------- */
 typedef struct gmf_pose_params {

@@ -78,8 +78,10 @@ def test_f1_fusion1(golden_dir):
     m = m.to(DEV).eval()
     for T in (12, 196, 300):
         b = synthetic.synthetic_batch(list(g["pair_seeds"]), N=8, T=T)
-        y = m(_gpu(b["p_tokens"]), queries_encoder=_gpu(b["q_tokens"]))
-        assert _maxerr(y.cpu(), g[f"out_T{T}"]) < 1e-4
+        for h2_attn in (True, False):          # context preparation + cross-attention on split-fp16 operands / on the fp32 MFMA
+            m.split_fp16_attn = h2_attn
+            y = m(_gpu(b["p_tokens"]), queries_encoder=_gpu(b["q_tokens"]))
+            assert _maxerr(y.cpu(), g[f"out_T{T}"]) < 1e-4, (T, h2_attn)
 
 
 @pytest.mark.parametrize("N,T", [(64, 12), (257, 196), (1000, 196), (33, 1), (1, 7)])
@@ -98,24 +100,40 @@ def test_f2_fusion2(golden_dir, N, T):
     # the reference feeds a transposed [B,C,N] view (PointDSC.py:70): strided queries must give the same result
     xt = _gpu(x).permute(0, 2, 1).contiguous().permute(0, 2, 1)
     assert torch.equal(m(_gpu(ctx), queries_encoder=xt), y)
+    m.split_fp16_attn = False                  # the fp32-MFMA form of context preparation + cross-attention
+    assert _maxerr(m(_gpu(ctx), queries_encoder=_gpu(x)).cpu(), g[f"out_N{N}_T{T}"]) < 1e-4
 
 
+@pytest.mark.parametrize("h2_attn", [True, False])
 @pytest.mark.parametrize("M,T", [(100, 12), (515, 300)])
-def test_f9_dgr_perceiver_256(golden_dir, M, T):
-    """DGR bottleneck instance: latent 256, context 128, one head of 128 (resunet_new.py:516-525)."""
+def test_f9_dgr_perceiver_256(golden_dir, M, T, h2_attn):
+    """DGR bottleneck instance: latent 256, context 128, one head of 128 (resunet_new.py:516-525); context preparation and
+    cross-attention on split-fp16 operands (default) and on the fp32 MFMA."""
     g = _load(golden_dir, "f9_dgr_perceiver.npz")
     sd = synthetic.seeded_state_dict(synthetic.fusion_layer_shapes("", 128, 256, 128, pe=True, out_to_query=True), seed=int(g["seed"]))
     m = gmf_amd.PerceiverIO(depth=0, dim=128, latent_dim=256, cross_heads=1, latent_heads=8, cross_dim_head=128,
                             latent_dim_head=128, pe=True)
     m.load_state_dict(sd)
     m = m.to(DEV).eval()
+    m.split_fp16_attn = h2_attn
     r = np.random.default_rng([109, M, T])
     x = torch.from_numpy(r.normal(0, 1, (1, M, 256)).astype(np.float32))
     ctx = torch.from_numpy(r.normal(0, 1, (1, T, 128)).astype(np.float32))
     # the DGR call site feeds F [M,256] unsqueezed to [1,M,256] (resunet_new.py:696-699)
     y = m(_gpu(ctx), queries_encoder=_gpu(x))
     assert y.shape == (1, M, 256)
-    assert _maxerr(y.cpu(), g[f"out_M{M}_T{T}"]) < 1e-4
+    err = _maxerr(y.cpu(), g[f"out_M{M}_T{T}"])
+    print(f"F9 M={M} T={T} split_fp16_attn={h2_attn}: max err {err:.3e}")
+    assert err < 1e-4
+    # small grids split the feed-forward's hidden chunks over up to 8 workgroups per row block: same sums, another order
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    try:
+        for hs in (1, 2, 8):
+            h.call("gmf_set_tuning", b"ff_hidden_splits", hs)
+            assert _maxerr(m(_gpu(ctx), queries_encoder=_gpu(x)).cpu(), g[f"out_M{M}_T{T}"]) < 1e-4, hs
+    finally:
+        h.call("gmf_set_tuning", b"ff_hidden_splits", 0)
 
 
 def test_f3_nonlocal_block(golden_dir, sd_full):

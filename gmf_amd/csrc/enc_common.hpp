@@ -82,6 +82,63 @@ GMF_DEVINL void lcpe_frag(float (&y)[CF], const float* __restrict__ pair_base, i
   }
 }
 
+// ---- LCPE with the neighbour rows taken from the neighbour LANES -------------------------------------------------------
+// lcpe_frag above loads the rows row - 1, row, row + 1 and the four tap vectors from global memory: 7 float4 loads per
+// 4 features, which the compiler - short of registers around them - issues as one dependent round trip after the other
+// (k_fusion_attn_w_h2: 40 x `s_waitcnt vmcnt(0)`, 25 of the kernel's 48 us at one wave per SIMD).  Here a lane's rows
+// row +- 1 are its neighbour lanes' registers (v_mov_b32_dpp wave_shr / wave_shl); only the row above the tile's first row and
+// the row below its last one come from memory - one LDS-DMA gather per K = 256 floats into a per-wave halo area - and the taps
+// are read from a copy of the kernel's per-feature vectors in the LDS.
+//   halo (per wave, 2 * K floats): float4 unit r * (K/4) + 2 g + h = features 8 g + 4 h .. + 3 of the row above (r = 0) / below (r = 1)
+//   taps_lds: w0[K] | w1[K] | w2[K] | b[K]
+template <int KF>
+struct LcpeHalo {
+  static constexpr int K = 2 * KF, U = K / 4;
+  GMF_DEVINL static void issue(const float* __restrict__ pair_base, int tile, int tiles, float* halo, int lane) {
+#pragma unroll
+    for (int q = 0; q < (2 * U) / 64; ++q) {
+      const int w = q * 64 + lane, r = w / U, u = w % U;
+      const bool other = (r == 0) ? (tile > 0) : (tile + 1 < tiles);        // else: any finite value of the own tile (it is masked)
+      const int st = other ? (r == 0 ? tile - 1 : tile + 1) : tile;
+      const int si = (r == 0) == other ? 31 : 0;
+      const float* src = pair_base + (size_t)st * (32 * K) + (size_t)(((u >> 1) * 64 + (u & 1) * 32 + si) * 4);
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                       (void __attribute__((address_space(3)))*)(halo + q * 256), 16, 0, 0);
+    }
+  }
+  GMF_DEVINL static float from_lane_below(float v) {   // lane L gets lane L - 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+  }
+  GMF_DEVINL static float from_lane_above(float v) {   // lane L gets lane L + 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+  }
+  // x (the tile's own rows, one per lane) -> x + b + w0 * x[row - 1] + w1 * x + w2 * x[row + 1], zero padding outside [0, n_rows)
+  GMF_DEVINL static void apply(float (&x)[KF], const float* halo, const float* taps_lds, int row, int n_rows, int lane) {
+    const int h = lane >> 5, i = lane & 31;
+    const bool has_m = row >= 1, has_p = row + 1 < n_rows, first = i == 0, last = i == 31;
+    const float4* hl = reinterpret_cast<const float4*>(halo) + h;
+    const float4* t0 = reinterpret_cast<const float4*>(taps_lds) + h;
+#pragma unroll
+    for (int g = 0; g < KF / 4; ++g) {
+      const float4 up = hl[2 * g], dn = hl[U + 2 * g];
+      const float4 w0 = t0[2 * g], w1 = t0[2 * g + K / 4], w2 = t0[2 * g + 2 * (K / 4)], b = t0[2 * g + 3 * (K / 4)];
+      const float upv[4] = {up.x, up.y, up.z, up.w}, dnv[4] = {dn.x, dn.y, dn.z, dn.w};
+      const float w0v[4] = {w0.x, w0.y, w0.z, w0.w}, w1v[4] = {w1.x, w1.y, w1.z, w1.w}, w2v[4] = {w2.x, w2.y, w2.z, w2.w};
+      const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xc = x[4 * g + e];
+        float xm = from_lane_below(xc), xq = from_lane_above(xc);
+        xm = first ? upv[e] : xm;
+        xq = last ? dnv[e] : xq;
+        xm = has_m ? xm : 0.f;
+        xq = has_p ? xq : 0.f;
+        x[4 * g + e] = xc + bv[e] + w0v[e] * xm + w1v[e] * xc + w2v[e] * xq;
+      }
+    }
+  }
+};
+
 // Split-fp16 weight images are stored as 256 W (packing.p32_h2s / p16_h2s): lo = fp16(256 w - hi) then stays a normal
 // fp16 number for |w| >= 2^-11 instead of falling into the subnormals (spacing 2^-24: a weight of 0.006 - the folded
 // softmax scale makes Wq that small - kept only 16 significant bits).  Consumers fold 2^-8 into the bias add

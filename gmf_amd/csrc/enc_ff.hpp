@@ -27,7 +27,7 @@ GMF_DEVINL void ff_chunks(const FragH2<8>& nx, f32x16 (&y)[4], float* lds, const
     const float* g = wst + (size_t)blob_stage(n_issued) * kStageFloats;
     float* dst = lds + (n_issued & (NB - 1)) * kStageFloats;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);
+    for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);   // (statement form: see StageRing)
     ++n_issued;
   };
   auto acquire = [&]() {

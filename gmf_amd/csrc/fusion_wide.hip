@@ -8,6 +8,7 @@
 //   k_ctx_prep_w     perceiver_io.py:126-128,46-49,89-91    LCPE(content) + LayerNorm_ctx + to_kv (128 -> 128 | 128)
 //   k_fusion_attn_w  perceiver_io.py:121-123,44,87-101,208  LCPE(q) + LayerNorm + to_q + softmax(QK^T)V + to_out + residual
 //   k_fusion_ff_w    perceiver_io.py:54-69,211              LayerNorm + Linear(256,2048) + GEGLU + Linear(1024,256) + residual
+#include <type_traits>
 #include "enc_common.hpp"
 #include "launchers.hpp"
 
@@ -340,7 +341,9 @@ __global__ void __launch_bounds__(256, 1)
 k_fusion_ff_w_h2(const float* __restrict__ x1, const float* __restrict__ wst, const float* __restrict__ vecs,
                  float* __restrict__ x2_out, int tiles, float* __restrict__ part) {
   using namespace wide;
-  __shared__ __attribute__((aligned(16))) float lds[kRingW * kStageFloats];
+  // LDS: the stage ring | the per-feature vectors (gamma | beta | b1 value | b1 gate | b2: 11 KiB) - a bias fetched from global
+  // memory at the top of every hidden chunk was a memory round trip per chunk with nothing to hide behind (one wave per SIMD)
+  __shared__ __attribute__((aligned(16))) float lds[kRingW * kStageFloats + 2 * LAT + 2 * FFHW + LAT];
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y;
@@ -350,6 +353,8 @@ k_fusion_ff_w_h2(const float* __restrict__ x1, const float* __restrict__ wst, co
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * LAT);
 
   const int hs = gridDim.z, n_chunks = (FFHW / 32) / hs, c0 = blockIdx.z * n_chunks;
+  float* const lvec = lds + kRingW * kStageFloats;
+  dma_issue(vecs, lvec, 11, wave, kWaves, lane);
   StageRing<kRingW> ss;
   ss.init(lds, wave, lane, wst + (size_t)c0 * 6 * kStageFloats, 6 * n_chunks);
   ss.prime();
@@ -357,14 +362,16 @@ k_fusion_ff_w_h2(const float* __restrict__ x1, const float* __restrict__ wst, co
   {
     float x[LATF], xn[LATF];
     load_frag_p32<LATF>(x, x1 + toff, lane);
-    layernorm_frag<LATF>(xn, x, vecs, vecs + LAT, h);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    layernorm_frag<LATF>(xn, x, lvec, lvec + LAT, h);
     nx.set(xn);
   }
   f32x16 y[8];
 #pragma unroll
   for (int mb = 0; mb < 8; ++mb) y[mb] = zero16();
-  const float* b1a = vecs + 2 * LAT;
-  const float* b1g = vecs + 2 * LAT + FFHW;
+  const float* b1a = lvec + 2 * LAT;
+  const float* b1g = lvec + 2 * LAT + FFHW;
 
   // acc (preloaded with the bias) += W(32 x 256) x^T from the two plane stages of one weight block
   auto w1_block = [&](f32x16& acc) {
@@ -416,7 +423,7 @@ k_fusion_ff_w_h2(const float* __restrict__ x1, const float* __restrict__ wst, co
 #pragma unroll
   for (int mb = 0; mb < 8; ++mb) {
     float b[16], xr[16], t[16];
-    load_vec16(b, vecs + 2 * LAT + 2 * FFHW, mb, h);
+    load_vec16(b, lvec + 2 * LAT + 2 * FFHW, mb, h);
     load_blk<LAT>(xr, x1 + toff, mb, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = fmaf(y[mb][r], kH2Inv, b[r]) + xr[r];
@@ -470,7 +477,7 @@ template <bool PE>
 __global__ void __launch_bounds__(256, 1)
 k_ctx_prep_w_h2(const float* __restrict__ ctx, const float* __restrict__ wst, const float* __restrict__ vecs,
                 float* __restrict__ out, int T, int ttiles) {
-  __shared__ __attribute__((aligned(16))) float lds[kRingW * kStageFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kRingW * kStageFloats + 6 * CX + kWaves * 2 * CX];
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y;
@@ -479,16 +486,22 @@ k_ctx_prep_w_h2(const float* __restrict__ ctx, const float* __restrict__ wst, co
   const int tile = active ? tile_raw : ttiles - 1;
   const float* pair_base = ctx + (size_t)pair * ttiles * (32 * CX);
   float* dst = out + ((size_t)pair * ttiles + tile) * (2 * kStageFloats);
+  float* const lvec = lds + kRingW * kStageFloats;          // taps (4 x 128) | gamma | beta: 3 KiB
+  float* const halo = lvec + 6 * CX + wave * (2 * CX);
 
+  dma_issue(vecs, lvec, 3, wave, kWaves, lane);
+  if (PE) LcpeHalo<CXF>::issue(pair_base, tile, ttiles, halo, lane);
   StageRing<kRingW> ss;
   ss.init(lds, wave, lane, wst, 8);
   ss.prime();
   FragH2<8> cx;
   {
     float x[CXF], cn[CXF];
-    if (PE) lcpe_w<CXF>(x, pair_base, tile * 32 + i, T, vecs, h);
-    else load_frag_p32<CXF>(x, pair_base + (size_t)tile * (32 * CX), lane);
-    layernorm_frag<CXF>(cn, x, vecs + 4 * CX, vecs + 5 * CX, h);
+    load_frag_p32<CXF>(x, pair_base + (size_t)tile * (32 * CX), lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (PE) LcpeHalo<CXF>::apply(x, halo, lvec, tile * 32 + i, T, lane);
+    layernorm_frag<CXF>(cn, x, lvec + 4 * CX, lvec + 5 * CX, h);
     cx.set(cn);
   }
 #pragma unroll
@@ -517,7 +530,8 @@ template <bool PE>
 __global__ void __launch_bounds__(256, 1)
 k_fusion_attn_w_h2(const float* __restrict__ xin, const float* __restrict__ ctx_img, const float* __restrict__ wst,
                    const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
-  __shared__ __attribute__((aligned(16))) float lds[kRingW * kStageFloats];
+  // LDS: the stage ring | the kernel's per-feature vectors (7 KiB) | per wave the two halo rows of the LCPE (2 KiB)
+  __shared__ __attribute__((aligned(16))) float lds[kRingW * kStageFloats + 7 * LAT + kWaves * 2 * LAT];
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y;
@@ -526,21 +540,28 @@ k_fusion_attn_w_h2(const float* __restrict__ xin, const float* __restrict__ ctx_
   const int tile = active ? tile_raw : tiles - 1;
   const float* pair_base = xin + (size_t)pair * tiles * (32 * LAT);
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * LAT);
+  float* const lvec = lds + kRingW * kStageFloats;
+  float* const halo = lvec + 7 * LAT + wave * (2 * LAT);
 
+  // everything the prologue needs is requested at once (older than the ring's pieces, so the ring's counted waits cover it)
+  dma_issue(vecs, lvec, 7, wave, kWaves, lane);
+  if (PE) LcpeHalo<LATF>::issue(pair_base, tile, tiles, halo, lane);
   StageRing<kRingW> ss;
   ss.init(lds, wave, lane, wst, 8, ctx_img + (size_t)pair * ttiles * (2 * kStageFloats), 2 * ttiles, wst + 8 * kStageFloats, 8);
   ss.prime();
 
   // one wave per SIMD (512 VGPRs): x' (128), its two fp16 planes (128) and the Q fragment (64) are live together
   float xp[LATF];
-  if (PE) lcpe_w<LATF>(xp, pair_base, tile * 32 + i, N, vecs, h);
-  else load_frag_p32<LATF>(xp, pair_base + (size_t)tile * (32 * LAT), lane);
+  load_frag_p32<LATF>(xp, pair_base + (size_t)tile * (32 * LAT), lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (PE) LcpeHalo<LATF>::apply(xp, halo, lvec, tile * 32 + i, N, lane);
   FragH2<8> qx;
   {
     FragH2<16> nx;
     {
       float xn[LATF];
-      layernorm_frag<LATF>(xn, xp, vecs + 4 * LAT, vecs + 5 * LAT, h);
+      layernorm_frag<LATF>(xn, xp, lvec + 4 * LAT, lvec + 5 * LAT, h);
       nx.set(xn);
     }
 #pragma unroll
@@ -615,17 +636,27 @@ k_fusion_attn_w_h2(const float* __restrict__ xin, const float* __restrict__ ctx_
       ox.set_block(db, t);
     }
   }
-#pragma unroll
-  for (int mb = 0; mb < 8; ++mb) {
-    const f16x8* lw = as_h2(ss.acquire());
+  // to_out: 8 stages, each followed by 4 stores per lane.  The ring's plain acquire() would wait for the previous stage's
+  // stores at every barrier (vmcnt counts stores too; a store's acknowledgement takes about as long as a whole stage), so the
+  // waits are counted: younger than stage j's pieces are the pieces of the up to two stages behind it and the stores of the up
+  // to three stages before it.  (Padding waves store their copy of the last tile as well - same values - so that the count
+  // is the same in every wave.)
+  auto out_stage = [&](auto jc) {
+    constexpr int mb = decltype(jc)::value;
+    constexpr int younger = 4 * (mb <= 5 ? 2 : 7 - mb) + 4 * (mb < 3 ? mb : 3);
+    const f16x8* lw = as_h2(ss.template acquire_counted<younger>());
     f32x16 acc = zero16();
     mma_wx_h2<8>(acc, lw, ox);
     float b[16], t[16];
-    load_vec16(b, vecs + 6 * LAT, mb, h);
+    load_vec16(b, lvec + 6 * LAT, mb, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, b[r]) + xp[16 * mb + r];
-    if (active) store_blk<LAT>(x1_out + toff, mb, t, lane);
-  }
+    store_blk<LAT>(x1_out + toff, mb, t, lane);
+  };
+  out_stage(std::integral_constant<int, 0>{}); out_stage(std::integral_constant<int, 1>{});
+  out_stage(std::integral_constant<int, 2>{}); out_stage(std::integral_constant<int, 3>{});
+  out_stage(std::integral_constant<int, 4>{}); out_stage(std::integral_constant<int, 5>{});
+  out_stage(std::integral_constant<int, 6>{}); out_stage(std::integral_constant<int, 7>{});
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -318,8 +318,11 @@ struct StageRing {
       else if (issued < seg_end[2]) g = seg_ptr[2] + (size_t)(issued - seg_end[1]) * kStageFloats;
       else g = seg_ptr[3] + (size_t)(issued - seg_end[2]) * kStageFloats;
       float* dst = base + (issued % NBUF) * kStageFloats;
+      // The statement form of the DMA (not the builtin): hipcc waits with vmcnt(0) before every barrier / LDS read that follows
+      // a builtin LDS-DMA - for the look-ahead stages and for every store in flight as well - which turned each stage of a
+      // one-wave-per-SIMD kernel into a full memory round trip (~1 us whatever it multiplied).  acquire() carries the waits.
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);
+      for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);
       ++issued;
     }
   }

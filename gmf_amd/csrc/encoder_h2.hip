@@ -387,6 +387,9 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
 // PART 0: the whole kernel.  PART 1 / PART 2: its two independent halves as workgroup ROLES of one launch (k_linear_roles, grids
 // of 256 .. ~300 workgroups: one workgroup per CU cannot hide the 71-stage chain of a wave, two roles per row block shorten
 // it to its longer half) - 1 = the Q'/K/V projections, 2 = Fusion-2 (LCPE + cross-attention + feed-forward).
+// LDS of the fused linear kernel: 4 stages | attention vectors | feed-forward vectors | 4 waves x 2 halo rows = 77.5 KiB (two workgroups per CU)
+constexpr int kLinLdsFloats = 4 * kStageFloats + 7 * C + (3 * C + 2 * FFH) + kWavesPerWG * 2 * C;
+
 template <int PART>
 GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const float* __restrict__ front_wst,
                                const float* __restrict__ front_vec, const float* __restrict__ ctx_img,
@@ -409,6 +412,17 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
   // the stores (whose acknowledgement takes a memory round trip) are waited for at a stage barrier.  For the counts to hold
   // on every wave, the padding waves of a pair's last workgroup store too: they recompute the pair's last tile and write the
   // same bits to the same place as the wave that owns it.
+  // Behind the ring (kLinLdsFloats): the per-feature vectors of the attention (7 x 128 floats) and of the feed-forward
+  // (1408 floats) and, per wave, the two halo rows of the LCPE - requested first, so every later counted wait covers them.
+  // (A bias / gamma / tap fetched from global memory where it is used is a memory round trip in the middle of a stage chain.)
+  float* const lvec_a = lds + 4 * kStageFloats;
+  float* const lvec_f = lvec_a + 7 * C;
+  float* const halo = lvec_f + (3 * C + 2 * FFH) + wave * (2 * C);
+  if (PART != 1) {
+    dma_vec(attn_vec, lvec_a, 7 * C, wave, kWavesPerWG, lane);
+    dma_vec(ff_vec, lvec_f, 3 * C + 2 * FFH, wave, kWavesPerWG, lane);
+    LcpeHalo<CF>::issue(pair_base, tile, tiles, halo, lane);
+  }
   StageRing<4> ss;
   if (PART == 0) ss.init(lds, wave, lane, front_wst + 4 * kStageFloats, 12, attn_wst, 2,
                          ctx_img + (size_t)pair * ttiles * kStageFloats, ttiles, attn_wst + 2 * kStageFloats, 2);
@@ -473,12 +487,17 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
     FragH2<4> qx;
     {
       float xp[CF];
-      lcpe_frag(xp, pair_base, tile * 32 + i, N, attn_vec, h);
+      load_frag_p32<CF>(xp, f_in + toff, lane);
+      if (PART == 2) {                           // (PART 0: the barriers of the Q'/K/V stages have made the vectors visible)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      LcpeHalo<CF>::apply(xp, halo, lvec_a, tile * 32 + i, N, lane);
       {
         FragH2<8> nx;
         {
           float xn[CF];
-          layernorm_frag<CF>(xn, xp, attn_vec + 4 * C, attn_vec + 5 * C, h);
+          layernorm_frag<CF>(xn, xp, lvec_a + 4 * C, lvec_a + 5 * C, h);
           nx.set(xn);
         }
 #pragma unroll
@@ -496,7 +515,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
         float b[16];
-        load_vec_block(b, attn_vec + 6 * C, mb, h);
+        load_vec_block(b, lvec_a + 6 * C, mb, h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) x1a[mb][r] = (xp[16 * mb + r] + b[r]) * 256.0f;
       }
@@ -578,18 +597,18 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) x1[16 * mb + r] = x1a[mb][r] * kH2Inv;
-    layernorm_frag<CF>(xn, x1, ff_vec, ff_vec + C, h);
+    layernorm_frag<CF>(xn, x1, lvec_f, lvec_f + C, h);
     nx.set(xn);
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       float b[16];
-      load_vec_block(b, ff_vec + 2 * C + 2 * FFH, mb, h);
+      load_vec_block(b, lvec_f + 2 * C + 2 * FFH, mb, h);
 #pragma unroll
       for (int r = 0; r < 16; ++r) y[mb][r] = (x1[16 * mb + r] + b[r]) * 256.0f;
     }
   }
   __syncthreads();                               // every wave is done with the 2-slot ring: the 4-slot ring may overwrite it
-  ff_chunks(nx, y, lds, ff_wst, ff_vec + 2 * C, ff_vec + 2 * C + FFH, wave, lane, h, 0, FFH / 32);
+  ff_chunks(nx, y, lds, ff_wst, lvec_f + 2 * C, lvec_f + 2 * C + FFH, wave, lane, h, 0, FFH / 32);
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     float t[16];
@@ -605,7 +624,7 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
             const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
             float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
             int ttiles) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kLinLdsFloats];
   linear_h2_body<0>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N, tiles,
                     T, ttiles);
 }
@@ -617,7 +636,7 @@ k_linear_roles(const float* __restrict__ f_in, const float* __restrict__ front_w
                const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
                float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
                int ttiles) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kLinLdsFloats];
   if (blockIdx.z == 0)
     linear_h2_body<1>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
                       tiles, T, ttiles);

@@ -50,7 +50,7 @@ k_conv_nhwc_h2(const float* __restrict__ x, const float* __restrict__ wimg, cons
     const float* g = wimg + (size_t)st * kStageFloats;
     float* dst = lds + (st % NB) * kStageFloats;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);
+    for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);   // (statement form: mfma_core.hpp, StageRing)
   };
   // every lane always loads (clamped address, value zeroed afterwards): the number of vector-memory operations in flight
   // must not depend on the data, the s_waitcnt counts below rely on it
@@ -176,7 +176,7 @@ k_conv3x3_patch_h2(const float* __restrict__ x, const float* __restrict__ wimg, 
     const float* g = wimg + (size_t)st * kStage;
     float* dst = lds + (st % NB) * kStage;
 #pragma unroll
-    for (int q = 0; q < KPS; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);
+    for (int q = 0; q < KPS; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);
   };
   // patch block cb: thread t moves the float4 quarter (t & 3) of patch pixels (t >> 2) + 64 j, j = 0 .. 3 (always four
   // loads, clamped address: the vmcnt counts below rely on it)

@@ -238,6 +238,13 @@ GMF_DEVINL void dma_piece_1k_s(const float* __restrict__ gsrc_piece_uniform, flo
                : "=&s"(keep) : "v"(lane_off16), "s"(gsrc_piece_uniform), "s"(lds_dst) : "memory");
 }
 
+// Copy a per-feature vector block of n_floats (a multiple of 4) to the LDS, 1 KiB pieces round-robin over the waves; the last
+// piece is cut by the execution mask (nothing is read behind the block).
+GMF_DEVINL void dma_vec(const float* __restrict__ gsrc, float* lds_dst, int n_floats, int wave, int n_waves, int lane) {
+  for (int p = wave; p * 256 < n_floats; p += n_waves)
+    if (p * 256 + lane * 4 < n_floats) dma_piece_1k(gsrc + p * 256, lds_dst + p * 256, lane);
+}
+
 // Copy `n_pieces` KiB from gsrc to lds_dst, pieces distributed round-robin over the waves.
 GMF_DEVINL void dma_issue(const float* __restrict__ gsrc, float* lds_dst, int n_pieces, int wave, int n_waves, int lane) {
   for (int p = wave; p < n_pieces; p += n_waves) dma_piece_1k(gsrc + p * 256, lds_dst + p * 256, lane);

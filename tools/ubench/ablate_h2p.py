@@ -45,6 +45,10 @@ PATCHES = {
     "no_dma": [
         (EK, "        if (u >= 3 && u < 11) issue_piece(t, u - 3);\n", ""),
     ],
+    "no_c_no_dma": [    # both streams of the tile loop gone: what is left is the arithmetic (small grids: is the loop latency-bound?)
+        (EK, "const f32x4 v = __builtin_nontemporal_load(ct + q * 64);", "const f32x4 v = {1.f, 1.f, 1.f, 1.f}; (void)ct;"),
+        (EK, "        if (u >= 3 && u < 11) issue_piece(t, u - 3);\n", ""),
+    ],
     "no_split": [
         (EK, "          split2h(x[j], x[j + 1], ph0, pl0, j);", "          ph0[j] = (_Float16)x[j]; ph0[j + 1] = (_Float16)x[j + 1];"),
         (EK, "          split2h(x[8 + j], x[8 + j + 1], ph1, pl1, j);", "          ph1[j] = (_Float16)x[8 + j]; ph1[j + 1] = (_Float16)x[8 + j + 1];"),
@@ -123,7 +127,7 @@ def run(argv):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_times.py")] + argv, env=env,
                            capture_output=True, text=True)
         print(f"== {name}", flush=True)
-        print("\n".join(l for l in r.stdout.splitlines() if "scattn" in l or "k_linear" in l or "encode:" in l), flush=True)
+        print("\n".join(l for l in r.stdout.splitlines() if "scattn" in l or "k_linear" in l or "k_small" in l or "encode:" in l), flush=True)
         if r.returncode:
             print(r.stderr[-1500:])
 

@@ -553,21 +553,43 @@ k_colsum_partial(const float* __restrict__ x, const float* __restrict__ y, const
   float s = 0.f, s1 = 0.f;
   if (c < C) {
     const float cm = cmean ? cmean[c] : 0.f, cr = crstd ? crstd[c] : 1.f;
-    for (long r = r0 + wave; r < r1; r += 4) {
-      float v = x[r * C + c];
-      if (relu_y && !(relu_y[r * C + c] > 0.f)) v = 0.f;
-      if (center_x) v -= cm;
-      s1 += v;
-      if (y) {
-        const int l = (int)(r % L) + shift;
-        if (l < 0 || l >= L) continue;
-        const long ry = r + shift;
-        float yv = y[ry * C + c];
-        if (mean) yv = (yv - mean[ry]) * rstd[ry];
-        if (cmean) yv = (yv - cm) * cr;
-        v *= yv;
+    // four rows of this wave at a time: their loads are all requested before the first is used (a chunk is 16 rows per wave -
+    // one load per round trip made the kernel 16 dependent round trips long); the additions keep the row order
+    for (long rb = r0 + wave; rb < r1; rb += 16) {
+      float v[4], yv[4], mu[4], rs[4], ry_mask[4];
+      bool ok[4], yok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long rr = rb + 4 * u;
+        ok[u] = rr < r1;
+        const long r = ok[u] ? rr : rb;
+        v[u] = x[r * C + c];
+        ry_mask[u] = relu_y ? relu_y[r * C + c] : 1.f;
+        yok[u] = true; yv[u] = 1.f; mu[u] = 0.f; rs[u] = 1.f;
+        if (y) {
+          const int l = (int)(r % L) + shift;
+          yok[u] = l >= 0 && l < L;
+          const long ry = yok[u] ? r + shift : r;
+          yv[u] = y[ry * C + c];
+          if (mean) { mu[u] = mean[ry]; rs[u] = rstd[ry]; }
+        }
       }
-      s += v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) break;
+        float vv = v[u];
+        if (relu_y && !(ry_mask[u] > 0.f)) vv = 0.f;
+        if (center_x) vv -= cm;
+        s1 += vv;
+        if (y) {
+          if (!yok[u]) continue;
+          float t = yv[u];
+          if (mean) t = (t - mu[u]) * rs[u];
+          if (cmean) t = (t - cm) * cr;
+          vv *= t;
+        }
+        s += vv;
+      }
     }
   }
   red[0][wave][lane] = s;

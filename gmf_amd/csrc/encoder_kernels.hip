@@ -1124,19 +1124,30 @@ k_scattn_fast(const float* __restrict__ q_img, const float* __restrict__ k_img, 
     for (int q = 0; q < 2; ++q)
       dma_piece_1k_s(gc + (size_t)t * kCFloats + q * 256, ldsC + slot * kCFloats + q * 256, lane_off16);
   };
-  // x = c * s with c one half of a 32-bit LDS word
-  auto cmul = [&](const float cdw, const float sv, const bool hi) {
+  // x' = c * s - m_off in ONE instruction, c one fp16 half of a 32-bit LDS word: the compiler selects v_fma_mix_f32 (fp16 x fp32
+  // + fp32 -> fp32) for this expression.  (Written as an asm statement the same instruction read the scores before the MFMA
+  // had delivered them: hipcc's hazard recogniser does not put the MFMA -> VALU wait states in front of inline assembly.)
+  auto cfma = [&](const float cdw, const float sv, const float neg_m_off, const bool hi) {
     const f16x2 hv = __builtin_bit_cast(f16x2, cdw);
-    return (float)(hi ? hv[1] : hv[0]) * sv;
+    return __builtin_fmaf((float)(hi ? hv[1] : hv[0]), sv, neg_m_off);
   };
 
   f32x16 oacc[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) oacc[db] = zero16();
-  float m_run = -INFINITY, l_half = 0.f;
+  float l_half = 0.f;
 
-  auto tile_step = [&](auto last_tag, const int t, const int slot) {
+  // The running maximum is taken LAZILY: the exponent offset m_off stays what it was as long as no score of the tile exceeds it
+  // by more than kSlack (the probabilities P' = 2^(x - m_off) then stay below 2^kSlack <= fp16's range, and a softmax does not
+  // care which offset its numerator and denominator share), so the steady state of a tile is: 16 fused c * s - m_off, their
+  // maximum (8 x v_max3), 16 exponentials, 8 packed conversions and 8 dot-products for the row sum - no exp2 of a maximum
+  // difference, no accumulator rescale.  Only when a score climbs above the slack (the first tile, and rarely after) the
+  // offset moves and accumulators and row sum are rescaled.
+  constexpr float kSlack = 15.0f;
+  float m_off = 0.f;                                   // defined by the first tile (l_half = 0, oacc = 0: nothing to rescale)
+  auto tile_step = [&](auto last_tag, auto first_tag, const int t, const int slot) {
     constexpr bool LAST = decltype(last_tag)::value;       // only the last key tile can hold keys >= N
+    constexpr bool FIRST = decltype(first_tag)::value;
     // everything issued two tiles ago or earlier has landed (tile t's K, V, c among it); the previous tile's 6 stay in flight
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __syncthreads();                                   // ... for every wave; and every wave is done with tile t - 1's slots
@@ -1150,35 +1161,38 @@ k_scattn_fast(const float* __restrict__ q_img, const float* __restrict__ k_img, 
 #pragma unroll
     for (int s = 0; s < 8; ++s) sc = mfma_h16(lk[s * 64], qh[s], sc);
     float x[16];
-    float mx = -INFINITY;
+    const float nm = FIRST ? 0.f : -m_off;
     const int jbase = t * 32 + 4 * h;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float cdw = (r < 8) ? c0a[r >> 1] : c0b[(r - 8) >> 1];
-      x[r] = cmul(cdw, sc[r], (r & 1) != 0);
+      x[r] = cfma(cdw, sc[r], nm, (r & 1) != 0);
       if (LAST) {
         const int jl = 8 * (r >> 2) + (r & 3);
         x[r] = (jbase + jl < N) ? x[r] : -INFINITY;
       }
     }
+    float mx = __builtin_fmaxf(x[0], x[1]);
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(mx, __builtin_fmaxf(x[r], x[r + 1]));
-    mx = xhalf_max_swap(mx);
-    const float m_new = __builtin_fmaxf(m_run, mx);
-    const bool moved = m_new > m_run;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    const float m_off = m_new - 10.0f;                 // P' = 2^10 P
-    float ls = 0.f;
+    for (int r = 2; r < 16; r += 2) mx = __builtin_fmaxf(mx, __builtin_fmaxf(x[r], x[r + 1]));
+    mx = xhalf_max_swap(mx);                            // the row's maximum over this tile, relative to the offset
+    if (FIRST || __any(mx > kSlack)) {
+      // new offset: this tile's maximum lands at 2^10 (as in the parity kernel); rows that stay within the slack keep theirs
+      const float shift = (FIRST || mx > kSlack) ? mx - 10.0f : 0.f;
+      const float alpha = FIRST ? 1.f : __builtin_amdgcn_exp2f(-shift);
+      m_off = FIRST ? shift : m_off + shift;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
-    l_half = fmaf(l_half, alpha, ls);
-    if (__any(moved)) {
+      for (int r = 0; r < 16; ++r) x[r] -= shift;
+      if (!FIRST) {
+        l_half *= alpha;
 #pragma unroll
-      for (int db = 0; db < 4; ++db)
+        for (int db = 0; db < 4; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       f16x8 ph;
@@ -1187,6 +1201,8 @@ k_scattn_fast(const float* __restrict__ q_img, const float* __restrict__ k_img, 
         const f32x2 xx = {x[8 * s2 + j], x[8 * s2 + j + 1]};
         const f16x2 hh = __builtin_convertvector(xx, f16x2);
         ph[j] = hh[0]; ph[j + 1] = hh[1];
+        // the row sum adds the ROUNDED probabilities, the ones the matrix pipe multiplies (v_dot2_f32_f16: two per instruction)
+        l_half = __builtin_amdgcn_fdot2(hh, f16x2{(_Float16)1, (_Float16)1}, l_half, false);
       }
 #pragma unroll
       for (int db = 0; db < 4; ++db) oacc[db] = mfma_h16(lv[(2 * db + s2) * 64], ph, oacc[db]);
@@ -1198,14 +1214,19 @@ k_scattn_fast(const float* __restrict__ q_img, const float* __restrict__ k_img, 
   issue_tile(1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   {
-    const std::false_type body;
-    const std::true_type tail;
-    int slot = 0;
-    for (int t = 0; t + 1 < tiles; ++t) {
-      tile_step(body, t, slot);
-      slot = (slot == 2) ? 0 : slot + 1;
+    const std::false_type no;
+    const std::true_type yes;
+    if (tiles == 1) {
+      tile_step(yes, yes, 0, 0);
+    } else {
+      tile_step(no, yes, 0, 0);
+      int slot = 1;
+      for (int t = 1; t + 1 < tiles; ++t) {
+        tile_step(no, no, t, slot);
+        slot = (slot == 2) ? 0 : slot + 1;
+      }
+      tile_step(yes, no, tiles - 1, slot);
     }
-    tile_step(tail, tiles - 1, slot);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped refills of the last tiles: nothing may land after the epilogue starts
   // ---- epilogue: normalise, fc_message, Fusion-2 branch, next PointCN (parity arithmetic) ----

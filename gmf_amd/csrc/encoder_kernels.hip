@@ -632,36 +632,28 @@ GMF_DEVINL float xhalf_max_swap(float v) {
 // rows, and the raw feat of a middle layer has no other reader.
 // The Fusion-2 branch x2 of the block sum, per 32-feature block of this wave's tile: read from the x2 image (FusTile), or -
 // small grids - formed here from the hidden-split feed-forward partials, x2 = (sum_z part[z]) / 256 + b2 + x1 with the
-// partials added in index order (FusFromParts: bit-identical to k_ff_reduce, which this replaces).
+// partials added in index order (k_scattn_merge, FusRegs: bit-identical to k_ff_reduce, which this replaces).
 struct FusTile {
   const float* tile;
   GMF_DEVINL void load(float (&fz)[16], int mb, int lane, int h) const { load_block_p32(fz, tile, mb, lane); }
 };
-struct FusFromParts {
-  const float* part_tile;   // this tile in part[0]
-  size_t split_stride;      // floats between part[z] and part[z + 1]
-  const float* x1_tile;
-  const float* b2;
-  int hs;
+
+// the Fusion-2 branch already summed into registers (k_scattn_merge: every partial is requested before the first stage is used)
+struct FusRegs {
+  const float (&f)[CF];
   GMF_DEVINL void load(float (&fz)[16], int mb, int lane, int h) const {
-    float b[16], xr[16], p[8][16];
-    load_vec_block(b, b2, mb, h);
 #pragma unroll
-    for (int z = 0; z < 8; ++z)
-      if (z < hs) load_block_p32(p[z], part_tile + (size_t)z * split_stride, mb, lane);
-    load_block_p32(xr, x1_tile, mb, lane);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) fz[r] = p[0][r];
-#pragma unroll
-    for (int z = 1; z < 8; ++z)
-      if (z < hs) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) fz[r] += p[z][r];
-      }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) fz[r] = fmaf(fz[r], kH2Inv, b[r]) + xr[r];
+    for (int r = 0; r < 16; ++r) fz[r] = f[16 * mb + r];
   }
 };
+
+// The epilogue's per-feature vectors in the LDS: ba[64] | bb[64] | bc[128] (the fc_message biases) | the next layer's PointCN
+// bias [128].  Issued before the epilogue's weight stages; their first acquire (wait + barrier) makes them visible.
+constexpr int kTailVecFloats = 3 * C;
+GMF_DEVINL void stage_tail_vecs(float* lvec, const float* __restrict__ vecs, const float* __restrict__ next_bias, int wave, int lane) {
+  if (wave == 0) dma_piece_1k(vecs, lvec, lane);                                   // 256 floats
+  if (wave == 1 && next_bias && lane < 32) dma_piece_1k(next_bias, lvec + 2 * C, lane);   // 128 floats
+}
 
 template <bool NEXT_PCN, class Stages, class Fus>
 GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stages& ss, const float* __restrict__ vecs,
@@ -1042,12 +1034,14 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
       for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
   }
   __syncthreads();
+  float* const lvec = lds + 2 * kStageFloats;    // (the epilogue streams its stages through the first two of the four slots)
+  stage_tail_vecs(lvec, vecs, next_wst ? next_bias : nullptr, wave, lane);
   StageStream ss;
   ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5, next_wst, next_wst ? 4 : 0);
   ss.prime();
   const FusTile ft{fus + toff};
-  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, ft, out + toff, lane, h, next_bias);
-  else scattn_epilogue_h2<false>(o, active, ss, vecs, ft, out + toff, lane, h);
+  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, lvec, ft, out + toff, lane, h, lvec + 2 * C);
+  else scattn_epilogue_h2<false>(o, active, ss, lvec, ft, out + toff, lane, h);
 }
 
 template <int NPROD, bool CH>
@@ -1239,12 +1233,14 @@ k_scattn_fast(const float* __restrict__ q_img, const float* __restrict__ k_img, 
       for (int r = 0; r < 16; ++r) o[16 * db + r] = oacc[db][r] * inv;
   }
   __syncthreads();
+  float* const lvec = lds + 2 * kStageFloats;
+  stage_tail_vecs(lvec, vecs, next_wst ? next_bias : nullptr, wave, lane);
   StageStream ss;
   ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5, next_wst, next_wst ? 4 : 0);
   ss.prime();
   const FusTile ft{fus + toff};
-  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, ft, out + toff, lane, h, next_bias);
-  else scattn_epilogue_h2<false>(o, active, ss, vecs, ft, out + toff, lane, h);
+  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, lvec, ft, out + toff, lane, h, lvec + 2 * C);
+  else scattn_epilogue_h2<false>(o, active, ss, lvec, ft, out + toff, lane, h);
 }
 
 // k_small_attn_ff: small grids, the second of the three launches of a layer - the first n_attn workgroups are the key-split
@@ -1313,7 +1309,9 @@ k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_
                int wgs_per_pair, int n_items, int n_full, int ksplits, const float* __restrict__ next_wst,
                const float* __restrict__ next_bias, const float* __restrict__ ff_part, int ff_hs, const float* __restrict__ x1,
                const float* __restrict__ ff_b2) {
-  __shared__ __attribute__((aligned(16))) float lds[9 * kStageFloats];
+  // (behind the nine stages: the biases of the epilogue - a bias fetched from global memory after each stage's MFMAs is a
+  // memory round trip per stage on a grid where nothing else runs on the CU)
+  __shared__ __attribute__((aligned(16))) float lds[9 * kStageFloats + kTailVecFloats];
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // split item r of XCD x: the workgroup slot (x, n_full + r * 1) of a ksplits = 1 mapping
@@ -1327,8 +1325,36 @@ k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_
   const size_t n_tiles_all = (size_t)(n_items / wgs_per_pair) * tiles;
   const size_t pt0 = (size_t)pair * tiles + tile;
   const size_t toff = pt0 * (32 * C);
+  float* const lvec = lds + 9 * kStageFloats;
+  stage_tail_vecs(lvec, vecs, next_wst ? next_bias : nullptr, wave, lane);
+  vecs = lvec;
+  next_bias = lvec + 2 * C;
   StagesPreloaded ss;
   ss.init(lds, wave, lane, wst, 5, next_wst);
+  // small grids: the Fusion-2 branch arrives as hidden-split partials (k_small_attn_ff): x2 = sum_z part[z] 2^-8 + b2 + x1, summed
+  // in index order HERE - all (hs + 1) x 16 loads of the tile in flight together with the weight stages - instead of block by
+  // block between the epilogue's last stages
+  float x2[CF];
+  if (ff_part) {
+    const float* pt = ff_part + toff;
+    const size_t zs = n_tiles_all * (32 * C);
+    float acc[CF], xr[CF];
+    load_frag_p32<CF>(acc, pt, lane);
+    load_frag_p32<CF>(xr, x1 + toff, lane);
+    for (int z = 1; z < ff_hs; ++z) {
+      float pz[CF];
+      load_frag_p32<CF>(pz, pt + (size_t)z * zs, lane);
+#pragma unroll
+      for (int e = 0; e < CF; ++e) acc[e] += pz[e];
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      float b[16];
+      load_vec_block(b, ff_b2, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x2[16 * mb + r] = fmaf(acc[16 * mb + r], kH2Inv, b[r]) + xr[16 * mb + r];
+    }
+  }
   float mk[8], lk[8];
   float M = -INFINITY;
 #pragma unroll
@@ -1365,8 +1391,8 @@ k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_
   const float inv = 1.0f / l;
 #pragma unroll
   for (int e = 0; e < CF; ++e) o[e] *= inv;
-  if (ff_part) {                                 // small grids: the Fusion-2 branch arrives as hidden-split partials (k_small_attn_ff)
-    const FusFromParts fp{ff_part + toff, n_tiles_all * (32 * C), x1 + toff, ff_b2, ff_hs};
+  if (ff_part) {
+    const FusRegs fp{x2};
     if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, fp, out + toff, lane, h, next_bias);
     else scattn_epilogue_h2<false>(o, active, ss, vecs, fp, out + toff, lane, h);
     return;
@@ -1374,6 +1400,155 @@ k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_
   const FusTile ft{fus + toff};
   if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, ft, out + toff, lane, h, next_bias);
   else scattn_epilogue_h2<false>(o, active, ss, vecs, ft, out + toff, lane, h);
+}
+
+// k_scattn_merge_tile: the merge step of the small-grid layer (every item split, Fusion-2 branch as hidden-split partials) with
+// ONE workgroup per query TILE instead of one per four: the grids it serves leave most CUs idle (B = 1, N = 5000: 40 row
+// blocks), and its cost is a dependent chain - partial loads, then fc_message's 5 + PointCN's 4 weight blocks one after the
+// other in each wave.  Here the four waves of a workgroup share ONE tile and split its 32-feature blocks: every wave merges
+// the partials of its own block (a quarter of the loads), and the blocks of a level are multiplied in PARALLEL -
+//   fc_message 128 -> 64 (2 blocks, waves 0 1) -> 64 (2 blocks) -> 128 (4 blocks, + the Fusion-2 branch) -> PointCN 128 (4 blocks)
+// - four levels instead of twelve block steps, the level outputs exchanged as split-fp16 fragments through 16 KiB of LDS.
+// Same arithmetic per element, same order of additions as k_scattn_merge: bit-identical results.  grid (tiles, B), block 256.
+__global__ void __launch_bounds__(256, 1)
+k_scattn_merge_tile(const float* __restrict__ part_o, const float* __restrict__ part_ml, const float* __restrict__ wst,
+                    const float* __restrict__ vecs, float* __restrict__ out, int tiles, int ksplits,
+                    const float* __restrict__ next_wst, const float* __restrict__ next_bias, const float* __restrict__ ff_part,
+                    int ff_hs, const float* __restrict__ x1, const float* __restrict__ ff_b2) {
+  __shared__ __attribute__((aligned(16))) float lds[10 * kStageFloats];       // 9 weight stages | exchange
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x, pair = blockIdx.y;
+  const size_t n_tiles_all = (size_t)gridDim.y * tiles;
+  const size_t pt0 = (size_t)pair * tiles + tile;
+  const size_t toff = pt0 * (32 * C);
+  float* const xch = lds + 9 * kStageFloats;
+  f16x8* const xh = reinterpret_cast<f16x8*>(xch);
+  StagesPreloaded ss;
+  ss.init(lds, wave, lane, wst, 5, next_wst);
+  auto stage = [&](int st) { return reinterpret_cast<const f16x8*>(lds + st * kStageFloats) + lane; };
+
+  // everything this wave will need from global memory is requested now
+  float b1[16], b2[16], b3[16], b4[16];
+  if (wave < 2) { load_vec_block(b1, vecs, wave, h); load_vec_block(b2, vecs + 64, wave, h); }
+  load_vec_block(b3, vecs + 128, wave, h);
+  if (next_wst) load_vec_block(b4, next_bias, wave, h);
+  float x2b[16];                                  // the Fusion-2 branch, block `wave`: x2 = sum_z part[z] 2^-8 + b2 + x1
+  {
+    float bb[16], xr[16], acc[16];
+    load_vec_block(bb, ff_b2, wave, h);
+    load_block_p32(acc, ff_part + toff, wave, lane);
+    load_block_p32(xr, x1 + toff, wave, lane);
+    for (int z = 1; z < ff_hs; ++z) {
+      float pz[16];
+      load_block_p32(pz, ff_part + toff + (size_t)z * n_tiles_all * (32 * C), wave, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += pz[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x2b[r] = fmaf(acc[r], kH2Inv, bb[r]) + xr[r];
+  }
+  // merge of the key-split partials, feature block `wave`
+  float o[16];
+  {
+    float mk[8], lk[8], ok[8][16];
+    float M = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      mk[k] = -INFINITY; lk[k] = 0.f;
+      if (k < ksplits) {
+        const float2 ml = *reinterpret_cast<const float2*>(part_ml + ((k * n_tiles_all + pt0) * 32 + i) * 2);
+        mk[k] = ml.x; lk[k] = ml.y;
+        load_block_p32(ok[k], part_o + (k * n_tiles_all + pt0) * (32 * C), wave, lane);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) M = fmaxf(M, mk[k]);
+    float l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < ksplits) {
+        const float wk = __builtin_amdgcn_exp2f(mk[k] - M);
+        l = fmaf(lk[k], wk, l);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = fmaf(ok[k][r], wk, o[r]);
+      }
+    }
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= inv;
+  }
+  store_block_h2(xch, wave, o, lane);             // the attention output as a 128-wide fragment image (16 KiB)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the nine weight stages
+  __syncthreads();
+  // ---- level 1: m1 = ReLU(Wa o + ba), 2 blocks ----
+  if (wave < 2) {
+    FragH2<8> ox;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { ox.h[s] = xh[(0 * 8 + s) * 64 + lane]; ox.l[s] = xh[(1 * 8 + s) * 64 + lane]; }
+    f32x16 acc = zero16();
+    mma_wx_h2<8>(acc, stage(wave), ox);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = fmaxf(fmaf(acc[r], kH2Inv, b1[r]), 0.f);
+    __syncthreads();                              // (both readers of `o` are done: m1 goes where it was)
+    f16x8 hi, lo;
+    split8h(&t[0], hi, lo); xh[(0 * 4 + 2 * wave) * 64 + lane] = hi; xh[(1 * 4 + 2 * wave) * 64 + lane] = lo;
+    split8h(&t[8], hi, lo); xh[(0 * 4 + 2 * wave + 1) * 64 + lane] = hi; xh[(1 * 4 + 2 * wave + 1) * 64 + lane] = lo;
+  } else {
+    __syncthreads();
+  }
+  __syncthreads();
+  // ---- level 2: m2 = ReLU(Wb m1 + bb), 2 blocks ----
+  if (wave < 2) {
+    FragH2<4> m1x;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { m1x.h[s] = xh[(0 * 4 + s) * 64 + lane]; m1x.l[s] = xh[(1 * 4 + s) * 64 + lane]; }
+    f32x16 acc = zero16();
+    mma_wx_h2<4>(acc, stage(2) + wave * (2 * 4 * 64), m1x);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = fmaxf(fmaf(acc[r], kH2Inv, b2[r]), 0.f);
+    __syncthreads();
+    f16x8 hi, lo;
+    split8h(&t[0], hi, lo); xh[(0 * 4 + 2 * wave) * 64 + lane] = hi; xh[(1 * 4 + 2 * wave) * 64 + lane] = lo;
+    split8h(&t[8], hi, lo); xh[(0 * 4 + 2 * wave + 1) * 64 + lane] = hi; xh[(1 * 4 + 2 * wave + 1) * 64 + lane] = lo;
+  } else {
+    __syncthreads();
+  }
+  __syncthreads();
+  // ---- level 3: feat = Wc m2 + bc + x2, 4 blocks ----
+  float tt[16];
+  {
+    FragH2<4> m2x;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { m2x.h[s] = xh[(0 * 4 + s) * 64 + lane]; m2x.l[s] = xh[(1 * 4 + s) * 64 + lane]; }
+    f32x16 acc = zero16();
+    mma_wx_h2<4>(acc, stage(3 + (wave >> 1)) + (wave & 1) * (2 * 4 * 64), m2x);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tt[r] = fmaf(acc[r], kH2Inv, b3[r]) + x2b[r];
+  }
+  if (!next_wst) {                                // last layer: the block output itself
+    store_block_p32(out + toff, wave, tt, lane);
+    return;
+  }
+  __syncthreads();                                // every wave has read m2
+  store_block_h2(xch, wave, tt, lane);
+  __syncthreads();
+  // ---- level 4: f_next = ReLU(Wp feat + bp), 4 blocks ----
+  {
+    FragH2<8> fx;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { fx.h[s] = xh[(0 * 8 + s) * 64 + lane]; fx.l[s] = xh[(1 * 8 + s) * 64 + lane]; }
+    f32x16 acc = zero16();
+    mma_wx_h2<8>(acc, stage(5 + wave), fx);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = fmaxf(fmaf(acc[r], kH2Inv, b4[r]), 0.f);
+    store_block_p32(out + toff, wave, t, lane);
+  }
 }
 
 // =========================================================================================
@@ -1880,15 +2055,19 @@ void plan_attn_split(const Tuning& tune, int W, int tiles, int max_splits, int* 
 // Preconditions (checked by the caller with plan_attn_split / plan_ff_split): every attention item is split, ff_hs > 1.
 hipError_t launch_small_attn_ff_merge(const float* q, const float* k, const float* v, const float* x1, const float* ff_wst,
                                       const float* ff_vecs, float* ff_part, int ff_hs, const float* tail_vecs, float* out, int B,
-                                      int N, int tiles, int ksplits, hipStream_t s, const CompatCache* cc) {
+                                      int N, int tiles, int ksplits, hipStream_t s, const CompatCache* cc, bool tile_merge) {
   const int wpp = (tiles + 3) / 4, W = wpp * B;
   const int per_xcd = (W >> 3) + ((W & 7) ? 1 : 0);
   const int n_attn = 8 * per_xcd * ksplits, n_ff = W * ff_hs;
   hipLaunchKernelGGL(k_small_attn_ff, dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
                      cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs);
-  hipLaunchKernelGGL(k_scattn_merge, dim3(8 * per_xcd), dim3(256), 0, s, cc->part_o, cc->part_ml, x1, cc->tail_wst_h2, tail_vecs, out,
-                     tiles, wpp, W, 0, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)ff_part, ff_hs, x1,
-                     ff_vecs + 2 * C + 2 * FFH);
+  if (tile_merge)
+    hipLaunchKernelGGL(k_scattn_merge_tile, dim3(tiles, B), dim3(256), 0, s, cc->part_o, cc->part_ml, cc->tail_wst_h2, tail_vecs, out,
+                       tiles, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)ff_part, ff_hs, x1, ff_vecs + 2 * C + 2 * FFH);
+  else
+    hipLaunchKernelGGL(k_scattn_merge, dim3(8 * per_xcd), dim3(256), 0, s, cc->part_o, cc->part_ml, x1, cc->tail_wst_h2, tail_vecs, out,
+                       tiles, wpp, W, 0, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)ff_part, ff_hs, x1,
+                       ff_vecs + 2 * C + 2 * FFH);
   return hipGetLastError();
 }
 

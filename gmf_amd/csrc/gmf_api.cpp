@@ -91,6 +91,10 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     t.topk_select = value != 0;
     return GMF_OK;
   }
+  if (std::strcmp(name, "small_merge_tile") == 0) {    // small grids: merge step per query tile (1, default) or per four (0)
+    t.small_merge_tile = value != 0;
+    return GMF_OK;
+  }
   if (std::strcmp(name, "mid_grid_roles") == 0) {      // two-launch form below this many base workgroups: linear kernel as two roles (0 = never)
     GMF_REQUIRE(value >= 0 && value <= 4096, GMF_ERR_BAD_ARG, "set_tuning: mid_grid_roles out of range (0..4096)");
     t.mid_grid_roles = value;
@@ -432,7 +436,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (int rc = prof_begin(h, st, &e0, &e1)) return rc;
         GMF_HIP(gmf::launch_small_attn_ff_merge(q, k, v, x1, ffw, ffv, ff_part, ff_hs, w->tail_vec + (size_t)l * w->tail_vec_stride,
-                                                last3 ? cur : f, B, N, tiles, small_ks, st, &cc));
+                                                last3 ? cur : f, B, N, tiles, small_ks, st, &cc, h->tune.small_merge_tile));
         if (e1) GMF_HIP(hipEventRecord(e1, st));
         continue;
       } else {

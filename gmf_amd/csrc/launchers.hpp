@@ -31,6 +31,7 @@ struct Tuning {
                              // little (32 x 5000: 1.10 ms split vs 1.07 ms whole, measured)
   int ff_split = 0;          // feed-forward hidden splits on small grids: 0 = automatic, 1 = off, 2 / 4 / 8 = forced
   bool front_split = true;   // small grids: one workgroup per output (Q' + f | K | V) of k_front_h2
+  bool small_merge_tile = true;   // small grids: the merge step with one workgroup per query tile, its waves splitting the feature blocks
   bool small_roles = true;   // small grids: three launches per layer with two kinds of workgroups each (else five or six)
   bool fused_linear = true;  // one kernel per layer for Q'/K/V + Fusion-2 (k_linear_h2) with the next PointCN in the attention epilogue
   int conv_patch = 1;        // stride-1 3x3 convolutions: 1 = LDS patch kernel (automatic form), 2 = never three workgroups per CU, 0 = gather kernel
@@ -87,7 +88,7 @@ hipError_t launch_small_front_fattn(const float* f, const float* front_wst, cons
                                     int N, int tiles, int T, int ttiles, hipStream_t s);
 hipError_t launch_small_attn_ff_merge(const float* q, const float* k, const float* v, const float* x1, const float* ff_wst,
                                       const float* ff_vecs, float* ff_part, int ff_hs, const float* tail_vecs, float* out, int B,
-                                      int N, int tiles, int ksplits, hipStream_t s, const CompatCache* cc);
+                                      int N, int tiles, int ksplits, hipStream_t s, const CompatCache* cc, bool tile_merge = true);
 hipError_t launch_ctx_prep_h2(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
                               int ttiles, int sets, int wst_stride, int vec_stride, hipStream_t s);
 hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,

@@ -765,6 +765,27 @@ def test_small_grid_three_launch_layers(golden_dir, model, roles, N):
     assert _maxerr(res["final_trans"].cpu(), g[f"final_trans_N{N}"]) < 1e-4
 
 
+@pytest.mark.parametrize("B,N", [(1, 5000), (1, 1000), (2, 1531), (3, 257)])
+def test_small_grid_merge_forms_are_bit_identical(model, B, N):
+    """The merge step of the small-grid layer: one workgroup per query tile whose four waves split the feature blocks and run
+    the blocks of a level in parallel (default) against one workgroup per four tiles - same arithmetic per element, same order."""
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    b = synthetic.synthetic_batch(list(range(40, 40 + B)), N=N, T=196)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    out = {}
+    try:
+        for form in (1, 0):
+            h.call("gmf_set_tuning", b"small_merge_tile", form)
+            res = model(data)
+            out[form] = (model.last_logits.clone(), res["final_trans"].clone())
+    finally:
+        h.call("gmf_set_tuning", b"small_merge_tile", 1)
+    assert torch.isfinite(out[1][0]).all()
+    assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][1], out[0][1])
+
+
 def test_tuning_rejects_unknown_and_removed_settings():
     """The round-1 timing-only ablations (scattn_variant 11..15: wrong results) and the measured-and-rejected forms are no
     longer part of the library: gmf_set_tuning refuses them, out-of-range values and unknown knobs with GMF_ERR_BAD_ARG (-1)

@@ -216,6 +216,8 @@ k_ctx_prep_h2(const float* __restrict__ ctx, const float* __restrict__ wst, cons
 // k_fusion_attn_h2: stages: Wq''[2] | ctx tiles [ttiles] (Kc | Vc fp16x2 images from k_ctx_prep_h2) | Wo[2]
 //   vecs: query taps | gamma | beta | bo (fp32).  P is scaled by 2^10 as in k_scattn_h2.
 // =========================================================================================
+constexpr int kFattnLdsFloats = kRing * kStageFloats + 7 * C + kWavesPerWG * 2 * C;   // ring | vectors | halo rows
+
 template <bool PE>
 GMF_DEVINL void fusion_attn_h2_body(float* lds, const int bx, const int pair, const float* __restrict__ xin,
                                     const float* __restrict__ ctx_img, const float* __restrict__ wst,
@@ -228,21 +230,30 @@ GMF_DEVINL void fusion_attn_h2_body(float* lds, const int bx, const int pair, co
   const float* pair_base = xin + (size_t)pair * tiles * (32 * C);
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
 
+  // behind the ring (kFattnLdsFloats): the kernel's per-feature vectors and, per wave, the two halo rows of the LCPE - requested
+  // before the ring's stages (k_linear_h2 has the reasons: a tap / gamma / bias fetched from global memory where it is used is a
+  // memory round trip in the middle of the chain, and a lone wave per SIMD has nothing to hide it behind)
+  float* const lvec = lds + kRing * kStageFloats;
+  float* const halo = lvec + 7 * C + wave * (2 * C);
+  dma_vec(vecs, lvec, 7 * C, wave, kWavesPerWG, lane);
+  if (PE) LcpeHalo<CF>::issue(pair_base, tile, tiles, halo, lane);
   StageRing<kRing> ss;
   ss.init(lds, wave, lane, wst, 2,
           ctx_img + (size_t)pair * ttiles * kStageFloats, ttiles, wst + 2 * kStageFloats, 2);
   ss.prime();
 
   float xp[CF];
-  if (PE) lcpe_frag(xp, pair_base, tile * 32 + i, N, vecs, h);
-  else load_frag_p32<CF>(xp, pair_base + (size_t)tile * (32 * C), lane);
+  load_frag_p32<CF>(xp, pair_base + (size_t)tile * (32 * C), lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (PE) LcpeHalo<CF>::apply(xp, halo, lvec, tile * 32 + i, N, lane);
 
   FragH2<4> qx;
   {
     FragH2<8> nx;
     {
       float xn[CF];
-      layernorm_frag<CF>(xn, xp, vecs + 4 * C, vecs + 5 * C, h);
+      layernorm_frag<CF>(xn, xp, lvec + 4 * C, lvec + 5 * C, h);
       nx.set(xn);
     }
 #pragma unroll
@@ -319,7 +330,7 @@ GMF_DEVINL void fusion_attn_h2_body(float* lds, const int bx, const int pair, co
       f32x16 acc = zero16();
       mma_wx_h2<4>(acc, lw + hb * (2 * 4 * 64), ox);     // a 32 x 64 block = 2 planes x 4 steps x 64 units
       float b[16], t[16];
-      load_vec_block(b, vecs + 6 * C, mb, h);
+      load_vec_block(b, lvec + 6 * C, mb, h);
 #pragma unroll
       for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, b[r]) + xp[16 * mb + r];
       if (active) store_block_p32(x1_out + toff, mb, t, lane);
@@ -331,7 +342,7 @@ template <bool PE>
 __global__ void __launch_bounds__(256, 2)
 k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_img, const float* __restrict__ wst,
                  const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
-  __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kFattnLdsFloats];
   fusion_attn_h2_body<PE>(lds, blockIdx.x, blockIdx.y, xin, ctx_img, wst, vecs, x1_out, N, tiles, T, ttiles);
 }
 
@@ -344,7 +355,7 @@ k_small_front_fattn(const float* __restrict__ f_in, const float* __restrict__ fr
                     const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
                     float* __restrict__ q_out, float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x1_out,
                     int N, int tiles, int T, int ttiles) {
-  __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kFattnLdsFloats];
   if (blockIdx.z < 3)
     front_h2_body<2>(lds, blockIdx.x, blockIdx.y, blockIdx.z, f_in, front_wst, front_vec, nullptr, q_out, k_out, v_out, N, tiles);
   else

@@ -650,7 +650,7 @@ int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, 
   GMF_HIP(gmf::launch_pack_p32(feat_n, fimg, B, N, kC, (long)N * kC, kC, 1, st));
   GMF_HIP(gmf::launch_seed_dist(fimg, seeds_use, dmat, B, N, Sn, st));
   GMF_HIP(gmf::launch_knn_seeds(feat_n, seeds_use, dmat, knn, B, N, Sn, k, st));
-  GMF_HIP(gmf::launch_seed_power(fimg, src_keypts, tgt_keypts, knn, snaps, conv, hsum, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));
+  GMF_HIP(gmf::launch_seed_power(feat_n, src_keypts, tgt_keypts, knn, snaps, conv, hsum, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));
   GMF_HIP(gmf::launch_seed_kabsch(src_keypts, tgt_keypts, knn, snaps, conv, sT, B, N, Sn, k, iters, hsum, stop_it, st));
   GMF_HIP(gmf::launch_score_hyp(src_keypts, tgt_keypts, sT, counts, B, N, Sn, p->inlier_threshold, st));
   GMF_HIP(gmf::launch_finalize_pose(src_keypts, tgt_keypts, sT, counts, fit, final_trans, final_labels, best, B, N, Sn,

@@ -221,16 +221,13 @@ int gmf_pose_head_backward(gmf_handle* h, const gmf_pose_params* p, const float*
   SetDevice sd(h);
   hipStream_t st = S(stream);
   const size_t BS = (size_t)B * Sn;
-  const size_t n_img = (size_t)B * tiles_of(N) * kTileFloats;
-  if (int rc = arena_reserve(h, arena_need(n_img, 4) + arena_need(BS * iters * k, 4) + arena_need(BS * iters, 1) + arena_need(1, 4)))
+  if (int rc = arena_reserve(h, arena_need(BS * iters * k, 4) + arena_need(BS * iters, 1) + arena_need(1, 4)))
     return rc;
-  float* fimg = arena_take<float>(h, n_img);
   float* snaps = arena_take<float>(h, BS * iters * k);
   unsigned char* conv = arena_take<unsigned char>(h, BS * iters);
   int* stop_it = arena_take<int>(h, 1);
   // the forward's iterates and convergence flags of every seed (the stop iteration is a property of all seeds of a pair)
-  GMF_HIP(gmf::launch_pack_p32(feat_n, fimg, B, N, kC, (long)N * kC, kC, 1, st));
-  GMF_HIP(gmf::launch_seed_power(fimg, src_keypts, tgt_keypts, knn_idx, snaps, conv, nullptr, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));
+  GMF_HIP(gmf::launch_seed_power(feat_n, src_keypts, tgt_keypts, knn_idx, snaps, conv, nullptr, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));
   GMF_HIP(hipMemsetAsync(d_feat_n, 0, (size_t)B * N * kC * sizeof(float), st));
   if (B > 1) GMF_HIP(gmf::launch_stop_iteration(conv, B, Sn, iters, stop_it, st));     // the reference's allclose spans the batch
   GMF_HIP(gmf::launch_pose_best_backward(feat_n, src_keypts, tgt_keypts, knn_idx, fitness, snaps, conv, d_final_trans, d_feat_n,

@@ -14,7 +14,7 @@ hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* 
 // hsum non-null ([B,S,15] doubles): the centroids and H of the weighted Kabsch problem of the LAST power iterate are summed
 // in the same kernel; launch_seed_kabsch given the same buffer then only runs the SVD (and redoes the sums of pairs whose
 // iteration stopped earlier)
-hipError_t launch_seed_power(const float* featn_img, const float* src, const float* tgt, const int* knn_idx, float* snaps,
+hipError_t launch_seed_power(const float* feat_n /* row-major [B, N, 128] */, const float* src, const float* tgt, const int* knn_idx, float* snaps,
                              unsigned char* conv, double* hsum, int B, int N, int S, int k, int iters, float sigma,
                              float sigma_d, hipStream_t s);
 hipError_t launch_seed_kabsch(const float* src, const float* tgt, const int* knn_idx, const float* snaps,

@@ -601,16 +601,20 @@ constexpr int kKMax = 64;
 // (G10 = G01^T) with 64 MFMAs each; lane (h, b) then owns column b of each tile and turns the dot products into
 // M entries together with the spatial term.
 __global__ void __launch_bounds__(64)
-k_seed_power(const float* __restrict__ featn_img, const float* __restrict__ src, const float* __restrict__ tgt,
+k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, const float* __restrict__ tgt,
              const int* __restrict__ knn_idx, float* __restrict__ snaps, unsigned char* __restrict__ conv,
-             double* __restrict__ hsum, int N, int tiles, int S, int k, int iters, float inv_sigma2, float inv_sigmad2) {
-  __shared__ float Mx[kKMax * (kKMax + 1)];
-  __shared__ float P[kKMax * 8];
-  __shared__ float vec[kKMax];
+             double* __restrict__ hsum, int N, int S, int k, int iters, float inv_sigma2, float inv_sigmad2) {
+  // LDS sized by k (dynamic): the k x k matrix with row stride k + 1 - at k = 40 9 KiB per seed instead of 19, i.e. 17 instead
+  // of 8 resident seeds per CU for a kernel that is one latency chain per seed
+  extern __shared__ __attribute__((aligned(16))) float seed_smem[];
+  float* const P = seed_smem;                      // [64][8]: xyz of the neighbour in the two clouds
+  float* const vec = P + kKMax * 8;                // [64]
+  float* const Mx = vec + kKMax;                   // [k][k + 1]
+  const int ld = k + 1;
   const int pair = blockIdx.y, s = blockIdx.x, a = threadIdx.x;
   const int lane = a, h = lane >> 5, i = lane & 31;
   const int* nb = knn_idx + ((size_t)pair * S + s) * k;
-  const float* pair_img = featn_img + (size_t)pair * tiles * (32 * 128);
+  const float* pair_rows = feat_n + (size_t)pair * N * 128;
   {
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* Pz = reinterpret_cast<float4*>(P);
@@ -623,9 +627,29 @@ k_seed_power(const float* __restrict__ featn_img, const float* __restrict__ src,
     P[a * 8 + 0] = ps[0]; P[a * 8 + 1] = ps[1]; P[a * 8 + 2] = ps[2];
     P[a * 8 + 4] = pt[0]; P[a * 8 + 5] = pt[1]; P[a * 8 + 6] = pt[2];
   }
+  // the neighbours' unit features as two 32-row fragments, gathered from the ROW-MAJOR features: a row is 4 cache lines there;
+  // in the P32 image (what the MFMA kernels stream) a row's 16-byte pieces lie 512 bytes apart - 32 lines per row, and this
+  // kernel's 16 000 gathering waves were bound by that line traffic (4 GB per launch at 32 x 5000)
+  auto row_frag = [&](float (&x)[64], const int row) {
+    if (row >= 0 && row < N) {
+      const float4* p = reinterpret_cast<const float4*>(pair_rows + (size_t)row * 128) + h;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {                 // fragment group g = features 32 (g >> 2) + 8 (g & 3) + 4 h .. + 3
+        const float4 t = p[8 * (g >> 2) + 2 * (g & 3)];
+        x[4 * g + 0] = t.x; x[4 * g + 1] = t.y; x[4 * g + 2] = t.z; x[4 * g + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 64; ++e) x[e] = 0.f;
+    }
+  };
   float fa[64], fb[64];
-  gmf::load_row_frag_p32<64>(fa, pair_img, (i < k) ? nb[i] : -1, N, h);
-  gmf::load_row_frag_p32<64>(fb, pair_img, (32 + i < k) ? nb[32 + i] : -1, N, h);
+  row_frag(fa, (i < k) ? nb[i] : -1);
+  if (k > 32) row_frag(fb, (32 + i < k) ? nb[32 + i] : -1);
+  else {
+#pragma unroll
+    for (int e = 0; e < 64; ++e) fb[e] = 0.f;
+  }
   __syncthreads();
 
   // tile (ta, tb): rows 32*ta + a', cols 32*tb + (lane & 31)
@@ -643,8 +667,8 @@ k_seed_power(const float* __restrict__ featn_img, const float* __restrict__ src,
         const float d = sqrtf(ax * ax + ay * ay + az * az) - sqrtf(bx * bx + by * by + bz * bz);
         const float ms = fmaxf(1.0f - d * d * inv_sigmad2, 0.f);
         const float m = (ar == b) ? 0.f : mf * ms;
-        Mx[ar * (kKMax + 1) + b] = m;
-        if (mirror) Mx[b * (kKMax + 1) + ar] = m;
+        Mx[ar * ld + b] = m;
+        if (mirror) Mx[b * ld + ar] = m;
       }
     }
   };
@@ -676,7 +700,7 @@ k_seed_power(const float* __restrict__ featn_img, const float* __restrict__ src,
   unsigned char* cv = conv + ((size_t)pair * S + s) * iters;
   for (int it = 0; it < iters; ++it) {
     float v = 0.f;
-    if (a < k) for (int b = 0; b < k; ++b) v = fmaf(Mx[a * (kKMax + 1) + b], vec[b], v);
+    if (a < k) for (int b = 0; b < k; ++b) v = fmaf(Mx[a * ld + b], vec[b], v);
     float n2 = (a < k) ? v * v : 0.f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o, 64);
@@ -1426,11 +1450,12 @@ hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* 
   return hipGetLastError();
 }
 
-hipError_t launch_seed_power(const float* featn_img, const float* src, const float* tgt, const int* knn_idx, float* snaps,
+hipError_t launch_seed_power(const float* feat_n, const float* src, const float* tgt, const int* knn_idx, float* snaps,
                              unsigned char* conv, double* hsum, int B, int N, int S, int k, int iters, float sigma,
                              float sigma_d, hipStream_t s) {
   if (k > kKMax) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_seed_power, dim3(S, B), dim3(64), 0, s, featn_img, src, tgt, knn_idx, snaps, conv, hsum, N, (N + 31) / 32, S, k,
+  const size_t lds_bytes = (size_t)(kKMax * 8 + kKMax + k * (k + 1)) * sizeof(float);
+  hipLaunchKernelGGL(k_seed_power, dim3(S, B), dim3(64), lds_bytes, s, feat_n, src, tgt, knn_idx, snaps, conv, hsum, N, S, k,
                      iters, 1.0f / (sigma * sigma), 1.0f / (sigma_d * sigma_d));
   return hipGetLastError();
 }

@@ -255,7 +255,7 @@ def sweep(dev):
                      "unit": "correspondences/s", "step_frac_of_peak": tf / peak})
         del model, data
         torch.cuda.empty_cache()
-    # the throughput numerics mode (gmf_set_tuning "precision" = 1; NOT the parity path, never the headline) on the headline
+    # the throughput numerics modes (gmf_set_tuning "precision" = 1, 2; NOT the parity path, never the headline) on the headline
     # workload, with its measured deviation from the parity mode on the same batch
     from gmf_amd import _lib
     model, _, _ = build_model(dev, "3dmatch")
@@ -264,17 +264,20 @@ def sweep(dev):
     hnd = _lib.handle_for(dev.index or 0)
     res0 = model(data)
     lg0, T0 = model.last_logits.clone(), res0["final_trans"].clone()
-    try:
-        hnd.call("gmf_set_tuning", b"precision", 1)
-        res1 = model(data)
-        dl, dT = float((model.last_logits - lg0).abs().max()), float((res1["final_trans"] - T0).abs().max())
-        dt = min(time_steps(drv, data, 5, 2)[0] for _ in range(3))
-    finally:
-        hnd.call("gmf_set_tuning", b"precision", 0)
-    ms = dt / 5 * 1e3
-    rows.append({"workload": "3dmatch 32 pairs x 5000, throughput numerics (precision = 1: fp16 one-product attention, fp16 compat)",
-                 "ms_per_step": ms, "value": 32 * 5000 / (ms * 1e-3), "unit": "correspondences/s",
-                 "max_abs_dlogit_vs_parity_mode": dl, "max_abs_dT_vs_parity_mode": dT, "within_parity_gate": False})
+    labels = {1: "throughput numerics (precision = 1: fp16 one-product attention, fp16 compat)",
+              2: "throughput numerics, level 2 (precision = 2: level 1 + one-product linear stages)"}
+    for level in (1, 2):
+        try:
+            hnd.call("gmf_set_tuning", b"precision", level)
+            res1 = model(data)
+            dl, dT = float((model.last_logits - lg0).abs().max()), float((res1["final_trans"] - T0).abs().max())
+            dt = min(time_steps(drv, data, 5, 2)[0] for _ in range(3))
+        finally:
+            hnd.call("gmf_set_tuning", b"precision", 0)
+        ms = dt / 5 * 1e3
+        rows.append({"workload": "3dmatch 32 pairs x 5000, " + labels[level],
+                     "ms_per_step": ms, "value": 32 * 5000 / (ms * 1e-3), "unit": "correspondences/s",
+                     "max_abs_dlogit_vs_parity_mode": dl, "max_abs_dT_vs_parity_mode": dT, "within_parity_gate": False})
     del model, data
     torch.cuda.empty_cache()
     return rows

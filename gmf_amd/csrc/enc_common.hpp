@@ -175,6 +175,30 @@ GMF_DEVINL void mma_xw_h2(f32x16& acc, const f16x8* lw, const FragH2<NS>& x) {
   for (int s = 0; s < NS; ++s) mma3(acc, x.h[s], x.l[s], lw[(0 * NS + s) * 64], lw[(1 * NS + s) * 64]);
 }
 
+// The same products with NP = 3 (parity: split-fp16, three partial products) or NP = 1 (the throughput numerics mode: only the
+// high planes are multiplied - the low planes are neither read from the LDS nor formed)
+template <int NP>
+GMF_DEVINL void mma_np(f32x16& acc, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
+  if (NP == 3) mma3(acc, ah, al, bh, bl);
+  else acc = mfma_h16(ah, bh, acc);
+}
+template <int NS, int NP>
+GMF_DEVINL void mma_wx_h2n(f32x16& acc, const f16x8* lw, const FragH2<NS>& x) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    if (NP == 3) mma3(acc, lw[(0 * NS + s) * 64], lw[(1 * NS + s) * 64], x.h[s], x.l[s]);
+    else acc = mfma_h16(lw[(0 * NS + s) * 64], x.h[s], acc);
+  }
+}
+template <int NS, int NP>
+GMF_DEVINL void mma_xw_h2n(f32x16& acc, const f16x8* lw, const FragH2<NS>& x) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    if (NP == 3) mma3(acc, x.h[s], x.l[s], lw[(0 * NS + s) * 64], lw[(1 * NS + s) * 64]);
+    else acc = mfma_h16(x.h[s], lw[(0 * NS + s) * 64], acc);
+  }
+}
+
 GMF_DEVINL const f16x8* as_h2(const float4* p) { return reinterpret_cast<const f16x8*>(p); }
 
 GMF_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -10,6 +10,7 @@ namespace gmf {
 // `lds` is a ring of NB = 4 stages owned by the workgroup (the caller has made sure no wave still reads it); on return
 // every DMA piece this wave issued has landed.  Stage order A0 G0 | A1 G1 W2_0 | ... addressed into the unchanged blob
 // (16 x (A | G | W2)); past the end the last stage is re-fetched into a free slot instead of branching.
+template <int NP = 3>
 GMF_DEVINL void ff_chunks(const FragH2<8>& nx, f32x16 (&y)[4], float* lds, const float* __restrict__ wst,
                           const float* __restrict__ b1a, const float* __restrict__ b1g, const int wave, const int lane,
                           const int h, const int c_begin, const int NCH) {
@@ -52,9 +53,9 @@ GMF_DEVINL void ff_chunks(const FragH2<8>& nx, f32x16 (&y)[4], float* lds, const
   f32x16 a0 = bias_acc(b1a, c_begin), g0 = bias_acc(b1g, c_begin), a1, g1;
   {
     const f16x8* lw = acquire();
-    mma_wx_h2<8>(a0, lw, nx);
+    mma_wx_h2n<8, NP>(a0, lw, nx);
     lw = acquire();
-    mma_wx_h2<8>(g0, lw, nx);
+    mma_wx_h2n<8, NP>(g0, lw, nx);
   }
   // chunk c: gated values from (a_cur, g_cur); W1 of chunk c+1 accumulates into (a_nxt, g_nxt) meanwhile
   auto chunk = [&](const int c, f32x16& a_cur, const f32x16& g_cur, f32x16& a_nxt, f32x16& g_nxt, const bool has_next) {
@@ -65,14 +66,15 @@ GMF_DEVINL void ff_chunks(const FragH2<8>& nx, f32x16 (&y)[4], float* lds, const
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const f16x8* lw = acquire();
-        f16x8 wh = lw[0], wl = lw[8 * 64];
+        f16x8 wh = lw[0], wl = wh;
+        if (NP == 3) wl = lw[8 * 64];
         f16x8 wh_n = wh, wl_n = wl;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
           const int u = 8 * half + s;
-          if (s < 7) { wh_n = lw[(0 * 8 + s + 1) * 64]; wl_n = lw[(1 * 8 + s + 1) * 64]; }
-          if (half == 0) mma3(a_nxt, wh, wl, nx.h[s], nx.l[s]);
-          else mma3(g_nxt, wh, wl, nx.h[s], nx.l[s]);
+          if (s < 7) { wh_n = lw[(0 * 8 + s + 1) * 64]; if (NP == 3) wl_n = lw[(1 * 8 + s + 1) * 64]; }
+          if (half == 0) mma_np<NP>(a_nxt, wh, wl, nx.h[s], nx.l[s]);
+          else mma_np<NP>(g_nxt, wh, wl, nx.h[s], nx.l[s]);
           wh = wh_n; wl = wl_n;
           a_cur[u] *= gelu_erf_1r(g_cur[u]);
           if (half == 1 && (s & 1)) { const int j = s - 1; split2h(a_cur[j], a_cur[j + 1], gx.h[0], gx.l[0], j); }
@@ -92,7 +94,8 @@ GMF_DEVINL void ff_chunks(const FragH2<8>& nx, f32x16 (&y)[4], float* lds, const
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
           const f16x8* lb = lw + mb * (2 * 2 * 64);
-          mma3(y[mb], lb[(0 * 2 + s) * 64], lb[(1 * 2 + s) * 64], gx.h[s], gx.l[s]);
+          if (NP == 3) mma3(y[mb], lb[(0 * 2 + s) * 64], lb[(1 * 2 + s) * 64], gx.h[s], gx.l[s]);
+          else y[mb] = mfma_h16(lb[(0 * 2 + s) * 64], gx.h[s], y[mb]);
           if (s == 0) { const int j = 2 * mb; split2h(a_cur[8 + j], a_cur[8 + j + 1], gx.h[1], gx.l[1], j); }
           __builtin_amdgcn_sched_barrier(0);
         }

@@ -401,7 +401,7 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
 // LDS of the fused linear kernel: 4 stages | attention vectors | feed-forward vectors | 4 waves x 2 halo rows = 77.5 KiB (two workgroups per CU)
 constexpr int kLinLdsFloats = 4 * kStageFloats + 7 * C + (3 * C + 2 * FFH) + kWavesPerWG * 2 * C;
 
-template <int PART>
+template <int PART, int NP = 3>
 GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const float* __restrict__ front_wst,
                                const float* __restrict__ front_vec, const float* __restrict__ ctx_img,
                                const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
@@ -468,7 +468,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
                                 : sidx == 0 ? ss.acquire_counted<kYounger[0]>() : sidx == 1 ? ss.acquire_counted<kYounger[1]>()
                                 : sidx == 2 ? ss.acquire_counted<kYounger[2]>() : ss.acquire_counted<kYounger[3]>());
         f32x16 acc = zero16();
-        mma_wx_h2<8>(acc, lw, fx);
+        mma_wx_h2n<8, NP>(acc, lw, fx);
         float t[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bqk[which][16 * mb + r]);
@@ -479,7 +479,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
     for (int db = 0; db < 4; ++db) {             // V (feature on lane)
       const f16x8* lw = as_h2(PART == 1 ? ss.acquire() : ss.acquire_counted<20>());
       f32x16 acc = zero16();
-      mma_xw_h2<8>(acc, lw, fx);
+      mma_xw_h2n<8, NP>(acc, lw, fx);
       float t[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bvv[db]);
@@ -515,7 +515,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
         for (int mb = 0; mb < 2; ++mb) {
           const f16x8* lw = as_h2(ss.acquire());
           f32x16 acc = zero16();
-          mma_wx_h2<8>(acc, lw, nx);
+          mma_wx_h2n<8, NP>(acc, lw, nx);
           float t[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) t[r] = acc[r] * kH2Inv;
@@ -538,7 +538,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
       const f16x8* lk = as_h2(ss.acquire());
       const f16x8* lv = lk + 2 * 4 * 64;            // Vc image follows the Kc image (2 planes x 4 steps)
       f32x16 sc = zero16();
-      mma_wx_h2<4>(sc, lk, qx);
+      mma_wx_h2n<4, NP>(sc, lk, qx);
       float x[16];
       float mx = -INFINITY;
       if (t + 1 < ttiles) {
@@ -576,7 +576,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const int slot = 2 * db + s2;
-          mma3(oacc[db], lv[(0 * 4 + slot) * 64], lv[(1 * 4 + slot) * 64], ph, pl);
+          mma_np<NP>(oacc[db], lv[(0 * 4 + slot) * 64], lv[(1 * 4 + slot) * 64], ph, pl);
         }
       }
     }
@@ -595,7 +595,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
     for (int st = 0; st < 2; ++st) {
       const f16x8* lw = as_h2(ss.acquire());
 #pragma unroll
-      for (int hb = 0; hb < 2; ++hb) mma_wx_h2<4>(x1a[2 * st + hb], lw + hb * (2 * 4 * 64), ox);
+      for (int hb = 0; hb < 2; ++hb) mma_wx_h2n<4, NP>(x1a[2 * st + hb], lw + hb * (2 * 4 * 64), ox);
     }
   }
 
@@ -619,7 +619,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
     }
   }
   __syncthreads();                               // every wave is done with the 2-slot ring: the 4-slot ring may overwrite it
-  ff_chunks(nx, y, lds, ff_wst, lvec_f + 2 * C, lvec_f + 2 * C + FFH, wave, lane, h, 0, FFH / 32);
+  ff_chunks<NP>(nx, y, lds, ff_wst, lvec_f + 2 * C, lvec_f + 2 * C + FFH, wave, lane, h, 0, FFH / 32);
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     float t[16];
@@ -629,6 +629,10 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
   }
 }
 
+// NP = 3: the parity kernel.  NP = 1: the throughput numerics mode (gmf_set_tuning "precision" = 1) - every product of the layer's
+// linear part on the high fp16 planes only (a third of the MFMAs, half the LDS reads); LayerNorms, softmax, GELU, biases and
+// residuals stay fp32.  NOT within the parity gate.
+template <int NP>
 __global__ void __launch_bounds__(256, 2)
 k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst, const float* __restrict__ front_vec,
             const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
@@ -636,8 +640,8 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
             float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
             int ttiles) {
   __shared__ __attribute__((aligned(16))) float lds[kLinLdsFloats];
-  linear_h2_body<0>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N, tiles,
-                    T, ttiles);
+  linear_h2_body<0, NP>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
+                        tiles, T, ttiles);
 }
 
 // grid (ceil(tiles / 4), B, 2): blockIdx.z = 0 the Q'/K/V role, 1 the Fusion-2 role of the same 128 rows
@@ -703,14 +707,18 @@ hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const 
 
 hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                             const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec, float* q,
-                            float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s) {
+                            float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s,
+                            bool one_product) {
   // grids that give a CU about one workgroup: two roles per row block (the Q'/K/V projections | Fusion-2) in one launch
   const int W = ((tiles + 3) / 4) * B;
   if (tune.mid_grid_roles > 0 && W < tune.mid_grid_roles)
     hipLaunchKernelGGL(k_linear_roles, tgrid(tiles, B, 2), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec,
                        ff_wst, ff_vec, q, k, v, x2, N, tiles, T, ttiles);
+  else if (one_product)                            // throughput numerics mode: high planes only
+    hipLaunchKernelGGL(k_linear_h2<1>, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
+                       ff_vec, q, k, v, x2, N, tiles, T, ttiles);
   else
-    hipLaunchKernelGGL(k_linear_h2, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
+    hipLaunchKernelGGL(k_linear_h2<3>, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
                        ff_vec, q, k, v, x2, N, tiles, T, ttiles);
   return hipGetLastError();
 }

@@ -100,8 +100,8 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     t.mid_grid_roles = value;
     return GMF_OK;
   }
-  if (std::strcmp(name, "precision") == 0) {           // 0 = parity numerics (default), 1 = throughput numerics (NOT within 1e-4)
-    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: precision must be 0 (parity) or 1 (throughput)");
+  if (std::strcmp(name, "precision") == 0) {           // 0 = parity numerics (default), 1 / 2 = throughput numerics (NOT within 1e-4)
+    GMF_REQUIRE(value >= 0 && value <= 2, GMF_ERR_BAD_ARG, "set_tuning: precision must be 0 (parity), 1 or 2 (throughput numerics)");
     t.precision = value;
     return GMF_OK;
   }
@@ -394,9 +394,10 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
                                       w->ctx_vec_stride, st));
   }
   GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st));
-  // throughput numerics mode ("precision" = 1): on the two-launch path of large grids the attention multiplies one fp16
-  // product and streams the compat matrix as fp16; every other path keeps the parity numerics
-  cc.half = h->tune.precision == 1 && h2 && L > 0 && want_cache && h->tune.fused_linear && h->tune.scattn_variant == 18 &&
+  // throughput numerics ("precision" = 1, 2): on the two-launch path of large grids the attention multiplies one fp16
+  // product and streams the compat matrix as fp16 (level 2: the layer's linear stages multiply one product as well); every
+  // other path keeps the parity numerics
+  cc.half = h->tune.precision >= 1 && h2 && L > 0 && want_cache && h->tune.fused_linear && h->tune.scattn_variant == 18 &&
             ((tiles + 3) / 4) * B >= 256;
   if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, cc.half, st));
 
@@ -425,7 +426,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
       const float* ffv = w->ff_vec + (size_t)l * w->ff_vec_stride;
       const float* ctx_l = ctxall + (size_t)l * tok;
       if (one_kernel) {
-        GMF_HIP(gmf::launch_linear_h2(h->tune, f, fw, fv, ctx_l, aw, av, ffw, ffv, q, k, v, x2, B, N, tiles, T, tt, st));
+        GMF_HIP(gmf::launch_linear_h2(h->tune, f, fw, fv, ctx_l, aw, av, ffw, ffv, q, k, v, x2, B, N, tiles, T, tt, st, cc.half && h->tune.precision == 2));
       } else if (small3) {
         // three launches: {Q' | K | V | cross-attention} -> {key-split attention | hidden-split feed-forward} -> merge
         GMF_HIP(gmf::launch_small_front_fattn(f, fw, fv, ctx_l, aw, av, q, k, v, x1, B, N, tiles, T, tt, st));

@@ -79,7 +79,7 @@ hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const 
 // mode 3: corr_pos -> layer0 -> PointCN -> f only.  launch_linear_h2: all linear stages of one layer from f (k_linear_h2)
 hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                             const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec, float* q,
-                            float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
+                            float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s, bool one_product = false);
 // small grids: three launches per layer (k_small_front_fattn | k_small_attn_ff | k_scattn_merge)
 void plan_attn_split(const Tuning& tune, int W, int tiles, int max_splits, int* n_full, int* ksplits);
 int plan_ff_split(const Tuning& tune, int base, int max_parts);

@@ -380,14 +380,16 @@ class PointDSC(nn.Module):
         """Numerics of the eval-mode encoder on this module's device: "parity" (default - fp32-equivalent split-fp16 products,
         logits within 1e-4 of the reference) or "throughput" (on large grids the spatial-consistency
         attention multiplies plain fp16 operands and streams the compat matrix as fp16; measured deviation from the parity
-        mode at 32 x 5000: logits 1e-3, identical inlier labels 99.999 %, 1.4-1.6x the throughput).  The setting lives in the
+        mode at 32 x 5000: logits 1.6e-4, identical inlier labels, 1.46x the throughput) or "throughput_max" (the layer's linear
+        stages on plain fp16 operands as well: logits 4e-2, 98-100 % identical labels, 1.6x).  The setting lives in the
         device's library handle (gmf_set_tuning "precision"), i.e. it applies to every module on that device."""
-        if mode not in ("parity", "throughput"):
-            raise ValueError("gmf_amd.PointDSC.set_precision: mode must be 'parity' or 'throughput'")
+        levels = {"parity": 0, "throughput": 1, "throughput_max": 2}
+        if mode not in levels:
+            raise ValueError("gmf_amd.PointDSC.set_precision: mode must be 'parity', 'throughput' or 'throughput_max'")
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("gmf_amd.PointDSC.set_precision: the module must be on a HIP device")
-        _lib.handle_for(dev.index or 0).call("gmf_set_tuning", b"precision", 1 if mode == "throughput" else 0)
+        _lib.handle_for(dev.index or 0).call("gmf_set_tuning", b"precision", levels[mode])
 
     # -- encoder: logits + normalised features ----------------------------------------------------
     def encode(self, corr_pos, src_keypts, tgt_keypts, p_tokens, q_tokens, want_features=False):

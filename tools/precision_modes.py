@@ -42,10 +42,11 @@ def run(mode, n=10):
     return dt, model.last_logits.clone(), res["final_trans"].clone(), res["final_labels"].clone()
 
 
+LEVEL = int(os.environ.get("LEVEL", "1"))      # 1: one-product attention + fp16 compat; 2: + one-product linear stages
 t0, lg0, T0, lab0 = run(0)
-t1, lg1, T1, lab1 = run(1)
+t1, lg1, T1, lab1 = run(LEVEL)
 h.call("gmf_set_tuning", b"precision", 0)
-print(f"B={B} N={N} {kind}: parity {t0 * 1e3:.2f} ms = {B * N / t0 / 1e6:.2f} M corr/s | throughput {t1 * 1e3:.2f} ms = {B * N / t1 / 1e6:.2f} M corr/s"
+print(f"B={B} N={N} {kind} (precision {LEVEL}): parity {t0 * 1e3:.2f} ms = {B * N / t0 / 1e6:.2f} M corr/s | throughput {t1 * 1e3:.2f} ms = {B * N / t1 / 1e6:.2f} M corr/s"
       f"  ({t0 / t1:.2f}x)")
 dl = (lg1 - lg0).abs()
 print(f"logits: max |d| {float(dl.max()):.3e}, mean |d| {float(dl.mean()):.3e}, logit scale (rms) {float(lg0.pow(2).mean().sqrt()):.2f}")

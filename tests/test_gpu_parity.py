@@ -205,6 +205,30 @@ def test_stress_conditioning(golden_dir):
     assert err < 4 * max(floor, 2e-5), (err, floor)
 
 
+@pytest.mark.parametrize("scene,N,T", [(95, 3000, 40), (97, 3000, 196), (3, 777, 196)])
+def test_random_scenes_against_the_fp32_noise_floor(model, sd_full, scene, N, T):
+    """Scenes of the randomised sweep (tests/tools/parity_sweep.py, seeds 1000 + scene).  Scene 95 is the one of its first 100 where
+    fp32 arithmetic itself is short of the 1e-4 gate: the reference's own fp32 evaluation is 6.3e-5 from an fp64 evaluation of the
+    same network, and two fp32 evaluations that differ only in summation order then differ by up to about twice that.  The
+    contract tested: within 1e-4 of the fp32 oracle, or - where the oracle's own distance from fp64 is the larger number - within
+    2.5 x that distance; and never further from the fp64 result than 2 x the fp32 oracle is."""
+    b = synthetic.synthetic_batch([1000 + scene], N=N, T=T)
+    o32 = O.pointdsc_forward(sd_full, b, testing=True)["logits"]
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd_full.items()}
+    b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()}
+    compat, _ = O.compat_matrix(b64["src_keypts"], b64["tgt_keypts"], 0.1)
+    o64 = O.classifier(sd64, O.encoder(sd64, b64["corr_pos"], compat, b64["p_tokens"], b64["q_tokens"], 12))
+    floor = float((o32.double() - o64).abs().max())
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    model(data)
+    lg = model.last_logits.cpu()
+    e32, e64 = _maxerr(lg, o32), float((lg.double() - o64).abs().max())
+    print(f"scene {scene}: HIP vs fp32 oracle {e32:.2e}, vs fp64 {e64:.2e}; fp32 oracle vs fp64 {floor:.2e}")
+    assert e32 < max(1e-4, 2.5 * floor), (e32, floor)
+    assert e64 < max(1e-4, 2.0 * floor), (e64, floor)
+
+
 def test_f5_f7_pose_head(golden_dir, model):
     g = _load(golden_dir, "f5_f7_pose_head.npz")
     N = int(g["N"])

@@ -660,6 +660,265 @@ k_fusion_attn_w_h2(const float* __restrict__ xin, const float* __restrict__ ctx_
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_fusion_attn_w_tile: the cross-attention of the 256-wide layer with ONE workgroup per 32-row tile, for grids of up to 256
+// tiles (the usual size of the DGR bottleneck: 1000 - 8000 voxels are 32 - 250 tiles, i.e. 8 - 63 workgroups of
+// k_fusion_attn_w_h2, each wave walking 36 dependent stages).  The four waves share the tile and split every level:
+//   LCPE + LayerNorm   each wave its quarter of the row's 256 features; the LayerNorm statistics are exchanged through the LDS
+//   to_q               4 blocks of 32 outputs, one per wave (K = 256)
+//   context tiles      dealt round-robin to the waves, partial softmaxes merged through the LDS (as key-split partials)
+//   to_out             8 blocks of 32 outputs, two per wave, + bias + the wave's quarter of x'
+// No wave shares a weight block with another, so the blocks are loaded straight into registers (the next block requested
+// before the current one is multiplied); the LDS only carries the exchanges.  Same arithmetic per product as
+// k_fusion_attn_w_h2; the LayerNorm sums and the context tiles are added in another order (fp32 rounding).
+// grid (tiles, B), block 256.
+// ---------------------------------------------------------------------------------------------
+template <bool PE>
+__global__ void __launch_bounds__(256, 1)
+k_fusion_attn_w_tile(const float* __restrict__ xin, const float* __restrict__ ctx_img, const float* __restrict__ wst,
+                     const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
+  using namespace wide;
+  // LDS: vectors (7 KiB) | halo rows (2 KiB) | LayerNorm partial sums [2][4][64] | exchange: LN'd row image (32 KiB) | q image
+  //      (16 KiB); later the same exchange area holds the softmax partials [wave][66][64] (66 KiB)
+  __shared__ __attribute__((aligned(16))) float lds[7 * LAT + 2 * LAT + 512 + 4 * 66 * 64];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x, pair = blockIdx.y;
+  const float* pair_base = xin + (size_t)pair * tiles * (32 * LAT);
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * LAT);
+  float* const lvec = lds;
+  float* const halo = lvec + 7 * LAT;
+  float* const stats = halo + 2 * LAT;
+  float* const xch = stats + 512;
+  f16x8* const nxh = reinterpret_cast<f16x8*>(xch);                 // [plane][16 steps][64 lanes]
+  f16x8* const qh = reinterpret_cast<f16x8*>(xch + 8192);           // [plane][8 steps][64 lanes]
+  const float* ctx_pair = ctx_img + (size_t)pair * ttiles * (2 * kStageFloats);
+  const int row = tile * 32 + i;
+  const int g0 = 8 * wave;                                         // this wave's fragment groups [g0, g0 + 8): 32 of the lane's 128 features
+
+  auto load16 = [&](f16x8 (&dst)[32], const int at, const float* g) {      // one 16 KiB stage: 16 fragments
+    const f16x8* p = reinterpret_cast<const f16x8*>(g) + lane;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) dst[at + u] = p[u * 64];
+  };
+  f16x8 wa[32], wb[32];
+
+  // ---- prologue requests ----
+  dma_issue(vecs, lvec, 7, wave, kWaves, lane);
+  if (PE && wave == 0) LcpeHalo<LATF>::issue(pair_base, tile, tiles, halo, lane);
+  float xq[32];
+  {
+    const float4* p = reinterpret_cast<const float4*>(pair_base + (size_t)tile * (32 * LAT)) + lane;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const float4 t = p[(g0 + g) * 64];
+      xq[4 * g + 0] = t.x; xq[4 * g + 1] = t.y; xq[4 * g + 2] = t.z; xq[4 * g + 3] = t.w;
+    }
+  }
+  load16(wa, 0, wst + (size_t)(2 * wave) * kStageFloats);           // Wq'' block `wave`: hi plane | lo plane
+  load16(wa, 16, wst + (size_t)(2 * wave + 1) * kStageFloats);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                                 // (A) vectors and halo rows are in the LDS
+  if (wave < ttiles) {                                             // first context tile of this wave: K stage | V stage
+    load16(wb, 0, ctx_pair + (size_t)(2 * wave) * kStageFloats);
+    load16(wb, 16, ctx_pair + (size_t)(2 * wave + 1) * kStageFloats);
+  }
+  // ---- LCPE on the quarter (neighbour rows from the neighbour lanes, LcpeHalo) ----
+  if (PE) {
+    const bool has_m = row >= 1, has_p = row + 1 < N, first = i == 0, last = i == 31;
+    const float4* hl = reinterpret_cast<const float4*>(halo) + h;
+    const float4* t0 = reinterpret_cast<const float4*>(lvec) + h;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int gg = g0 + g;
+      const float4 up = hl[2 * gg], dn = hl[LAT / 4 + 2 * gg];
+      const float4 w0 = t0[2 * gg], w1 = t0[2 * gg + LAT / 4], w2 = t0[2 * gg + 2 * (LAT / 4)], b = t0[2 * gg + 3 * (LAT / 4)];
+      const float upv[4] = {up.x, up.y, up.z, up.w}, dnv[4] = {dn.x, dn.y, dn.z, dn.w};
+      const float w0v[4] = {w0.x, w0.y, w0.z, w0.w}, w1v[4] = {w1.x, w1.y, w1.z, w1.w}, w2v[4] = {w2.x, w2.y, w2.z, w2.w};
+      const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xc = xq[4 * g + e];
+        float xm = LcpeHalo<LATF>::from_lane_below(xc), xn = LcpeHalo<LATF>::from_lane_above(xc);
+        xm = first ? upv[e] : xm;
+        xn = last ? dnv[e] : xn;
+        xm = has_m ? xm : 0.f;
+        xn = has_p ? xn : 0.f;
+        xq[4 * g + e] = xc + bv[e] + w0v[e] * xm + w1v[e] * xc + w2v[e] * xn;
+      }
+    }
+  }
+  // ---- LayerNorm over the 256 features of a row: two passes, partial sums of the four waves through the LDS ----
+  float mu, rstd;
+  {
+    float sp = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) sp += xq[e];
+    sp = xhalf_sum(sp);
+    stats[(0 * 4 + wave) * 64 + lane] = sp;
+    __syncthreads();                                               // (B)
+    mu = ((stats[(0 * 4 + 0) * 64 + lane] + stats[(0 * 4 + 1) * 64 + lane]) + stats[(0 * 4 + 2) * 64 + lane]) + stats[(0 * 4 + 3) * 64 + lane];
+    mu *= 1.0f / LAT;
+    float vp = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) { const float d = xq[e] - mu; vp = fmaf(d, d, vp); }
+    vp = xhalf_sum(vp);
+    stats[(1 * 4 + wave) * 64 + lane] = vp;
+    __syncthreads();                                               // (C)
+    const float var = ((stats[(1 * 4 + 0) * 64 + lane] + stats[(1 * 4 + 1) * 64 + lane]) + stats[(1 * 4 + 2) * 64 + lane]) + stats[(1 * 4 + 3) * 64 + lane];
+    rstd = rsqrtf(var * (1.0f / LAT) + 1e-5f);
+  }
+  {
+    const float4* pg = reinterpret_cast<const float4*>(lvec + 4 * LAT) + h;
+    const float4* pb = reinterpret_cast<const float4*>(lvec + 5 * LAT) + h;
+    float xn[32];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const float4 ga = pg[2 * (g0 + g)], be = pb[2 * (g0 + g)];
+      xn[4 * g + 0] = fmaf((xq[4 * g + 0] - mu) * rstd, ga.x, be.x);
+      xn[4 * g + 1] = fmaf((xq[4 * g + 1] - mu) * rstd, ga.y, be.y);
+      xn[4 * g + 2] = fmaf((xq[4 * g + 2] - mu) * rstd, ga.z, be.z);
+      xn[4 * g + 3] = fmaf((xq[4 * g + 3] - mu) * rstd, ga.w, be.w);
+    }
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) {                               // the quarter is k-steps 4 w .. 4 w + 3 of the row fragment
+      f16x8 hi, lo;
+      split8h(&xn[8 * ss], hi, lo);
+      nxh[(0 * 16 + 4 * wave + ss) * 64 + lane] = hi;
+      nxh[(1 * 16 + 4 * wave + ss) * 64 + lane] = lo;
+    }
+  }
+  __syncthreads();                                                 // (D) the LayerNorm'd row is in the LDS
+  // ---- to_q, block `wave` (K = 256; the row fragment is read from the LDS step by step) ----
+  {
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const f16x8 xh = nxh[(0 * 16 + s) * 64 + lane], xl = nxh[(1 * 16 + s) * 64 + lane];
+      acc = mfma_h16(wa[s], xl, acc);
+      acc = mfma_h16(wa[s], xh, acc);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = mfma_h16(wa[16 + s], nxh[(0 * 16 + s) * 64 + lane], acc);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = acc[r] * kH2Inv;
+    f16x8 hi, lo;
+    split8h(&t[0], hi, lo); qh[(0 * 8 + 2 * wave) * 64 + lane] = hi; qh[(1 * 8 + 2 * wave) * 64 + lane] = lo;
+    split8h(&t[8], hi, lo); qh[(0 * 8 + 2 * wave + 1) * 64 + lane] = hi; qh[(1 * 8 + 2 * wave + 1) * 64 + lane] = lo;
+  }
+  if (wave + 4 < ttiles) {                                         // second context tile of this wave
+    load16(wa, 0, ctx_pair + (size_t)(2 * (wave + 4)) * kStageFloats);
+    load16(wa, 16, ctx_pair + (size_t)(2 * (wave + 4) + 1) * kStageFloats);
+  }
+  __syncthreads();                                                 // (E) q is in the LDS
+  FragH2<8> qx;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) { qx.h[s] = qh[(0 * 8 + s) * 64 + lane]; qx.l[s] = qh[(1 * 8 + s) * 64 + lane]; }
+  // ---- context tiles wave, wave + 4, ...: [0..15] K (hi | lo planes x 8 steps), [16..31] V (hi | lo planes x 8 slots) ----
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) oacc[db] = zero16();
+  float m_run = -INFINITY, l_half = 0.f;
+  auto ctx_tile = [&](const int t, const f16x8 (&w)[32]) {
+    f32x16 sc = zero16();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) mma3(sc, w[s], w[8 + s], qx.h[s], qx.l[s]);
+    float x[16];
+    float mx = -INFINITY;
+    const int jbase = t * 32 + 4 * h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jl = 8 * (r >> 2) + (r & 3);
+      x[r] = (jbase + jl < T) ? sc[r] : -INFINITY;
+      mx = fmaxf(mx, x[r]);
+    }
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    const float m_off = m_new - 10.0f;
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
+    l_half = fmaf(l_half, alpha, ls);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f16x8 ph, pl;
+      split8h(&x[8 * s2], ph, pl);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int slot = 2 * db + s2;
+        mma3(oacc[db], w[16 + slot], w[24 + slot], ph, pl);
+      }
+    }
+  };
+  if (wave < ttiles) ctx_tile(wave, wb);
+  if (wave + 8 < ttiles) {
+    load16(wb, 0, ctx_pair + (size_t)(2 * (wave + 8)) * kStageFloats);
+    load16(wb, 16, ctx_pair + (size_t)(2 * (wave + 8) + 1) * kStageFloats);
+  }
+  if (wave + 4 < ttiles) ctx_tile(wave + 4, wa);
+  load16(wa, 0, wst + (size_t)(8 + 2 * wave) * kStageFloats);      // Wo blocks 2 w, 2 w + 1
+  load16(wa, 16, wst + (size_t)(8 + 2 * wave + 1) * kStageFloats);
+  if (wave + 8 < ttiles) ctx_tile(wave + 8, wb);
+  for (int t = wave + 12; t < ttiles; t += 4) {                    // (more than 384 context tokens)
+    load16(wb, 0, ctx_pair + (size_t)(2 * t) * kStageFloats);
+    load16(wb, 16, ctx_pair + (size_t)(2 * t + 1) * kStageFloats);
+    ctx_tile(t, wb);
+  }
+  // ---- merge the waves' partial softmaxes (wave order), to_out blocks 2 w and 2 w + 1 ----
+  __syncthreads();                                                 // (F) every wave has read q: the exchange area is free
+  {
+    float* mine = xch + wave * (66 * 64) + lane;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[(16 * db + r) * 64] = oacc[db][r];
+    mine[64 * 64] = m_run;
+    mine[65 * 64] = l_half;
+  }
+  __syncthreads();                                                 // (G)
+  FragH2<8> ox;
+  {
+    float mw[4], M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mw[w] = xch[w * (66 * 64) + 64 * 64 + lane]; M = fmaxf(M, mw[w]); }
+    float a[4], l = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { a[w] = __builtin_amdgcn_exp2f(mw[w] - M); l = fmaf(xch[w * (66 * 64) + 65 * 64 + lane], a[w], l); }
+    const float inv = 1.0f / xhalf_sum(l);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float o = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) o = fmaf(xch[w * (66 * 64) + (16 * db + r) * 64 + lane], a[w], o);
+        t[r] = o * inv;
+      }
+      ox.set_block(db, t);
+    }
+  }
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+    const int mb = 2 * wave + hb;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) mma3(acc, wa[16 * hb + s], wa[16 * hb + 8 + s], ox.h[s], ox.l[s]);
+    float b[16], t[16];
+    load_vec16(b, lvec + 6 * LAT, mb, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, b[r]) + xq[16 * hb + r];
+    store_blk<LAT>(x1_out + toff, mb, t, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 static inline dim3 wgrid(int tiles, int B) { return dim3((tiles + kWaves - 1) / kWaves, B); }
 
 hipError_t launch_ctx_prep_w(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
@@ -684,7 +943,12 @@ hipError_t launch_ctx_prep_w_h2(bool pe, const float* ctx, const float* wst_h2, 
 }
 
 hipError_t launch_fusion_attn_w_h2(bool pe, const float* x, const float* ctx_img, const float* wst_h2, const float* vecs,
-                                   float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s) {
+                                   float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s, bool tile_form) {
+  if (tile_form && tiles * B <= 256) {             // a single round of one-tile workgroups
+    if (pe) hipLaunchKernelGGL(k_fusion_attn_w_tile<true>, dim3(tiles, B), dim3(256), 0, s, x, ctx_img, wst_h2, vecs, x1, N, tiles, T, ttiles);
+    else hipLaunchKernelGGL(k_fusion_attn_w_tile<false>, dim3(tiles, B), dim3(256), 0, s, x, ctx_img, wst_h2, vecs, x1, N, tiles, T, ttiles);
+    return hipGetLastError();
+  }
   if (pe) hipLaunchKernelGGL(k_fusion_attn_w_h2<true>, wgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst_h2, vecs, x1, N, tiles, T, ttiles);
   else hipLaunchKernelGGL(k_fusion_attn_w_h2<false>, wgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst_h2, vecs, x1, N, tiles, T, ttiles);
   return hipGetLastError();

@@ -91,6 +91,10 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     t.topk_select = value != 0;
     return GMF_OK;
   }
+  if (std::strcmp(name, "wide_attn_tile") == 0) {      // 256-wide layer: cross-attention per tile (1, default; grids of up to 256 tiles) or per four tiles (0)
+    t.wide_attn_tile = value != 0;
+    return GMF_OK;
+  }
   if (std::strcmp(name, "small_merge_tile") == 0) {    // small grids: merge step per query tile (1, default) or per four (0)
     t.small_merge_tile = value != 0;
     return GMF_OK;
@@ -560,7 +564,7 @@ int gmf_fusion_layer_forward(gmf_handle* h, int pe, int latent_dim, int d_head, 
   } else {
     if (attn_wst_h2) {
       GMF_HIP(gmf::launch_ctx_prep_w_h2(pe != 0, cimg, ctx_wst_h2, ctx_vec, ctx, B, T, tt, st));
-      GMF_HIP(gmf::launch_fusion_attn_w_h2(pe != 0, xin, ctx, attn_wst_h2, attn_vec, x1, B, N, tiles, T, tt, st));
+      GMF_HIP(gmf::launch_fusion_attn_w_h2(pe != 0, xin, ctx, attn_wst_h2, attn_vec, x1, B, N, tiles, T, tt, st, h->tune.wide_attn_tile));
     } else {
       GMF_HIP(gmf::launch_ctx_prep_w(pe != 0, cimg, ctx_wst, ctx_vec, ctx, B, T, tt, st));
       GMF_HIP(gmf::launch_fusion_attn_w(pe != 0, xin, ctx, attn_wst, attn_vec, x1, B, N, tiles, T, tt, st));

@@ -31,6 +31,7 @@ struct Tuning {
                              // little (32 x 5000: 1.10 ms split vs 1.07 ms whole, measured)
   int ff_split = 0;          // feed-forward hidden splits on small grids: 0 = automatic, 1 = off, 2 / 4 / 8 = forced
   bool front_split = true;   // small grids: one workgroup per output (Q' + f | K | V) of k_front_h2
+  bool wide_attn_tile = true;     // 256-wide layer: cross-attention with one workgroup per tile on grids of up to 256 tiles
   bool small_merge_tile = true;   // small grids: the merge step with one workgroup per query tile, its waves splitting the feature blocks
   bool small_roles = true;   // small grids: three launches per layer with two kinds of workgroups each (else five or six)
   bool fused_linear = true;  // one kernel per layer for Q'/K/V + Fusion-2 (k_linear_h2) with the next PointCN in the attention epilogue
@@ -70,7 +71,7 @@ hipError_t launch_fusion_ff_w(const float* x1, const float* wst, const float* ve
 hipError_t launch_ctx_prep_w_h2(bool pe, const float* ctx, const float* wst_h2, const float* vecs, float* out, int B, int T,
                                 int ttiles, hipStream_t s);
 hipError_t launch_fusion_attn_w_h2(bool pe, const float* x, const float* ctx_img, const float* wst_h2, const float* vecs,
-                                   float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
+                                   float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s, bool tile_form = true);
 hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const float* vecs, float* x2, int B, int tiles, hipStream_t s,
                                  float* part = nullptr, int hs = 1);
 int plan_ff_split_w(int base_wgs);

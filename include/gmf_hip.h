@@ -74,6 +74,9 @@ long long gmf_workspace_bytes(gmf_handle* h);
  *   "ff_hidden_splits"  : 0 = automatic (small grids only), 1 = off, 2 / 4 / 8 = forced.
  *   "front_output_split": 1 = small grids use one workgroup per output of the front kernel (default), 0 = never.
  *   "fused_linear"      : 1 = one kernel per layer for Q'/K/V + Fusion-2 (default), 0 = the three-kernel sequence.
+ *   "wide_attn_tile"    : 1 = the cross-attention of the (256, 128) FusionLayer runs one workgroup per 32-row tile on grids of up
+ *                         to 256 tiles, its waves splitting the feature blocks and the context tiles (default), 0 = one
+ *                         workgroup per four tiles.
  *   "small_merge_tile"  : 1 = the merge step of the small-grid layer runs one workgroup per query tile whose four waves split
  *                         the feature blocks (default; bit-identical results), 0 = one workgroup per four tiles.
  *   "mid_grid_roles"    : W (default 512): on grids of 256 .. W - 1 base workgroups that kernel runs as two workgroup roles per

@@ -132,8 +132,12 @@ def test_f9_dgr_perceiver_256(golden_dir, M, T, h2_attn):
         for hs in (1, 2, 8):
             h.call("gmf_set_tuning", b"ff_hidden_splits", hs)
             assert _maxerr(m(_gpu(ctx), queries_encoder=_gpu(x)).cpu(), g[f"out_M{M}_T{T}"]) < 1e-4, hs
+        h.call("gmf_set_tuning", b"ff_hidden_splits", 0)
+        h.call("gmf_set_tuning", b"wide_attn_tile", 0)     # the cross-attention with one workgroup per four tiles
+        assert _maxerr(m(_gpu(ctx), queries_encoder=_gpu(x)).cpu(), g[f"out_M{M}_T{T}"]) < 1e-4
     finally:
         h.call("gmf_set_tuning", b"ff_hidden_splits", 0)
+        h.call("gmf_set_tuning", b"wide_attn_tile", 1)
 
 
 def test_f3_nonlocal_block(golden_dir, sd_full):

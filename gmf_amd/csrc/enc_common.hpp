@@ -106,6 +106,18 @@ struct LcpeHalo {
                                        (void __attribute__((address_space(3)))*)(halo + q * 256), 16, 0, 0);
     }
   }
+  // the same two rows from a ROW-MAJOR [n_rows, K] tensor (the kernels that read their input without a packing pass)
+  GMF_DEVINL static void issue_rowmajor(const float* __restrict__ rows_base, int tile, int n_rows, float* halo, int lane) {
+#pragma unroll
+    for (int q = 0; q < (2 * U) / 64; ++q) {
+      const int w = q * 64 + lane, r = w / U, u = w % U, g = u >> 1, hh = u & 1;
+      int row = (r == 0) ? tile * 32 - 1 : tile * 32 + 32;
+      row = min(max(row, 0), n_rows - 1);                                    // (outside: any finite row, it is masked)
+      const float* src = rows_base + (size_t)row * K + (32 * (g >> 2) + 8 * (g & 3) + 4 * hh);
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                       (void __attribute__((address_space(3)))*)(halo + q * 256), 16, 0, 0);
+    }
+  }
   GMF_DEVINL static float from_lane_below(float v) {   // lane L gets lane L - 1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
   }

@@ -432,9 +432,10 @@ k_fusion_ff_w_h2(const float* __restrict__ x1, const float* __restrict__ wst, co
 }
 
 // x2 = sum_z part[z] * 2^-8 + b2 + x1 (z in index order).  grid (ceil(tiles/4), B, 8): a wave adds one 32 x 32 block.
+// out_rm (may be null): the caller's strided [B, n_rows, 256] output - written here instead of the image + an unpacking pass.
 __global__ void __launch_bounds__(256)
 k_ff_reduce_w(const float* __restrict__ part, const float* __restrict__ x1, const float* __restrict__ vecs,
-              float* __restrict__ x2_out, int tiles, int hs) {
+              float* __restrict__ x2_out, int tiles, int hs, float* __restrict__ out_rm, long o_sb, long o_sr, long o_sk, int n_rows) {
   using namespace wide;
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int tile = blockIdx.x * kWaves + (threadIdx.x >> 6);
@@ -459,6 +460,17 @@ k_ff_reduce_w(const float* __restrict__ part, const float* __restrict__ x1, cons
     }
 #pragma unroll
   for (int r = 0; r < 16; ++r) t[r] = fmaf(t[r], kH2Inv, b[r]) + xr[r];
+  if (out_rm) {
+    const int row = tile * 32 + (lane & 31);
+    if (row < n_rows) {
+      float* p = out_rm + (long)blockIdx.y * o_sb + (long)row * o_sr;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[(long)(32 * mb + 8 * q + 4 * h + e) * o_sk] = t[4 * q + e];
+    }
+    return;
+  }
   store_blk<LAT>(x2_out + toff, mb, t, lane);
 }
 
@@ -473,7 +485,8 @@ k_ff_reduce_w(const float* __restrict__ part, const float* __restrict__ x1, cons
 // Context image per token tile (2 stages, as before): Kc | Vc as fp16x2 images for d_head = 128:
 //   Kc unit ((plane*8 + s)*64 + lane), Vc unit ((plane*8 + slot)*64 + lane), slot = 2*db + s2.
 // ---------------------------------------------------------------------------------------------
-template <bool PE>
+// ROWMAJOR: `ctx` is the caller's [B, T, 128] tensor itself (no packing pass in front of this 3-workgroup kernel).
+template <bool PE, bool ROWMAJOR>
 __global__ void __launch_bounds__(256, 1)
 k_ctx_prep_w_h2(const float* __restrict__ ctx, const float* __restrict__ wst, const float* __restrict__ vecs,
                 float* __restrict__ out, int T, int ttiles) {
@@ -484,20 +497,34 @@ k_ctx_prep_w_h2(const float* __restrict__ ctx, const float* __restrict__ wst, co
   const int tile_raw = blockIdx.x * kWaves + wave;
   const bool active = tile_raw < ttiles;
   const int tile = active ? tile_raw : ttiles - 1;
-  const float* pair_base = ctx + (size_t)pair * ttiles * (32 * CX);
+  const float* pair_base = ROWMAJOR ? ctx + (size_t)pair * T * CX : ctx + (size_t)pair * ttiles * (32 * CX);
   float* dst = out + ((size_t)pair * ttiles + tile) * (2 * kStageFloats);
   float* const lvec = lds + kRingW * kStageFloats;          // taps (4 x 128) | gamma | beta: 3 KiB
   float* const halo = lvec + 6 * CX + wave * (2 * CX);
 
   dma_issue(vecs, lvec, 3, wave, kWaves, lane);
-  if (PE) LcpeHalo<CXF>::issue(pair_base, tile, ttiles, halo, lane);
+  if (PE) {
+    if (ROWMAJOR) LcpeHalo<CXF>::issue_rowmajor(pair_base, tile, T, halo, lane);
+    else LcpeHalo<CXF>::issue(pair_base, tile, ttiles, halo, lane);
+  }
   StageRing<kRingW> ss;
   ss.init(lds, wave, lane, wst, 8);
   ss.prime();
   FragH2<8> cx;
   {
     float x[CXF], cn[CXF];
-    load_frag_p32<CXF>(x, pair_base + (size_t)tile * (32 * CX), lane);
+    if (ROWMAJOR) {
+      const int row = tile * 32 + i;
+      const float4* p = reinterpret_cast<const float4*>(pair_base + (size_t)min(row, T - 1) * CX) + h;
+#pragma unroll
+      for (int g = 0; g < CXF / 4; ++g) {           // fragment group g = features 32 (g >> 2) + 8 (g & 3) + 4 h .. + 3
+        const float4 t = p[8 * (g >> 2) + 2 * (g & 3)];
+        const bool ok = row < T;
+        x[4 * g + 0] = ok ? t.x : 0.f; x[4 * g + 1] = ok ? t.y : 0.f; x[4 * g + 2] = ok ? t.z : 0.f; x[4 * g + 3] = ok ? t.w : 0.f;
+      }
+    } else {
+      load_frag_p32<CXF>(x, pair_base + (size_t)tile * (32 * CX), lane);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (PE) LcpeHalo<CXF>::apply(x, halo, lvec, tile * 32 + i, T, lane);
@@ -936,9 +963,14 @@ hipError_t launch_fusion_attn_w(bool pe, const float* x, const float* ctx_img, c
 }
 
 hipError_t launch_ctx_prep_w_h2(bool pe, const float* ctx, const float* wst_h2, const float* vecs, float* out, int B, int T,
-                                int ttiles, hipStream_t s) {
-  if (pe) hipLaunchKernelGGL(k_ctx_prep_w_h2<true>, wgrid(ttiles, B), dim3(256), 0, s, ctx, wst_h2, vecs, out, T, ttiles);
-  else hipLaunchKernelGGL(k_ctx_prep_w_h2<false>, wgrid(ttiles, B), dim3(256), 0, s, ctx, wst_h2, vecs, out, T, ttiles);
+                                int ttiles, hipStream_t s, bool rowmajor) {
+  if (rowmajor) {
+    if (pe) hipLaunchKernelGGL((k_ctx_prep_w_h2<true, true>), wgrid(ttiles, B), dim3(256), 0, s, ctx, wst_h2, vecs, out, T, ttiles);
+    else hipLaunchKernelGGL((k_ctx_prep_w_h2<false, true>), wgrid(ttiles, B), dim3(256), 0, s, ctx, wst_h2, vecs, out, T, ttiles);
+  } else {
+    if (pe) hipLaunchKernelGGL((k_ctx_prep_w_h2<true, false>), wgrid(ttiles, B), dim3(256), 0, s, ctx, wst_h2, vecs, out, T, ttiles);
+    else hipLaunchKernelGGL((k_ctx_prep_w_h2<false, false>), wgrid(ttiles, B), dim3(256), 0, s, ctx, wst_h2, vecs, out, T, ttiles);
+  }
   return hipGetLastError();
 }
 
@@ -962,11 +994,11 @@ int plan_ff_split_w(int base_wgs) {
 }
 
 hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const float* vecs, float* x2, int B, int tiles, hipStream_t s,
-                                 float* part, int hs) {
+                                 float* part, int hs, float* out_rm, long o_sb, long o_sr, long o_sk, int n_rows) {
   const dim3 g = wgrid(tiles, B);
   if (part && hs > 1) {
     hipLaunchKernelGGL(k_fusion_ff_w_h2, dim3(g.x, g.y, hs), dim3(256), 0, s, x1, wst_h2, vecs, x2, tiles, part);
-    hipLaunchKernelGGL(k_ff_reduce_w, dim3(g.x, g.y, 8), dim3(256), 0, s, part, x1, vecs, x2, tiles, hs);
+    hipLaunchKernelGGL(k_ff_reduce_w, dim3(g.x, g.y, 8), dim3(256), 0, s, part, x1, vecs, x2, tiles, hs, out_rm, o_sb, o_sr, o_sk, n_rows);
   } else {
     hipLaunchKernelGGL(k_fusion_ff_w_h2, g, dim3(256), 0, s, x1, wst_h2, vecs, x2, tiles, (float*)nullptr);
   }

@@ -549,7 +549,10 @@ int gmf_fusion_layer_forward(gmf_handle* h, int pe, int latent_dim, int d_head, 
   float* cimg = arena_take<float>(h, tok);
   float* ctx = arena_take<float>(h, ctxsz);
   float* ff_part_w = ff_hs_w > 1 ? arena_take<float>(h, (size_t)ff_hs_w * act) : nullptr;
-  GMF_HIP(gmf::launch_pack_p32(data, cimg, B, T, kC, (long)T * kC, kC, 1, st));
+  // the split-fp16 kernels of the 256-wide layer read the context tokens row-major and (hidden-split feed-forward) write the
+  // output through its strides: on the small grids this layer usually runs on, a packing pass is a launch like any other
+  const bool wide_direct = wide && attn_wst_h2 != nullptr;
+  if (!wide_direct) GMF_HIP(gmf::launch_pack_p32(data, cimg, B, T, kC, (long)T * kC, kC, 1, st));
   GMF_HIP(gmf::launch_pack_p32(queries, xin, B, N, latent_dim, q_sb, q_sr, q_sk, st));
   if (narrow) {
     if (attn_wst_h2) {
@@ -563,11 +566,15 @@ int gmf_fusion_layer_forward(gmf_handle* h, int pe, int latent_dim, int d_head, 
     else GMF_HIP(gmf::launch_fusion_ff(x1, ff_wst, ff_vec, x2, B, tiles, st));
   } else {
     if (attn_wst_h2) {
-      GMF_HIP(gmf::launch_ctx_prep_w_h2(pe != 0, cimg, ctx_wst_h2, ctx_vec, ctx, B, T, tt, st));
+      GMF_HIP(gmf::launch_ctx_prep_w_h2(pe != 0, data, ctx_wst_h2, ctx_vec, ctx, B, T, tt, st, true));
       GMF_HIP(gmf::launch_fusion_attn_w_h2(pe != 0, xin, ctx, attn_wst_h2, attn_vec, x1, B, N, tiles, T, tt, st, h->tune.wide_attn_tile));
     } else {
       GMF_HIP(gmf::launch_ctx_prep_w(pe != 0, cimg, ctx_wst, ctx_vec, ctx, B, T, tt, st));
       GMF_HIP(gmf::launch_fusion_attn_w(pe != 0, xin, ctx, attn_wst, attn_vec, x1, B, N, tiles, T, tt, st));
+    }
+    if (ff_wst_h2 && ff_hs_w > 1) {                 // the partials' reduction writes the caller's tensor
+      GMF_HIP(gmf::launch_fusion_ff_w_h2(x1, ff_wst_h2, ff_vec, x2, B, tiles, st, ff_part_w, ff_hs_w, out, o_sb, o_sr, o_sk, N));
+      return GMF_OK;
     }
     if (ff_wst_h2) GMF_HIP(gmf::launch_fusion_ff_w_h2(x1, ff_wst_h2, ff_vec, x2, B, tiles, st, ff_part_w, ff_hs_w));
     else GMF_HIP(gmf::launch_fusion_ff_w(x1, ff_wst, ff_vec, x2, B, tiles, st));

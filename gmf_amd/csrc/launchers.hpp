@@ -69,11 +69,12 @@ hipError_t launch_fusion_attn_w(bool pe, const float* x, const float* ctx_img, c
                                 float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
 hipError_t launch_fusion_ff_w(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
 hipError_t launch_ctx_prep_w_h2(bool pe, const float* ctx, const float* wst_h2, const float* vecs, float* out, int B, int T,
-                                int ttiles, hipStream_t s);
+                                int ttiles, hipStream_t s, bool rowmajor = false);
 hipError_t launch_fusion_attn_w_h2(bool pe, const float* x, const float* ctx_img, const float* wst_h2, const float* vecs,
                                    float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s, bool tile_form = true);
 hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const float* vecs, float* x2, int B, int tiles, hipStream_t s,
-                                 float* part = nullptr, int hs = 1);
+                                 float* part = nullptr, int hs = 1, float* out_rm = nullptr, long o_sb = 0, long o_sr = 0,
+                                 long o_sk = 0, int n_rows = 0);
 int plan_ff_split_w(int base_wgs);
 hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
                            float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s);

@@ -143,7 +143,19 @@ k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const fl
 //   Kc: unit ((plane*4 + s)*64 + lane), 2 planes x 4 k-steps = 2048 floats ; Vc: unit ((plane*4 + slot)*64 + lane),
 //   slot = 2*db + s2, 2048 floats.   stages (4): Wk[2] | Wv[2] as fp16x2 images.
 // =========================================================================================
-template <bool PE>
+// a row of a ROW-MAJOR [n_rows, 128] tensor as a fragment (zero beyond n_rows): the kernels that read the caller's tokens
+// directly instead of a packed image (one launch less where launches are what a pass costs)
+GMF_DEVINL void load_frag_rowmajor(float (&x)[CF], const float* __restrict__ rows_base, int row, int n_rows, int h) {
+  const float4* p = reinterpret_cast<const float4*>(rows_base + (size_t)min(row, n_rows - 1) * C) + h;
+  const bool ok = row < n_rows;
+#pragma unroll
+  for (int g = 0; g < CF / 4; ++g) {                 // fragment group g = features 32 (g >> 2) + 8 (g & 3) + 4 h .. + 3
+    const float4 t = p[8 * (g >> 2) + 2 * (g & 3)];
+    x[4 * g + 0] = ok ? t.x : 0.f; x[4 * g + 1] = ok ? t.y : 0.f; x[4 * g + 2] = ok ? t.z : 0.f; x[4 * g + 3] = ok ? t.w : 0.f;
+  }
+}
+
+template <bool PE, bool ROWMAJOR = false>
 __global__ void __launch_bounds__(256, 2)
 k_ctx_prep_h2(const float* __restrict__ ctx, const float* __restrict__ wst, const float* __restrict__ vecs,
               float* __restrict__ out, int T, int ttiles, int wst_stride, int vec_stride) {
@@ -156,7 +168,7 @@ k_ctx_prep_h2(const float* __restrict__ ctx, const float* __restrict__ wst, cons
   const int tile = active ? tile_raw : ttiles - 1;
   wst += (size_t)set * wst_stride;
   vecs += (size_t)set * vec_stride;
-  const float* pair_base = ctx + (size_t)pair * ttiles * (32 * C);
+  const float* pair_base = ROWMAJOR ? ctx + (size_t)pair * T * C : ctx + (size_t)pair * ttiles * (32 * C);
   float* dst = out + (((size_t)set * nb + pair) * ttiles + tile) * kStageFloats;
 
   StageStream ss;
@@ -166,6 +178,7 @@ k_ctx_prep_h2(const float* __restrict__ ctx, const float* __restrict__ wst, cons
   {
     float x[CF], cn[CF];
     if (PE) lcpe_frag(x, pair_base, tile * 32 + i, T, vecs, h);
+    else if (ROWMAJOR) load_frag_rowmajor(x, pair_base, tile * 32 + i, T, h);
     else load_frag_p32<CF>(x, pair_base + (size_t)tile * (32 * C), lane);
     layernorm_frag<CF>(cn, x, vecs + 4 * C, vecs + 5 * C, h);
     cx.set(cn);
@@ -218,7 +231,7 @@ k_ctx_prep_h2(const float* __restrict__ ctx, const float* __restrict__ wst, cons
 // =========================================================================================
 constexpr int kFattnLdsFloats = kRing * kStageFloats + 7 * C + kWavesPerWG * 2 * C;   // ring | vectors | halo rows
 
-template <bool PE>
+template <bool PE, bool ROWMAJOR = false>
 GMF_DEVINL void fusion_attn_h2_body(float* lds, const int bx, const int pair, const float* __restrict__ xin,
                                     const float* __restrict__ ctx_img, const float* __restrict__ wst,
                                     const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
@@ -227,7 +240,7 @@ GMF_DEVINL void fusion_attn_h2_body(float* lds, const int bx, const int pair, co
   const int tile_raw = bx * kWavesPerWG + wave;
   const bool active = tile_raw < tiles;
   const int tile = active ? tile_raw : tiles - 1;
-  const float* pair_base = xin + (size_t)pair * tiles * (32 * C);
+  const float* pair_base = ROWMAJOR ? xin + (size_t)pair * N * C : xin + (size_t)pair * tiles * (32 * C);
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
 
   // behind the ring (kFattnLdsFloats): the kernel's per-feature vectors and, per wave, the two halo rows of the LCPE - requested
@@ -243,7 +256,9 @@ GMF_DEVINL void fusion_attn_h2_body(float* lds, const int bx, const int pair, co
   ss.prime();
 
   float xp[CF];
-  load_frag_p32<CF>(xp, pair_base + (size_t)tile * (32 * C), lane);
+  static_assert(!(PE && ROWMAJOR), "the row-major form is the Fusion-1 instance (no LCPE)");
+  if (ROWMAJOR) load_frag_rowmajor(xp, pair_base, tile * 32 + i, N, h);
+  else load_frag_p32<CF>(xp, pair_base + (size_t)tile * (32 * C), lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (PE) LcpeHalo<CF>::apply(xp, halo, lvec, tile * 32 + i, N, lane);
@@ -338,12 +353,12 @@ GMF_DEVINL void fusion_attn_h2_body(float* lds, const int bx, const int pair, co
   }
 }
 
-template <bool PE>
+template <bool PE, bool ROWMAJOR = false>
 __global__ void __launch_bounds__(256, 2)
 k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_img, const float* __restrict__ wst,
                  const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
   __shared__ __attribute__((aligned(16))) float lds[kFattnLdsFloats];
-  fusion_attn_h2_body<PE>(lds, blockIdx.x, blockIdx.y, xin, ctx_img, wst, vecs, x1_out, N, tiles, T, ttiles);
+  fusion_attn_h2_body<PE, ROWMAJOR>(lds, blockIdx.x, blockIdx.y, xin, ctx_img, wst, vecs, x1_out, N, tiles, T, ttiles);
 }
 
 // k_small_front_fattn: small grids (e.g. B = 1, the reference's evaluation mode) - the first of the three launches of a layer:
@@ -724,15 +739,17 @@ hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* fro
 }
 
 hipError_t launch_ctx_prep_h2(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
-                              int ttiles, int sets, int wst_stride, int vec_stride, hipStream_t s) {
+                              int ttiles, int sets, int wst_stride, int vec_stride, hipStream_t s, bool rowmajor) {
   if (pe) hipLaunchKernelGGL(k_ctx_prep_h2<true>, tgrid(ttiles, B, sets), dim3(256), 0, s, ctx, wst, vecs, out, T, ttiles, wst_stride, vec_stride);
+  else if (rowmajor) hipLaunchKernelGGL((k_ctx_prep_h2<false, true>), tgrid(ttiles, B, sets), dim3(256), 0, s, ctx, wst, vecs, out, T, ttiles, wst_stride, vec_stride);
   else hipLaunchKernelGGL(k_ctx_prep_h2<false>, tgrid(ttiles, B, sets), dim3(256), 0, s, ctx, wst, vecs, out, T, ttiles, wst_stride, vec_stride);
   return hipGetLastError();
 }
 
 hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
-                                 float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s) {
+                                 float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s, bool rowmajor) {
   if (pe) hipLaunchKernelGGL(k_fusion_attn_h2<true>, tgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
+  else if (rowmajor) hipLaunchKernelGGL((k_fusion_attn_h2<false, true>), tgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
   else hipLaunchKernelGGL(k_fusion_attn_h2<false>, tgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
   return hipGetLastError();
 }

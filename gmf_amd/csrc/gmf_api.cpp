@@ -378,14 +378,15 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   }
 
   // Fusion-1: image_feat = FusionLayer(p_tok (context), queries = q_tok), pe = False (PointDSC.py:137)
-  GMF_HIP(gmf::launch_pack_p32(p_tokens, pimg, B, T, kC, (long)T * kC, kC, 1, st));
-  GMF_HIP(gmf::launch_pack_p32(q_tokens, qimg, B, T, kC, (long)T * kC, kC, 1, st));
   if (h2 && w->f1_ctx_wst_h2 && w->f1_attn_wst_h2 && w->f1_ff_wst_h2) {
-    GMF_HIP(gmf::launch_ctx_prep_h2(false, pimg, w->f1_ctx_wst_h2, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st));
-    GMF_HIP(gmf::launch_fusion_attn_h2(false, qimg, f1ctx, w->f1_attn_wst_h2, w->f1_attn_vec, x1t, B, T, tt, T, tt, st));
+    // (the two token tensors are read row-major: no packing launches in front of these few-workgroup kernels)
+    GMF_HIP(gmf::launch_ctx_prep_h2(false, p_tokens, w->f1_ctx_wst_h2, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st, true));
+    GMF_HIP(gmf::launch_fusion_attn_h2(false, q_tokens, f1ctx, w->f1_attn_wst_h2, w->f1_attn_vec, x1t, B, T, tt, T, tt, st, true));
     GMF_HIP(gmf::launch_fusion_ff_h2(h->tune, x1t, w->f1_ff_wst_h2, w->f1_ff_vec, imgfeat, B, tt, st,
                                      tt <= tiles ? cc.part_o : nullptr, tt <= tiles ? cc.max_splits : 0));
   } else {
+    GMF_HIP(gmf::launch_pack_p32(p_tokens, pimg, B, T, kC, (long)T * kC, kC, 1, st));
+    GMF_HIP(gmf::launch_pack_p32(q_tokens, qimg, B, T, kC, (long)T * kC, kC, 1, st));
     GMF_HIP(gmf::launch_ctx_prep(false, pimg, w->f1_ctx_wst, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st));
     GMF_HIP(gmf::launch_fusion_attn(false, qimg, f1ctx, w->f1_attn_wst, w->f1_attn_vec, x1t, B, T, tt, T, tt, st));
     GMF_HIP(gmf::launch_fusion_ff(x1t, w->f1_ff_wst, w->f1_ff_vec, imgfeat, B, tt, st));

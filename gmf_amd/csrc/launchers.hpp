@@ -92,9 +92,9 @@ hipError_t launch_small_attn_ff_merge(const float* q, const float* k, const floa
                                       const float* ff_vecs, float* ff_part, int ff_hs, const float* tail_vecs, float* out, int B,
                                       int N, int tiles, int ksplits, hipStream_t s, const CompatCache* cc, bool tile_merge = true);
 hipError_t launch_ctx_prep_h2(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
-                              int ttiles, int sets, int wst_stride, int vec_stride, hipStream_t s);
+                              int ttiles, int sets, int wst_stride, int vec_stride, hipStream_t s, bool rowmajor = false);
 hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
-                                 float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
+                                 float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s, bool rowmajor = false);
 hipError_t launch_fusion_ff_h2(const Tuning& tune, const float* x1, const float* wst, const float* vecs, float* x2, int B,
                                int tiles, hipStream_t s, float* part = nullptr, int max_parts = 0);
 int padded_desc_width(int d);

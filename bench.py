@@ -280,6 +280,44 @@ def sweep(dev):
                      "max_abs_dlogit_vs_parity_mode": dl, "max_abs_dT_vs_parity_mode": dT, "within_parity_gate": False})
     del model, data
     torch.cuda.empty_cache()
+    # the DGR plugin surface (BASELINE config 5: batched weighted-SVD pose, N = 8000; and the bottleneck PerceiverIO of row a15)
+    import numpy as np
+    import gmf_amd
+    from gmf_amd import synthetic
+
+    def best_ms(fn, n):
+        for _ in range(2):
+            fn()
+        best = float("inf")
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / n * 1e3)
+        return best
+
+    Bd, Nd = 32, 8000
+    scenes = [synthetic.dgr_scene(Nd, 500 + i) for i in range(Bd)]
+    X = torch.cat([sc[0] for sc in scenes]).to(dev)
+    Y = torch.cat([sc[1] for sc in scenes]).to(dev)
+    wts = torch.cat([sc[2] for sc in scenes]).to(dev)
+    off = [i * Nd for i in range(Bd + 1)]
+    ms = best_ms(lambda: gmf_amd.weighted_procrustes_batched(X, Y, wts, off, np.finfo(np.float32).eps), 20)
+    rows.append({"workload": "dgr weighted_procrustes, 32 problems x 8000 correspondences (config 5)", "ms_per_step": ms,
+                 "value": Bd * Nd / (ms * 1e-3), "unit": "correspondences/s"})
+    ms = best_ms(lambda: gmf_amd.global_registration_batched(X, Y, wts, off, break_threshold_ratio=1e-4, quantization_size=0.1), 5)
+    rows.append({"workload": "dgr GlobalRegistration (Adam refinement to convergence), 32 problems x 8000 correspondences", "ms_per_step": ms,
+                 "value": Bd * Nd / (ms * 1e-3), "unit": "correspondences/s"})
+    pio = gmf_amd.PerceiverIO(depth=0, dim=128, latent_dim=256, cross_heads=1, latent_heads=8, cross_dim_head=128,
+                              latent_dim_head=64, pe=True).to(dev).eval()
+    for M in (1000, 4000, 20000):
+        xq, img = torch.randn(1, M, 256, device=dev), torch.randn(1, 300, 128, device=dev)
+        ms = best_ms(lambda: pio(img, queries_encoder=xq), 10)
+        rows.append({"workload": f"dgr bottleneck PerceiverIO (256 wide, head 128), {M} voxels x 300 image tokens", "ms_per_step": ms,
+                     "value": M / (ms * 1e-3), "unit": "voxels/s",
+                     "algorithmic_tflops": M * (1713152 + 512 * 300) / (ms * 1e-3) / 1e12})
     return rows
 
 

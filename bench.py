@@ -149,6 +149,7 @@ def main():
     batch, data = make_batch(dev, seeds, N, T, args.kind)
     torch.cuda.synchronize()
 
+    driver.check_status = False          # (the status column of the packed rows is read once, after the timed region)
     for _ in range(args.warmup):
         out = driver.step(data)
     torch.cuda.synchronize()
@@ -171,10 +172,12 @@ def main():
     # diagnostics outside the timed region: per-rank step time, and one more step with the model / gather split timed by events
     per_rank_ms = driver.gather_floats(t_local / args.steps * 1e3)
     driver.time_steps = True
+    driver.check_status = True           # any rank that failed during the run raises here, on every rank
     driver.step(data)
     model_ms, gather_ms = driver.read_timings()
     driver.time_steps = False
     gather_all = driver.gather_floats(gather_ms if gather_ms is not None else 0.0)
+    devices = driver.gather_objects(device_identity(dev_index))
 
     if rank != 0:
         driver.close()
@@ -220,6 +223,8 @@ def main():
                  "flops_per_step": step_flops(B, N, T), "note": "F_logits of SURVEY.md section 8d x pairs / step time"},
         "ranks": {"per_rank_ms_per_step": per_rank_ms, "model_ms": model_ms, "all_gather_ms": gather_ms,
                   "all_gather_ms_per_rank": gather_all,
+                  "devices": devices, "distinct_devices": len({d["pci"] + "/" + d["uuid"] for d in devices}),
+                  "nranks": driver.group_size(), "backend": driver.backend_name(),
                   "note": "outside the timed region: one extra step with HIP events around the forward and around pack + all-gather"},
         "csrc_sha16": sha,
     }
@@ -229,6 +234,8 @@ def main():
         line["sweep"] = sweep(dev)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"], line["parity"] = cpu_baseline(sd, batch, out, N, T, tau)
+        if args.kind == "3dmatch":
+            line["parity"]["kitti_shape"] = kitti_parity(dev)
     print(json.dumps(line))
     driver.close()
 
@@ -321,6 +328,14 @@ def sweep(dev):
     return rows
 
 
+def device_identity(index: int) -> dict:
+    """What tells one GPU of the node from another: name, PCI address and UUID of this rank's device, its host process."""
+    p = torch.cuda.get_device_properties(index)
+    pci = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    return {"rank": int(os.environ.get("RANK", "0")), "device_index": index, "name": p.name, "pci": pci,
+            "uuid": str(getattr(p, "uuid", "")), "cus": p.multi_processor_count, "pid": os.getpid()}
+
+
 def host_cpu_share() -> int:
     """CPUs this process may really use: min(affinity mask, cgroup v2 cpu.max quota)."""
     n = len(os.sched_getaffinity(0))
@@ -373,7 +388,41 @@ def cpu_baseline(sd, batch, gpu_out, N, T, tau):
     parity = {"max_abs_dlogit": float((gpu_out["logits"][:1].cpu() - ref["logits"]).abs().max()),
               "max_abs_dT": float((gpu_out["final_trans"][:1].cpu() - ref["final_trans"]).abs().max()),
               "vs": "CPU oracle on pair 0 of the timed batch"}
+    # which of the two fp32 evaluations is closer to the exact network: an fp64 evaluation of the same encoder on the same pair
+    truth = fp64_logits(sd, one, float(sd["sigma_d"]) if "sigma_d" in sd else 0.10)
+    parity["max_abs_dlogit_vs_fp64"] = {"hip": float((gpu_out["logits"][:1].cpu().double() - truth).abs().max()),
+                                        "fp32_oracle": float((ref["logits"].double() - truth).abs().max()),
+                                        "note": "fp64 evaluation of the same encoder + classifier (oracle code, float64) on pair 0"}
     return base, parity
+
+
+def fp64_logits(sd, one, sigma_d):
+    """Inlier logits of the oracle's encoder + classifier evaluated in float64 (the reference network without fp32 rounding)."""
+    from oracle import gmf_oracle as O
+    sd64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in sd.items()}
+    b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in one.items()}
+    with torch.no_grad():
+        compat64, _ = O.compat_matrix(b64["src_keypts"], b64["tgt_keypts"], sigma_d)
+        return O.classifier(sd64, O.encoder(sd64, b64["corr_pos"], compat64, b64["p_tokens"], b64["q_tokens"], 12))
+
+
+def kitti_parity(dev):
+    """The same pair of numbers for ONE KITTI-shape pair (config 3: N = 10000, sigma_d = 1.2, +-40 m coordinates): HIP and the
+    fp32 oracle against the fp64 evaluation, and against each other."""
+    from oracle import gmf_oracle as O
+    model, sd, tau = build_model(dev, "kitti")
+    batch, data = make_batch(dev, [0], 10000, 196, "kitti")
+    res = model(data)
+    torch.cuda.synchronize()
+    lg = model.last_logits.cpu()
+    with torch.no_grad():
+        ref = O.pointdsc_forward(sd, batch, inlier_threshold=tau, nms_radius=tau, testing=True)
+    truth = fp64_logits(sd, batch, 1.2)
+    return {"workload": "1 kitti-shape pair x 10000 correspondences (config 3), sigma_d 1.2",
+            "max_abs_dlogit": float((lg - ref["logits"]).abs().max()),
+            "max_abs_dT": float((res["final_trans"].cpu() - ref["final_trans"]).abs().max()),
+            "max_abs_dlogit_vs_fp64": {"hip": float((lg.double() - truth).abs().max()),
+                                       "fp32_oracle": float((ref["logits"].double() - truth).abs().max())}}
 
 
 if __name__ == "__main__":

@@ -2,6 +2,8 @@
 
 There is NO fallback: if the shared library is missing, or a call returns a non-zero status,
 a RuntimeError is raised (the reference's assert/exception semantics).
+A non-finite result (an activation outside the fp16 range of the split MFMA operands) sets a sticky status bit on the
+device: the next forward of a drop-in module on that device, or `gmf_amd.check_status()`, raises.
 """
 from __future__ import annotations
 
@@ -56,6 +58,9 @@ SIGNATURES = {
     "gmf_destroy": (None, [_vp]),
     "gmf_last_error_string": (C.c_char_p, [_vp]),
     "gmf_workspace_bytes": (_ll, [_vp]),
+    "gmf_set_workspace": (C.c_int, [_vp, _vp, _ll]),
+    "gmf_workspace_wanted": (_ll, [_vp]),
+    "gmf_status_read": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
     "gmf_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "gmf_profile_enable": (C.c_int, [_vp, C.c_int]),
     "gmf_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
@@ -133,14 +138,22 @@ def load_library() -> C.CDLL:
             fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.gmf_abi_version() != 2:
+        if lib.gmf_abi_version() != 3:
             raise RuntimeError("gmf_amd: libgmf_hip.so ABI version mismatch")
         _lib = lib
         return lib
 
 
+GMF_ERR_WORKSPACE = -6
+GMF_STATUS_NONFINITE = 1
+
+
 class Handle:
-    """Per-device library handle (`gmf_create`).  Not thread-safe; one per device per process."""
+    """Per-device library handle (`gmf_create`).  One per device per process; calls on it are serialised by the library.
+
+    The library's workspace is a torch tensor (`gmf_set_workspace`): the memory belongs to torch's caching allocator, not
+    to a private hipMalloc block.  It grows on demand - a call that needs more returns GMF_ERR_WORKSPACE, `call` allocates
+    what `gmf_workspace_wanted` says and repeats the call once."""
 
     def __init__(self, device: int):
         self.lib = load_library()
@@ -151,14 +164,51 @@ class Handle:
                                "(no HIP device?) - the HIP path is mandatory, there is no CPU fallback")
         self.h = h
         self.device = device
+        self._ws = None               # torch.uint8 tensor behind gmf_set_workspace
+        self.torch_workspace = True   # False: the library keeps its own hipMalloc block (non-torch hosts do the same)
 
     def check(self, rc: int, what: str):
         if rc != 0:
             msg = self.lib.gmf_last_error_string(self.h)
             raise RuntimeError(f"gmf_amd: {what} failed (status {rc}): {msg.decode() if msg else ''}")
 
+    def _grow_workspace(self):
+        import torch
+        want = int(self.lib.gmf_workspace_wanted(self.h))
+        # release the old block first (torch's allocator is stream-ordered: work already queued on the stream keeps it valid)
+        self.check(self.lib.gmf_set_workspace(self.h, None, 0), "gmf_set_workspace")
+        if self._ws is not None:
+            self._ws.record_stream(torch.cuda.current_stream(self.device))
+        self._ws = None
+        self._ws = torch.empty(want, dtype=torch.uint8, device=torch.device("cuda", self.device))
+        self.check(self.lib.gmf_set_workspace(self.h, self._ws.data_ptr(), want), "gmf_set_workspace")
+
     def call(self, name: str, *args):
-        self.check(getattr(self.lib, name)(self.h, *args), name)
+        fn = getattr(self.lib, name)
+        if self.torch_workspace and self._ws is None:
+            # start with an empty caller-provided workspace, so the library never allocates a block of its own
+            import torch
+            self._ws = torch.empty(256, dtype=torch.uint8, device=torch.device("cuda", self.device))
+            self.check(self.lib.gmf_set_workspace(self.h, self._ws.data_ptr(), 256), "gmf_set_workspace")
+        rc = fn(self.h, *args)
+        if rc == GMF_ERR_WORKSPACE and self.torch_workspace:
+            self._grow_workspace()
+            rc = fn(self.h, *args)
+        self.check(rc, name)
+
+    def status(self, clear: bool = False) -> int:
+        """The handle's sticky status word (no device synchronisation: it reflects the work that has FINISHED)."""
+        f = C.c_int(0)
+        self.check(self.lib.gmf_status_read(self.h, C.byref(f), 1 if clear else 0), "gmf_status_read")
+        return f.value
+
+    def raise_if_flagged(self, where: str):
+        f = self.status(clear=True)
+        if f & GMF_STATUS_NONFINITE:
+            raise RuntimeError(
+                f"gmf_amd: {where}: a non-finite value (NaN / inf) reached an output of an earlier call on this device - "
+                "an input was non-finite, or an activation left the range of the split-fp16 MFMA operands (|x| < 65504; "
+                "INTEGRATION.md, 'Supported value range').  The outputs of that call are not valid.")
 
     def __del__(self):
         try:
@@ -167,6 +217,24 @@ class Handle:
                 self.h = None
         except Exception:
             pass
+
+
+def check_status(device=None, synchronize: bool = True):
+    """Raise if any call on `device` since the last check produced a non-finite logit, feature norm or fusion output.
+    Synchronises the device first (pass synchronize=False after a synchronisation of your own)."""
+    import torch
+    if device is None:
+        idx = torch.cuda.current_device()
+    elif isinstance(device, int):
+        idx = device
+    else:
+        idx = torch.device(device).index
+        idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _handles:
+        return
+    if synchronize:
+        torch.cuda.synchronize(idx)
+    _handles[idx].raise_if_flagged("check_status")
 
 
 _handles: Dict[int, Handle] = {}

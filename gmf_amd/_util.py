@@ -19,9 +19,14 @@ def dev_index(t: torch.Tensor) -> int:
     return t.device.index if t.device.index is not None else torch.cuda.current_device()
 
 
-def handle_and_stream(t: torch.Tensor):
+def handle_and_stream(t: torch.Tensor, check: bool = False):
+    """(library handle, current stream) of t's device.  check: raise now if an EARLIER call on this device flagged a
+    non-finite result (a host read of the handle's status word - no synchronisation)."""
     idx = dev_index(t)
-    return _lib.handle_for(idx), torch.cuda.current_stream(idx).cuda_stream
+    h = _lib.handle_for(idx)
+    if check:
+        h.raise_if_flagged("forward")
+    return h, torch.cuda.current_stream(idx).cuda_stream
 
 
 class WeightWatcher:

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -17,6 +18,19 @@ struct gmf_handle {
   void* arena = nullptr;
   size_t arena_bytes = 0;
   size_t arena_used = 0;
+  // caller-provided workspace (gmf_set_workspace): when set, the library allocates nothing; a call that needs more returns
+  // GMF_ERR_WORKSPACE and gmf_workspace_wanted() says how much
+  bool arena_external = false;
+  size_t arena_wanted = 0;
+  // calls on one handle are serialised (the workspace of one call is reused by the next); a call on another stream than the
+  // previous one first makes its stream wait for the previous stream's work (the two would otherwise share the workspace)
+  std::mutex mu;
+  hipStream_t last_stream = nullptr;
+  bool have_last_stream = false;
+  hipEvent_t xs_event = nullptr;
+  // sticky status word in host-mapped memory (gmf_status_read): kernels OR bits into it through status_dev
+  int* status_host = nullptr;
+  int* status_dev = nullptr;
   gmf::Tuning tune;   // per-handle knobs (gmf_set_tuning); no process-global state
   // optional in-situ timing of the dominant kernel (k_scattn): event pairs recorded on the caller's stream
   bool profile = false;
@@ -50,11 +64,17 @@ inline int hip_fail(gmf_handle* h, hipError_t e, const char* where) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Bump allocator over one device block.  Growing frees and reallocates (hipFree synchronises the
-// device, so no kernel can still be using the old block).
+// Bump allocator over one device block.  Library-owned (default): growing frees and reallocates (hipFree synchronises the
+// device, so no kernel can still be using the old block - and it must not happen inside a stream capture: run every shape
+// once before capturing).  Caller-provided (gmf_set_workspace): never allocates; too small -> GMF_ERR_WORKSPACE.
 inline int arena_reserve(gmf_handle* h, size_t bytes) {
   h->arena_used = 0;
   if (bytes <= h->arena_bytes) return GMF_OK;
+  if (h->arena_external) {
+    h->arena_wanted = align_up(bytes + bytes / 8, 1 << 20);
+    return fail(h, GMF_ERR_WORKSPACE, "gmf: the caller-provided workspace holds " + std::to_string(h->arena_bytes) + " B, this call needs " +
+                                          std::to_string(bytes) + " B (gmf_workspace_wanted, gmf_set_workspace)");
+  }
   if (h->arena) {
     hipError_t e = hipFree(h->arena);
     h->arena = nullptr;
@@ -83,9 +103,35 @@ inline size_t arena_need(size_t count, size_t elem) { return align_up(count * el
 inline hipStream_t S(gmf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline int tiles_of(int n) { return (n + 31) / 32; }
 
+// Entered by every entry point after its argument checks: takes the handle's lock, makes the handle's device current for the
+// duration of the call and restores the caller's device afterwards, and orders this call's stream behind the previous
+// call's when they differ (both use the same workspace).
 struct SetDevice {
   gmf_handle* h;
-  explicit SetDevice(gmf_handle* hh) : h(hh) { (void)hipSetDevice(hh->device); }
-};
+  std::unique_lock<std::mutex> lock;
+  int prev = -1;
+  explicit SetDevice(gmf_handle* hh) : h(hh), lock(hh->mu) { enter(); }
+  SetDevice(gmf_handle* hh, gmf_stream_t stream) : h(hh), lock(hh->mu) {
+    enter();
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (h->have_last_stream && st != h->last_stream) {
+      if (!h->xs_event) (void)hipEventCreateWithFlags(&h->xs_event, hipEventDisableTiming);
+      if (h->xs_event && hipEventRecord(h->xs_event, h->last_stream) == hipSuccess) (void)hipStreamWaitEvent(st, h->xs_event, 0);
+    }
+    h->last_stream = st;
+    h->have_last_stream = true;
+  }
+  ~SetDevice() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  SetDevice(const SetDevice&) = delete;
+  SetDevice& operator=(const SetDevice&) = delete;
 
+ private:
+  void enter() {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != h->device) prev = cur;
+    if (cur != h->device) (void)hipSetDevice(h->device);
+  }
+};
 

@@ -90,7 +90,7 @@ GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const in
         float b[16];
         load_vec_block(b, vecs, mb, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) f[16 * mb + r] = fmaxf(fmaf(acc[r], kH2Inv, b[r]), 0.f);
+        for (int r = 0; r < 16; ++r) f[16 * mb + r] = relu_nan(fmaf(acc[r], kH2Inv, b[r]));
       }
     }
   }

@@ -93,7 +93,7 @@ k_front(const float* __restrict__ in, const float* __restrict__ wst, const float
       float b[16];
       load_vec_block(b, vecs, mb, h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) f[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+      for (int r = 0; r < 16; ++r) f[16 * mb + r] = relu_nan(acc[r] + b[r]);
     }
   }
   if (active) store_frag_p32<CF>(f_out + toff, f, lane);
@@ -260,7 +260,7 @@ k_scattn(const float* __restrict__ q_img, const float* __restrict__ k_img, const
     float b[16];
     load_vec_block(b, vecs, mb, h);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = relu_nan(acc[r] + b[r]);
   }
   {
     const float4* lw = ss.acquire();
@@ -271,7 +271,7 @@ k_scattn(const float* __restrict__ q_img, const float* __restrict__ k_img, const
       float b[16];
       load_vec_block(b, vecs + 64, mb, h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = relu_nan(acc[r] + b[r]);
     }
   }
 #pragma unroll
@@ -497,7 +497,7 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
     float b[16];
     load_vec_block(b, vecs, mb, h);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+    for (int r = 0; r < 16; ++r) m1[16 * mb + r] = relu_nan(acc[r] + b[r]);
   }
   {
     const float4* lw = ss.acquire();
@@ -508,7 +508,7 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
       float b[16];
       load_vec_block(b, vecs + 64, mb, h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = fmaxf(acc[r] + b[r], 0.f);
+      for (int r = 0; r < 16; ++r) m2[16 * mb + r] = relu_nan(acc[r] + b[r]);
     }
   }
 #pragma unroll
@@ -541,9 +541,13 @@ constexpr int kJPerWave = 8;
 // c is exactly symmetric (the squared differences do not see the sign of s_i - s_j), so only tiles J >= I are
 // evaluated; a tile with J > I is also written as tile (J, I) after a 32 x 32 transpose through a per-wave LDS buffer
 // (16 ds_write_b32 + 16 ds_read_b32 instead of 16 x ~26 vector instructions with two correctly rounded square roots).
-// HALF (the throughput numerics mode, gmf_set_tuning "precision" = 1): c is stored as fp16, 2 KiB per tile
-// ([q2][lane][8 halves], registers r = 8 q2 .. 8 q2 + 7) - half the stream of the 12 attention launches.
-template <bool HALF>
+// FMT (CompatCache::fmt): 0 = fp32, 4 KiB per tile.  The 16-bit formats are 2 KiB per tile ([q2][lane][8 x 16 bit], registers
+// r = 8 q2 .. 8 q2 + 7) - half the stream of the 12 attention launches:
+//   1 = c as fp16 (the throughput numerics mode, gmf_set_tuning "precision" = 1);
+//   2 = c as 16-bit fixed point, u = rint(65535 c) (uniform absolute error <= 7.6e-6; gmf_set_tuning "compat_format" = 2, opt-in).
+// (Measured and dropped, round 3: fp16 of 1 - c - exact where c = 1, coarse below c = 0.5 - and 16-bit fixed point of sqrt(1 - c),
+// the error structure of the reference's own fp32 rounding; profiles/r03_compat_formats.txt.)
+template <int FMT>
 __global__ void __launch_bounds__(256)
 k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int N, int tiles, float inv_sig2) {
   __shared__ float tr[4 * 32 * 33];
@@ -557,17 +561,26 @@ k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int 
     const float4 a = pp[0], b = pp[1];
     si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
   }
-  constexpr int kTile16 = HALF ? 128 : 256;          // 16-byte pieces per tile
+  constexpr int kTile16 = FMT ? 128 : 256;          // 16-byte pieces per tile
   float4* const cbase = reinterpret_cast<float4*>(c_dense) + pbase * (size_t)tiles * kTile16 + lane;
   float4* const crow = cbase + (size_t)I * tiles * kTile16;
   auto store_tile = [&](float4* ct, const float (&c)[16]) {
-    if (HALF) {
+    if (FMT == 1) {
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
         f16x8 hv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) hv[e] = (_Float16)c[8 * q2 + e];
         ct[q2 * 64] = __builtin_bit_cast(float4, hv);
+      }
+    } else if (FMT == 2) {
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        unsigned wv[4];
+        auto enc = [](float cv) { return (unsigned)__builtin_rintf(cv * 65535.0f); };
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) wv[e >> 1] = enc(c[8 * q2 + e]) | (enc(c[8 * q2 + e + 1]) << 16);
+        ct[q2 * 64] = make_float4(__uint_as_float(wv[0]), __uint_as_float(wv[1]), __uint_as_float(wv[2]), __uint_as_float(wv[3]));
       }
     } else {
 #pragma unroll
@@ -672,7 +685,7 @@ GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stag
       float b[16], t1[16];
       load_vec_block(b, vecs, mb, h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t1[r] = fmaxf(fmaf(acc[r], kH2Inv, b[r]), 0.f);
+      for (int r = 0; r < 16; ++r) t1[r] = relu_nan(fmaf(acc[r], kH2Inv, b[r]));
       m1x.set_block(mb, t1);
     }
     {
@@ -685,7 +698,7 @@ GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stag
         float b[16], t2[16];
         load_vec_block(b, vecs + 64, mb, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t2[r] = fmaxf(fmaf(acc[r], kH2Inv, b[r]), 0.f);
+        for (int r = 0; r < 16; ++r) t2[r] = relu_nan(fmaf(acc[r], kH2Inv, b[r]));
         m2x.set_block(mb, t2);
       }
     }
@@ -717,7 +730,7 @@ GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stag
         float b[16], tt[16];
         load_vec_block(b, next_bias, mb, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tt[r] = fmaxf(fmaf(acc[r], kH2Inv, b[r]), 0.f);
+        for (int r = 0; r < 16; ++r) tt[r] = relu_nan(fmaf(acc[r], kH2Inv, b[r]));
         store_block_p32(out_tile, mb, tt, lane);
       }
     }
@@ -744,11 +757,13 @@ GMF_DEVINL AttnItem attn_item(int L, int n_items, int n_full, int ksplits) {
 }
 
 // `bid`: the workgroup's index in the attention grid; `lds`: 64 KiB owned by the workgroup.
-// NPROD = 3, CH = false: the parity form (split-fp16 operands, three partial products, c as fp32).
-// NPROD = 1, CH = true: the THROUGHPUT numerics mode (gmf_set_tuning "precision" = 1): only the high
+// NPROD = 3, CFMT = 0: the parity form (split-fp16 operands, three partial products, c as fp32); CFMT = 2: the same with c
+// streamed as 16-bit fixed point (k_compat_build<2>; gmf_set_tuning "compat_format" = 2, opt-in).
+// NPROD = 1, CFMT = 1: the THROUGHPUT numerics mode (gmf_set_tuning "precision" = 1): only the high
 // fp16 planes of Q', K, V and of the probabilities are multiplied (one product, fp32 accumulation; the softmax statistics,
 // the compat product and the epilogue stay as they are) and c is streamed as fp16 - NOT within the 1e-4 parity gate.
-template <int NPROD = 3, bool CH = false>
+constexpr float kInvU16 = 1.0f / 65535.0f;
+template <int NPROD = 3, int CFMT = 0>
 GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restrict__ q_img, const float* __restrict__ k_img,
                                 const float* __restrict__ v_img, const float* __restrict__ fus, const float* __restrict__ wst,
                                 const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, int wgs_per_pair,
@@ -784,17 +799,25 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
       if (NPROD == 3) ql[s] = qp[(1 * 8 + s) * 64];
     }
   }
-  constexpr int kCTile16 = CH ? 128 : 256;             // 16-byte pieces per c tile
+  constexpr int kCTile16 = CFMT ? 128 : 256;           // 16-byte pieces per c tile
   const f32x4* const crow = reinterpret_cast<const f32x4*>(c_dense) + ((pbase + tile) * (size_t)tiles) * kCTile16 + lane;
-  float c[16];
+  float c[16];                                         // CFMT 0 / 1: the compat values of the tile
+  unsigned cw[8];                                      // CFMT 2: the tile's 16 x 16 bit as loaded (decoded where the scores are formed)
   auto fetch_c = [&](int t) {
     const f32x4* ct = crow + (size_t)t * kCTile16;
-    if (CH) {
+    if (CFMT == 1) {
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
         const f16x8 hv = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(ct + q2 * 64));
 #pragma unroll
         for (int e = 0; e < 8; ++e) c[8 * q2 + e] = (float)hv[e];
+      }
+    } else if (CFMT >= 2) {
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const f32x4 v = __builtin_nontemporal_load(ct + q2 * 64);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cw[4 * q2 + e] = __float_as_uint(v[e]);
       }
     } else {
 #pragma unroll
@@ -803,6 +826,15 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
         c[4 * q + 0] = v[0]; c[4 * q + 1] = v[1]; c[4 * q + 2] = v[2]; c[4 * q + 3] = v[3];
       }
     }
+  };
+  // score of register r: c * s.  CFMT 2: u * s with u = 65535 c (v_cvt_f32_u32 with a 16-bit source select) - the factor
+  // 1 / 65535 is applied where the scores are used (row maximum: once per tile; exponent: an fma instead of a subtraction).
+  auto score = [&](int r, float sv) -> float {
+    if (CFMT == 2) return (float)((r & 1) ? (cw[r >> 1] >> 16) : (cw[r >> 1] & 0xffffu)) * sv;
+    return c[r] * sv;
+  };
+  auto expo = [&](float xv, float m_off) -> float {
+    return __builtin_amdgcn_exp2f(CFMT == 2 ? fmaf(xv, kInvU16, -m_off) : xv - m_off);
   };
   // one product (hi x hi) or the three of the split-fp16 scheme
   auto mma_n = [&](f32x16& acc, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
@@ -849,8 +881,8 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-      x[r] = c[r] * s_cur[r];
-      x[r + 1] = c[r + 1] * s_cur[r + 1];
+      x[r] = score(r, s_cur[r]);
+      x[r + 1] = score(r + 1, s_cur[r + 1]);
       mx = __builtin_fmaxf(mx, __builtin_fmaxf(x[r], x[r + 1]));
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -889,6 +921,7 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
     // the compiler sinks the phase-1 vector work below it, out of the MFMA issue gaps
     {
       mx = xhalf_max_swap(mx);
+      if (CFMT == 2) mx *= kInvU16;
       const float m_new = __builtin_fmaxf(m_run, mx);
       moved = m_new > m_run;
       alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -912,14 +945,14 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
           // (the row maximum and the accumulator rescale are settled before the phase: see below)
         } else if (u <= 11) {
           const int r = u - 2;               // exponentials 0..9
-          x[r] = __builtin_amdgcn_exp2f(x[r] - m_off);
+          x[r] = expo(x[r], m_off);
           ls += x[r];
         } else if (u <= 15) {
           const int j = 2 * (u - 12);        // split pairs 0..3: the first 8 keys
           to_planes2(x[j], x[j + 1], ph0, pl0, j);
         } else if (u <= 21) {
           const int r = u - 6;               // exponentials 10..15
-          x[r] = __builtin_amdgcn_exp2f(x[r] - m_off);
+          x[r] = expo(x[r], m_off);
           ls += x[r];
         } else {
           const int j = 2 * (u - 22);        // split pairs 4, 5
@@ -967,13 +1000,14 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
       mx = __builtin_fmaxf(mx, x[r]);
     }
     mx = xhalf_max_swap(mx);
+    if (CFMT == 2) mx *= kInvU16;
     const float m_new = __builtin_fmaxf(m_run, mx);
     const bool moved = m_new > m_run;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     const float m_off = m_new - 10.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
+    for (int r = 0; r < 16; ++r) { x[r] = expo(x[r], m_off); ls += x[r]; }
     rescale(moved, alpha);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -1044,7 +1078,7 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   else scattn_epilogue_h2<false>(o, active, ss, lvec, ft, out + toff, lane, h);
 }
 
-template <int NPROD, bool CH>
+template <int NPROD, int CFMT>
 __global__ void __launch_bounds__(256, 2)
 k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
              const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
@@ -1052,7 +1086,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
              int n_items, int n_full, int ksplits, float* __restrict__ part_o, float* __restrict__ part_ml,
              const float* __restrict__ next_wst, const float* __restrict__ next_bias) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
-  scattn_h2p_body<NPROD, CH>(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items,
+  scattn_h2p_body<NPROD, CFMT>(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items,
                              n_full, ksplits, part_o, part_ml, next_wst, next_bias);
 }
 
@@ -1248,6 +1282,7 @@ k_scattn_fast(const float* __restrict__ q_img, const float* __restrict__ k_img, 
 // feed-forward workgroups (they need only x1).  Both write partial results; k_scattn_merge adds them up.  As separate
 // launches the two cost their sum on these latency-bound grids (B = 1, N = 5000: 44 + 18 us per layer); the attention
 // workgroups are one per CU (attn_item), so the feed-forward workgroups find a second slot on every CU.
+template <int CFMT>
 __global__ void __launch_bounds__(256, 2)
 k_small_attn_ff(const int n_attn, const float* __restrict__ q_img, const float* __restrict__ k_img,
                 const float* __restrict__ v_img, const float* __restrict__ tail_wst, const float* __restrict__ tail_vecs, int N,
@@ -1259,8 +1294,8 @@ k_small_attn_ff(const int n_attn, const float* __restrict__ q_img, const float* 
   if ((int)blockIdx.x < n_attn) {
     // (n_full = 0: every item is split and leaves through the partial-result branch; `fus` / `out` of the whole-item epilogue
     // are never touched - they get valid pointers all the same, a literal null there crashes this compiler's optimiser)
-    scattn_h2p_body(lds, blockIdx.x, q_img, k_img, v_img, x1, tail_wst, tail_vecs, ff_part, N, tiles, wgs_per_pair, c_dense,
-                    n_items, 0, ksplits, part_o, part_ml, nullptr, nullptr);
+    scattn_h2p_body<3, CFMT>(lds, blockIdx.x, q_img, k_img, v_img, x1, tail_wst, tail_vecs, ff_part, N, tiles, wgs_per_pair, c_dense,
+                             n_items, 0, ksplits, part_o, part_ml, nullptr, nullptr);
   } else {
     const int id = (int)blockIdx.x - n_attn;           // (bx, pair, z) with z fastest: the splits of a row block start together
     const int z = id % ff_hs, r = id / ff_hs;
@@ -1492,7 +1527,7 @@ k_scattn_merge_tile(const float* __restrict__ part_o, const float* __restrict__ 
     mma_wx_h2<8>(acc, stage(wave), ox);
     float t[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = fmaxf(fmaf(acc[r], kH2Inv, b1[r]), 0.f);
+    for (int r = 0; r < 16; ++r) t[r] = relu_nan(fmaf(acc[r], kH2Inv, b1[r]));
     __syncthreads();                              // (both readers of `o` are done: m1 goes where it was)
     f16x8 hi, lo;
     split8h(&t[0], hi, lo); xh[(0 * 4 + 2 * wave) * 64 + lane] = hi; xh[(1 * 4 + 2 * wave) * 64 + lane] = lo;
@@ -1510,7 +1545,7 @@ k_scattn_merge_tile(const float* __restrict__ part_o, const float* __restrict__ 
     mma_wx_h2<4>(acc, stage(2) + wave * (2 * 4 * 64), m1x);
     float t[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = fmaxf(fmaf(acc[r], kH2Inv, b2[r]), 0.f);
+    for (int r = 0; r < 16; ++r) t[r] = relu_nan(fmaf(acc[r], kH2Inv, b2[r]));
     __syncthreads();
     f16x8 hi, lo;
     split8h(&t[0], hi, lo); xh[(0 * 4 + 2 * wave) * 64 + lane] = hi; xh[(1 * 4 + 2 * wave) * 64 + lane] = lo;
@@ -1546,7 +1581,7 @@ k_scattn_merge_tile(const float* __restrict__ part_o, const float* __restrict__ 
     mma_wx_h2<8>(acc, stage(5 + wave), fx);
     float t[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = fmaxf(fmaf(acc[r], kH2Inv, b4[r]), 0.f);
+    for (int r = 0; r < 16; ++r) t[r] = relu_nan(fmaf(acc[r], kH2Inv, b4[r]));
     store_block_p32(out + toff, wave, t, lane);
   }
 }
@@ -1789,7 +1824,7 @@ k_fusion_ff(const float* __restrict__ x1, const float* __restrict__ wst, const f
 // =========================================================================================
 __global__ void __launch_bounds__(256, 2)
 k_head(const float* __restrict__ feat_img, const float* __restrict__ wst, const float* __restrict__ vecs,
-       float* __restrict__ logits, float* __restrict__ feat_n, float* __restrict__ feat_rm, int N, int tiles) {
+       float* __restrict__ logits, float* __restrict__ feat_n, float* __restrict__ feat_rm, int N, int tiles, int* status) {
   __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i = lane & 31;
   const int pair = blockIdx.y;
@@ -1834,7 +1869,13 @@ k_head(const float* __restrict__ feat_img, const float* __restrict__ wst, const 
   float ss2 = 0.f;
 #pragma unroll
   for (int k = 0; k < CF; ++k) ss2 = fmaf(x[k], x[k], ss2);
-  const float inv = 1.0f / fmaxf(sqrtf(xhalf_sum(ss2)), 1e-12f);
+  const float nrm2 = xhalf_sum(ss2);
+  // an activation beyond the fp16 range of the split operands (or a non-finite input) surfaces here as inf / NaN: the status
+  // word says so; the logit is stored as it is, the row's unit features as zeros - the pose head derives neighbour INDICES
+  // from them, and a library must not turn a bad input into an out-of-bounds gather
+  const bool bad_row = not_finite(nrm2);
+  flag_status(status, active && row < N && (not_finite(logit) || bad_row), 1);
+  const float inv = 1.0f / fmaxf(sqrtf(nrm2), 1e-12f);
 
   if (active && row < N) {
     const size_t ro = ((size_t)pair * N + row);
@@ -1842,7 +1883,8 @@ k_head(const float* __restrict__ feat_img, const float* __restrict__ wst, const 
     float4* pn = reinterpret_cast<float4*>(feat_n + ro * C) + h;
 #pragma unroll
     for (int g = 0; g < CF / 4; ++g)
-      pn[2 * g] = make_float4(x[4 * g] * inv, x[4 * g + 1] * inv, x[4 * g + 2] * inv, x[4 * g + 3] * inv);
+      pn[2 * g] = bad_row ? make_float4(0.f, 0.f, 0.f, 0.f)
+                          : make_float4(x[4 * g] * inv, x[4 * g + 1] * inv, x[4 * g + 2] * inv, x[4 * g + 3] * inv);
     if (feat_rm) {
       float4* pr = reinterpret_cast<float4*>(feat_rm + ro * C) + h;
 #pragma unroll
@@ -1936,7 +1978,7 @@ __global__ void k_pack_p32(const float* __restrict__ src, float* __restrict__ ds
 
 // P32 image -> strided [B, n_rows, K]
 __global__ void k_unpack_p32(const float* __restrict__ src, float* __restrict__ dst, int n_rows, int tiles, int K,
-                             long sb, long sr, long sk, long total4) {
+                             long sb, long sr, long sk, long total4, int* status) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
   const int lane = idx & 63;
@@ -1952,6 +1994,8 @@ __global__ void k_unpack_p32(const float* __restrict__ src, float* __restrict__ 
     const float4 v = reinterpret_cast<const float4*>(src)[idx];
     float* p = dst + b * sb + (long)row * sr + (long)k0 * sk;
     p[0] = v.x; p[sk] = v.y; p[2 * sk] = v.z; p[3 * sk] = v.w;
+    if (status && (not_finite(v.x) || not_finite(v.y) || not_finite(v.z) || not_finite(v.w)))
+      __hip_atomic_fetch_or(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -2007,10 +2051,12 @@ hipError_t launch_front(int mode, const float* in, const float* wst, const float
   return hipGetLastError();
 }
 
-hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, bool half, hipStream_t s) {
+hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, int fmt, hipStream_t s) {
   const dim3 grid(tiles, (tiles + 4 * kJPerWave - 1) / (4 * kJPerWave), B);
-  if (half) hipLaunchKernelGGL(k_compat_build<true>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, 1.0f / (sigma_d * sigma_d));
-  else hipLaunchKernelGGL(k_compat_build<false>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, 1.0f / (sigma_d * sigma_d));
+  const float inv = 1.0f / (sigma_d * sigma_d);
+  if (fmt == 1) hipLaunchKernelGGL(k_compat_build<1>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, inv);
+  else if (fmt == 2) hipLaunchKernelGGL(k_compat_build<2>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, inv);
+  else hipLaunchKernelGGL(k_compat_build<0>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, inv);
   return hipGetLastError();
 }
 
@@ -2059,8 +2105,12 @@ hipError_t launch_small_attn_ff_merge(const float* q, const float* k, const floa
   const int wpp = (tiles + 3) / 4, W = wpp * B;
   const int per_xcd = (W >> 3) + ((W & 7) ? 1 : 0);
   const int n_attn = 8 * per_xcd * ksplits, n_ff = W * ff_hs;
-  hipLaunchKernelGGL(k_small_attn_ff, dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
-                     cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs);
+  if (cc->fmt == 2)
+    hipLaunchKernelGGL(k_small_attn_ff<2>, dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs);
+  else
+    hipLaunchKernelGGL(k_small_attn_ff<0>, dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs);
   if (tile_merge)
     hipLaunchKernelGGL(k_scattn_merge_tile, dim3(tiles, B), dim3(256), 0, s, cc->part_o, cc->part_ml, cc->tail_wst_h2, tail_vecs, out,
                        tiles, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)ff_part, ff_hs, x1, ff_vecs + 2 * C + 2 * FFH);
@@ -2095,10 +2145,13 @@ hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, 
       hipLaunchKernelGGL(k_scattn_fast, dim3(8 * per_xcd), dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, W,
                          cc->next_wst_h2, cc->next_bias);
     else if (cc->half)  // ... with a split tail: one fp16 product, c streamed as fp16 (the cache was built that way)
-      hipLaunchKernelGGL((k_scattn_h2p<1, true>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, W,
+      hipLaunchKernelGGL((k_scattn_h2p<1, 1>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, W,
                          n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias);
+    else if (cc->fmt == 2)   // parity arithmetic, c streamed as 16-bit fixed point
+      hipLaunchKernelGGL((k_scattn_h2p<3, 2>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias);
     else
-      hipLaunchKernelGGL((k_scattn_h2p<3, false>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
+      hipLaunchKernelGGL((k_scattn_h2p<3, 0>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
                          W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias);
     if (max_tail > 0)
       hipLaunchKernelGGL(k_scattn_merge, dim3(8 * max_tail), dim3(256), 0, s, cc->part_o, cc->part_ml, fus, cc->tail_wst_h2, vecs, out,
@@ -2136,8 +2189,8 @@ hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs
 }
 
 hipError_t launch_head(const float* feat_img, const float* wst, const float* vecs, float* logits, float* feat_n,
-                       float* feat_rm, int B, int N, int tiles, hipStream_t s) {
-  hipLaunchKernelGGL(k_head, tile_grid(tiles, B), dim3(256), 0, s, feat_img, wst, vecs, logits, feat_n, feat_rm, N, tiles);
+                       float* feat_rm, int B, int N, int tiles, hipStream_t s, int* status) {
+  hipLaunchKernelGGL(k_head, tile_grid(tiles, B), dim3(256), 0, s, feat_img, wst, vecs, logits, feat_n, feat_rm, N, tiles, status);
   return hipGetLastError();
 }
 
@@ -2157,10 +2210,10 @@ hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int 
   return hipGetLastError();
 }
 
-hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s) {
+hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s, int* status) {
   const int tiles = (n_rows + 31) / 32;
   const long total4 = (long)B * tiles * (K / 8) * 64;
-  hipLaunchKernelGGL(k_unpack_p32, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, src, dst, n_rows, tiles, K, sb, sr, sk, total4);
+  hipLaunchKernelGGL(k_unpack_p32, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, src, dst, n_rows, tiles, K, sb, sr, sk, total4, status);
   return hipGetLastError();
 }
 

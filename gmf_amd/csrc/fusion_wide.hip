@@ -435,7 +435,8 @@ k_fusion_ff_w_h2(const float* __restrict__ x1, const float* __restrict__ wst, co
 // out_rm (may be null): the caller's strided [B, n_rows, 256] output - written here instead of the image + an unpacking pass.
 __global__ void __launch_bounds__(256)
 k_ff_reduce_w(const float* __restrict__ part, const float* __restrict__ x1, const float* __restrict__ vecs,
-              float* __restrict__ x2_out, int tiles, int hs, float* __restrict__ out_rm, long o_sb, long o_sr, long o_sk, int n_rows) {
+              float* __restrict__ x2_out, int tiles, int hs, float* __restrict__ out_rm, long o_sb, long o_sr, long o_sk, int n_rows,
+              int* status) {
   using namespace wide;
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int tile = blockIdx.x * kWaves + (threadIdx.x >> 6);
@@ -462,6 +463,10 @@ k_ff_reduce_w(const float* __restrict__ part, const float* __restrict__ x1, cons
   for (int r = 0; r < 16; ++r) t[r] = fmaf(t[r], kH2Inv, b[r]) + xr[r];
   if (out_rm) {
     const int row = tile * 32 + (lane & 31);
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bad = bad || not_finite(t[r]);
+    flag_status(status, bad && row < n_rows, 1);
     if (row < n_rows) {
       float* p = out_rm + (long)blockIdx.y * o_sb + (long)row * o_sr;
 #pragma unroll
@@ -994,11 +999,11 @@ int plan_ff_split_w(int base_wgs) {
 }
 
 hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const float* vecs, float* x2, int B, int tiles, hipStream_t s,
-                                 float* part, int hs, float* out_rm, long o_sb, long o_sr, long o_sk, int n_rows) {
+                                 float* part, int hs, float* out_rm, long o_sb, long o_sr, long o_sk, int n_rows, int* status) {
   const dim3 g = wgrid(tiles, B);
   if (part && hs > 1) {
     hipLaunchKernelGGL(k_fusion_ff_w_h2, dim3(g.x, g.y, hs), dim3(256), 0, s, x1, wst_h2, vecs, x2, tiles, part);
-    hipLaunchKernelGGL(k_ff_reduce_w, dim3(g.x, g.y, 8), dim3(256), 0, s, part, x1, vecs, x2, tiles, hs, out_rm, o_sb, o_sr, o_sk, n_rows);
+    hipLaunchKernelGGL(k_ff_reduce_w, dim3(g.x, g.y, 8), dim3(256), 0, s, part, x1, vecs, x2, tiles, hs, out_rm, o_sb, o_sr, o_sk, n_rows, status);
   } else {
     hipLaunchKernelGGL(k_fusion_ff_w_h2, g, dim3(256), 0, s, x1, wst_h2, vecs, x2, tiles, (float*)nullptr);
   }

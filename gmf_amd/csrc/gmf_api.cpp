@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -27,7 +28,51 @@ int gmf_create(int device, gmf_handle** out) {
   gmf_handle* h = new (std::nothrow) gmf_handle();
   if (!h) return GMF_ERR_OOM;
   h->device = device;
+  // the sticky status word: host memory mapped into the device's address space (read by the host without a synchronisation)
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(device);
+  void* hp = nullptr;
+  if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+      h->status_host = static_cast<int*>(hp);
+      h->status_dev = static_cast<int*>(dp);
+      *h->status_host = 0;
+    } else {
+      (void)hipHostFree(hp);
+    }
+  }
+  if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+  if (!h->status_dev) { delete h; return GMF_ERR_OOM; }
   *out = h;
+  return GMF_OK;
+}
+
+int gmf_set_workspace(gmf_handle* h, void* device_ptr, long long bytes) {
+  GMF_REQUIRE(h, GMF_ERR_BAD_ARG, "set_workspace: null handle");
+  GMF_REQUIRE((device_ptr == nullptr) == (bytes == 0) && bytes >= 0, GMF_ERR_BAD_ARG, "set_workspace: pass a pointer with its size, or NULL and 0");
+  GMF_REQUIRE(((uintptr_t)device_ptr & 255) == 0, GMF_ERR_BAD_ARG, "set_workspace: the block must be 256-byte aligned");
+  SetDevice sd(h);
+  if (!h->arena_external && h->arena) {          // the library's own block goes (hipFree synchronises the device)
+    hipError_t e = hipFree(h->arena);
+    h->arena = nullptr;
+    h->arena_bytes = 0;
+    if (e != hipSuccess) return hip_fail(h, e, "hipFree(workspace)");
+  }
+  h->arena = device_ptr;
+  h->arena_bytes = (size_t)bytes;
+  h->arena_external = device_ptr != nullptr;
+  h->arena_used = 0;
+  return GMF_OK;
+}
+
+long long gmf_workspace_wanted(gmf_handle* h) { return h ? (long long)h->arena_wanted : 0; }
+
+int gmf_status_read(gmf_handle* h, int* flags, int clear) {
+  GMF_REQUIRE(h && flags, GMF_ERR_BAD_ARG, "status_read: null pointer");
+  int* w = h->status_host;
+  *flags = clear ? __atomic_exchange_n(w, 0, __ATOMIC_RELAXED) : __atomic_load_n(w, __ATOMIC_RELAXED);
   return GMF_OK;
 }
 
@@ -92,16 +137,23 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     return GMF_OK;
   }
   if (std::strcmp(name, "wide_attn_tile") == 0) {      // 256-wide layer: cross-attention per tile (1, default; grids of up to 256 tiles) or per four tiles (0)
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: wide_attn_tile must be 0 or 1");
     t.wide_attn_tile = value != 0;
     return GMF_OK;
   }
   if (std::strcmp(name, "small_merge_tile") == 0) {    // small grids: merge step per query tile (1, default) or per four (0)
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: small_merge_tile must be 0 or 1");
     t.small_merge_tile = value != 0;
     return GMF_OK;
   }
   if (std::strcmp(name, "mid_grid_roles") == 0) {      // two-launch form below this many base workgroups: linear kernel as two roles (0 = never)
     GMF_REQUIRE(value >= 0 && value <= 4096, GMF_ERR_BAD_ARG, "set_tuning: mid_grid_roles out of range (0..4096)");
     t.mid_grid_roles = value;
+    return GMF_OK;
+  }
+  if (std::strcmp(name, "compat_format") == 0) {       // element format of the compat cache: 0 = fp32 (default), 2 = 16-bit fixed point (opt-in)
+    GMF_REQUIRE(value == 0 || value == 2, GMF_ERR_BAD_ARG, "set_tuning: compat_format must be 0 (fp32) or 2 (16-bit fixed point of c)");
+    t.compat_format = value;
     return GMF_OK;
   }
   if (std::strcmp(name, "precision") == 0) {           // 0 = parity numerics (default), 1 / 2 = throughput numerics (NOT within 1e-4)
@@ -138,10 +190,13 @@ int gmf_profile_read(gmf_handle* h, double* scattn_ms_total, int* scattn_launche
 void gmf_destroy(gmf_handle* h) {
   if (!h) return;
   for (auto& e : h->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  if (h->arena) {
-    (void)hipSetDevice(h->device);
-    (void)hipFree(h->arena);
-  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(h->device);
+  if (h->arena && !h->arena_external) (void)hipFree(h->arena);
+  if (h->xs_event) (void)hipEventDestroy(h->xs_event);
+  if (h->status_host) (void)hipHostFree(h->status_host);
+  if (prev >= 0 && prev != h->device) (void)hipSetDevice(prev);
   delete h;
 }
 
@@ -154,7 +209,7 @@ int gmf_pack_rows_p32(gmf_handle* h, const float* src, long long sb, long long s
                       int K, float* dst, gmf_stream_t stream) {
   GMF_REQUIRE(h && src && dst, GMF_ERR_BAD_ARG, "pack_rows_p32: null pointer");
   GMF_REQUIRE(B > 0 && n_rows > 0 && K > 0 && K % 8 == 0, GMF_ERR_UNSUPPORTED_SHAPE, "pack_rows_p32: K must be a positive multiple of 8");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_pack_p32(src, dst, B, n_rows, K, sb, sr, sk, S(stream)));
   return GMF_OK;
 }
@@ -163,7 +218,7 @@ int gmf_unpack_rows_p32(gmf_handle* h, const float* src_img, int B, int n_rows, 
                         long long sr, long long sk, gmf_stream_t stream) {
   GMF_REQUIRE(h && src_img && dst, GMF_ERR_BAD_ARG, "unpack_rows_p32: null pointer");
   GMF_REQUIRE(B > 0 && n_rows > 0 && K > 0 && K % 8 == 0, GMF_ERR_UNSUPPORTED_SHAPE, "unpack_rows_p32: K must be a positive multiple of 8");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_unpack_p32(src_img, dst, B, n_rows, K, sb, sr, sk, S(stream)));
   return GMF_OK;
 }
@@ -171,7 +226,7 @@ int gmf_unpack_rows_p32(gmf_handle* h, const float* src_img, int B, int n_rows, 
 int gmf_pack_pts8(gmf_handle* h, const float* src, const float* tgt, int B, int N, float* dst, gmf_stream_t stream) {
   GMF_REQUIRE(h && src && tgt && dst, GMF_ERR_BAD_ARG, "pack_pts8: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "pack_pts8: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_pack_pts8(src, tgt, dst, B, N, S(stream)));
   return GMF_OK;
 }
@@ -181,7 +236,7 @@ int gmf_front_forward(gmf_handle* h, int first, const float* in, const float* ws
                       float* q, float* k, float* v, int B, int N, gmf_stream_t stream) {
   GMF_REQUIRE(h && in && wst && vecs && f && q && k && v, GMF_ERR_BAD_ARG, "front_forward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "front_forward: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_front(first ? 1 : 0, in, wst, vecs, f, q, k, v, B, N, tiles_of(N), S(stream)));
   return GMF_OK;
 }
@@ -192,7 +247,7 @@ int gmf_scattn_forward(gmf_handle* h, const float* q, const float* k, const floa
   GMF_REQUIRE(h && q && k && v && pts8 && fusion2_out && wst && vecs && out, GMF_ERR_BAD_ARG, "scattn_forward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "scattn_forward: empty input");
   GMF_REQUIRE(sigma_d > 0.f, GMF_ERR_BAD_ARG, "scattn_forward: sigma_d must be positive");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_scattn_fp32(q, k, v, pts8, fusion2_out, wst, vecs, out, B, N, tiles_of(N), sigma_d, S(stream)));
   return GMF_OK;
 }
@@ -202,7 +257,7 @@ int gmf_scattn_forward_dense(gmf_handle* h, const float* q, const float* k, cons
                              gmf_stream_t stream) {
   GMF_REQUIRE(h && q && k && v && attention && fusion2_out && wst && vecs && out, GMF_ERR_BAD_ARG, "scattn_forward_dense: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "scattn_forward_dense: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_scattn_dense(q, k, v, attention, fusion2_out, wst, vecs, out, B, N, tiles_of(N), S(stream)));
   return GMF_OK;
 }
@@ -211,7 +266,7 @@ int gmf_fusion_ctx_prepare(gmf_handle* h, int pe, const float* ctx, const float*
                            int B, int T, int sets, int wst_stride, int vec_stride, gmf_stream_t stream) {
   GMF_REQUIRE(h && ctx && wst && vecs && out, GMF_ERR_BAD_ARG, "fusion_ctx_prepare: null pointer");
   GMF_REQUIRE(B > 0 && T > 0 && sets > 0, GMF_ERR_UNSUPPORTED_SHAPE, "fusion_ctx_prepare: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_ctx_prep(pe != 0, ctx, wst, vecs, out, B, T, tiles_of(T), sets, wst_stride, vec_stride, S(stream)));
   return GMF_OK;
 }
@@ -220,7 +275,7 @@ int gmf_fusion_attn_forward(gmf_handle* h, int pe, const float* x, const float* 
                             const float* vecs, float* x1, int B, int N, int T, gmf_stream_t stream) {
   GMF_REQUIRE(h && x && ctx_img && wst && vecs && x1, GMF_ERR_BAD_ARG, "fusion_attn_forward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "fusion_attn_forward: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_fusion_attn(pe != 0, x, ctx_img, wst, vecs, x1, B, N, tiles_of(N), T, tiles_of(T), S(stream)));
   return GMF_OK;
 }
@@ -229,7 +284,7 @@ int gmf_fusion_ff_forward(gmf_handle* h, const float* x1, const float* wst, cons
                           int N, gmf_stream_t stream) {
   GMF_REQUIRE(h && x1 && wst && vecs && x2, GMF_ERR_BAD_ARG, "fusion_ff_forward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "fusion_ff_forward: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_fusion_ff(x1, wst, vecs, x2, B, tiles_of(N), S(stream)));
   return GMF_OK;
 }
@@ -238,8 +293,8 @@ int gmf_classifier_forward(gmf_handle* h, const float* feat_img, const float* ws
                            float* feat_n, float* feat, int B, int N, gmf_stream_t stream) {
   GMF_REQUIRE(h && feat_img && wst && vecs && logits && feat_n, GMF_ERR_BAD_ARG, "classifier_forward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "classifier_forward: empty input");
-  SetDevice sd(h);
-  GMF_HIP(gmf::launch_head(feat_img, wst, vecs, logits, feat_n, feat, B, N, tiles_of(N), S(stream)));
+  SetDevice sd(h, stream);
+  GMF_HIP(gmf::launch_head(feat_img, wst, vecs, logits, feat_n, feat, B, N, tiles_of(N), S(stream), h->status_dev));
   return GMF_OK;
 }
 
@@ -328,7 +383,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   GMF_REQUIRE(corr_pos && src_keypts && tgt_keypts && p_tokens && q_tokens && logits && feat_n, GMF_ERR_BAD_ARG,
               "encoder_forward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "encoder_forward: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   hipStream_t st = S(stream);
   const int L = w->num_layers;
   const int tiles = tiles_of(N), tt = tiles_of(T);
@@ -337,8 +392,10 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   // compat cache (built once per batch, streamed by all L attention launches): 4 KiB per pair of 32-row tiles
   const size_t n_tt = (size_t)B * tiles * tiles;
   const bool h2 = use_h2(h, w, false);
-  const bool want_cache = h2 && (L > 1) && h->tune.use_cache && n_tt * 4096 <= ((size_t)96 << 30);
-  const size_t cache_need = want_cache ? arena_need(n_tt * 1024, 4) : 0;
+  // (2 KiB per tile pair in the 16-bit formats of the pipelined kernel, 4 KiB as fp32)
+  const size_t c_tile_floats = (h->tune.scattn_variant == 18 && h->tune.compat_format != 0) ? 512 : 1024;
+  const bool want_cache = h2 && (L > 1) && h->tune.use_cache && n_tt * c_tile_floats * 4 <= ((size_t)96 << 30);
+  const size_t cache_need = want_cache ? arena_need(n_tt * c_tile_floats, 4) : 0;
   // key-split attention for small grids (fewer than 256 workgroups of 128 queries): partial-result workspace
   // (small grids: up to 8 splits of every query block; large grids: the last partial round of workgroups is split in 2..4)
   const int kMaxSplits = ((tiles + 3) / 4) * B < 384 ? 8 : 4;
@@ -366,7 +423,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   gmf::CompatCache cc{nullptr, nullptr, nullptr, nullptr, 0};
   float* c_dense = nullptr;
   if (want_cache) {
-    c_dense = arena_take<float>(h, n_tt * 1024);
+    c_dense = arena_take<float>(h, n_tt * c_tile_floats);
     cc.dense = c_dense;
   }
   float* ff_part = nullptr;
@@ -404,7 +461,10 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   // other path keeps the parity numerics
   cc.half = h->tune.precision >= 1 && h2 && L > 0 && want_cache && h->tune.fused_linear && h->tune.scattn_variant == 18 &&
             ((tiles + 3) / 4) * B >= 256;
-  if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, cc.half, st));
+  // the cache's element format: fp16 c in the throughput mode; else the handle's "compat_format" wherever the pipelined
+  // kernel (variant 18) is the cache's only reader
+  cc.fmt = cc.half ? 1 : (want_cache && h->tune.scattn_variant == 18) ? h->tune.compat_format : 0;
+  if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, cc.fmt, st));
 
   float* cur = featA;
   float* nxt = featB;
@@ -458,7 +518,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
       cc.next_bias = last ? nullptr : w->front_vec + (size_t)(l + 1) * w->front_vec_stride;
       if (int rc = run_scattn(h, w, l, q, k, v, pts8, x2, last ? cur : f, B, N, st, nullptr, &cc)) return rc;
     }
-    GMF_HIP(gmf::launch_head(cur, w->head_wst, w->head_vec, logits, feat_n, feat, B, N, tiles, st));
+    GMF_HIP(gmf::launch_head(cur, w->head_wst, w->head_vec, logits, feat_n, feat, B, N, tiles, st, h->status_dev));
     return GMF_OK;
   }
   if (L == 0) {
@@ -476,7 +536,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
                                 &cc)) return rc;
     float* t = cur; cur = nxt; nxt = t;
   }
-  GMF_HIP(gmf::launch_head(cur, w->head_wst, w->head_vec, logits, feat_n, feat, B, N, tiles, st));
+  GMF_HIP(gmf::launch_head(cur, w->head_wst, w->head_vec, logits, feat_n, feat, B, N, tiles, st, h->status_dev));
   return GMF_OK;
 }
 
@@ -490,7 +550,7 @@ int gmf_nonlocal_block_forward(gmf_handle* h, const gmf_encoder_weights* w, int 
   GMF_REQUIRE(layer >= 0 && layer < w->num_layers, GMF_ERR_BAD_ARG, "nonlocal_block_forward: layer out of range");
   GMF_REQUIRE(B > 0 && N > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "nonlocal_block_forward: empty input");
   GMF_REQUIRE(apply_pointcn == 0 || apply_pointcn == 1, GMF_ERR_BAD_ARG, "nonlocal_block_forward: bad flag");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   hipStream_t st = S(stream);
   const int tiles = tiles_of(N), tt = tiles_of(T);
   const size_t act = (size_t)B * tiles * kTileFloats;
@@ -533,7 +593,7 @@ int gmf_fusion_layer_forward(gmf_handle* h, int pe, int latent_dim, int d_head, 
   const bool narrow = (latent_dim == 128 && d_head == 64), wide = (latent_dim == 256 && d_head == 128);
   GMF_REQUIRE(narrow || wide, GMF_ERR_UNSUPPORTED_SHAPE,
               "fusion_layer_forward: kernels exist for (latent_dim, d_head) = (128, 64) and (256, 128), context dim 128");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   hipStream_t st = S(stream);
   const int tiles = tiles_of(N), tt = tiles_of(T);
   const size_t act = (size_t)B * tiles * 32 * latent_dim;
@@ -574,13 +634,13 @@ int gmf_fusion_layer_forward(gmf_handle* h, int pe, int latent_dim, int d_head, 
       GMF_HIP(gmf::launch_fusion_attn_w(pe != 0, xin, ctx, attn_wst, attn_vec, x1, B, N, tiles, T, tt, st));
     }
     if (ff_wst_h2 && ff_hs_w > 1) {                 // the partials' reduction writes the caller's tensor
-      GMF_HIP(gmf::launch_fusion_ff_w_h2(x1, ff_wst_h2, ff_vec, x2, B, tiles, st, ff_part_w, ff_hs_w, out, o_sb, o_sr, o_sk, N));
+      GMF_HIP(gmf::launch_fusion_ff_w_h2(x1, ff_wst_h2, ff_vec, x2, B, tiles, st, ff_part_w, ff_hs_w, out, o_sb, o_sr, o_sk, N, h->status_dev));
       return GMF_OK;
     }
     if (ff_wst_h2) GMF_HIP(gmf::launch_fusion_ff_w_h2(x1, ff_wst_h2, ff_vec, x2, B, tiles, st, ff_part_w, ff_hs_w));
     else GMF_HIP(gmf::launch_fusion_ff_w(x1, ff_wst, ff_vec, x2, B, tiles, st));
   }
-  GMF_HIP(gmf::launch_unpack_p32(x2, out, B, N, latent_dim, o_sb, o_sr, o_sk, st));
+  GMF_HIP(gmf::launch_unpack_p32(x2, out, B, N, latent_dim, o_sb, o_sr, o_sk, st, h->status_dev));
   return GMF_OK;
 }
 
@@ -590,7 +650,7 @@ int gmf_pick_seeds(gmf_handle* h, const float* src_keypts, const float* scores, 
   GMF_REQUIRE(h && src_keypts && scores && seeds_out, GMF_ERR_BAD_ARG, "pick_seeds: null pointer");
   GMF_REQUIRE(B > 0 && N > 0 && num_seeds > 0 && num_seeds <= N, GMF_ERR_UNSUPPORTED_SHAPE, "pick_seeds: need 0 < num_seeds <= N");
   GMF_REQUIRE(N <= 16384, GMF_ERR_UNSUPPORTED_SHAPE, "pick_seeds: N > 16384 is not supported by the in-LDS sort");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   hipStream_t st = S(stream);
   const float* keys = scores;
   if (use_nms) {
@@ -619,7 +679,7 @@ int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, 
   GMF_REQUIRE(N <= 16384 || seeds_in, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: N > 16384 needs caller-provided seeds");
   GMF_REQUIRE((size_t)N * 4 <= 150 * 1024, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: N too large for the in-LDS kNN (max 38400)");
   GMF_REQUIRE(p->sigma > 0.f && p->sigma_d > 0.f, GMF_ERR_BAD_ARG, "pose_head: sigma, sigma_d must be positive");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   hipStream_t st = S(stream);
   const size_t BS = (size_t)B * Sn;
   const size_t need = arena_need((size_t)B * N, 4) + arena_need(BS, 4) + arena_need(BS * k, 4) +
@@ -676,7 +736,7 @@ int gmf_knn_rows(gmf_handle* h, const float* feat_n, const int* rows, int B, int
   GMF_REQUIRE(h && feat_n && rows && knn_out, GMF_ERR_BAD_ARG, "knn_rows: null pointer");
   GMF_REQUIRE(B > 0 && N > 1 && Sn > 0 && k > 0 && k <= N - 1, GMF_ERR_UNSUPPORTED_SHAPE, "knn_rows: need 0 < k <= N-1");
   GMF_REQUIRE((size_t)N * 4 <= 150 * 1024, GMF_ERR_UNSUPPORTED_SHAPE, "knn_rows: N too large for the in-LDS kNN (max 38400)");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_knn_seeds(feat_n, rows, nullptr, knn_out, B, N, Sn, k, S(stream)));
   return GMF_OK;
 }
@@ -688,7 +748,7 @@ int gmf_nn_match(gmf_handle* h, const float* F0, const float* F1, int N0, int N1
   GMF_REQUIRE(mode >= 0 && mode <= 2, GMF_ERR_BAD_ARG, "nn_match: mode must be 0 (PointDSC), 1 (DGR L2) or 2 (DGR SquareL2)");
   const int K = gmf::padded_desc_width(d);
   GMF_REQUIRE(K > 0, GMF_ERR_UNSUPPORTED_SHAPE, "nn_match: descriptor width above 128 is not supported");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   const size_t n0 = (size_t)tiles_of(N0) * 32 * K, n1 = (size_t)tiles_of(N1) * 32 * K + 4096;
   if (int rc = arena_reserve(h, arena_need(n0, 4) + arena_need(n1, 4) + arena_need((size_t)N1, 4))) return rc;
   float* i0 = arena_take<float>(h, n0);
@@ -702,7 +762,7 @@ int gmf_procrustes_batched(gmf_handle* h, const float* A, const float* Bp, const
                            float weight_threshold, float* T44, gmf_stream_t stream) {
   GMF_REQUIRE(h && A && Bp && T44, GMF_ERR_BAD_ARG, "procrustes_batched: null pointer");
   GMF_REQUIRE(n > 0 && k > 0, GMF_ERR_UNSUPPORTED_SHAPE, "procrustes_batched: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_rigid_transform(A, Bp, weights, T44, n, k, weight_threshold, S(stream)));
   return GMF_OK;
 }
@@ -712,7 +772,7 @@ int gmf_post_refinement(gmf_handle* h, const float* T_in, const float* src_keypt
   GMF_REQUIRE(h && T_in && src_keypts && tgt_keypts && T_out, GMF_ERR_BAD_ARG, "post_refinement: null pointer");
   GMF_REQUIRE(B > 0 && N > 0 && iters >= 0, GMF_ERR_UNSUPPORTED_SHAPE, "post_refinement: empty input");
   GMF_REQUIRE(refine_threshold > 0.f, GMF_ERR_BAD_ARG, "post_refinement: threshold must be positive");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_post_refine(T_in, src_keypts, tgt_keypts, T_out, B, N, refine_threshold, iters, S(stream)));
   return GMF_OK;
 }
@@ -721,7 +781,7 @@ int gmf_weighted_procrustes(gmf_handle* h, const float* X, const float* Y, const
                             float eps, float* R, float* t, gmf_stream_t stream) {
   GMF_REQUIRE(h && X && Y && w && offsets && R && t, GMF_ERR_BAD_ARG, "weighted_procrustes: null pointer");
   GMF_REQUIRE(B > 0, GMF_ERR_UNSUPPORTED_SHAPE, "weighted_procrustes: empty batch");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_weighted_procrustes(X, Y, w, offsets, B, eps, R, t, S(stream)));
   return GMF_OK;
 }
@@ -734,7 +794,7 @@ int gmf_global_registration(gmf_handle* h, const float* X, const float* Y, const
   GMF_REQUIRE(B > 0, GMF_ERR_UNSUPPORTED_SHAPE, "global_registration: empty batch");
   GMF_REQUIRE(quantization_size > 0.f && max_iter >= 0 && max_break_count >= 1, GMF_ERR_BAD_ARG,
               "global_registration: quantization_size must be > 0, max_iter >= 0, max_break_count >= 1");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_global_registration(X, Y, w, offsets, B, eps, quantization_size, max_iter, max_break_count,
                                           break_threshold_ratio, R, t, stats, max_points > 0 ? max_points : (1 << 30), S(stream)));
   return GMF_OK;
@@ -746,7 +806,7 @@ int gmf_similarity_matrix(gmf_handle* h, const float* feat_n, int B, int N, floa
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "similarity_matrix: empty input");
   GMF_REQUIRE(ldm >= N, GMF_ERR_BAD_ARG, "similarity_matrix: ldm (row stride of M in floats) must be >= N");
   GMF_REQUIRE(sigma != 0.f, GMF_ERR_BAD_ARG, "similarity_matrix: sigma must be non-zero");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   const size_t n_img = gmf::similarity_image_floats(B, N);
   if (int rc = arena_reserve(h, arena_need(n_img, 4))) return rc;
   float* img = arena_take<float>(h, n_img);
@@ -759,7 +819,7 @@ int gmf_spectral_matching_loss(gmf_handle* h, const float* M, int ldm, const flo
   GMF_REQUIRE(h && M && gt_labels && loss_out, GMF_ERR_BAD_ARG, "spectral_matching_loss: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "spectral_matching_loss: empty input");
   GMF_REQUIRE(ldm >= N, GMF_ERR_BAD_ARG, "spectral_matching_loss: ldm (row stride of M in floats) must be >= N");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   const size_t n_part = (size_t)2 * B * gmf::sm_parts_per_pair(B, N);
   if (int rc = arena_reserve(h, arena_need(n_part, 8) + arena_need((size_t)B, 8))) return rc;
   double* part = arena_take<double>(h, n_part);
@@ -773,7 +833,7 @@ int gmf_spectral_matching_loss_fused(gmf_handle* h, const float* feat_n, const f
   GMF_REQUIRE(h && feat_n && gt_labels && loss_out, GMF_ERR_BAD_ARG, "spectral_matching_loss_fused: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "spectral_matching_loss_fused: empty input");
   GMF_REQUIRE(sigma != 0.f, GMF_ERR_BAD_ARG, "spectral_matching_loss_fused: sigma must be non-zero");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   const size_t n_img = gmf::similarity_image_floats(B, N);
   const size_t n_part = (size_t)2 * B * gmf::sm_fused_parts_per_pair(B, N);
   if (int rc = arena_reserve(h, arena_need(n_img, 4) + arena_need(n_part, 8) + arena_need((size_t)B, 8))) return rc;
@@ -789,7 +849,7 @@ int gmf_spectral_matching_backward(gmf_handle* h, const float* feat_n, const flo
   GMF_REQUIRE(h && feat_n && gt_labels && d_feat_n && d_sigma, GMF_ERR_BAD_ARG, "spectral_matching_backward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "spectral_matching_backward: empty input");
   GMF_REQUIRE(sigma != 0.f, GMF_ERR_BAD_ARG, "spectral_matching_backward: sigma must be non-zero");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   const size_t n_img = gmf::similarity_image_floats(B, N);
   const size_t n_part = (size_t)gmf::sm_backward_parts(B, N);
   if (int rc = arena_reserve(h, 2 * arena_need(n_img, 4) + arena_need((size_t)4 * B, 4) + arena_need(n_part, 8))) return rc;
@@ -805,7 +865,7 @@ int gmf_classification_loss(gmf_handle* h, const float* pred, const float* gt, c
                             int balanced, float* out6, gmf_stream_t stream) {
   GMF_REQUIRE(h && pred && gt && out6, GMF_ERR_BAD_ARG, "classification_loss: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "classification_loss: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   const size_t n_part = (size_t)9 * gmf::classification_parts(B, N);
   if (int rc = arena_reserve(h, arena_need(n_part, 8))) return rc;
   double* part = arena_take<double>(h, n_part);
@@ -819,7 +879,7 @@ int gmf_transformation_loss(gmf_handle* h, const float* trans, const float* gt_t
   GMF_REQUIRE(h && trans && gt_trans && src_keypts && tgt_keypts && probs && out5, GMF_ERR_BAD_ARG,
               "transformation_loss: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "transformation_loss: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   const size_t n_part = (size_t)3 * B * gmf::transformation_slices(B, N);
   if (int rc = arena_reserve(h, arena_need(n_part, 8))) return rc;
   double* part = arena_take<double>(h, n_part);
@@ -832,7 +892,7 @@ int gmf_bias_relu_nhwc(gmf_handle* h, float* y, const float* bias, const float* 
                        gmf_stream_t stream) {
   GMF_REQUIRE(h && y && bias, GMF_ERR_BAD_ARG, "bias_relu_nhwc: null pointer");
   GMF_REQUIRE(n_pixels > 0 && C > 0 && C % 4 == 0, GMF_ERR_UNSUPPORTED_SHAPE, "bias_relu_nhwc: need n_pixels > 0 and C a positive multiple of 4");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_bias_relu_nhwc(y, bias, residual, (long)n_pixels, C, S(stream)));
   return GMF_OK;
 }
@@ -842,7 +902,7 @@ int gmf_stem_forward(gmf_handle* h, const float* x, long long sb, long long sc, 
   GMF_REQUIRE(h && x && wimg && bias && y, GMF_ERR_BAD_ARG, "stem_forward: null pointer");
   GMF_REQUIRE(B > 0 && H > 0 && W > 0, GMF_ERR_UNSUPPORTED_SHAPE, "stem_forward: empty input");
   GMF_REQUIRE(B <= 65535, GMF_ERR_UNSUPPORTED_SHAPE, "stem_forward: at most 65535 images per call");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_stem_h2(x, (long)sb, (long)sc, (long)sh, (long)sw, wimg, bias, y, B, H, W, S(stream)));
   return GMF_OK;
 }
@@ -855,7 +915,7 @@ int gmf_conv_nhwc(gmf_handle* h, const float* x, const float* wimg, const float*
                      (cin == 128 && cout == 128 && ksize == 3 && stride == 1) || (cin == 64 && cout == 128 && ksize == 1 && stride == 2);
   GMF_REQUIRE(known, GMF_ERR_UNSUPPORTED_SHAPE,
               "conv_nhwc: supported are the ResNet-34 layer1 / layer2 shapes (64->64 3x3 s1, 64->128 3x3 s2, 128->128 3x3 s1, 64->128 1x1 s2)");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_conv_nhwc_h2(h->tune, x, wimg, bias, residual, y, B, H, W, cin, cout, ksize, stride, relu, S(stream)));
   return GMF_OK;
 }

@@ -12,7 +12,7 @@ int gmf_gemm_f32(gmf_handle* h, int trans_a, int trans_b, const float* A, const 
   GMF_REQUIRE(h && A && B && C, GMF_ERR_BAD_ARG, "gemm_f32: null pointer");
   GMF_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, GMF_ERR_UNSUPPORTED_SHAPE, "gemm_f32: empty problem");
   GMF_REQUIRE((long long)batch * ((M + 127) / 128) <= 2000000 , GMF_ERR_UNSUPPORTED_SHAPE, "gemm_f32: grid too large");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   const int ksplits = gmf::gemm_ksplits(trans_a != 0, trans_b != 0, A, B, M, N, K, (long)lda, (long)ldb, (long)stride_a, (long)stride_b, batch);
   float* part = nullptr;
   if (ksplits > 1) {
@@ -28,7 +28,7 @@ int gmf_lcpe(gmf_handle* h, int backward, const float* x, const float* w, const 
              gmf_stream_t stream) {
   GMF_REQUIRE(h && x && w && y && (backward || bias), GMF_ERR_BAD_ARG, "lcpe: null pointer");
   GMF_REQUIRE(rows > 0 && L > 0 && C > 0 && rows % L == 0, GMF_ERR_UNSUPPORTED_SHAPE, "lcpe: rows must be a positive multiple of L");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_lcpe(backward != 0, x, w, bias, y, rows, L, C, S(stream)));
   return GMF_OK;
 }
@@ -37,7 +37,7 @@ int gmf_layernorm_forward(gmf_handle* h, const float* x, const float* gamma, con
                           long long rows, int C, gmf_stream_t stream) {
   GMF_REQUIRE(h && x && gamma && beta && y && mean && rstd, GMF_ERR_BAD_ARG, "layernorm_forward: null pointer");
   GMF_REQUIRE(rows > 0 && C > 0, GMF_ERR_UNSUPPORTED_SHAPE, "layernorm_forward: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_ln_fwd(x, gamma, beta, y, mean, rstd, (long)rows, C, S(stream)));
   return GMF_OK;
 }
@@ -46,7 +46,7 @@ int gmf_layernorm_backward(gmf_handle* h, const float* dy, const float* x, const
                            const float* dx_add, float* dx, long long rows, int C, gmf_stream_t stream) {
   GMF_REQUIRE(h && dy && x && gamma && mean && rstd && dx, GMF_ERR_BAD_ARG, "layernorm_backward: null pointer");
   GMF_REQUIRE(rows > 0 && C > 0, GMF_ERR_UNSUPPORTED_SHAPE, "layernorm_backward: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_ln_bwd(dy, x, gamma, mean, rstd, dx_add, dx, (long)rows, C, S(stream)));
   return GMF_OK;
 }
@@ -55,7 +55,7 @@ int gmf_softmax_rows(gmf_handle* h, int backward, const float* a, const float* b
                      float scale, gmf_stream_t stream) {
   GMF_REQUIRE(h && a && out && (!backward || b), GMF_ERR_BAD_ARG, "softmax_rows: null pointer");
   GMF_REQUIRE(rows > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "softmax_rows: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_softmax(backward != 0, a, b, mul, out, (long)rows, T, scale, S(stream)));
   return GMF_OK;
 }
@@ -64,7 +64,7 @@ int gmf_geglu(gmf_handle* h, int backward, const float* hdn, const float* dg, fl
               gmf_stream_t stream) {
   GMF_REQUIRE(h && hdn && out && (!backward || dg), GMF_ERR_BAD_ARG, "geglu: null pointer");
   GMF_REQUIRE(rows > 0 && H > 0, GMF_ERR_UNSUPPORTED_SHAPE, "geglu: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_geglu(backward != 0, hdn, dg, out, (long)rows, H, S(stream)));
   return GMF_OK;
 }
@@ -76,7 +76,7 @@ int gmf_colsum(gmf_handle* h, const float* x, const float* y, const float* mean,
   GMF_REQUIRE((mean == nullptr) == (rstd == nullptr) && (!mean || y), GMF_ERR_BAD_ARG, "colsum: mean and rstd come together, with y");
   GMF_REQUIRE(rows > 0 && C > 0 && L > 0 && rows % L == 0, GMF_ERR_UNSUPPORTED_SHAPE, "colsum: rows must be a positive multiple of L");
   GMF_REQUIRE(shift >= -1 && shift <= 1, GMF_ERR_BAD_ARG, "colsum: shift must be -1, 0 or 1");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_REQUIRE(!dual || y, GMF_ERR_BAD_ARG, "colsum: dual needs y (without y both sums are the same)");
   const size_t n_part = (size_t)gmf::colsum_chunks((long)rows) * C * (dual ? 2 : 1);
   if (int rc = arena_reserve(h, arena_need(n_part, 4))) return rc;
@@ -93,7 +93,7 @@ int gmf_batchnorm_train_forward(gmf_handle* h, const float* x, const float* gamm
   GMF_REQUIRE(h && x && gamma && beta && y && mean && rstd, GMF_ERR_BAD_ARG, "batchnorm_train_forward: null pointer");
   GMF_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GMF_ERR_BAD_ARG, "batchnorm_train_forward: running stats come together");
   GMF_REQUIRE(rows > 1 && C > 0, GMF_ERR_UNSUPPORTED_SHAPE, "batchnorm_train_forward: need more than one row");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   const size_t n_part = (size_t)gmf::colsum_chunks((long)rows) * C;
   if (int rc = arena_reserve(h, arena_need(n_part, 4) + 2 * arena_need((size_t)C, 4))) return rc;
   float* part = arena_take<float>(h, n_part);
@@ -114,7 +114,7 @@ int gmf_batchnorm_train_backward(gmf_handle* h, const float* dy, const float* x,
                                  gmf_stream_t stream) {
   GMF_REQUIRE(h && dy && x && mean && rstd && gamma && dx && dgamma && dbeta, GMF_ERR_BAD_ARG, "batchnorm_train_backward: null pointer");
   GMF_REQUIRE(rows > 1 && C > 0, GMF_ERR_UNSUPPORTED_SHAPE, "batchnorm_train_backward: need more than one row");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   const size_t n_part = (size_t)gmf::colsum_chunks((long)rows) * C * 2;
   if (int rc = arena_reserve(h, arena_need(n_part, 4))) return rc;
   float* part = arena_take<float>(h, n_part);
@@ -129,7 +129,7 @@ int gmf_normalize_rows(gmf_handle* h, int backward, const float* a, const float*
                        gmf_stream_t stream) {
   GMF_REQUIRE(h && a && nrm && out && (!backward || dy), GMF_ERR_BAD_ARG, "normalize_rows: null pointer");
   GMF_REQUIRE(rows > 0 && C > 0, GMF_ERR_UNSUPPORTED_SHAPE, "normalize_rows: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_normalize(backward != 0, a, dy, nrm, out, (long)rows, C, S(stream)));
   return GMF_OK;
 }
@@ -137,7 +137,7 @@ int gmf_normalize_rows(gmf_handle* h, int backward, const float* a, const float*
 int gmf_relu_backward(gmf_handle* h, const float* dy, const float* y, float* out, long long total, gmf_stream_t stream) {
   GMF_REQUIRE(h && dy && y && out, GMF_ERR_BAD_ARG, "relu_backward: null pointer");
   GMF_REQUIRE(total > 0, GMF_ERR_UNSUPPORTED_SHAPE, "relu_backward: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_relu_bwd(dy, y, out, (long)total, S(stream)));
   return GMF_OK;
 }
@@ -146,7 +146,7 @@ int gmf_classification_backward(gmf_handle* h, const float* pred, const float* g
                                 float* d_pred, gmf_stream_t stream) {
   GMF_REQUIRE(h && pred && gt && d_pred, GMF_ERR_BAD_ARG, "classification_backward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "classification_backward: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   if (int rc = arena_reserve(h, arena_need(1, 4))) return rc;
   float* pw = arena_take<float>(h, 1);
   GMF_HIP(gmf::launch_bce_bwd(pred, gt, weight, d_pred, pw, balanced, (long)B * N, S(stream)));
@@ -157,7 +157,7 @@ int gmf_spectral_matching_dense_backward(gmf_handle* h, const float* M, int ldm,
                                          float* dM, gmf_stream_t stream) {
   GMF_REQUIRE(h && M && gt_labels && dM, GMF_ERR_BAD_ARG, "spectral_matching_dense_backward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0 && ldm >= N, GMF_ERR_UNSUPPORTED_SHAPE, "spectral_matching_dense_backward: need ldm >= N > 0");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   if (int rc = arena_reserve(h, arena_need((size_t)4 * B, 4))) return rc;
   float* consts = arena_take<float>(h, (size_t)4 * B);
   GMF_HIP(gmf::launch_sm_dense_bwd(M, ldm, gt_labels, consts, dM, B, N, balanced, S(stream)));
@@ -169,7 +169,7 @@ int gmf_similarity_backward(gmf_handle* h, const float* feat_n, const float* dM,
   GMF_REQUIRE(h && feat_n && dM && d_feat_n && d_sigma, GMF_ERR_BAD_ARG, "similarity_backward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "similarity_backward: empty input");
   GMF_REQUIRE(sigma != 0.f, GMF_ERR_BAD_ARG, "similarity_backward: sigma must be non-zero");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   const size_t nn = (size_t)B * N * N, rows = (size_t)B * N;
   const size_t n_part = (size_t)gmf::colsum_chunks((long)rows);
   if (int rc = arena_reserve(h, 2 * arena_need(nn, 4) + arena_need(rows, 4) + arena_need(n_part, 4))) return rc;
@@ -193,7 +193,7 @@ int gmf_compat_dense(gmf_handle* h, const float* src_keypts, const float* tgt_ke
   GMF_REQUIRE(h && src_keypts && tgt_keypts && out, GMF_ERR_BAD_ARG, "compat_dense: null pointer");
   GMF_REQUIRE(B > 0 && N > 0 && N <= 65535 && B <= 65535, GMF_ERR_UNSUPPORTED_SHAPE, "compat_dense: need 0 < B, N <= 65535");
   GMF_REQUIRE(sigma_d > 0.f, GMF_ERR_BAD_ARG, "compat_dense: sigma_d must be positive");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_compat_dense(src_keypts, tgt_keypts, out, B, N, sigma_d, S(stream)));
   return GMF_OK;
 }
@@ -202,7 +202,7 @@ int gmf_transformation_loss_backward(gmf_handle* h, const float* trans, const fl
                                      const float* probs, int B, int N, float* d_trans, gmf_stream_t stream) {
   GMF_REQUIRE(h && trans && src_keypts && tgt_keypts && probs && d_trans, GMF_ERR_BAD_ARG, "transformation_loss_backward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "transformation_loss_backward: empty input");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_tl_backward(trans, src_keypts, tgt_keypts, probs, d_trans, B, N, S(stream)));
   return GMF_OK;
 }
@@ -218,7 +218,7 @@ int gmf_pose_head_backward(gmf_handle* h, const gmf_pose_params* p, const float*
   GMF_REQUIRE(iters > 0 && iters <= 64, GMF_ERR_BAD_ARG, "pose_head_backward: bad num_iterations");
   GMF_REQUIRE(p->refine_iters == 0, GMF_ERR_BAD_ARG, "pose_head_backward: the post-refinement (test mode) is not differentiable");
   GMF_REQUIRE(p->sigma > 0.f && p->sigma_d > 0.f, GMF_ERR_BAD_ARG, "pose_head_backward: sigma, sigma_d must be positive");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   hipStream_t st = S(stream);
   const size_t BS = (size_t)B * Sn;
   if (int rc = arena_reserve(h, arena_need(BS * iters * k, 4) + arena_need(BS * iters, 1) + arena_need(1, 4)))
@@ -239,7 +239,7 @@ int gmf_weighted_procrustes_backward(gmf_handle* h, const float* X, const float*
                                      float eps, const float* d_R, const float* d_t, float* d_w, gmf_stream_t stream) {
   GMF_REQUIRE(h && X && Y && w && offsets && d_R && d_t && d_w, GMF_ERR_BAD_ARG, "weighted_procrustes_backward: null pointer");
   GMF_REQUIRE(B > 0, GMF_ERR_UNSUPPORTED_SHAPE, "weighted_procrustes_backward: empty batch");
-  SetDevice sd(h);
+  SetDevice sd(h, stream);
   GMF_HIP(gmf::launch_wp_backward(X, Y, w, offsets, B, eps, d_R, d_t, d_w, S(stream)));
   return GMF_OK;
 }

@@ -16,7 +16,9 @@ struct CompatCache {
   const float* next_wst_h2 = nullptr;
   const float* next_bias = nullptr;
   bool half = false;          // `dense` holds fp16 tiles (2 KiB each) and the attention multiplies one fp16 product: the
-                              // throughput numerics mode (Tuning::precision = 1), large grids only
+                              // throughput numerics mode (Tuning::precision = 1), large grids only (then fmt = 1)
+  int fmt = 0;                // element format of `dense` (k_compat_build): 0 = fp32 (4 KiB per tile); 16-bit, 2 KiB per tile:
+                              // 1 = fp16 c (with `half`), 2 = fixed point rint(65535 c)
 };
 
 // Per-handle tuning knobs (gmf_set_tuning).  Every value selects between forms that compute the same result up to
@@ -40,12 +42,16 @@ struct Tuning {
   bool topk_select = true;   // radix select of the S seeds (false = full bitonic sort)
   int mid_grid_roles = 512;  // two-launch form on grids below this many base workgroups (>= 256): the linear kernel runs as two
                              // workgroup roles per row block (Q'/K/V | Fusion-2); 0 = never
+  int compat_format = 0;     // element format of the compat cache on the cached, pipelined path: 0 = fp32 (default); 2 = 16-bit fixed
+                             // point, rint(65535 c): half the attention's c stream and half the build, -4 % per step, absolute
+                             // error <= 7.6e-6 on c.  Measured: inside the parity contract on 3DMatch-shape
+                             // inputs, 4-8x the reference's own fp32 noise on KITTI-shape inputs - so it is opt-in, not the default
   int precision = 0;         // NOT rounding-equivalent: 0 = parity numerics (fp32-equivalent split-fp16 products, the default);
                              // 1 = throughput numerics: the spatial-consistency attention multiplies plain
                              // fp16 operands (one product, fp32 accumulation) and streams c as fp16 - outside the 1e-4 gate
 };
 
-hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, bool half, hipStream_t s);
+hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, int fmt, hipStream_t s);
 hipError_t launch_front(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
                         float* v, int B, int N, int tiles, hipStream_t s);
 hipError_t launch_scattn_fp32(const float* q, const float* k, const float* v, const float* pts8, const float* fus,
@@ -62,7 +68,7 @@ hipError_t launch_fusion_attn(bool pe, const float* x, const float* ctx_img, con
                               float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
 hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
 hipError_t launch_head(const float* feat_img, const float* wst, const float* vecs, float* logits, float* feat_n,
-                       float* feat_rm, int B, int N, int tiles, hipStream_t s);
+                       float* feat_rm, int B, int N, int tiles, hipStream_t s, int* status = nullptr);
 hipError_t launch_ctx_prep_w(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
                              int ttiles, hipStream_t s);
 hipError_t launch_fusion_attn_w(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
@@ -74,7 +80,7 @@ hipError_t launch_fusion_attn_w_h2(bool pe, const float* x, const float* ctx_img
                                    float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s, bool tile_form = true);
 hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const float* vecs, float* x2, int B, int tiles, hipStream_t s,
                                  float* part = nullptr, int hs = 1, float* out_rm = nullptr, long o_sb = 0, long o_sr = 0,
-                                 long o_sk = 0, int n_rows = 0);
+                                 long o_sk = 0, int n_rows = 0, int* status = nullptr);
 int plan_ff_split_w(int base_wgs);
 hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
                            float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s);
@@ -102,7 +108,7 @@ hipError_t launch_nn_match(const float* F0, const float* F1, float* f0_img, floa
                            float* dist, int N0, int N1, int d, int mode, hipStream_t s);
 hipError_t launch_seed_dist(const float* featn_img, const int* seeds, float* dist, int B, int N, int S, hipStream_t s);
 hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s);
-hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s);
+hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s, int* status = nullptr);
 hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s);
 
 // validation step (row f-4, forward half): validation_kernels.hip

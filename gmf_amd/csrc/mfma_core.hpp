@@ -105,6 +105,20 @@ GMF_DEVINL void mma3(f32x16& acc, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
   acc = mfma_h16(ah, bh, acc);
 }
 
+// Sticky status word of the handle (host-mapped, gmf_status_read): OR `bits` into it when any lane of the wave saw `bad`.
+// One system-scope atomic per wave and only in the failure case: the good path costs a vote.
+GMF_DEVINL void flag_status(int* status, bool bad, int bits) {
+  if (status && __any(bad)) {
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
+      __hip_atomic_fetch_or(status, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// ReLU that lets a NaN THROUGH (fmaxf / v_max_f32 return the other operand): an activation that left the fp16 range of the split
+// operands becomes (inf, -inf) planes and NaN in the next product; with fmaxf the next ReLU turned that NaN into 0 and the
+// overflow passed silently.  One compare + select instead of one max, in the epilogues only.
+GMF_DEVINL float relu_nan(float x) { return x < 0.f ? 0.f : x; }
+GMF_DEVINL bool not_finite(float v) { return !(__builtin_fabsf(v) <= 3.4028234e38f); }
+
 GMF_DEVINL f32x16 zero16() {
   f32x16 z;
 #pragma unroll

@@ -434,6 +434,7 @@ k_knn_seeds(const float* __restrict__ feat_n, const int* __restrict__ seeds, con
     if (threadIdx.x == 0) {
       float v = red_v[0]; int ix = red_i[0];
       for (int w = 1; w < 4; ++w) if (red_v[w] < v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
+      if (ix >= N) ix = min(it, N - 1);      // (a row of NaNs never wins a comparison: the index list must stay in range all the same)
       if (it > 0) knn_idx[((size_t)pair * S + s) * k + (it - 1)] = ix;
       dist[ix] = INFINITY;
     }
@@ -477,7 +478,7 @@ k_knn_select(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N
       const float ov = red_v[buf][w]; const int oi = red_i[buf][w];
       if (ov < wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
     }
-    if (it > 0 && tid == 0) knn_idx[((size_t)pair * S + s) * k + (it - 1)] = wi;
+    if (it > 0 && tid == 0) knn_idx[((size_t)pair * S + s) * k + (it - 1)] = (wi < N) ? wi : min(it, N - 1);   // (NaN rows: in range all the same)
     if ((wi & 255) == tid) {               // owner: drop the element, rescan the registers
       const int mm = wi >> 8;
       bv = INFINITY; bm = 0;
@@ -511,6 +512,9 @@ k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, 
   const int pair = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
   const float* dr = dist_in + ((size_t)pair * S + s) * N;
   int* out = knn_idx + ((size_t)pair * S + s) * k;
+  // a row with NaN distances yields fewer than k + 1 candidates: every slot holds an in-range index before the ranks are
+  // written (the barriers below order this store before theirs), so no consumer ever gathers through an uninitialised index
+  if (tid < k) out[tid] = min(tid + 1, N - 1);
   float v[EPT];
 #pragma unroll
   for (int m = 0; m < EPT; ++m) { const int j = tid + 256 * m; v[m] = (j < N) ? dr[j] : INFINITY; }
@@ -574,7 +578,7 @@ k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, 
       const float ov = red_v[buf][w]; const int oi = red_i[buf][w];
       if (ov < wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
     }
-    if (it > 0 && tid == 0) out[it - 1] = wi;
+    if (it > 0 && tid == 0) out[it - 1] = (wi < N) ? wi : min(it, N - 1);
     if ((wi & 255) == tid) {
       const int mm = wi >> 8;
       bv = INFINITY; bm = 0;

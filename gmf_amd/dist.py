@@ -7,7 +7,8 @@ reference has no counterpart - it is single-process, single-GPU (train_3DMatch.p
 
 Uneven shards (B % world != 0) are padded to the largest shard inside the packed buffer and trimmed after the
 gather, so the collective always sees equal sizes; the shard sizes come from `shard_range` (pure arithmetic, the
-same on every rank - no size exchange).
+same on every rank - no size exchange).  The packed row carries one status float behind the pose: a rank that fails
+before the collective still enters it and all ranks raise together (no rank is left waiting for a timeout).
 """
 from __future__ import annotations
 
@@ -57,6 +58,9 @@ class ShardedBatchDriver:
         self.last_model_ms: Optional[float] = None      # device time of the local forward (cuda) / wall time (cpu)
         self.last_gather_ms: Optional[float] = None     # ... of pack + all-gather + unpack
         self.time_steps = False                         # record the two figures above (adds event records, no host sync)
+        # read the gathered status column after every step (one small device-to-host read): a failure on another rank then
+        # raises here too instead of returning padding.  bench.py switches it off inside its timed loop and checks once after.
+        self.check_status = True
         self._events = None
         # a gloo group with the model on a HIP device (a multi-process rehearsal on one GPU): collectives go through the host
         self.stage_host = False
@@ -101,37 +105,70 @@ class ShardedBatchDriver:
     def _collective(self) -> bool:
         return (self.world > 1 or self.always_collective) and dist.is_initialized()
 
+    @staticmethod
+    def _rows_and_width(data) -> Tuple[int, int]:
+        """(pairs, correspondences per pair) of a batch dict, from its first [B, N, ...] tensor."""
+        t = next(v for v in data.values() if torch.is_tensor(v) and v.dim() >= 2)
+        return int(t.shape[0]), int(t.shape[1])
+
     def step(self, data, sizes: Optional[List[int]] = None) -> Dict[str, torch.Tensor]:
+        """One sharded step.  A failure on ONE rank must not leave the others blocked in the collective: with a process
+        group, a rank whose forward raises, or whose data disagrees with the shard plan, still enters the all-gather - with
+        an all-padding buffer and its status column set - and EVERY rank raises after it.  A rank whose shard is empty
+        (B < world: shard_sizes gives [1, 1, 1, 0]) skips the model and contributes padding only."""
         self._mark(0)
-        res = self.model(data)
-        logits = res["logits"] if "logits" in res else self.model.last_logits
-        trans = res["final_trans"]
-        out = {"logits": logits, "final_trans": trans, "final_labels": res.get("final_labels")}
-        self._mark(1)
-        if self._collective():
-            b, n = logits.shape
+        coll = self._collective()
+        b, n = self._rows_and_width(data)
+        err: Optional[BaseException] = None
+        res = None
+        if coll:
             if sizes is None:
                 sizes = [b] * self.world
             if len(sizes) != self.world or sizes[self.rank] != b:
-                raise RuntimeError(f"gmf_amd.dist: rank {self.rank} holds {b} pairs but the shard plan says {sizes}: every "
+                err = RuntimeError(f"gmf_amd.dist: rank {self.rank} holds {b} pairs but the shard plan says {sizes}: every "
                                    "rank must pass the same `sizes` (shard_sizes(B, world)), or equal shards without it")
-            bmax = max(sizes)
-            # one packed buffer per rank: [bmax, N + 16] = logits | pose, rows >= b are padding
-            buf = torch.zeros((bmax, n + 16), device=logits.device, dtype=logits.dtype) if bmax != b else \
-                torch.empty((bmax, n + 16), device=logits.device, dtype=logits.dtype)
-            buf[:b, :n] = logits
-            buf[:b, n:] = trans.reshape(b, 16)
+        if err is None and b > 0:
+            try:
+                res = self.model(data)
+            except Exception as e:               # noqa: BLE001 - re-raised below, on every rank, after the collective
+                if not coll:
+                    raise
+                err = e
+        if res is not None:
+            logits = res["logits"] if "logits" in res else self.model.last_logits
+            trans = res["final_trans"]
+            labels = res.get("final_labels")
+        else:                                    # empty shard, or a failed rank: padding only
+            logits = torch.zeros((0, n), device=self.device)
+            trans = torch.zeros((0, 4, 4), device=self.device)
+            labels = None
+        out = {"logits": logits, "final_trans": trans, "final_labels": labels}
+        self._mark(1)
+        if coll:
+            bl = logits.shape[0]
+            bmax = max(max(sizes), 1) if len(sizes) == self.world else max(b, 1)
+            # one packed buffer per rank: [bmax, N + 17] = logits | pose | status, rows >= bl are padding
+            buf = torch.zeros((bmax, n + 17), device=self.device, dtype=torch.float32)
+            if bl:
+                buf[:bl, :n] = logits
+                buf[:bl, n:n + 16] = trans.reshape(bl, 16)
+            if err is not None:
+                buf[:, n + 16] = 1.0
             if self.stage_host:
-                g_host = torch.empty((self.world * bmax, n + 16), dtype=logits.dtype)
+                g_host = torch.empty((self.world * bmax, n + 17), dtype=torch.float32)
                 dist.all_gather_into_tensor(g_host, buf.cpu())
-                gathered = g_host.to(logits.device)
+                gathered = g_host.to(self.device)
             else:
-                gathered = torch.empty((self.world * bmax, n + 16), device=logits.device, dtype=logits.dtype)
+                gathered = torch.empty((self.world * bmax, n + 17), device=self.device, dtype=torch.float32)
                 dist.all_gather_into_tensor(gathered, buf)       # the ONE exchange step of the batch
+            failed = [r for r in range(self.world) if float(gathered[r * bmax, n + 16]) != 0.0] if (err is not None or self.check_status) else []
+            if failed:
+                raise RuntimeError(f"gmf_amd.dist: the step failed on rank(s) {failed}; every rank leaves the collective and "
+                                   f"raises (rank {self.rank}: {err if err is not None else 'ok'})") from err
             if min(sizes) != bmax:
                 gathered = torch.cat([gathered[r * bmax:r * bmax + sizes[r]] for r in range(self.world)])
             out["all_logits"] = gathered[:, :n]
-            out["all_trans"] = gathered[:, n:].reshape(-1, 4, 4)
+            out["all_trans"] = gathered[:, n:n + 16].reshape(-1, 4, 4)
         else:
             out["all_logits"], out["all_trans"] = logits, trans
         self._mark(2)
@@ -162,6 +199,21 @@ class ShardedBatchDriver:
         allv = torch.empty(self.world, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(allv, t)
         return [float(v) for v in allv.cpu()]
+
+    def gather_objects(self, obj) -> list:
+        """One picklable object from every rank (diagnostics: which device each rank ran on)."""
+        if self.world == 1 or not dist.is_initialized():
+            return [obj]
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
+    def group_size(self) -> int:
+        """Ranks of the process group as the backend reports them (1 without a group)."""
+        return dist.get_world_size() if dist.is_initialized() else 1
+
+    def backend_name(self) -> str:
+        return str(dist.get_backend()) if dist.is_initialized() else "none"
 
     def close(self):
         if self.own_pg and dist.is_initialized():

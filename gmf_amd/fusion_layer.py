@@ -113,7 +113,7 @@ class FusionLayer(nn.Module):
         if Cq != blobs["latent_dim"]:
             raise RuntimeError(f"gmf_amd.FusionLayer: queries are {Cq} wide but the layer was built for {blobs['latent_dim']}")
         out = torch.empty((B, N, Cq), device=x.device, dtype=torch.float32)
-        h, st = handle_and_stream(x)
+        h, st = handle_and_stream(x, check=True)            # (raises if an earlier forward on this device produced NaN / inf)
         h.call("gmf_fusion_layer_forward", 1 if self.pe else 0, blobs["latent_dim"], blobs["d_head"],
                blobs["ctx_wst"].data_ptr(), blobs["ctx_vec"].data_ptr(), blobs["attn_wst"].data_ptr(),
                blobs["attn_vec"].data_ptr(), blobs["ff_wst"].data_ptr(), blobs["ff_vec"].data_ptr(),

@@ -414,7 +414,7 @@ class PointDSC(nn.Module):
         logits = torch.empty((B, N), device=dev)
         feat_n = torch.empty((B, N, 128), device=dev)
         feat = torch.empty((B, N, 128), device=dev) if want_features else None
-        h, st = handle_and_stream(corr_pos)
+        h, st = handle_and_stream(corr_pos, check=True)     # (raises if an earlier forward on this device produced NaN / inf)
         h.call("gmf_encoder_forward", pw.struct, corr_pos.data_ptr(), src.data_ptr(), tgt.data_ptr(),
                p_tokens.data_ptr(), q_tokens.data_ptr(), B, N, T, logits.data_ptr(), feat_n.data_ptr(),
                None if feat is None else feat.data_ptr(), st)

@@ -14,7 +14,10 @@
  *     void*; NULL = the default stream) and performs no host synchronisation;
  *   - return value: 0 = GMF_OK, negative = error (see enum); gmf_last_error_string(h) has details;
  *     no exception or abort ever crosses this boundary;
- *   - a handle is bound to one device and is not thread-safe; distinct handles are independent;
+ *   - a handle is bound to one device; distinct handles are independent.  Calls on ONE handle are serialised by an
+ *     internal lock and every call reuses the handle's workspace, so a handle serves one logical stream of work: a call on a
+ *     different stream than the previous call first waits (on the device) for the previous stream's work; the caller's
+ *     current device is restored on return;
  *   - all tensors are fp32.  "P32 image" / "T image" are the tiled layouts described in
  *     gmf_amd/csrc/mfma_core.hpp; gmf_pack_rows_p32 / gmf_unpack_rows_p32 convert from and to
  *     arbitrary strided [B, rows, K] views (row-major [B,N,C] or channel-major [B,C,N]).
@@ -35,10 +38,11 @@ enum {
   GMF_ERR_UNSUPPORTED_SHAPE = -2,
   GMF_ERR_HIP = -3,
   GMF_ERR_NO_DEVICE = -4,
-  GMF_ERR_OOM = -5
+  GMF_ERR_OOM = -5,
+  GMF_ERR_WORKSPACE = -6   /* the caller-provided workspace (gmf_set_workspace) is too small for this call */
 };
 
-#define GMF_ABI_VERSION 2
+#define GMF_ABI_VERSION 3
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 int gmf_abi_version(void);
@@ -46,8 +50,27 @@ int gmf_abi_version(void);
 int gmf_create(int device, gmf_handle** out);
 void gmf_destroy(gmf_handle* h);
 const char* gmf_last_error_string(gmf_handle* h);
-/* Bytes of library-owned device workspace currently held by the handle. */
+/* Bytes of device workspace currently held by the handle (library-owned or caller-provided). */
 long long gmf_workspace_bytes(gmf_handle* h);
+/* Workspace ownership.  By default the library owns ONE device block per handle (hipMalloc, grown with a device
+ * synchronisation when a larger shape arrives - never grow it inside a stream capture).  gmf_set_workspace hands the
+ * library a caller-owned device block instead (e.g. a torch tensor: the memory then belongs to the caller's allocator, and
+ * the library frees its own block); a call that needs more than `bytes` returns GMF_ERR_WORKSPACE without launching anything
+ * and gmf_workspace_wanted() returns the size that call asked for (with headroom): allocate, set, call again.
+ * gmf_set_workspace(h, NULL, 0) returns to the library-owned block.  The block must stay valid until the work of the last
+ * call that used it has completed on its stream.  (The reference has no counterpart: its intermediates are torch tensors.) */
+int gmf_set_workspace(gmf_handle* h, void* device_ptr, long long bytes);
+long long gmf_workspace_wanted(gmf_handle* h);
+
+/* Sticky status word of the handle, kept in host-mapped memory: kernels OR bits into it, the host reads it WITHOUT any
+ * device synchronisation (after the caller's own stream / device synchronisation it reflects every finished call).
+ *   GMF_STATUS_NONFINITE: an inlier logit, a feature norm (gmf_encoder_forward / gmf_classifier_forward) or an output
+ *   element of gmf_fusion_layer_forward was NaN or infinite.  The split-fp16 MFMA operands hold |x| < 65504 (weights are
+ *   checked when they are packed; activations cannot be): an activation beyond that range turns into inf / NaN and ends up
+ *   here instead of passing silently.  The reference (fp32 throughout) has no such limit.
+ * *flags receives the word; clear != 0 resets it. */
+#define GMF_STATUS_NONFINITE 1
+int gmf_status_read(gmf_handle* h, int* flags, int clear);
 
 /* Per-handle tuning knobs (state lives in the handle; no process globals, no environment variables).  Every setting
  * except "precision" computes the same result up to rounding - there is no timing-only or wrong-result mode in the
@@ -70,6 +93,12 @@ long long gmf_workspace_bytes(gmf_handle* h);
  *   "compat_cache"      : 1 = build the compat matrix once per batch (default), 0 = recompute c_ij in the attention kernel
  *                         (what the library does by itself when the cache would exceed 96 GB); 0 implies the
  *                         non-pipelined kernel.
+ *   "compat_format"     : element format of the compat cache on the pipelined path: 0 = fp32 (default); 2 = 16-bit fixed point
+ *                         rint(65535 c) - half the cache, half its stream, -4 % per step, |dc| <= 7.6e-6.  Opt-in: measured inside
+ *                         the 1e-4 gate on 3DMatch-shape inputs, but 4-8x the reference's own fp32 noise on KITTI-shape inputs
+ *                         (profiles/r03_compat_formats.txt).
+ *   "attn_tail_split"   : 1 = large grids: the last partial round of attention workgroups is split by keys, 0 = whole (default).
+ *   "small_grid_roles"  : 1 = small grids run three launches per layer with mixed workgroup roles (default), 0 = one per stage.
  *   "attn_key_splits"   : 0 = automatic (small grids only), 1 = off, 2..8 = forced number of key splits.
  *   "ff_hidden_splits"  : 0 = automatic (small grids only), 1 = off, 2 / 4 / 8 = forced.
  *   "front_output_split": 1 = small grids use one workgroup per output of the front kernel (default), 0 = never.

@@ -474,7 +474,34 @@ def gen_f21(reg):
     np.savez_compressed(os.path.join(GOLD, "f21_weighted_procrustes_backward.npz"), **out)
 
 
+def gen_f9b():
+    """F9b: the fpfh twin of the DGR bottleneck layer - GMF_DeepGlobalRegistration_fpfh/model/perceiver_io.py:112-200 has NO
+    `cpe` (no LCPE) and is instantiated at the same 256-wide bottleneck (…_fpfh/model/resunet_new.py:516-525: latent 256,
+    head 128).  Same seeded weights as F9 minus the cpe tensors; M = 100 / 515 voxels."""
+    spec = importlib.util.spec_from_file_location(
+        "dgr_perceiver_io_fpfh", os.path.join(REF, "GMF_DeepGlobalRegistration/GMF_DeepGlobalRegistration_fpfh/model/perceiver_io.py"))
+    pio = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pio)
+    shapes = O.fusion_layer_shapes("", 128, 256, 128, pe=False, out_to_query=True)
+    sd = O.seeded_state_dict(shapes, seed=119)
+    ref = pio.PerceiverIO(depth=0, dim=128, latent_dim=256, cross_heads=1, latent_heads=8,
+                          cross_dim_head=128, latent_dim_head=128).eval()
+    ref.load_state_dict(sd)
+    out = {}
+    for M, T in ((100, 12), (515, 300)):
+        r = np.random.default_rng([119, M, T])
+        x = torch.from_numpy(r.normal(0, 1, (1, M, 256)).astype(np.float32))
+        ctx = torch.from_numpy(r.normal(0, 1, (1, T, 128)).astype(np.float32))
+        with torch.no_grad():
+            out[f"out_M{M}_T{T}"] = _np(ref(ctx, queries_encoder=x))
+        print("F9b", M, T, "|out|max", float(np.abs(out[f"out_M{M}_T{T}"]).max()))
+    np.savez_compressed(os.path.join(GOLD, "f9b_dgr_perceiver_fpfh.npz"), seed=119, **out)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f9b":
+        gen_f9b()
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f20":
         gen_f20(_import_reference()[0])
         return

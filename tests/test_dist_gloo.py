@@ -75,10 +75,54 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-@pytest.mark.parametrize("B", [6, 5])
+def _failing_worker(rank, world, port, q):
+    """Rank 1's forward raises before the collective: rank 0 must not be left waiting in the all-gather - both ranks raise."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from gmf_amd.dist import ShardedBatchDriver
+
+    def model(data):
+        if rank == 1:
+            raise ValueError("boom on rank 1")
+        return _fake_model(data)
+
+    drv = ShardedBatchDriver(model, world, rank, torch.device("cpu"), backend="gloo")
+    msg = None
+    try:
+        drv.run(_global_batch(B=4))
+    except RuntimeError as e:
+        msg = str(e)
+    # the group is still usable afterwards (nobody is stuck inside a collective)
+    out = ShardedBatchDriver(_fake_model, world, rank, torch.device("cpu")).run(_global_batch(B=4))
+    q.put((rank, msg, out["all_logits"].clone()))
+    drv.close()
+
+
+def test_failure_on_one_rank_raises_on_every_rank():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _fake_model(_global_batch(B=4))
+    for rank, msg, logits in got:
+        assert msg is not None and "rank(s) [1]" in msg, msg
+        assert ("boom" in msg) == (rank == 1)
+        assert torch.equal(logits, ref["logits"])
+
+
+@pytest.mark.parametrize("B", [6, 5, 1])
 def test_two_rank_gloo_matches_single_process(B):
-    """6 pairs over 2 ranks (equal shards) and 5 pairs over 2 ranks (3 + 2: padded to the larger shard inside the packed
-    buffer and trimmed after the gather): every rank ends with the single-process result bit for bit, after exactly ONE
+    """6 pairs over 2 ranks (equal shards), 5 pairs over 2 ranks (3 + 2: padded to the larger shard inside the packed
+    buffer and trimmed after the gather) and ONE pair over 2 ranks (rank 1's shard is empty: it skips the model and
+    contributes padding only): every rank ends with the single-process result bit for bit, after exactly ONE
     collective per step."""
     world = 2
     port = _free_port()                  # (a fixed port can still be held by a previous run)
@@ -100,7 +144,9 @@ def test_two_rank_gloo_matches_single_process(B):
         assert per_rank == [10.0, 11.0]
         assert ms[0] is not None and ms[0] >= 0 and ms[1] >= 0
         if B % world != 0:
-            assert bad is not None and "shard plan" in bad
+            # every rank raises after the collective; the rank(s) whose data disagrees with the plan say why
+            assert bad is not None and "failed on rank(s)" in bad
+            assert ("shard plan" in bad) == (rank == 1 or B == 5)
 
 
 def test_shard_sizes_match_ranges():

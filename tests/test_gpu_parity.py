@@ -46,7 +46,7 @@ def model(sd_full):
 def test_native_library_loaded():
     from gmf_amd import _lib
     lib = _lib.load_library()
-    assert lib.gmf_abi_version() == 2
+    assert lib.gmf_abi_version() == 3
     assert _lib.handle_for(0).h
 
 
@@ -138,6 +138,120 @@ def test_f9_dgr_perceiver_256(golden_dir, M, T, h2_attn):
     finally:
         h.call("gmf_set_tuning", b"ff_hidden_splits", 0)
         h.call("gmf_set_tuning", b"wide_attn_tile", 1)
+
+
+@pytest.mark.parametrize("h2_attn", [True, False])
+@pytest.mark.parametrize("M,T", [(100, 12), (515, 300)])
+def test_f9b_dgr_perceiver_256_fpfh_twin(golden_dir, M, T, h2_attn):
+    """The fpfh twin of the DGR bottleneck layer: GMF_DeepGlobalRegistration_fpfh/model/perceiver_io.py:112-200 has no `cpe`
+    (no LCPE) and is built at the same widths (latent 256, head 128; ..._fpfh/model/resunet_new.py:516-525).  Golden F9b is
+    that module's own output; split-fp16 and fp32-MFMA forms."""
+    g = _load(golden_dir, "f9b_dgr_perceiver_fpfh.npz")
+    sd = synthetic.seeded_state_dict(synthetic.fusion_layer_shapes("", 128, 256, 128, pe=False, out_to_query=True), seed=int(g["seed"]))
+    m = gmf_amd.PerceiverIO(depth=0, dim=128, latent_dim=256, cross_heads=1, latent_heads=8, cross_dim_head=128,
+                            latent_dim_head=128)          # the fpfh constructor has no `pe` argument: the default is False
+    assert not any(k.startswith("cpe.") for k in m.state_dict())
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.split_fp16_attn = h2_attn
+    r = np.random.default_rng([119, M, T])
+    x = torch.from_numpy(r.normal(0, 1, (1, M, 256)).astype(np.float32))
+    ctx = torch.from_numpy(r.normal(0, 1, (1, T, 128)).astype(np.float32))
+    y = m(_gpu(ctx), queries_encoder=_gpu(x))
+    err = _maxerr(y.cpu(), g[f"out_M{M}_T{T}"])
+    print(f"F9b M={M} T={T} split_fp16_attn={h2_attn}: max err {err:.3e}")
+    assert err < 1e-4
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    try:
+        for hs in (1, 8):
+            h.call("gmf_set_tuning", b"ff_hidden_splits", hs)
+            assert _maxerr(m(_gpu(ctx), queries_encoder=_gpu(x)).cpu(), g[f"out_M{M}_T{T}"]) < 1e-4, hs
+        h.call("gmf_set_tuning", b"ff_hidden_splits", 0)
+        h.call("gmf_set_tuning", b"wide_attn_tile", 0)
+        assert _maxerr(m(_gpu(ctx), queries_encoder=_gpu(x)).cpu(), g[f"out_M{M}_T{T}"]) < 1e-4
+    finally:
+        h.call("gmf_set_tuning", b"ff_hidden_splits", 0)
+        h.call("gmf_set_tuning", b"wide_attn_tile", 1)
+
+
+def test_non_finite_results_set_the_status_word(model):
+    """Activations beyond the range of the split-fp16 MFMA operands (|x| < 65504) turn into inf / NaN.  The reference has no such
+    limit; here the overflow must not pass silently: the classifier kernel (and the last kernel of a FusionLayer) set a sticky
+    status bit in host-mapped memory, `gmf_amd.check_status()` raises after a synchronisation, and so does the NEXT forward."""
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    b = synthetic.synthetic_batch([5, 6], N=300, T=40)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    model(data)
+    gmf_amd.check_status()                                   # a normal forward leaves the word clear
+    assert h.status() == 0
+    bad = dict(data)
+    bad["corr_pos"] = data["corr_pos"] * 1e30                # layer0's output leaves the fp16 range by far
+    model(bad)
+    with pytest.raises(RuntimeError, match="non-finite"):
+        gmf_amd.check_status()
+    assert h.status() == 0                                   # reading it through the wrapper clears it
+    model(bad)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="non-finite"):    # ... and the next forward on the device reports it too
+        model(data)
+    res = model(data)                                        # the flag was cleared by the raise: the handle is usable again
+    gmf_amd.check_status()
+    assert torch.isfinite(res["final_trans"]).all()
+    # FusionLayer / PerceiverIO surface: NaN in the queries reaches the output and the word
+    m = gmf_amd.PerceiverIO(depth=0, dim=128, latent_dim=256, cross_heads=1, latent_heads=8, cross_dim_head=128,
+                            latent_dim_head=128, pe=True).to(DEV).eval()
+    x = torch.randn(1, 200, 256, device=DEV)
+    ctx = torch.randn(1, 50, 128, device=DEV)
+    m(ctx, queries_encoder=x)
+    gmf_amd.check_status()
+    x[0, 7, 3] = float("nan")
+    m(ctx, queries_encoder=x)
+    with pytest.raises(RuntimeError, match="non-finite"):
+        gmf_amd.check_status()
+
+
+def test_workspace_is_a_torch_tensor_and_the_device_is_restored(model):
+    """gmf_set_workspace: the Python host hands the library a torch tensor (the memory belongs to torch's allocator), grows it
+    when a call reports GMF_ERR_WORKSPACE, and results do not depend on who owns the block.  Every call leaves the caller's
+    current device as it found it."""
+    import ctypes as C
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    b = synthetic.synthetic_batch([11], N=500, T=40)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    r1 = model(data)
+    lg1 = model.last_logits.clone()
+    assert h._ws is not None and h.lib.gmf_workspace_bytes(h.h) == h._ws.numel()
+    # a too-small caller block: the raw call reports GMF_ERR_WORKSPACE and what it wants, and launches nothing
+    small = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    h.check(h.lib.gmf_set_workspace(h.h, small.data_ptr(), small.numel()), "gmf_set_workspace")
+    h._ws = small
+    assert h.lib.gmf_workspace_wanted(h.h) >= 0
+    r2 = model(data)                                         # Handle.call grows the tensor and repeats the call
+    assert h._ws.numel() > (1 << 20) and h.lib.gmf_workspace_bytes(h.h) == h._ws.numel()
+    assert torch.equal(model.last_logits, lg1) and torch.equal(r2["final_trans"], r1["final_trans"])
+    # library-owned block (what a host without an allocator of its own gets): same bits
+    h.check(h.lib.gmf_set_workspace(h.h, None, 0), "gmf_set_workspace")
+    h._ws, h.torch_workspace = None, False
+    try:
+        r3 = model(data)
+        assert h.lib.gmf_workspace_bytes(h.h) > 0
+        assert torch.equal(model.last_logits, lg1) and torch.equal(r3["final_trans"], r1["final_trans"])
+    finally:
+        h.torch_workspace = True
+    model(data)
+    assert h._ws is not None
+    # misuse is rejected
+    assert h.lib.gmf_set_workspace(h.h, C.c_void_p(h._ws.data_ptr() + 4), 1024) == -1      # not 256-byte aligned
+    assert h.lib.gmf_set_workspace(h.h, None, 1024) == -1
+    # the caller's current device survives a call (one visible device here: the call must at least not change it)
+    before = torch.cuda.current_device()
+    model(data)
+    assert torch.cuda.current_device() == before
 
 
 def test_f3_nonlocal_block(golden_dir, sd_full):

@@ -56,6 +56,18 @@ def test_f9_dgr_perceiver(golden_dir, M, T):
     _close(O.fusion_layer(sd, "", ctx, x, pe=True), g[f"out_M{M}_T{T}"])
 
 
+@pytest.mark.parametrize("M,T", [(100, 12), (515, 300)])
+def test_f9b_dgr_perceiver_fpfh(golden_dir, M, T):
+    """The fpfh twin (GMF_DeepGlobalRegistration_fpfh/model/perceiver_io.py:112-200: no cpe) at the 256 / 128 bottleneck."""
+    g = _load(golden_dir, "f9b_dgr_perceiver_fpfh.npz")
+    sd = O.seeded_state_dict(O.fusion_layer_shapes("", 128, 256, 128, pe=False, out_to_query=True), seed=int(g["seed"]))
+    assert not any(k.startswith("cpe.") for k in sd)
+    r = np.random.default_rng([119, M, T])
+    x = torch.from_numpy(r.normal(0, 1, (1, M, 256)).astype(np.float32))
+    ctx = torch.from_numpy(r.normal(0, 1, (1, T, 128)).astype(np.float32))
+    _close(O.fusion_layer(sd, "", ctx, x, pe=False), g[f"out_M{M}_T{T}"])
+
+
 @pytest.fixture(scope="module")
 def sd_full():
     return O.seeded_state_dict(O.pointdsc_shapes(6, 12, 128), seed=7)

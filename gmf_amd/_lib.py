@@ -41,6 +41,44 @@ class EncoderWeights(C.Structure):
     ]
 
 
+class Tensor(C.Structure):
+    """Mirror of `struct gmf_tensor` (include/gmf_hip.h): one named fp32 state_dict tensor."""
+    _fields_ = [("name", C.c_char_p), ("data", _vp), ("ndim", C.c_int), ("shape", _ll * 4)]
+
+
+class FusionWeights(C.Structure):
+    """Mirror of `struct gmf_fusion_weights` (include/gmf_hip.h)."""
+    _fields_ = [("latent_dim", C.c_int), ("d_head", C.c_int), ("pe", C.c_int), ("split_fp16", C.c_int),
+                ("max_abs_scaled", C.c_float),
+                ("ctx_wst", _vp), ("ctx_vec", _vp), ("attn_wst", _vp), ("attn_vec", _vp), ("ff_wst", _vp), ("ff_vec", _vp),
+                ("ctx_wst_h2", _vp), ("attn_wst_h2", _vp), ("ff_wst_h2", _vp)]
+
+
+GMF_PACK_DEVICE_TENSORS = 1
+GMF_PACK_STANDALONE_BLOCK = 2
+
+
+def tensor_list(sd):
+    """state_dict -> (ctypes array of gmf_tensor, keep-alive list).  Floating tensors only, as contiguous fp32 on the host."""
+    import torch
+    keep, items = [], []
+    for k, v in sd.items():
+        if not (torch.is_tensor(v) and v.is_floating_point()):
+            continue
+        t = v.detach().to("cpu", torch.float32).contiguous()
+        if t.dim() > 4:
+            continue
+        name = k.encode()
+        keep += [t, name]
+        e = Tensor()
+        e.name, e.data, e.ndim = name, t.data_ptr(), t.dim()
+        for d in range(4):
+            e.shape[d] = t.shape[d] if d < t.dim() else 1
+        items.append(e)
+    arr = (Tensor * len(items))(*items)
+    return arr, keep
+
+
 class PoseParams(C.Structure):
     """Mirror of `struct gmf_pose_params` (include/gmf_hip.h)."""
     _fields_ = [
@@ -74,6 +112,13 @@ SIGNATURES = {
     "gmf_fusion_attn_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "gmf_fusion_ff_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "gmf_classifier_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "gmf_encoder_pack_weights": (C.c_int, [_vp, C.POINTER(Tensor), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "gmf_packed_encoder_weights": (C.POINTER(EncoderWeights), [_vp]),
+    "gmf_packed_encoder_info": (C.c_int, [_vp, _f32p, _f32p, _i32p, _f32p]),
+    "gmf_packed_encoder_free": (None, [_vp]),
+    "gmf_fusion_pack_weights": (C.c_int, [_vp, C.POINTER(Tensor), C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "gmf_packed_fusion_weights": (C.POINTER(FusionWeights), [_vp]),
+    "gmf_packed_fusion_free": (None, [_vp]),
     "gmf_encoder_forward": (C.c_int, [_vp, C.POINTER(EncoderWeights), _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                       _vp, _vp, _vp, _vp]),
     "gmf_nonlocal_block_forward": (C.c_int, [_vp, C.POINTER(EncoderWeights), C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp,

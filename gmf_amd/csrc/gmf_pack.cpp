@@ -1,0 +1,535 @@
+// Weight packing behind the C ABI (include/gmf_hip.h: gmf_encoder_pack_weights, gmf_fusion_pack_weights): the reference's
+// state_dict tensors -> the blobs the kernels stream.  Host code: a few hundred small permutes over 4 M parameters, then ONE
+// upload.  A non-Python host needs nothing else to run gmf_encoder_forward / gmf_pose_head (tests/abi_cpp/abi_host.cpp).
+//
+// What is folded here (and nowhere else):
+//   * eval-mode BatchNorm into the preceding conv1x1 (PointDSC.py:104-109 PointCN, :13-21 fc_message);
+//   * the softmax scales 1/sqrt(C) (PointDSC.py:60) and 1/sqrt(d_head) (fusion_layer.py:76,88) times log2(e) into the Q
+//     projections, so the kernels use exp2 directly;
+//   * every dense weight [out, in] as its P32 image (mfma_core.hpp) - fp32, and as split-fp16 planes of 256 W (enc_common.hpp,
+//     kH2Inv); the GEGLU W1 planes stay unscaled.
+// Blob layouts: the table at the top of gmf_amd/packing.py (the Python twin of this file, kept for the standalone modules and
+// as the bit-for-bit cross-check of tests/test_abi_host.py).
+#include "../../include/gmf_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "api_common.hpp"
+
+#pragma clang fp contract(off)      // the folds below are separate multiplies and adds, as torch evaluates them
+
+namespace {
+
+constexpr int kCw = 128;            // correspondence / context feature width
+constexpr double kLog2e = 1.4426950408889634;
+constexpr float kFp16Max = 65504.0f;
+
+struct Mat {                        // dense row-major [M, K]
+  int M = 0, K = 0;
+  std::vector<float> v;
+  Mat() = default;
+  Mat(int m, int k) : M(m), K(k), v((size_t)m * k, 0.f) {}
+  float& at(int r, int c) { return v[(size_t)r * K + c]; }
+  float at(int r, int c) const { return v[(size_t)r * K + c]; }
+};
+
+struct Tensor { const float* data; int ndim; long long shape[4]; long long numel; };
+
+struct StateDict {
+  std::map<std::string, Tensor> t;
+  std::vector<std::vector<float>> staged;     // device tensors copied to the host
+  bool has(const std::string& k) const { return t.count(k) != 0; }
+};
+
+struct PackError { int code; std::string msg; };
+
+const Tensor& need(const StateDict& sd, const std::string& k) {
+  auto it = sd.t.find(k);
+  if (it == sd.t.end()) throw PackError{GMF_ERR_BAD_ARG, "gmf: pack: tensor `" + k + "` is missing from the state dict"};
+  return it->second;
+}
+
+// conv1x1 / Linear weight [out, in(, 1)] as a matrix
+Mat mat_of(const StateDict& sd, const std::string& k, int want_out = -1, int want_in = -1) {
+  const Tensor& t = need(sd, k);
+  const bool ok = (t.ndim == 2) || (t.ndim == 3 && t.shape[2] == 1);
+  if (!ok) throw PackError{GMF_ERR_UNSUPPORTED_SHAPE, "gmf: pack: `" + k + "` must be [out, in] or [out, in, 1]"};
+  Mat m((int)t.shape[0], (int)t.shape[1]);
+  if ((want_out >= 0 && m.M != want_out) || (want_in >= 0 && m.K != want_in))
+    throw PackError{GMF_ERR_UNSUPPORTED_SHAPE, "gmf: pack: `" + k + "` has shape [" + std::to_string(m.M) + ", " + std::to_string(m.K) +
+                                                  "], expected [" + std::to_string(want_out) + ", " + std::to_string(want_in) + "]"};
+  std::memcpy(m.v.data(), t.data, m.v.size() * sizeof(float));
+  return m;
+}
+
+std::vector<float> vec_of(const StateDict& sd, const std::string& k, long long want = -1) {
+  const Tensor& t = need(sd, k);
+  if (want >= 0 && t.numel != want)
+    throw PackError{GMF_ERR_UNSUPPORTED_SHAPE, "gmf: pack: `" + k + "` has " + std::to_string(t.numel) + " elements, expected " + std::to_string(want)};
+  return std::vector<float>(t.data, t.data + t.numel);
+}
+
+void append(std::vector<float>& dst, const std::vector<float>& src) { dst.insert(dst.end(), src.begin(), src.end()); }
+void append_zeros(std::vector<float>& dst, size_t n) { dst.insert(dst.end(), n, 0.f); }
+
+Mat rows(const Mat& W, int r0, int n) {
+  Mat o(n, W.K);
+  std::memcpy(o.v.data(), W.v.data() + (size_t)r0 * W.K, o.v.size() * sizeof(float));
+  return o;
+}
+Mat cols(const Mat& W, int c0, int n) {
+  Mat o(W.M, n);
+  for (int r = 0; r < W.M; ++r) std::memcpy(&o.at(r, 0), &W.v[(size_t)r * W.K + c0], n * sizeof(float));
+  return o;
+}
+Mat scaled(const Mat& W, float s) {
+  Mat o = W;
+  for (float& x : o.v) x = x * s;
+  return o;
+}
+
+// ---- images -------------------------------------------------------------------------------------------------------------
+// P32 image of W [M, K]: float index ((mb * K/8 + g) * 64 + lane) * 4 + e = W[32 mb + i][8 g + 4 h + e], lane = (h, i)
+void p32(std::vector<float>& out, const Mat& W) {
+  if (W.M % 32 || W.K % 8) throw PackError{GMF_ERR_UNSUPPORTED_SHAPE, "gmf: pack: P32 image needs M % 32 == 0 and K % 8 == 0"};
+  const size_t base = out.size();
+  out.resize(base + W.v.size());
+  float* o = out.data() + base;
+  for (int mb = 0; mb < W.M / 32; ++mb)
+    for (int g = 0; g < W.K / 8; ++g)
+      for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 32; ++i)
+          for (int e = 0; e < 4; ++e) *o++ = W.at(32 * mb + i, 8 * g + 4 * h + e);
+}
+
+// split-fp16 image of W [M, K] (K % 16 == 0): per 32-output block [plane hi | lo][k-step S][lane = (h, i)][8 fp16], the k-step's
+// elements in fragment order f = 8 S + j -> feature 32 (f >> 4) + 8 ((f & 15) >> 2) + 4 h + (f & 3); W ~ hi + lo, both RNE.
+// Returns false (nothing appended) when a value lies outside the fp16 range.
+bool p32_h2(std::vector<float>& out, const Mat& W, float scale, float* amax_out) {
+  if (W.M % 32 || W.K % 16) throw PackError{GMF_ERR_UNSUPPORTED_SHAPE, "gmf: pack: split-fp16 image needs M % 32 == 0 and K % 16 == 0"};
+  float amax = 0.f;
+  bool finite = true;
+  for (float x : W.v) {
+    const float a = std::fabs(x * scale);
+    if (!(a <= kFp16Max)) finite = false;
+    if (a > amax) amax = a;
+  }
+  if (amax_out && (amax > *amax_out || !finite)) *amax_out = finite ? amax : INFINITY;
+  if (!finite) return false;
+  const int S = W.K / 16;
+  const size_t base = out.size();
+  out.resize(base + W.v.size());                      // 2 planes x 2 bytes = 4 bytes per element
+  uint16_t* o = reinterpret_cast<uint16_t*>(out.data() + base);
+  for (int mb = 0; mb < W.M / 32; ++mb)
+    for (int plane = 0; plane < 2; ++plane)
+      for (int s = 0; s < S; ++s)
+        for (int h = 0; h < 2; ++h)
+          for (int i = 0; i < 32; ++i)
+            for (int j = 0; j < 8; ++j) {
+              const int f = 8 * s + j;
+              const int col = 32 * (f >> 4) + 8 * ((f & 15) >> 2) + 4 * h + (f & 3);
+              const float w = W.at(32 * mb + i, col) * scale;
+              const _Float16 hi = (_Float16)w;
+              const _Float16 val = plane == 0 ? hi : (_Float16)(w - (float)hi);
+              uint16_t bits;
+              std::memcpy(&bits, &val, 2);
+              *o++ = bits;
+            }
+  return true;
+}
+
+enum class Img { F32, H2S };        // fp32 P32 images | split-fp16 images of 256 W (W1 of the GEGLU: unscaled)
+
+struct Ctx {
+  bool ok = true;                   // false: some weight left the fp16 range (split images are then dropped)
+  float amax = 0.f;
+  void img(std::vector<float>& out, const Mat& W, Img kind, bool unscaled_w1 = false) {
+    if (kind == Img::F32) { p32(out, W); return; }
+    if (!p32_h2(out, W, unscaled_w1 ? 1.0f : 256.0f, &amax)) { ok = false; append_zeros(out, W.v.size()); }
+  }
+};
+
+// conv1x1 (W, b) followed by eval BatchNorm `p`  ->  (W', b')      (packing.fold_bn)
+void fold_bn(Mat& W, std::vector<float>& b, const StateDict& sd, const std::string& p) {
+  const std::vector<float> g = vec_of(sd, p + "weight", W.M), beta = vec_of(sd, p + "bias", W.M);
+  const std::vector<float> mean = vec_of(sd, p + "running_mean", W.M), var = vec_of(sd, p + "running_var", W.M);
+  for (int r = 0; r < W.M; ++r) {
+    const float scale = g[r] * (1.0f / std::sqrt(var[r] + 1e-5f));
+    for (int c = 0; c < W.K; ++c) W.at(r, c) = W.at(r, c) * scale;
+    b[r] = (b[r] - mean[r]) * scale + beta[r];
+  }
+}
+
+// depthwise Conv1d taps [C, 1, 3] + bias [C]  ->  w0[C] | w1[C] | w2[C] | b[C]
+void taps(std::vector<float>& out, const StateDict& sd, const std::string& wname, const std::string& bname, int Cn) {
+  const Tensor& w = need(sd, wname);
+  if (w.numel != 3LL * Cn) throw PackError{GMF_ERR_UNSUPPORTED_SHAPE, "gmf: pack: `" + wname + "` must be [" + std::to_string(Cn) + ", 1, 3]"};
+  const std::vector<float> b = vec_of(sd, bname, Cn);
+  for (int k = 0; k < 3; ++k)
+    for (int c = 0; c < Cn; ++c) out.push_back(w.data[3 * c + k]);
+  append(out, b);
+}
+
+struct FusionBlobs {
+  int lat = 0, dh = 0;
+  std::vector<float> ctx_wst, ctx_vec, attn_wst, attn_vec, ff_wst, ff_vec;
+};
+
+// One FusionLayer / PerceiverIO with depth = 0 (fusion_layer.py:131-201, perceiver_io.py:139-221)   (packing.pack_fusion)
+FusionBlobs pack_fusion(const StateDict& sd, const std::string& prefix, bool pe, Img kind, Ctx& cx) {
+  FusionBlobs o;
+  const std::string a = prefix + "cross_attend_blocks.0.", f = prefix + "cross_attend_blocks.1.";
+  Mat wq = mat_of(sd, a + "fn.to_q.weight");
+  o.dh = wq.M; o.lat = wq.K;
+  const bool known = (o.lat == 128 && o.dh == 64) || (o.lat == 256 && o.dh == 128);
+  if (!known)
+    throw PackError{GMF_ERR_UNSUPPORTED_SHAPE, "gmf: pack: HIP fusion kernels exist for (latent_dim, d_head) = (128, 64) and (256, 128); got (" +
+                                                  std::to_string(o.lat) + ", " + std::to_string(o.dh) + ")"};
+  const Mat wkv = mat_of(sd, a + "fn.to_kv.weight", 2 * o.dh, kCw);
+  const Mat wo = mat_of(sd, a + "fn.to_out.weight", o.lat, o.dh);
+  cx.img(o.ctx_wst, rows(wkv, 0, o.dh), kind);
+  cx.img(o.ctx_wst, rows(wkv, o.dh, o.dh), kind);
+  if (pe) taps(o.ctx_vec, sd, prefix + "cpe.proj_content.weight", prefix + "cpe.proj_content.bias", kCw);
+  else append_zeros(o.ctx_vec, 4 * kCw);
+  append(o.ctx_vec, vec_of(sd, a + "norm_context.weight", kCw));
+  append(o.ctx_vec, vec_of(sd, a + "norm_context.bias", kCw));
+  cx.img(o.attn_wst, scaled(wq, (float)(std::pow((double)o.dh, -0.5) * kLog2e)), kind);
+  cx.img(o.attn_wst, wo, kind);
+  if (pe) taps(o.attn_vec, sd, prefix + "cpe.proj_q.weight", prefix + "cpe.proj_q.bias", o.lat);
+  else append_zeros(o.attn_vec, 4 * (size_t)o.lat);
+  append(o.attn_vec, vec_of(sd, a + "norm.weight", o.lat));
+  append(o.attn_vec, vec_of(sd, a + "norm.bias", o.lat));
+  append(o.attn_vec, vec_of(sd, a + "fn.to_out.bias", o.lat));
+  const int hid = 4 * o.lat;
+  const Mat W1 = mat_of(sd, f + "fn.net.0.weight", 2 * hid, o.lat), W2 = mat_of(sd, f + "fn.net.2.weight", o.lat, hid);
+  const std::vector<float> b1 = vec_of(sd, f + "fn.net.0.bias", 2 * hid), b2 = vec_of(sd, f + "fn.net.2.bias", o.lat);
+  for (int c = 0; c < hid / 32; ++c) {
+    cx.img(o.ff_wst, rows(W1, 32 * c, 32), kind, true);
+    cx.img(o.ff_wst, rows(W1, hid + 32 * c, 32), kind, true);
+    cx.img(o.ff_wst, cols(W2, 32 * c, 32), kind);
+  }
+  append(o.ff_vec, vec_of(sd, f + "norm.weight", o.lat));
+  append(o.ff_vec, vec_of(sd, f + "norm.bias", o.lat));
+  append(o.ff_vec, b1);                                   // value half | gate half
+  append(o.ff_vec, b2);
+  return o;
+}
+
+// PointCN_layer_i (BatchNorm folded) + projection_{q,k,v} (+ layer0)   (PointDSC.py:88,104-109,23-25; packing.pack_front)
+void pack_front(const StateDict& sd, int layer, bool with_layer0, bool identity_pointcn, Img kind, Ctx& cx, std::vector<float>& wst,
+                std::vector<float>* vec) {
+  const std::string n = "encoder.blocks.NonLocal_layer_" + std::to_string(layer) + ".";
+  const std::string pc = "encoder.blocks.PointCN_layer_" + std::to_string(layer) + ".";
+  Mat Wp(kCw, kCw);
+  std::vector<float> bp(kCw, 0.f);
+  if (identity_pointcn) {
+    for (int i = 0; i < kCw; ++i) Wp.at(i, i) = 1.f;
+  } else {
+    Wp = mat_of(sd, pc + "0.weight", kCw, kCw);
+    bp = vec_of(sd, pc + "0.bias", kCw);
+    fold_bn(Wp, bp, sd, pc + "1.");
+  }
+  const float cq = (float)(kLog2e / std::sqrt((double)kCw));
+  Mat Wq = scaled(mat_of(sd, n + "projection_q.weight", kCw, kCw), cq);
+  std::vector<float> bq = vec_of(sd, n + "projection_q.bias", kCw);
+  for (float& x : bq) x = x * cq;
+  const Mat Wk = mat_of(sd, n + "projection_k.weight", kCw, kCw), Wv = mat_of(sd, n + "projection_v.weight", kCw, kCw);
+  cx.img(wst, Wp, kind);
+  cx.img(wst, Wq, kind);
+  cx.img(wst, Wk, kind);
+  cx.img(wst, Wv, kind);
+  if (!vec) return;
+  append(*vec, bp);
+  append(*vec, bq);
+  append(*vec, vec_of(sd, n + "projection_k.bias", kCw));
+  append(*vec, vec_of(sd, n + "projection_v.bias", kCw));
+  if (with_layer0) {
+    const Mat W0 = mat_of(sd, "encoder.layer0.weight", kCw);
+    if (W0.K > 8) throw PackError{GMF_ERR_UNSUPPORTED_SHAPE, "gmf: pack: in_dim > 8 is not supported by the layer0 MFMA prologue"};
+    Mat W0p(kCw, 8);
+    for (int r = 0; r < kCw; ++r)
+      for (int c = 0; c < W0.K; ++c) W0p.at(r, c) = W0.at(r, c);
+    append(*vec, vec_of(sd, "encoder.layer0.bias", kCw));
+    p32(*vec, W0p);
+  } else {
+    append_zeros(*vec, kCw + 1024);
+  }
+}
+
+// fc_message with both BatchNorms folded (PointDSC.py:13-21)   (packing.pack_tail)
+void pack_tail(const StateDict& sd, int layer, Img kind, Ctx& cx, std::vector<float>& wst, std::vector<float>* vec) {
+  const std::string p = "encoder.blocks.NonLocal_layer_" + std::to_string(layer) + ".fc_message.";
+  Mat Wa = mat_of(sd, p + "0.weight", 64, kCw), Wb = mat_of(sd, p + "3.weight", 64, 64);
+  const Mat Wc = mat_of(sd, p + "6.weight", kCw, 64);
+  std::vector<float> ba = vec_of(sd, p + "0.bias", 64), bb = vec_of(sd, p + "3.bias", 64);
+  fold_bn(Wa, ba, sd, p + "1.");
+  fold_bn(Wb, bb, sd, p + "4.");
+  cx.img(wst, Wa, kind);
+  cx.img(wst, Wb, kind);
+  cx.img(wst, Wc, kind);
+  if (!vec) return;
+  append(*vec, ba);
+  append(*vec, bb);
+  append(*vec, vec_of(sd, p + "6.bias", kCw));
+}
+
+// classification head (PointDSC.py:175-181)   (packing.pack_head)
+void pack_head(const StateDict& sd, std::vector<float>& wst, std::vector<float>& vec) {
+  p32(wst, mat_of(sd, "classification.0.weight", 32, kCw));
+  p32(wst, mat_of(sd, "classification.2.weight", 32, 32));
+  append_zeros(wst, 8192 - 4096 - 1024);
+  append(vec, vec_of(sd, "classification.0.bias", 32));
+  append(vec, vec_of(sd, "classification.2.bias", 32));
+  append(vec, vec_of(sd, "classification.4.weight", 32));
+  append(vec, vec_of(sd, "classification.4.bias", 1));
+  append_zeros(vec, 128 - 97);
+}
+
+// state dict from the caller's tensor list; device tensors are staged to the host first
+int read_state(gmf_handle* h, const gmf_tensor* ts, int n, int on_device, StateDict& sd, std::string& err) {
+  for (int i = 0; i < n; ++i) {
+    const gmf_tensor& t = ts[i];
+    if (!t.name || !t.data || t.ndim < 0 || t.ndim > 4) { err = "gmf: pack: tensor " + std::to_string(i) + " has no name / data or a bad rank"; return GMF_ERR_BAD_ARG; }
+    Tensor e{t.data, t.ndim, {1, 1, 1, 1}, 1};
+    for (int d = 0; d < t.ndim; ++d) {
+      if (t.shape[d] < 0) { err = std::string("gmf: pack: negative extent in `") + t.name + "`"; return GMF_ERR_BAD_ARG; }
+      e.shape[d] = t.shape[d];
+      e.numel *= t.shape[d];
+    }
+    if (on_device) {
+      if (!h) { err = "gmf: pack: device tensors need a handle"; return GMF_ERR_BAD_ARG; }
+      sd.staged.emplace_back((size_t)e.numel);
+      hipError_t rc = hipMemcpy(sd.staged.back().data(), t.data, (size_t)e.numel * sizeof(float), hipMemcpyDeviceToHost);
+      if (rc != hipSuccess) { err = std::string("gmf: pack: hipMemcpy(`") + t.name + "`): " + hipGetErrorString(rc); return GMF_ERR_HIP; }
+      e.data = sd.staged.back().data();
+    }
+    sd.t[t.name] = e;
+  }
+  return GMF_OK;
+}
+
+// all blobs in ONE block (host, then device): offsets in floats, 64-float aligned
+struct Block {
+  std::vector<float> host;
+  size_t add(const std::vector<float>& v) {
+    const size_t off = (host.size() + 63) / 64 * 64;
+    host.resize(off);
+    host.insert(host.end(), v.begin(), v.end());
+    return off;
+  }
+};
+
+}  // namespace
+
+struct gmf_packed_encoder {
+  gmf_encoder_weights w{};
+  float sigma = 1.0f;
+  int split_fp16 = 0;
+  float amax = 0.f;                 // largest |value| seen while splitting (inf: a weight was not finite)
+  float* device_block = nullptr;    // library-owned device copy (nullptr: the blobs live in host_block)
+  int device = -1;
+  std::vector<float> host_block;
+};
+
+struct gmf_packed_fusion {
+  gmf_fusion_weights w{};
+  float* device_block = nullptr;
+  int device = -1;
+  std::vector<float> host_block;
+};
+
+namespace {
+
+// moves `blk` to the device of `h` (or keeps it on the host when h is null) and returns the base pointer the offsets refer to
+int place(gmf_handle* h, Block& blk, std::vector<float>& host_keep, float** device_block, int* device, const float** base, std::string& err) {
+  if (!h) {
+    host_keep.swap(blk.host);
+    *base = host_keep.data();
+    return GMF_OK;
+  }
+  SetDevice sd(h);
+  void* d = nullptr;
+  hipError_t rc = hipMalloc(&d, blk.host.size() * sizeof(float));
+  if (rc != hipSuccess) { err = std::string("gmf: pack: hipMalloc: ") + hipGetErrorString(rc); return GMF_ERR_OOM; }
+  rc = hipMemcpy(d, blk.host.data(), blk.host.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (rc != hipSuccess) { (void)hipFree(d); err = std::string("gmf: pack: hipMemcpy: ") + hipGetErrorString(rc); return GMF_ERR_HIP; }
+  *device_block = static_cast<float*>(d);
+  *device = h->device;
+  *base = *device_block;
+  return GMF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gmf_encoder_pack_weights(gmf_handle* h, const gmf_tensor* tensors, int n_tensors, int num_layers, int flags,
+                             gmf_packed_encoder** out) {
+  if (!out) return GMF_ERR_BAD_ARG;
+  *out = nullptr;
+  std::string err;
+  auto bail = [&](int code, const std::string& m) { if (h) h->err = m; return code; };
+  if (!tensors || n_tensors <= 0 || num_layers < 0 || num_layers > 64) return bail(GMF_ERR_BAD_ARG, "gmf: encoder_pack_weights: bad arguments");
+  const bool on_device = (flags & GMF_PACK_DEVICE_TENSORS) != 0, standalone = (flags & GMF_PACK_STANDALONE_BLOCK) != 0;
+  gmf_packed_encoder* p = new (std::nothrow) gmf_packed_encoder();
+  if (!p) return GMF_ERR_OOM;
+  try {
+    StateDict sd;
+    if (int rc = read_state(h, tensors, n_tensors, on_device, sd, err)) { delete p; return bail(rc, err); }
+    const int L = num_layers;
+    const bool has_f1 = sd.has("encoder.fusion_layer_1.cross_attend_blocks.0.fn.to_q.weight");
+    const bool has_l0 = sd.has("encoder.layer0.weight");
+    const bool has_head = sd.has("classification.0.weight");
+    Block blk;
+    struct Off { size_t v = 0; bool set = false; };
+    auto put = [&](Off& o, const std::vector<float>& v) { o.v = blk.add(v); o.set = true; };
+    Off f1[6], f1h[3], ctx[2], attn[2], ff[2], front[2], tail[2], head[2], ctxh, attnh, ffh, fronth, tailh;
+    Ctx c32, ch2;
+    if (has_f1) {
+      FusionBlobs b = pack_fusion(sd, "encoder.fusion_layer_1.", false, Img::F32, c32);
+      if (b.lat != 128) throw PackError{GMF_ERR_UNSUPPORTED_SHAPE, "gmf: pack: fusion_layer_1 must be 128 wide"};
+      put(f1[0], b.ctx_wst); put(f1[1], b.ctx_vec); put(f1[2], b.attn_wst); put(f1[3], b.attn_vec); put(f1[4], b.ff_wst); put(f1[5], b.ff_vec);
+      FusionBlobs bh = pack_fusion(sd, "encoder.fusion_layer_1.", false, Img::H2S, ch2);
+      put(f1h[0], bh.ctx_wst); put(f1h[1], bh.attn_wst); put(f1h[2], bh.ff_wst);
+    }
+    if (L > 0) {
+      std::vector<float> cw, cv, aw, av, fw, fv, cwh, awh, fwh, frw, frv, frwh, tw, tv, twh;
+      for (int l = 0; l < L; ++l) {
+        const std::string pre = "encoder.blocks.NonLocal_layer_" + std::to_string(l) + ".fusion_layer_2.";
+        FusionBlobs b = pack_fusion(sd, pre, true, Img::F32, c32);
+        if (b.lat != 128) throw PackError{GMF_ERR_UNSUPPORTED_SHAPE, "gmf: pack: fusion_layer_2 must be 128 wide"};
+        append(cw, b.ctx_wst); append(cv, b.ctx_vec); append(aw, b.attn_wst); append(av, b.attn_vec); append(fw, b.ff_wst); append(fv, b.ff_vec);
+        FusionBlobs bh = pack_fusion(sd, pre, true, Img::H2S, ch2);
+        append(cwh, bh.ctx_wst); append(awh, bh.attn_wst); append(fwh, bh.ff_wst);
+        pack_front(sd, l, l == 0 && has_l0, standalone, Img::F32, c32, frw, &frv);
+        pack_front(sd, l, l == 0 && has_l0, standalone, Img::H2S, ch2, frwh, nullptr);
+        pack_tail(sd, l, Img::F32, c32, tw, &tv);
+        pack_tail(sd, l, Img::H2S, ch2, twh, nullptr);
+      }
+      put(ctx[0], cw); put(ctx[1], cv); put(attn[0], aw); put(attn[1], av); put(ff[0], fw); put(ff[1], fv);
+      put(front[0], frw); put(front[1], frv); put(tail[0], tw); put(tail[1], tv);
+      put(ctxh, cwh); put(attnh, awh); put(ffh, fwh); put(fronth, frwh); put(tailh, twh);
+    }
+    if (has_head) {
+      std::vector<float> hw, hv;
+      pack_head(sd, hw, hv);
+      put(head[0], hw); put(head[1], hv);
+    }
+    p->split_fp16 = ch2.ok ? 1 : 0;
+    p->amax = ch2.amax;
+    p->sigma = sd.has("sigma") ? need(sd, "sigma").data[0] : 1.0f;
+    const float sigma_d = sd.has("sigma_spat") ? need(sd, "sigma_spat").data[0] : 0.1f;
+    const float* base = nullptr;
+    if (int rc = place(h, blk, p->host_block, &p->device_block, &p->device, &base, err)) { delete p; return bail(rc, err); }
+    auto at = [&](const Off& o) -> const float* { return o.set ? base + o.v : nullptr; };
+    gmf_encoder_weights& w = p->w;
+    w.num_layers = L;
+    w.f1_ctx_wst = at(f1[0]); w.f1_ctx_vec = at(f1[1]); w.f1_attn_wst = at(f1[2]); w.f1_attn_vec = at(f1[3]);
+    w.f1_ff_wst = at(f1[4]); w.f1_ff_vec = at(f1[5]);
+    w.ctx_wst = at(ctx[0]); w.ctx_vec = at(ctx[1]); w.ctx_wst_stride = 16384; w.ctx_vec_stride = 768;
+    w.attn_wst = at(attn[0]); w.attn_vec = at(attn[1]); w.attn_wst_stride = 16384; w.attn_vec_stride = 896;
+    w.ff_wst = at(ff[0]); w.ff_vec = at(ff[1]); w.ff_wst_stride = 196608; w.ff_vec_stride = 1408;
+    w.front_wst = at(front[0]); w.front_vec = at(front[1]); w.front_wst_stride = 65536; w.front_vec_stride = 1664;
+    w.tail_wst = at(tail[0]); w.tail_vec = at(tail[1]); w.tail_wst_stride = 20480; w.tail_vec_stride = 256;
+    w.head_wst = at(head[0]); w.head_vec = at(head[1]);
+    w.sigma_d = sigma_d;
+    if (ch2.ok) {            // a weight outside the fp16 range: no split images, every stage on the fp32 MFMA (gmf_packed_encoder_info says so)
+      w.front_wst_h2 = at(fronth); w.ctx_wst_h2 = at(ctxh); w.attn_wst_h2 = at(attnh); w.ff_wst_h2 = at(ffh);
+      w.f1_ctx_wst_h2 = at(f1h[0]); w.f1_attn_wst_h2 = at(f1h[1]); w.f1_ff_wst_h2 = at(f1h[2]);
+      w.tail_wst_h2 = at(tailh);
+    }
+  } catch (const PackError& e) {
+    delete p;
+    return bail(e.code, e.msg);
+  } catch (const std::bad_alloc&) {
+    delete p;
+    return bail(GMF_ERR_OOM, "gmf: pack: out of host memory");
+  }
+  *out = p;
+  return GMF_OK;
+}
+
+const gmf_encoder_weights* gmf_packed_encoder_weights(const gmf_packed_encoder* p) { return p ? &p->w : nullptr; }
+
+int gmf_packed_encoder_info(const gmf_packed_encoder* p, float* sigma, float* sigma_d, int* split_fp16, float* max_abs_scaled) {
+  if (!p) return GMF_ERR_BAD_ARG;
+  if (sigma) *sigma = p->sigma;
+  if (sigma_d) *sigma_d = p->w.sigma_d;
+  if (split_fp16) *split_fp16 = p->split_fp16;
+  if (max_abs_scaled) *max_abs_scaled = p->amax;
+  return GMF_OK;
+}
+
+void gmf_packed_encoder_free(gmf_packed_encoder* p) {
+  if (!p) return;
+  if (p->device_block) {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(p->device);
+    (void)hipFree(p->device_block);
+    if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+  }
+  delete p;
+}
+
+int gmf_fusion_pack_weights(gmf_handle* h, const gmf_tensor* tensors, int n_tensors, const char* prefix, int pe, int flags,
+                            gmf_packed_fusion** out) {
+  if (!out) return GMF_ERR_BAD_ARG;
+  *out = nullptr;
+  std::string err;
+  auto bail = [&](int code, const std::string& m) { if (h) h->err = m; return code; };
+  if (!tensors || n_tensors <= 0) return bail(GMF_ERR_BAD_ARG, "gmf: fusion_pack_weights: bad arguments");
+  gmf_packed_fusion* p = new (std::nothrow) gmf_packed_fusion();
+  if (!p) return GMF_ERR_OOM;
+  try {
+    StateDict sd;
+    if (int rc = read_state(h, tensors, n_tensors, (flags & GMF_PACK_DEVICE_TENSORS) != 0, sd, err)) { delete p; return bail(rc, err); }
+    const std::string pre = prefix ? prefix : "";
+    Ctx c32, ch2;
+    FusionBlobs b = pack_fusion(sd, pre, pe != 0, Img::F32, c32);
+    FusionBlobs bh = pack_fusion(sd, pre, pe != 0, Img::H2S, ch2);
+    Block blk;
+    const size_t o0 = blk.add(b.ctx_wst), o1 = blk.add(b.ctx_vec), o2 = blk.add(b.attn_wst), o3 = blk.add(b.attn_vec), o4 = blk.add(b.ff_wst),
+                 o5 = blk.add(b.ff_vec), o6 = blk.add(bh.ctx_wst), o7 = blk.add(bh.attn_wst), o8 = blk.add(bh.ff_wst);
+    const float* base = nullptr;
+    if (int rc = place(h, blk, p->host_block, &p->device_block, &p->device, &base, err)) { delete p; return bail(rc, err); }
+    gmf_fusion_weights& w = p->w;
+    w.latent_dim = b.lat; w.d_head = b.dh; w.pe = pe != 0;
+    w.ctx_wst = base + o0; w.ctx_vec = base + o1; w.attn_wst = base + o2; w.attn_vec = base + o3; w.ff_wst = base + o4; w.ff_vec = base + o5;
+    if (ch2.ok) { w.ctx_wst_h2 = base + o6; w.attn_wst_h2 = base + o7; w.ff_wst_h2 = base + o8; }
+    w.split_fp16 = ch2.ok ? 1 : 0;
+    w.max_abs_scaled = ch2.amax;
+  } catch (const PackError& e) {
+    delete p;
+    return bail(e.code, e.msg);
+  } catch (const std::bad_alloc&) {
+    delete p;
+    return bail(GMF_ERR_OOM, "gmf: pack: out of host memory");
+  }
+  *out = p;
+  return GMF_OK;
+}
+
+const gmf_fusion_weights* gmf_packed_fusion_weights(const gmf_packed_fusion* p) { return p ? &p->w : nullptr; }
+
+void gmf_packed_fusion_free(gmf_packed_fusion* p) {
+  if (!p) return;
+  if (p->device_block) {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(p->device);
+    (void)hipFree(p->device_block);
+    if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+  }
+  delete p;
+}
+
+}  // extern "C"

@@ -79,18 +79,11 @@ class FusionLayer(nn.Module):
         self.split_fp16_attn = True    # context preparation + cross-attention likewise
 
     def _blobs(self, device):
+        """The layer's packed weights (`gmf_fusion_pack_weights`, C ABI) from the module's own state_dict, cached until a
+        parameter changes."""
         ver = (params_version(self), str(device))
         if self._packed is None or self._packed_version != ver:
-            sd = {k: v.detach().to("cpu", torch.float32) for k, v in self.state_dict().items()}
-            packed = packing.pack_fusion(sd, "", self.pe)
-            try:
-                h2 = packing.pack_fusion(sd, "", self.pe, img=packing.p32_h2s)
-                packed["ff_wst_h2"], packed["ctx_wst_h2"], packed["attn_wst_h2"] = h2["ff_wst"], h2["ctx_wst"], h2["attn_wst"]
-            except ValueError as e:          # a weight outside the fp16 range: the layer on the fp32 MFMA, said once per pack
-                import warnings
-                warnings.warn(f"{e}  This FusionLayer runs on the fp32 MFMA.", RuntimeWarning)
-                packed["ff_wst_h2"] = packed["ctx_wst_h2"] = packed["attn_wst_h2"] = None
-            self._packed = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in packed.items()}
+            self._packed = packing.PackedFusion(self.state_dict(), self.pe, device)
             self._packed_version = ver
         return self._packed
 
@@ -110,16 +103,14 @@ class FusionLayer(nn.Module):
         if data.shape[2] != packing.C:
             raise NotImplementedError(f"gmf_amd.FusionLayer: HIP kernels are built for 128-wide context tokens, got {data.shape[2]}")
         blobs = self._blobs(x.device)
-        if Cq != blobs["latent_dim"]:
-            raise RuntimeError(f"gmf_amd.FusionLayer: queries are {Cq} wide but the layer was built for {blobs['latent_dim']}")
+        if Cq != blobs.latent_dim:
+            raise RuntimeError(f"gmf_amd.FusionLayer: queries are {Cq} wide but the layer was built for {blobs.latent_dim}")
         out = torch.empty((B, N, Cq), device=x.device, dtype=torch.float32)
         h, st = handle_and_stream(x, check=True)            # (raises if an earlier forward on this device produced NaN / inf)
-        h.call("gmf_fusion_layer_forward", 1 if self.pe else 0, blobs["latent_dim"], blobs["d_head"],
-               blobs["ctx_wst"].data_ptr(), blobs["ctx_vec"].data_ptr(), blobs["attn_wst"].data_ptr(),
-               blobs["attn_vec"].data_ptr(), blobs["ff_wst"].data_ptr(), blobs["ff_vec"].data_ptr(),
+        h.call("gmf_fusion_layer_forward", 1 if self.pe else 0, blobs.latent_dim, blobs.d_head,
+               blobs.ctx_wst, blobs.ctx_vec, blobs.attn_wst, blobs.attn_vec, blobs.ff_wst, blobs.ff_vec,
                data.data_ptr(), x.data_ptr(), x.stride(0), x.stride(1), x.stride(2),
                out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), B, N, T, st,
-               blobs["ff_wst_h2"].data_ptr() if (self.split_fp16_ff and blobs["ff_wst_h2"] is not None) else None,
-               *((blobs["ctx_wst_h2"].data_ptr(), blobs["attn_wst_h2"].data_ptr())
-                 if (self.split_fp16_attn and blobs["attn_wst_h2"] is not None) else (None, None)))
+               blobs.ff_wst_h2 if (self.split_fp16_ff and blobs.ff_wst_h2) else None,
+               *((blobs.ctx_wst_h2, blobs.attn_wst_h2) if (self.split_fp16_attn and blobs.attn_wst_h2) else (None, None)))
         return out

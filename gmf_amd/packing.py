@@ -254,69 +254,138 @@ def pack_head(sd):
     return wst.contiguous(), vec.contiguous()
 
 
-class PackedEncoder:
-    """All blobs of NonLocalNet + classifier on one device, plus the ctypes struct handed to the C ABI."""
+def _no_object():
+    return None
+
+
+class _Owned:
+    """Owner of one library object: never duplicated (a deep copy or a pickle of the module that holds it gets None and
+    packs again on its next forward), freed exactly once."""
+    _free = None
+
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_no_object, ())
+
+    def __del__(self):
+        try:
+            if getattr(self, "_p", None):
+                getattr(self._lib, self._free)(self._p)
+                self._p = None
+        except Exception:
+            pass
+
+
+class PackedFusion(_Owned):
+    """One FusionLayer / PerceiverIO packed by `gmf_fusion_pack_weights` (C ABI): the device pointers
+    `gmf_fusion_layer_forward` takes, as plain integers (None where a split-fp16 image does not exist)."""
+    _free = "gmf_packed_fusion_free"
+
+    def __init__(self, sd: Dict[str, torch.Tensor], pe: bool, device, prefix: str = ""):
+        import ctypes as C
+        dev = torch.device(device)
+        lib = _lib.load_library()
+        self._lib = lib
+        hd = _lib.handle_for(dev.index if dev.index is not None else torch.cuda.current_device()) if dev.type == "cuda" else None
+        arr, keep = _lib.tensor_list(sd)
+        out = C.c_void_p()
+        rc = lib.gmf_fusion_pack_weights(hd.h if hd else None, arr, len(arr), prefix.encode(), 1 if pe else 0, 0, C.byref(out))
+        if rc != 0:
+            msg = lib.gmf_last_error_string(hd.h).decode() if hd else ""
+            if rc == -2:
+                raise NotImplementedError(f"gmf_amd: gmf_fusion_pack_weights: {msg} (no fallback path exists)")
+            raise RuntimeError(f"gmf_amd: gmf_fusion_pack_weights failed (status {rc}): {msg}")
+        del keep
+        self._p = out
+        w = lib.gmf_packed_fusion_weights(out).contents
+        self.latent_dim, self.d_head, self.split_fp16 = int(w.latent_dim), int(w.d_head), bool(w.split_fp16)
+        for k in ("ctx_wst", "ctx_vec", "attn_wst", "attn_vec", "ff_wst", "ff_vec", "ctx_wst_h2", "attn_wst_h2", "ff_wst_h2"):
+            setattr(self, k, getattr(w, k))
+        if not self.split_fp16:
+            import warnings
+            warnings.warn(f"gmf_amd.packing: a dense weight has max |value| = {w.max_abs_scaled:.6g} after folding/scaling, outside the "
+                          "fp16 range of the split-fp16 MFMA operands.  This FusionLayer runs on the fp32 MFMA.", RuntimeWarning)
+
+
+class PackedEncoder(_Owned):
+    """All blobs of NonLocalNet + classifier in one library-owned device block, packed by the C ABI
+    (`gmf_encoder_pack_weights`, gmf_amd/csrc/gmf_pack.cpp): this class only lists the state_dict tensors by name and keeps
+    the handle.  `struct` is the `gmf_encoder_weights` the forward entry points take.  (The pure-Python packers above produce
+    the same blobs bit for bit - tests/test_abi_host.py - and are kept as that cross-check.)"""
+    _free = "gmf_packed_encoder_free"
 
     def __init__(self, sd: Dict[str, torch.Tensor], num_layers: int, device, standalone_block: bool = False):
-        # pack on the host (a few hundred small permutes), then move the finished blobs to the device once
-        sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items() if v.is_floating_point()}
+        import ctypes as C
         self.num_layers = num_layers
-        f1 = pack_fusion(sd, "encoder.fusion_layer_1.", pe=False) if "encoder.fusion_layer_1.cross_attend_blocks.0.fn.to_q.weight" in sd else None
-        f2 = [pack_fusion(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.", pe=True) for i in range(num_layers)]
-        fronts = [pack_front(sd, i, with_layer0=(i == 0 and "encoder.layer0.weight" in sd),
-                             identity_pointcn=standalone_block) for i in range(num_layers)]
-        tails = [pack_tail(sd, i) for i in range(num_layers)]
-        st = lambda lst: torch.stack(lst).contiguous() if lst else torch.zeros(1)
-        self.t = {
-            "ctx_wst": st([f["ctx_wst"] for f in f2]), "ctx_vec": st([f["ctx_vec"] for f in f2]),
-            "attn_wst": st([f["attn_wst"] for f in f2]), "attn_vec": st([f["attn_vec"] for f in f2]),
-            "ff_wst": st([f["ff_wst"] for f in f2]), "ff_vec": st([f["ff_vec"] for f in f2]),
-            "front_wst": st([f[0] for f in fronts]), "front_vec": st([f[1] for f in fronts]),
-            "tail_wst": st([t[0] for t in tails]), "tail_vec": st([t[1] for t in tails]),
-        }
-        if f1 is not None:
-            for k, v in f1.items():
-                self.t["f1_" + k] = v
-        # split-fp16 images of every dense weight.  A weight outside the fp16 range (|256 w| > 65504) cannot be split; the
-        # encoder then runs every stage on the fp32 MFMA (still the HIP path - slower, same results) and says so once.
-        self.split_fp16 = True
-        try:
-            h2 = {}
-            if f1 is not None:
-                f1h = pack_fusion(sd, "encoder.fusion_layer_1.", pe=False, img=p32_h2s)
-                for k in ("ctx_wst", "attn_wst", "ff_wst"):
-                    h2["f1_" + k + "_h2"] = f1h[k]
-            if num_layers > 0:
-                f2h = [pack_fusion(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.", pe=True, img=p32_h2s) for i in range(num_layers)]
-                for k in ("ctx_wst", "attn_wst", "ff_wst"):
-                    h2[k + "_h2"] = torch.stack([f[k] for f in f2h]).contiguous()
-                h2["front_wst_h2"] = torch.stack([pack_front(sd, i, with_layer0=(i == 0 and "encoder.layer0.weight" in sd),
-                                                             identity_pointcn=standalone_block, img=p32_h2s)[0]
-                                                  for i in range(num_layers)]).contiguous()
-                h2["tail_wst_h2"] = torch.stack([pack_tail(sd, i, img=p32_h2s)[0] for i in range(num_layers)]).contiguous()
-            self.t.update(h2)
-        except ValueError as e:
+        dev = torch.device(device)
+        on_gpu = dev.type == "cuda"
+        lib = _lib.load_library()
+        self._lib = lib
+        hd = _lib.handle_for(dev.index if dev.index is not None else torch.cuda.current_device()) if on_gpu else None
+        arr, keep = _lib.tensor_list(sd)
+        out = C.c_void_p()
+        rc = lib.gmf_encoder_pack_weights(hd.h if hd else None, arr, len(arr), int(num_layers),
+                                          _lib.GMF_PACK_STANDALONE_BLOCK if standalone_block else 0, C.byref(out))
+        if rc != 0:
+            msg = lib.gmf_last_error_string(hd.h).decode() if hd else ""
+            if rc == -2:
+                raise NotImplementedError(f"gmf_amd: gmf_encoder_pack_weights: {msg} (no fallback path exists)")
+            raise RuntimeError(f"gmf_amd: gmf_encoder_pack_weights failed (status {rc}): {msg}")
+        del keep
+        self._p = out
+        sig, sig_d, split, amax = C.c_float(), C.c_float(), C.c_int(), C.c_float()
+        lib.gmf_packed_encoder_info(out, C.byref(sig), C.byref(sig_d), C.byref(split), C.byref(amax))
+        self.sigma, self.sigma_d = float(sig.value), float(sig_d.value)      # read once here: no per-call host sync
+        self.split_fp16 = bool(split.value)
+        if not self.split_fp16:
             import warnings
-            warnings.warn(f"{e}  Falling back to the fp32-MFMA kernels for the whole encoder (about 3x slower).", RuntimeWarning)
-            self.split_fp16 = False
-        if "classification.0.weight" in sd:
-            self.t["head_wst"], self.t["head_vec"] = pack_head(sd)
-        self.t = {k: v.to(device) for k, v in self.t.items() if torch.is_tensor(v)}
-        self.sigma_d = float(sd["sigma_spat"].detach().reshape(-1)[0]) if "sigma_spat" in sd else 0.1
-        self.sigma = float(sd["sigma"].detach().reshape(-1)[0]) if "sigma" in sd else 1.0   # read once here: no per-call host sync
-        w = _lib.EncoderWeights()
-        w.num_layers = num_layers
-        for name in ("f1_ctx_wst", "f1_ctx_vec", "f1_attn_wst", "f1_attn_vec", "f1_ff_wst", "f1_ff_vec",
-                     "ctx_wst", "ctx_vec", "attn_wst", "attn_vec", "ff_wst", "ff_vec", "front_wst", "front_vec",
-                     "tail_wst", "tail_vec", "head_wst", "head_vec"):
-            setattr(w, name, self.t[name].data_ptr() if name in self.t else None)
-        w.ctx_wst_stride, w.ctx_vec_stride = CTX_WST, CTX_VEC
-        w.attn_wst_stride, w.attn_vec_stride = ATTN_WST, ATTN_VEC
-        w.ff_wst_stride, w.ff_vec_stride = FF_WST, FF_VEC
-        w.front_wst_stride, w.front_vec_stride = FRONT_WST, FRONT_VEC
-        w.tail_wst_stride, w.tail_vec_stride = TAIL_WST, TAIL_VEC
-        w.sigma_d = self.sigma_d
-        for name in ("front_wst_h2", "ctx_wst_h2", "attn_wst_h2", "ff_wst_h2", "f1_ctx_wst_h2", "f1_attn_wst_h2", "f1_ff_wst_h2",
-                     "tail_wst_h2"):
-            setattr(w, name, self.t[name].data_ptr() if name in self.t else None)
-        self.struct = w
+            warnings.warn(f"gmf_amd.packing: a dense weight has max |value| = {amax.value:.6g} after folding/scaling, outside the fp16 "
+                          "range (65504; 255.8 for weights stored as 256 w) of the split-fp16 MFMA operands.  Falling back to the "
+                          "fp32-MFMA kernels for the whole encoder (about 3x slower).", RuntimeWarning)
+        self.struct = lib.gmf_packed_encoder_weights(out)       # POINTER(EncoderWeights) into the packed object
+
+
+def python_packed_encoder(sd: Dict[str, torch.Tensor], num_layers: int, standalone_block: bool = False):
+    """The encoder's blobs by the pure-Python packers (host tensors): the cross-check of the C packer.  Returns
+    (dict name -> tensor, split_fp16)."""
+    sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items() if v.is_floating_point()}
+    f1 = pack_fusion(sd, "encoder.fusion_layer_1.", pe=False) if "encoder.fusion_layer_1.cross_attend_blocks.0.fn.to_q.weight" in sd else None
+    f2 = [pack_fusion(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.", pe=True) for i in range(num_layers)]
+    fronts = [pack_front(sd, i, with_layer0=(i == 0 and "encoder.layer0.weight" in sd),
+                         identity_pointcn=standalone_block) for i in range(num_layers)]
+    tails = [pack_tail(sd, i) for i in range(num_layers)]
+    st = lambda lst: torch.stack(lst).contiguous() if lst else torch.zeros(1)
+    t = {
+        "ctx_wst": st([f["ctx_wst"] for f in f2]), "ctx_vec": st([f["ctx_vec"] for f in f2]),
+        "attn_wst": st([f["attn_wst"] for f in f2]), "attn_vec": st([f["attn_vec"] for f in f2]),
+        "ff_wst": st([f["ff_wst"] for f in f2]), "ff_vec": st([f["ff_vec"] for f in f2]),
+        "front_wst": st([f[0] for f in fronts]), "front_vec": st([f[1] for f in fronts]),
+        "tail_wst": st([x[0] for x in tails]), "tail_vec": st([x[1] for x in tails]),
+    }
+    if f1 is not None:
+        for k, v in f1.items():
+            if torch.is_tensor(v):
+                t["f1_" + k] = v
+    split = True
+    try:
+        h2 = {}
+        if f1 is not None:
+            f1h = pack_fusion(sd, "encoder.fusion_layer_1.", pe=False, img=p32_h2s)
+            for k in ("ctx_wst", "attn_wst", "ff_wst"):
+                h2["f1_" + k + "_h2"] = f1h[k]
+        if num_layers > 0:
+            f2h = [pack_fusion(sd, f"encoder.blocks.NonLocal_layer_{i}.fusion_layer_2.", pe=True, img=p32_h2s) for i in range(num_layers)]
+            for k in ("ctx_wst", "attn_wst", "ff_wst"):
+                h2[k + "_h2"] = torch.stack([f[k] for f in f2h]).contiguous()
+            h2["front_wst_h2"] = torch.stack([pack_front(sd, i, with_layer0=(i == 0 and "encoder.layer0.weight" in sd),
+                                                         identity_pointcn=standalone_block, img=p32_h2s)[0]
+                                              for i in range(num_layers)]).contiguous()
+            h2["tail_wst_h2"] = torch.stack([pack_tail(sd, i, img=p32_h2s)[0] for i in range(num_layers)]).contiguous()
+        t.update(h2)
+    except ValueError:
+        split = False
+    if "classification.0.weight" in sd:
+        t["head_wst"], t["head_vec"] = pack_head(sd)
+    return t, split

@@ -381,15 +381,13 @@ class PointDSC(nn.Module):
         logits within 1e-4 of the reference) or "throughput" (on large grids the spatial-consistency
         attention multiplies plain fp16 operands and streams the compat matrix as fp16; measured deviation from the parity
         mode at 32 x 5000: logits 1.6e-4, identical inlier labels, 1.46x the throughput) or "throughput_max" (the layer's linear
-        stages on plain fp16 operands as well: logits 4e-2, 98-100 % identical labels, 1.6x).  The setting lives in the
-        device's library handle (gmf_set_tuning "precision"), i.e. it applies to every module on that device."""
+        stages on plain fp16 operands as well: logits 4e-2, 98-100 % identical labels, 1.6x).  The setting belongs to THIS
+        module: its forward sets the library handle's "precision" knob for the duration of the call and puts the previous
+        value back, so other modules on the device keep their own numerics."""
         levels = {"parity": 0, "throughput": 1, "throughput_max": 2}
         if mode not in levels:
             raise ValueError("gmf_amd.PointDSC.set_precision: mode must be 'parity', 'throughput' or 'throughput_max'")
-        dev = next(self.parameters()).device
-        if dev.type != "cuda":
-            raise RuntimeError("gmf_amd.PointDSC.set_precision: the module must be on a HIP device")
-        _lib.handle_for(dev.index or 0).call("gmf_set_tuning", b"precision", levels[mode])
+        self._precision = levels[mode]
 
     # -- encoder: logits + normalised features ----------------------------------------------------
     def encode(self, corr_pos, src_keypts, tgt_keypts, p_tokens, q_tokens, want_features=False):
@@ -415,9 +413,16 @@ class PointDSC(nn.Module):
         feat_n = torch.empty((B, N, 128), device=dev)
         feat = torch.empty((B, N, 128), device=dev) if want_features else None
         h, st = handle_and_stream(corr_pos, check=True)     # (raises if an earlier forward on this device produced NaN / inf)
-        h.call("gmf_encoder_forward", pw.struct, corr_pos.data_ptr(), src.data_ptr(), tgt.data_ptr(),
-               p_tokens.data_ptr(), q_tokens.data_ptr(), B, N, T, logits.data_ptr(), feat_n.data_ptr(),
-               None if feat is None else feat.data_ptr(), st)
+        prec = getattr(self, "_precision", 0)
+        if prec:
+            h.call("gmf_set_tuning", b"precision", prec)
+        try:
+            h.call("gmf_encoder_forward", pw.struct, corr_pos.data_ptr(), src.data_ptr(), tgt.data_ptr(),
+                   p_tokens.data_ptr(), q_tokens.data_ptr(), B, N, T, logits.data_ptr(), feat_n.data_ptr(),
+                   None if feat is None else feat.data_ptr(), st)
+        finally:
+            if prec:
+                h.call("gmf_set_tuning", b"precision", 0)
         return logits, feat_n, feat
 
     # -- pose head --------------------------------------------------------------------------------

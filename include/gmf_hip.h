@@ -194,6 +194,50 @@ typedef struct gmf_encoder_weights {
   const float* tail_wst_h2;
 } gmf_encoder_weights;
 
+/* ---- weight packing ---------------------------------------------------------------------------
+ * The reference keeps its weights as a PyTorch state_dict (588 non-image tensors under the names of SURVEY.md section 8b) and
+ * has no packed form; the kernels stream blobs (P32 images, BatchNorm folded, softmax scales folded, split-fp16 planes).
+ * These entry points build the blobs from the state_dict tensors themselves, so that a host in any language can go from a
+ * checkpoint to gmf_encoder_forward: list the tensors by their reference names, pack once, run.
+ * Tensors are contiguous fp32; shapes as torch stores them (conv1x1 weights [out, in, 1], depthwise taps [C, 1, 3]). */
+typedef struct gmf_tensor {
+  const char* name;          /* state_dict key, e.g. "encoder.blocks.NonLocal_layer_3.projection_q.weight" */
+  const float* data;         /* host pointer (default) or device pointer (GMF_PACK_DEVICE_TENSORS) */
+  int ndim;                  /* 0 .. 4 */
+  long long shape[4];
+} gmf_tensor;
+#define GMF_PACK_DEVICE_TENSORS 1     /* `data` pointers are device pointers (copied to the host first) */
+#define GMF_PACK_STANDALONE_BLOCK 2   /* NonLocalBlock on its own (PointDSC.py:40-74): no PointCN in front (identity) */
+typedef struct gmf_packed_encoder gmf_packed_encoder;
+/* Packs NonLocalNet (Fusion-1 if present, layer0, num_layers x {PointCN, NonLocalBlock with its Fusion-2}) + classifier
+ * (PointDSC.py:77-181) into ONE library-owned device block on h's device and fills a gmf_encoder_weights that points into it.
+ * Tensors the list does not need are ignored (the image encoder, num_batches_tracked); a missing one is GMF_ERR_BAD_ARG with
+ * its name in gmf_last_error_string.  h may be NULL: the blobs then stay in host memory (inspection / tests; not for kernels).
+ * A weight outside the fp16 range of the split operands (|256 w| > 65504, e.g. a BatchNorm with a tiny running_var) leaves the
+ * *_h2 pointers NULL: every stage then runs on the fp32 MFMA; gmf_packed_encoder_info reports it. */
+int gmf_encoder_pack_weights(gmf_handle* h, const gmf_tensor* tensors, int n_tensors, int num_layers, int flags,
+                             gmf_packed_encoder** out);
+const struct gmf_encoder_weights* gmf_packed_encoder_weights(const gmf_packed_encoder* p);
+/* sigma (PointDSC.py:164, for gmf_pose_params), sigma_d (= sigma_spat, :165), whether the split-fp16 images were built, and
+ * the largest |value| met while splitting (inf: a weight was not finite).  Any output pointer may be NULL. */
+int gmf_packed_encoder_info(const gmf_packed_encoder* p, float* sigma, float* sigma_d, int* split_fp16, float* max_abs_scaled);
+void gmf_packed_encoder_free(gmf_packed_encoder* p);
+
+/* One FusionLayer / PerceiverIO with depth = 0 (fusion_layer.py:131-201, perceiver_io.py:139-221; widths (128, 64) and
+ * (256, 128)): the arguments of gmf_fusion_layer_forward.  `prefix` is prepended to the module's own key names
+ * ("cross_attend_blocks.0.fn.to_q.weight", "cpe.proj_q.weight", ...); pe = whether the layer has a `cpe`. */
+typedef struct gmf_fusion_weights {
+  int latent_dim, d_head, pe, split_fp16;
+  float max_abs_scaled;
+  const float *ctx_wst, *ctx_vec, *attn_wst, *attn_vec, *ff_wst, *ff_vec;
+  const float *ctx_wst_h2, *attn_wst_h2, *ff_wst_h2;      /* NULL when a weight is outside the fp16 range */
+} gmf_fusion_weights;
+typedef struct gmf_packed_fusion gmf_packed_fusion;
+int gmf_fusion_pack_weights(gmf_handle* h, const gmf_tensor* tensors, int n_tensors, const char* prefix, int pe, int flags,
+                            gmf_packed_fusion** out);
+const gmf_fusion_weights* gmf_packed_fusion_weights(const gmf_packed_fusion* p);
+void gmf_packed_fusion_free(gmf_packed_fusion* p);
+
 /* PointDSC.forward up to the logits (PointDSC.py:216-241) with image TOKENS as input:
  * corr_pos [B,N,6], src/tgt_keypts [B,N,3], p_tokens/q_tokens [B,T,128] (row-major)
  * -> logits [B,N], feat_n [B,N,128] (unit rows), feat [B,N,128] (may be NULL). */

@@ -1,20 +1,119 @@
 // A C++ host of the C ABI (include/gmf_hip.h) with no Python and no torch in the process: device buffers from hipMalloc,
-// the DGR pose calls on synthetic scenes with a known rigid motion, status codes and the error string.
-//   hipcc -O2 -I include tests/abi_cpp/abi_host.cpp -L gmf_amd -lgmf_hip -Wl,-rpath,$PWD/gmf_amd -o abi_host && ./abi_host
+// the DGR pose calls on synthetic scenes with a known rigid motion, status codes and the error string - and, given a dump file,
+// THE HOT PATH: state_dict tensors -> gmf_encoder_pack_weights -> gmf_encoder_forward -> gmf_pose_head, checked against the
+// reference's own outputs (golden F4) carried in the same dump.
+//   hipcc -O2 -I include tests/abi_cpp/abi_host.cpp -L gmf_amd -lgmf_hip -Wl,-rpath,$PWD/gmf_amd -o abi_host && ./abi_host [dump]
+// Dump format (written by tests/test_gpu_parity.py::test_cpp_host_of_the_c_abi, little endian): "GMFD", int32 count, then per
+// tensor: int32 name length, name, int32 ndim, int64 shape[4], float32 data.  Names: the reference's state_dict keys,
+// "input.corr_pos" [B,N,6], "input.src_keypts", "input.tgt_keypts" [B,N,3], "input.p_tokens", "input.q_tokens" [B,T,128],
+// "expect.logits" [B,N], "expect.final_trans" [B,4,4], "param.num_layers" [1].
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
+#include <cstring>
+#include <map>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "gmf_hip.h"
 
 #define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
 
-int main() {
+struct Named { std::string name; int ndim; long long shape[4]; std::vector<float> data; };
+
+static bool read_dump(const char* path, std::vector<Named>& out) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return false;
+  char magic[4];
+  int32_t n = 0;
+  bool ok = std::fread(magic, 1, 4, f) == 4 && std::memcmp(magic, "GMFD", 4) == 0 && std::fread(&n, 4, 1, f) == 1 && n > 0 && n < 100000;
+  for (int i = 0; ok && i < n; ++i) {
+    Named t;
+    int32_t len = 0, nd = 0;
+    int64_t shp[4];
+    ok = std::fread(&len, 4, 1, f) == 1 && len > 0 && len < 4096;
+    if (!ok) break;
+    t.name.resize(len);
+    ok = std::fread(&t.name[0], 1, len, f) == (size_t)len && std::fread(&nd, 4, 1, f) == 1 && std::fread(shp, 8, 4, f) == 4;
+    if (!ok) break;
+    t.ndim = nd;
+    size_t numel = 1;
+    for (int d = 0; d < 4; ++d) { t.shape[d] = shp[d]; numel *= (size_t)shp[d]; }
+    t.data.resize(numel);
+    ok = std::fread(t.data.data(), 4, numel, f) == numel;
+    out.push_back(std::move(t));
+  }
+  std::fclose(f);
+  return ok;
+}
+
+// state_dict -> packed weights -> logits -> pose, all through the C ABI, against the reference's outputs in the dump
+static int run_hot_path(gmf_handle* h, const char* path, hipStream_t st) {
+  std::vector<Named> ts;
+  if (!read_dump(path, ts)) { std::printf("cannot read dump %s\n", path); return 1; }
+  std::map<std::string, const Named*> by;
+  std::vector<gmf_tensor> sd;
+  for (const Named& t : ts) {
+    by[t.name] = &t;
+    if (t.name.rfind("input.", 0) == 0 || t.name.rfind("expect.", 0) == 0 || t.name.rfind("param.", 0) == 0) continue;
+    gmf_tensor g;
+    g.name = t.name.c_str(); g.data = t.data.data(); g.ndim = t.ndim;
+    for (int d = 0; d < 4; ++d) g.shape[d] = t.shape[d];
+    sd.push_back(g);
+  }
+  for (const char* k : {"input.corr_pos", "input.src_keypts", "input.tgt_keypts", "input.p_tokens", "input.q_tokens", "expect.logits",
+                        "expect.final_trans", "param.num_layers"})
+    if (!by.count(k)) { std::printf("dump lacks %s\n", k); return 1; }
+  const int L = (int)by["param.num_layers"]->data[0];
+  const Named& cp = *by["input.corr_pos"];
+  const int B = (int)cp.shape[0], N = (int)cp.shape[1], T = (int)by["input.p_tokens"]->shape[1];
+  gmf_packed_encoder* pk = nullptr;
+  int rc = gmf_encoder_pack_weights(h, sd.data(), (int)sd.size(), L, 0, &pk);
+  if (rc != GMF_OK) { std::printf("gmf_encoder_pack_weights: status %d, %s\n", rc, gmf_last_error_string(h)); return 1; }
+  float sigma = 0.f, sigma_d = 0.f;
+  int split = 0;
+  gmf_packed_encoder_info(pk, &sigma, &sigma_d, &split, nullptr);
+  std::printf("packed %d tensors, %d layers: sigma %.3f sigma_d %.3f split_fp16 %d\n", (int)sd.size(), L, sigma, sigma_d, split);
+  auto up = [&](const Named& t, float** d) {
+    if (hipMalloc((void**)d, t.data.size() * 4) != hipSuccess) return false;
+    return hipMemcpy(*d, t.data.data(), t.data.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  float *dcp, *dsrc, *dtgt, *dp, *dq, *dlog, *dfn, *dT, *dlab;
+  if (!up(cp, &dcp) || !up(*by["input.src_keypts"], &dsrc) || !up(*by["input.tgt_keypts"], &dtgt) || !up(*by["input.p_tokens"], &dp) ||
+      !up(*by["input.q_tokens"], &dq)) { std::printf("upload failed\n"); return 2; }
+  CHECK_HIP(hipMalloc(&dlog, (size_t)B * N * 4)); CHECK_HIP(hipMalloc(&dfn, (size_t)B * N * 128 * 4));
+  CHECK_HIP(hipMalloc(&dT, (size_t)B * 16 * 4)); CHECK_HIP(hipMalloc(&dlab, (size_t)B * N * 4));
+  rc = gmf_encoder_forward(h, gmf_packed_encoder_weights(pk), dcp, dsrc, dtgt, dp, dq, B, N, T, dlog, dfn, nullptr, st);
+  if (rc != GMF_OK) { std::printf("gmf_encoder_forward: status %d, %s\n", rc, gmf_last_error_string(h)); return 1; }
+  gmf_pose_params pp;
+  pp.num_seeds = (int)(N * 0.1); pp.k = 40 < N - 1 ? 40 : N - 1; pp.num_iterations = 10; pp.use_nms = 1; pp.refine_iters = 20;
+  pp.sigma = sigma; pp.sigma_d = sigma_d; pp.inlier_threshold = 0.10f; pp.nms_radius = 0.10f; pp.refine_threshold = 0.10f;
+  rc = gmf_pose_head(h, &pp, dfn, dsrc, dtgt, dlog, nullptr, B, N, dT, dlab, nullptr, nullptr, nullptr, nullptr, st);
+  if (rc != GMF_OK) { std::printf("gmf_pose_head: status %d, %s\n", rc, gmf_last_error_string(h)); return 1; }
+  CHECK_HIP(hipStreamSynchronize(st));
+  int flags = -1;
+  gmf_status_read(h, &flags, 1);
+  std::vector<float> lg((size_t)B * N), Tm((size_t)B * 16);
+  CHECK_HIP(hipMemcpy(lg.data(), dlog, lg.size() * 4, hipMemcpyDeviceToHost));
+  CHECK_HIP(hipMemcpy(Tm.data(), dT, Tm.size() * 4, hipMemcpyDeviceToHost));
+  float el = 0.f, eT = 0.f;
+  const Named& xl = *by["expect.logits"];
+  const Named& xT = *by["expect.final_trans"];
+  for (size_t i = 0; i < lg.size(); ++i) el = std::fmax(el, std::fabs(lg[i] - xl.data[i]));
+  for (size_t i = 0; i < Tm.size(); ++i) eT = std::fmax(eT, std::fabs(Tm[i] - xT.data[i]));
+  std::printf("hot path (B = %d, N = %d, T = %d): max |logit - reference| = %.3e, max |T - reference| = %.3e, status word %d\n", B, N, T, el, eT, flags);
+  gmf_packed_encoder_free(pk);
+  for (float* d : {dcp, dsrc, dtgt, dp, dq, dlog, dfn, dT, dlab}) (void)hipFree(d);
+  return (el < 1e-4f && eT < 1e-4f && flags == 0) ? 0 : 1;
+}
+
+int main(int argc, char** argv) {
   gmf_handle* h = nullptr;
   if (gmf_create(0, &h) != GMF_OK || !h) { std::printf("gmf_create failed\n"); return 1; }
+  if (gmf_abi_version() != GMF_ABI_VERSION) { std::printf("ABI version mismatch\n"); return 1; }
 
   const int B = 4, N = 3000;
   std::mt19937 rng(7);
@@ -118,6 +217,11 @@ int main() {
   rc = gmf_weighted_procrustes(h, nullptr, dY, dW, dOff, B, 1.1920929e-7f, dR, dt, st);
   if (rc == GMF_OK) { std::printf("null pointer was accepted\n"); return 1; }
   std::printf("bad call -> status %d, \"%s\"\n", rc, gmf_last_error_string(h));
+
+  if (argc > 1) {
+    if (int r = run_hot_path(h, argv[1], st)) return r;
+    std::printf("hot path OK\n");
+  }
 
   gmf_destroy(h);
   std::printf("ABI host OK\n");

@@ -113,6 +113,97 @@ def test_bn_folding_and_blob_sizes():
     assert wst.numel() == 2 * 4096
 
 
+def _c_blob(ptr, n):
+    return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_float)), shape=(n,)).view(np.uint32)
+
+
+@pytest.mark.parametrize("standalone", [False, True])
+def test_c_weight_packing_equals_python_packing_bit_for_bit(standalone):
+    """gmf_encoder_pack_weights (C ABI, gmf_amd/csrc/gmf_pack.cpp) builds the encoder's blobs from the state_dict tensors by name:
+    BatchNorm folding, softmax-scale folding, P32 images and split-fp16 planes.  Every blob equals the pure-Python packers'
+    (gmf_amd/packing.py) bit for bit.  With h = NULL the blobs stay in host memory, so this runs without a GPU."""
+    from gmf_amd import _lib, packing, synthetic
+    L = 3
+    sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, L, 128), seed=11)
+    if standalone:
+        sd = {k: v for k, v in sd.items() if k.startswith("encoder.blocks.NonLocal_layer_0.")}
+        L = 1
+    lib = _lib.load_library()
+    arr, keep = _lib.tensor_list(sd)
+    out = ctypes.c_void_p()
+    flags = _lib.GMF_PACK_STANDALONE_BLOCK if standalone else 0
+    assert lib.gmf_encoder_pack_weights(None, arr, len(arr), L, flags, ctypes.byref(out)) == 0
+    try:
+        w = lib.gmf_packed_encoder_weights(out).contents
+        ref, split = packing.python_packed_encoder(sd, L, standalone_block=standalone)
+        assert split and w.num_layers == L
+        names = [f[0] for f in _lib.EncoderWeights._fields_]
+        checked = 0
+        for name, t in ref.items():
+            assert name in names
+            ptr = getattr(w, name)
+            assert ptr, name
+            assert np.array_equal(_c_blob(ptr, t.numel()), t.reshape(-1).numpy().view(np.uint32)), name
+            checked += 1
+        assert checked == (15 if standalone else 26)      # (standalone block: no Fusion-1, no classifier)
+        assert (w.front_wst_stride, w.tail_wst_stride, w.ff_wst_stride) == (packing.FRONT_WST, packing.TAIL_WST, packing.FF_WST)
+        sig, sig_d, sp, amax = ctypes.c_float(), ctypes.c_float(), ctypes.c_int(), ctypes.c_float()
+        assert lib.gmf_packed_encoder_info(out, ctypes.byref(sig), ctypes.byref(sig_d), ctypes.byref(sp), ctypes.byref(amax)) == 0
+        if not standalone:
+            assert sig.value == float(sd["sigma"].reshape(-1)[0]) and sig_d.value == float(sd["sigma_spat"].reshape(-1)[0])
+        assert sp.value == 1 and 0 < amax.value <= 65504
+    finally:
+        lib.gmf_packed_encoder_free(out)
+
+
+def test_c_weight_packing_rejects_and_falls_back():
+    """A missing tensor is named; a weight outside the fp16 range drops the split-fp16 images (the fp32-MFMA path remains), as the
+    Python packers do; unsupported widths are GMF_ERR_UNSUPPORTED_SHAPE."""
+    from gmf_amd import _lib, packing, synthetic
+    lib = _lib.load_library()
+    sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 2, 128), seed=3)
+    out = ctypes.c_void_p()
+    miss = {k: v for k, v in sd.items() if k != "encoder.blocks.NonLocal_layer_1.projection_k.bias"}
+    arr, keep = _lib.tensor_list(miss)
+    assert lib.gmf_encoder_pack_weights(None, arr, len(arr), 2, 0, ctypes.byref(out)) == -1 and not out.value
+    big = dict(sd)
+    big["encoder.blocks.PointCN_layer_1.1.weight"] = sd["encoder.blocks.PointCN_layer_1.1.weight"] * 1e5     # folds to |256 w| > 65504
+    arr, keep = _lib.tensor_list(big)
+    assert lib.gmf_encoder_pack_weights(None, arr, len(arr), 2, 0, ctypes.byref(out)) == 0
+    try:
+        w = lib.gmf_packed_encoder_weights(out).contents
+        assert not w.front_wst_h2 and not w.ff_wst_h2 and not w.tail_wst_h2 and w.front_wst and w.ff_wst
+        sp = ctypes.c_int(7)
+        lib.gmf_packed_encoder_info(out, None, None, ctypes.byref(sp), None)
+        assert sp.value == 0
+        ref, split = packing.python_packed_encoder(big, 2)
+        assert not split
+        assert np.array_equal(_c_blob(w.front_wst, ref["front_wst"].numel()), ref["front_wst"].reshape(-1).numpy().view(np.uint32))
+    finally:
+        lib.gmf_packed_encoder_free(out)
+    # one FusionLayer: both widths, with and without LCPE, against packing.pack_fusion
+    for lat, dh, pe in ((128, 64, True), (256, 128, True), (256, 128, False)):
+        fsd = synthetic.seeded_state_dict(synthetic.fusion_layer_shapes("", 128, lat, dh, pe=pe, out_to_query=True), seed=5)
+        arr, keep = _lib.tensor_list(fsd)
+        pf = ctypes.c_void_p()
+        assert lib.gmf_fusion_pack_weights(None, arr, len(arr), b"", int(pe), 0, ctypes.byref(pf)) == 0
+        try:
+            fw = lib.gmf_packed_fusion_weights(pf).contents
+            assert (fw.latent_dim, fw.d_head, fw.split_fp16) == (lat, dh, 1)
+            ref = packing.pack_fusion(fsd, "", pe)
+            refh = packing.pack_fusion(fsd, "", pe, img=packing.p32_h2s)
+            for k in ("ctx_wst", "ctx_vec", "attn_wst", "attn_vec", "ff_wst", "ff_vec"):
+                assert np.array_equal(_c_blob(getattr(fw, k), ref[k].numel()), ref[k].numpy().view(np.uint32)), (lat, pe, k)
+            for k in ("ctx_wst", "attn_wst", "ff_wst"):
+                assert np.array_equal(_c_blob(getattr(fw, k + "_h2"), refh[k].numel()), refh[k].numpy().view(np.uint32)), (lat, pe, k)
+        finally:
+            lib.gmf_packed_fusion_free(pf)
+    bad = synthetic.seeded_state_dict(synthetic.fusion_layer_shapes("", 128, 512, 64, pe=False), seed=1)
+    arr, keep = _lib.tensor_list(bad)
+    pf = ctypes.c_void_p()
+    assert lib.gmf_fusion_pack_weights(None, arr, len(arr), b"", 0, 0, ctypes.byref(pf)) == -2 and not pf.value
+
+
 def test_synthetic_scene_is_consistent():
     from gmf_amd import synthetic
     p = synthetic.synthetic_pair(5, 500)

@@ -328,8 +328,10 @@ def test_random_scenes_against_the_fp32_noise_floor(model, sd_full, scene, N, T)
     """Scenes of the randomised sweep (tests/tools/parity_sweep.py, seeds 1000 + scene).  Scene 95 is the one of its first 100 where
     fp32 arithmetic itself is short of the 1e-4 gate: the reference's own fp32 evaluation is 6.3e-5 from an fp64 evaluation of the
     same network, and two fp32 evaluations that differ only in summation order then differ by up to about twice that.  The
-    contract tested: within 1e-4 of the fp32 oracle, or - where the oracle's own distance from fp64 is the larger number - within
-    2.5 x that distance; and never further from the fp64 result than 2 x the fp32 oracle is."""
+    contract tested [r3, tightened]: the HIP logits are no further from the EXACT network (the fp64 evaluation) than 1.5 x the
+    reference's own fp32 evaluation is, plus 2e-5 - "about as accurate as the reference", stated against the truth rather than
+    against the other fp32 result (measured over the 100-scene sweep: HIP median 1.3e-5 / oracle 1.5e-5; worst ratio scene 95:
+    9.7e-5 against 6.3e-5) - and within 1e-4 of the fp32 oracle wherever that bound leaves room for it."""
     b = synthetic.synthetic_batch([1000 + scene], N=N, T=T)
     o32 = O.pointdsc_forward(sd_full, b, testing=True)["logits"]
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd_full.items()}
@@ -343,8 +345,8 @@ def test_random_scenes_against_the_fp32_noise_floor(model, sd_full, scene, N, T)
     lg = model.last_logits.cpu()
     e32, e64 = _maxerr(lg, o32), float((lg.double() - o64).abs().max())
     print(f"scene {scene}: HIP vs fp32 oracle {e32:.2e}, vs fp64 {e64:.2e}; fp32 oracle vs fp64 {floor:.2e}")
-    assert e32 < max(1e-4, 2.5 * floor), (e32, floor)
-    assert e64 < max(1e-4, 2.0 * floor), (e64, floor)
+    assert e64 < 1.5 * floor + 2e-5, (e64, floor)
+    assert e32 < max(1e-4, 2.5 * floor + 2e-5), (e32, floor)       # (follows from the line above by the triangle inequality)
 
 
 def test_f5_f7_pose_head(golden_dir, model):
@@ -446,6 +448,20 @@ def test_throughput_precision_mode(model):
     r2 = model(data)
     assert torch.equal(model.last_logits, lg0) and torch.equal(r2["final_trans"], T0)
     assert torch.equal(model(small)["final_trans"], rs1)      # the small grid never left the parity numerics
+    # PointDSC.set_precision belongs to the MODULE: its own forwards run in that mode, the handle's knob is back at parity after
+    # each of them, so another module on the same device keeps the parity numerics
+    import copy
+    other = copy.deepcopy(model)                              # (the packed weights are never shared: the copy packs its own)
+    try:
+        model.set_precision("throughput")
+        model(data)
+        assert torch.equal(model.last_logits, lg1)
+        other(data)
+        assert torch.equal(other.last_logits, lg0)
+    finally:
+        model.set_precision("parity")
+    model(data)
+    assert torch.equal(model.last_logits, lg0)
 
 
 def test_throughput_precision_level_2(model):
@@ -619,14 +635,17 @@ def test_kitti_shape_long_sequence():
     d2["testing"] = True
     r2 = m(d2)
     # KITTI coordinates are ~40x larger than 3DMatch ones, so with the same weights the fp32 noise floor of the
-    # computation itself (oracle fp32 vs oracle fp64) is ~1.4e-4 here; the gate is 2x that floor (1e-4 at least).
+    # computation itself (oracle fp32 vs oracle fp64) is ~1.4e-4 here.  [r3, tightened] the HIP logits are no further from the
+    # fp64 evaluation than 1.5 x the reference's own fp32 evaluation is, plus 2e-5 (measured: 1.27e-4 against 1.39e-4).
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     b64 = {k: v.double() for k, v in b2.items()}
     compat, _ = O.compat_matrix(b64["src_keypts"], b64["tgt_keypts"], 1.2)
     o64 = O.classifier(sd64, O.encoder(sd64, b64["corr_pos"], compat, b64["p_tokens"], b64["q_tokens"], 12))
     floor = float((ref["logits"].double() - o64).abs().max())
-    assert _maxerr(m.last_logits.cpu(), ref["logits"]) < max(1e-4, 2 * floor), floor
-    assert float((m.last_logits.cpu().double() - o64).abs().max()) < max(1e-4, 2 * floor), floor
+    e64 = float((m.last_logits.cpu().double() - o64).abs().max())
+    print(f"kitti N=700: HIP vs fp64 {e64:.2e}, fp32 oracle vs fp64 {floor:.2e}, HIP vs fp32 oracle {_maxerr(m.last_logits.cpu(), ref['logits']):.2e}")
+    assert e64 < 1.5 * floor + 2e-5, (e64, floor)
+    assert _maxerr(m.last_logits.cpu(), ref["logits"]) < max(1e-4, 2.5 * floor + 2e-5), floor
     assert _maxerr(r2["final_trans"].cpu(), ref["final_trans"]) < 1e-3
 
 
@@ -1137,10 +1156,24 @@ def test_key_split_attention(golden_dir, model, N, splits):
         h.call("gmf_set_tuning", b"attn_key_splits", 0)
 
 
-def test_cpp_host_of_the_c_abi(tmp_path):
+def _write_dump(path, tensors):
+    """name -> array as the "GMFD" dump tests/abi_cpp/abi_host.cpp reads."""
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"GMFD" + struct.pack("<i", len(tensors)))
+        for name, a in tensors.items():
+            a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+            shp = list(a.shape) + [1] * (4 - a.ndim)
+            nb = name.encode()
+            f.write(struct.pack("<i", len(nb)) + nb + struct.pack("<i", a.ndim) + struct.pack("<4q", *shp))
+            f.write(a.tobytes())
+
+
+def test_cpp_host_of_the_c_abi(tmp_path, golden_dir, sd_full):
     """A C++ program (tests/abi_cpp/abi_host.cpp) drives libgmf_hip.so through include/gmf_hip.h with hipMalloc'd buffers -
-    no Python, no torch in that process: weighted Procrustes and the robust refinement recover known rigid motions,
-    and a bad call returns a status code with a message."""
+    no Python, no torch in that process.  The hot path: the state_dict tensors by name -> gmf_encoder_pack_weights ->
+    gmf_encoder_forward -> gmf_pose_head reproduce the reference's logits and pose (golden F4, N = 257) to 1e-4; then weighted
+    Procrustes and the robust refinement recover known rigid motions, and a bad call returns a status code with a message."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -1150,8 +1183,19 @@ def test_cpp_host_of_the_c_abi(tmp_path):
     build = subprocess.run([hipcc, "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "abi_cpp", "abi_host.cpp"),
                             "-L", libdir, "-lgmf_hip", f"-Wl,-rpath,{libdir}", "-o", exe], capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-2000:]
-    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-    assert run.returncode == 0 and "ABI host OK" in run.stdout, run.stdout[-2000:] + run.stderr[-1000:]
+    g = _load(golden_dir, "f4_f10_pointdsc.npz")
+    N = 257
+    b = synthetic.synthetic_batch(list(g[f"pair_seeds_N{N}"]), N=N, T=196)
+    dump = {k: v.numpy() for k, v in sd_full.items() if v.is_floating_point()}
+    for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens"):
+        dump["input." + k] = b[k].numpy()
+    dump["expect.logits"], dump["expect.final_trans"] = g[f"logits_N{N}"], g[f"final_trans_N{N}"]
+    dump["param.num_layers"] = np.array([12.0], np.float32)
+    path = str(tmp_path / "f4.gmfd")
+    _write_dump(path, dump)
+    run = subprocess.run([exe, path], capture_output=True, text=True, timeout=120)
+    print(run.stdout[-1500:])
+    assert run.returncode == 0 and "ABI host OK" in run.stdout and "hot path OK" in run.stdout, run.stdout[-2000:] + run.stderr[-1000:]
 
 
 @pytest.mark.parametrize("N", [1500, 3000])

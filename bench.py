@@ -262,6 +262,41 @@ def sweep(dev):
                      "unit": "correspondences/s", "step_frac_of_peak": tf / peak})
         del model, data
         torch.cuda.empty_cache()
+    # ragged batch: 32 pairs whose N is drawn from U[4000, 5500] (what the reference's evaluation loop sees pair by pair,
+    # evaluation/test_3DMatch.py:69) in ONE launch (gmf_encoder_forward_ragged + gmf_pose_head_ragged), against the same pairs
+    # fed one B = 1 call at a time
+    import numpy as np
+    from gmf_amd import synthetic
+    model, _, _ = build_model(dev, "3dmatch")
+    sizes = [int(n) for n in np.random.default_rng(77).integers(4000, 5501, size=32)]
+    pairs = [synthetic.synthetic_batch([900 + i], N=n, T=196) for i, n in enumerate(sizes)]
+    rag = {k: [b[k][0].to(dev) for b in pairs] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    rag["p_tokens"] = torch.cat([b["p_tokens"] for b in pairs]).to(dev)
+    rag["q_tokens"] = torch.cat([b["q_tokens"] for b in pairs]).to(dev)
+    packed = {k: torch.cat(rag[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    packed.update(p_tokens=rag["p_tokens"], q_tokens=rag["q_tokens"], n_points=sizes, testing=True)
+    singles = [{**{k: b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}, "testing": True} for b in pairs]
+
+    def timed(fn, n):
+        for _ in range(2):
+            fn()
+        best = float("inf")
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / n * 1e3)
+        return best
+
+    ms_r = timed(lambda: model(packed), 5)
+    ms_1 = timed(lambda: [model(d) for d in singles], 2)
+    rows.append({"workload": "3dmatch 32 pairs, N ~ U[4000, 5500] (sum %d), ONE ragged launch" % sum(sizes), "ms_per_step": ms_r,
+                 "value": sum(sizes) / (ms_r * 1e-3), "unit": "correspondences/s",
+                 "same_pairs_as_32_calls_with_B_1": {"ms": ms_1, "value": sum(sizes) / (ms_1 * 1e-3)}})
+    del model, rag, packed, singles, pairs
+    torch.cuda.empty_cache()
     # the throughput numerics modes (gmf_set_tuning "precision" = 1, 2; NOT the parity path, never the headline) on the headline
     # workload, with its measured deviation from the parity mode on the same batch
     from gmf_amd import _lib
@@ -312,8 +347,12 @@ def sweep(dev):
     wts = torch.cat([sc[2] for sc in scenes]).to(dev)
     off = [i * Nd for i in range(Bd + 1)]
     ms = best_ms(lambda: gmf_amd.weighted_procrustes_batched(X, Y, wts, off, np.finfo(np.float32).eps), 20)
+    wp_bytes = Bd * (28.0 * Nd + 48.0)               # 28 B per correspondence in, 48 B out per pair
     rows.append({"workload": "dgr weighted_procrustes, 32 problems x 8000 correspondences (config 5)", "ms_per_step": ms,
-                 "value": Bd * Nd / (ms * 1e-3), "unit": "correspondences/s"})
+                 "value": Bd * Nd / (ms * 1e-3), "unit": "correspondences/s",
+                 "roofline": {"bound": "hbm", "achieved": wp_bytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": wp_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                              "note": "latency-bound: 7 MB per launch - two passes of one workgroup per pair; the HBM figure is what the size implies, not what limits it"}})
     ms = best_ms(lambda: gmf_amd.global_registration_batched(X, Y, wts, off, break_threshold_ratio=1e-4, quantization_size=0.1), 5)
     rows.append({"workload": "dgr GlobalRegistration (Adam refinement to convergence), 32 problems x 8000 correspondences", "ms_per_step": ms,
                  "value": Bd * Nd / (ms * 1e-3), "unit": "correspondences/s"})
@@ -322,9 +361,10 @@ def sweep(dev):
     for M in (1000, 4000, 20000):
         xq, img = torch.randn(1, M, 256, device=dev), torch.randn(1, 300, 128, device=dev)
         ms = best_ms(lambda: pio(img, queries_encoder=xq), 10)
+        tf = M * (1713152 + 512 * 300) / (ms * 1e-3) / 1e12
         rows.append({"workload": f"dgr bottleneck PerceiverIO (256 wide, head 128), {M} voxels x 300 image tokens", "ms_per_step": ms,
-                     "value": M / (ms * 1e-3), "unit": "voxels/s",
-                     "algorithmic_tflops": M * (1713152 + 512 * 300) / (ms * 1e-3) / 1e12})
+                     "value": M / (ms * 1e-3), "unit": "voxels/s", "algorithmic_tflops": tf,
+                     "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}})
     return rows
 
 

@@ -121,6 +121,10 @@ SIGNATURES = {
     "gmf_packed_fusion_free": (None, [_vp]),
     "gmf_encoder_forward": (C.c_int, [_vp, C.POINTER(EncoderWeights), _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                       _vp, _vp, _vp, _vp]),
+    "gmf_encoder_forward_ragged": (C.c_int, [_vp, C.POINTER(EncoderWeights), _vp, _vp, _vp, _vp, _vp, _i32p, C.c_int, C.c_int,
+                                             _vp, _vp, _vp, _vp]),
+    "gmf_pose_head_ragged": (C.c_int, [_vp, C.POINTER(PoseParams), C.c_double, _vp, _vp, _vp, _vp, _i32p, C.c_int, _vp, _vp, _vp,
+                                       _vp, _vp, _vp, _vp]),
     "gmf_nonlocal_block_forward": (C.c_int, [_vp, C.POINTER(EncoderWeights), C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp,
                                              C.c_int, C.c_int, C.c_int, _vp]),
     "gmf_fusion_layer_forward": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll,

@@ -28,6 +28,9 @@ struct gmf_handle {
   hipStream_t last_stream = nullptr;
   bool have_last_stream = false;
   hipEvent_t xs_event = nullptr;
+  // host copies of the per-pair tables of ragged calls (two, alternating: an asynchronous upload may still be reading one)
+  std::vector<gmf::PairTab> ptab_host[2];
+  int ptab_flip = 0;
   // sticky status word in host-mapped memory (gmf_status_read): kernels OR bits into it through status_dev
   int* status_host = nullptr;
   int* status_dev = nullptr;

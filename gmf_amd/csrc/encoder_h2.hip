@@ -29,12 +29,17 @@ constexpr int kRing = GMF_H2_RING;   // LDS ring depth of the weight / context s
 template <int MODE>
 GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const int zsel_in, const float* __restrict__ in,
                               const float* __restrict__ wst, const float* __restrict__ vecs, float* __restrict__ f_out,
-                              float* __restrict__ q_out, float* __restrict__ k_out, float* __restrict__ v_out, int N, int tiles) {
+                              float* __restrict__ q_out, float* __restrict__ k_out, float* __restrict__ v_out, int N, int tiles,
+                              const PairTab* __restrict__ ptab = nullptr) {
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t row0 = pair_row0(ptab, pair, N);            // ragged batch (MODE 3 only): corr_pos is packed [sum n, 6]
+  N = pair_rows(ptab, pair, N);
+  const int tiles_p = ptab ? (N + 31) >> 5 : tiles;
+  if (bx * kWavesPerWG >= tiles_p) return;                 // (uniform per workgroup, before any barrier)
   const int tile_raw = bx * kWavesPerWG + wave;
-  const bool active = tile_raw < tiles;
-  const int tile = active ? tile_raw : tiles - 1;
+  const bool active = tile_raw < tiles_p;
+  const int tile = active ? tile_raw : tiles_p - 1;
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
 
   // gridDim.z == 3 (small grids): workgroup z recomputes PointCN (MODE 0 / 1) and produces ONE of Q' (z = 0, it also stores
@@ -60,7 +65,7 @@ GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const in
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int k = 4 * h + e;
-        pk[e] = (row < N && k < 6) ? in[((size_t)pair * N + row) * 6 + k] : 0.f;
+        pk[e] = (row < N && k < 6) ? in[(row0 + row) * 6 + k] : 0.f;
       }
       const float4* w0 = reinterpret_cast<const float4*>(vecs + 5 * C) + lane;
 #pragma unroll
@@ -132,10 +137,10 @@ template <int MODE>
 __global__ void __launch_bounds__(256, 2)
 k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const float* __restrict__ vecs,
            float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out,
-           float* __restrict__ v_out, int N, int tiles) {
+           float* __restrict__ v_out, int N, int tiles, const PairTab* __restrict__ ptab) {
   __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
   front_h2_body<MODE>(lds, blockIdx.x, blockIdx.y, gridDim.z == 3 ? (int)blockIdx.z : -1, in, wst, vecs, f_out, q_out, k_out, v_out,
-                      N, tiles);
+                      N, tiles, ptab);
 }
 
 // =========================================================================================
@@ -422,13 +427,18 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
                                const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
                                const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
                                float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles,
-                               int T, int ttiles) {
+                               int T, int ttiles, const PairTab* __restrict__ ptab = nullptr) {
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y;
+  // ragged batch: the pair's own rows and tiles - the LCPE's zero padding sits at ITS last row, row blocks beyond its tiles have
+  // nothing to do (uniform per workgroup, before any barrier); the slot in every image keeps the stride `tiles`
+  if (ptab) N = ptab[pair].n;
+  const int tiles_p = ptab ? (N + 31) >> 5 : tiles;
+  if ((int)blockIdx.x * kWavesPerWG >= tiles_p) return;
   const int tile_raw = blockIdx.x * kWavesPerWG + wave;
-  const bool active = tile_raw < tiles;
-  const int tile = active ? tile_raw : tiles - 1;
+  const bool active = tile_raw < tiles_p;
+  const int tile = active ? tile_raw : tiles_p - 1;
   const float* pair_base = f_in + (size_t)pair * tiles * (32 * C);
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
 
@@ -447,7 +457,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
   if (PART != 1) {
     dma_vec(attn_vec, lvec_a, 7 * C, wave, kWavesPerWG, lane);
     dma_vec(ff_vec, lvec_f, 3 * C + 2 * FFH, wave, kWavesPerWG, lane);
-    LcpeHalo<CF>::issue(pair_base, tile, tiles, halo, lane);
+    LcpeHalo<CF>::issue(pair_base, tile, tiles_p, halo, lane);
   }
   StageRing<4> ss;
   if (PART == 0) ss.init(lds, wave, lane, front_wst + 4 * kStageFloats, 12, attn_wst, 2,
@@ -653,10 +663,10 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
             const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
             const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
             float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
-            int ttiles) {
+            int ttiles, const PairTab* __restrict__ ptab) {
   __shared__ __attribute__((aligned(16))) float lds[kLinLdsFloats];
   linear_h2_body<0, NP>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
-                        tiles, T, ttiles);
+                        tiles, T, ttiles, ptab);
 }
 
 // grid (ceil(tiles / 4), B, 2): blockIdx.z = 0 the Q'/K/V role, 1 the Fusion-2 role of the same 128 rows
@@ -710,31 +720,31 @@ k_ff_reduce(const float* __restrict__ part, const float* __restrict__ x1, const 
 static inline dim3 tgrid(int tiles, int B, int sets = 1) { return dim3((tiles + kWavesPerWG - 1) / kWavesPerWG, B, sets); }
 
 hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
-                           float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s) {
+                           float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s, const PairTab* ptab) {
   dim3 g = tgrid(tiles, B);
   if (g.x * B < 128 && tune.front_split) g.z = 3;      // small grids: one workgroup per output (Q' + f | K | V)
-  if (mode == 3) { g.z = 1; hipLaunchKernelGGL(k_front_h2<3>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles); }
-  else if (mode == 1) hipLaunchKernelGGL(k_front_h2<1>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
-  else if (mode == 2) hipLaunchKernelGGL(k_front_h2<2>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
-  else hipLaunchKernelGGL(k_front_h2<0>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles);
+  if (mode == 3) { g.z = 1; hipLaunchKernelGGL(k_front_h2<3>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab); }
+  else if (mode == 1) hipLaunchKernelGGL(k_front_h2<1>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab);
+  else if (mode == 2) hipLaunchKernelGGL(k_front_h2<2>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab);
+  else hipLaunchKernelGGL(k_front_h2<0>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab);
   return hipGetLastError();
 }
 
 hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                             const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec, float* q,
                             float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s,
-                            bool one_product) {
+                            bool one_product, const PairTab* ptab) {
   // grids that give a CU about one workgroup: two roles per row block (the Q'/K/V projections | Fusion-2) in one launch
   const int W = ((tiles + 3) / 4) * B;
-  if (tune.mid_grid_roles > 0 && W < tune.mid_grid_roles)
+  if (tune.mid_grid_roles > 0 && W < tune.mid_grid_roles && !ptab)
     hipLaunchKernelGGL(k_linear_roles, tgrid(tiles, B, 2), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec,
                        ff_wst, ff_vec, q, k, v, x2, N, tiles, T, ttiles);
   else if (one_product)                            // throughput numerics mode: high planes only
     hipLaunchKernelGGL(k_linear_h2<1>, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
-                       ff_vec, q, k, v, x2, N, tiles, T, ttiles);
+                       ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab);
   else
     hipLaunchKernelGGL(k_linear_h2<3>, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
-                       ff_vec, q, k, v, x2, N, tiles, T, ttiles);
+                       ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab);
   return hipGetLastError();
 }
 

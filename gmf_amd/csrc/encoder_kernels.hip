@@ -549,11 +549,14 @@ constexpr int kJPerWave = 8;
 // the error structure of the reference's own fp32 rounding; profiles/r03_compat_formats.txt.)
 template <int FMT>
 __global__ void __launch_bounds__(256)
-k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int N, int tiles, float inv_sig2) {
+k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int N, int tiles, float inv_sig2,
+               const PairTab* __restrict__ ptab) {
   __shared__ float tr[4 * 32 * 33];
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.z, I = blockIdx.x;
+  const int tiles_p = (pair_rows(ptab, pair, N) + 31) >> 5;      // ragged batch: this pair's own tiles (the slot keeps `tiles`)
+  if (I >= tiles_p) return;
   const size_t pbase = (size_t)pair * tiles;
   float si[3], ti[3];
   {
@@ -589,7 +592,7 @@ k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int 
   };
   float* const mt = tr + wave * 32 * 33;
   const int j0 = (blockIdx.y * 4 + wave) * kJPerWave;
-  for (int J = max(j0, I); J < min(tiles, j0 + kJPerWave); ++J) {
+  for (int J = max(j0, I); J < min(tiles_p, j0 + kJPerWave); ++J) {
     const float4* lp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)J * 32) * 8) + 8 * h;
     float c[16];
 #pragma unroll
@@ -769,7 +772,7 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
                                 const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, int wgs_per_pair,
                                 const float* __restrict__ c_dense, int n_items, int n_full, int ksplits,
                                 float* __restrict__ part_o, float* __restrict__ part_ml, const float* __restrict__ next_wst,
-                                const float* __restrict__ next_bias) {
+                                const float* __restrict__ next_bias, const PairTab* __restrict__ ptab = nullptr) {
   float* const ldsK = lds;
   float* const ldsV = lds + 2 * kStageFloats;
   constexpr int WAVES = 4;
@@ -781,12 +784,17 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   const bool split = it.split;
   const int ks = it.ks;
   const int pair = it.item / wgs_per_pair, qblock = it.item - pair * wgs_per_pair;
+  // ragged batch: the pair's own row and tile counts (its slot in every image keeps the stride `tiles`); query blocks beyond
+  // them have nothing to do (uniform per workgroup, before any barrier)
+  if (ptab) N = ptab[pair].n;
+  const int tiles_p = ptab ? (N + 31) >> 5 : tiles;
+  if (qblock * WAVES >= tiles_p) return;
   // key tiles [t_begin, t_end) of this workgroup
-  const int t_begin = split ? (tiles * ks) / ksplits : 0;
-  const int t_end = split ? (tiles * (ks + 1)) / ksplits : tiles;
+  const int t_begin = split ? (tiles_p * ks) / ksplits : 0;
+  const int t_end = split ? (tiles_p * (ks + 1)) / ksplits : tiles_p;
   const int tile_raw = qblock * WAVES + wave;
-  const bool active = tile_raw < tiles;
-  const int tile = active ? tile_raw : tiles - 1;
+  const bool active = tile_raw < tiles_p;
+  const int tile = active ? tile_raw : tiles_p - 1;
   const size_t pbase = (size_t)pair * tiles;
   const size_t toff = (pbase + tile) * (32 * C);
 
@@ -1084,10 +1092,10 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
              const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
              float* __restrict__ out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_dense,
              int n_items, int n_full, int ksplits, float* __restrict__ part_o, float* __restrict__ part_ml,
-             const float* __restrict__ next_wst, const float* __restrict__ next_bias) {
+             const float* __restrict__ next_wst, const float* __restrict__ next_bias, const PairTab* __restrict__ ptab) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
   scattn_h2p_body<NPROD, CFMT>(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items,
-                             n_full, ksplits, part_o, part_ml, next_wst, next_bias);
+                             n_full, ksplits, part_o, part_ml, next_wst, next_bias, ptab);
 }
 
 // =========================================================================================
@@ -1824,13 +1832,18 @@ k_fusion_ff(const float* __restrict__ x1, const float* __restrict__ wst, const f
 // =========================================================================================
 __global__ void __launch_bounds__(256, 2)
 k_head(const float* __restrict__ feat_img, const float* __restrict__ wst, const float* __restrict__ vecs,
-       float* __restrict__ logits, float* __restrict__ feat_n, float* __restrict__ feat_rm, int N, int tiles, int* status) {
+       float* __restrict__ logits, float* __restrict__ feat_n, float* __restrict__ feat_rm, int N, int tiles, int* status,
+       const PairTab* __restrict__ ptab) {
   __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i = lane & 31;
   const int pair = blockIdx.y;
+  const size_t row0 = pair_row0(ptab, pair, N);            // ragged batch: the outputs are packed [sum n, ...]
+  N = pair_rows(ptab, pair, N);
+  const int tiles_p = (N + 31) >> 5;
+  if ((int)blockIdx.x * kWavesPerWG >= tiles_p) return;
   const int tile_raw = blockIdx.x * kWavesPerWG + wave;
-  const bool active = tile_raw < tiles;
-  const int tile = active ? tile_raw : tiles - 1;
+  const bool active = tile_raw < tiles_p;
+  const int tile = active ? tile_raw : tiles_p - 1;
   const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
   const int row = tile * 32 + i;
 
@@ -1878,7 +1891,7 @@ k_head(const float* __restrict__ feat_img, const float* __restrict__ wst, const 
   const float inv = 1.0f / fmaxf(sqrtf(nrm2), 1e-12f);
 
   if (active && row < N) {
-    const size_t ro = ((size_t)pair * N + row);
+    const size_t ro = row0 + row;
     if (h == 0) logits[ro] = logit;
     float4* pn = reinterpret_cast<float4*>(feat_n + ro * C) + h;
 #pragma unroll
@@ -1902,17 +1915,23 @@ k_head(const float* __restrict__ feat_img, const float* __restrict__ wst, const 
 // =========================================================================================
 __global__ void __launch_bounds__(256, 2)
 k_seed_dist(const float* __restrict__ featn_img, const int* __restrict__ seeds, float* __restrict__ dist,
-            int N, int tiles, int S, int chunks) {
+            int N, int tiles, int S, int chunks, const PairTab* __restrict__ ptab) {
   __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y / chunks, chunk = blockIdx.y - pair * chunks;   // key tiles are split over `chunks` workgroups
-  const int per = (tiles + chunks - 1) / chunks;
-  const int t0 = chunk * per, t1 = min(tiles, t0 + per);
+  // ragged batch: the pair's own rows / tiles / seeds; the image slot and the distance rows keep the strides of the largest pair
+  const int Nmax = N, Smax = S;
+  N = pair_rows(ptab, pair, N);
+  S = ptab ? ptab[pair].S : S;
+  const int tiles_p = (N + 31) >> 5;
+  if ((int)blockIdx.x * kWavesPerWG * 32 >= S) return;        // (uniform per workgroup, before any barrier)
+  const int per = (tiles_p + chunks - 1) / chunks;
+  const int t0 = chunk * per, t1 = min(tiles_p, t0 + per);
   const int seed_base = (blockIdx.x * kWavesPerWG + wave) * 32;
   const float* pair_img = featn_img + (size_t)pair * tiles * (32 * C);
   const int my = seed_base + i;
-  const int row = (my < S) ? seeds[(size_t)pair * S + my] : 0;
+  const int row = (my < S) ? seeds[(size_t)pair * Smax + my] : 0;
   float sf[CF];
   load_row_frag_p32<CF>(sf, pair_img, row, N, h);
   if (t0 >= t1) return;                         // uniform over the workgroup
@@ -1924,7 +1943,7 @@ k_seed_dist(const float* __restrict__ featn_img, const int* __restrict__ seeds, 
   StageStream ss;
   ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, pair_img + (size_t)t0 * kStageFloats, t1 - t0);
   ss.prime();
-  float* drow = dist + ((size_t)pair * S) * N;
+  float* drow = dist + ((size_t)pair * Smax) * Nmax;
   for (int t = t0; t < t1; ++t) {
     const float4* lk = ss.acquire();
     f32x16 acc = zero16();
@@ -1945,7 +1964,7 @@ k_seed_dist(const float* __restrict__ featn_img, const int* __restrict__ seeds, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int sd = seed_base + 8 * (r >> 2) + 4 * h + (r & 3);
-        if (sd < S) drow[(size_t)sd * N + j] = 2.0f - 2.0f * acc[r];
+        if (sd < S) drow[(size_t)sd * Nmax + j] = 2.0f - 2.0f * acc[r];
       }
     }
   }
@@ -1956,7 +1975,7 @@ k_seed_dist(const float* __restrict__ featn_img, const int* __restrict__ seeds, 
 // =========================================================================================
 // strided [B, n_rows, K] (element (b,r,k) at b*sb + r*sr + k*sk) -> P32 image [B, tiles, 32*K]; rows >= n_rows are 0
 __global__ void k_pack_p32(const float* __restrict__ src, float* __restrict__ dst, int n_rows, int tiles, int K,
-                           long sb, long sr, long sk, long total4) {
+                           long sb, long sr, long sk, long total4, const PairTab* __restrict__ ptab) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
   const int lane = idx & 63;
@@ -1969,8 +1988,8 @@ __global__ void k_pack_p32(const float* __restrict__ src, float* __restrict__ ds
   const int row = tile * 32 + (lane & 31);
   const int k0 = 8 * g + 4 * (lane >> 5);
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row < n_rows) {
-    const float* p = src + b * sb + (long)row * sr + (long)k0 * sk;
+  if (row < pair_rows(ptab, (int)b, n_rows)) {      // ragged batch: pair b's rows start at row0 of the packed [sum n, K] tensor
+    const float* p = src + (ptab ? (long)ptab[b].row0 * sr : b * sb) + (long)row * sr + (long)k0 * sk;
     v = make_float4(p[0], p[sk], p[2 * sk], p[3 * sk]);
   }
   reinterpret_cast<float4*>(dst)[idx] = v;
@@ -2001,15 +2020,16 @@ __global__ void k_unpack_p32(const float* __restrict__ src, float* __restrict__ 
 
 // src,tgt [B,N,3] -> pts8 [B, Npad, 8] (zero padded rows)
 __global__ void k_pack_pts8(const float* __restrict__ src, const float* __restrict__ tgt, float* __restrict__ dst,
-                            int N, int Npad, long total) {
+                            int N, int Npad, long total, const PairTab* __restrict__ ptab) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int row = idx % Npad;
   const long b = idx / Npad;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-  if (row < N) {
-    const float* ps = src + (b * N + row) * 3;
-    const float* pt = tgt + (b * N + row) * 3;
+  if (row < pair_rows(ptab, (int)b, N)) {
+    const size_t r0 = pair_row0(ptab, (int)b, N) + row;
+    const float* ps = src + r0 * 3;
+    const float* pt = tgt + r0 * 3;
     a = make_float4(ps[0], ps[1], ps[2], 0.f);
     c = make_float4(pt[0], pt[1], pt[2], 0.f);
   }
@@ -2051,12 +2071,13 @@ hipError_t launch_front(int mode, const float* in, const float* wst, const float
   return hipGetLastError();
 }
 
-hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, int fmt, hipStream_t s) {
+hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, int fmt, hipStream_t s,
+                               const PairTab* ptab) {
   const dim3 grid(tiles, (tiles + 4 * kJPerWave - 1) / (4 * kJPerWave), B);
   const float inv = 1.0f / (sigma_d * sigma_d);
-  if (fmt == 1) hipLaunchKernelGGL(k_compat_build<1>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, inv);
-  else if (fmt == 2) hipLaunchKernelGGL(k_compat_build<2>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, inv);
-  else hipLaunchKernelGGL(k_compat_build<0>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, inv);
+  if (fmt == 1) hipLaunchKernelGGL(k_compat_build<1>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, inv, ptab);
+  else if (fmt == 2) hipLaunchKernelGGL(k_compat_build<2>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, inv, ptab);
+  else hipLaunchKernelGGL(k_compat_build<0>, grid, dim3(256), 0, s, pts8, c_dense, N, tiles, inv, ptab);
   return hipGetLastError();
 }
 
@@ -2139,6 +2160,7 @@ hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, 
     const int per_xcd = (W >> 3) + ((W & 7) ? 1 : 0);
     int n_full, ksplits;
     plan_attn_split(tune, W, tiles, cc->part_o ? cc->max_splits : 0, &n_full, &ksplits);
+    if (cc->ptab) { n_full = per_xcd; ksplits = 1; }       // ragged batch: whole items only (the key-split forms assume one N)
     const int max_tail = std::max(0, per_xcd - n_full);
     const dim3 grid(8 * (std::min(n_full, per_xcd) + max_tail * ksplits));
     if (cc->half && max_tail == 0)   // throughput numerics mode, whole items only: the three-tiles-in-flight form
@@ -2146,13 +2168,13 @@ hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, 
                          cc->next_wst_h2, cc->next_bias);
     else if (cc->half)  // ... with a split tail: one fp16 product, c streamed as fp16 (the cache was built that way)
       hipLaunchKernelGGL((k_scattn_h2p<1, 1>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, W,
-                         n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias);
+                         n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab);
     else if (cc->fmt == 2)   // parity arithmetic, c streamed as 16-bit fixed point
       hipLaunchKernelGGL((k_scattn_h2p<3, 2>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
-                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias);
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab);
     else
       hipLaunchKernelGGL((k_scattn_h2p<3, 0>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
-                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias);
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab);
     if (max_tail > 0)
       hipLaunchKernelGGL(k_scattn_merge, dim3(8 * max_tail), dim3(256), 0, s, cc->part_o, cc->part_ml, fus, cc->tail_wst_h2, vecs, out,
                          tiles, wpp, W, n_full, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)nullptr, 0,
@@ -2189,24 +2211,24 @@ hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs
 }
 
 hipError_t launch_head(const float* feat_img, const float* wst, const float* vecs, float* logits, float* feat_n,
-                       float* feat_rm, int B, int N, int tiles, hipStream_t s, int* status) {
-  hipLaunchKernelGGL(k_head, tile_grid(tiles, B), dim3(256), 0, s, feat_img, wst, vecs, logits, feat_n, feat_rm, N, tiles, status);
+                       float* feat_rm, int B, int N, int tiles, hipStream_t s, int* status, const PairTab* ptab) {
+  hipLaunchKernelGGL(k_head, tile_grid(tiles, B), dim3(256), 0, s, feat_img, wst, vecs, logits, feat_n, feat_rm, N, tiles, status, ptab);
   return hipGetLastError();
 }
 
-hipError_t launch_seed_dist(const float* featn_img, const int* seeds, float* dist, int B, int N, int S, hipStream_t s) {
+hipError_t launch_seed_dist(const float* featn_img, const int* seeds, float* dist, int B, int N, int S, hipStream_t s, const PairTab* ptab) {
   const int tiles = (N + 31) / 32;
   const int sblocks = (S + 127) / 128;
   int chunks = 1;                                  // enough workgroups to fill 256 CUs twice over
   while (chunks < 16 && sblocks * B * chunks < 1024 && tiles / (2 * chunks) >= 4) chunks *= 2;
-  hipLaunchKernelGGL(k_seed_dist, dim3(sblocks, B * chunks), dim3(256), 0, s, featn_img, seeds, dist, N, tiles, S, chunks);
+  hipLaunchKernelGGL(k_seed_dist, dim3(sblocks, B * chunks), dim3(256), 0, s, featn_img, seeds, dist, N, tiles, S, chunks, ptab);
   return hipGetLastError();
 }
 
-hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s) {
+hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s, const PairTab* ptab) {
   const int tiles = (n_rows + 31) / 32;
   const long total4 = (long)B * tiles * (K / 8) * 64;
-  hipLaunchKernelGGL(k_pack_p32, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, src, dst, n_rows, tiles, K, sb, sr, sk, total4);
+  hipLaunchKernelGGL(k_pack_p32, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, src, dst, n_rows, tiles, K, sb, sr, sk, total4, ptab);
   return hipGetLastError();
 }
 
@@ -2217,10 +2239,10 @@ hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, in
   return hipGetLastError();
 }
 
-hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s) {
+hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s, const PairTab* ptab) {
   const int Npad = ((N + 31) / 32) * 32;
   const long total = (long)B * Npad;
-  hipLaunchKernelGGL(k_pack_pts8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, tgt, dst, N, Npad, total);
+  hipLaunchKernelGGL(k_pack_pts8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, tgt, dst, N, Npad, total, ptab);
   return hipGetLastError();
 }
 

@@ -375,16 +375,65 @@ static int run_scattn(gmf_handle* h, const gmf_encoder_weights* w, int l, const 
   return GMF_OK;
 }
 
+// Host table of a ragged batch -> h->ptab_host (kept alive in the handle: the upload is asynchronous) ; returns max n, sum n.
+// ratio < 0: the encoder's table (S, k unused).
+static int build_pair_table(gmf_handle* h, const int* n_points, int B, double ratio, int k, int* n_max, long long* n_sum, int* s_max) {
+  h->ptab_flip ^= 1;
+  std::vector<gmf::PairTab>& tab = h->ptab_host[h->ptab_flip];
+  tab.resize((size_t)B);
+  long long row = 0;
+  int nm = 0, sm = 0;
+  for (int b = 0; b < B; ++b) {
+    const int n = n_points[b];
+    GMF_REQUIRE(n > 0, GMF_ERR_UNSUPPORTED_SHAPE, "ragged batch: every pair needs at least one correspondence");
+    GMF_REQUIRE(row + n <= 0x7fffffffLL, GMF_ERR_UNSUPPORTED_SHAPE, "ragged batch: more than 2^31 rows");
+    const int Sb = ratio >= 0.0 ? (int)((double)n * ratio) : 0;     // S = int(N * ratio)   PointDSC.py:244
+    tab[b] = gmf::PairTab{(int)row, n, Sb, k};
+    row += n;
+    nm = n > nm ? n : nm;
+    sm = Sb > sm ? Sb : sm;
+  }
+  *n_max = nm;
+  *n_sum = row;
+  if (s_max) *s_max = sm;
+  return GMF_OK;
+}
+
+static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, const float* corr_pos, const float* src_keypts,
+                                const float* tgt_keypts, const float* p_tokens, const float* q_tokens, int B, int N, int T,
+                                float* logits, float* feat_n, float* feat, gmf_stream_t stream, const int* n_points);
+
 int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float* corr_pos, const float* src_keypts,
                         const float* tgt_keypts, const float* p_tokens, const float* q_tokens, int B, int N, int T,
                         float* logits, float* feat_n, float* feat, gmf_stream_t stream) {
   GMF_REQUIRE(h, GMF_ERR_BAD_ARG, "encoder_forward: null handle");
+  GMF_REQUIRE(B > 0 && N > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "encoder_forward: empty input");
+  return encoder_forward_impl(h, w, corr_pos, src_keypts, tgt_keypts, p_tokens, q_tokens, B, N, T, logits, feat_n, feat, stream, nullptr);
+}
+
+int gmf_encoder_forward_ragged(gmf_handle* h, const gmf_encoder_weights* w, const float* corr_pos, const float* src_keypts,
+                               const float* tgt_keypts, const float* p_tokens, const float* q_tokens, const int* n_points, int B,
+                               int T, float* logits, float* feat_n, float* feat, gmf_stream_t stream) {
+  GMF_REQUIRE(h, GMF_ERR_BAD_ARG, "encoder_forward_ragged: null handle");
+  GMF_REQUIRE(n_points, GMF_ERR_BAD_ARG, "encoder_forward_ragged: null n_points");
+  GMF_REQUIRE(B > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "encoder_forward_ragged: empty input");
+  return encoder_forward_impl(h, w, corr_pos, src_keypts, tgt_keypts, p_tokens, q_tokens, B, 0, T, logits, feat_n, feat, stream, n_points);
+}
+
+static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, const float* corr_pos, const float* src_keypts,
+                                const float* tgt_keypts, const float* p_tokens, const float* q_tokens, int B, int N, int T,
+                                float* logits, float* feat_n, float* feat, gmf_stream_t stream, const int* n_points) {
   if (int rc = check_weights(h, w)) return rc;
   GMF_REQUIRE(corr_pos && src_keypts && tgt_keypts && p_tokens && q_tokens && logits && feat_n, GMF_ERR_BAD_ARG,
               "encoder_forward: null pointer");
-  GMF_REQUIRE(B > 0 && N > 0 && T > 0, GMF_ERR_UNSUPPORTED_SHAPE, "encoder_forward: empty input");
   SetDevice sd(h, stream);
   hipStream_t st = S(stream);
+  // ragged batch: per-pair sizes from the host; every image keeps a slot of tiles(max n) tiles per pair
+  const bool ragged = n_points != nullptr;
+  if (ragged) {
+    long long n_sum = 0;
+    if (int rc = build_pair_table(h, n_points, B, -1.0, 0, &N, &n_sum, nullptr)) return rc;
+  }
   const int L = w->num_layers;
   const int tiles = tiles_of(N), tt = tiles_of(T);
   const size_t act = (size_t)B * tiles * kTileFloats;
@@ -403,8 +452,15 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   const size_t split_need = want_split ? arena_need((size_t)kMaxSplits * act, 4) + arena_need((size_t)kMaxSplits * B * tiles * 64, 4) +
                                              (kMaxSplits == 8 ? arena_need((size_t)8 * act, 4) : 0) : 0;
   const size_t need = 8 * arena_need(act, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +
-                      5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4) + cache_need + split_need;
+                      5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4) + cache_need + split_need +
+                      arena_need((size_t)B, sizeof(gmf::PairTab));
   if (int rc = arena_reserve(h, need)) return rc;
+  const gmf::PairTab* ptab = nullptr;
+  if (ragged) {
+    gmf::PairTab* dtab = arena_take<gmf::PairTab>(h, (size_t)B);
+    GMF_HIP(hipMemcpyAsync(dtab, h->ptab_host[h->ptab_flip].data(), (size_t)B * sizeof(gmf::PairTab), hipMemcpyHostToDevice, st));
+    ptab = dtab;
+  }
   float* featA = arena_take<float>(h, act);
   float* featB = arena_take<float>(h, act);
   float* f = arena_take<float>(h, act);
@@ -455,16 +511,17 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
     else GMF_HIP(gmf::launch_ctx_prep(true, imgfeat, w->ctx_wst, w->ctx_vec, ctxall, B, T, tt, L, w->ctx_wst_stride,
                                       w->ctx_vec_stride, st));
   }
-  GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st));
+  GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st, ptab));
   // throughput numerics ("precision" = 1, 2): on the two-launch path of large grids the attention multiplies one fp16
   // product and streams the compat matrix as fp16 (level 2: the layer's linear stages multiply one product as well); every
   // other path keeps the parity numerics
   cc.half = h->tune.precision >= 1 && h2 && L > 0 && want_cache && h->tune.fused_linear && h->tune.scattn_variant == 18 &&
-            ((tiles + 3) / 4) * B >= 256;
+            ((tiles + 3) / 4) * B >= 256 && !ragged;
   // the cache's element format: fp16 c in the throughput mode; else the handle's "compat_format" wherever the pipelined
   // kernel (variant 18) is the cache's only reader
   cc.fmt = cc.half ? 1 : (want_cache && h->tune.scattn_variant == 18) ? h->tune.compat_format : 0;
-  if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, cc.fmt, st));
+  cc.ptab = ptab;
+  if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, cc.fmt, st, ptab));
 
   float* cur = featA;
   float* nxt = featB;
@@ -473,15 +530,18 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
   //   k_linear_h2 : f -> Q', K, V (split-fp16 images) and x2 = Fusion-2(f)        (small grids: the three split-capable kernels)
   //   k_scattn_h2p: Q', K, V, c, x2 -> f_{l+1} = ReLU(PointCN_{l+1}(fc_message(attention) + x2))   (last layer: the features)
   const bool fuse = h2 && L > 0 && want_cache && h->tune.fused_linear && h->tune.scattn_variant == 18;
+  GMF_REQUIRE(fuse || !ragged, GMF_ERR_UNSUPPORTED_SHAPE,
+              "encoder_forward_ragged: ragged batches run on the default path only (split-fp16 weight images, at least two layers, the "
+              "compat cache, \"fused_linear\" = 1, \"scattn_variant\" = 18)");
   if (fuse) {
     const int Wg = ((tiles + 3) / 4) * B;
-    const bool one_kernel = Wg >= 256;      // below: key / hidden / output splits fill the chip better
+    const bool one_kernel = Wg >= 256 || ragged;      // below: key / hidden / output splits fill the chip better (uniform batches)
     // small grids: when both the attention and the feed-forward are split anyway, their workgroups share launches
     int small_nf = 1, small_ks = 1;
     gmf::plan_attn_split(h->tune, Wg, tiles, cc.part_o ? cc.max_splits : 0, &small_nf, &small_ks);
     const int ff_hs = cc.part_o ? gmf::plan_ff_split(h->tune, Wg, cc.max_splits) : 1;
     const bool small3 = !one_kernel && h->tune.small_roles && small_nf == 0 && small_ks > 1 && ff_hs > 1 && ff_part;
-    GMF_HIP(gmf::launch_front_h2(h->tune, 3, corr_pos, w->front_wst_h2, w->front_vec, f, q, k, v, B, N, tiles, st));
+    GMF_HIP(gmf::launch_front_h2(h->tune, 3, corr_pos, w->front_wst_h2, w->front_vec, f, q, k, v, B, N, tiles, st, ptab));
     for (int l = 0; l < L; ++l) {
       const float* fw = w->front_wst_h2 + (size_t)l * w->front_wst_stride;
       const float* fv = w->front_vec + (size_t)l * w->front_vec_stride;
@@ -491,7 +551,8 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
       const float* ffv = w->ff_vec + (size_t)l * w->ff_vec_stride;
       const float* ctx_l = ctxall + (size_t)l * tok;
       if (one_kernel) {
-        GMF_HIP(gmf::launch_linear_h2(h->tune, f, fw, fv, ctx_l, aw, av, ffw, ffv, q, k, v, x2, B, N, tiles, T, tt, st, cc.half && h->tune.precision == 2));
+        GMF_HIP(gmf::launch_linear_h2(h->tune, f, fw, fv, ctx_l, aw, av, ffw, ffv, q, k, v, x2, B, N, tiles, T, tt, st,
+                                      cc.half && h->tune.precision == 2, ptab));
       } else if (small3) {
         // three launches: {Q' | K | V | cross-attention} -> {key-split attention | hidden-split feed-forward} -> merge
         GMF_HIP(gmf::launch_small_front_fattn(f, fw, fv, ctx_l, aw, av, q, k, v, x1, B, N, tiles, T, tt, st));
@@ -518,7 +579,7 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
       cc.next_bias = last ? nullptr : w->front_vec + (size_t)(l + 1) * w->front_vec_stride;
       if (int rc = run_scattn(h, w, l, q, k, v, pts8, x2, last ? cur : f, B, N, st, nullptr, &cc)) return rc;
     }
-    GMF_HIP(gmf::launch_head(cur, w->head_wst, w->head_vec, logits, feat_n, feat, B, N, tiles, st, h->status_dev));
+    GMF_HIP(gmf::launch_head(cur, w->head_wst, w->head_vec, logits, feat_n, feat, B, N, tiles, st, h->status_dev, ptab));
     return GMF_OK;
   }
   if (L == 0) {
@@ -665,13 +726,53 @@ int gmf_pick_seeds(gmf_handle* h, const float* src_keypts, const float* scores, 
   return GMF_OK;
 }
 
+static int pose_head_impl(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, const float* src_keypts,
+                          const float* tgt_keypts, const float* logits, const int* seeds_in, int B, int N, float* final_trans,
+                          float* final_labels, int* seeds_out, int* knn_out, float* seed_trans, float* fitness,
+                          gmf_stream_t stream, const int* n_points, double ratio);
+
 int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, const float* src_keypts,
                   const float* tgt_keypts, const float* logits, const int* seeds_in, int B, int N, float* final_trans,
                   float* final_labels, int* seeds_out, int* knn_out, float* seed_trans, float* fitness,
                   gmf_stream_t stream) {
-  GMF_REQUIRE(h && p && feat_n && src_keypts && tgt_keypts && final_trans && final_labels, GMF_ERR_BAD_ARG, "pose_head: null pointer");
+  GMF_REQUIRE(h && p, GMF_ERR_BAD_ARG, "pose_head: null pointer");
+  GMF_REQUIRE(B > 0 && N > 1, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: need N > 1");
+  return pose_head_impl(h, p, feat_n, src_keypts, tgt_keypts, logits, seeds_in, B, N, final_trans, final_labels, seeds_out, knn_out,
+                        seed_trans, fitness, stream, nullptr, 0.0);
+}
+
+int gmf_pose_head_ragged(gmf_handle* h, const gmf_pose_params* p, double ratio, const float* feat_n, const float* src_keypts,
+                         const float* tgt_keypts, const float* logits, const int* n_points, int B, float* final_trans,
+                         float* final_labels, int* seeds_out, int* knn_out, float* seed_trans, float* fitness,
+                         gmf_stream_t stream) {
+  GMF_REQUIRE(h && p && n_points, GMF_ERR_BAD_ARG, "pose_head_ragged: null pointer");
+  GMF_REQUIRE(B > 0, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head_ragged: empty batch");
+  GMF_REQUIRE(ratio > 0.0 && ratio <= 1.0, GMF_ERR_BAD_ARG, "pose_head_ragged: ratio must be in (0, 1]");
+  GMF_REQUIRE(logits, GMF_ERR_BAD_ARG, "pose_head_ragged: the seeds come from the logits (no caller-provided seeds)");
+  return pose_head_impl(h, p, feat_n, src_keypts, tgt_keypts, logits, nullptr, B, 0, final_trans, final_labels, seeds_out, knn_out,
+                        seed_trans, fitness, stream, n_points, ratio);
+}
+
+static int pose_head_impl(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, const float* src_keypts,
+                          const float* tgt_keypts, const float* logits, const int* seeds_in, int B, int N, float* final_trans,
+                          float* final_labels, int* seeds_out, int* knn_out, float* seed_trans, float* fitness,
+                          gmf_stream_t stream, const int* n_points, double ratio) {
+  GMF_REQUIRE(feat_n && src_keypts && tgt_keypts && final_trans && final_labels, GMF_ERR_BAD_ARG, "pose_head: null pointer");
   GMF_REQUIRE(seeds_in || logits, GMF_ERR_BAD_ARG, "pose_head: need logits or seeds_in");
-  const int Sn = p->num_seeds, k = p->k, iters = p->num_iterations;
+  const bool ragged = n_points != nullptr;
+  int Sn = p->num_seeds;
+  const int k = p->k, iters = p->num_iterations;
+  long long n_sum = (long long)B * N;
+  SetDevice sd(h, stream);
+  if (ragged) {
+    // per-pair sizes from the host: S = int(n * ratio) seeds each; N, Sn below are the largest pair's (grids, buffer strides)
+    if (int rc = build_pair_table(h, n_points, B, ratio, k, &N, &n_sum, &Sn)) return rc;
+    for (int b = 0; b < B; ++b) {
+      GMF_REQUIRE(n_points[b] > k, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head_ragged: every pair needs more than k correspondences (k = min(k, N - 1) "
+                                                               "per pair is not supported in a ragged batch: run such a pair on its own)");
+      GMF_REQUIRE((int)((double)n_points[b] * ratio) >= 1, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head_ragged: a pair would have no seed (int(n * ratio) = 0)");
+    }
+  }
   GMF_REQUIRE(B > 0 && N > 1, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: need N > 1");
   GMF_REQUIRE(Sn > 0 && Sn <= N, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: need 0 < num_seeds <= N");
   GMF_REQUIRE(k > 0 && k <= 64 && k <= N - 1, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: need 0 < k <= min(64, N-1)");
@@ -679,13 +780,13 @@ int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, 
   GMF_REQUIRE(N <= 16384 || seeds_in, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: N > 16384 needs caller-provided seeds");
   GMF_REQUIRE((size_t)N * 4 <= 150 * 1024, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: N too large for the in-LDS kNN (max 38400)");
   GMF_REQUIRE(p->sigma > 0.f && p->sigma_d > 0.f, GMF_ERR_BAD_ARG, "pose_head: sigma, sigma_d must be positive");
-  SetDevice sd(h, stream);
   hipStream_t st = S(stream);
   const size_t BS = (size_t)B * Sn;
   const size_t need = arena_need((size_t)B * N, 4) + arena_need(BS, 4) + arena_need(BS * k, 4) +
                       arena_need(BS * iters * k, 4) + arena_need(BS * iters, 1) + arena_need(BS * 16, 4) +
                       arena_need(BS, 4) + arena_need(BS, 4) + arena_need(B, 4) + arena_need(BS * 15, 8) + arena_need(1, 4) +
-                      arena_need((size_t)B * tiles_of(N) * kTileFloats, 4) + arena_need(BS * N, 4);
+                      arena_need((size_t)B * tiles_of(N) * kTileFloats, 4) + arena_need(BS * N, 4) +
+                      arena_need((size_t)B, sizeof(gmf::PairTab));
   if (int rc = arena_reserve(h, need)) return rc;
   float* fimg = arena_take<float>(h, (size_t)B * tiles_of(N) * kTileFloats);
   float* dmat = arena_take<float>(h, BS * N);
@@ -700,6 +801,17 @@ int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, 
   int* best = arena_take<int>(h, B);
   double* hsum = arena_take<double>(h, BS * 15);
   int* stop_it = arena_take<int>(h, 1);
+  const gmf::PairTab* ptab = nullptr;
+  if (ragged) {
+    gmf::PairTab* dtab = arena_take<gmf::PairTab>(h, (size_t)B);
+    GMF_HIP(hipMemcpyAsync(dtab, h->ptab_host[h->ptab_flip].data(), (size_t)B * sizeof(gmf::PairTab), hipMemcpyHostToDevice, st));
+    ptab = dtab;
+    // per-seed outputs are [B, S_max, ...] slots: the slots behind a pair's own seeds are defined (zero), not left-over memory
+    if (seeds_out) GMF_HIP(hipMemsetAsync(seeds_out, 0, BS * sizeof(int), st));
+    if (knn_out) GMF_HIP(hipMemsetAsync(knn_out, 0, BS * k * sizeof(int), st));
+    if (seed_trans) GMF_HIP(hipMemsetAsync(seed_trans, 0, BS * 16 * sizeof(float), st));
+    if (fitness) GMF_HIP(hipMemsetAsync(fitness, 0, BS * sizeof(float), st));
+  }
   if (seeds_out) seeds = seeds_out;
   if (knn_out) knn = knn_out;
   if (seed_trans) sT = seed_trans;
@@ -711,23 +823,23 @@ int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, 
     if (p->use_nms) {
       // dmat is free until k_seed_dist: it doubles as the grid-binning scratch of the NMS when it is large enough
       float* scr = (BS * N >= gmf::nms_scratch_floats(B, N)) ? dmat : nullptr;
-      GMF_HIP(gmf::launch_nms_keys(h->tune, src_keypts, logits, keys, B, N, p->nms_radius, st, scr));
+      GMF_HIP(gmf::launch_nms_keys(h->tune, src_keypts, logits, keys, B, N, p->nms_radius, st, scr, ptab, (long)n_sum));
       kk = keys;
     }
-    GMF_HIP(gmf::launch_sort_topk(h->tune, kk, seeds, B, N, Sn, st));
+    GMF_HIP(gmf::launch_sort_topk(h->tune, kk, seeds, B, N, Sn, st, ptab));
     seeds_use = seeds;
   } else if (seeds_out) {
     GMF_HIP(hipMemcpyAsync(seeds_out, seeds_in, BS * sizeof(int), hipMemcpyDeviceToDevice, st));
   }
   // feature-space distances of the seed rows by MFMA (k_seed_dist), then per-seed top-(k+1) selection
-  GMF_HIP(gmf::launch_pack_p32(feat_n, fimg, B, N, kC, (long)N * kC, kC, 1, st));
-  GMF_HIP(gmf::launch_seed_dist(fimg, seeds_use, dmat, B, N, Sn, st));
-  GMF_HIP(gmf::launch_knn_seeds(feat_n, seeds_use, dmat, knn, B, N, Sn, k, st));
-  GMF_HIP(gmf::launch_seed_power(feat_n, src_keypts, tgt_keypts, knn, snaps, conv, hsum, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));
-  GMF_HIP(gmf::launch_seed_kabsch(src_keypts, tgt_keypts, knn, snaps, conv, sT, B, N, Sn, k, iters, hsum, stop_it, st));
-  GMF_HIP(gmf::launch_score_hyp(src_keypts, tgt_keypts, sT, counts, B, N, Sn, p->inlier_threshold, st));
+  GMF_HIP(gmf::launch_pack_p32(feat_n, fimg, B, N, kC, (long)N * kC, kC, 1, st, ptab));
+  GMF_HIP(gmf::launch_seed_dist(fimg, seeds_use, dmat, B, N, Sn, st, ptab));
+  GMF_HIP(gmf::launch_knn_seeds(feat_n, seeds_use, dmat, knn, B, N, Sn, k, st, ptab));
+  GMF_HIP(gmf::launch_seed_power(feat_n, src_keypts, tgt_keypts, knn, snaps, conv, hsum, B, N, Sn, k, iters, p->sigma, p->sigma_d, st, ptab));
+  GMF_HIP(gmf::launch_seed_kabsch(src_keypts, tgt_keypts, knn, snaps, conv, sT, B, N, Sn, k, iters, hsum, stop_it, st, ptab));
+  GMF_HIP(gmf::launch_score_hyp(src_keypts, tgt_keypts, sT, counts, B, N, Sn, p->inlier_threshold, st, ptab));
   GMF_HIP(gmf::launch_finalize_pose(src_keypts, tgt_keypts, sT, counts, fit, final_trans, final_labels, best, B, N, Sn,
-                                    p->inlier_threshold, p->refine_threshold, p->refine_iters, st));
+                                    p->inlier_threshold, p->refine_threshold, p->refine_iters, st, ptab));
   return GMF_OK;
 }
 

@@ -4,6 +4,13 @@
 
 namespace gmf {
 
+// Ragged batches (gmf_encoder_forward_ragged / gmf_pose_head_ragged): pair b owns rows [row0, row0 + n) of the caller's packed
+// row-major tensors ([sum n, ...]); S = int(n * ratio) seeds and k = min(k, n - 1) neighbours in the pose head.  The table is
+// built on the host from the caller's per-pair sizes and uploaded with the call.  Kernels take a nullable pointer: null =
+// the uniform batch [B, N, ...].  Internally every pair keeps a slot of tiles(max n) tiles; a pair's tiles beyond its own are
+// neither computed nor read.
+struct PairTab { int row0, n, S, k; };
+
 // compat matrix built once per batch by launch_compat_build (see k_compat_build): [B, tiles, tiles, 1024] floats
 struct CompatCache {
   const float* dense;
@@ -17,6 +24,7 @@ struct CompatCache {
   const float* next_bias = nullptr;
   bool half = false;          // `dense` holds fp16 tiles (2 KiB each) and the attention multiplies one fp16 product: the
                               // throughput numerics mode (Tuning::precision = 1), large grids only (then fmt = 1)
+  const PairTab* ptab = nullptr;   // ragged batch: per-pair rows (device), else null
   int fmt = 0;                // element format of `dense` (k_compat_build): 0 = fp32 (4 KiB per tile); 16-bit, 2 KiB per tile:
                               // 1 = fp16 c (with `half`), 2 = fixed point rint(65535 c)
 };
@@ -51,7 +59,8 @@ struct Tuning {
                              // fp16 operands (one product, fp32 accumulation) and streams c as fp16 - outside the 1e-4 gate
 };
 
-hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, int fmt, hipStream_t s);
+hipError_t launch_compat_build(const float* pts8, float* c_dense, int B, int N, int tiles, float sigma_d, int fmt, hipStream_t s,
+                               const PairTab* ptab = nullptr);
 hipError_t launch_front(int mode, const float* in, const float* wst, const float* vecs, float* f, float* q, float* k,
                         float* v, int B, int N, int tiles, hipStream_t s);
 hipError_t launch_scattn_fp32(const float* q, const float* k, const float* v, const float* pts8, const float* fus,
@@ -68,7 +77,7 @@ hipError_t launch_fusion_attn(bool pe, const float* x, const float* ctx_img, con
                               float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
 hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
 hipError_t launch_head(const float* feat_img, const float* wst, const float* vecs, float* logits, float* feat_n,
-                       float* feat_rm, int B, int N, int tiles, hipStream_t s, int* status = nullptr);
+                       float* feat_rm, int B, int N, int tiles, hipStream_t s, int* status = nullptr, const PairTab* ptab = nullptr);
 hipError_t launch_ctx_prep_w(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
                              int ttiles, hipStream_t s);
 hipError_t launch_fusion_attn_w(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
@@ -83,11 +92,12 @@ hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const flo
                                  long o_sk = 0, int n_rows = 0, int* status = nullptr);
 int plan_ff_split_w(int base_wgs);
 hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
-                           float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s);
+                           float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s, const PairTab* ptab = nullptr);
 // mode 3: corr_pos -> layer0 -> PointCN -> f only.  launch_linear_h2: all linear stages of one layer from f (k_linear_h2)
 hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                             const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec, float* q,
-                            float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s, bool one_product = false);
+                            float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s, bool one_product = false,
+                            const PairTab* ptab = nullptr);
 // small grids: three launches per layer (k_small_front_fattn | k_small_attn_ff | k_scattn_merge)
 void plan_attn_split(const Tuning& tune, int W, int tiles, int max_splits, int* n_full, int* ksplits);
 int plan_ff_split(const Tuning& tune, int base, int max_parts);
@@ -106,10 +116,10 @@ hipError_t launch_fusion_ff_h2(const Tuning& tune, const float* x1, const float*
 int padded_desc_width(int d);
 hipError_t launch_nn_match(const float* F0, const float* F1, float* f0_img, float* f1_img, float* norm2, int* idx,
                            float* dist, int N0, int N1, int d, int mode, hipStream_t s);
-hipError_t launch_seed_dist(const float* featn_img, const int* seeds, float* dist, int B, int N, int S, hipStream_t s);
-hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s);
+hipError_t launch_seed_dist(const float* featn_img, const int* seeds, float* dist, int B, int N, int S, hipStream_t s, const PairTab* ptab = nullptr);
+hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s, const PairTab* ptab = nullptr);
 hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s, int* status = nullptr);
-hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s);
+hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s, const PairTab* ptab = nullptr);
 
 // validation step (row f-4, forward half): validation_kernels.hip
 size_t similarity_image_floats(int B, int N);

@@ -28,7 +28,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "launchers.hpp"
+
+#define GMF_DEVINL __device__ __forceinline__
+
 namespace gmf {
+
+// rows of pair `pair` and where they start in the caller's row-major tensors (uniform batch: N and pair * N)
+GMF_DEVINL int pair_rows(const PairTab* pt, int pair, int N) { return pt ? pt[pair].n : N; }
+GMF_DEVINL size_t pair_row0(const PairTab* pt, int pair, int N) { return pt ? (size_t)pt[pair].row0 : (size_t)pair * N; }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,8 +44,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWave = 64;
 constexpr int kTileRows = 32;
 constexpr int kStageFloats = 4096;  // one weight / K / V stage = 16 KiB
-
-#define GMF_DEVINL __device__ __forceinline__
 
 GMF_DEVINL f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);

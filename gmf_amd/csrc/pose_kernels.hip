@@ -27,6 +27,10 @@ namespace gmf {
 
 #define GMF_DEVINL __device__ __forceinline__
 
+// Ragged batches (PairTab, launchers.hpp): the rows of pair `pair` in the caller's packed tensors, its own N and seed count.
+// Library-internal per-pair buffers keep the strides of the LARGEST pair (the kernel's N / S arguments).
+GMF_DEVINL int pair_seeds(const PairTab* pt, int pair, int S) { return pt ? pt[pair].S : S; }
+
 // T (row-major 4x4 fp32) from R (double) and centroids:  t = cB - R cA   (common.py:46-50)
 GMF_DEVINL void write_T(float* T, const double* R, const double* ca, const double* cb) {
 #pragma unroll
@@ -103,14 +107,18 @@ GMF_DEVINL void block_sum_tree(double (&v)[NV], double* sh /* >= NV*17 doubles *
 typedef float nms_f2 __attribute__((ext_vector_type(2)));
 
 __global__ void __launch_bounds__(256)
-k_nms_keys(const float* __restrict__ src, const float* __restrict__ scores, float* __restrict__ keys, int N, float R2t) {
+k_nms_keys(const float* __restrict__ src, const float* __restrict__ scores, float* __restrict__ keys, int N, float R2t,
+           const PairTab* __restrict__ ptab) {
   // candidates of a block as structure-of-arrays so that two of them load as one register pair: the squared distance of a
   // point to TWO candidates is 6 packed-fp32 instructions (v_pk_add/mul/fma_f32) with the same roundings as the scalar form
   __shared__ __attribute__((aligned(8))) float sx[256], sy[256], sz[256], sw[256];
   const int pair = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const float* ps = src + (size_t)pair * N * 3;
-  const float* sc = scores + (size_t)pair * N;
+  const size_t row0 = pair_row0(ptab, pair, N);
+  N = pair_rows(ptab, pair, N);
+  if ((int)blockIdx.x * 256 >= N) return;
+  const float* ps = src + row0 * 3;
+  const float* sc = scores + row0;
   float xi = 0, yi = 0, zi = 0, si = 0;
   if (i < N) { xi = ps[3 * i]; yi = ps[3 * i + 1]; zi = ps[3 * i + 2]; si = sc[i]; }
   const nms_f2 xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
@@ -136,8 +144,8 @@ k_nms_keys(const float* __restrict__ src, const float* __restrict__ scores, floa
     }
   }
   if (i < N) {
-    if (js == 1) keys[(size_t)pair * N + i] = si * (is_max ? 1.f : 0.f);
-    else if (!is_max) keys[(size_t)pair * N + i] = si * 0.f;
+    if (js == 1) keys[row0 + i] = si * (is_max ? 1.f : 0.f);
+    else if (!is_max) keys[row0 + i] = si * 0.f;
   }
 }
 
@@ -156,15 +164,18 @@ constexpr int kNmsCells = 4096, kNmsHdr = 4104;
 GMF_DEVINL int nms_cell_coord(float x, float inv_cell) { return ((int)floorf(x * inv_cell)) & 15; }
 
 __global__ void __launch_bounds__(1024)
-k_nms_bin(const float* __restrict__ src, const float* __restrict__ scores, float* __restrict__ scratch, int N, float inv_cell) {
+k_nms_bin(const float* __restrict__ src, const float* __restrict__ scores, float* __restrict__ scratch, int N, float inv_cell,
+          const PairTab* __restrict__ ptab) {
   __shared__ unsigned cnt[kNmsCells];
   __shared__ unsigned wtot[16];
   __shared__ int bad;
   const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* ps = src + (size_t)pair * N * 3;
-  const float* sc = scores + (size_t)pair * N;
-  float4* sorted = reinterpret_cast<float4*>(scratch + (size_t)pair * ((size_t)4 * N + kNmsHdr));
+  float4* sorted = reinterpret_cast<float4*>(scratch + (size_t)pair * ((size_t)4 * N + kNmsHdr));     // (slot of the largest pair)
   int* hdr = reinterpret_cast<int*>(sorted + N);
+  const size_t row0 = pair_row0(ptab, pair, N);
+  N = pair_rows(ptab, pair, N);
+  const float* ps = src + row0 * 3;
+  const float* sc = scores + row0;
   for (int c = tid; c < kNmsCells; c += 1024) cnt[c] = 0;
   if (tid == 0) bad = 0;
   __syncthreads();
@@ -206,14 +217,16 @@ k_nms_bin(const float* __restrict__ src, const float* __restrict__ scores, float
 
 __global__ void __launch_bounds__(256)
 k_nms_keys_binned(const float* __restrict__ src, const float* __restrict__ scores, const float* __restrict__ scratch,
-                  float* __restrict__ keys, int N, float R2t, float inv_cell) {
+                  float* __restrict__ keys, int N, float R2t, float inv_cell, const PairTab* __restrict__ ptab) {
   const int pair = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
   const float4* sorted = reinterpret_cast<const float4*>(scratch + (size_t)pair * ((size_t)4 * N + kNmsHdr));
   const int* hdr = reinterpret_cast<const int*>(sorted + N);
-  const float* ps = src + (size_t)pair * N * 3;
-  const float xi = ps[3 * i], yi = ps[3 * i + 1], zi = ps[3 * i + 2], si = scores[(size_t)pair * N + i];
+  const size_t row0 = pair_row0(ptab, pair, N);
+  N = pair_rows(ptab, pair, N);
+  if (i >= N) return;
+  const float* ps = src + row0 * 3;
+  const float xi = ps[3 * i], yi = ps[3 * i + 1], zi = ps[3 * i + 2], si = scores[row0 + i];
   bool is_max = true;
   auto scan = [&](int j0, int j1) {
     for (int j = j0; j < j1; ++j) {
@@ -241,7 +254,7 @@ k_nms_keys_binned(const float* __restrict__ src, const float* __restrict__ score
         }
       }
   }
-  keys[(size_t)pair * N + i] = si * (is_max ? 1.f : 0.f);
+  keys[row0 + i] = si * (is_max ? 1.f : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -252,13 +265,17 @@ k_nms_keys_binned(const float* __restrict__ src, const float* __restrict__ score
 GMF_DEVINL bool key_before(float ka, int ia, float kb, int ib) { return (ka > kb) || (ka == kb && ia < ib); }
 
 __global__ void __launch_bounds__(1024)
-k_sort_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, int M, int S) {
+k_sort_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, int M, int S, const PairTab* __restrict__ ptab) {
   extern __shared__ unsigned char smem_raw[];
   float* sk = reinterpret_cast<float*>(smem_raw);
   int* si = reinterpret_cast<int*>(smem_raw + (size_t)M * 4);
   const int pair = blockIdx.x;
+  const size_t row0 = pair_row0(ptab, pair, N);
+  const int S_out = S;                                  // (stride of the output list: the largest pair's)
+  N = pair_rows(ptab, pair, N);
+  S = pair_seeds(ptab, pair, S);
   for (int t = threadIdx.x; t < M; t += blockDim.x) {
-    sk[t] = (t < N) ? keys[(size_t)pair * N + t] : -INFINITY;
+    sk[t] = (t < N) ? keys[row0 + t] : -INFINITY;
     si[t] = (t < N) ? t : 0x7fffffff;
   }
   __syncthreads();
@@ -276,7 +293,7 @@ k_sort_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, in
       __syncthreads();
     }
   }
-  for (int t = threadIdx.x; t < S; t += blockDim.x) out_idx[(size_t)pair * S + t] = si[t];
+  for (int t = threadIdx.x; t < S; t += blockDim.x) out_idx[(size_t)pair * S_out + t] = si[t];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -290,7 +307,7 @@ k_sort_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, in
 // grid (B), block 1024, dynamic LDS = N*4 + S*8 bytes
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-k_select_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, int S) {
+k_select_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, int S, const PairTab* __restrict__ ptab) {
   extern __shared__ unsigned char smem_raw[];
   unsigned* d = reinterpret_cast<unsigned*>(smem_raw);                                   // [N]
   unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem_raw + (((size_t)N * 4 + 7) & ~(size_t)7));   // [S]
@@ -299,8 +316,12 @@ k_select_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, 
   __shared__ unsigned s_prefix, s_rank;
   const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr unsigned kZero = 0x7fffffffu;          // d of +0.0
+  const size_t row0 = pair_row0(ptab, pair, N);
+  const int S_out = S;                             // (stride of the output list: the largest pair's; the LDS was sized by it too)
+  N = pair_rows(ptab, pair, N);
+  S = pair_seeds(ptab, pair, S);
   for (int t = tid; t < N; t += 1024) {
-    float f = keys[(size_t)pair * N + t];
+    float f = keys[row0 + t];
     if (f == 0.0f) f = 0.0f;                       // -0 -> +0
     const unsigned bits = __float_as_uint(f);
     const unsigned u = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
@@ -379,7 +400,7 @@ k_select_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, 
     const unsigned long long me = sel[e];
     int rank = 0;
     for (int j = 0; j < S; ++j) rank += sel[j] < me ? 1 : 0;
-    out_idx[(size_t)pair * S + rank] = (int)(unsigned)(me & 0xffffffffull);
+    out_idx[(size_t)pair * S_out + rank] = (int)(unsigned)(me & 0xffffffffull);
   }
 }
 
@@ -390,15 +411,18 @@ k_select_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, 
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_knn_seeds(const float* __restrict__ feat_n, const int* __restrict__ seeds, const float* __restrict__ dist_in,
-            int* __restrict__ knn_idx, int N, int S, int k) {
+            int* __restrict__ knn_idx, int N, int S, int k, const PairTab* __restrict__ ptab) {
   extern __shared__ float dist[];
   __shared__ float fs[128];
   __shared__ float red_v[4];
   __shared__ int red_i[4];
   const int pair = blockIdx.y, s = blockIdx.x;
-  const float* fb = feat_n + (size_t)pair * N * 128;
+  if (s >= pair_seeds(ptab, pair, S)) return;
+  const float* fb = feat_n + pair_row0(ptab, pair, N) * 128;
+  const float* dr0 = dist_in ? dist_in + ((size_t)pair * S + s) * N : nullptr;     // (strides of the largest pair)
+  N = pair_rows(ptab, pair, N);
   if (dist_in) {        // distances precomputed by k_seed_dist (MFMA): just stage the row in LDS
-    const float* dr = dist_in + ((size_t)pair * S + s) * N;
+    const float* dr = dr0;
     for (int j = threadIdx.x; j < N; j += 256) dist[j] = dr[j];
   } else {
   const int seed = seeds[(size_t)pair * S + s];
@@ -450,12 +474,14 @@ k_knn_seeds(const float* __restrict__ feat_n, const int* __restrict__ seeds, con
 // ---------------------------------------------------------------------------------------
 template <int EPT>
 __global__ void __launch_bounds__(256)
-k_knn_select(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N, int S, int k) {
+k_knn_select(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N, int S, int k, const PairTab* __restrict__ ptab) {
   __shared__ float red_v[2][4];
   __shared__ int red_i[2][4];
   const int pair = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  if (s >= pair_seeds(ptab, pair, S)) return;
   const float* dr = dist_in + ((size_t)pair * S + s) * N;
+  N = pair_rows(ptab, pair, N);
   float v[EPT];
 #pragma unroll
   for (int m = 0; m < EPT; ++m) { const int j = tid + 256 * m; v[m] = (j < N) ? dr[j] : INFINITY; }
@@ -501,7 +527,7 @@ constexpr int kCandMax = 1024;
 
 template <int EPT>
 __global__ void __launch_bounds__(256)
-k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N, int S, int k) {
+k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N, int S, int k, const PairTab* __restrict__ ptab) {
   __shared__ float mins[256];
   __shared__ float cand_v[kCandMax];
   __shared__ int cand_i[kCandMax];
@@ -510,8 +536,10 @@ k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, 
   __shared__ float red_v[2][4];
   __shared__ int red_i[2][4];
   const int pair = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
-  const float* dr = dist_in + ((size_t)pair * S + s) * N;
+  if (s >= pair_seeds(ptab, pair, S)) return;
+  const float* dr = dist_in + ((size_t)pair * S + s) * N;                 // (strides of the largest pair)
   int* out = knn_idx + ((size_t)pair * S + s) * k;
+  N = pair_rows(ptab, pair, N);
   // a row with NaN distances yields fewer than k + 1 candidates: every slot holds an in-range index before the ranks are
   // written (the barriers below order this store before theirs), so no consumer ever gathers through an uninitialised index
   if (tid < k) out[tid] = min(tid + 1, N - 1);
@@ -607,7 +635,8 @@ constexpr int kKMax = 64;
 __global__ void __launch_bounds__(64)
 k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, const float* __restrict__ tgt,
              const int* __restrict__ knn_idx, float* __restrict__ snaps, unsigned char* __restrict__ conv,
-             double* __restrict__ hsum, int N, int S, int k, int iters, float inv_sigma2, float inv_sigmad2) {
+             double* __restrict__ hsum, int N, int S, int k, int iters, float inv_sigma2, float inv_sigmad2,
+             const PairTab* __restrict__ ptab) {
   // LDS sized by k (dynamic): the k x k matrix with row stride k + 1 - at k = 40 9 KiB per seed instead of 19, i.e. 17 instead
   // of 8 resident seeds per CU for a kernel that is one latency chain per seed
   extern __shared__ __attribute__((aligned(16))) float seed_smem[];
@@ -617,8 +646,11 @@ k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, co
   const int ld = k + 1;
   const int pair = blockIdx.y, s = blockIdx.x, a = threadIdx.x;
   const int lane = a, h = lane >> 5, i = lane & 31;
+  if (s >= pair_seeds(ptab, pair, S)) return;                // (ragged batch; the per-seed buffers keep the stride S)
   const int* nb = knn_idx + ((size_t)pair * S + s) * k;
-  const float* pair_rows = feat_n + (size_t)pair * N * 128;
+  const size_t row0 = pair_row0(ptab, pair, N);
+  N = gmf::pair_rows(ptab, pair, N);
+  const float* pair_rows = feat_n + row0 * 128;
   {
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* Pz = reinterpret_cast<float4*>(P);
@@ -626,8 +658,8 @@ k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, co
   }
   if (a < k) {
     const int j = nb[a];
-    const float* ps = src + ((size_t)pair * N + j) * 3;
-    const float* pt = tgt + ((size_t)pair * N + j) * 3;
+    const float* ps = src + (row0 + j) * 3;
+    const float* pt = tgt + (row0 + j) * 3;
     P[a * 8 + 0] = ps[0]; P[a * 8 + 1] = ps[1]; P[a * 8 + 2] = ps[2];
     P[a * 8 + 4] = pt[0]; P[a * 8 + 5] = pt[1]; P[a * 8 + 6] = pt[2];
   }
@@ -785,9 +817,12 @@ k_stop_iteration(const unsigned char* __restrict__ conv, int total_seeds, int it
 __global__ void __launch_bounds__(64)
 k_seed_kabsch(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ knn_idx,
               const float* __restrict__ snaps, const unsigned char* __restrict__ conv, float* __restrict__ seed_T,
-              int N, int S, int k, int iters, const double* __restrict__ hsum, const int* __restrict__ stop_batch) {
+              int N, int S, int k, int iters, const double* __restrict__ hsum, const int* __restrict__ stop_batch,
+              const PairTab* __restrict__ ptab) {
   __shared__ int stop_it;
   const int pair = blockIdx.y;
+  const int S_p = pair_seeds(ptab, pair, S);                // (ragged batch; the per-seed buffers keep the stride S)
+  if ((int)blockIdx.x * 64 >= S_p) return;
   // global early exit: first iteration at which EVERY seed passed allclose (PointDSC.py:444) - of the whole batch
   // (stop_batch, from k_stop_iteration) or, for a single pair, found here
   if (threadIdx.x == 0) stop_it = iters - 1;
@@ -799,14 +834,14 @@ k_seed_kabsch(const float* __restrict__ src, const float* __restrict__ tgt, cons
     int first = iters - 1;
     for (int it = 0; it < iters - 1; ++it) {
       bool ok = true;
-      for (int s2 = threadIdx.x; s2 < S; s2 += 64) ok = ok && (cv[(size_t)s2 * iters + it] != 0);
+      for (int s2 = threadIdx.x; s2 < S_p; s2 += 64) ok = ok && (cv[(size_t)s2 * iters + it] != 0);
       if (__all(ok)) { first = it; break; }
     }
     if (threadIdx.x == 0) stop_it = first;
   }
   __syncthreads();
   const int s = blockIdx.x * 64 + threadIdx.x;
-  if (s >= S) return;
+  if (s >= S_p) return;
   if (hsum && stop_it == iters - 1) {                // k_seed_power already summed the last iterate: only the SVD is left
     const double* hs = hsum + ((size_t)pair * S + s) * 15;
     double ca[3], cb[3], H[9], R[9];
@@ -823,8 +858,8 @@ k_seed_kabsch(const float* __restrict__ src, const float* __restrict__ tgt, cons
   float sv = 0.f;
   for (int r = 0; r < k; ++r) sv += v[r];
   const float inv = 1.0f / (sv + 1e-6f);
-  const float* ps = src + (size_t)pair * N * 3;
-  const float* pt = tgt + (size_t)pair * N * 3;
+  const float* ps = src + pair_row0(ptab, pair, N) * 3;
+  const float* pt = tgt + pair_row0(ptab, pair, N) * 3;
   double sw = 0, ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
   for (int r = 0; r < k; ++r) {
     float w = v[r] * inv;
@@ -858,18 +893,21 @@ constexpr int kHypPerWG = 8;
 
 __global__ void __launch_bounds__(256)
 k_score_hyp(const float* __restrict__ src, const float* __restrict__ tgt, const float* __restrict__ seed_T,
-            int* __restrict__ counts, int N, int S, float tau2t) {
+            int* __restrict__ counts, int N, int S, float tau2t, const PairTab* __restrict__ ptab) {
   __shared__ int red[4][kHypPerWG];
   const int pair = blockIdx.y, s0 = blockIdx.x * kHypPerWG;
+  const int S_p = pair_seeds(ptab, pair, S);                // (ragged batch; the per-seed buffers keep the stride S)
+  if (s0 >= S_p) return;
   float Tm[kHypPerWG][12];
 #pragma unroll
   for (int q = 0; q < kHypPerWG; ++q) {
-    const float* T = seed_T + ((size_t)pair * S + min(s0 + q, S - 1)) * 16;
+    const float* T = seed_T + ((size_t)pair * S + min(s0 + q, S_p - 1)) * 16;
 #pragma unroll
     for (int e = 0; e < 12; ++e) Tm[q][e] = T[e];
   }
-  const float* ps = src + (size_t)pair * N * 3;
-  const float* pt = tgt + (size_t)pair * N * 3;
+  const float* ps = src + pair_row0(ptab, pair, N) * 3;
+  const float* pt = tgt + pair_row0(ptab, pair, N) * 3;
+  N = pair_rows(ptab, pair, N);
   int cnt[kHypPerWG];
 #pragma unroll
   for (int q = 0; q < kHypPerWG; ++q) cnt[q] = 0;
@@ -891,7 +929,7 @@ k_score_hyp(const float* __restrict__ src, const float* __restrict__ tgt, const 
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = cnt[q];
   }
   __syncthreads();
-  if (threadIdx.x < kHypPerWG && s0 + threadIdx.x < S)
+  if (threadIdx.x < kHypPerWG && s0 + threadIdx.x < S_p)
     counts[(size_t)pair * S + s0 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
@@ -1017,17 +1055,20 @@ __global__ void __launch_bounds__(1024)
 k_finalize_pose(const float* __restrict__ src, const float* __restrict__ tgt, const float* __restrict__ seed_T,
                 const int* __restrict__ counts, float* __restrict__ fitness, float* __restrict__ final_T,
                 float* __restrict__ labels, int* __restrict__ best_out, int N, int S, float tau, float refine_thr,
-                int refine_iters) {
+                int refine_iters, const PairTab* __restrict__ ptab) {
   __shared__ double sh[17 * 17];
   __shared__ float Tcur[16];
   __shared__ int s_best;
   __shared__ int red_c[16], red_i[16];
   const int pair = blockIdx.x;
-  const float* ps = src + (size_t)pair * N * 3;
-  const float* pt = tgt + (size_t)pair * N * 3;
+  const size_t row0 = pair_row0(ptab, pair, N);              // (ragged batch: labels are packed [sum n]; per-seed buffers keep the stride S)
+  const int S_p = pair_seeds(ptab, pair, S);
+  N = pair_rows(ptab, pair, N);
+  const float* ps = src + row0 * 3;
+  const float* pt = tgt + row0 * 3;
   // argmax (first maximal index)
   int bc = -1, bi = 0x7fffffff;
-  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+  for (int s = threadIdx.x; s < S_p; s += blockDim.x) {
     const int c = counts[(size_t)pair * S + s];
     fitness[(size_t)pair * S + s] = (float)c / (float)N;
     if (c > bc) { bc = c; bi = s; }
@@ -1057,7 +1098,7 @@ k_finalize_pose(const float* __restrict__ src, const float* __restrict__ tgt, co
       const float dx = (r00 * x + r01 * y + r02 * z) + t0 - pt[3 * j];
       const float dy = (r10 * x + r11 * y + r12 * z) + t1 - pt[3 * j + 1];
       const float dz = (r20 * x + r21 * y + r22 * z) + t2 - pt[3 * j + 2];
-      labels[(size_t)pair * N + j] = (sqrtf(dx * dx + dy * dy + dz * dz) < tau) ? 1.f : 0.f;
+      labels[row0 + j] = (sqrtf(dx * dx + dy * dy + dz * dz) < tau) ? 1.f : 0.f;
     }
   }
   irls_refine(ps, pt, N, Tcur, refine_thr, refine_iters, sh);
@@ -1384,7 +1425,7 @@ size_t nms_scratch_floats(int B, int N) { return (size_t)B * ((size_t)4 * N + kN
 
 // tune.nms_binned: 1 = grid-binned candidates for N >= 1024 on grids of >= 128 workgroups (default), 2 = whenever N >= 1024, 0 = all pairs
 hipError_t launch_nms_keys(const Tuning& tune, const float* src, const float* scores, float* keys, int B, int N, float R, hipStream_t s,
-                           float* scratch) {
+                           float* scratch, const PairTab* ptab, long total_rows) {
   // The reference tests sqrt(d2) >= R (PointDSC.py:283).  sqrtf is monotone, so that is d2 >= t for the smallest float t
   // with sqrtf(t) >= R; finding t on the host removes the square root from the N^2 loop without changing one decision.
   float t = R * R;
@@ -1398,22 +1439,22 @@ hipError_t launch_nms_keys(const Tuning& tune, const float* src, const float* sc
   // (on small grids - B = 1 - the two binned launches cost more latency than the candidate-split all-pairs kernel saves)
   if (scratch && tune.nms_binned && N >= 1024 && (nblk * B >= 128 || tune.nms_binned == 2) && R > 0.f && std::isfinite(R)) {
     const float inv_cell = 1.0f / (1.01f * R);
-    hipLaunchKernelGGL(k_nms_bin, dim3(B), dim3(1024), 0, s, src, scores, scratch, N, inv_cell);
-    hipLaunchKernelGGL(k_nms_keys_binned, dim3(nblk, B), dim3(256), 0, s, src, scores, scratch, keys, N, t, inv_cell);
+    hipLaunchKernelGGL(k_nms_bin, dim3(B), dim3(1024), 0, s, src, scores, scratch, N, inv_cell, ptab);
+    hipLaunchKernelGGL(k_nms_keys_binned, dim3(nblk, B), dim3(256), 0, s, src, scores, scratch, keys, N, t, inv_cell, ptab);
     return hipGetLastError();
   }
   int js = 1;
   if (nblk * B < 256) js = std::min(std::min(16, nblk), (512 + nblk * B - 1) / (nblk * B));
   if (js > 1) {
-    hipError_t e = hipMemcpyAsync(keys, scores, (size_t)B * N * sizeof(float), hipMemcpyDeviceToDevice, s);
+    hipError_t e = hipMemcpyAsync(keys, scores, (size_t)(ptab ? total_rows : (long)B * N) * sizeof(float), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_nms_keys, dim3(nblk, B, js), dim3(256), 0, s, src, scores, keys, N, t);
+  hipLaunchKernelGGL(k_nms_keys, dim3(nblk, B, js), dim3(256), 0, s, src, scores, keys, N, t, ptab);
   return hipGetLastError();
 }
 
 // tune.topk_select: radix select + rank placement (default) or the full bitonic sort
-hipError_t launch_sort_topk(const Tuning& tune, const float* keys, int* out_idx, int B, int N, int S, hipStream_t s) {
+hipError_t launch_sort_topk(const Tuning& tune, const float* keys, int* out_idx, int B, int N, int S, hipStream_t s, const PairTab* ptab) {
   const int M = next_pow2(N < 2 ? 2 : N);
   if (M > 16384) return hipErrorInvalidValue;
   constexpr size_t kSelectLds = 156 * 1024;        // dynamic LDS the select kernel may use (160 KiB minus its static arrays)
@@ -1424,56 +1465,56 @@ hipError_t launch_sort_topk(const Tuning& tune, const float* keys, int* out_idx,
                                          (int)kSelectLds);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_select_topk, dim3(B), dim3(1024), need, s, keys, out_idx, N, S);
+    hipLaunchKernelGGL(k_select_topk, dim3(B), dim3(1024), need, s, keys, out_idx, N, S, ptab);
     return hipGetLastError();
   }
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_topk), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_sort_topk, dim3(B), dim3(1024), (size_t)M * 8, s, keys, out_idx, N, M, S);
+  hipLaunchKernelGGL(k_sort_topk, dim3(B), dim3(1024), (size_t)M * 8, s, keys, out_idx, N, M, S, ptab);
   return hipGetLastError();
 }
 
 hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* dist_in, int* knn_idx, int B, int N, int S,
-                            int k, hipStream_t s) {
+                            int k, hipStream_t s, const PairTab* ptab) {
   if ((size_t)N * 4 > 150 * 1024) return hipErrorInvalidValue;
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_seeds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return e;
   }
   if (dist_in && N <= 256 * 32) {
-    hipLaunchKernelGGL(k_knn_select_fast<32>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k);
+    hipLaunchKernelGGL(k_knn_select_fast<32>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab);
     return hipGetLastError();
   }
   if (dist_in && N <= 256 * 64) {
-    hipLaunchKernelGGL(k_knn_select_fast<64>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k);
+    hipLaunchKernelGGL(k_knn_select_fast<64>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(k_knn_seeds, dim3(S, B), dim3(256), (size_t)N * 4, s, feat_n, seeds, dist_in, knn_idx, N, S, k);
+  hipLaunchKernelGGL(k_knn_seeds, dim3(S, B), dim3(256), (size_t)N * 4, s, feat_n, seeds, dist_in, knn_idx, N, S, k, ptab);
   return hipGetLastError();
 }
 
 hipError_t launch_seed_power(const float* feat_n, const float* src, const float* tgt, const int* knn_idx, float* snaps,
                              unsigned char* conv, double* hsum, int B, int N, int S, int k, int iters, float sigma,
-                             float sigma_d, hipStream_t s) {
+                             float sigma_d, hipStream_t s, const PairTab* ptab) {
   if (k > kKMax) return hipErrorInvalidValue;
   const size_t lds_bytes = (size_t)(kKMax * 8 + kKMax + k * (k + 1)) * sizeof(float);
   hipLaunchKernelGGL(k_seed_power, dim3(S, B), dim3(64), lds_bytes, s, feat_n, src, tgt, knn_idx, snaps, conv, hsum, N, S, k,
-                     iters, 1.0f / (sigma * sigma), 1.0f / (sigma_d * sigma_d));
+                     iters, 1.0f / (sigma * sigma), 1.0f / (sigma_d * sigma_d), ptab);
   return hipGetLastError();
 }
 
 hipError_t launch_seed_kabsch(const float* src, const float* tgt, const int* knn_idx, const float* snaps,
                               const unsigned char* conv, float* seed_T, int B, int N, int S, int k, int iters,
-                              const double* hsum, int* stop_scratch, hipStream_t s) {
+                              const double* hsum, int* stop_scratch, hipStream_t s, const PairTab* ptab) {
   const int* stop_batch = nullptr;
-  if (B > 1 && stop_scratch) {          // the reference's allclose spans the batch
+  if (B > 1 && stop_scratch && !ptab) { // the reference's allclose spans the batch (a ragged batch is B independent B = 1 calls)
     hipLaunchKernelGGL(k_stop_iteration, dim3(1), dim3(1024), 0, s, conv, B * S, iters, stop_scratch);
     stop_batch = stop_scratch;
   }
   hipLaunchKernelGGL(k_seed_kabsch, dim3((S + 63) / 64, B), dim3(64), 0, s, src, tgt, knn_idx, snaps, conv, seed_T, N, S, k, iters,
-                     hsum, stop_batch);
+                     hsum, stop_batch, ptab);
   return hipGetLastError();
 }
 
@@ -1483,7 +1524,7 @@ hipError_t launch_stop_iteration(const unsigned char* conv, int B, int S, int it
 }
 
 hipError_t launch_score_hyp(const float* src, const float* tgt, const float* seed_T, int* counts, int B, int N, int S,
-                            float tau, hipStream_t s) {
+                            float tau, hipStream_t s, const PairTab* ptab) {
   // sqrtf(d2) < tau  <=>  d2 < t for the smallest float t with sqrtf(t) >= tau (sqrtf is monotone): no square root per pair
   float t = tau * tau;
   if (tau > 0.f) {
@@ -1492,15 +1533,15 @@ hipError_t launch_score_hyp(const float* src, const float* tgt, const float* see
   } else {
     t = 0.f;
   }
-  hipLaunchKernelGGL(k_score_hyp, dim3((S + kHypPerWG - 1) / kHypPerWG, B), dim3(256), 0, s, src, tgt, seed_T, counts, N, S, t);
+  hipLaunchKernelGGL(k_score_hyp, dim3((S + kHypPerWG - 1) / kHypPerWG, B), dim3(256), 0, s, src, tgt, seed_T, counts, N, S, t, ptab);
   return hipGetLastError();
 }
 
 hipError_t launch_finalize_pose(const float* src, const float* tgt, const float* seed_T, const int* counts, float* fitness,
                                 float* final_T, float* labels, int* best, int B, int N, int S, float tau, float refine_thr,
-                                int refine_iters, hipStream_t s) {
+                                int refine_iters, hipStream_t s, const PairTab* ptab) {
   hipLaunchKernelGGL(k_finalize_pose, dim3(B), dim3(N <= 2048 ? 256 : 1024), 0, s, src, tgt, seed_T, counts, fitness, final_T, labels, best, N, S,
-                     tau, refine_thr, refine_iters);
+                     tau, refine_thr, refine_iters, ptab);
   return hipGetLastError();
 }
 

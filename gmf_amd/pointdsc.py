@@ -490,7 +490,62 @@ class PointDSC(nn.Module):
         final_trans = T.pose_head_train(self, feat_n, self.sigma, src, tgt, logits.detach().contiguous(), (sigma, sigma_d))
         return {"final_trans": final_trans, "final_labels": logits, "M": M}
 
+    # -- ragged batches: pairs with their own numbers of correspondences in ONE launch ----------------------------------------
+    def forward_ragged(self, data):
+        """Test-mode forward for B pairs that each have their OWN N - what the reference's evaluation loop feeds one pair at a
+        time (evaluation/test_3DMatch.py:24-119; PointDSC.py:279,504 assert B == 1), here in one launch at batch throughput.
+        `data`: "corr_pos", "src_keypts", "tgt_keypts" as LISTS of B tensors [n_b, 6] / [n_b, 3] (or already packed
+        [sum n, .] tensors together with "n_points", a list of B ints); "p_tokens" / "q_tokens" [B, T, 128] (or "p_image" /
+        "q_image").  Returns "final_trans" [B, 4, 4], "final_labels" and "logits" as lists of B tensors [n_b]; every pair's
+        result equals its own B = 1 call.  `last_logits` / `last_features` hold the packed tensors."""
+        if self.training:
+            raise RuntimeError("gmf_amd.PointDSC.forward_ragged is the eval() test-mode path")
+        import ctypes as C
+        cp, sk, tk = data["corr_pos"], data["src_keypts"], data["tgt_keypts"]
+        if isinstance(cp, (list, tuple)):
+            n_points = [int(t.shape[0]) for t in cp]
+            if [int(t.shape[0]) for t in sk] != n_points or [int(t.shape[0]) for t in tk] != n_points:
+                raise RuntimeError("gmf_amd.PointDSC.forward_ragged: corr_pos / src_keypts / tgt_keypts disagree on the pairs' sizes")
+            cp, sk, tk = torch.cat(list(cp)), torch.cat(list(sk)), torch.cat(list(tk))
+        else:
+            n_points = [int(n) for n in data["n_points"]]
+        cp = require_cuda_f32(cp, "corr_pos").contiguous()
+        sk = require_cuda_f32(sk, "src_keypts").contiguous()
+        tk = require_cuda_f32(tk, "tgt_keypts").contiguous()
+        B, total = len(n_points), sum(n_points)
+        if cp.shape != (total, self.encoder.layer0.weight.shape[1]) or sk.shape != (total, 3) or tk.shape != (total, 3):
+            raise RuntimeError("gmf_amd.PointDSC.forward_ragged: packed tensors must be [sum n, 6] / [sum n, 3]")
+        if "p_tokens" in data:
+            p_tok, q_tok = data["p_tokens"], data["q_tokens"]
+        else:
+            with torch.no_grad():
+                tok = self.encoder.image_tokens(torch.cat([data["p_image"], data["q_image"]]))
+                p_tok, q_tok = tok[:B], tok[B:]
+        p_tok = require_cuda_f32(p_tok, "p_tokens").contiguous()
+        q_tok = require_cuda_f32(q_tok, "q_tokens").contiguous()
+        T = p_tok.shape[1]
+        if p_tok.shape != (B, T, 128) or q_tok.shape != (B, T, 128):
+            raise RuntimeError("gmf_amd.PointDSC.forward_ragged: image tokens must be [B,T,128] for both images")
+        dev = cp.device
+        pw = self._weights(dev)
+        npts = (C.c_int * B)(*n_points)
+        logits = torch.empty(total, device=dev)
+        feat_n = torch.empty((total, 128), device=dev)
+        final_T = torch.empty((B, 4, 4), device=dev)
+        labels = torch.empty(total, device=dev)
+        pp, _, _ = self._pose_params(max(n_points), True, None, dev)
+        h, st = handle_and_stream(cp, check=True)
+        h.call("gmf_encoder_forward_ragged", pw.struct, cp.data_ptr(), sk.data_ptr(), tk.data_ptr(), p_tok.data_ptr(), q_tok.data_ptr(),
+               npts, B, T, logits.data_ptr(), feat_n.data_ptr(), None, st)
+        h.call("gmf_pose_head_ragged", pp, float(self.ratio), feat_n.data_ptr(), sk.data_ptr(), tk.data_ptr(), logits.data_ptr(), npts, B,
+               final_T.data_ptr(), labels.data_ptr(), None, None, None, None, st)
+        self.last_logits, self.last_features = logits, feat_n
+        return {"final_trans": final_T, "final_labels": list(torch.split(labels, n_points)), "logits": list(torch.split(logits, n_points)),
+                "M": None}
+
     def forward(self, data):
+        if isinstance(data.get("corr_pos"), (list, tuple)) or "n_points" in data:
+            return self.forward_ragged(data)
         if self.training and torch.is_grad_enabled():
             if "testing" in data.keys():
                 raise RuntimeError("gmf_amd.PointDSC: test mode (`testing` key) in train() mode with autograd enabled - call eval() "

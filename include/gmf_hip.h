@@ -245,6 +245,17 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
                         const float* tgt_keypts, const float* p_tokens, const float* q_tokens, int B, int N, int T,
                         float* logits, float* feat_n, float* feat, gmf_stream_t stream);
 
+/* The same for a RAGGED batch: B pairs, each with its OWN number of correspondences, in one launch.  The reference feeds its
+ * evaluation loop one pair at a time, each with its own N (evaluation/test_3DMatch.py:24-119, PointDSC.py:279,504 assert
+ * B == 1); its collate function clips a training batch to the smallest N (datasets/dataloader.py:6-23).  Here the row-major
+ * tensors are PACKED: pair b owns rows [n_0 + .. + n_{b-1}, + n_b) of corr_pos [sum n, 6], src/tgt_keypts [sum n, 3], logits
+ * [sum n], feat_n / feat [sum n, 128]; the tokens stay [B, T, 128].  n_points: HOST array [B] (the caller knows its tensor
+ * shapes; the library sizes its grids from it).  The result equals B calls with B = 1, pair by pair.  Default path only (split-
+ * fp16 weight images, num_layers >= 2, "fused_linear" = 1, "scattn_variant" = 18): otherwise GMF_ERR_UNSUPPORTED_SHAPE. */
+int gmf_encoder_forward_ragged(gmf_handle* h, const gmf_encoder_weights* w, const float* corr_pos, const float* src_keypts,
+                               const float* tgt_keypts, const float* p_tokens, const float* q_tokens, const int* n_points, int B,
+                               int T, float* logits, float* feat_n, float* feat, gmf_stream_t stream);
+
 /* One NonLocalBlock on P32 images (PointDSC.py:40-74): feat_img -> out_img given the fused image tokens
  * (P32 image [B,Tt,..]) and EITHER pts8 (compat recomputed in-kernel) OR the dense `attention` [B,N,N]
  * (exactly one of the two non-NULL).  layer selects the weight set inside `w`. */
@@ -292,6 +303,16 @@ int gmf_pose_head(gmf_handle* h, const gmf_pose_params* p, const float* feat_n, 
                   const float* tgt_keypts, const float* logits, const int* seeds_in, int B, int N, float* final_trans,
                   float* final_labels, int* seeds_out, int* knn_out, float* seed_trans, float* fitness,
                   gmf_stream_t stream);
+
+/* gmf_pose_head for a ragged batch (packing as gmf_encoder_forward_ragged; n_points: HOST array [B]): pair b uses
+ * S_b = int(n_b * ratio) seeds (PointDSC.py:244; p->num_seeds is ignored) and is solved exactly as a B = 1 call - the power
+ * iteration's allclose exit (PointDSC.py:444) is resolved per pair.  Every pair needs more than p->k correspondences.
+ * final_trans [B,16]; final_labels [sum n]; the optional per-seed outputs are [B, S_max, ...] with S_max = max S_b, the slots
+ * behind a pair's own seeds zero. */
+int gmf_pose_head_ragged(gmf_handle* h, const gmf_pose_params* p, double ratio, const float* feat_n, const float* src_keypts,
+                         const float* tgt_keypts, const float* logits, const int* n_points, int B, float* final_trans,
+                         float* final_labels, int* seeds_out, int* knn_out, float* seed_trans, float* fitness,
+                         gmf_stream_t stream);
 
 /* pick_seeds / plain top-S only (PointDSC.py:268-286 / :246). */
 int gmf_pick_seeds(gmf_handle* h, const float* src_keypts, const float* scores, int B, int N, float nms_radius,

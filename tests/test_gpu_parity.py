@@ -304,6 +304,62 @@ def test_batched_equals_per_pair(model):
         assert torch.equal(full[i:i + 1], one)
 
 
+def test_ragged_batch_equals_per_pair_calls(model):
+    """gmf_encoder_forward_ragged + gmf_pose_head_ragged: four pairs with their OWN N in one launch (what the reference's
+    evaluation loop feeds one pair at a time, evaluation/test_3DMatch.py:69) give each pair the result of its own B = 1 call -
+    logits to 5e-5 (the ragged launch runs the large-grid kernels, a B = 1 call the small-grid ones: other summation orders),
+    poses to 1e-4, identical inlier labels up to the points a 5e-5 logit change can flip."""
+    sizes = [700, 1531, 5000, 257]
+    keys = ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")
+    pairs = [synthetic.synthetic_batch([300 + i], N=n, T=196) for i, n in enumerate(sizes)]
+    rag = {k: [_gpu(b[k][0]) for b in pairs] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    rag["p_tokens"] = torch.cat([_gpu(b["p_tokens"]) for b in pairs])
+    rag["q_tokens"] = torch.cat([_gpu(b["q_tokens"]) for b in pairs])
+    rag["testing"] = True
+    out = model(rag)                                           # lists -> forward_ragged
+    assert out["final_trans"].shape == (4, 4, 4) and [t.shape[0] for t in out["final_labels"]] == sizes
+    gmf_amd.check_status()
+    for i, b in enumerate(pairs):
+        one = {k: _gpu(b[k]) for k in keys}
+        one["testing"] = True
+        r1 = model(one)
+        dl = _maxerr(out["logits"][i].cpu(), model.last_logits[0].cpu())
+        dT = _maxerr(out["final_trans"][i].cpu(), r1["final_trans"][0].cpu())
+        same = float((out["final_labels"][i] == r1["final_labels"][0]).float().mean())
+        print(f"ragged pair {i} (N = {sizes[i]}): max |dlogit| {dl:.2e}, max |dT| {dT:.2e}, labels equal {same:.4f}")
+        assert dl < 5e-5, (i, dl)
+        assert dT < 1e-4, (i, dT)
+        assert same > 0.999
+    # the packed form with "n_points" is the same call
+    packed = {k: torch.cat(rag[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    packed.update(p_tokens=rag["p_tokens"], q_tokens=rag["q_tokens"], n_points=sizes, testing=True)
+    out2 = model(packed)
+    assert torch.equal(out2["final_trans"], out["final_trans"]) and all(torch.equal(a, b) for a, b in zip(out2["logits"], out["logits"]))
+
+
+def test_ragged_batch_of_equal_sizes_is_the_uniform_batch(model):
+    """With every n_b equal the ragged entry points run the very kernels of the uniform large-grid batch: logits bit for bit.
+    (The pose differs in ONE documented respect: a ragged batch resolves the power iteration's allclose exit per pair - B
+    independent B = 1 calls - where the uniform batch resolves it over the batch as the reference's tensor-wide test does.)"""
+    B, N = 33, 1000                                            # 33 x 8 = 264 row blocks: the large-grid (two-launch) form
+    b = synthetic.synthetic_batch(list(range(500, 500 + B)), N=N, T=196)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    ru = model(data)
+    lg_u = model.last_logits.clone()
+    rag = {k: [data[k][i] for i in range(B)] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    rag.update(p_tokens=data["p_tokens"], q_tokens=data["q_tokens"], testing=True)
+    rr = model(rag)
+    assert torch.equal(torch.stack(rr["logits"]), lg_u)
+    assert _maxerr(rr["final_trans"].cpu(), ru["final_trans"].cpu()) < 1e-4
+    # misuse: a pair too small for its k neighbours is refused, not mis-computed
+    bad = dict(rag)
+    for k in ("corr_pos", "src_keypts", "tgt_keypts"):
+        bad[k] = [t[:30] if i == 2 else t for i, t in enumerate(rag[k])]
+    with pytest.raises(RuntimeError, match="more than k"):
+        model(bad)
+
+
 def test_stress_conditioning(golden_dir):
     """gain 0.9 weights amplify rounding by ~1.4x per block: two fp32 evaluations that only differ in summation
     order disagree by the noise floor |oracle32 - oracle64|.  The HIP path must stay within 4x that floor."""

@@ -11,9 +11,16 @@ int gmf_gemm_f32(gmf_handle* h, int trans_a, int trans_b, const float* A, const 
                  long long stride_b, long long stride_c, int batch, float alpha, int relu, gmf_stream_t stream) {
   GMF_REQUIRE(h && A && B && C, GMF_ERR_BAD_ARG, "gemm_f32: null pointer");
   GMF_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, GMF_ERR_UNSUPPORTED_SHAPE, "gemm_f32: empty problem");
-  GMF_REQUIRE((long long)batch * ((M + 127) / 128) <= 2000000 , GMF_ERR_UNSUPPORTED_SHAPE, "gemm_f32: grid too large");
+  // leading dimensions: a row of op(X) as it is stored must fit its stride (a smaller one reads or writes out of bounds on the device)
+  GMF_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, GMF_ERR_BAD_ARG,
+              "gemm_f32: need lda >= (trans_a ? M : K), ldb >= (trans_b ? K : N), ldc >= N (row strides in floats)");
+  GMF_REQUIRE(batch == 1 || (stride_a >= 0 && stride_b >= 0 && stride_c >= N), GMF_ERR_BAD_ARG,
+              "gemm_f32: batched outputs overlap (stride_c < N) or a batch stride is negative");
+  // grid limits: blockIdx.y = ceil(M / 64) at most, blockIdx.z = batch * ksplits (ksplits <= 128)
+  GMF_REQUIRE((M + 63) / 64 <= 65535, GMF_ERR_UNSUPPORTED_SHAPE, "gemm_f32: M too large for one launch (ceil(M / 64) > 65535)");
   SetDevice sd(h, stream);
   const int ksplits = gmf::gemm_ksplits(trans_a != 0, trans_b != 0, A, B, M, N, K, (long)lda, (long)ldb, (long)stride_a, (long)stride_b, batch);
+  GMF_REQUIRE((long long)batch * ksplits <= 65535, GMF_ERR_UNSUPPORTED_SHAPE, "gemm_f32: batch * k-splits exceeds 65535 workgroups in z: split the batch");
   float* part = nullptr;
   if (ksplits > 1) {
     if (int rc = arena_reserve(h, arena_need((size_t)batch * ksplits * M * N, 4))) return rc;

@@ -73,6 +73,13 @@ GMF_DEVINL f32x2 resid2h(f16x2 hh, float x0, float x1) {
   return f32x2{r0, r1};
 }
 
+// HAZARD INVARIANT of resid2h / lo2h (hipcc places no MFMA -> VALU wait states in front of inline assembly - DESIGN.md section 3,
+// "What this toolchain does behind hand-scheduled code"): x0 / x1 may be MFMA accumulators, and the asm statements below read
+// them.  They are safe BY CONSTRUCTION, not by luck of scheduling: their operand `hh` is the result of the compiler-scheduled
+// conversion of the SAME x0 / x1 (every caller forms it with __builtin_convertvector right before), so that conversion - which
+// the hazard recogniser does guard - reads the accumulators first, and the statements cannot be issued before their operand
+// exists.  Do not call these with an `hh` that was not computed from the very x0 / x1 passed along.  (The C form
+// (_Float16)(x - (float)hh) compiles to cvt + cvt + sub + sub + cvt_pk: 6 instructions per pair instead of 3.)
 // fp16(x - float(hi)) for a pair, written straight into the two halves of one register: v_fma_mixlo_f16 / v_fma_mixhi_f16
 // round the (exact) difference to fp16 themselves, so the low plane of a pair costs 2 instructions instead of 2 + a
 // v_cvt_pk (3 per pair with the hi conversion instead of 4).  Bit-identical to convert(resid2h(...)), checked over all
@@ -357,7 +364,9 @@ struct StageRing {
 #pragma unroll
     for (int k = 0; k < NBUF - 1; ++k) issue_one();
   }
-  // acquire with a caller-counted wait: YOUNGER is a lower bound of the vector-memory operations (DMA pieces of later stages,
+  // acquire with a caller-counted wait.  CONTRACT: YOUNGER must be a LOWER bound (too small only waits longer; too large lets a
+  // stage through before it has landed) - each call site states how it counts next to the call, and tools/soak_determinism.py
+  // (bitwise-equal results over hundreds of runs) is the standing check.  YOUNGER is a lower bound of the vector-memory operations (DMA pieces of later stages,
   // loads, stores - vmcnt counts them all, in issue order) this wave has issued after the pieces of the stage being acquired.
   // Lets stores and later stages stay in flight across the stage barrier.
   template <int YOUNGER>

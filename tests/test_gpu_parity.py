@@ -1079,6 +1079,18 @@ def test_backward_entry_points_reject_bad_arguments():
     assert L.gmf_compat_dense(h.h, pts.data_ptr(), pts.data_ptr(), 2, 64, 0.0, x.data_ptr(), None) == -1
     assert L.gmf_weighted_procrustes_backward(h.h, pts.data_ptr(), pts.data_ptr(), fit.data_ptr(), None, 1, 1e-7, gT.data_ptr(),
                                               gT.data_ptr(), fit.data_ptr(), None) == -1
+    # gmf_gemm_f32: a leading dimension smaller than the row it strides, overlapping batched outputs and a z-grid beyond 65535 are
+    # refused on the host (they used to reach the device as out-of-bounds accesses or an opaque launch error)
+    A, Bm, Cm = torch.zeros(64, 32, device=DEV), torch.zeros(32, 48, device=DEV), torch.zeros(64, 48, device=DEV)
+    gemm = lambda **kw: L.gmf_gemm_f32(h.h, kw.get("ta", 0), kw.get("tb", 0), A.data_ptr(), Bm.data_ptr(), Cm.data_ptr(), None, None,
+                                       kw.get("M", 64), kw.get("N", 48), kw.get("K", 32), kw.get("lda", 32), kw.get("ldb", 48),
+                                       kw.get("ldc", 48), kw.get("sa", 0), kw.get("sb", 0), kw.get("sc", 0), kw.get("batch", 1), 1.0, 0, None)
+    assert gemm() == 0
+    assert gemm(lda=31) == -1 and b"lda" in L.gmf_last_error_string(h.h)
+    assert gemm(ldb=47) == -1 and gemm(ldc=47) == -1
+    assert gemm(ta=1, lda=63) == -1                    # op(A) = A^T: rows of A are M long
+    assert gemm(batch=2, sc=40) == -1                  # outputs of the two problems overlap
+    assert gemm(batch=70000, sc=64 * 48) == -2 and b"65535" in L.gmf_last_error_string(h.h)
     torch.cuda.synchronize()
 
 

@@ -292,16 +292,6 @@ k_scattn(const float* __restrict__ q_img, const float* __restrict__ k_img, const
   }
 }
 
-// Correctly rounded square root for the squared distances (normal range or exactly 0): v_sqrt_f32 (1 ulp) plus
-// one FMA correction step, y' = y + (x - y*y) * (0.5 * rsq(x)).  Agrees with sqrtf bit for bit on 6.7e7 sampled
-// squared distances (tools/ubench/sqrt_check.hip; raw v_sqrt_f32 differs on 15 % of them) at 6 instructions
-// instead of the ~14 of hipcc's general sqrtf expansion (which also handles denormals and scaling).
-GMF_DEVINL float sqrt_cr(float x) {
-  const float y = __builtin_amdgcn_sqrtf(x);
-  const float hr = 0.5f * __builtin_amdgcn_rsqf(fmaxf(x, 1e-36f));
-  return fmaf(fmaf(-y, y, x), hr, y);
-}
-
 // d = ||a|| - ||b|| from the squared lengths in the reference's form, sqrt(a2) - sqrt(b2) with correctly rounded square
 // roots (sqrt_cr), i.e. the same roundings as torch.norm on the CPU (PointDSC.py:217-219).
 GMF_DEVINL float len_diff(float a2, float b2) { return sqrt_cr(a2) - sqrt_cr(b2); }

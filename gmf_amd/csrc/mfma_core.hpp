@@ -215,6 +215,17 @@ GMF_DEVINL void load_row_frag_p32(float (&x)[KF], const float* __restrict__ pair
   }
 }
 
+// Correctly rounded square root for the squared distances (normal range or exactly 0): v_sqrt_f32 (1 ulp) plus
+// one FMA correction step, y' = y + (x - y*y) * (0.5 * rsq(x)).  Agrees with sqrtf bit for bit on 6.7e7 sampled
+// squared distances (tools/ubench/sqrt_check.hip; raw v_sqrt_f32 differs on 15 % of them) at 6 instructions
+// instead of the ~14 of hipcc's general sqrtf expansion (which also handles denormals and scaling).
+GMF_DEVINL float sqrt_cr(float x) {
+  const float y = __builtin_amdgcn_sqrtf(x);
+  const float hr = 0.5f * __builtin_amdgcn_rsqf(fmaxf(x, 1e-36f));
+  return fmaf(fmaf(-y, y, x), hr, y);
+}
+
+
 // Sum / max over the two K-halves of a row (lane l and l^32 hold the two halves).
 GMF_DEVINL float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 GMF_DEVINL float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }

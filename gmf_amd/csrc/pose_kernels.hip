@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <algorithm>
+#include <type_traits>
 
 #include "launchers_pose.hpp"
 #include "mfma_core.hpp"
@@ -526,11 +527,11 @@ k_knn_select(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N
 constexpr int kCandMax = 1024;
 
 template <int EPT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, EPT <= 20 ? 6 : EPT <= 32 ? 5 : 3)      // (a latency chain per row: 5-6 rows per SIMD in flight)
 k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N, int S, int k, const PairTab* __restrict__ ptab) {
   __shared__ float mins[256];
-  __shared__ float cand_v[kCandMax];
-  __shared__ int cand_i[kCandMax];
+  __shared__ __attribute__((aligned(16))) float cand_v[kCandMax + 4];
+  __shared__ __attribute__((aligned(16))) int cand_i[kCandMax + 4];
   __shared__ float T_sh;
   __shared__ int count;
   __shared__ float red_v[2][4];
@@ -549,10 +550,33 @@ k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, 
   float bv = INFINITY; int bm = 0;
 #pragma unroll
   for (int m = 0; m < EPT; ++m) if (v[m] < bv) { bv = v[m]; bm = m; }
-  mins[tid] = bv;
   if (tid == 0) count = 0;
-  __syncthreads();
-  {
+  if (k + 1 <= 64) {
+    // T from 64 GROUP minima (a group = 4 neighbouring threads = 4 * EPT elements): the (k + 1)-th smallest of 64 distinct
+    // elements also bounds the (k + 1)-th smallest overall, at a 16th of the comparisons (every thread used to rank its own
+    // minimum among all 256 - 65 536 comparisons per seed row, half of this kernel's instructions); the candidate count grows
+    // from ~k + 4 to ~1.5 k, far below kCandMax.
+    float gv = fminf(bv, __shfl_xor(bv, 1, 64));
+    gv = fminf(gv, __shfl_xor(gv, 2, 64));
+    if ((tid & 3) == 0) mins[tid >> 2] = gv;
+    __syncthreads();
+    if (tid < 64) {
+      const float mine = mins[tid];
+      int rank = 0;
+      const float4* m4 = reinterpret_cast<const float4*>(mins);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float4 q = m4[u];
+        rank += (q.x < mine || (q.x == mine && 4 * u + 0 < tid)) ? 1 : 0;
+        rank += (q.y < mine || (q.y == mine && 4 * u + 1 < tid)) ? 1 : 0;
+        rank += (q.z < mine || (q.z == mine && 4 * u + 2 < tid)) ? 1 : 0;
+        rank += (q.w < mine || (q.w == mine && 4 * u + 3 < tid)) ? 1 : 0;
+      }
+      if (rank == k) T_sh = mine;          // exactly one of the 64 has this rank
+    }
+  } else {
+    mins[tid] = bv;
+    __syncthreads();
     int rank = 0;
     const float4* m4 = reinterpret_cast<const float4*>(mins);
 #pragma unroll 8
@@ -567,22 +591,52 @@ k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, 
   }
   __syncthreads();
   const float T = T_sh;
+  // candidates (elements <= T) into the LDS: a thread counts its own, a wave-wide prefix sum places them behind ONE LDS atomic
+  // per wave (there used to be one atomic per candidate)
+  {
+    const int lane = tid & 63;
+    int mine = 0;
 #pragma unroll
-  for (int m = 0; m < EPT; ++m) {
-    if (v[m] <= T) {
-      const int pos = atomicAdd(&count, 1);
-      if (pos < kCandMax) { cand_v[pos] = v[m]; cand_i[pos] = tid + 256 * m; }
+    for (int m = 0; m < EPT; ++m) mine += (v[m] <= T) ? 1 : 0;
+    int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    int base = 0;
+    if (lane == 63 && inc) base = atomicAdd(&count, inc);
+    base = __shfl(base, 63, 64);
+    int pos = base + inc - mine;
+    if (mine) {
+#pragma unroll
+      for (int m = 0; m < EPT; ++m) {
+        if (v[m] <= T) {
+          if (pos < kCandMax) { cand_v[pos] = v[m]; cand_i[pos] = tid + 256 * m; }
+          ++pos;
+        }
+      }
     }
   }
   __syncthreads();
   const int c = count;
   if (c <= kCandMax) {
+    // rank of every candidate among the candidates under (distance, index), four candidates per LDS read (the tail of the last
+    // group of four is padded with +inf / the largest index, which ranks behind everything)
+    const int c4 = (c + 3) & ~3;
+    if (tid < c4 - c) { cand_v[c + tid] = INFINITY; cand_i[c + tid] = 0x7fffffff; }
+    __syncthreads();
+    const float4* cv4 = reinterpret_cast<const float4*>(cand_v);
+    const int4* ci4 = reinterpret_cast<const int4*>(cand_i);
     for (int p = tid; p < c; p += 256) {
       const float pv = cand_v[p]; const int pi = cand_i[p];
       int rank = 0;
-      for (int q = 0; q < c; ++q) {
-        const float qv = cand_v[q]; const int qi = cand_i[q];
-        rank += (qv < pv || (qv == pv && qi < pi)) ? 1 : 0;
+      for (int q = 0; q < c4 / 4; ++q) {
+        const float4 qv = cv4[q]; const int4 qi = ci4[q];
+        rank += (qv.x < pv || (qv.x == pv && qi.x < pi)) ? 1 : 0;
+        rank += (qv.y < pv || (qv.y == pv && qi.y < pi)) ? 1 : 0;
+        rank += (qv.z < pv || (qv.z == pv && qi.z < pi)) ? 1 : 0;
+        rank += (qv.w < pv || (qv.w == pv && qi.w < pi)) ? 1 : 0;
       }
       if (rank >= 1 && rank <= k) out[rank - 1] = pi;     // rank 0 (the row itself) is dropped, common.py:74
     }
@@ -688,7 +742,10 @@ k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, co
   }
   __syncthreads();
 
-  // tile (ta, tb): rows 32*ta + a', cols 32*tb + (lane & 31)
+  // tile (ta, tb): rows 32*ta + a', cols 32*tb + (lane & 31).  Branch-free per element (rows / columns beyond k read the zeroed
+  // padding of P and are not stored), square roots by sqrt_cr (bit-identical to sqrtf on squared distances, 6 instructions
+  // instead of ~20): the 48 elements of a seed used to be 48 basic blocks with two full sqrtf expansions each - 60 % of the
+  // kernel's instructions.
   auto emit_tile = [&](const gmf::f32x16& g, int ta, int tb, bool mirror) {
     const int b = 32 * tb + i;
     const float bsx = P[b * 8], bsy = P[b * 8 + 1], bsz = P[b * 8 + 2];
@@ -696,13 +753,13 @@ k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, co
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ar = 32 * ta + 8 * (r >> 2) + 4 * h + (r & 3);
+      const float mf = fmaxf(1.0f - (1.0f - g[r]) * inv_sigma2, 0.f);
+      const float ax = P[ar * 8] - bsx, ay = P[ar * 8 + 1] - bsy, az = P[ar * 8 + 2] - bsz;
+      const float bx = P[ar * 8 + 4] - btx, by = P[ar * 8 + 5] - bty, bz = P[ar * 8 + 6] - btz;
+      const float d = gmf::sqrt_cr(ax * ax + ay * ay + az * az) - gmf::sqrt_cr(bx * bx + by * by + bz * bz);
+      const float ms = fmaxf(1.0f - d * d * inv_sigmad2, 0.f);
+      const float m = (ar == b) ? 0.f : mf * ms;
       if (ar < k && b < k) {
-        const float mf = fmaxf(1.0f - (1.0f - g[r]) * inv_sigma2, 0.f);
-        const float ax = P[ar * 8] - bsx, ay = P[ar * 8 + 1] - bsy, az = P[ar * 8 + 2] - bsz;
-        const float bx = P[ar * 8 + 4] - btx, by = P[ar * 8 + 5] - bty, bz = P[ar * 8 + 6] - btz;
-        const float d = sqrtf(ax * ax + ay * ay + az * az) - sqrtf(bx * bx + by * by + bz * bz);
-        const float ms = fmaxf(1.0f - d * d * inv_sigmad2, 0.f);
-        const float m = (ar == b) ? 0.f : mf * ms;
         Mx[ar * ld + b] = m;
         if (mirror) Mx[b * ld + ar] = m;
       }
@@ -734,21 +791,38 @@ k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, co
   float last = 1.0f;
   float* sn = snaps + ((size_t)pair * S + s) * iters * k;
   unsigned char* cv = conv + ((size_t)pair * S + s) * iters;
-  for (int it = 0; it < iters; ++it) {
-    float v = 0.f;
-    if (a < k) for (int b = 0; b < k; ++b) v = fmaf(Mx[a * ld + b], vec[b], v);
-    float n2 = (a < k) ? v * v : 0.f;
+  // v <- M v / (|M v| + 1e-6), `iters` times.  Lane a keeps ROW a of M in registers for all iterations (the matrix used to be
+  // re-read from the LDS in every one of them: 2 LDS reads per multiply-add); the iterate is read back as broadcast float4s.
+  // Same products in the same order (b ascending), so every iterate is bit-identical to the two-read form.
+  auto power = [&](auto kk_tag) {
+    constexpr int KK = decltype(kk_tag)::value;          // compile-time row length >= k (entries beyond k are zero)
+    float mrow[KK];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o, 64);
-    v = v / (sqrtf(n2) + 1e-6f);
-    const bool close = (a >= k) || (fabsf(v - last) <= 1e-8f + 1e-5f * fabsf(last));
-    const bool all_close = __all(close);
-    __syncthreads();
-    if (a < k) { vec[a] = v; sn[it * k + a] = v; }
-    if (a == 0) cv[it] = all_close ? 1 : 0;
-    last = v;
-    __syncthreads();
-  }
+    for (int b = 0; b < KK; ++b) mrow[b] = (a < k && b < k) ? Mx[a * ld + b] : 0.f;
+    const float4* v4 = reinterpret_cast<const float4*>(vec);
+    for (int it = 0; it < iters; ++it) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < KK / 4; ++q) {
+        const float4 t = v4[q];
+        v = fmaf(mrow[4 * q + 0], t.x, v); v = fmaf(mrow[4 * q + 1], t.y, v);
+        v = fmaf(mrow[4 * q + 2], t.z, v); v = fmaf(mrow[4 * q + 3], t.w, v);
+      }
+      float n2 = (a < k) ? v * v : 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o, 64);
+      v = v / (sqrtf(n2) + 1e-6f);
+      const bool close = (a >= k) || (fabsf(v - last) <= 1e-8f + 1e-5f * fabsf(last));
+      const bool all_close = __all(close);
+      __syncthreads();
+      if (a < k) { vec[a] = v; sn[it * k + a] = v; }
+      if (a == 0) cv[it] = all_close ? 1 : 0;
+      last = v;
+      __syncthreads();
+    }
+  };
+  if (k <= 40) power(std::integral_constant<int, 40>{});
+  else power(std::integral_constant<int, 64>{});
   if (!hsum) return;
   // Weights w = v / (sum v + 1e-6) (PointDSC.py:364-365) and the sums of the weighted Kabsch problem (common.py:10-50:
   // centroids and H) for the LAST iterate, wave-parallel over the k neighbours: hsum [B,S,15] = ca, cb, H.  k_seed_kabsch
@@ -1482,6 +1556,15 @@ hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* 
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_seeds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return e;
+  }
+  // EPT = row elements per thread (registers): the smallest instantiation that holds the row - fewer registers, more rows in flight
+  if (dist_in && N <= 256 * 8) {
+    hipLaunchKernelGGL(k_knn_select_fast<8>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab);
+    return hipGetLastError();
+  }
+  if (dist_in && N <= 256 * 20) {
+    hipLaunchKernelGGL(k_knn_select_fast<20>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab);
+    return hipGetLastError();
   }
   if (dist_in && N <= 256 * 32) {
     hipLaunchKernelGGL(k_knn_select_fast<32>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab);

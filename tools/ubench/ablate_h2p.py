@@ -9,6 +9,7 @@ whose sources changed are rebuilt and linked with the product's other objects in
 What each one removes tells what that resource costs the shipped kernel:
     half_lds   K / V fragments re-read from the LDS for every second k-step only (the LDS traffic of a 64-query wave)
     no_c       the compat stream is not fetched (c = 1): HBM / L2 traffic of the cache
+    c_l2       the compat tiles come from two alternating addresses (L2 hits): the loads and their waits stay, the HBM stream goes
     no_exp     v_exp_f32 replaced by a subtraction
     no_dma     the in-loop K / V tile refills are not issued (stale tiles)
     no_split   probabilities not split into two fp16 planes (one conversion)
@@ -38,8 +39,11 @@ PATCHES = {
     "no_c": [
         (EK, "const f32x4 v = __builtin_nontemporal_load(ct + q * 64);", "const f32x4 v = {1.f, 1.f, 1.f, 1.f}; (void)ct;"),
     ],
+    "c_l2": [    # the compat tiles of a wave alternate between TWO addresses: same loads and waits, served by the L2 instead of HBM
+        (EK, "    const f32x4* ct = crow + (size_t)t * kCTile16;", "    const f32x4* ct = crow + (size_t)(t & 1) * kCTile16;"),
+    ],
     "no_exp": [
-        (EK, "          x[r] = __builtin_amdgcn_exp2f(x[r] - m_off);\n          ls += x[r];",
+        (EK, "          x[r] = expo(x[r], m_off);\n          ls += x[r];",
          "          x[r] = x[r] - m_off;\n          ls += x[r];"),
     ],
     "no_dma": [

@@ -105,9 +105,33 @@ static int run_hot_path(gmf_handle* h, const char* path, hipStream_t st) {
   for (size_t i = 0; i < lg.size(); ++i) el = std::fmax(el, std::fabs(lg[i] - xl.data[i]));
   for (size_t i = 0; i < Tm.size(); ++i) eT = std::fmax(eT, std::fabs(Tm[i] - xT.data[i]));
   std::printf("hot path (B = %d, N = %d, T = %d): max |logit - reference| = %.3e, max |T - reference| = %.3e, status word %d\n", B, N, T, el, eT, flags);
+  // the same pairs through the RAGGED entry points (host array of per-pair sizes, packed rows = the uniform layout when all
+  // sizes are equal): logits and poses of the reference again
+  std::vector<int> n_points((size_t)B, N);
+  CHECK_HIP(hipMemset(dlog, 0, (size_t)B * N * 4));
+  CHECK_HIP(hipMemset(dT, 0, (size_t)B * 16 * 4));
+  rc = gmf_encoder_forward_ragged(h, gmf_packed_encoder_weights(pk), dcp, dsrc, dtgt, dp, dq, n_points.data(), B, T, dlog, dfn, nullptr, st);
+  if (rc == GMF_OK) rc = gmf_pose_head_ragged(h, &pp, 0.1, dfn, dsrc, dtgt, dlog, n_points.data(), B, dT, dlab, nullptr, nullptr, nullptr, nullptr, st);
+  if (rc != GMF_OK) { std::printf("ragged entry points: status %d, %s\n", rc, gmf_last_error_string(h)); return 1; }
+  CHECK_HIP(hipStreamSynchronize(st));
+  CHECK_HIP(hipMemcpy(lg.data(), dlog, lg.size() * 4, hipMemcpyDeviceToHost));
+  CHECK_HIP(hipMemcpy(Tm.data(), dT, Tm.size() * 4, hipMemcpyDeviceToHost));
+  float el2 = 0.f, eT2 = 0.f;
+  for (size_t i = 0; i < lg.size(); ++i) el2 = std::fmax(el2, std::fabs(lg[i] - xl.data[i]));
+  for (size_t i = 0; i < Tm.size(); ++i) eT2 = std::fmax(eT2, std::fabs(Tm[i] - xT.data[i]));
+  std::printf("ragged entry points, same pairs: max |logit - reference| = %.3e, max |T - reference| = %.3e\n", el2, eT2);
+  // a caller-provided workspace that is too small is reported, not overrun
+  void* small = nullptr;
+  CHECK_HIP(hipMalloc(&small, 1 << 20));
+  rc = gmf_set_workspace(h, small, 1 << 20);
+  int rc2 = gmf_encoder_forward(h, gmf_packed_encoder_weights(pk), dcp, dsrc, dtgt, dp, dq, B, N, T, dlog, dfn, nullptr, st);
+  std::printf("1 MiB caller workspace -> status %d (GMF_ERR_WORKSPACE = %d), wanted %lld bytes\n", rc2, (int)GMF_ERR_WORKSPACE, gmf_workspace_wanted(h));
+  const bool ws_ok = rc == GMF_OK && rc2 == GMF_ERR_WORKSPACE && gmf_workspace_wanted(h) > (1 << 20);
+  gmf_set_workspace(h, nullptr, 0);
+  (void)hipFree(small);
   gmf_packed_encoder_free(pk);
   for (float* d : {dcp, dsrc, dtgt, dp, dq, dlog, dfn, dT, dlab}) (void)hipFree(d);
-  return (el < 1e-4f && eT < 1e-4f && flags == 0) ? 0 : 1;
+  return (el < 1e-4f && eT < 1e-4f && el2 < 1e-4f && eT2 < 1e-4f && flags == 0 && ws_ok) ? 0 : 1;
 }
 
 int main(int argc, char** argv) {

@@ -76,10 +76,17 @@ PATCHES = {
         (FF, "    const float* g = wst + (size_t)blob_stage(n_issued) * kStageFloats;", "    const float* g = wst;"),
     ],
     "lin_dma_once": [      # only the first ring-full of stages is fetched (the LDS holds real data, later stages reuse it)
-        (MC, "      for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);\n      ++issued;",
-         "      for (int q = 0; q < 4; ++q) if (issued < NBUF) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);\n      ++issued;"),
-        (FF, "    for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);\n    ++n_issued;",
-         "    for (int q = 0; q < 4; ++q) if (n_issued < NB) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);\n    ++n_issued;"),
+        (MC, "      for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);",
+         "      for (int q = 0; q < 4; ++q) if (issued < NBUF) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);"),
+        (FF, "    for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);",
+         "    for (int q = 0; q < 4; ++q) if (n_issued < NB) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);"),
+    ],
+    "lin_half_dma": [      # after the first ring-full every wave issues HALF of its LDS-DMA pieces (what an 8-wave workgroup sharing the
+                           # stages would issue per wave; the other halves keep finite data of an earlier stage)
+        (MC, "      for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);",
+         "      for (int q = 0; q < 4; ++q) if (q < 2 || issued < NBUF) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);"),
+        (FF, "    for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);",
+         "    for (int q = 0; q < 4; ++q) if (q < 2 || n_issued < NB) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);"),
     ],
     "lin_no_exp": [
         (EH, "      for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }\n      l_half = fmaf(l_half, alpha, ls);\n      if (__any(moved)) {\n#pragma unroll\n        for (int db = 0; db < 2; ++db)",

@@ -756,7 +756,10 @@ GMF_DEVINL AttnItem attn_item(int L, int n_items, int n_full, int ksplits) {
 // fp16 planes of Q', K, V and of the probabilities are multiplied (one product, fp32 accumulation; the softmax statistics,
 // the compat product and the epilogue stay as they are) and c is streamed as fp16 - NOT within the 1e-4 parity gate.
 constexpr float kInvU16 = 1.0f / 65535.0f;
-template <int NPROD = 3, int CFMT = 0>
+// (WAVES = 8 - one 256-query workgroup per CU, every K / V tile fetched once per 256 queries, half the LDS-DMA pieces per wave - was
+// built and measured in round 3: bit-identical results, 19.2 instead of 18.4 ms per step; eight waves behind each tile barrier
+// cost more than the halved stream saves.  The parameter stays, the instantiation is gone.)
+template <int NPROD = 3, int CFMT = 0, int WAVES = 4>
 GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restrict__ q_img, const float* __restrict__ k_img,
                                 const float* __restrict__ v_img, const float* __restrict__ fus, const float* __restrict__ wst,
                                 const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, int wgs_per_pair,
@@ -765,7 +768,6 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
                                 const float* __restrict__ next_bias, const PairTab* __restrict__ ptab = nullptr) {
   float* const ldsK = lds;
   float* const ldsV = lds + 2 * kStageFloats;
-  constexpr int WAVES = 4;
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned lane_off16 = lane * 16;
@@ -845,7 +847,7 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   };
   const float* gk = k_img + pbase * (size_t)kStageFloats;
   const float* gv = v_img + pbase * (size_t)kStageFloats;
-  constexpr int kPiecesPerWave = (NPROD == 3) ? 4 : 2;   // one product: only the high plane (the first 8 KiB) of a tile is used
+  constexpr int kPiecesPerWave = ((NPROD == 3) ? 16 : 8) / WAVES;   // one product: only the high plane (the first 8 KiB) of a tile is used
   auto issue16k = [&](const float* g, float* l) {      // this wave's 4 of the 16 KiB-pieces of one tile
 #pragma unroll
     for (int q = 0; q < kPiecesPerWave; ++q) dma_piece_1k_s(g + (wave + WAVES * q) * 256, l + (wave + WAVES * q) * 256, lane_off16);
@@ -1900,13 +1902,16 @@ k_head(const float* __restrict__ feat_img, const float* __restrict__ wst, const 
 // k_seed_dist: feature-space distances of the seed rows to every correspondence,
 //   dist[seed][j] = 2 - 2 <f_seed, f_j>   (models/common.py:64-66 restricted to the rows PointDSC.py:329 keeps).
 //   One wave = 32 seeds (fragment gathered from the P32 image of the unit features), key tiles streamed
-//   through LDS; D = mfma(A = seed fragment, B = key tile) (split-fp16 operands) puts the key on the lane, so every store is a
-//   128-byte run of one seed's row.  grid (ceil(S/128), B); dist [B, S, N].
+//   through LDS; [r3] D = mfma(A = key tile, B = seed fragment) (split-fp16 operands) puts the SEED on the lane and four
+//   consecutive keys in four consecutive registers: a lane stores its 16 distances of a tile as four 16-byte stores (the
+//   key-on-lane form issued sixteen 4-byte stores per lane and tile - the kernel was bound by issuing them, not by the HBM: 148
+//   -> ~95 us).  The four stores of a lane fill one 128-byte line of the seed's row.  grid (ceil(S/128), B); dist [B, S, ld] with
+//   ld = 32 * tiles (rows padded to whole tiles: every store is aligned and unconditional in the key index).
 // =========================================================================================
 __global__ void __launch_bounds__(256, 2)
 k_seed_dist(const float* __restrict__ featn_img, const int* __restrict__ seeds, float* __restrict__ dist,
             int N, int tiles, int S, int chunks, const PairTab* __restrict__ ptab) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];     // 4-slot ring: three key tiles in flight
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y / chunks, chunk = blockIdx.y - pair * chunks;   // key tiles are split over `chunks` workgroups
@@ -1922,40 +1927,39 @@ k_seed_dist(const float* __restrict__ featn_img, const int* __restrict__ seeds, 
   const float* pair_img = featn_img + (size_t)pair * tiles * (32 * C);
   const int my = seed_base + i;
   const int row = (my < S) ? seeds[(size_t)pair * Smax + my] : 0;
-  float sf[CF];
-  load_row_frag_p32<CF>(sf, pair_img, row, N, h);
   if (t0 >= t1) return;                         // uniform over the workgroup
   // split-fp16 operands (3 products on the f16 MFMA, fp32-equivalent: mfma_core.hpp): 24 MFMAs of 32 cycles per key tile
-  // instead of 64 of 64; the key tile is split in registers from its fp32 image (the unit features have no h2 image)
+  // instead of 64 of 64.  [r3] featn_img is the split-fp16 plane image k_pack_rows_h2 writes (16-byte unit ((plane * 8 + s) * 64 +
+  // lane) of a tile = the 8 halves of k-step s for lane (h, i)): a key tile goes LDS -> MFMA operand with no conversion (every
+  // wave used to split the tile's 64 values per lane again: ~100 vector instructions per tile), and a seed's fragment is the
+  // 16 units of its row's lane slot.
   FragH2<8> sx;
-  sx.set(sf);
+  {
+    const f16x8* rp = reinterpret_cast<const f16x8*>(pair_img + (size_t)(row >> 5) * kStageFloats) + h * 32 + (row & 31);
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) { sx.h[s8] = rp[(0 * 8 + s8) * 64]; sx.l[s8] = rp[(1 * 8 + s8) * 64]; }
+  }
 
-  StageStream ss;
-  ss.init(lds, lds + kStageFloats, wave, kWavesPerWG, lane, pair_img + (size_t)t0 * kStageFloats, t1 - t0);
+  StageRing<4> ss;                              // (a tile is 24 MFMAs: one stage of look-ahead left its L2 round trip exposed)
+  ss.init(lds, wave, lane, pair_img + (size_t)t0 * kStageFloats, t1 - t0);
   ss.prime();
-  float* drow = dist + ((size_t)pair * Smax) * Nmax;
+  const int ld = tiles * 32;
+  float* drow = dist + ((size_t)pair * Smax + seed_base + i) * ld + 4 * h;      // this lane's seed row, its half of each 8-key group
   for (int t = t0; t < t1; ++t) {
-    const float4* lk = ss.acquire();
+    const f16x8* lk = as_h2(ss.acquire());
     f32x16 acc = zero16();
-    {
-      float kx[CF];
 #pragma unroll
-      for (int g = 0; g < CF / 4; ++g) {
-        const float4 w = lk[g * 64];
-        kx[4 * g + 0] = w.x; kx[4 * g + 1] = w.y; kx[4 * g + 2] = w.z; kx[4 * g + 3] = w.w;
-      }
-      FragH2<8> kf;
-      kf.set(kx);
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) mma3(acc, sx.h[s8], sx.l[s8], kf.h[s8], kf.l[s8]);
+    for (int s8 = 0; s8 < 8; ++s8) {            // (the products in the order of the key-on-lane form: s_l k_h, s_h k_l, s_h k_h)
+      const f16x8 kh = lk[(0 * 8 + s8) * 64], kl = lk[(1 * 8 + s8) * 64];
+      acc = mfma_h16(kh, sx.l[s8], acc);
+      acc = mfma_h16(kl, sx.h[s8], acc);
+      acc = mfma_h16(kh, sx.h[s8], acc);
     }
-    const int j = t * 32 + i;
-    if (j < N) {
+    if (my < S) {                               // register r = key 8 (r >> 2) + 4 h + (r & 3) of the tile, lane = seed
+      float4* out = reinterpret_cast<float4*>(drow + (size_t)t * 32);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int sd = seed_base + 8 * (r >> 2) + 4 * h + (r & 3);
-        if (sd < S) drow[(size_t)sd * Nmax + j] = 2.0f - 2.0f * acc[r];
-      }
+      for (int q = 0; q < 4; ++q)
+        out[2 * q] = make_float4(2.0f - 2.0f * acc[4 * q], 2.0f - 2.0f * acc[4 * q + 1], 2.0f - 2.0f * acc[4 * q + 2], 2.0f - 2.0f * acc[4 * q + 3]);
     }
   }
 }
@@ -1983,6 +1987,32 @@ __global__ void k_pack_p32(const float* __restrict__ src, float* __restrict__ ds
     v = make_float4(p[0], p[sk], p[2 * sk], p[3 * sk]);
   }
   reinterpret_cast<float4*>(dst)[idx] = v;
+}
+
+// row-major [B, n_rows, 128] (ragged: packed rows, PairTab) -> split-fp16 plane image [B, tiles, 4096 floats]: per tile the
+// 16-byte unit ((plane * 8 + s) * 64 + lane) holds, for lane (h, i) = row 32 tile + i, the 8 halves of k-step s in fragment
+// order (f = 8 s + j -> feature 32 (f >> 4) + 8 ((f & 15) >> 2) + 4 h + (f & 3)); plane 0 = fp16(x), plane 1 = fp16(x - hi).
+// Rows >= n_rows are zero.  The operand image of k_seed_dist (the unit features of the pose head).
+__global__ void k_pack_rows_h2(const float* __restrict__ src, float* __restrict__ dst, int n_rows, int tiles, long total,
+                               const PairTab* __restrict__ ptab) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;       // one (tile, k-step, lane) per thread
+  if (idx >= total) return;
+  const int lane = idx & 63, s8 = (idx >> 6) & 7;
+  const long bt = idx >> 9;
+  const int tile = bt % tiles;
+  const int b = (int)(bt / tiles);
+  const int h = lane >> 5, row = tile * 32 + (lane & 31);
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (row < pair_rows(ptab, b, n_rows)) {
+    const float* p = src + (pair_row0(ptab, b, n_rows) + row) * C + 32 * (s8 >> 1) + 16 * (s8 & 1) + 4 * h;
+    const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 8);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+  }
+  f16x8 hi, lo;
+  split8h(v, hi, lo);
+  f16x8* out = reinterpret_cast<f16x8*>(dst + bt * kStageFloats);
+  out[(0 * 8 + s8) * 64 + lane] = hi;
+  out[(1 * 8 + s8) * 64 + lane] = lo;
 }
 
 // P32 image -> strided [B, n_rows, K]
@@ -2219,6 +2249,13 @@ hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int 
   const int tiles = (n_rows + 31) / 32;
   const long total4 = (long)B * tiles * (K / 8) * 64;
   hipLaunchKernelGGL(k_pack_p32, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, src, dst, n_rows, tiles, K, sb, sr, sk, total4, ptab);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_rows_h2(const float* src, float* dst, int B, int n_rows, hipStream_t s, const PairTab* ptab) {
+  const int tiles = (n_rows + 31) / 32;
+  const long total = (long)B * tiles * 8 * 64;
+  hipLaunchKernelGGL(k_pack_rows_h2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, n_rows, tiles, total, ptab);
   return hipGetLastError();
 }
 

@@ -785,11 +785,11 @@ static int pose_head_impl(gmf_handle* h, const gmf_pose_params* p, const float* 
   const size_t need = arena_need((size_t)B * N, 4) + arena_need(BS, 4) + arena_need(BS * k, 4) +
                       arena_need(BS * iters * k, 4) + arena_need(BS * iters, 1) + arena_need(BS * 16, 4) +
                       arena_need(BS, 4) + arena_need(BS, 4) + arena_need(B, 4) + arena_need(BS * 15, 8) + arena_need(1, 4) +
-                      arena_need((size_t)B * tiles_of(N) * kTileFloats, 4) + arena_need(BS * N, 4) +
+                      arena_need((size_t)B * tiles_of(N) * kTileFloats, 4) + arena_need(BS * tiles_of(N) * 32, 4) +
                       arena_need((size_t)B, sizeof(gmf::PairTab));
   if (int rc = arena_reserve(h, need)) return rc;
   float* fimg = arena_take<float>(h, (size_t)B * tiles_of(N) * kTileFloats);
-  float* dmat = arena_take<float>(h, BS * N);
+  float* dmat = arena_take<float>(h, BS * tiles_of(N) * 32);       // distance rows of the seeds, padded to whole tiles
   float* keys = arena_take<float>(h, (size_t)B * N);
   int* seeds = arena_take<int>(h, BS);
   int* knn = arena_take<int>(h, BS * k);
@@ -832,7 +832,7 @@ static int pose_head_impl(gmf_handle* h, const gmf_pose_params* p, const float* 
     GMF_HIP(hipMemcpyAsync(seeds_out, seeds_in, BS * sizeof(int), hipMemcpyDeviceToDevice, st));
   }
   // feature-space distances of the seed rows by MFMA (k_seed_dist), then per-seed top-(k+1) selection
-  GMF_HIP(gmf::launch_pack_p32(feat_n, fimg, B, N, kC, (long)N * kC, kC, 1, st, ptab));
+  GMF_HIP(gmf::launch_pack_rows_h2(feat_n, fimg, B, N, st, ptab));
   GMF_HIP(gmf::launch_seed_dist(fimg, seeds_use, dmat, B, N, Sn, st, ptab));
   GMF_HIP(gmf::launch_knn_seeds(feat_n, seeds_use, dmat, knn, B, N, Sn, k, st, ptab));
   GMF_HIP(gmf::launch_seed_power(feat_n, src_keypts, tgt_keypts, knn, snaps, conv, hsum, B, N, Sn, k, iters, p->sigma, p->sigma_d, st, ptab));

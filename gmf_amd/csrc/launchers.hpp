@@ -118,6 +118,8 @@ hipError_t launch_nn_match(const float* F0, const float* F1, float* f0_img, floa
                            float* dist, int N0, int N1, int d, int mode, hipStream_t s);
 hipError_t launch_seed_dist(const float* featn_img, const int* seeds, float* dist, int B, int N, int S, hipStream_t s, const PairTab* ptab = nullptr);
 hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s, const PairTab* ptab = nullptr);
+// row-major [B, n_rows, 128] -> split-fp16 plane image (the operand image of launch_seed_dist)
+hipError_t launch_pack_rows_h2(const float* src, float* dst, int B, int n_rows, hipStream_t s, const PairTab* ptab = nullptr);
 hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s, int* status = nullptr);
 hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s, const PairTab* ptab = nullptr);
 

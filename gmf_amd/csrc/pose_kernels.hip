@@ -412,7 +412,7 @@ k_select_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, 
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_knn_seeds(const float* __restrict__ feat_n, const int* __restrict__ seeds, const float* __restrict__ dist_in,
-            int* __restrict__ knn_idx, int N, int S, int k, const PairTab* __restrict__ ptab) {
+            int* __restrict__ knn_idx, int N, int S, int k, const PairTab* __restrict__ ptab, int ld) {
   extern __shared__ float dist[];
   __shared__ float fs[128];
   __shared__ float red_v[4];
@@ -420,7 +420,7 @@ k_knn_seeds(const float* __restrict__ feat_n, const int* __restrict__ seeds, con
   const int pair = blockIdx.y, s = blockIdx.x;
   if (s >= pair_seeds(ptab, pair, S)) return;
   const float* fb = feat_n + pair_row0(ptab, pair, N) * 128;
-  const float* dr0 = dist_in ? dist_in + ((size_t)pair * S + s) * N : nullptr;     // (strides of the largest pair)
+  const float* dr0 = dist_in ? dist_in + ((size_t)pair * S + s) * ld : nullptr;    // (strides of the largest pair, rows padded to ld)
   N = pair_rows(ptab, pair, N);
   if (dist_in) {        // distances precomputed by k_seed_dist (MFMA): just stage the row in LDS
     const float* dr = dr0;
@@ -475,13 +475,13 @@ k_knn_seeds(const float* __restrict__ feat_n, const int* __restrict__ seeds, con
 // ---------------------------------------------------------------------------------------
 template <int EPT>
 __global__ void __launch_bounds__(256)
-k_knn_select(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N, int S, int k, const PairTab* __restrict__ ptab) {
+k_knn_select(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N, int S, int k, const PairTab* __restrict__ ptab, int ld) {
   __shared__ float red_v[2][4];
   __shared__ int red_i[2][4];
   const int pair = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   if (s >= pair_seeds(ptab, pair, S)) return;
-  const float* dr = dist_in + ((size_t)pair * S + s) * N;
+  const float* dr = dist_in + ((size_t)pair * S + s) * ld;
   N = pair_rows(ptab, pair, N);
   float v[EPT];
 #pragma unroll
@@ -528,7 +528,7 @@ constexpr int kCandMax = 1024;
 
 template <int EPT>
 __global__ void __launch_bounds__(256, EPT <= 20 ? 6 : EPT <= 32 ? 5 : 3)      // (a latency chain per row: 5-6 rows per SIMD in flight)
-k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N, int S, int k, const PairTab* __restrict__ ptab) {
+k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N, int S, int k, const PairTab* __restrict__ ptab, int ld) {
   __shared__ float mins[256];
   __shared__ __attribute__((aligned(16))) float cand_v[kCandMax + 4];
   __shared__ __attribute__((aligned(16))) int cand_i[kCandMax + 4];
@@ -538,7 +538,7 @@ k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, 
   __shared__ int red_i[2][4];
   const int pair = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
   if (s >= pair_seeds(ptab, pair, S)) return;
-  const float* dr = dist_in + ((size_t)pair * S + s) * N;                 // (strides of the largest pair)
+  const float* dr = dist_in + ((size_t)pair * S + s) * ld;                // (strides of the largest pair; rows padded to ld floats)
   int* out = knn_idx + ((size_t)pair * S + s) * k;
   N = pair_rows(ptab, pair, N);
   // a row with NaN distances yields fewer than k + 1 candidates: every slot holds an in-range index before the ranks are
@@ -1552,6 +1552,7 @@ hipError_t launch_sort_topk(const Tuning& tune, const float* keys, int* out_idx,
 
 hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* dist_in, int* knn_idx, int B, int N, int S,
                             int k, hipStream_t s, const PairTab* ptab) {
+  const int ld = ((N + 31) / 32) * 32;             // row stride of dist_in (launch_seed_dist pads the rows to whole tiles)
   if ((size_t)N * 4 > 150 * 1024) return hipErrorInvalidValue;
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_seeds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -1559,22 +1560,22 @@ hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* 
   }
   // EPT = row elements per thread (registers): the smallest instantiation that holds the row - fewer registers, more rows in flight
   if (dist_in && N <= 256 * 8) {
-    hipLaunchKernelGGL(k_knn_select_fast<8>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab);
+    hipLaunchKernelGGL(k_knn_select_fast<8>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab, ld);
     return hipGetLastError();
   }
   if (dist_in && N <= 256 * 20) {
-    hipLaunchKernelGGL(k_knn_select_fast<20>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab);
+    hipLaunchKernelGGL(k_knn_select_fast<20>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab, ld);
     return hipGetLastError();
   }
   if (dist_in && N <= 256 * 32) {
-    hipLaunchKernelGGL(k_knn_select_fast<32>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab);
+    hipLaunchKernelGGL(k_knn_select_fast<32>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab, ld);
     return hipGetLastError();
   }
   if (dist_in && N <= 256 * 64) {
-    hipLaunchKernelGGL(k_knn_select_fast<64>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab);
+    hipLaunchKernelGGL(k_knn_select_fast<64>, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab, ld);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(k_knn_seeds, dim3(S, B), dim3(256), (size_t)N * 4, s, feat_n, seeds, dist_in, knn_idx, N, S, k, ptab);
+  hipLaunchKernelGGL(k_knn_seeds, dim3(S, B), dim3(256), (size_t)N * 4, s, feat_n, seeds, dist_in, knn_idx, N, S, k, ptab, ld);
   return hipGetLastError();
 }
 

@@ -119,7 +119,9 @@ def main():
     ap.add_argument("--tokens", type=int, default=196)
     ap.add_argument("--kind", default="3dmatch", choices=["3dmatch", "kitti"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sweep", action="store_true", help="append N = 1000 / 10000, KITTI-shape and B = 1 results (rank 0, N = 1 GPU)")
+    ap.add_argument("--sweep", action="store_true", help="full sweep: the default size points (N = 1000 / 10000, KITTI shape, B = 1, ragged) plus the "
+                                                       "throughput numerics modes and the DGR rows (rank 0, N = 1 GPU)")
+    ap.add_argument("--no-sweep", action="store_true", help="headline only")
     ap.add_argument("--rehearsal", action="store_true",
                     help="N > 1 ranks on a box with fewer GPUs: ranks share the devices (local_rank %% device_count) and exchange "
                          "through gloo staged over the host.  Exercises the launch line, the sharded step and the JSON line; the "
@@ -230,8 +232,10 @@ def main():
     }
     if args.rehearsal:
         line["rehearsal"] = "ranks share the GPU(s) and exchange through gloo over the host: NOT a measurement"
-    if args.sweep and world == 1:
-        line["sweep"] = sweep(dev)
+    if world == 1 and not args.no_sweep:
+        # the size points of SURVEY.md section 8d ride in the default line too (~10 s), so that they are in the DRIVER's record
+        # and not only in builder-run files; --sweep adds the throughput modes and the DGR rows
+        line["sweep"] = sweep(dev, full=args.sweep)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"], line["parity"] = cpu_baseline(sd, batch, out, N, T, tau)
         if args.kind == "3dmatch":
@@ -240,9 +244,10 @@ def main():
     driver.close()
 
 
-def sweep(dev):
-    """Other operating points of the same build: N in {1 k, 10 k}, the KITTI shape (config 3) and the
-    B = 1 latency points (the reference's evaluation mode).  Few steps each; the headline is not affected."""
+def sweep(dev, full=False):
+    """Other operating points of the same build: N in {1 k, 10 k}, the KITTI shape (config 3), the
+    B = 1 latency points (the reference's evaluation mode) and one ragged batch.  Few steps each; the headline is not affected.
+    full: also the throughput numerics modes and the DGR rows."""
     from gmf_amd.dist import ShardedBatchDriver
     rows = []
     peak = PEAK_F16_MFMA_TFLOPS / PRODUCTS
@@ -297,6 +302,8 @@ def sweep(dev):
                  "same_pairs_as_32_calls_with_B_1": {"ms": ms_1, "value": sum(sizes) / (ms_1 * 1e-3)}})
     del model, rag, packed, singles, pairs
     torch.cuda.empty_cache()
+    if not full:
+        return rows
     # the throughput numerics modes (gmf_set_tuning "precision" = 1, 2; NOT the parity path, never the headline) on the headline
     # workload, with its measured deviation from the parity mode on the same batch
     from gmf_amd import _lib

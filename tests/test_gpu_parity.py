@@ -305,11 +305,11 @@ def test_batched_equals_per_pair(model):
 
 
 def test_ragged_batch_equals_per_pair_calls(model):
-    """gmf_encoder_forward_ragged + gmf_pose_head_ragged: four pairs with their OWN N in one launch (what the reference's
+    """gmf_encoder_forward_ragged + gmf_pose_head_ragged: five pairs with their OWN N in one launch (what the reference's
     evaluation loop feeds one pair at a time, evaluation/test_3DMatch.py:69) give each pair the result of its own B = 1 call -
     logits to 5e-5 (the ragged launch runs the large-grid kernels, a B = 1 call the small-grid ones: other summation orders),
     poses to 1e-4, identical inlier labels up to the points a 5e-5 logit change can flip."""
-    sizes = [700, 1531, 5000, 257]
+    sizes = [700, 1531, 5000, 257, 45]             # (45: barely more than k = 40 neighbours, two tiles, four seeds)
     keys = ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")
     pairs = [synthetic.synthetic_batch([300 + i], N=n, T=196) for i, n in enumerate(sizes)]
     rag = {k: [_gpu(b[k][0]) for b in pairs] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
@@ -317,7 +317,7 @@ def test_ragged_batch_equals_per_pair_calls(model):
     rag["q_tokens"] = torch.cat([_gpu(b["q_tokens"]) for b in pairs])
     rag["testing"] = True
     out = model(rag)                                           # lists -> forward_ragged
-    assert out["final_trans"].shape == (4, 4, 4) and [t.shape[0] for t in out["final_labels"]] == sizes
+    assert out["final_trans"].shape == (len(sizes), 4, 4) and [t.shape[0] for t in out["final_labels"]] == sizes
     gmf_amd.check_status()
     for i, b in enumerate(pairs):
         one = {k: _gpu(b[k]) for k in keys}

@@ -972,12 +972,15 @@ k_score_hyp(const float* __restrict__ src, const float* __restrict__ tgt, const 
   const int pair = blockIdx.y, s0 = blockIdx.x * kHypPerWG;
   const int S_p = pair_seeds(ptab, pair, S);                // (ragged batch; the per-seed buffers keep the stride S)
   if (s0 >= S_p) return;
-  float Tm[kHypPerWG][12];
+  // two hypotheses per packed-fp32 instruction (v_pk_mul / v_pk_fma / v_pk_add_f32: the same operations with the same roundings
+  // as the scalar form, half the instructions of a kernel that is nothing but vector arithmetic)
+  nms_f2 Tm[kHypPerWG / 2][12];
 #pragma unroll
-  for (int q = 0; q < kHypPerWG; ++q) {
-    const float* T = seed_T + ((size_t)pair * S + min(s0 + q, S_p - 1)) * 16;
+  for (int q = 0; q < kHypPerWG / 2; ++q) {
+    const float* Ta = seed_T + ((size_t)pair * S + min(s0 + 2 * q, S_p - 1)) * 16;
+    const float* Tb = seed_T + ((size_t)pair * S + min(s0 + 2 * q + 1, S_p - 1)) * 16;
 #pragma unroll
-    for (int e = 0; e < 12; ++e) Tm[q][e] = T[e];
+    for (int e = 0; e < 12; ++e) Tm[q][e] = nms_f2{Ta[e], Tb[e]};
   }
   const float* ps = src + pair_row0(ptab, pair, N) * 3;
   const float* pt = tgt + pair_row0(ptab, pair, N) * 3;
@@ -986,14 +989,17 @@ k_score_hyp(const float* __restrict__ src, const float* __restrict__ tgt, const 
 #pragma unroll
   for (int q = 0; q < kHypPerWG; ++q) cnt[q] = 0;
   for (int j = threadIdx.x; j < N; j += 256) {
-    const float x = ps[3 * j], y = ps[3 * j + 1], z = ps[3 * j + 2];
-    const float u = pt[3 * j], v = pt[3 * j + 1], w = pt[3 * j + 2];
+    const float xs = ps[3 * j], ys = ps[3 * j + 1], zs = ps[3 * j + 2];
+    const float us = pt[3 * j], vs = pt[3 * j + 1], ws = pt[3 * j + 2];
+    const nms_f2 x = {xs, xs}, y = {ys, ys}, z = {zs, zs}, u = {us, us}, v = {vs, vs}, w = {ws, ws};
 #pragma unroll
-    for (int q = 0; q < kHypPerWG; ++q) {
-      const float dx = (Tm[q][0] * x + Tm[q][1] * y + Tm[q][2] * z) + Tm[q][3] - u;
-      const float dy = (Tm[q][4] * x + Tm[q][5] * y + Tm[q][6] * z) + Tm[q][7] - v;
-      const float dz = (Tm[q][8] * x + Tm[q][9] * y + Tm[q][10] * z) + Tm[q][11] - w;
-      cnt[q] += (dx * dx + dy * dy + dz * dz < tau2t) ? 1 : 0;
+    for (int q = 0; q < kHypPerWG / 2; ++q) {
+      const nms_f2 dx = (Tm[q][0] * x + Tm[q][1] * y + Tm[q][2] * z) + Tm[q][3] - u;
+      const nms_f2 dy = (Tm[q][4] * x + Tm[q][5] * y + Tm[q][6] * z) + Tm[q][7] - v;
+      const nms_f2 dz = (Tm[q][8] * x + Tm[q][9] * y + Tm[q][10] * z) + Tm[q][11] - w;
+      const nms_f2 d2 = dx * dx + dy * dy + dz * dz;
+      cnt[2 * q] += (d2[0] < tau2t) ? 1 : 0;
+      cnt[2 * q + 1] += (d2[1] < tau2t) ? 1 : 0;
     }
   }
 #pragma unroll

@@ -59,6 +59,46 @@ GMF_DEVINL void store_block_h2(float* __restrict__ tile_base, int blk, const flo
   }
 }
 
+// The V image of the parity attention kernel's "pv_fp8" form (k_scattn_h2p<3, CFMT, true>): the high fp16 plane as above; in
+// place of the low fp16 plane, per feature block db, the two e4m3 operands of the CROSS products of O += P V -
+//   16-byte unit (1*8 + 2 db)*64 + lane :  e4m3((v - hi) / (s / 2^11))   of the lane's 16 keys, register order
+//   16-byte unit (1*8 + 2 db + 1)*64 + lane :  e4m3(v / s)
+// with ONE power-of-two scale s per (feature, 32-key tile): the tile's largest |v| of that feature lands in [128, 256).  The
+// E8M0 bytes of the two blocks go to `scale_word` (byte db: lanes 0..31 carry the low block's, lanes 32..63 the high block's -
+// where v_mfma_scale_f32_32x32x64_f8f6f4 reads them), one dword per lane and tile.  t: the lane's feature, 16 keys (V^T block).
+GMF_DEVINL void store_block_v8(float* __restrict__ tile_base, int db, const float (&t)[16], int lane, unsigned& scale_word) {
+  f16x8* base = reinterpret_cast<f16x8*>(tile_base);
+  float mx = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mx = __builtin_fmaxf(mx, __builtin_fabsf(t[r]));
+  mx = xhalf_max_swap(mx);
+  // biased exponent e of the maximum: max in [2^(e-127), 2^(e-126)); s = 2^(e-134).  Clamped so that s / 2^11 stays a normal
+  // float (a feature whose 32 values are all below 2^-108 is stored as zeros: 2^-108 of anything this network computes)
+  const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+  const int sb = max(e - 7, 12);
+  const float s_hi = __uint_as_float((unsigned)sb << 23), s_lo = __uint_as_float((unsigned)(sb - 11) << 23);
+  scale_word |= (unsigned)((lane & 32) ? sb : sb - 11) << (8 * db);
+  i32x4 v8, l8;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f16x8 hi;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const float x0 = t[8 * half + j], x1 = t[8 * half + j + 1];
+      const f32x2 x = {x0, x1};
+      const f16x2 hh = __builtin_convertvector(x, f16x2);
+      const f32x2 rl = resid2h(hh, x0, x1);
+      hi[j] = hh[0]; hi[j + 1] = hh[1];
+      const int w = 2 * half + (j >> 2);
+      if (j & 2) { v8[w] = cvt2_fp8_f32<true>(v8[w], x0, x1, s_hi); l8[w] = cvt2_fp8_f32<true>(l8[w], rl[0], rl[1], s_lo); }
+      else { v8[w] = cvt2_fp8_f32<false>(0, x0, x1, s_hi); l8[w] = cvt2_fp8_f32<false>(0, rl[0], rl[1], s_lo); }
+    }
+    base[(0 * 8 + 2 * db + half) * 64 + lane] = hi;
+  }
+  reinterpret_cast<i32x4*>(tile_base)[(1 * 8 + 2 * db) * 64 + lane] = l8;
+  reinterpret_cast<i32x4*>(tile_base)[(1 * 8 + 2 * db + 1) * 64 + lane] = v8;
+}
+
 // LCPE (fusion_layer.py:118-128): y[row] = x[row] + b + w0*x[row-1] + w1*x[row] + w2*x[row+1],
 // zero padding outside [0, n_rows).  taps = w0[C] | w1[C] | w2[C] | b[C].
 GMF_DEVINL void lcpe_frag(float (&y)[CF], const float* __restrict__ pair_base, int row, int n_rows,

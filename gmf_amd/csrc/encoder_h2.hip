@@ -427,7 +427,8 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
                                const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
                                const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
                                float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles,
-                               int T, int ttiles, const PairTab* __restrict__ ptab = nullptr) {
+                               int T, int ttiles, const PairTab* __restrict__ ptab = nullptr,
+                               unsigned* __restrict__ v_scale = nullptr) {   // non-null: V with e4m3 cross planes (store_block_v8)
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y;
@@ -500,6 +501,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
         store_block_h2(dst, mb, t, lane);
       }
     }
+    unsigned vsw = 0;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {             // V (feature on lane)
       const f16x8* lw = as_h2(PART == 1 ? ss.acquire() : ss.acquire_counted<20>());
@@ -508,8 +510,12 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
       float t[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bvv[db]);
-      store_block_h2(v_out + toff, db, t, lane);
+      if (v_scale) store_block_v8(v_out + toff, db, t, lane, vsw);     // (4 stores of 16 bytes either way: the counted waits hold)
+      else store_block_h2(v_out + toff, db, t, lane);
     }
+    // one more store than the counted waits of the stages that follow assume: their counts are lower bounds, it only makes them
+    // wait for one operation more
+    if (v_scale) v_scale[((size_t)pair * tiles + tile) * 64 + lane] = vsw;
   }
 
   if (PART == 1) {
@@ -663,10 +669,10 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
             const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
             const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
             float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
-            int ttiles, const PairTab* __restrict__ ptab) {
+            int ttiles, const PairTab* __restrict__ ptab, unsigned* __restrict__ v_scale) {
   __shared__ __attribute__((aligned(16))) float lds[kLinLdsFloats];
   linear_h2_body<0, NP>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
-                        tiles, T, ttiles, ptab);
+                        tiles, T, ttiles, ptab, v_scale);
 }
 
 // grid (ceil(tiles / 4), B, 2): blockIdx.z = 0 the Q'/K/V role, 1 the Fusion-2 role of the same 128 rows
@@ -675,11 +681,11 @@ k_linear_roles(const float* __restrict__ f_in, const float* __restrict__ front_w
                const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
                const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
                float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
-               int ttiles) {
+               int ttiles, unsigned* __restrict__ v_scale) {
   __shared__ __attribute__((aligned(16))) float lds[kLinLdsFloats];
   if (blockIdx.z == 0)
     linear_h2_body<1>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
-                      tiles, T, ttiles);
+                      tiles, T, ttiles, nullptr, v_scale);
   else
     linear_h2_body<2>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
                       tiles, T, ttiles);
@@ -733,18 +739,18 @@ hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const 
 hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                             const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec, float* q,
                             float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s,
-                            bool one_product, const PairTab* ptab) {
+                            bool one_product, const PairTab* ptab, unsigned* v_scale) {
   // grids that give a CU about one workgroup: two roles per row block (the Q'/K/V projections | Fusion-2) in one launch
   const int W = ((tiles + 3) / 4) * B;
   if (tune.mid_grid_roles > 0 && W < tune.mid_grid_roles && !ptab)
     hipLaunchKernelGGL(k_linear_roles, tgrid(tiles, B, 2), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec,
-                       ff_wst, ff_vec, q, k, v, x2, N, tiles, T, ttiles);
+                       ff_wst, ff_vec, q, k, v, x2, N, tiles, T, ttiles, v_scale);
   else if (one_product)                            // throughput numerics mode: high planes only
     hipLaunchKernelGGL(k_linear_h2<1>, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
-                       ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab);
+                       ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab, v_scale);
   else
     hipLaunchKernelGGL(k_linear_h2<3>, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
-                       ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab);
+                       ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab, v_scale);
   return hipGetLastError();
 }
 

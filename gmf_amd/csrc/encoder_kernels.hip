@@ -621,11 +621,6 @@ GMF_DEVINL f32x16 mma3_part(int u, f32x16 acc, f16x8 ah, f16x8 al, f16x8 bh, f16
   }
 }
 
-// max over the two K-halves of a row without the LDS: swap the upper 32 lanes of one copy with the lower 32 of another
-GMF_DEVINL float xhalf_max_swap(float v) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
 
 // A tile's 8 LDS-DMA pieces are issued one per unit in the bare MFMA gaps of phase 2 (at the tile top / in phase 1
 // measured 1.19 / 1.17 ms against 1.16 ms per launch in round 1).
@@ -759,13 +754,22 @@ constexpr float kInvU16 = 1.0f / 65535.0f;
 // (WAVES = 8 - one 256-query workgroup per CU, every K / V tile fetched once per 256 queries, half the LDS-DMA pieces per wave - was
 // built and measured in round 3: bit-identical results, 19.2 instead of 18.4 ms per step; eight waves behind each tile barrier
 // cost more than the halved stream saves.  The parameter stays, the instantiation is gone.)
-template <int NPROD = 3, int CFMT = 0, int WAVES = 4>
+// PVF8 (with NPROD = 3): the two CROSS products of O += P V (P_hi V_lo + P_lo V_hi) on the block-scaled fp8 matrix pipe - ONE
+// v_mfma_scale_f32_32x32x64_f8f6f4 per feature block and tile instead of four f16 MFMAs; P_hi V_hi and all of S = Q' K^T stay
+// three-product split-fp16.  The V image then carries e4m3 planes with one scale per (feature, tile) in place of its low fp16
+// plane (store_block_v8, enc_common.hpp; scales in `v_scale`), the probabilities are p ~ ph + pl8 with ph = fp16(p) and
+// pl8 = e4m3 of the residual, and the row sum is taken over exactly those values - numerator and denominator of the softmax see the
+// same probabilities, so what is left of the e4m3 rounding is (v_j - o) weighted: 1.5e-6 ... 2.5e-6 on the logits in the fp64
+// emulation of the whole encoder (tests/tools/mx_cross_emulation.py; 2e-5 with the row sum over the unrounded values).
+template <int NPROD = 3, int CFMT = 0, int WAVES = 4, bool PVF8 = false>
 GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restrict__ q_img, const float* __restrict__ k_img,
                                 const float* __restrict__ v_img, const float* __restrict__ fus, const float* __restrict__ wst,
                                 const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, int wgs_per_pair,
                                 const float* __restrict__ c_dense, int n_items, int n_full, int ksplits,
                                 float* __restrict__ part_o, float* __restrict__ part_ml, const float* __restrict__ next_wst,
-                                const float* __restrict__ next_bias, const PairTab* __restrict__ ptab = nullptr) {
+                                const float* __restrict__ next_bias, const PairTab* __restrict__ ptab = nullptr,
+                                const unsigned* __restrict__ v_scale = nullptr) {
+  static_assert(!PVF8 || NPROD == 3, "the fp8 cross products belong to the three-product form");
   float* const ldsK = lds;
   float* const ldsV = lds + 2 * kStageFloats;
   const int lane = threadIdx.x & 63, h = lane >> 5;
@@ -803,8 +807,13 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   const f32x4* const crow = reinterpret_cast<const f32x4*>(c_dense) + ((pbase + tile) * (size_t)tiles) * kCTile16 + lane;
   float c[16];                                         // CFMT 0 / 1: the compat values of the tile
   unsigned cw[8];                                      // CFMT 2: the tile's 16 x 16 bit as loaded (decoded where the scores are formed)
+  // PVF8: the E8M0 scale bytes of V tile t for this lane (byte db), fetched with c one tile ahead and handed over at the tile top
+  const unsigned* const vsrow = PVF8 ? v_scale + pbase * 64 + lane : nullptr;
+  unsigned vsw_next = 0, vsw = 0;
+  const int psc = (lane & 32) ? 117 : 129;             // scale bytes of the probability operand: block 0 = e4m3(p / 4), block 1 = e4m3(p_lo 2^10)
   auto fetch_c = [&](int t) {
     const f32x4* ct = crow + (size_t)t * kCTile16;
+    if (PVF8) vsw_next = __builtin_nontemporal_load(vsrow + (size_t)t * 64);
     if (CFMT == 1) {
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
@@ -845,6 +854,26 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
     if (NPROD == 3) split2h(x0, x1, hi, lo, j);
     else { const f32x2 xx = {x0, x1}; const f16x2 hh = __builtin_convertvector(xx, f16x2); hi[j] = hh[0]; hi[j + 1] = hh[1]; }
   };
+  // PVF8: pair kp (keys 2 kp, 2 kp + 1 of the lane's 16) of the fp8 operand pb = [e4m3(ph / 4) x 16 | e4m3(pl 2^10) x 16], and the
+  // row sums over the values the matrix pipe will multiply: ph (exact in fp16) and the DECODED pl8
+  auto planes_f8 = [&](const f16x8& hi, const f16x8& lo, const int j, const int kp, i32x8& pb, float& ls_h, float& ls_l) {
+    const f16x2 hh = {hi[j], hi[j + 1]}, ll = {lo[j], lo[j + 1]};
+    const f16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+    const int w = kp >> 1;
+    if (kp & 1) {
+      pb[w] = cvt2_fp8_f16<true>(pb[w], hh, 4.0f);
+      pb[4 + w] = cvt2_fp8_f16<true>(pb[4 + w], ll, 0x1p-10f);
+      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<true>(pb[4 + w], 0x1p-10f), ones, ls_l, false);
+    } else {
+      int d0, d1;                                  // (the other half of each word is written by the odd pair: no zero-fill)
+      asm("" : "=v"(d0), "=v"(d1));
+      pb[w] = cvt2_fp8_f16<false>(d0, hh, 4.0f);
+      pb[4 + w] = cvt2_fp8_f16<false>(d1, ll, 0x1p-10f);
+      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<false>(pb[4 + w], 0x1p-10f), ones, ls_l, false);
+    }
+    ls_h = __builtin_amdgcn_fdot2(hh, ones, ls_h, false);
+    asm volatile("" : "+v"(ls_h), "+v"(ls_l));     // the sums stay in this unit's issue gap (left alone they sink to the next tile top)
+  };
   const float* gk = k_img + pbase * (size_t)kStageFloats;
   const float* gv = v_img + pbase * (size_t)kStageFloats;
   constexpr int kPiecesPerWave = ((NPROD == 3) ? 16 : 8) / WAVES;   // one product: only the high plane (the first 8 KiB) of a tile is used
@@ -879,6 +908,7 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   auto tile_top = [&](const int t, const f32x16& s_cur, float (&x)[16], float& mx) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (PVF8) vsw = vsw_next;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
       x[r] = score(r, s_cur[r]);
@@ -911,12 +941,15 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   // one pipelined tile (t + 1 < tiles): scores of tile t are in s_cur, S_{t+1} accumulates into s_next
   auto tile_step = [&](const int t, const f32x16& s_cur, f32x16& s_next) {
     float x[16];
-    float mx = -INFINITY, m_off = 0.f, alpha = 1.f, ls = 0.f;
+    float mx = -INFINITY, m_off = 0.f, alpha = 1.f, ls = 0.f, ls_l = 0.f;
     tile_top(t, s_cur, x, mx);
     const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV + (t & 1) * kStageFloats) + lane;
     const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK + ((t + 1) & 1) * kStageFloats) + lane;
     bool moved = false;
     f16x8 ph0, pl0, ph1, pl1;
+    i32x8 pb;
+    f16x8 vr[3];                             // PVF8: V_hi fragments of phase 2, read three MFMAs ahead of their use
+    auto hslot = [](int u) { return (0 * 8 + 2 * (u & 3) + (u >> 2)) * 64; };
     // running maximum first, and the (rare) accumulator rescale with it: no branch may sit between the two phases, or
     // the compiler sinks the phase-1 vector work below it, out of the MFMA issue gaps
     {
@@ -946,21 +979,57 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
         } else if (u <= 11) {
           const int r = u - 2;               // exponentials 0..9
           x[r] = expo(x[r], m_off);
-          ls += x[r];
+          if (!PVF8) ls += x[r];
         } else if (u <= 15) {
           const int j = 2 * (u - 12);        // split pairs 0..3: the first 8 keys
           to_planes2(x[j], x[j + 1], ph0, pl0, j);
         } else if (u <= 21) {
           const int r = u - 6;               // exponentials 10..15
           x[r] = expo(x[r], m_off);
-          ls += x[r];
-        } else {
+          if (!PVF8) ls += x[r];
+        } else if (!PVF8) {
           const int j = 2 * (u - 22);        // split pairs 4, 5
           to_planes2(x[8 + j], x[8 + j + 1], ph1, pl1, j);
+        } else {
+          const int j = 4 * (u - 22);        // PVF8: split pairs 4, 5 | 6, 7 (the row-sum additions left this phase)
+          to_planes2(x[8 + j], x[8 + j + 1], ph1, pl1, j);
+          to_planes2(x[8 + j + 2], x[8 + j + 3], ph1, pl1, j + 2);
         }
+        if (PVF8 && u >= 21) vr[u - 21] = lv[hslot(u - 21)];
+        // PVF8: the K_{t+2} pieces leave in the first units of phase 1 (their slot held K_t, read during tile t - 1), the V_{t+1}
+        // pieces in the first units of phase 2: 1.111 -> 1.082 ms per launch against all eight in phase 2 (all eight in phase 1:
+        // 1.107; tools/ubench/ablate_h2p.py p8_*)
+        if (PVF8 && u < 4) issue_piece(t, u);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (PVF8) {
+      // ---- phase 2, fp8 form: 8 x P_hi V_hi on the f16 pipe - in their issue gaps the e4m3 planes of the probabilities, their row
+      //      sums and the tile's 8 LDS-DMA pieces - then ONE block-scaled fp8 MFMA per feature block for both cross products ----
+      // (every LDS read is issued >= 3 MFMAs / >= 128 matrix-pipe cycles ahead of its use: with one MFMA per fragment - not the
+      // three of the split-fp16 form - a read issued one unit ahead left the pipe waiting for the LDS in every unit)
+      const i32x4* lv8 = reinterpret_cast<const i32x4*>(lv);
+      i32x4 fa[2][2];
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        if (u < 8) {
+          const int s2 = u >> 2, db = u & 3;
+          oacc[db] = mfma_h16(vr[u % 3], s2 ? ph1 : ph0, oacc[db]);
+          if (u + 3 < 8) vr[u % 3] = lv[hslot(u + 3)];
+          if (u == 4 || u == 6) { const int fd = (u - 4) >> 1; fa[fd][0] = lv8[(1 * 8 + 2 * fd) * 64]; fa[fd][1] = lv8[(1 * 8 + 2 * fd + 1) * 64]; }
+          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);
+          if (u < 4) issue_piece(t, u + 4);     // V_{t+1}; the K pieces went out in phase 1
+        } else {
+          const int db = u - 8;
+          const i32x4 a_lo = fa[db & 1][0], a_hi = fa[db & 1][1];
+          const i32x8 va = {a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
+          oacc[db] = mfma_f8s(va, pb, oacc[db], db, (int)vsw, psc);
+          if (db < 2) { fa[db & 1][0] = lv8[(1 * 8 + 2 * db + 4) * 64]; fa[db & 1][1] = lv8[(1 * 8 + 2 * db + 5) * 64]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ls += ls_l;
+    } else
     // ---- phase 2: O^T += V_t^T P^T, the remaining exponentials and the second split in its issue gaps ----
     {
       f16x8 vh = lv[0], vl = vh;
@@ -1007,8 +1076,29 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
     m_run = m_new;
     const float m_off = m_new - 10.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { x[r] = expo(x[r], m_off); ls += x[r]; }
+    for (int r = 0; r < 16; ++r) { x[r] = expo(x[r], m_off); if (!PVF8) ls += x[r]; }
     rescale(moved, alpha);
+    if (PVF8) {
+      i32x8 pb;
+      float ls_l = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8 ph, pl;
+        split8h(&x[8 * s2], ph, pl);
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) planes_f8(ph, pl, j, 4 * s2 + (j >> 1), pb, ls, ls_l);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) oacc[db] = mfma_h16(lv[(0 * 8 + 2 * db + s2) * 64], ph, oacc[db]);
+      }
+      ls += ls_l;
+      const i32x4* lv8 = reinterpret_cast<const i32x4*>(lv);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const i32x4 a_lo = lv8[(1 * 8 + 2 * db) * 64], a_hi = lv8[(1 * 8 + 2 * db + 1) * 64];
+        const i32x8 va = {a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
+        oacc[db] = mfma_f8s(va, pb, oacc[db], db, (int)vsw, psc);
+      }
+    } else {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       f16x8 ph, pl;
@@ -1018,6 +1108,7 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
         const int slot = 2 * db + s2;
         mma_n(oacc[db], lv[(0 * 8 + slot) * 64], lv[(1 * 8 + slot) * 64], ph, pl);
       }
+    }
     }
     l_half = fmaf(l_half, alpha, ls);
   };
@@ -1078,16 +1169,17 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   else scattn_epilogue_h2<false>(o, active, ss, lvec, ft, out + toff, lane, h);
 }
 
-template <int NPROD, int CFMT>
+template <int NPROD, int CFMT, bool PVF8 = false>
 __global__ void __launch_bounds__(256, 2)
 k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
              const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
              float* __restrict__ out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_dense,
              int n_items, int n_full, int ksplits, float* __restrict__ part_o, float* __restrict__ part_ml,
-             const float* __restrict__ next_wst, const float* __restrict__ next_bias, const PairTab* __restrict__ ptab) {
+             const float* __restrict__ next_wst, const float* __restrict__ next_bias, const PairTab* __restrict__ ptab,
+             const unsigned* __restrict__ v_scale) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
-  scattn_h2p_body<NPROD, CFMT>(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items,
-                             n_full, ksplits, part_o, part_ml, next_wst, next_bias, ptab);
+  scattn_h2p_body<NPROD, CFMT, 4, PVF8>(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items,
+                             n_full, ksplits, part_o, part_ml, next_wst, next_bias, ptab, v_scale);
 }
 
 // =========================================================================================
@@ -2188,13 +2280,19 @@ hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, 
                          cc->next_wst_h2, cc->next_bias);
     else if (cc->half)  // ... with a split tail: one fp16 product, c streamed as fp16 (the cache was built that way)
       hipLaunchKernelGGL((k_scattn_h2p<1, 1>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, W,
-                         n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab);
-    else if (cc->fmt == 2)   // parity arithmetic, c streamed as 16-bit fixed point
+                         n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr);
+    else if (cc->fmt == 2 && cc->v_scale)   // parity arithmetic, c streamed as 16-bit fixed point; fp8 cross products of P V
+      hipLaunchKernelGGL((k_scattn_h2p<3, 2, true>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, cc->v_scale);
+    else if (cc->fmt == 2)
       hipLaunchKernelGGL((k_scattn_h2p<3, 2>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
-                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab);
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr);
+    else if (cc->v_scale)    // the default: V image with e4m3 cross planes (k_linear_h2 wrote it that way)
+      hipLaunchKernelGGL((k_scattn_h2p<3, 0, true>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, cc->v_scale);
     else
       hipLaunchKernelGGL((k_scattn_h2p<3, 0>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
-                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab);
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr);
     if (max_tail > 0)
       hipLaunchKernelGGL(k_scattn_merge, dim3(8 * max_tail), dim3(256), 0, s, cc->part_o, cc->part_ml, fus, cc->tail_wst_h2, vecs, out,
                          tiles, wpp, W, n_full, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)nullptr, 0,

@@ -151,6 +151,11 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     t.mid_grid_roles = value;
     return GMF_OK;
   }
+  if (std::strcmp(name, "pv_fp8") == 0) {       // large grids: the cross products of O += P V on the block-scaled fp8 pipe (default 1)
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: pv_fp8 must be 0 or 1");
+    t.pv_fp8 = value != 0;
+    return GMF_OK;
+  }
   if (std::strcmp(name, "compat_format") == 0) {       // element format of the compat cache: 0 = fp32 (default), 2 = 16-bit fixed point (opt-in)
     GMF_REQUIRE(value == 0 || value == 2, GMF_ERR_BAD_ARG, "set_tuning: compat_format must be 0 (fp32) or 2 (16-bit fixed point of c)");
     t.compat_format = value;
@@ -453,7 +458,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
                                              (kMaxSplits == 8 ? arena_need((size_t)8 * act, 4) : 0) : 0;
   const size_t need = 8 * arena_need(act, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +
                       5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4) + cache_need + split_need +
-                      arena_need((size_t)B, sizeof(gmf::PairTab));
+                      arena_need((size_t)B, sizeof(gmf::PairTab)) + arena_need((size_t)B * tiles * 64, 4);
   if (int rc = arena_reserve(h, need)) return rc;
   const gmf::PairTab* ptab = nullptr;
   if (ragged) {
@@ -476,6 +481,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
   float* x1t = arena_take<float>(h, tok);
   float* imgfeat = arena_take<float>(h, tok);
   float* ctxall = arena_take<float>(h, (size_t)(L > 0 ? L : 1) * tok);
+  unsigned* v_scale = arena_take<unsigned>(h, (size_t)B * tiles * 64);     // scale words of the V image's e4m3 planes ("pv_fp8")
   gmf::CompatCache cc{nullptr, nullptr, nullptr, nullptr, 0};
   float* c_dense = nullptr;
   if (want_cache) {
@@ -551,8 +557,10 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
       const float* ffv = w->ff_vec + (size_t)l * w->ff_vec_stride;
       const float* ctx_l = ctxall + (size_t)l * tok;
       if (one_kernel) {
+        // large grids, parity arithmetic: V with e4m3 cross planes for k_scattn_h2p<3, *, true> (the only reader of this V)
+        cc.v_scale = (h->tune.pv_fp8 && !cc.half) ? v_scale : nullptr;
         GMF_HIP(gmf::launch_linear_h2(h->tune, f, fw, fv, ctx_l, aw, av, ffw, ffv, q, k, v, x2, B, N, tiles, T, tt, st,
-                                      cc.half && h->tune.precision == 2, ptab));
+                                      cc.half && h->tune.precision == 2, ptab, cc.v_scale));
       } else if (small3) {
         // three launches: {Q' | K | V | cross-attention} -> {key-split attention | hidden-split feed-forward} -> merge
         GMF_HIP(gmf::launch_small_front_fattn(f, fw, fv, ctx_l, aw, av, q, k, v, x1, B, N, tiles, T, tt, st));

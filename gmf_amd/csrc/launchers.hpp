@@ -27,6 +27,8 @@ struct CompatCache {
   const PairTab* ptab = nullptr;   // ragged batch: per-pair rows (device), else null
   int fmt = 0;                // element format of `dense` (k_compat_build): 0 = fp32 (4 KiB per tile); 16-bit, 2 KiB per tile:
                               // 1 = fp16 c (with `half`), 2 = fixed point rint(65535 c)
+  unsigned* v_scale = nullptr;   // non-null: the layer's V image carries e4m3 cross planes (store_block_v8) and these are their
+                                 // scale words, [B * tiles][64]; k_linear_h2 writes both, k_scattn_h2p<3, *, true> reads them
 };
 
 // Per-handle tuning knobs (gmf_set_tuning).  Every value selects between forms that compute the same result up to
@@ -50,6 +52,8 @@ struct Tuning {
   bool topk_select = true;   // radix select of the S seeds (false = full bitonic sort)
   int mid_grid_roles = 512;  // two-launch form on grids below this many base workgroups (>= 256): the linear kernel runs as two
                              // workgroup roles per row block (Q'/K/V | Fusion-2); 0 = never
+  bool pv_fp8 = true;        // large grids, parity arithmetic: the two cross products of O += P V on the block-scaled fp8 matrix
+                             // pipe (k_scattn_h2p<3, *, true>).  0 = all three products on the f16 pipe
   int compat_format = 0;     // element format of the compat cache on the cached, pipelined path: 0 = fp32 (default); 2 = 16-bit fixed
                              // point, rint(65535 c): half the attention's c stream and half the build, -4 % per step, absolute
                              // error <= 7.6e-6 on c.  Measured: inside the parity contract on 3DMatch-shape
@@ -97,7 +101,7 @@ hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const 
 hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                             const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec, float* q,
                             float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s, bool one_product = false,
-                            const PairTab* ptab = nullptr);
+                            const PairTab* ptab = nullptr, unsigned* v_scale = nullptr);   // v_scale: CompatCache::v_scale
 // small grids: three launches per layer (k_small_front_fattn | k_small_attn_ff | k_scattn_merge)
 void plan_attn_split(const Tuning& tune, int W, int tiles, int max_splits, int* n_full, int* ksplits);
 int plan_ff_split(const Tuning& tune, int base, int max_parts);

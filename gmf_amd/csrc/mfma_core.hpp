@@ -112,6 +112,36 @@ GMF_DEVINL void split2h(float x0, float x1, f16x8& hi, f16x8& lo, int j) {
   lo[j] = ll[0]; lo[j + 1] = ll[1];
 }
 
+// ---- e4m3 planes for the block-scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) ------------------------------------------------
+// Measured on gfx950 (tools/ubench/mfma_scale_probe.hip, fp8_cvt_probe.hip): a lane's 32 operand bytes are k-positions
+// (half h = lane >> 5, byte b); byte b of half h of A meets byte b of half h of B; bytes 0..15 of BOTH halves form scale block 0,
+// whose E8M0 scale is the selected byte of lanes 0..31's scale register (lane = the operand's row / column), bytes 16..31 form
+// block 1, scaled by lanes 32..63's.  The conversions compute e4m3(x / scale), round to nearest even, NaN beyond 448; the
+// decode multiplies by the scale.  32 f16 MFMAs + 4 of these take 0.80 of the time of 48 f16 MFMAs (the clock rises as well).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+template <bool HI_WORD>
+GMF_DEVINL int cvt2_fp8_f16(int d, f16x2 v, float scale) {       // e4m3(v / scale) for a pair, into one 16-bit half of d
+  return __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(__builtin_bit_cast(i16x2, d), v, scale, HI_WORD));
+}
+template <bool HI_WORD>
+GMF_DEVINL int cvt2_fp8_f32(int d, float x0, float x1, float scale) {
+  return __builtin_bit_cast(int, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(i16x2, d), x0, x1, scale, HI_WORD));
+}
+template <bool HI_WORD>
+GMF_DEVINL f16x2 dec2_fp8_f16(int d, float scale) {               // the two e4m3 values of one half of d, times scale (exact in fp16)
+  return __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(d, scale, HI_WORD);
+}
+GMF_DEVINL f32x16 mfma_f8s(i32x8 a, i32x8 b, f32x16 c, int opsel_a, int scale_a, int scale_b) {
+  switch (opsel_a) {      // (the byte select is an immediate)
+    case 0: return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, scale_b);
+    case 1: return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 1, scale_a, 0, scale_b);
+    case 2: return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 2, scale_a, 0, scale_b);
+    default: return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 3, scale_a, 0, scale_b);
+  }
+}
+
 GMF_DEVINL void mma3(f32x16& acc, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
   acc = mfma_h16(al, bh, acc);
   acc = mfma_h16(ah, bl, acc);
@@ -229,6 +259,11 @@ GMF_DEVINL float sqrt_cr(float x) {
 // Sum / max over the two K-halves of a row (lane l and l^32 hold the two halves).
 GMF_DEVINL float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 GMF_DEVINL float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+// max over the two K-halves of a row without the LDS: swap the upper 32 lanes of one copy with the lower 32 of another
+GMF_DEVINL float xhalf_max_swap(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 
 // LayerNorm of a row fragment (eps 1e-5, biased variance, two-pass as nn.LayerNorm).
 template <int KF>

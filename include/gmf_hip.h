@@ -97,6 +97,12 @@ int gmf_status_read(gmf_handle* h, int* flags, int clear);
  *                         rint(65535 c) - half the cache, half its stream, -4 % per step, |dc| <= 7.6e-6.  Opt-in: measured inside
  *                         the 1e-4 gate on 3DMatch-shape inputs, but 4-8x the reference's own fp32 noise on KITTI-shape inputs
  *                         (profiles/r03_compat_formats.txt).
+ *   "pv_fp8"            : large grids, parity arithmetic: 1 (default) = the two CROSS products of the attention's O += P V (P_hi V_lo +
+ *                         P_lo V_hi) run on the block-scaled fp8 matrix pipe, one v_mfma_scale_f32_32x32x64_f8f6f4 per feature block
+ *                         and key tile, with e4m3 operands, one scale per (feature, tile) and the softmax row sum taken over exactly
+ *                         the probabilities the pipe multiplies; P_hi V_hi and all of Q'K^T keep the three-product split-fp16
+ *                         form.  0 = all three products of P V on the f16 pipe.  Logits of the two forms differ by <= 3e-5 (mean
+ *                         2e-6) at 32 x 5000, the parity sweeps are indistinguishable (profiles/r03_pv_fp8.txt).
  *   "attn_tail_split"   : 1 = large grids: the last partial round of attention workgroups is split by keys, 0 = whole (default).
  *   "small_grid_roles"  : 1 = small grids run three launches per layer with mixed workgroup roles (default), 0 = one per stage.
  *   "attn_key_splits"   : 0 = automatic (small grids only), 1 = off, 2..8 = forced number of key splits.

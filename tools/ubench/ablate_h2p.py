@@ -57,6 +57,17 @@ PATCHES = {
         (EK, "          split2h(x[j], x[j + 1], ph0, pl0, j);", "          ph0[j] = (_Float16)x[j]; ph0[j + 1] = (_Float16)x[j + 1];"),
         (EK, "          split2h(x[8 + j], x[8 + j + 1], ph1, pl1, j);", "          ph1[j] = (_Float16)x[8 + j]; ph1[j + 1] = (_Float16)x[8 + j + 1];"),
     ],
+    # ---- schedule variants of the pv_fp8 form (these compute the SAME results; A/B in one process).  Shipped: K pieces in phase 1
+    #      units 0..3, V pieces in phase 2 units 0..3 (1.082 ms); measured against it: all eight in phase 2 1.111, all eight in
+    #      phase 1 1.107, K at the tile top 1.131 / 1.124 (same box as 1.124 for the shipped form), V in phase 2 units 4..7 1.135
+    "p8_pieces_p2": [      # all 8 LDS-DMA pieces of a tile in phase 2
+        (EK, "          if (u < 4) issue_piece(t, u + 4);     // V_{t+1}; the K pieces went out in phase 1\n", "          issue_piece(t, u);\n"),
+        (EK, "        if (PVF8 && u < 4) issue_piece(t, u);", ""),
+    ],
+    "p8_no_consist": [     # timing only: the row sum without the decoded low plane (what the consistent sum costs: nothing measurable)
+        (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<true>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),
+        (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<false>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),
+    ],
     "lin_no_gelu": [
         (FF, "a_cur[u] *= gelu_erf_1r(g_cur[u]);", "a_cur[u] *= g_cur[u];"),
     ],

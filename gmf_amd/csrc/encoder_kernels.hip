@@ -1054,6 +1054,90 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
     }
     l_half = fmaf(l_half, alpha, ls);
   };
+  // PVF8: the tile step with NO serial vector work at the tile top.  The compat product, the row maximum and the (rare) rescale
+  // of tile t sit in the issue gaps of the first S_{t+1} MFMAs (units 0..3), the exponentials and splits follow in units 4..20;
+  // behind the tile barrier a wave goes straight back to the matrix pipe.  (In the form above those ~45 dependent instructions
+  // ran between the barrier and the first MFMA of every tile, on all four waves of the workgroup at the same time: a timing-only
+  // build without them was 16 % faster than one that merely dropped the c loads - tools/ubench/ablate_h2p.py p8_no_scores / no_c.)
+  auto tile_step_f8 = [&](const int t, const f32x16& s_cur, f32x16& s_next) {
+    float x[16];
+    float mx = -INFINITY, m_off = 0.f, alpha = 1.f, ls = 0.f, ls_l = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    vsw = vsw_next;
+    const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV + (t & 1) * kStageFloats) + lane;
+    const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK + ((t + 1) & 1) * kStageFloats) + lane;
+    f16x8 ph0, pl0, ph1, pl1;
+    i32x8 pb;
+    f16x8 vr[3];
+    auto hslot = [](int u) { return (0 * 8 + 2 * (u & 3) + (u >> 2)) * 64; };
+    s_next = zero16();
+    {
+      f16x8 kh = lk[0], kl = lk[8 * 64];
+      f16x8 kh_n = kh, kl_n = kl;
+#pragma unroll
+      for (int u = 0; u < 24; ++u) {
+        const int s = u / 3, pr = u % 3;
+        if (pr == 0 && s < 7) { kh_n = lk[(0 * 8 + s + 1) * 64]; kl_n = lk[(1 * 8 + s + 1) * 64]; }
+        s_next = mma3_part(pr, s_next, kh, kl, qh[s], ql[s]);
+        if (pr == 2) { kh = kh_n; kl = kl_n; }
+        if (u < 4) {
+#pragma unroll
+          for (int r = 4 * u; r < 4 * u + 4; r += 2) {
+            x[r] = score(r, s_cur[r]);
+            x[r + 1] = score(r + 1, s_cur[r + 1]);
+            mx = __builtin_fmaxf(mx, __builtin_fmaxf(x[r], x[r + 1]));
+          }
+        }
+        if (u == 3) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + 1 < t_end) fetch_c(t + 1);            // (c_t is consumed)
+          __builtin_amdgcn_sched_barrier(0);
+          mx = xhalf_max_swap(mx);
+          if (CFMT == 2) mx *= kInvU16;
+          const float m_new = __builtin_fmaxf(m_run, mx);
+          const bool moved = m_new > m_run;
+          alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          m_run = m_new;
+          m_off = m_new - 10.0f;               // P' = 2^10 P
+          rescale(moved, alpha);
+        }
+        if (u >= 4 && u < 20) x[u - 4] = expo(x[u - 4], m_off);
+        if (u >= 6 && u <= 18 && (u & 1) == 0) {         // split pair k once its two exponentials are there (units 5 + 2 k)
+          const int k = (u - 6) >> 1;
+          if (k < 4) split2h(x[2 * k], x[2 * k + 1], ph0, pl0, 2 * k);
+          else split2h(x[2 * k], x[2 * k + 1], ph1, pl1, 2 * k - 8);
+        }
+        if (u == 20) split2h(x[14], x[15], ph1, pl1, 6);
+        if (u >= 8 && u < 12) issue_piece(t, u - 8);     // K_{t+2}
+        if (u >= 21) vr[u - 21] = lv[hslot(u - 21)];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    {
+      const i32x4* lv8 = reinterpret_cast<const i32x4*>(lv);
+      i32x4 fa[2][2];
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        if (u < 8) {
+          const int s2 = u >> 2, db = u & 3;
+          oacc[db] = mfma_h16(vr[u % 3], s2 ? ph1 : ph0, oacc[db]);
+          if (u + 3 < 8) vr[u % 3] = lv[hslot(u + 3)];
+          if (u == 4 || u == 6) { const int fd = (u - 4) >> 1; fa[fd][0] = lv8[(1 * 8 + 2 * fd) * 64]; fa[fd][1] = lv8[(1 * 8 + 2 * fd + 1) * 64]; }
+          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);
+          if (u < 4) issue_piece(t, u + 4);             // V_{t+1}
+        } else {
+          const int db = u - 8;
+          const i32x4 a_lo = fa[db & 1][0], a_hi = fa[db & 1][1];
+          const i32x8 va = {a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
+          oacc[db] = mfma_f8s(va, pb, oacc[db], db, (int)vsw, psc);
+          if (db < 2) { fa[db & 1][0] = lv8[(1 * 8 + 2 * db + 4) * 64]; fa[db & 1][1] = lv8[(1 * 8 + 2 * db + 5) * 64]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    l_half = fmaf(l_half, alpha, ls + ls_l);
+  };
   // the last tile (keys >= N masked out), no S_{t+1} to overlap with
   auto tile_last = [&](const int t, const f32x16& s_cur) {
     float x[16];
@@ -1125,12 +1209,21 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
     }
   } else {
     int t = t_begin;
+    if (PVF8) {
+      for (; t + 2 < t_end; t += 2) {
+        tile_step_f8(t, s_a, s_b);
+        tile_step_f8(t + 1, s_b, s_a);
+      }
+      if (t + 1 < t_end) { tile_step_f8(t, s_a, s_b); tile_last(t + 1, s_b); }
+      else tile_last(t, s_a);
+    } else {
     for (; t + 2 < t_end; t += 2) {          // explicit ping-pong: no accumulator copies at the loop back-edge
       tile_step(t, s_a, s_b);
       tile_step(t + 1, s_b, s_a);
     }
     if (t + 1 < t_end) { tile_step(t, s_a, s_b); tile_last(t + 1, s_b); }
     else tile_last(t, s_a);
+    }
   }
   if (split) {
     // partial result of this key range: un-normalised O as a P32 tile image, row maximum and row sum

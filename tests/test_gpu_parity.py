@@ -360,6 +360,53 @@ def test_ragged_batch_of_equal_sizes_is_the_uniform_batch(model):
         model(bad)
 
 
+@pytest.mark.parametrize("kind", ["3dmatch", "kitti"])
+def test_pv_fp8_form_against_the_oracle(kind):
+    """The large-grid attention multiplies the two cross products of O += P V on the block-scaled fp8 matrix pipe ("pv_fp8" = 1, the
+    default).  Scenes travel as a ragged batch (ragged batches always take the large-grid path) and every scene
+    is held to the fp32 oracle (PointDSC.py:56-64) AND to an fp64 evaluation, in both forms; the two forms agree to 5e-5.  The
+    KITTI shape (coordinates of +-40 m, attention logits two orders larger) is the case a 16-bit compat cache failed."""
+    from gmf_amd import _lib
+    sigma_d = 0.1 if kind == "3dmatch" else 1.2
+    sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7, sigma_d=sigma_d)
+    m = gmf_amd.PointDSC(num_layers=12) if kind == "3dmatch" else gmf_amd.PointDSC(
+        in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1, inlier_threshold=1.2, sigma_d=1.2, k=40, nms_radius=1.2)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(DEV).eval()
+    sizes = [777, 1500, 2048] if kind == "3dmatch" else [700, 1500]
+    seeds = [1003, 1011, 1017] if kind == "3dmatch" else [83, 84]
+    pairs = [synthetic.synthetic_batch([sc], N=n, T=196, kind=kind) for sc, n in zip(seeds, sizes)]
+    kw = {} if kind == "3dmatch" else {"inlier_threshold": 1.2, "nms_radius": 1.2}
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    refs, truths = [], []
+    for b in pairs:
+        refs.append(O.pointdsc_forward(sd, b, testing=True, **kw)["logits"][0])
+        b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()}
+        c64, _ = O.compat_matrix(b64["src_keypts"], b64["tgt_keypts"], sigma_d)
+        truths.append(O.classifier(sd64, O.encoder(sd64, b64["corr_pos"], c64, b64["p_tokens"], b64["q_tokens"], 12))[0])
+    rag = {k: [_gpu(b[k][0]) for b in pairs] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    rag.update(p_tokens=torch.cat([_gpu(b["p_tokens"]) for b in pairs]), q_tokens=torch.cat([_gpu(b["q_tokens"]) for b in pairs]), testing=True)
+    h = _lib.handle_for(0)
+    got = {}
+    try:
+        for form in (0, 1):
+            h.call("gmf_set_tuning", b"pv_fp8", form)
+            got[form] = [lg.cpu() for lg in m(rag)["logits"]]
+    finally:
+        h.call("gmf_set_tuning", b"pv_fp8", 1)
+    for i in range(len(pairs)):
+        floor = float((refs[i].double() - truths[i]).abs().max())        # the reference's own fp32 evaluation against fp64
+        for form in (0, 1):
+            e32, e64 = _maxerr(got[form][i], refs[i]), float((got[form][i].double() - truths[i]).abs().max())
+            print(f"{kind} N={sizes[i]} pv_fp8={form}: vs fp32 oracle {e32:.2e}, vs fp64 {e64:.2e} (fp32 oracle vs fp64 {floor:.2e})")
+            assert e64 < 1.5 * floor + 2e-5, (kind, i, form, e64, floor)
+            if kind == "3dmatch":
+                assert e32 < 1e-4, (i, form, e32)
+        assert _maxerr(got[0][i], got[1][i]) < (5e-5 if kind == "3dmatch" else 2e-4), (kind, i)
+    with pytest.raises(RuntimeError):
+        h.call("gmf_set_tuning", b"pv_fp8", 2)
+
+
 def test_stress_conditioning(golden_dir):
     """gain 0.9 weights amplify rounding by ~1.4x per block: two fp32 evaluations that only differ in summation
     order disagree by the noise floor |oracle32 - oracle64|.  The HIP path must stay within 4x that floor."""

@@ -43,8 +43,8 @@ PATCHES = {
         (EK, "    const f32x4* ct = crow + (size_t)t * kCTile16;", "    const f32x4* ct = crow + (size_t)(t & 1) * kCTile16;"),
     ],
     "no_exp": [
-        (EK, "          x[r] = expo(x[r], m_off);\n          ls += x[r];",
-         "          x[r] = x[r] - m_off;\n          ls += x[r];"),
+        (EK, "          x[r] = expo(x[r], m_off);\n          if (!PVF8) ls += x[r];",
+         "          x[r] = x[r] - m_off;\n          if (!PVF8) ls += x[r];"),
     ],
     "no_dma": [
         (EK, "        if (u >= 3 && u < 11) issue_piece(t, u - 3);\n", ""),
@@ -63,6 +63,34 @@ PATCHES = {
     "p8_pieces_p2": [      # all 8 LDS-DMA pieces of a tile in phase 2
         (EK, "          if (u < 4) issue_piece(t, u + 4);     // V_{t+1}; the K pieces went out in phase 1\n", "          issue_piece(t, u);\n"),
         (EK, "        if (PVF8 && u < 4) issue_piece(t, u);", ""),
+    ],
+    # timing-only sensitivities of the pv_fp8 form (wrong results)
+    "p8_no_fp8": [         # the four fp8 MFMAs of a tile not issued: 256 matrix-pipe cycles less per tile and wave
+        (EK, "          oacc[db] = mfma_f8s(va, pb, oacc[db], db, (int)vsw, psc);\n          if (db < 2)", "          asm volatile(\"\" :: \"v\"(va), \"v\"(pb));\n          if (db < 2)"),
+    ],
+    "p8_no_hh": [          # the eight P_hi V_hi MFMAs not issued (256 cycles)
+        (EK, "          oacc[db] = mfma_h16(vr[u % 3], s2 ? ph1 : ph0, oacc[db]);", "          asm volatile(\"\" :: \"v\"(vr[u % 3]));"),
+    ],
+    "p8_no_scores": [      # the tile top without the compat product and the row maximum (x = s, maximum 0): its serial vector work
+        (EK, "      x[r] = score(r, s_cur[r]);\n      x[r + 1] = score(r + 1, s_cur[r + 1]);\n      mx = __builtin_fmaxf(mx, __builtin_fmaxf(x[r], x[r + 1]));",
+         "      x[r] = s_cur[r] * 1e-3f;\n      x[r + 1] = s_cur[r + 1] * 1e-3f;\n      mx = 0.f;"),
+    ],
+    "p8_no_barrier": [     # the tile barrier removed (racy)
+        (EK, "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    __syncthreads();\n    if (PVF8) vsw = vsw_next;", "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    if (PVF8) vsw = vsw_next;"),
+    ],
+    "p8_no_dma": [         # the in-loop K / V refills not issued (stale tiles)
+        (EK, "          if (u < 4) issue_piece(t, u + 4);     // V_{t+1}; the K pieces went out in phase 1\n", ""),
+        (EK, "        if (PVF8 && u < 4) issue_piece(t, u);", ""),
+    ],
+    "p8_dma_l2": [         # the refills come from two alternating tiles (L2 / L1 hits): same instructions, same LDS writes, no L2 misses
+        (EK, "      if (t + 2 < t_end) dma_piece_1k_s(gk + (size_t)(t + 2) * kStageFloats + (wave + WAVES * q) * 256,",
+             "      if (t + 2 < t_end) dma_piece_1k_s(gk + (size_t)(t & 1) * kStageFloats + (wave + WAVES * q) * 256,"),
+        (EK, "      dma_piece_1k_s(gv + (size_t)(t + 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256,",
+             "      dma_piece_1k_s(gv + (size_t)((t + 1) & 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256,"),
+    ],
+    "p8_top_scores": [     # the compat product / row maximum at the tile top (the shared tile step) instead of inside phase 1
+        (EK, "        tile_step_f8(t, s_a, s_b);\n        tile_step_f8(t + 1, s_b, s_a);", "        tile_step(t, s_a, s_b);\n        tile_step(t + 1, s_b, s_a);"),
+        (EK, "      if (t + 1 < t_end) { tile_step_f8(t, s_a, s_b); tile_last(t + 1, s_b); }", "      if (t + 1 < t_end) { tile_step(t, s_a, s_b); tile_last(t + 1, s_b); }"),
     ],
     "p8_no_consist": [     # timing only: the row sum without the decoded low plane (what the consistent sum costs: nothing measurable)
         (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<true>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),

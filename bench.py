@@ -205,7 +205,7 @@ def main():
         "metric": "correspondences/sec (whole node)", "value": value, "unit": "correspondences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (split-fp16 MFMA operands, fp32 accumulate)", "data": "synthetic",
+        "dtype": "f32 (split-fp16 MFMA operands, fp32 accumulate; the two cross products of the attention's P.V on block-scaled e4m3 operands)", "data": "synthetic",
         "config": {"workload": f"synthetic {args.kind}-shape pairs, PointDSC.forward test mode (logits + R,t)",
                    "pairs_per_gpu": B, "global_pairs": world * B, "n_corr": N, "feat_dim": 128, "image_tokens": T,
                    "layers": 12, "parallelism": f"pairs sharded over {world} GPU(s), one RCCL all-gather of packed logits+poses"},
@@ -218,8 +218,14 @@ def main():
                      "hbm_gbs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
                      "hbm_frac_of_peak": (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None,
                      "peak_note": (f"f16 MFMA dense peak {PEAK_F16_MFMA_TFLOPS:.0f} TFLOP/s / {PRODUCTS} partial products per algorithmic "
-                                   "multiply-add (split-fp16 operands, fp32 accumulate, fp32-equivalent results)"),
-                     "executed_mfma_tflops": achieved * PRODUCTS,
+                                   "multiply-add (split-fp16 operands, fp32 accumulate, fp32-equivalent results) - the yardstick of rounds "
+                                   "1-2, kept.  Since round 3 the two cross products of O += P V run on the block-scaled fp8 pipe: a "
+                                   "tile takes 32 f16 + 4 fp8 matrix instructions = 1280 matrix-pipe cycles instead of 48 x 32 = 1536"),
+                     # matrix-pipe cycles the kernel needs per algorithmic flop, as a fraction of the cycles it had ("pipe_busy" if
+                     # nothing else stalled it): 1280 of 1536 cycles per tile
+                     "frac_of_pipe_cycles": achieved / (peak * 1536.0 / 1280.0),
+                     "executed_mfma_tflops": achieved * PRODUCTS * 1280.0 / 1536.0,
+                     "executed_note": "f16-equivalent matrix-pipe work per second (an fp8 MFMA of 64 cycles counted as two f16 MFMAs of 32)",
                      "avg_launch_ms": avg_ms, "launches_timed": launches.value, "flops_per_launch": flops},
         "step": {"algorithmic_tflops": step_tflops, "frac_of_peak": step_tflops / peak,
                  "flops_per_step": step_flops(B, N, T), "note": "F_logits of SURVEY.md section 8d x pairs / step time"},

@@ -407,6 +407,36 @@ def test_pv_fp8_form_against_the_oracle(kind):
         h.call("gmf_set_tuning", b"pv_fp8", 2)
 
 
+def test_compat_format_16bit_is_an_opt_in_within_the_gate_on_3dmatch_shape(model, sd_full):
+    """gmf_set_tuning("compat_format", 2): the compat cache as 16-bit fixed point (half the cache and its stream; DESIGN section 4b
+    has why it is not the default: KITTI-shape inputs).  On a 3DMatch-shape large-grid batch both attention forms (pv_fp8 0 / 1)
+    stay within 1e-4 of the fp32 oracle with it, and within 1e-4 of the fp32-cache logits."""
+    from gmf_amd import _lib
+    B, N = 33, 1000                                            # 264 row blocks: the large-grid (two-launch) form
+    b = synthetic.synthetic_batch(list(range(700, 700 + B)), N=N, T=196)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    one = {k: v[:1] for k, v in b.items() if torch.is_tensor(v)}
+    ref0 = O.pointdsc_forward(sd_full, one, testing=True)["logits"][0]
+    h = _lib.handle_for(0)
+    model(data)
+    base = model.last_logits.clone()
+    try:
+        for pv in (0, 1):
+            h.call("gmf_set_tuning", b"pv_fp8", pv)
+            h.call("gmf_set_tuning", b"compat_format", 2)
+            model(data)
+            lg = model.last_logits.clone()
+            d, e = _maxerr(lg.cpu(), base.cpu()), _maxerr(lg[0].cpu(), ref0)
+            print(f"compat_format 2, pv_fp8 {pv}: vs fp32 cache {d:.2e}, pair 0 vs oracle {e:.2e}")
+            assert d < 1e-4 and e < 1e-4, (pv, d, e)
+        with pytest.raises(RuntimeError):
+            h.call("gmf_set_tuning", b"compat_format", 3)
+    finally:
+        h.call("gmf_set_tuning", b"compat_format", 0)
+        h.call("gmf_set_tuning", b"pv_fp8", 1)
+
+
 def test_stress_conditioning(golden_dir):
     """gain 0.9 weights amplify rounding by ~1.4x per block: two fp32 evaluations that only differ in summation
     order disagree by the noise floor |oracle32 - oracle64|.  The HIP path must stay within 4x that floor."""

@@ -30,7 +30,7 @@ template <int MODE>
 GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const int zsel_in, const float* __restrict__ in,
                               const float* __restrict__ wst, const float* __restrict__ vecs, float* __restrict__ f_out,
                               float* __restrict__ q_out, float* __restrict__ k_out, float* __restrict__ v_out, int N, int tiles,
-                              const PairTab* __restrict__ ptab = nullptr) {
+                              const PairTab* __restrict__ ptab = nullptr, unsigned* __restrict__ v_scale = nullptr) {
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t row0 = pair_row0(ptab, pair, N);            // ragged batch (MODE 3 only): corr_pos is packed [sum n, 6]
@@ -120,6 +120,7 @@ GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const in
     }
   }
   if (zsplit && zsel != 2) return;
+  unsigned vsw = 0;
 #pragma unroll
   for (int db = 0; db < 4; ++db) {             // V (feature on lane)
     const f16x8* lw = as_h2(ss.acquire());
@@ -129,18 +130,22 @@ GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const in
     float t[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bv);
-    if (active) store_block_h2(v_out + toff, db, t, lane);
+    if (active) {
+      if (v_scale) store_block_v8(v_out + toff, db, t, lane, vsw);     // the attention's pv_fp8 form (CompatCache::v_scale)
+      else store_block_h2(v_out + toff, db, t, lane);
+    }
   }
+  if (active && v_scale) v_scale[((size_t)pair * tiles + tile) * 64 + lane] = vsw;
 }
 
 template <int MODE>
 __global__ void __launch_bounds__(256, 2)
 k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const float* __restrict__ vecs,
            float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out,
-           float* __restrict__ v_out, int N, int tiles, const PairTab* __restrict__ ptab) {
+           float* __restrict__ v_out, int N, int tiles, const PairTab* __restrict__ ptab, unsigned* __restrict__ v_scale) {
   __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
   front_h2_body<MODE>(lds, blockIdx.x, blockIdx.y, gridDim.z == 3 ? (int)blockIdx.z : -1, in, wst, vecs, f_out, q_out, k_out, v_out,
-                      N, tiles, ptab);
+                      N, tiles, ptab, v_scale);
 }
 
 // =========================================================================================
@@ -374,10 +379,11 @@ __global__ void __launch_bounds__(256, 2)
 k_small_front_fattn(const float* __restrict__ f_in, const float* __restrict__ front_wst, const float* __restrict__ front_vec,
                     const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
                     float* __restrict__ q_out, float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x1_out,
-                    int N, int tiles, int T, int ttiles) {
+                    int N, int tiles, int T, int ttiles, unsigned* __restrict__ v_scale) {
   __shared__ __attribute__((aligned(16))) float lds[kFattnLdsFloats];
   if (blockIdx.z < 3)
-    front_h2_body<2>(lds, blockIdx.x, blockIdx.y, blockIdx.z, f_in, front_wst, front_vec, nullptr, q_out, k_out, v_out, N, tiles);
+    front_h2_body<2>(lds, blockIdx.x, blockIdx.y, blockIdx.z, f_in, front_wst, front_vec, nullptr, q_out, k_out, v_out, N, tiles,
+                     nullptr, v_scale);
   else
     fusion_attn_h2_body<true>(lds, blockIdx.x, blockIdx.y, f_in, ctx_img, attn_wst, attn_vec, x1_out, N, tiles, T, ttiles);
 }
@@ -726,13 +732,13 @@ k_ff_reduce(const float* __restrict__ part, const float* __restrict__ x1, const 
 static inline dim3 tgrid(int tiles, int B, int sets = 1) { return dim3((tiles + kWavesPerWG - 1) / kWavesPerWG, B, sets); }
 
 hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
-                           float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s, const PairTab* ptab) {
+                           float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s, const PairTab* ptab, unsigned* v_scale) {
   dim3 g = tgrid(tiles, B);
   if (g.x * B < 128 && tune.front_split) g.z = 3;      // small grids: one workgroup per output (Q' + f | K | V)
-  if (mode == 3) { g.z = 1; hipLaunchKernelGGL(k_front_h2<3>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab); }
-  else if (mode == 1) hipLaunchKernelGGL(k_front_h2<1>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab);
-  else if (mode == 2) hipLaunchKernelGGL(k_front_h2<2>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab);
-  else hipLaunchKernelGGL(k_front_h2<0>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab);
+  if (mode == 3) { g.z = 1; hipLaunchKernelGGL(k_front_h2<3>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab, v_scale); }
+  else if (mode == 1) hipLaunchKernelGGL(k_front_h2<1>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab, v_scale);
+  else if (mode == 2) hipLaunchKernelGGL(k_front_h2<2>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab, v_scale);
+  else hipLaunchKernelGGL(k_front_h2<0>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab, v_scale);
   return hipGetLastError();
 }
 
@@ -784,9 +790,9 @@ int plan_ff_split(const Tuning& tune, int base, int max_parts) {
 
 hipError_t launch_small_front_fattn(const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                                     const float* attn_wst, const float* attn_vec, float* q, float* k, float* v, float* x1, int B,
-                                    int N, int tiles, int T, int ttiles, hipStream_t s) {
+                                    int N, int tiles, int T, int ttiles, hipStream_t s, unsigned* v_scale) {
   hipLaunchKernelGGL(k_small_front_fattn, tgrid(tiles, B, 4), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec,
-                     q, k, v, x1, N, tiles, T, ttiles);
+                     q, k, v, x1, N, tiles, T, ttiles, v_scale);
   return hipGetLastError();
 }
 

@@ -1467,20 +1467,20 @@ k_scattn_fast(const float* __restrict__ q_img, const float* __restrict__ k_img, 
 // feed-forward workgroups (they need only x1).  Both write partial results; k_scattn_merge adds them up.  As separate
 // launches the two cost their sum on these latency-bound grids (B = 1, N = 5000: 44 + 18 us per layer); the attention
 // workgroups are one per CU (attn_item), so the feed-forward workgroups find a second slot on every CU.
-template <int CFMT>
+template <int CFMT, bool PVF8 = false>
 __global__ void __launch_bounds__(256, 2)
 k_small_attn_ff(const int n_attn, const float* __restrict__ q_img, const float* __restrict__ k_img,
                 const float* __restrict__ v_img, const float* __restrict__ tail_wst, const float* __restrict__ tail_vecs, int N,
                 int tiles, int wgs_per_pair, const float* __restrict__ c_dense, int n_items, int ksplits,
                 float* __restrict__ part_o, float* __restrict__ part_ml, const float* __restrict__ x1,
                 const float* __restrict__ ff_wst, const float* __restrict__ ff_vecs, float* __restrict__ ff_part, int n_pairs,
-                int ff_hs) {
+                int ff_hs, const unsigned* __restrict__ v_scale) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
   if ((int)blockIdx.x < n_attn) {
     // (n_full = 0: every item is split and leaves through the partial-result branch; `fus` / `out` of the whole-item epilogue
     // are never touched - they get valid pointers all the same, a literal null there crashes this compiler's optimiser)
-    scattn_h2p_body<3, CFMT>(lds, blockIdx.x, q_img, k_img, v_img, x1, tail_wst, tail_vecs, ff_part, N, tiles, wgs_per_pair, c_dense,
-                             n_items, 0, ksplits, part_o, part_ml, nullptr, nullptr);
+    scattn_h2p_body<3, CFMT, 4, PVF8>(lds, blockIdx.x, q_img, k_img, v_img, x1, tail_wst, tail_vecs, ff_part, N, tiles, wgs_per_pair, c_dense,
+                                      n_items, 0, ksplits, part_o, part_ml, nullptr, nullptr, nullptr, v_scale);
   } else {
     const int id = (int)blockIdx.x - n_attn;           // (bx, pair, z) with z fastest: the splits of a row block start together
     const int z = id % ff_hs, r = id / ff_hs;
@@ -2331,12 +2331,18 @@ hipError_t launch_small_attn_ff_merge(const float* q, const float* k, const floa
   const int wpp = (tiles + 3) / 4, W = wpp * B;
   const int per_xcd = (W >> 3) + ((W & 7) ? 1 : 0);
   const int n_attn = 8 * per_xcd * ksplits, n_ff = W * ff_hs;
-  if (cc->fmt == 2)
+  if (cc->fmt == 2 && cc->v_scale)
+    hipLaunchKernelGGL((k_small_attn_ff<2, true>), dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, cc->v_scale);
+  else if (cc->fmt == 2)
     hipLaunchKernelGGL(k_small_attn_ff<2>, dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
-                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs);
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, (const unsigned*)nullptr);
+  else if (cc->v_scale)
+    hipLaunchKernelGGL((k_small_attn_ff<0, true>), dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, cc->v_scale);
   else
     hipLaunchKernelGGL(k_small_attn_ff<0>, dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
-                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs);
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, (const unsigned*)nullptr);
   if (tile_merge)
     hipLaunchKernelGGL(k_scattn_merge_tile, dim3(tiles, B), dim3(256), 0, s, cc->part_o, cc->part_ml, cc->tail_wst_h2, tail_vecs, out,
                        tiles, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)ff_part, ff_hs, x1, ff_vecs + 2 * C + 2 * FFH);

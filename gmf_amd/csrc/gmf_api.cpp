@@ -548,6 +548,9 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
     const int ff_hs = cc.part_o ? gmf::plan_ff_split(h->tune, Wg, cc.max_splits) : 1;
     const bool small3 = !one_kernel && h->tune.small_roles && small_nf == 0 && small_ks > 1 && ff_hs > 1 && ff_part;
     GMF_HIP(gmf::launch_front_h2(h->tune, 3, corr_pos, w->front_wst_h2, w->front_vec, f, q, k, v, B, N, tiles, st, ptab));
+    // parity arithmetic: V with e4m3 cross planes for the pv_fp8 form of the attention body (scattn_h2p_body<3, *, 4, true>), which every
+    // attention kernel of this path instantiates - large grids, split tails and the small-grid role kernels alike
+    cc.v_scale = (h->tune.pv_fp8 && !cc.half) ? v_scale : nullptr;
     for (int l = 0; l < L; ++l) {
       const float* fw = w->front_wst_h2 + (size_t)l * w->front_wst_stride;
       const float* fv = w->front_vec + (size_t)l * w->front_vec_stride;
@@ -557,13 +560,11 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
       const float* ffv = w->ff_vec + (size_t)l * w->ff_vec_stride;
       const float* ctx_l = ctxall + (size_t)l * tok;
       if (one_kernel) {
-        // large grids, parity arithmetic: V with e4m3 cross planes for k_scattn_h2p<3, *, true> (the only reader of this V)
-        cc.v_scale = (h->tune.pv_fp8 && !cc.half) ? v_scale : nullptr;
         GMF_HIP(gmf::launch_linear_h2(h->tune, f, fw, fv, ctx_l, aw, av, ffw, ffv, q, k, v, x2, B, N, tiles, T, tt, st,
                                       cc.half && h->tune.precision == 2, ptab, cc.v_scale));
       } else if (small3) {
         // three launches: {Q' | K | V | cross-attention} -> {key-split attention | hidden-split feed-forward} -> merge
-        GMF_HIP(gmf::launch_small_front_fattn(f, fw, fv, ctx_l, aw, av, q, k, v, x1, B, N, tiles, T, tt, st));
+        GMF_HIP(gmf::launch_small_front_fattn(f, fw, fv, ctx_l, aw, av, q, k, v, x1, B, N, tiles, T, tt, st, cc.v_scale));
         const bool last3 = (l + 1 == L);
         cc.tail_wst_h2 = w->tail_wst_h2 + (size_t)l * w->tail_wst_stride;
         cc.next_wst_h2 = last3 ? nullptr : w->front_wst_h2 + (size_t)(l + 1) * w->front_wst_stride;
@@ -577,7 +578,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
       } else {
         // (projecting Q'/K/V on a side stream beside the Fusion-2 kernels, forked and joined with events, was measured at
         // B = 1: 1.62 vs 1.58 ms at N = 5000, 1.08 vs 1.00 ms at N = 1000 - the event round trips cost more than the overlap gives)
-        GMF_HIP(gmf::launch_front_h2(h->tune, 2, f, fw, fv, f, q, k, v, B, N, tiles, st));
+        GMF_HIP(gmf::launch_front_h2(h->tune, 2, f, fw, fv, f, q, k, v, B, N, tiles, st, nullptr, cc.v_scale));
         GMF_HIP(gmf::launch_fusion_attn_h2(true, f, ctx_l, aw, av, x1, B, N, tiles, T, tt, st));
         GMF_HIP(gmf::launch_fusion_ff_h2(h->tune, x1, ffw, ffv, x2, B, tiles, st, cc.part_o, cc.max_splits));
       }

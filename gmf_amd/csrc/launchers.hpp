@@ -52,8 +52,8 @@ struct Tuning {
   bool topk_select = true;   // radix select of the S seeds (false = full bitonic sort)
   int mid_grid_roles = 512;  // two-launch form on grids below this many base workgroups (>= 256): the linear kernel runs as two
                              // workgroup roles per row block (Q'/K/V | Fusion-2); 0 = never
-  bool pv_fp8 = true;        // large grids, parity arithmetic: the two cross products of O += P V on the block-scaled fp8 matrix
-                             // pipe (k_scattn_h2p<3, *, true>).  0 = all three products on the f16 pipe
+  bool pv_fp8 = true;        // parity arithmetic of the default path: the two cross products of O += P V on the block-scaled fp8 matrix
+                             // pipe (scattn_h2p_body<3, *, 4, true>).  0 = all three products on the f16 pipe
   int compat_format = 0;     // element format of the compat cache on the cached, pipelined path: 0 = fp32 (default); 2 = 16-bit fixed
                              // point, rint(65535 c): half the attention's c stream and half the build, -4 % per step, absolute
                              // error <= 7.6e-6 on c.  Measured: inside the parity contract on 3DMatch-shape
@@ -96,7 +96,8 @@ hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const flo
                                  long o_sk = 0, int n_rows = 0, int* status = nullptr);
 int plan_ff_split_w(int base_wgs);
 hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
-                           float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s, const PairTab* ptab = nullptr);
+                           float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s, const PairTab* ptab = nullptr,
+                           unsigned* v_scale = nullptr);   // v_scale: V with e4m3 cross planes (CompatCache::v_scale)
 // mode 3: corr_pos -> layer0 -> PointCN -> f only.  launch_linear_h2: all linear stages of one layer from f (k_linear_h2)
 hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                             const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec, float* q,
@@ -107,7 +108,7 @@ void plan_attn_split(const Tuning& tune, int W, int tiles, int max_splits, int* 
 int plan_ff_split(const Tuning& tune, int base, int max_parts);
 hipError_t launch_small_front_fattn(const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                                     const float* attn_wst, const float* attn_vec, float* q, float* k, float* v, float* x1, int B,
-                                    int N, int tiles, int T, int ttiles, hipStream_t s);
+                                    int N, int tiles, int T, int ttiles, hipStream_t s, unsigned* v_scale = nullptr);
 hipError_t launch_small_attn_ff_merge(const float* q, const float* k, const float* v, const float* x1, const float* ff_wst,
                                       const float* ff_vecs, float* ff_part, int ff_hs, const float* tail_vecs, float* out, int B,
                                       int N, int tiles, int ksplits, hipStream_t s, const CompatCache* cc, bool tile_merge = true);

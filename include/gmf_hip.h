@@ -97,7 +97,7 @@ int gmf_status_read(gmf_handle* h, int* flags, int clear);
  *                         rint(65535 c) - half the cache, half its stream, -4 % per step, |dc| <= 7.6e-6.  Opt-in: measured inside
  *                         the 1e-4 gate on 3DMatch-shape inputs, but 4-8x the reference's own fp32 noise on KITTI-shape inputs
  *                         (profiles/r03_compat_formats.txt).
- *   "pv_fp8"            : large grids, parity arithmetic: 1 (default) = the two CROSS products of the attention's O += P V (P_hi V_lo +
+ *   "pv_fp8"            : parity arithmetic of the default path (scattn_variant 18, fused_linear 1): 1 (default) = the two CROSS products of the attention's O += P V (P_hi V_lo +
  *                         P_lo V_hi) run on the block-scaled fp8 matrix pipe, one v_mfma_scale_f32_32x32x64_f8f6f4 per feature block
  *                         and key tile, with e4m3 operands, one scale per (feature, tile) and the softmax row sum taken over exactly
  *                         the probabilities the pipe multiplies; P_hi V_hi and all of Q'K^T keep the three-product split-fp16

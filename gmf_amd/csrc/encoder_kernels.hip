@@ -941,15 +941,12 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   // one pipelined tile (t + 1 < tiles): scores of tile t are in s_cur, S_{t+1} accumulates into s_next
   auto tile_step = [&](const int t, const f32x16& s_cur, f32x16& s_next) {
     float x[16];
-    float mx = -INFINITY, m_off = 0.f, alpha = 1.f, ls = 0.f, ls_l = 0.f;
+    float mx = -INFINITY, m_off = 0.f, alpha = 1.f, ls = 0.f;
     tile_top(t, s_cur, x, mx);
     const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV + (t & 1) * kStageFloats) + lane;
     const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK + ((t + 1) & 1) * kStageFloats) + lane;
     bool moved = false;
     f16x8 ph0, pl0, ph1, pl1;
-    i32x8 pb;
-    f16x8 vr[3];                             // PVF8: V_hi fragments of phase 2, read three MFMAs ahead of their use
-    auto hslot = [](int u) { return (0 * 8 + 2 * (u & 3) + (u >> 2)) * 64; };
     // running maximum first, and the (rare) accumulator rescale with it: no branch may sit between the two phases, or
     // the compiler sinks the phase-1 vector work below it, out of the MFMA issue gaps
     {
@@ -979,57 +976,21 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
         } else if (u <= 11) {
           const int r = u - 2;               // exponentials 0..9
           x[r] = expo(x[r], m_off);
-          if (!PVF8) ls += x[r];
+          ls += x[r];
         } else if (u <= 15) {
           const int j = 2 * (u - 12);        // split pairs 0..3: the first 8 keys
           to_planes2(x[j], x[j + 1], ph0, pl0, j);
         } else if (u <= 21) {
           const int r = u - 6;               // exponentials 10..15
           x[r] = expo(x[r], m_off);
-          if (!PVF8) ls += x[r];
-        } else if (!PVF8) {
+          ls += x[r];
+        } else {
           const int j = 2 * (u - 22);        // split pairs 4, 5
           to_planes2(x[8 + j], x[8 + j + 1], ph1, pl1, j);
-        } else {
-          const int j = 4 * (u - 22);        // PVF8: split pairs 4, 5 | 6, 7 (the row-sum additions left this phase)
-          to_planes2(x[8 + j], x[8 + j + 1], ph1, pl1, j);
-          to_planes2(x[8 + j + 2], x[8 + j + 3], ph1, pl1, j + 2);
         }
-        if (PVF8 && u >= 21) vr[u - 21] = lv[hslot(u - 21)];
-        // PVF8: the K_{t+2} pieces leave in the first units of phase 1 (their slot held K_t, read during tile t - 1), the V_{t+1}
-        // pieces in the first units of phase 2: 1.111 -> 1.082 ms per launch against all eight in phase 2 (all eight in phase 1:
-        // 1.107; tools/ubench/ablate_h2p.py p8_*)
-        if (PVF8 && u < 4) issue_piece(t, u);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (PVF8) {
-      // ---- phase 2, fp8 form: 8 x P_hi V_hi on the f16 pipe - in their issue gaps the e4m3 planes of the probabilities, their row
-      //      sums and the tile's 8 LDS-DMA pieces - then ONE block-scaled fp8 MFMA per feature block for both cross products ----
-      // (every LDS read is issued >= 3 MFMAs / >= 128 matrix-pipe cycles ahead of its use: with one MFMA per fragment - not the
-      // three of the split-fp16 form - a read issued one unit ahead left the pipe waiting for the LDS in every unit)
-      const i32x4* lv8 = reinterpret_cast<const i32x4*>(lv);
-      i32x4 fa[2][2];
-#pragma unroll
-      for (int u = 0; u < 12; ++u) {
-        if (u < 8) {
-          const int s2 = u >> 2, db = u & 3;
-          oacc[db] = mfma_h16(vr[u % 3], s2 ? ph1 : ph0, oacc[db]);
-          if (u + 3 < 8) vr[u % 3] = lv[hslot(u + 3)];
-          if (u == 4 || u == 6) { const int fd = (u - 4) >> 1; fa[fd][0] = lv8[(1 * 8 + 2 * fd) * 64]; fa[fd][1] = lv8[(1 * 8 + 2 * fd + 1) * 64]; }
-          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);
-          if (u < 4) issue_piece(t, u + 4);     // V_{t+1}; the K pieces went out in phase 1
-        } else {
-          const int db = u - 8;
-          const i32x4 a_lo = fa[db & 1][0], a_hi = fa[db & 1][1];
-          const i32x8 va = {a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
-          oacc[db] = mfma_f8s(va, pb, oacc[db], db, (int)vsw, psc);
-          if (db < 2) { fa[db & 1][0] = lv8[(1 * 8 + 2 * db + 4) * 64]; fa[db & 1][1] = lv8[(1 * 8 + 2 * db + 5) * 64]; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      ls += ls_l;
-    } else
     // ---- phase 2: O^T += V_t^T P^T, the remaining exponentials and the second split in its issue gaps ----
     {
       f16x8 vh = lv[0], vl = vh;
@@ -1059,6 +1020,7 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   // behind the tile barrier a wave goes straight back to the matrix pipe.  (In the form above those ~45 dependent instructions
   // ran between the barrier and the first MFMA of every tile, on all four waves of the workgroup at the same time: a timing-only
   // build without them was 16 % faster than one that merely dropped the c loads - tools/ubench/ablate_h2p.py p8_no_scores / no_c.)
+  constexpr float kLazy = 5.0f;
   auto tile_step_f8 = [&](const int t, const f32x16& s_cur, f32x16& s_next) {
     float x[16];
     float mx = -INFINITY, m_off = 0.f, alpha = 1.f, ls = 0.f, ls_l = 0.f;
@@ -1095,11 +1057,16 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
           __builtin_amdgcn_sched_barrier(0);
           mx = xhalf_max_swap(mx);
           if (CFMT == 2) mx *= kInvU16;
-          const float m_new = __builtin_fmaxf(m_run, mx);
-          const bool moved = m_new > m_run;
+          // LAZY reference: m_run only moves when a score exceeds it by more than kLazy (2^kLazy in probability), and the
+          // probabilities are formed as 2^(10 - kLazy) P, so that p <= 2^10 either way (the e4m3 planes' range).  A wave's 32 rows
+          // set new maxima in half of its 157 tiles (in nearly all of a key-split workgroup's 26), each costing the 64
+          // multiplications of the accumulator rescale on the critical path; beyond the margin they are rare.  The scale of
+          // numerator and denominator is the same power of two: O / l does not change.
+          const bool moved = mx > m_run + kLazy;
+          const float m_new = moved ? mx : m_run;
           alpha = __builtin_amdgcn_exp2f(m_run - m_new);
           m_run = m_new;
-          m_off = m_new - 10.0f;               // P' = 2^10 P
+          m_off = m_new - (10.0f - kLazy);
           rescale(moved, alpha);
         }
         if (u >= 4 && u < 20) x[u - 4] = expo(x[u - 4], m_off);
@@ -1109,7 +1076,11 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
           else split2h(x[2 * k], x[2 * k + 1], ph1, pl1, 2 * k - 8);
         }
         if (u == 20) split2h(x[14], x[15], ph1, pl1, 6);
-        if (u >= 8 && u < 12) issue_piece(t, u - 8);     // K_{t+2}
+        // the tile ring's refills ride in the lighter units of this phase: K_{t+2} (its slot held K_t, read during tile t - 1) at units
+        // 12..15, V_{t+1} (slot of V_{t-1}) at units 20..23 - 1051 us per launch against 1062-1069 with V in the first units of phase 2
+        // (B = 1: 46.9 against 48.1 us per layer; tools/ubench/ablate_h2p.py p8_*)
+        if (u >= 12 && u < 16) issue_piece(t, u - 12);
+        if (u >= 20) issue_piece(t, u - 16);
         if (u >= 21) vr[u - 21] = lv[hslot(u - 21)];
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1125,7 +1096,6 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
           if (u + 3 < 8) vr[u % 3] = lv[hslot(u + 3)];
           if (u == 4 || u == 6) { const int fd = (u - 4) >> 1; fa[fd][0] = lv8[(1 * 8 + 2 * fd) * 64]; fa[fd][1] = lv8[(1 * 8 + 2 * fd + 1) * 64]; }
           planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);
-          if (u < 4) issue_piece(t, u + 4);             // V_{t+1}
         } else {
           const int db = u - 8;
           const i32x4 a_lo = fa[db & 1][0], a_hi = fa[db & 1][1];
@@ -1158,7 +1128,7 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
     const bool moved = m_new > m_run;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
-    const float m_off = m_new - 10.0f;
+    const float m_off = m_new - (PVF8 ? 10.0f - kLazy : 10.0f);      // (the scale of the tiles before it: tile_step_f8)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { x[r] = expo(x[r], m_off); if (!PVF8) ls += x[r]; }
     rescale(moved, alpha);

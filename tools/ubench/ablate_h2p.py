@@ -12,13 +12,10 @@ What each one removes tells what that resource costs the shipped kernel:
     c_l2       the compat tiles come from two alternating addresses (L2 hits): the loads and their waits stay, the HBM stream goes
     no_exp     v_exp_f32 replaced by a subtraction
     no_dma     the in-loop K / V tile refills are not issued (stale tiles)
-    no_split   probabilities not split into two fp16 planes (one conversion)
 and for k_linear_h2 (prefix lin_):
     lin_no_gelu     GELU of the feed-forward replaced by the identity
     lin_no_barrier  the stage barriers removed (racy)
-    lin_no_dma      the weight / context stages not fetched (stale LDS)
     lin_no_exp      the cross-attention's exponentials replaced by a subtraction
-    lin_dma_same    every stage fetched from the same 16 KiB (same DMA count and waits, no L2 traffic)
 """
 import os
 import shutil
@@ -43,8 +40,7 @@ PATCHES = {
         (EK, "    const f32x4* ct = crow + (size_t)t * kCTile16;", "    const f32x4* ct = crow + (size_t)(t & 1) * kCTile16;"),
     ],
     "no_exp": [
-        (EK, "          x[r] = expo(x[r], m_off);\n          if (!PVF8) ls += x[r];",
-         "          x[r] = x[r] - m_off;\n          if (!PVF8) ls += x[r];"),
+        (EK, "        if (u >= 4 && u < 20) x[u - 4] = expo(x[u - 4], m_off);", "        if (u >= 4 && u < 20) x[u - 4] = x[u - 4] - m_off;"),
     ],
     "no_dma": [
         (EK, "        if (u >= 3 && u < 11) issue_piece(t, u - 3);\n", ""),
@@ -53,17 +49,9 @@ PATCHES = {
         (EK, "const f32x4 v = __builtin_nontemporal_load(ct + q * 64);", "const f32x4 v = {1.f, 1.f, 1.f, 1.f}; (void)ct;"),
         (EK, "        if (u >= 3 && u < 11) issue_piece(t, u - 3);\n", ""),
     ],
-    "no_split": [
-        (EK, "          split2h(x[j], x[j + 1], ph0, pl0, j);", "          ph0[j] = (_Float16)x[j]; ph0[j + 1] = (_Float16)x[j + 1];"),
-        (EK, "          split2h(x[8 + j], x[8 + j + 1], ph1, pl1, j);", "          ph1[j] = (_Float16)x[8 + j]; ph1[j + 1] = (_Float16)x[8 + j + 1];"),
-    ],
     # ---- schedule variants of the pv_fp8 form (these compute the SAME results; A/B in one process).  Shipped: K pieces in phase 1
     #      units 0..3, V pieces in phase 2 units 0..3 (1.082 ms); measured against it: all eight in phase 2 1.111, all eight in
     #      phase 1 1.107, K at the tile top 1.131 / 1.124 (same box as 1.124 for the shipped form), V in phase 2 units 4..7 1.135
-    "p8_pieces_p2": [      # all 8 LDS-DMA pieces of a tile in phase 2
-        (EK, "          if (u < 4) issue_piece(t, u + 4);     // V_{t+1}; the K pieces went out in phase 1\n", "          issue_piece(t, u);\n"),
-        (EK, "        if (PVF8 && u < 4) issue_piece(t, u);", ""),
-    ],
     # timing-only sensitivities of the pv_fp8 form (wrong results)
     "p8_no_fp8": [         # the four fp8 MFMAs of a tile not issued: 256 matrix-pipe cycles less per tile and wave
         (EK, "          oacc[db] = mfma_f8s(va, pb, oacc[db], db, (int)vsw, psc);\n          if (db < 2)", "          asm volatile(\"\" :: \"v\"(va), \"v\"(pb));\n          if (db < 2)"),
@@ -71,16 +59,11 @@ PATCHES = {
     "p8_no_hh": [          # the eight P_hi V_hi MFMAs not issued (256 cycles)
         (EK, "          oacc[db] = mfma_h16(vr[u % 3], s2 ? ph1 : ph0, oacc[db]);", "          asm volatile(\"\" :: \"v\"(vr[u % 3]));"),
     ],
-    "p8_no_scores": [      # the tile top without the compat product and the row maximum (x = s, maximum 0): its serial vector work
-        (EK, "      x[r] = score(r, s_cur[r]);\n      x[r + 1] = score(r + 1, s_cur[r + 1]);\n      mx = __builtin_fmaxf(mx, __builtin_fmaxf(x[r], x[r + 1]));",
-         "      x[r] = s_cur[r] * 1e-3f;\n      x[r + 1] = s_cur[r + 1] * 1e-3f;\n      mx = 0.f;"),
-    ],
     "p8_no_barrier": [     # the tile barrier removed (racy)
         (EK, "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    __syncthreads();\n    if (PVF8) vsw = vsw_next;", "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    if (PVF8) vsw = vsw_next;"),
     ],
-    "p8_no_dma": [         # the in-loop K / V refills not issued (stale tiles)
-        (EK, "          if (u < 4) issue_piece(t, u + 4);     // V_{t+1}; the K pieces went out in phase 1\n", ""),
-        (EK, "        if (PVF8 && u < 4) issue_piece(t, u);", ""),
+    "p8_no_dma": [         # the in-loop K / V refills not issued (stale tiles: the SAME data every tile - quieter operands, see DESIGN)
+        (EK, "        if (u >= 12 && u < 16) issue_piece(t, u - 12);\n        if (u >= 20) issue_piece(t, u - 16);\n", ""),
     ],
     "p8_dma_l2": [         # the refills come from two alternating tiles (L2 / L1 hits): same instructions, same LDS writes, no L2 misses
         (EK, "      if (t + 2 < t_end) dma_piece_1k_s(gk + (size_t)(t + 2) * kStageFloats + (wave + WAVES * q) * 256,",
@@ -88,9 +71,10 @@ PATCHES = {
         (EK, "      dma_piece_1k_s(gv + (size_t)(t + 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256,",
              "      dma_piece_1k_s(gv + (size_t)((t + 1) & 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256,"),
     ],
-    "p8_top_scores": [     # the compat product / row maximum at the tile top (the shared tile step) instead of inside phase 1
-        (EK, "        tile_step_f8(t, s_a, s_b);\n        tile_step_f8(t + 1, s_b, s_a);", "        tile_step(t, s_a, s_b);\n        tile_step(t + 1, s_b, s_a);"),
-        (EK, "      if (t + 1 < t_end) { tile_step_f8(t, s_a, s_b); tile_last(t + 1, s_b); }", "      if (t + 1 < t_end) { tile_step(t, s_a, s_b); tile_last(t + 1, s_b); }"),
+    "p8_v_p2": [           # V pieces in the first units of phase 2 and K pieces at units 8..11 of phase 1 (the form before the last move)
+        (EK, "        if (u >= 12 && u < 16) issue_piece(t, u - 12);\n        if (u >= 20) issue_piece(t, u - 16);\n", "        if (u >= 8 && u < 12) issue_piece(t, u - 8);\n"),
+        (EK, "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n        } else {\n          const int db = u - 8;\n          const i32x4 a_lo = fa[db & 1][0], a_hi = fa[db & 1][1];\n          const i32x8 va = {a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};\n          oacc[db] = mfma_f8s(va, pb, oacc[db], db, (int)vsw, psc);\n          if (db < 2) { fa[db & 1][0] = lv8[(1 * 8 + 2 * db + 4) * 64]; fa[db & 1][1] = lv8[(1 * 8 + 2 * db + 5) * 64]; }\n        }\n        __builtin_amdgcn_sched_barrier(0);\n      }\n    }\n    l_half = fmaf(l_half, alpha, ls + ls_l);",
+              "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n          if (u < 4) issue_piece(t, u + 4);\n        } else {\n          const int db = u - 8;\n          const i32x4 a_lo = fa[db & 1][0], a_hi = fa[db & 1][1];\n          const i32x8 va = {a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};\n          oacc[db] = mfma_f8s(va, pb, oacc[db], db, (int)vsw, psc);\n          if (db < 2) { fa[db & 1][0] = lv8[(1 * 8 + 2 * db + 4) * 64]; fa[db & 1][1] = lv8[(1 * 8 + 2 * db + 5) * 64]; }\n        }\n        __builtin_amdgcn_sched_barrier(0);\n      }\n    }\n    l_half = fmaf(l_half, alpha, ls + ls_l);"),
     ],
     "p8_no_consist": [     # timing only: the row sum without the decoded low plane (what the consistent sum costs: nothing measurable)
         (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<true>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),
@@ -104,15 +88,6 @@ PATCHES = {
         (MC, "    __syncthreads();            // everyone's pieces of this stage landed; the slot of the previous stage is free\n", ""),
         (FF, "    asm volatile(\"s_waitcnt vmcnt(8)\" ::: \"memory\");   // all but this wave's pieces of the 2 younger stages have landed\n    __syncthreads();",
          "    asm volatile(\"s_waitcnt vmcnt(8)\" ::: \"memory\");"),
-    ],
-    "lin_no_dma": [
-        (MC, "      for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);\n      ++issued;", "      for (int q = 0; q < 1; ++q) { (void)g; (void)dst; }\n      ++issued;"),
-        (FF, "    for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, lane);\n    ++n_issued;", "    for (int q = 0; q < 1; ++q) { (void)g; (void)dst; }\n    ++n_issued;"),
-    ],
-    "lin_dma_same": [      # every stage is fetched from the SAME 16 KiB of global memory (hot in the L1): same DMA count, no L2 traffic
-        (MC, "      float* dst = base + (issued % NBUF) * kStageFloats;\n#pragma unroll\n      for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256,",
-         "      float* dst = base + (issued % NBUF) * kStageFloats;\n      g = seg_ptr[0];\n#pragma unroll\n      for (int q = 0; q < 4; ++q) dma_piece_1k(g + (wave + 4 * q) * 256,"),
-        (FF, "    const float* g = wst + (size_t)blob_stage(n_issued) * kStageFloats;", "    const float* g = wst;"),
     ],
     "lin_dma_once": [      # only the first ring-full of stages is fetched (the LDS holds real data, later stages reuse it)
         (MC, "      for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);",

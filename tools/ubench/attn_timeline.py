@@ -41,7 +41,8 @@ def build():
     rep("        if (u >= 21) vr[u - 21] = lv[hslot(u - 21)];\n        __builtin_amdgcn_sched_barrier(0);\n      }\n    }\n",
         "        if (u >= 21) vr[u - 21] = lv[hslot(u - 21)];\n        __builtin_amdgcn_sched_barrier(0);\n"
         "        if (u == 3) TL(t, 2); if (u == 7) TL(t, 3); if (u == 11) TL(t, 4); if (u == 19) TL(t, 5);\n      }\n    }\n    TL(t, 6);\n")
-    rep("          if (u < 4) issue_piece(t, u + 4);             // V_{t+1}\n", "          if (u < 4) issue_piece(t, u + 4);             // V_{t+1}\n          if (u == 7) TL(t, 7);\n")
+    rep("          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n        } else {",
+        "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n          if (u == 7) TL(t, 7);\n        } else {")
     rep("    l_half = fmaf(l_half, alpha, ls + ls_l);\n  };\n", "    TL(t, 8);\n    l_half = fmaf(l_half, alpha, ls + ls_l);\n  };\n")
     a = text.index("// PVF8 (with NPROD = 3): the two CROSS products")
     pre = (f'__device__ unsigned long long g_tl[{NT * NS}];\n'
@@ -87,7 +88,7 @@ def run(B, N):
     rc = lib.gmf_dbg_attn_timeline(buf)
     assert rc == 0, rc
     v = list(buf)
-    names = ["barrier wait", "u0-3 scores+max", "u4-7", "u8-11 (+K pieces)", "u12-19", "u20-23", "ph2 hh u0-7 (+conv, V pieces)", "ph2 fp8 u8-11", "to next entry"]
+    names = ["barrier wait", "u0-3 scores+max, fetch c, offset", "u4-7", "u8-11", "u12-19 (+K pieces)", "u20-23 (+V pieces)", "ph2 hh u0-7 (+conversions)", "ph2 fp8 u8-11", "to next entry"]
     print(f"B={B} N={N}: wave 0 of workgroup 0, last launch; core-clock cycles per key tile")
     tot = [0] * 9
     n = 0
@@ -102,7 +103,7 @@ def run(B, N):
     if n:
         for nm, x in zip(names, tot):
             print(f"  {nm:34s} {x / n:8.0f}")
-        print(f"  {'tile':34s} {sum(tot) / n:8.0f}   (matrix-pipe time of the tile: 24 x 32 + 8 x 32 + 4 x 64 = 1280)")
+        print(f"  {'tile':34s} {sum(tot) / n:8.0f}   (matrix-pipe time of the tile: 24 x 32 + 8 x 32 + 4 x 64 = 1280; the stamps themselves stretch the tile by ~10 %: more of them distort it beyond use)")
 
 
 if __name__ == "__main__":

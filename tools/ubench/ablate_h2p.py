@@ -76,6 +76,14 @@ PATCHES = {
         (EK, "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n        } else {\n          const int db = u - 8;\n          const i32x4 a_lo = fa[db & 1][0], a_hi = fa[db & 1][1];\n          const i32x8 va = {a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};\n          oacc[db] = mfma_f8s(va, pb, oacc[db], db, (int)vsw, psc);\n          if (db < 2) { fa[db & 1][0] = lv8[(1 * 8 + 2 * db + 4) * 64]; fa[db & 1][1] = lv8[(1 * 8 + 2 * db + 5) * 64]; }\n        }\n        __builtin_amdgcn_sched_barrier(0);\n      }\n    }\n    l_half = fmaf(l_half, alpha, ls + ls_l);",
               "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n          if (u < 4) issue_piece(t, u + 4);\n        } else {\n          const int db = u - 8;\n          const i32x4 a_lo = fa[db & 1][0], a_hi = fa[db & 1][1];\n          const i32x8 va = {a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};\n          oacc[db] = mfma_f8s(va, pb, oacc[db], db, (int)vsw, psc);\n          if (db < 2) { fa[db & 1][0] = lv8[(1 * 8 + 2 * db + 4) * 64]; fa[db & 1][1] = lv8[(1 * 8 + 2 * db + 5) * 64]; }\n        }\n        __builtin_amdgcn_sched_barrier(0);\n      }\n    }\n    l_half = fmaf(l_half, alpha, ls + ls_l);"),
     ],
+    "p8_no_softmax": [     # timing only: no exponentials, no splits, no plane conversions - the probabilities' planes are (changing) copies of
+                           # the scores' bits; MFMAs, LDS reads, refills, compat product and row maximum stay.  What the softmax's vector work costs.
+        (EK, "        if (u >= 4 && u < 20) x[u - 4] = expo(x[u - 4], m_off);", ""),
+        (EK, "          if (k < 4) split2h(x[2 * k], x[2 * k + 1], ph0, pl0, 2 * k);\n          else split2h(x[2 * k], x[2 * k + 1], ph1, pl1, 2 * k - 8);",
+             "          if (k < 4) { ph0[2 * k] = (_Float16)1.0f; ph0[2 * k + 1] = (_Float16)0.5f; pl0[2 * k] = (_Float16)0.001f; pl0[2 * k + 1] = (_Float16)0.002f; }\n          else { ph1[2 * k - 8] = (_Float16)1.0f; ph1[2 * k - 7] = (_Float16)0.5f; pl1[2 * k - 8] = (_Float16)0.001f; pl1[2 * k - 7] = (_Float16)0.002f; }\n          asm volatile(\"\" :: \"v\"(x[2 * k]), \"v\"(x[2 * k + 1]));"),
+        (EK, "        if (u == 20) split2h(x[14], x[15], ph1, pl1, 6);", "        if (u == 20) { ph1[6] = (_Float16)1.0f; ph1[7] = (_Float16)0.5f; pl1[6] = (_Float16)0.001f; pl1[7] = (_Float16)0.002f; asm volatile(\"\" :: \"v\"(x[14]), \"v\"(x[15])); }"),
+        (EK, "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n        } else {", "          pb[u] = 0x38383838; ls += 1.0f;\n        } else {"),
+    ],
     "p8_no_consist": [     # timing only: the row sum without the decoded low plane (what the consistent sum costs: nothing measurable)
         (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<true>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),
         (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<false>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),

@@ -37,7 +37,8 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(src, h.data(), n * 2, hipMemcpyHostToDevice));
   const int iters = 4000;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int nacc = 1; nacc <= 4; nacc *= 2) {
+  for (int pass = 0; pass < 6; ++pass) {
+    const int nacc = (pass < 3) ? (4 >> pass) : (1 << (pass - 3));      // 4, 2, 1, 1, 2, 4: order effects (temperature) show up as asymmetry
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(e0));

@@ -1,0 +1,98 @@
+"""Where a wave of k_linear_h2 spends its 32-row tile: core-clock stamps (s_memtime) of wave 0 of workgroup (0, 0) at the start, behind
+the Q'/K/V projections (12 weight stages), behind the cross-attention (LCPE, LayerNorm, to_q, 7 context tiles, to_out) and behind the
+GEGLU feed-forward (48 stages).  Patched COPY of encoder_h2.hip in tools/_ab/libgmf_hip_lin_tl.so.
+
+    python tools/ubench/linear_timeline.py build       # here
+    python tools/ubench/linear_timeline.py run B N     # GPU box
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, "gmf_amd", "csrc")
+OUT = os.path.join(ROOT, "tools", "_ab")
+LIB = os.path.join(OUT, "libgmf_hip_lin_tl.so")
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    subprocess.check_call(["make", "-C", CSRC, "-j4"])
+    work = os.path.join(OUT, "src_lin_tl")
+    shutil.rmtree(work, ignore_errors=True)
+    os.makedirs(work)
+    for f in os.listdir(CSRC):
+        if f.endswith((".hpp", ".hip")):
+            shutil.copy(os.path.join(CSRC, f), work)
+    path = os.path.join(work, "encoder_h2.hip")
+    text = open(path).read()
+
+    def rep(old, new, count=1):
+        nonlocal text
+        assert text.count(old) == count, (old[:60], text.count(old))
+        text = text.replace(old, new)
+    rep("  // ---- Q', K, V from f ---------------------------------------------------------------------------------------------\n",
+        "  LTL(0);\n  // ---- Q', K, V from f ---------------------------------------------------------------------------------------------\n")
+    rep("  if (PART == 2) ss.prime();\n  // ---- cross-attention: x1 = x' + Wo softmax(q Kc^T) Vc + bo",
+        "  LTL(1);\n  if (PART == 2) ss.prime();\n  // ---- cross-attention: x1 = x' + Wo softmax(q Kc^T) Vc + bo")
+    rep("  // ---- feed-forward: x2 = x1 + W2 GEGLU(W1 LN(x1) + b1) + b2 --------------------------------------------------------\n",
+        "  LTL(2);\n  // ---- feed-forward: x2 = x1 + W2 GEGLU(W1 LN(x1) + b1) + b2 --------------------------------------------------------\n")
+    rep("  ff_chunks<NP>(nx, y, lds, ff_wst, lvec_f + 2 * C, lvec_f + 2 * C + FFH, wave, lane, h, 0, FFH / 32);\n#pragma unroll\n  for (int mb = 0; mb < 4; ++mb) {\n    float t[16];",
+        "  LTL(3);\n  ff_chunks<NP>(nx, y, lds, ff_wst, lvec_f + 2 * C, lvec_f + 2 * C + FFH, wave, lane, h, 0, FFH / 32);\n  LTL(4);\n#pragma unroll\n  for (int mb = 0; mb < 4; ++mb) {\n    float t[16];")
+    a = text.index("// k_linear_h2: every linear stage of one encoder layer in ONE pass")
+    pre = ('__device__ unsigned long long g_ltl[8];\n'
+           '#define LTL(k) do { asm volatile("s_nop 0" ::: "memory"); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) '
+           'g_ltl[k] = __builtin_readcyclecounter(); asm volatile("s_nop 0" ::: "memory"); } while (0)\n')
+    text = text[:a] + pre + text[a:]
+    text = text.rstrip()
+    assert text.endswith("}  // namespace gmf")
+    text = text[:-len("}  // namespace gmf")] + ('}  // namespace gmf\nextern "C" int gmf_dbg_linear_timeline(unsigned long long* out) {\n'
+                                               '  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gmf::g_ltl), 8 * sizeof(unsigned long long));\n}\n')
+    open(path, "w").write(text)
+    obj = os.path.join(work, "encoder_h2.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+                           "-fno-slp-vectorize", "-c", path, "-o", obj])
+    rest = [os.path.join(CSRC, o) for o in os.listdir(CSRC) if o.endswith(".o") and o != "encoder_h2.o"]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", obj] + rest + ["-o", LIB])
+    shutil.rmtree(work)
+    print("built", LIB)
+
+
+def run(B, N):
+    import ctypes as C
+    import torch
+    sys.path.insert(0, ROOT)
+    from gmf_amd import _lib
+    _lib.LIB_PATH = LIB
+    import gmf_amd
+    from gmf_amd import synthetic
+    dev = torch.device("cuda:0")
+    sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7)
+    model = gmf_amd.PointDSC(num_layers=12)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(dev).eval()
+    b = synthetic.synthetic_batch(list(range(B)), N=N, T=196)
+    data = {k: b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    for _ in range(5):
+        model(data)
+    torch.cuda.synchronize()
+    lib = _lib.handle_for(0).lib
+    buf = (C.c_ulonglong * 8)()
+    lib.gmf_dbg_linear_timeline.argtypes = [C.POINTER(C.c_ulonglong)]
+    assert lib.gmf_dbg_linear_timeline(buf) == 0
+    v = list(buf)
+    names = ["Q'/K/V projections (12 stages, 288 MFMAs)", "cross-attention (LCPE, LN, to_q, 7 context tiles, to_out; ~300 MFMAs)",
+             "LayerNorm + residual seed of the feed-forward", "GEGLU feed-forward (48 stages, 1152 MFMAs)"]
+    print(f"B={B} N={N}: k_linear_h2, wave 0 of workgroup (0, 0), last launch; core-clock cycles")
+    for k, nm in enumerate(names):
+        print(f"  {nm:76s} {v[k + 1] - v[k]:8d}")
+    print(f"  {'total':76s} {v[4] - v[0]:8d}")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    else:
+        run(int(sys.argv[2]), int(sys.argv[3]))

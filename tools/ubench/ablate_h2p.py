@@ -88,6 +88,11 @@ PATCHES = {
         (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<true>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),
         (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<false>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),
     ],
+    "lin_no_qkv_stores": [ # timing only: the Q' / K / V images are not stored (is the projection phase waiting for its own stores through the in-order vmcnt?)
+        (EH, "        store_block_h2(dst, mb, t, lane);\n      }\n    }\n    unsigned vsw = 0;", "        if (lane > 100000) store_block_h2(dst, mb, t, lane);\n        asm volatile(\"\" :: \"v\"(t[0]), \"v\"(t[5]), \"v\"(t[10]), \"v\"(t[15]));\n      }\n    }\n    unsigned vsw = 0;"),
+        (EH, "      if (v_scale) store_block_v8(v_out + toff, db, t, lane, vsw);     // (4 stores of 16 bytes either way: the counted waits hold)\n      else store_block_h2(v_out + toff, db, t, lane);",
+             "      if (lane > 100000) store_block_h2(v_out + toff, db, t, lane);\n      asm volatile(\"\" :: \"v\"(t[0]), \"v\"(t[5]), \"v\"(t[10]), \"v\"(t[15]));"),
+    ],
     "lin_no_gelu": [
         (FF, "a_cur[u] *= gelu_erf_1r(g_cur[u]);", "a_cur[u] *= g_cur[u];"),
     ],

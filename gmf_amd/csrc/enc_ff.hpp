@@ -27,8 +27,7 @@ GMF_DEVINL void ff_chunks(const FragH2<8>& nx, f32x16 (&y)[4], float* lds, const
   auto issue_one = [&]() {
     const float* g = wst + (size_t)blob_stage(n_issued) * kStageFloats;
     float* dst = lds + (n_issued & (NB - 1)) * kStageFloats;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);   // (statement form: see StageRing)
+    dma_4k_s(g + wave * 1024, dst + wave * 1024, (unsigned)lane * 16u);   // (statement form, one M0 setup per stage: see StageRing)
     ++n_issued;
   };
   auto acquire = [&]() {

@@ -930,6 +930,15 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
                      ldsV + ((t + 1) & 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256, lane_off16);
     }
   };
+  // the same refills as ONE statement per tile and wave (dma_4k_s: the wave's four consecutive KiB under one M0 / address setup)
+  auto issue_k4 = [&](const int t) {
+    if (WAVES == 4 && t + 2 < t_end && (NPROD == 3 || wave < 2))
+      dma_4k_s(gk + (size_t)(t + 2) * kStageFloats + wave * 1024, ldsK + (t & 1) * kStageFloats + wave * 1024, lane_off16);
+  };
+  auto issue_v4 = [&](const int t) {
+    if (WAVES == 4 && (NPROD == 3 || wave < 2))
+      dma_4k_s(gv + (size_t)(t + 1) * kStageFloats + wave * 1024, ldsV + ((t + 1) & 1) * kStageFloats + wave * 1024, lane_off16);
+  };
   auto rescale = [&](const bool moved, const float alpha) {
     if (__any(moved)) {
 #pragma unroll
@@ -1076,11 +1085,11 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
           else split2h(x[2 * k], x[2 * k + 1], ph1, pl1, 2 * k - 8);
         }
         if (u == 20) split2h(x[14], x[15], ph1, pl1, 6);
-        // the tile ring's refills ride in the lighter units of this phase: K_{t+2} (its slot held K_t, read during tile t - 1) at units
-        // 12..15, V_{t+1} (slot of V_{t-1}) at units 20..23 - 1051 us per launch against 1062-1069 with V in the first units of phase 2
-        // (B = 1: 46.9 against 48.1 us per layer; tools/ubench/ablate_h2p.py p8_*)
-        if (u >= 12 && u < 16) issue_piece(t, u - 12);
-        if (u >= 20) issue_piece(t, u - 16);
+        // the tile ring's refills ride in the lighter units of this phase, each as ONE statement (dma_4k_s): K_{t+2} (its slot held K_t, read
+        // during tile t - 1) at unit 12, V_{t+1} (slot of V_{t-1}) at unit 20 - 1028 us per launch against 1043 for eight separately set-up
+        // pieces at units 12..15 / 20..23, which in turn beat V in the first units of phase 2 by 1 % (tools/ubench/ablate_h2p.py p8_*)
+        if (u == 12) issue_k4(t);
+        if (u == 20) issue_v4(t);
         if (u >= 21) vr[u - 21] = lv[hslot(u - 21)];
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1173,8 +1182,11 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (t + 1 < t_end) {
+        if (PVF8) { issue_k4(t); issue_v4(t); }      // (the same KiB of every stage as this wave would fetch with queries: tile_step_f8)
+        else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) issue_piece(t, q);
+          for (int q = 0; q < 8; ++q) issue_piece(t, q);
+        }
       }
     }
   } else {

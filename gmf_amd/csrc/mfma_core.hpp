@@ -311,6 +311,19 @@ GMF_DEVINL void dma_piece_1k_s(const float* __restrict__ gsrc_piece_uniform, flo
                : "=&s"(keep) : "v"(lane_off16), "s"(gsrc_piece_uniform), "s"(lds_dst) : "memory");
 }
 
+// FOUR consecutive KiB (a wave's quarter of a 16 KiB stage) under ONE M0 / address setup: the instruction's 13-bit immediate offset is
+// added to the global address AND to the LDS address, so pieces 1..3 are the same instruction with offset:1024 / 2048 / 3072 - 4 vector-memory
+// and 4 scalar instructions per wave and stage where four dma_piece_1k_s cost 4 + ~32 (a wave issues nothing else while it issues these:
+// tools/ubench/mfma_valu_overlap.hip).  Which wave fetches which KiB of a stage is immaterial: a stage is read behind a barrier.
+GMF_DEVINL void dma_4k_s(const float* __restrict__ gsrc_uniform, float* lds_dst_base, unsigned lane_off16) {
+  unsigned keep;
+  const unsigned lds_dst = (unsigned)(uintptr_t)(void __attribute__((address_space(3)))*)(lds_dst_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_off16), "s"(gsrc_uniform), "s"(lds_dst) : "memory");
+}
+
 // Copy a per-feature vector block of n_floats (a multiple of 4) to the LDS, 1 KiB pieces round-robin over the waves; the last
 // piece is cut by the execution mask (nothing is read behind the block).
 GMF_DEVINL void dma_vec(const float* __restrict__ gsrc, float* lds_dst, int n_floats, int wave, int n_waves, int lane) {
@@ -401,8 +414,7 @@ struct StageRing {
       // The statement form of the DMA (not the builtin): hipcc waits with vmcnt(0) before every barrier / LDS read that follows
       // a builtin LDS-DMA - for the look-ahead stages and for every store in flight as well - which turned each stage of a
       // one-wave-per-SIMD kernel into a full memory round trip (~1 us whatever it multiplied).  acquire() carries the waits.
-#pragma unroll
-      for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);
+      dma_4k_s(g + wave * 1024, dst + wave * 1024, (unsigned)lane * 16u);
       ++issued;
     }
   }

@@ -62,19 +62,11 @@ PATCHES = {
     "p8_no_barrier": [     # the tile barrier removed (racy)
         (EK, "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    __syncthreads();\n    if (PVF8) vsw = vsw_next;", "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    if (PVF8) vsw = vsw_next;"),
     ],
-    "p8_no_dma": [         # the in-loop K / V refills not issued (stale tiles: the SAME data every tile - quieter operands, see DESIGN)
-        (EK, "        if (u >= 12 && u < 16) issue_piece(t, u - 12);\n        if (u >= 20) issue_piece(t, u - 16);\n", ""),
-    ],
     "p8_dma_l2": [         # the refills come from two alternating tiles (L2 / L1 hits): same instructions, same LDS writes, no L2 misses
         (EK, "      if (t + 2 < t_end) dma_piece_1k_s(gk + (size_t)(t + 2) * kStageFloats + (wave + WAVES * q) * 256,",
              "      if (t + 2 < t_end) dma_piece_1k_s(gk + (size_t)(t & 1) * kStageFloats + (wave + WAVES * q) * 256,"),
         (EK, "      dma_piece_1k_s(gv + (size_t)(t + 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256,",
              "      dma_piece_1k_s(gv + (size_t)((t + 1) & 1) * kStageFloats + (wave + WAVES * (q - 4)) * 256,"),
-    ],
-    "p8_v_p2": [           # V pieces in the first units of phase 2 and K pieces at units 8..11 of phase 1 (the form before the last move)
-        (EK, "        if (u >= 12 && u < 16) issue_piece(t, u - 12);\n        if (u >= 20) issue_piece(t, u - 16);\n", "        if (u >= 8 && u < 12) issue_piece(t, u - 8);\n"),
-        (EK, "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n        } else {\n          const int db = u - 8;\n          const i32x4 a_lo = fa[db & 1][0], a_hi = fa[db & 1][1];\n          const i32x8 va = {a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};\n          oacc[db] = mfma_f8s(va, pb, oacc[db], db, (int)vsw, psc);\n          if (db < 2) { fa[db & 1][0] = lv8[(1 * 8 + 2 * db + 4) * 64]; fa[db & 1][1] = lv8[(1 * 8 + 2 * db + 5) * 64]; }\n        }\n        __builtin_amdgcn_sched_barrier(0);\n      }\n    }\n    l_half = fmaf(l_half, alpha, ls + ls_l);",
-              "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n          if (u < 4) issue_piece(t, u + 4);\n        } else {\n          const int db = u - 8;\n          const i32x4 a_lo = fa[db & 1][0], a_hi = fa[db & 1][1];\n          const i32x8 va = {a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};\n          oacc[db] = mfma_f8s(va, pb, oacc[db], db, (int)vsw, psc);\n          if (db < 2) { fa[db & 1][0] = lv8[(1 * 8 + 2 * db + 4) * 64]; fa[db & 1][1] = lv8[(1 * 8 + 2 * db + 5) * 64]; }\n        }\n        __builtin_amdgcn_sched_barrier(0);\n      }\n    }\n    l_half = fmaf(l_half, alpha, ls + ls_l);"),
     ],
     "p8_no_softmax": [     # timing only: no exponentials, no splits, no plane conversions - the probabilities' planes are (changing) copies of
                            # the scores' bits; MFMAs, LDS reads, refills, compat product and row maximum stay.  What the softmax's vector work costs.
@@ -93,6 +85,16 @@ PATCHES = {
         (EH, "      if (v_scale) store_block_v8(v_out + toff, db, t, lane, vsw);     // (4 stores of 16 bytes either way: the counted waits hold)\n      else store_block_h2(v_out + toff, db, t, lane);",
              "      if (lane > 100000) store_block_h2(v_out + toff, db, t, lane);\n      asm volatile(\"\" :: \"v\"(t[0]), \"v\"(t[5]), \"v\"(t[10]), \"v\"(t[15]));"),
     ],
+    "p8_dma_pieces": [     # the attention tile ring refilled by eight separately set-up pieces (K at units 12..15, V at 20..23) instead of two statements
+        (EK, "        if (u == 12) issue_k4(t);\n        if (u == 20) issue_v4(t);\n", "        if (u >= 12 && u < 16) issue_piece(t, u - 12);\n        if (u >= 20) issue_piece(t, u - 16);\n"),
+        (EK, "        if (PVF8) { issue_k4(t); issue_v4(t); }", "        if (false) { }"),
+    ],
+    "lin_dma_pieces": [    # the stage refills as four separately set-up 1 KiB pieces per wave (the form before dma_4k_s)
+        (MC, "      dma_4k_s(g + wave * 1024, dst + wave * 1024, (unsigned)lane * 16u);\n      ++issued;",
+             "#pragma unroll\n      for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);\n      ++issued;"),
+        (FF, "    dma_4k_s(g + wave * 1024, dst + wave * 1024, (unsigned)lane * 16u);   // (statement form, one M0 setup per stage: see StageRing)",
+             "#pragma unroll\n    for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);"),
+    ],
     "lin_no_gelu": [
         (FF, "a_cur[u] *= gelu_erf_1r(g_cur[u]);", "a_cur[u] *= g_cur[u];"),
     ],
@@ -101,19 +103,6 @@ PATCHES = {
         (MC, "    __syncthreads();            // everyone's pieces of this stage landed; the slot of the previous stage is free\n", ""),
         (FF, "    asm volatile(\"s_waitcnt vmcnt(8)\" ::: \"memory\");   // all but this wave's pieces of the 2 younger stages have landed\n    __syncthreads();",
          "    asm volatile(\"s_waitcnt vmcnt(8)\" ::: \"memory\");"),
-    ],
-    "lin_dma_once": [      # only the first ring-full of stages is fetched (the LDS holds real data, later stages reuse it)
-        (MC, "      for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);",
-         "      for (int q = 0; q < 4; ++q) if (issued < NBUF) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);"),
-        (FF, "    for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);",
-         "    for (int q = 0; q < 4; ++q) if (n_issued < NB) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);"),
-    ],
-    "lin_half_dma": [      # after the first ring-full every wave issues HALF of its LDS-DMA pieces (what an 8-wave workgroup sharing the
-                           # stages would issue per wave; the other halves keep finite data of an earlier stage)
-        (MC, "      for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);",
-         "      for (int q = 0; q < 4; ++q) if (q < 2 || issued < NBUF) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);"),
-        (FF, "    for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);",
-         "    for (int q = 0; q < 4; ++q) if (q < 2 || n_issued < NB) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);"),
     ],
     "lin_no_exp": [
         (EH, "      for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }\n      l_half = fmaf(l_half, alpha, ls);\n      if (__any(moved)) {\n#pragma unroll\n        for (int db = 0; db < 2; ++db)",

@@ -49,8 +49,7 @@ k_conv_nhwc_h2(const float* __restrict__ x, const float* __restrict__ wimg, cons
   auto issue_stage = [&](int st) {
     const float* g = wimg + (size_t)st * kStageFloats;
     float* dst = lds + (st % NB) * kStageFloats;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dma_piece_1k_s(g + (wave + 4 * q) * 256, dst + (wave + 4 * q) * 256, (unsigned)lane * 16u);   // (statement form: mfma_core.hpp, StageRing)
+    dma_4k_s(g + wave * 1024, dst + wave * 1024, (unsigned)lane * 16u);   // (4 vector-memory operations, one setup: mfma_core.hpp, StageRing)
   };
   // every lane always loads (clamped address, value zeroed afterwards): the number of vector-memory operations in flight
   // must not depend on the data, the s_waitcnt counts below rely on it

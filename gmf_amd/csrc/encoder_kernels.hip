@@ -1025,10 +1025,12 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
     l_half = fmaf(l_half, alpha, ls);
   };
   // PVF8: the tile step with NO serial vector work at the tile top.  The compat product, the row maximum and the (rare) rescale
-  // of tile t sit in the issue gaps of the first S_{t+1} MFMAs (units 0..3), the exponentials and splits follow in units 4..20;
-  // behind the tile barrier a wave goes straight back to the matrix pipe.  (In the form above those ~45 dependent instructions
-  // ran between the barrier and the first MFMA of every tile, on all four waves of the workgroup at the same time: a timing-only
-  // build without them was 16 % faster than one that merely dropped the c loads - tools/ubench/ablate_h2p.py p8_no_scores / no_c.)
+  // of tile t are interleaved with the first S_{t+1} MFMAs (units 0..3), the exponentials and splits follow in units 4..20;
+  // behind the tile barrier a wave goes straight back to the matrix pipe (1080-1087 us per launch against 1091-1097 with those ~45
+  // dependent instructions between the barrier and the first MFMA, on all four waves of the workgroup at once).
+  // What the interleaving is for: a wave's own vector instructions do NOT overlap its MFMA (tools/ubench/mfma_valu_overlap.hip:
+  // 34.5 + 3.2 K cycles for one MFMA + K v_fma) - it is the OTHER wave of the SIMD that runs its vector work under this wave's
+  // MFMAs, and only a fine alternation of the two kinds gives it the chance.
   constexpr float kLazy = 5.0f;
   auto tile_step_f8 = [&](const int t, const f32x16& s_cur, f32x16& s_next) {
     float x[16];

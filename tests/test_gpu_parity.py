@@ -407,6 +407,43 @@ def test_pv_fp8_form_against_the_oracle(kind):
         h.call("gmf_set_tuning", b"pv_fp8", 2)
 
 
+def test_outlier_correspondence_with_huge_coordinates(model, sd_full):
+    """One correspondence whose coordinates are 300 x larger than the scene: its V row dominates the per-(feature, key tile) scale
+    of the e4m3 cross planes of its tile (the other 31 keys of that tile then lose bits of their CROSS terms
+    only), its Q' / K rows produce attention logits far outside the others'.  Both attention forms, the small-grid path (B = 1)
+    and the large-grid path (the same scene in a ragged batch), stay within the contract against an fp64 evaluation."""
+    from gmf_amd import _lib
+    b = synthetic.synthetic_batch([321], N=1000, T=196)
+    for k in ("src_keypts", "tgt_keypts"):
+        b[k] = b[k].clone()
+        b[k][0, 17] *= 300.0
+    b["corr_pos"] = torch.cat([b["src_keypts"], b["tgt_keypts"]], dim=-1)
+    ref = O.pointdsc_forward(sd_full, b, testing=True)["logits"][0]
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd_full.items()}
+    b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()}
+    c64, _ = O.compat_matrix(b64["src_keypts"], b64["tgt_keypts"], 0.1)
+    truth = O.classifier(sd64, O.encoder(sd64, b64["corr_pos"], c64, b64["p_tokens"], b64["q_tokens"], 12))[0]
+    floor = float((ref.double() - truth).abs().max())
+    one = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    one["testing"] = True
+    rag = {k: [one[k][0], one[k][0]] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    rag.update(p_tokens=torch.cat([one["p_tokens"]] * 2), q_tokens=torch.cat([one["q_tokens"]] * 2), testing=True)
+    h = _lib.handle_for(0)
+    try:
+        for pv in (0, 1):
+            h.call("gmf_set_tuning", b"pv_fp8", pv)
+            model(one)
+            small = model.last_logits[0].cpu()
+            large = model(rag)["logits"][0].cpu()
+            for name, lg in (("small grid", small), ("large grid", large)):
+                e64 = float((lg.double() - truth).abs().max())
+                print(f"outlier scene, pv_fp8 {pv}, {name}: vs fp64 {e64:.2e}, vs fp32 oracle {_maxerr(lg, ref):.2e} (fp32 oracle vs fp64 {floor:.2e})")
+                assert torch.isfinite(lg).all()
+                assert e64 < 1.5 * floor + 2e-5, (pv, name, e64, floor)
+    finally:
+        h.call("gmf_set_tuning", b"pv_fp8", 1)
+
+
 def test_compat_format_16bit_is_an_opt_in_within_the_gate_on_3dmatch_shape(model, sd_full):
     """gmf_set_tuning("compat_format", 2): the compat cache as 16-bit fixed point (half the cache and its stream; DESIGN section 4b
     has why it is not the default: KITTI-shape inputs).  On a 3DMatch-shape large-grid batch both attention forms (pv_fp8 0 / 1)

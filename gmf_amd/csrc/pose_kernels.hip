@@ -682,9 +682,9 @@ k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, 
 // ---------------------------------------------------------------------------------------
 constexpr int kKMax = 64;
 
-// The k x k feature Gram matrix comes from the f32 MFMA: the wave gathers its neighbours' unit features as two
-// 32-row fragments straight from the P32 image (no LDS staging of features) and forms G00, G01, G11
-// (G10 = G01^T) with 64 MFMAs each; lane (h, b) then owns column b of each tile and turns the dot products into
+// The k x k feature Gram matrix comes from the f16 MFMA on split-fp16 operands (fp32-equivalent, mfma_core.hpp): the wave gathers its
+// neighbours' unit features as two 32-row fragments from the row-major features (no LDS staging) and forms G00, G01, G11
+// (G10 = G01^T) with 24 MFMAs each; lane (h, b) then owns column b of each tile and turns the dot products into
 // M entries together with the spatial term.
 __global__ void __launch_bounds__(64)
 k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, const float* __restrict__ tgt,

@@ -72,10 +72,14 @@ GMF_DEVINL void store_block_v8(float* __restrict__ tile_base, int db, const floa
 #pragma unroll
   for (int r = 0; r < 16; ++r) mx = __builtin_fmaxf(mx, __builtin_fabsf(t[r]));
   mx = xhalf_max_swap(mx);
-  // biased exponent e of the maximum: max in [2^(e-127), 2^(e-126)); s = 2^(e-134).  Clamped so that s / 2^11 stays a normal
-  // float (a feature whose 32 values are all below 2^-108 is stored as zeros: 2^-108 of anything this network computes)
+  // biased exponent e of the maximum: max in [2^(e-127), 2^(e-126)); s = 2^(e-134).  The scale has a FLOOR of 2^-22
+  // (sb >= 105): below |v| = 2^-14 the high plane fp16(v) is subnormal, so the residual v - hi is no longer 2^-12 |v| but
+  // absolute, up to 2^-25 - with the scale following a tile maximum below 2^-15 that residual / (s / 2^11) left e4m3's
+  // range (448) and the conversion returned NaN bytes, which poisoned the feature of O for every query of the pair
+  // (ADVICE r3).  With the floor the scaled residual is at most 2^-25 / 2^-33 = 256; a tile of values that small keeps
+  // absolute errors of 2^-42 in its cross terms - far below anything else in the product.
   const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
-  const int sb = max(e - 7, 12);
+  const int sb = max(e - 7, 105);
   const float s_hi = __uint_as_float((unsigned)sb << 23), s_lo = __uint_as_float((unsigned)(sb - 11) << 23);
   scale_word |= (unsigned)((lane & 32) ? sb : sb - 11) << (8 * db);
   i32x4 v8, l8;

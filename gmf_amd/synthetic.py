@@ -150,6 +150,19 @@ def seeded_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, gain: float
     return out
 
 
+def kitti_conditioned(sd: SD, div: float = 13.0) -> SD:
+    """The seeded weights re-conditioned for KITTI-shape inputs (coordinates of +-40 m instead of 0..3 m).
+
+    `corr_pos` enters the network through `encoder.layer0` alone (PointDSC.py:139); the seeded first-layer weights are
+    scaled for 3DMatch-size coordinates, so on +-40 m inputs every activation behind them is ~13x larger and the
+    reference's own fp32 evaluation is 3e-4 from the exact network.  Dividing that one weight by `div` brings the
+    activations back to the 3DMatch scale (fp32 floor 1.7e-5 at N = 700 / 2000, logit spread unchanged), which is what
+    makes the literal 1e-4 gate testable on the sigma_d = 1.2 path (golden F22).  Returns a new dict; `sd` is not modified."""
+    out = dict(sd)
+    out["encoder.layer0.weight"] = sd["encoder.layer0.weight"] / div
+    return out
+
+
 def random_rotation(r: np.random.Generator) -> np.ndarray:
     q, _ = np.linalg.qr(r.normal(size=(3, 3)))
     if np.linalg.det(q) < 0:

@@ -424,8 +424,9 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
 // PART 0: the whole kernel.  PART 1 / PART 2: its two independent halves as workgroup ROLES of one launch (k_linear_roles, grids
 // of 256 .. ~300 workgroups: one workgroup per CU cannot hide the 71-stage chain of a wave, two roles per row block shorten
 // it to its longer half) - 1 = the Q'/K/V projections, 2 = Fusion-2 (LCPE + cross-attention + feed-forward).
-// LDS of the fused linear kernel: 4 stages | attention vectors | feed-forward vectors | 4 waves x 2 halo rows = 77.5 KiB (two workgroups per CU)
-constexpr int kLinLdsFloats = 4 * kStageFloats + 7 * C + (3 * C + 2 * FFH) + kWavesPerWG * 2 * C;
+// LDS of the fused linear kernel: 4 stages | attention vectors | feed-forward vectors | 4 waves x 2 halo rows | the three projection
+// biases = 78.5 KiB (two workgroups per CU)
+constexpr int kLinLdsFloats = 4 * kStageFloats + 7 * C + (3 * C + 2 * FFH) + kWavesPerWG * 2 * C + 3 * C;
 
 template <int PART, int NP = 3>
 GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const float* __restrict__ front_wst,
@@ -461,6 +462,8 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
   float* const lvec_a = lds + 4 * kStageFloats;
   float* const lvec_f = lvec_a + 7 * C;
   float* const halo = lvec_f + (3 * C + 2 * FFH) + wave * (2 * C);
+  float* const lvec_p = lvec_f + (3 * C + 2 * FFH) + kWavesPerWG * (2 * C);      // bq' | bk | bv
+  if (PART != 2) dma_vec(front_vec + C, lvec_p, 3 * C, wave, kWavesPerWG, lane);
   if (PART != 1) {
     dma_vec(attn_vec, lvec_a, 7 * C, wave, kWavesPerWG, lane);
     dma_vec(ff_vec, lvec_f, 3 * C + 2 * FFH, wave, kWavesPerWG, lane);
@@ -473,21 +476,17 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
   else ss.init(lds, wave, lane, attn_wst, 2, ctx_img + (size_t)pair * ttiles * kStageFloats, ttiles, attn_wst + 2 * kStageFloats, 2);
 
   // ---- Q', K, V from f ---------------------------------------------------------------------------------------------
+  // [r4] f is loaded ONCE and stays in registers for the Fusion-2 half (PART 0): a reload behind the 48 stores of this phase
+  // retires in order behind them, i.e. only when the last store has been acknowledged (stamped: 1 500 - 27 000 cycles).
+  float f[CF];
   if (PART != 2) {
     FragH2<8> fx;
-    {
-      float f[CF];
-      load_frag_p32<CF>(f, f_in + toff, lane);
-      fx.set(f);
-    }
-    // every bias of the phase is loaded up front: a load inside the stage loop would sit between the DMA pieces in the
-    // vmcnt queue and the compiler's wait for it would drain the stages in flight
-    float bqk[2][CF], bvv[4];
-    load_vec_frag<CF>(bqk[0], front_vec + 1 * C, h);
-    load_vec_frag<CF>(bqk[1], front_vec + 2 * C, h);
-#pragma unroll
-    for (int db = 0; db < 4; ++db) bvv[db] = front_vec[3 * C + 32 * db + i];
-    ss.prime();                                  // AFTER the loads above: their wait then leaves the three primed stages in flight
+    load_frag_p32<CF>(f, f_in + toff, lane);
+    fx.set(f);
+    // [r4] the three bias vectors come from the LDS copy (lvec_p): held in registers they were 128 VGPRs, and the compiler - which
+    // counts its own loads but not the ring's DMA pieces - put `s_waitcnt vmcnt(35 .. 32)` in front of every stage's bias add,
+    // i.e. a wait for the store acknowledgements of four stages back in the middle of every epilogue from stage 5 on.
+    ss.prime();                                  // AFTER the load above: its wait then leaves the three primed stages in flight
 #pragma unroll
     for (int which = 0; which < 2; ++which) {   // Q', K
       float* dst = (which == 0 ? q_out : k_out) + toff;
@@ -501,9 +500,10 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
                                 : sidx == 2 ? ss.acquire_counted<kYounger[2]>() : ss.acquire_counted<kYounger[3]>());
         f32x16 acc = zero16();
         mma_wx_h2n<8, NP>(acc, lw, fx);
-        float t[16];
+        float t[16], bb[16];
+        load_vec_block(bb, lvec_p + which * C, mb, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bqk[which][16 * mb + r]);
+        for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bb[r]);
         store_block_h2(dst, mb, t, lane);
       }
     }
@@ -514,8 +514,9 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
       f32x16 acc = zero16();
       mma_xw_h2n<8, NP>(acc, lw, fx);
       float t[16];
+      const float bvd = lvec_p[2 * C + 32 * db + i];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bvv[db]);
+      for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bvd);
       if (v_scale) store_block_v8(v_out + toff, db, t, lane, vsw);     // (4 stores of 16 bytes either way: the counted waits hold)
       else store_block_h2(v_out + toff, db, t, lane);
     }
@@ -535,7 +536,11 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
     FragH2<4> qx;
     {
       float xp[CF];
-      load_frag_p32<CF>(xp, f_in + toff, lane);
+      if (PART == 2) load_frag_p32<CF>(xp, f_in + toff, lane);
+      else {
+#pragma unroll
+        for (int k = 0; k < CF; ++k) xp[k] = f[k];
+      }
       if (PART == 2) {                           // (PART 0: the barriers of the Q'/K/V stages have made the vectors visible)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

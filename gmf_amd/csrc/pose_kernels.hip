@@ -307,13 +307,20 @@ k_sort_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, in
 //   passes of the bitonic network at N = 5000.
 // grid (B), block 1024, dynamic LDS = N*4 + S*8 bytes
 // ---------------------------------------------------------------------------------------
+// KEYS_IN_LDS = false [r4]: the same selection for ANY N (the reference has no limit, PointDSC.py:268-286; its 3DMatch evaluation
+// feeds num_node = 'all', evaluation/test_3DMatch.py:143): the transformed keys are not staged in the LDS but re-read from global
+// memory (L2-resident: 4 N bytes per pair) in each of the four histogram passes and the two compaction passes; the counters of the
+// ordered compaction are two 32-bit fields instead of 16 + 16 bits.  Every decision is the same function of the same keys, so both
+// forms give identical seed lists (tests: test_topk_select_equals_full_sort, test_topk_select_any_size).
+// dynamic LDS = S*8 bytes (+ N*4 + 8 with the keys in the LDS)
+template <bool KEYS_IN_LDS>
 __global__ void __launch_bounds__(1024)
 k_select_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, int S, const PairTab* __restrict__ ptab) {
   extern __shared__ unsigned char smem_raw[];
-  unsigned* d = reinterpret_cast<unsigned*>(smem_raw);                                   // [N]
-  unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem_raw + (((size_t)N * 4 + 7) & ~(size_t)7));   // [S]
+  unsigned* d = reinterpret_cast<unsigned*>(smem_raw);                                   // [N] (KEYS_IN_LDS)
+  unsigned long long* sel = reinterpret_cast<unsigned long long*>(KEYS_IN_LDS ? smem_raw + (((size_t)N * 4 + 7) & ~(size_t)7) : smem_raw);   // [S]
   __shared__ unsigned hist[256];
-  __shared__ unsigned wtot[16];
+  __shared__ unsigned wtot[16], wtot2[16];
   __shared__ unsigned s_prefix, s_rank;
   const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr unsigned kZero = 0x7fffffffu;          // d of +0.0
@@ -321,21 +328,24 @@ k_select_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, 
   const int S_out = S;                             // (stride of the output list: the largest pair's; the LDS was sized by it too)
   N = pair_rows(ptab, pair, N);
   S = pair_seeds(ptab, pair, S);
-  for (int t = tid; t < N; t += 1024) {
-    float f = keys[row0 + t];
+  auto to_d = [](float f) -> unsigned {
     if (f == 0.0f) f = 0.0f;                       // -0 -> +0
     const unsigned bits = __float_as_uint(f);
     const unsigned u = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-    d[t] = ~u;
+    return ~u;
+  };
+  auto dval = [&](int t) -> unsigned { return KEYS_IN_LDS ? d[t] : to_d(keys[row0 + t]); };
+  if (KEYS_IN_LDS) {
+    for (int t = tid; t < N; t += 1024) d[t] = to_d(keys[row0 + t]);
+    __syncthreads();
   }
-  __syncthreads();
   unsigned prefix = 0, mask = 0, r = (unsigned)(S - 1);                                  // 0-based rank still to resolve
   for (int shift = 24; shift >= 0; shift -= 8) {
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
     unsigned zc = 0;
     for (int t = tid; t < N; t += 1024) {
-      const unsigned v = d[t];
+      const unsigned v = dval(t);
       if ((v & mask) == prefix) {
         if (v == kZero) ++zc; else atomicAdd(&hist[(v >> shift) & 255u], 1u);
       }
@@ -370,23 +380,22 @@ k_select_topk(const float* __restrict__ keys, int* __restrict__ out_idx, int N, 
   }
   const unsigned thr = prefix, need_eq = r + 1;    // winners: d < thr, and the first need_eq of d == thr by index
   // ordered compaction: thread t owns the contiguous indices [t * per, (t + 1) * per)
-  const int per = (N + 1023) / 1024, lo = tid * per, hi = min(N, lo + per);
-  unsigned cnt = 0;                                // low 16 bits: d < thr, high 16 bits: d == thr  (N <= 16384)
-  for (int t = lo; t < hi; ++t) cnt += (d[t] < thr ? 1u : 0u) + (d[t] == thr ? 0x10000u : 0u);
-  unsigned inc = cnt;
+  const int per = (N + 1023) / 1024, lo = min(N, tid * per), hi = min(N, lo + per);
+  unsigned c_lt = 0, c_eq = 0;
+  for (int t = lo; t < hi; ++t) { const unsigned v = dval(t); c_lt += (v < thr) ? 1u : 0u; c_eq += (v == thr) ? 1u : 0u; }
+  unsigned i_lt = c_lt, i_eq = c_eq;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const unsigned up = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += up;
+    const unsigned u1 = __shfl_up(i_lt, o, 64), u2 = __shfl_up(i_eq, o, 64);
+    if (lane >= o) { i_lt += u1; i_eq += u2; }
   }
-  if (lane == 63) wtot[wave] = inc;
+  if (lane == 63) { wtot[wave] = i_lt; wtot2[wave] = i_eq; }
   __syncthreads();
-  unsigned base = 0;
-  for (int w = 0; w < wave; ++w) base += wtot[w];
-  unsigned before = base + inc - cnt;
-  unsigned lt_b = before & 0xffffu, eq_b = before >> 16;
+  unsigned b_lt = 0, b_eq = 0;
+  for (int w = 0; w < wave; ++w) { b_lt += wtot[w]; b_eq += wtot2[w]; }
+  unsigned lt_b = b_lt + i_lt - c_lt, eq_b = b_eq + i_eq - c_eq;
   for (int t = lo; t < hi; ++t) {
-    const unsigned v = d[t];
+    const unsigned v = dval(t);
     if (v < thr) {
       sel[lt_b + min(eq_b, need_eq)] = ((unsigned long long)v << 32) | (unsigned)t;
       ++lt_b;
@@ -670,6 +679,100 @@ k_knn_select_fast(const float* __restrict__ dist_in, int* __restrict__ knn_idx, 
         if (v[m] < bv) { bv = v[m]; bm = m; }
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// [r4] The same selection for rows of ANY length (N > 16 384: the reference has no limit, common.py:53-75): the distance row is not held
+// in registers but streamed from global memory twice - once for the per-thread minima that give the threshold T (the (k + 1)-th
+// smallest of the 64 group minima, exactly as above), once to collect the candidates <= T (one LDS atomic per candidate: ~1.5 k of
+// them per row) - and the candidates are ranked under (distance, index) as above.  The output is a function of the row alone, so it
+// equals k_knn_select_fast's wherever both apply (test_knn_stream_equals_register_form).  Adversarial rows (more than kCandMax
+// candidates) take k + 1 streamed rounds: the next element in (distance, index) order behind the last one extracted.
+// grid (S, B), block 256.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_knn_select_stream(const float* __restrict__ dist_in, int* __restrict__ knn_idx, int N, int S, int k, const PairTab* __restrict__ ptab, int ld) {
+  __shared__ float mins[256];
+  __shared__ __attribute__((aligned(16))) float cand_v[kCandMax + 4];
+  __shared__ __attribute__((aligned(16))) int cand_i[kCandMax + 4];
+  __shared__ float T_sh;
+  __shared__ int count;
+  __shared__ float red_v[2][4];
+  __shared__ int red_i[2][4];
+  const int pair = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+  if (s >= pair_seeds(ptab, pair, S)) return;
+  const float* dr = dist_in + ((size_t)pair * S + s) * ld;
+  int* out = knn_idx + ((size_t)pair * S + s) * k;
+  N = pair_rows(ptab, pair, N);
+  if (tid < k) out[tid] = min(tid + 1, N - 1);     // (NaN rows: every slot holds an in-range index, see k_knn_select_fast)
+  float bv = INFINITY;
+  for (int j = tid; j < N; j += 256) bv = fminf(bv, dr[j]);
+  if (tid == 0) count = 0;
+  if (k + 1 <= 64) {
+    float gv = fminf(bv, __shfl_xor(bv, 1, 64));
+    gv = fminf(gv, __shfl_xor(gv, 2, 64));
+    if ((tid & 3) == 0) mins[tid >> 2] = gv;
+    __syncthreads();
+    if (tid < 64) {
+      const float mine = mins[tid];
+      int rank = 0;
+      for (int u = 0; u < 64; ++u) { const float q = mins[u]; rank += (q < mine || (q == mine && u < tid)) ? 1 : 0; }
+      if (rank == k) T_sh = mine;
+    }
+  } else {
+    mins[tid] = bv;
+    __syncthreads();
+    int rank = 0;
+    for (int u = 0; u < 256; ++u) { const float q = mins[u]; rank += (q < bv || (q == bv && u < tid)) ? 1 : 0; }
+    if (rank == k) T_sh = bv;
+  }
+  __syncthreads();
+  const float T = T_sh;
+  for (int j = tid; j < N; j += 256) {
+    const float v = dr[j];
+    if (v <= T) {
+      const int pos = atomicAdd(&count, 1);
+      if (pos < kCandMax) { cand_v[pos] = v; cand_i[pos] = j; }
+    }
+  }
+  __syncthreads();
+  const int c = count;
+  if (c <= kCandMax) {
+    for (int p = tid; p < c; p += 256) {
+      const float pv = cand_v[p]; const int pi = cand_i[p];
+      int rank = 0;
+      for (int q = 0; q < c; ++q) { const float qv = cand_v[q]; const int qi = cand_i[q]; rank += (qv < pv || (qv == pv && qi < pi)) ? 1 : 0; }
+      if (rank >= 1 && rank <= k) out[rank - 1] = pi;     // rank 0 (the row itself) is dropped, common.py:74
+    }
+    return;
+  }
+  // fallback: k + 1 streamed rounds, each the smallest element behind (last_v, last_i) in (distance, index) order
+  const int lane = tid & 63, wave = tid >> 6;
+  float last_v = -INFINITY; int last_i = -1;
+  for (int it = 0; it <= k; ++it) {
+    float rv = INFINITY; int ri = 0x7fffffff;
+    for (int j = tid; j < N; j += 256) {
+      const float v = dr[j];
+      const bool behind = v > last_v || (v == last_v && j > last_i);
+      if (behind && (v < rv || (v == rv && j < ri))) { rv = v; ri = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(rv, o, 64); const int oi = __shfl_xor(ri, o, 64);
+      if (ov < rv || (ov == rv && oi < ri)) { rv = ov; ri = oi; }
+    }
+    const int buf = it & 1;
+    if (lane == 0) { red_v[buf][wave] = rv; red_i[buf][wave] = ri; }
+    __syncthreads();
+    float wv = red_v[buf][0]; int wi = red_i[buf][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float ov = red_v[buf][w]; const int oi = red_i[buf][w];
+      if (ov < wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
+    }
+    if (it > 0 && tid == 0) out[it - 1] = (wi < N) ? wi : min(it, N - 1);
+    last_v = wv; last_i = wi;
   }
 }
 
@@ -1536,16 +1639,25 @@ hipError_t launch_nms_keys(const Tuning& tune, const float* src, const float* sc
 // tune.topk_select: radix select + rank placement (default) or the full bitonic sort
 hipError_t launch_sort_topk(const Tuning& tune, const float* keys, int* out_idx, int B, int N, int S, hipStream_t s, const PairTab* ptab) {
   const int M = next_pow2(N < 2 ? 2 : N);
-  if (M > 16384) return hipErrorInvalidValue;
   constexpr size_t kSelectLds = 156 * 1024;        // dynamic LDS the select kernel may use (160 KiB minus its static arrays)
   const size_t need = (size_t)N * 4 + 8 + (size_t)S * 8;
-  if (tune.topk_select && S >= 1 && S <= N && need <= kSelectLds) {
+  if (S < 1 || S > N) return hipErrorInvalidValue;
+  if (tune.topk_select && need <= kSelectLds) {
     {   // per device and cheap: no process-wide "already set" flag
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_topk), hipFuncAttributeMaxDynamicSharedMemorySize,
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_topk<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)kSelectLds);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_select_topk, dim3(B), dim3(1024), need, s, keys, out_idx, N, S, ptab);
+    hipLaunchKernelGGL(k_select_topk<true>, dim3(B), dim3(1024), need, s, keys, out_idx, N, S, ptab);
+    return hipGetLastError();
+  }
+  if (M > 16384 || (tune.topk_select && need > kSelectLds)) {
+    // [r4] any N: the keys stay in global memory, only the S winners live in the LDS (S <= 19 968, i.e. N < 200 000 at ratio 0.1)
+    if ((size_t)S * 8 > kSelectLds) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_topk<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kSelectLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_select_topk<false>, dim3(B), dim3(1024), (size_t)S * 8, s, keys, out_idx, N, S, ptab);
     return hipGetLastError();
   }
   {
@@ -1559,6 +1671,10 @@ hipError_t launch_sort_topk(const Tuning& tune, const float* keys, int* out_idx,
 hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* dist_in, int* knn_idx, int B, int N, int S,
                             int k, hipStream_t s, const PairTab* ptab) {
   const int ld = ((N + 31) / 32) * 32;             // row stride of dist_in (launch_seed_dist pads the rows to whole tiles)
+  if (dist_in && N > 256 * 64) {                   // [r4] rows of any length: streamed selection
+    hipLaunchKernelGGL(k_knn_select_stream, dim3(S, B), dim3(256), 0, s, dist_in, knn_idx, N, S, k, ptab, ld);
+    return hipGetLastError();
+  }
   if ((size_t)N * 4 > 150 * 1024) return hipErrorInvalidValue;
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_seeds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

@@ -57,8 +57,8 @@ def tiles(x, dim):      # pad dim to a multiple of 32 and view it as [.., n/32, 
 
 
 def make_attention(scheme):
-    lowp = {"fp8x": e4m3, "fp6x": e2m3, "fp8qk": e4m3, "fp8pv": e4m3, "fp8pv_c": e4m3, "fp6pv_c": e2m3}.get(scheme)
-    qk_low = scheme in ("fp8x", "fp6x", "fp8qk")
+    lowp = {"fp8x": e4m3, "fp6x": e2m3, "fp8qk": e4m3, "fp8pv": e4m3, "fp8pv_c": e4m3, "fp6pv_c": e2m3, "fp8x_c": e4m3}.get(scheme)
+    qk_low = scheme in ("fp8x", "fp6x", "fp8qk", "fp8x_c")
     pv_low = scheme in ("fp8x", "fp6x", "fp8pv")
 
     def sc_attention(feat, compat, Wq, bq, Wk, bk, Wv, bv):
@@ -89,7 +89,7 @@ def make_attention(scheme):
             vl8 = e2m3(vlt, 2).reshape(v.shape[0], -1, v.shape[2])[:, :v.shape[1]]
             o = ph @ vh + p8 @ vl8 + pl8 @ v8
             return o.float().double() / (ph + pl8).sum(-1, keepdim=True)
-        if scheme == "fp8pv_c":      # P planes as UNSCALED e4m3 of (256 p) and of 256 (p - ph); row sum over ph + pl8; V block-scaled
+        if scheme in ("fp8pv_c", "fp8x_c"):      # P planes as UNSCALED e4m3 of (256 p) and of 256 (p - ph); row sum over ph + pl8; V block-scaled
             fix = lambda x: (x * 256.0).float().to(torch.float8_e4m3fn).double() / 256.0
             p8, pl8 = fix(p), fix(pl)
             vt, _ = tiles(v, 1); vlt, _ = tiles(vl, 1)
@@ -112,11 +112,16 @@ def make_attention(scheme):
 
 
 def main():
-    kind = sys.argv[1] if len(sys.argv) > 1 else "3dmatch"
-    N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-    seeds = [int(a) for a in sys.argv[3:]] or [1000, 1001, 1002, 1003]
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    flags = [a for a in sys.argv[1:] if a.startswith("--")]
+    kind = args[0] if len(args) > 0 else "3dmatch"
+    N = int(args[1]) if len(args) > 1 else 1000
+    seeds = [int(a) for a in args[2:]] or [1000, 1001, 1002, 1003]
     sigma_d = 0.1 if kind == "3dmatch" else 1.2
     sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7)
+    if "--cond" in flags:          # the KITTI-conditioned weight set (synthetic.kitti_conditioned; golden F22)
+        sd = synthetic.kitti_conditioned(sd)
+    schemes = ("split3", "fp8pv_c", "fp8x_c", "fp6pv_c") if "--qk" in flags else ("split3", "fp8pv_c", "fp6pv_c")
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     exact = O.sc_attention
     print(f"{kind} N={N}: max |logit - fp64 logit| per scheme")
@@ -129,7 +134,7 @@ def main():
         ref32 = O.classifier(sd, O.encoder(sd, b["corr_pos"], compat32, b["p_tokens"], b["q_tokens"], 12))
         row = [f"seed {seed}: fp32 oracle {float((ref32.double() - truth).abs().max()):.2e}"]
         try:
-            for scheme in ("split3", "fp8pv_c", "fp6pv_c"):
+            for scheme in schemes:
                 O.sc_attention = make_attention(scheme)
                 # the compat term as the kernel sees it: the fp32 cache
                 got = O.classifier(sd64, O.encoder(sd64, b64["corr_pos"], compat32.double(), b64["p_tokens"], b64["q_tokens"], 12))

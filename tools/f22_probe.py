@@ -1,0 +1,60 @@
+"""Golden F22, stress weight set, N = 2000 (GPU box): where every selectable form of the HIP path lands against the fp64
+evaluation and against the reference's own fp32 logits - is 4.9e-4 (against the reference's 2.8e-4) a property of one form or of
+the conditioning?    python tools/f22_probe.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gmf_amd                                   # noqa: E402
+from gmf_amd import _lib, synthetic              # noqa: E402
+from oracle import gmf_oracle as O               # noqa: E402
+
+g = np.load(os.path.join(ROOT, "tests", "golden", "f22_kitti_branch.npz"))
+dev = torch.device("cuda:0")
+for wset in ("stress", "cond"):
+    for N, seed in g["cases"]:
+        N, seed = int(N), int(seed)
+        tag = f"{wset}_{N}_{seed}"
+        sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7, sigma_d=1.2)
+        if wset == "cond":
+            sd = synthetic.kitti_conditioned(sd)
+        m = gmf_amd.PointDSC(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1, inlier_threshold=1.2,
+                             sigma_d=1.2, k=40, nms_radius=1.2)
+        m.load_state_dict(sd, strict=False)
+        m = m.to(dev).eval()
+        b = synthetic.synthetic_batch([seed], N=N, T=196, kind="kitti")
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        b64 = {k: v.double() for k, v in b.items()}
+        c64, _ = O.compat_matrix(b64["src_keypts"], b64["tgt_keypts"], 1.2)
+        truth = O.classifier(sd64, O.encoder(sd64, b64["corr_pos"], c64, b64["p_tokens"], b64["q_tokens"], 12))[0]
+        with torch.no_grad():
+            orc = O.pointdsc_forward(sd, b, inlier_threshold=1.2, nms_radius=1.2, testing=True)["logits"][0]
+        ref = torch.from_numpy(g[f"logits_{tag}"])[0]
+        one = {k: b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+        one["testing"] = True
+        rag = {k: [one[k][0], one[k][0]] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+        rag.update(p_tokens=torch.cat([one["p_tokens"]] * 2), q_tokens=torch.cat([one["q_tokens"]] * 2), testing=True)
+        h = _lib.handle_for(0)
+        print(f"{tag}: reference vs fp64 {float((ref.double() - truth).abs().max()):.2e}, oracle vs fp64 {float((orc.double() - truth).abs().max()):.2e}, "
+              f"oracle vs reference {float((orc - ref).abs().max()):.2e}")
+
+        def show(name, lg):
+            lg = lg.cpu()
+            print(f"   {name:46s} vs fp64 {float((lg.double() - truth).abs().max()):.2e}  mean {float((lg.double() - truth).abs().mean()):.2e}   vs reference {float((lg - ref).abs().max()):.2e}")
+        for knob, vals in (("pv_fp8", (1, 0)), ("scattn_variant", (0, 9)), ("attn_key_splits", (1,)), ("small_grid_roles", (0,)), ("fused_linear", (0,))):
+            for v in vals:
+                try:
+                    h.call("gmf_set_tuning", knob.encode(), v)
+                    m(one)
+                    show(f"B = 1, {knob} = {v}", m.last_logits[0])
+                    if knob == "pv_fp8":
+                        show(f"ragged (large grid), {knob} = {v}", m(rag)["logits"][0])
+                except RuntimeError as e:
+                    print("   ", knob, v, "refused:", str(e)[:90])
+                finally:
+                    dflt = {"pv_fp8": 1, "scattn_variant": 18, "attn_key_splits": 0, "small_grid_roles": 1, "fused_linear": 1}[knob]
+                    h.call("gmf_set_tuning", knob.encode(), dflt)

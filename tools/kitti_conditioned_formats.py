@@ -1,0 +1,49 @@
+"""the opt-in forms re-measured on BOTH KITTI-shape weight sets - "stress" (the seeded weights, scaled for
+3DMatch-size coordinates: the reference's own fp32 is 3e-4 from the exact network) and "cond" (synthetic.kitti_conditioned:
+layer0.weight / 13, fp32 floor 1.7e-5; golden F22 pins this branch).  Per pair (N = 700 ... 3000, one ragged launch = the
+large-grid kernels): max |logit - fp64 logit| of the HIP path under compat_format 0 / 2 and pv_fp8 1 / 0, next to the fp32
+oracle's own distance from fp64, and HIP against the fp32 oracle.   GPU box:  python tools/kitti_conditioned_formats.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gmf_amd                                   # noqa: E402
+from gmf_amd import _lib, synthetic              # noqa: E402
+from oracle import gmf_oracle as O               # noqa: E402
+
+torch.set_num_threads(16)
+dev = torch.device("cuda:0")
+sizes, seeds = [700, 1500, 2000, 3000], [83, 85, 84, 86]
+pairs = [synthetic.synthetic_batch([s], N=n, T=196, kind="kitti") for s, n in zip(seeds, sizes)]
+rag = {k: [b[k][0].to(dev) for b in pairs] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+rag.update(p_tokens=torch.cat([b["p_tokens"] for b in pairs]).to(dev), q_tokens=torch.cat([b["q_tokens"] for b in pairs]).to(dev), testing=True)
+h = _lib.handle_for(0)
+base = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7, sigma_d=1.2)
+for wset, sd in (("stress", base), ("cond", synthetic.kitti_conditioned(base))):
+    m = gmf_amd.PointDSC(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1, inlier_threshold=1.2, sigma_d=1.2,
+                         k=40, nms_radius=1.2)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(dev).eval()
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    refs, truths = [], []
+    for b in pairs:
+        with torch.no_grad():
+            refs.append(O.pointdsc_forward(sd, b, inlier_threshold=1.2, nms_radius=1.2, testing=True)["logits"][0])
+            b64 = {k: v.double() for k, v in b.items()}
+            c64, _ = O.compat_matrix(b64["src_keypts"], b64["tgt_keypts"], 1.2)
+            truths.append(O.classifier(sd64, O.encoder(sd64, b64["corr_pos"], c64, b64["p_tokens"], b64["q_tokens"], 12))[0])
+    print(f"== weight set {wset}: fp32 oracle vs fp64 per pair: " + "  ".join(f"N={n}: {float((r.double() - t).abs().max()):.2e}" for n, r, t in zip(sizes, refs, truths)), flush=True)
+    try:
+        for fmt, pv in ((0, 1), (0, 0), (2, 1), (2, 0)):
+            h.call("gmf_set_tuning", b"compat_format", fmt)
+            h.call("gmf_set_tuning", b"pv_fp8", pv)
+            got = [lg.cpu() for lg in m(rag)["logits"]]
+            row = []
+            for n, g, r, t in zip(sizes, got, refs, truths):
+                row.append(f"N={n}: vs fp64 {float((g.double() - t).abs().max()):.2e} / vs oracle {float((g - r).abs().max()):.2e}")
+            print(f"   compat_format {fmt}, pv_fp8 {pv}:  " + "   ".join(row), flush=True)
+    finally:
+        h.call("gmf_set_tuning", b"compat_format", 0)
+        h.call("gmf_set_tuning", b"pv_fp8", 1)

@@ -76,6 +76,18 @@ PATCHES = {
         (EK, "        if (u == 20) split2h(x[14], x[15], ph1, pl1, 6);", "        if (u == 20) { ph1[6] = (_Float16)1.0f; ph1[7] = (_Float16)0.5f; pl1[6] = (_Float16)0.001f; pl1[7] = (_Float16)0.002f; asm volatile(\"\" :: \"v\"(x[14]), \"v\"(x[15])); }"),
         (EK, "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n        } else {", "          pb[u] = 0x38383838; ls += 1.0f;\n        } else {"),
     ],
+    # ---- the SKELETON of the pv_fp8 tile loop - its matrix stream (24 + 8 f16 MFMAs and 4 block-scaled fp8 MFMAs per
+    #      tile and wave), its LDS fragment reads, its LDS-DMA tile ring and its compat stream (four non-temporal 16-byte loads per lane
+    #      and tile, consumed one tile later) with NO softmax: no compat product, no row maximum, no exponentials, no splits, no plane
+    #      conversions, no row sums, no rescale.  The probabilities' operands are the scores' own bits (8 v_cvt_pk_f16_f32 per tile keep the
+    #      data changing: an MFMA stream on constant operands runs at a higher clock and proves nothing).  What pipe-GHz does the chip
+    #      sustain with everything the kernel streams but none of its vector work?  p8_skel keeps the tile barrier, p8_skel_nobar drops it
+    #      (racy), p8_skel_nostream also drops the compat loads and the ring refills (the bare matrix + LDS-read stream of this kernel).
+    "p8_skel": "SKEL",
+    "p8_skel_nobar": "SKEL+NOBAR",
+    "p8_skel_nostream": "SKEL+NOBAR+NOSTREAM",
+    "p8_skel_noc": "SKEL+NOBAR+NOC",              # ... no compat loads, ring refills kept
+    "p8_skel_norefill": "SKEL+NOBAR+NOREFILL",    # ... no ring refills (stale K / V tiles), compat loads kept
     "p8_no_consist": [     # timing only: the row sum without the decoded low plane (what the consistent sum costs: nothing measurable)
         (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<true>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),
         (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<false>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),
@@ -109,6 +121,61 @@ PATCHES = {
          "      for (int r = 0; r < 16; ++r) { x[r] = x[r] - m_off; ls += x[r]; }\n      l_half = fmaf(l_half, alpha, ls);\n      if (__any(moved)) {\n#pragma unroll\n        for (int db = 0; db < 2; ++db)"),
     ],
 }
+
+_SKEL = [
+    (EK, """        if (u < 4) {
+#pragma unroll
+          for (int r = 4 * u; r < 4 * u + 4; r += 2) {
+            x[r] = score(r, s_cur[r]);
+            x[r + 1] = score(r + 1, s_cur[r + 1]);
+            mx = __builtin_fmaxf(mx, __builtin_fmaxf(x[r], x[r + 1]));
+          }
+        }
+""", """        if (u == 0) asm volatile("" :: "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]), "v"(c[10]), "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]));
+"""),
+    (EK, """          mx = xhalf_max_swap(mx);
+          if (CFMT == 2) mx *= kInvU16;
+          // LAZY reference""", """          if (false) {
+          // LAZY reference"""),
+    (EK, """          m_off = m_new - (10.0f - kLazy);
+          rescale(moved, alpha);
+        }
+        if (u >= 4 && u < 20) x[u - 4] = expo(x[u - 4], m_off);""", """          }
+        }"""),
+    (EK, """          const bool moved = mx > m_run + kLazy;
+          const float m_new = moved ? mx : m_run;
+          alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          m_run = m_new;
+""", ""),
+    (EK, """          if (k < 4) split2h(x[2 * k], x[2 * k + 1], ph0, pl0, 2 * k);
+          else split2h(x[2 * k], x[2 * k + 1], ph1, pl1, 2 * k - 8);""",
+     """          { const f32x2 xx_ = {s_cur[2 * k], s_cur[2 * k + 1]}; const f16x2 hh_ = __builtin_convertvector(xx_, f16x2);
+            if (k < 4) { ph0[2 * k] = hh_[0]; ph0[2 * k + 1] = hh_[1]; pl0[2 * k] = hh_[1]; pl0[2 * k + 1] = hh_[0]; }
+            else { ph1[2 * k - 8] = hh_[0]; ph1[2 * k - 7] = hh_[1]; pl1[2 * k - 8] = hh_[1]; pl1[2 * k - 7] = hh_[0]; } }"""),
+    (EK, "        if (u == 20) split2h(x[14], x[15], ph1, pl1, 6);",
+     "        if (u == 20) { const f32x2 xx_ = {s_cur[14], s_cur[15]}; const f16x2 hh_ = __builtin_convertvector(xx_, f16x2); ph1[6] = hh_[0]; ph1[7] = hh_[1]; pl1[6] = hh_[1]; pl1[7] = hh_[0]; }"),
+    (EK, "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n        } else {",
+     "          pb[u] = __builtin_bit_cast(i32x4, u < 4 ? ph0 : pl1)[u & 3] & 0x3f3f3f3f; ls += 1.0f;\n        } else {"),
+]
+_NOBAR = [
+    (EK, "    float mx = -INFINITY, m_off = 0.f, alpha = 1.f, ls = 0.f, ls_l = 0.f;\n    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    __syncthreads();\n    vsw = vsw_next;",
+     "    float mx = -INFINITY, m_off = 0.f, alpha = 1.f, ls = 0.f, ls_l = 0.f;\n    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    vsw = vsw_next;"),
+]
+_NOC = [
+    (EK, "const f32x4 v = __builtin_nontemporal_load(ct + q * 64);", "const f32x4 v = {1.f, 1.f, 1.f, 1.f}; (void)ct;"),
+    (EK, "    if (PVF8) vsw_next = __builtin_nontemporal_load(vsrow + (size_t)t * 64);", "    if (PVF8) vsw_next = 0x7f7f7f7fu;"),
+]
+_NOREFILL = [
+    (EK, "        if (u == 12) issue_k4(t);\n        if (u == 20) issue_v4(t);\n", ""),
+]
+_NOSTREAM = [
+    (EK, "const f32x4 v = __builtin_nontemporal_load(ct + q * 64);", "const f32x4 v = {1.f, 1.f, 1.f, 1.f}; (void)ct;"),
+    (EK, "        if (u == 12) issue_k4(t);\n        if (u == 20) issue_v4(t);\n", ""),
+    (EK, "    if (PVF8) vsw_next = __builtin_nontemporal_load(vsrow + (size_t)t * 64);", "    if (PVF8) vsw_next = 0x7f7f7f7fu;"),
+]
+for _k, _v in list(PATCHES.items()):
+    if isinstance(_v, str):
+        PATCHES[_k] = sum(({"SKEL": _SKEL, "NOBAR": _NOBAR, "NOSTREAM": _NOSTREAM, "NOC": _NOC, "NOREFILL": _NOREFILL}[t] for t in _v.split("+")), [])
 OBJ_OF = {EK: ["encoder_kernels"], EH: ["encoder_h2"], FF: ["encoder_kernels", "encoder_h2"], MC: ["encoder_kernels", "encoder_h2"]}
 
 

@@ -719,7 +719,7 @@ int gmf_pick_seeds(gmf_handle* h, const float* src_keypts, const float* scores, 
                    int use_nms, int num_seeds, int* seeds_out, gmf_stream_t stream) {
   GMF_REQUIRE(h && src_keypts && scores && seeds_out, GMF_ERR_BAD_ARG, "pick_seeds: null pointer");
   GMF_REQUIRE(B > 0 && N > 0 && num_seeds > 0 && num_seeds <= N, GMF_ERR_UNSUPPORTED_SHAPE, "pick_seeds: need 0 < num_seeds <= N");
-  GMF_REQUIRE(N <= 16384, GMF_ERR_UNSUPPORTED_SHAPE, "pick_seeds: N > 16384 is not supported by the in-LDS sort");
+  GMF_REQUIRE((size_t)num_seeds * 8 <= 156 * 1024, GMF_ERR_UNSUPPORTED_SHAPE, "pick_seeds: more than 19968 seeds (the winners' list lives in the LDS)");
   SetDevice sd(h, stream);
   hipStream_t st = S(stream);
   const float* keys = scores;
@@ -786,8 +786,9 @@ static int pose_head_impl(gmf_handle* h, const gmf_pose_params* p, const float* 
   GMF_REQUIRE(Sn > 0 && Sn <= N, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: need 0 < num_seeds <= N");
   GMF_REQUIRE(k > 0 && k <= 64 && k <= N - 1, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: need 0 < k <= min(64, N-1)");
   GMF_REQUIRE(iters > 0 && iters <= 64, GMF_ERR_BAD_ARG, "pose_head: bad num_iterations");
-  GMF_REQUIRE(N <= 16384 || seeds_in, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: N > 16384 needs caller-provided seeds");
-  GMF_REQUIRE((size_t)N * 4 <= 150 * 1024, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: N too large for the in-LDS kNN (max 38400)");
+  // [r4] no limit on N (the reference has none: PointDSC.py:268-286, common.py:53-75; evaluation/test_3DMatch.py:143 feeds num_node = 'all'):
+  // above 16 384 rows the seed selection reads its keys from global memory and the kNN selection streams the distance rows
+  GMF_REQUIRE(seeds_in || (size_t)Sn * 8 <= 156 * 1024, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: more than 19968 seeds per pair (the winners' list lives in the LDS)");
   GMF_REQUIRE(p->sigma > 0.f && p->sigma_d > 0.f, GMF_ERR_BAD_ARG, "pose_head: sigma, sigma_d must be positive");
   hipStream_t st = S(stream);
   const size_t BS = (size_t)B * Sn;

@@ -2273,10 +2273,13 @@ def test_loss_modules_gradients_and_forward_only_rest():
         gmf_amd.ClassificationLoss()(torch.zeros(1, 8), torch.zeros(1, 8))
 
 
-@pytest.mark.parametrize("B,N,S", [(3, 5000, 500), (2, 37, 3), (1, 16384, 1638), (2, 1000, 1000), (4, 2049, 1)])
+@pytest.mark.parametrize("B,N,S", [(3, 5000, 500), (2, 37, 3), (1, 16384, 1638), (2, 1000, 1000), (4, 2049, 1),
+                                   (1, 16385, 1638), (2, 20000, 2000), (1, 40000, 4000), (2, 70001, 700), (1, 33000, 19000)])
 def test_topk_select_equals_full_sort(B, N, S):
     """The radix-select form of argsort(descending)[:S] against the full bitonic sort and against a stable host sort:
-    many exact ties (zeros of both signs, repeated values), negative keys, S = 1 and S = N."""
+    many exact ties (zeros of both signs, repeated values), negative keys, S = 1 and S = N.  [r4] N > 16 384 (the reference has
+    no limit: PointDSC.py:268-286): the keys stay in global memory (k_select_topk<false>; above 65 535 rows the counters of
+    the ordered compaction need more than 16 bits), both knob settings then run that form."""
     from gmf_amd import _lib
     h = _lib.handle_for(0)
     st = torch.cuda.current_stream().cuda_stream
@@ -2299,6 +2302,67 @@ def test_topk_select_equals_full_sort(B, N, S):
     want = torch.sort(keys.double() + 0.0, dim=1, descending=True, stable=True)[1][:, :S]
     assert torch.equal(outs[0].long(), want)
     assert torch.equal(outs[1].long(), want)
+
+
+def _nms_keys_chunked(src, scores, R, chunk=1000):
+    """PointDSC.pick_seeds' keys (PointDSC.py:276-285) without the [N, N] matrices: score_i * [all_j (score_i >= score_j or
+    ||src_i - src_j|| >= R)], the same element-wise arithmetic as the oracle's pick_seeds, row blocks at a time."""
+    N = src.shape[1]
+    keys = torch.empty(N)
+    for i0 in range(0, N, chunk):
+        d = torch.norm(src[0, i0:i0 + chunk, None, :] - src[0, None, :, :], dim=-1)
+        ge = scores[0, i0:i0 + chunk, None] >= scores[0, None, :]
+        keys[i0:i0 + chunk] = scores[0, i0:i0 + chunk] * (ge | (d >= R)).all(dim=-1).float()
+    return keys
+
+
+@pytest.mark.parametrize("N", [3000, 20000, 40000])
+def test_pose_head_beyond_16384(model, N):
+    """[r4] The test-mode pose head has no limit on N any more (the reference has none, PointDSC.py:268-286 / common.py:53-75, and its
+    3DMatch evaluation feeds every correspondence: evaluation/test_3DMatch.py:143): N = 20 000 and 40 000 (seed selection with the
+    keys in global memory, streamed kNN selection) against the oracle's functions, F5-style - seeds (the oracle's keys, stable
+    order), the k neighbours of every seed row, the per-seed hypotheses from those neighbours, their fitness, the chosen pose and
+    the refinement.  N = 3000 runs the same comparison on the in-LDS path and checks the chunked key helper against the oracle's
+    own pick_seeds."""
+    torch.set_num_threads(16)
+    b = synthetic.synthetic_batch([900 + N % 97], N=N, T=12)
+    r = np.random.default_rng([205, N])
+    feat = torch.from_numpy(r.normal(0, 1, (1, N, 128)).astype(np.float32))
+    inl = b["gt_labels"][0] > 0
+    feat[0, inl] += 2.5 * torch.from_numpy(r.normal(0, 1, (1, 128)).astype(np.float32))
+    feat_n = torch.nn.functional.normalize(feat, p=2, dim=-1)
+    scores = torch.from_numpy(r.normal(0, 1, (1, N)).astype(np.float32)) + 2.0 * b["gt_labels"]
+    src, tgt = b["src_keypts"], b["tgt_keypts"]
+    S, k = N // 10, 40
+    fT, labels, aux = model.pose_head(_gpu(feat_n), _gpu(src), _gpu(tgt), _gpu(scores), testing=True, return_aux=True)
+    # seeds: the reference's keys, ordered (key descending, index ascending)
+    keys = _nms_keys_chunked(src, scores, 0.10)
+    if N <= 3000:
+        sdist = torch.norm(src[:, :, None, :] - src[:, None, :, :], dim=-1)
+        ref_seeds = O.pick_seeds(sdist, scores, 0.10, S)
+        n_pos = int((keys > 0).sum())
+        assert torch.equal(ref_seeds[0, :min(S, n_pos)], torch.sort(keys, descending=True, stable=True)[1][:min(S, n_pos)])
+    want = torch.sort(keys.double() + 0.0, descending=True, stable=True)[1][:S]
+    seeds = aux["seeds"][0].cpu().long()
+    assert torch.equal(seeds, want)
+    # the k neighbours of every seed row under 2 - 2 <f_s, f_j> (common.py:70-74; rank 0 dropped)
+    d = 2 - 2 * (feat_n[0, seeds] @ feat_n[0].T)
+    ref_knn = d.topk(k + 1, dim=-1, largest=False)[1][:, 1:]
+    got_knn = aux["knn_idx"][0].cpu().long()
+    same = (torch.sort(got_knn, -1)[0] == torch.sort(ref_knn, -1)[0]).float().mean()
+    assert float(same) > 0.999, float(same)             # (two fp32 evaluations of d order near-ties differently)
+    assert int(got_knn.min()) >= 0 and int(got_knn.max()) < N
+    # per-seed hypotheses from the HIP path's own neighbour lists, fitness, best hypothesis, refinement
+    sigma, sigma_d = float(model.sigma.detach()), float(model.sigma_spat)
+    w, sk, tk = O.seed_weights(feat_n, src, tgt, got_knn[None], sigma, sigma_d, model.num_iterations)
+    Ts = O.rigid_transform_3d(sk, tk, w).reshape(1, -1, 4, 4)
+    assert _maxerr(aux["seed_trans"].cpu(), Ts) < 1e-3
+    fit, best_T, lab = O.score_hypotheses(Ts, src, tgt, 0.10)
+    assert _maxerr(aux["fitness"].cpu(), fit) < 2e-4     # (a hypothesis 1e-4 away moves a few of N points across the threshold)
+    ref_T = O.post_refinement(best_T, src, tgt, 0.10)
+    assert _maxerr(fT.cpu(), ref_T) < 1e-4
+    assert _maxerr(fT.cpu(), b["gt_trans"]) < 5e-3
+    assert float((labels.cpu() == lab).float().mean()) > 0.999
 
 
 @pytest.mark.parametrize("case", ["3dmatch", "kitti", "clustered", "wrapped", "far", "tiny_radius"])

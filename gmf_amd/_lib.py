@@ -100,6 +100,7 @@ SIGNATURES = {
     "gmf_workspace_wanted": (_ll, [_vp]),
     "gmf_status_read": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
     "gmf_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "gmf_get_tuning": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int)]),
     "gmf_profile_enable": (C.c_int, [_vp, C.c_int]),
     "gmf_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "gmf_pack_rows_p32": (C.c_int, [_vp, _vp, _ll, _ll, _ll, C.c_int, C.c_int, C.c_int, _vp, _vp]),
@@ -187,7 +188,7 @@ def load_library() -> C.CDLL:
             fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.gmf_abi_version() != 3:
+        if lib.gmf_abi_version() != 4:
             raise RuntimeError("gmf_amd: libgmf_hip.so ABI version mismatch")
         _lib = lib
         return lib

@@ -28,9 +28,13 @@ struct gmf_handle {
   hipStream_t last_stream = nullptr;
   bool have_last_stream = false;
   hipEvent_t xs_event = nullptr;
-  // host copies of the per-pair tables of ragged calls (two, alternating: an asynchronous upload may still be reading one)
-  std::vector<gmf::PairTab> ptab_host[2];
-  int ptab_flip = 0;
+  // host copies of the per-pair tables of ragged calls: a ring of PINNED slots, each guarded by an event recorded behind its
+  // upload - a slot is only rewritten once the copy that read it has run (a pageable std::vector handed to
+  // hipMemcpyAsync is only safe if the runtime happens to stage it synchronously)
+  struct PtabSlot { gmf::PairTab* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+  static constexpr int kPtabSlots = 8;
+  PtabSlot ptab_ring[kPtabSlots];
+  int ptab_next = 0, ptab_cur = 0;
   // sticky status word in host-mapped memory (gmf_status_read): kernels OR bits into it through status_dev
   int* status_host = nullptr;
   int* status_dev = nullptr;

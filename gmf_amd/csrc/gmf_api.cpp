@@ -78,6 +78,7 @@ int gmf_status_read(gmf_handle* h, int* flags, int clear) {
 
 int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
   GMF_REQUIRE(h && name, GMF_ERR_BAD_ARG, "set_tuning: null pointer");
+  std::lock_guard<std::mutex> lock(h->mu);        // (forwards read h->tune under the same lock)
   gmf::Tuning& t = h->tune;
   if (std::strcmp(name, "scattn_variant") == 0) {
     GMF_REQUIRE(value == 0 || value == 9 || value == 18, GMF_ERR_BAD_ARG,
@@ -169,6 +170,24 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
   return fail(h, GMF_ERR_BAD_ARG, std::string("gmf: set_tuning: unknown knob ") + name);
 }
 
+// The current value of a knob (the counterpart of gmf_set_tuning: a caller that changes a knob for one call can put back what it found).
+int gmf_get_tuning(gmf_handle* h, const char* name, int* value) {
+  GMF_REQUIRE(h && name && value, GMF_ERR_BAD_ARG, "get_tuning: null pointer");
+  std::lock_guard<std::mutex> lock(h->mu);
+  const gmf::Tuning& t = h->tune;
+  const struct { const char* name; int v; } tab[] = {
+      {"scattn_variant", t.scattn_variant}, {"front_output_split", t.front_split ? 1 : 0}, {"ff_hidden_splits", t.ff_split},
+      {"attn_key_splits", t.key_splits}, {"attn_tail_split", t.tail_split ? 1 : 0}, {"small_grid_roles", t.small_roles ? 1 : 0},
+      {"fused_linear", t.fused_linear ? 1 : 0}, {"compat_cache", t.use_cache ? 1 : 0}, {"conv_lds_patch", t.conv_patch},
+      {"nms_binned", t.nms_binned}, {"topk_select", t.topk_select ? 1 : 0}, {"wide_attn_tile", t.wide_attn_tile ? 1 : 0},
+      {"small_merge_tile", t.small_merge_tile ? 1 : 0}, {"mid_grid_roles", t.mid_grid_roles}, {"pv_fp8", t.pv_fp8 ? 1 : 0},
+      {"compat_format", t.compat_format}, {"precision", t.precision}};
+  for (const auto& e : tab) {
+    if (std::strcmp(name, e.name) == 0) { *value = e.v; return GMF_OK; }
+  }
+  return fail(h, GMF_ERR_BAD_ARG, std::string("gmf: get_tuning: unknown knob ") + name);
+}
+
 int gmf_profile_enable(gmf_handle* h, int on) {
   GMF_REQUIRE(h, GMF_ERR_BAD_ARG, "profile_enable: null handle");
   h->profile = (on != 0);
@@ -200,6 +219,10 @@ void gmf_destroy(gmf_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->arena && !h->arena_external) (void)hipFree(h->arena);
   if (h->xs_event) (void)hipEventDestroy(h->xs_event);
+  for (auto& sl : h->ptab_ring) {
+    if (sl.ev) (void)hipEventDestroy(sl.ev);
+    if (sl.host) (void)hipHostFree(sl.host);
+  }
   if (h->status_host) (void)hipHostFree(h->status_host);
   if (prev >= 0 && prev != h->device) (void)hipSetDevice(prev);
   delete h;
@@ -380,17 +403,33 @@ static int run_scattn(gmf_handle* h, const gmf_encoder_weights* w, int l, const 
   return GMF_OK;
 }
 
-// Host table of a ragged batch -> h->ptab_host (kept alive in the handle: the upload is asynchronous) ; returns max n, sum n.
-// ratio < 0: the encoder's table (S, k unused).
+// Host table of a ragged batch -> the next slot of the handle's pinned ring; returns max n, sum n.
+// ratio < 0: the encoder's table (S, k unused).  The caller uploads it with upload_pair_table().
 static int build_pair_table(gmf_handle* h, const int* n_points, int B, double ratio, int k, int* n_max, long long* n_sum, int* s_max) {
-  h->ptab_flip ^= 1;
-  std::vector<gmf::PairTab>& tab = h->ptab_host[h->ptab_flip];
-  tab.resize((size_t)B);
+  for (int b = 0; b < B; ++b) {
+    GMF_REQUIRE(n_points[b] > 0, GMF_ERR_UNSUPPORTED_SHAPE, "ragged batch: every pair needs at least one correspondence");
+  }
+  h->ptab_cur = h->ptab_next;
+  h->ptab_next = (h->ptab_next + 1) % gmf_handle::kPtabSlots;
+  gmf_handle::PtabSlot& slot = h->ptab_ring[h->ptab_cur];
+  if (slot.pending) {                         // (eight uploads ago: long done unless the host runs far ahead of the device)
+    GMF_HIP(hipEventSynchronize(slot.ev));
+    slot.pending = false;
+  }
+  if (slot.cap < (size_t)B) {
+    if (slot.host) GMF_HIP(hipHostFree(slot.host));
+    slot.host = nullptr;
+    slot.cap = 0;
+    const size_t cap = ((size_t)B + 63) / 64 * 64;
+    GMF_HIP(hipHostMalloc(reinterpret_cast<void**>(&slot.host), cap * sizeof(gmf::PairTab), hipHostMallocDefault));
+    slot.cap = cap;
+  }
+  if (!slot.ev) GMF_HIP(hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
+  gmf::PairTab* tab = slot.host;
   long long row = 0;
   int nm = 0, sm = 0;
   for (int b = 0; b < B; ++b) {
     const int n = n_points[b];
-    GMF_REQUIRE(n > 0, GMF_ERR_UNSUPPORTED_SHAPE, "ragged batch: every pair needs at least one correspondence");
     GMF_REQUIRE(row + n <= 0x7fffffffLL, GMF_ERR_UNSUPPORTED_SHAPE, "ragged batch: more than 2^31 rows");
     const int Sb = ratio >= 0.0 ? (int)((double)n * ratio) : 0;     // S = int(N * ratio)   PointDSC.py:244
     tab[b] = gmf::PairTab{(int)row, n, Sb, k};
@@ -401,6 +440,15 @@ static int build_pair_table(gmf_handle* h, const int* n_points, int B, double ra
   *n_max = nm;
   *n_sum = row;
   if (s_max) *s_max = sm;
+  return GMF_OK;
+}
+
+// the current slot -> device, asynchronously on the call's stream; the slot's event marks the copy
+static int upload_pair_table(gmf_handle* h, gmf::PairTab* dtab, int B, hipStream_t st) {
+  gmf_handle::PtabSlot& slot = h->ptab_ring[h->ptab_cur];
+  GMF_HIP(hipMemcpyAsync(dtab, slot.host, (size_t)B * sizeof(gmf::PairTab), hipMemcpyHostToDevice, st));
+  GMF_HIP(hipEventRecord(slot.ev, st));
+  slot.pending = true;
   return GMF_OK;
 }
 
@@ -450,6 +498,11 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
   const size_t c_tile_floats = (h->tune.scattn_variant == 18 && h->tune.compat_format != 0) ? 512 : 1024;
   const bool want_cache = h2 && (L > 1) && h->tune.use_cache && n_tt * c_tile_floats * 4 <= ((size_t)96 << 30);
   const size_t cache_need = want_cache ? arena_need(n_tt * c_tile_floats, 4) : 0;
+  // Two launches per layer (the default path): see below.  Checked BEFORE the workspace is reserved and anything is launched
+  const bool fuse = h2 && L > 0 && want_cache && h->tune.fused_linear && h->tune.scattn_variant == 18;
+  GMF_REQUIRE(fuse || !ragged, GMF_ERR_UNSUPPORTED_SHAPE,
+              "encoder_forward_ragged: ragged batches run on the default path only (split-fp16 weight images, at least two layers, the "
+              "compat cache, \"fused_linear\" = 1, \"scattn_variant\" = 18)");
   // key-split attention for small grids (fewer than 256 workgroups of 128 queries): partial-result workspace
   // (small grids: up to 8 splits of every query block; large grids: the last partial round of workgroups is split in 2..4)
   const int kMaxSplits = ((tiles + 3) / 4) * B < 384 ? 8 : 4;
@@ -463,7 +516,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
   const gmf::PairTab* ptab = nullptr;
   if (ragged) {
     gmf::PairTab* dtab = arena_take<gmf::PairTab>(h, (size_t)B);
-    GMF_HIP(hipMemcpyAsync(dtab, h->ptab_host[h->ptab_flip].data(), (size_t)B * sizeof(gmf::PairTab), hipMemcpyHostToDevice, st));
+    if (int rc = upload_pair_table(h, dtab, B, st)) return rc;
     ptab = dtab;
   }
   float* featA = arena_take<float>(h, act);
@@ -535,10 +588,6 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
   // runs in the PREVIOUS layer's attention epilogue (layer 0: a small f-only kernel), so a layer is
   //   k_linear_h2 : f -> Q', K, V (split-fp16 images) and x2 = Fusion-2(f)        (small grids: the three split-capable kernels)
   //   k_scattn_h2p: Q', K, V, c, x2 -> f_{l+1} = ReLU(PointCN_{l+1}(fc_message(attention) + x2))   (last layer: the features)
-  const bool fuse = h2 && L > 0 && want_cache && h->tune.fused_linear && h->tune.scattn_variant == 18;
-  GMF_REQUIRE(fuse || !ragged, GMF_ERR_UNSUPPORTED_SHAPE,
-              "encoder_forward_ragged: ragged batches run on the default path only (split-fp16 weight images, at least two layers, the "
-              "compat cache, \"fused_linear\" = 1, \"scattn_variant\" = 18)");
   if (fuse) {
     const int Wg = ((tiles + 3) / 4) * B;
     const bool one_kernel = Wg >= 256 || ragged;      // below: key / hidden / output splits fill the chip better (uniform batches)
@@ -814,7 +863,7 @@ static int pose_head_impl(gmf_handle* h, const gmf_pose_params* p, const float* 
   const gmf::PairTab* ptab = nullptr;
   if (ragged) {
     gmf::PairTab* dtab = arena_take<gmf::PairTab>(h, (size_t)B);
-    GMF_HIP(hipMemcpyAsync(dtab, h->ptab_host[h->ptab_flip].data(), (size_t)B * sizeof(gmf::PairTab), hipMemcpyHostToDevice, st));
+    if (int rc = upload_pair_table(h, dtab, B, st)) return rc;
     ptab = dtab;
     // per-seed outputs are [B, S_max, ...] slots: the slots behind a pair's own seeds are defined (zero), not left-over memory
     if (seeds_out) GMF_HIP(hipMemsetAsync(seeds_out, 0, BS * sizeof(int), st));

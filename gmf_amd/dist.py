@@ -107,15 +107,20 @@ class ShardedBatchDriver:
 
     @staticmethod
     def _rows_and_width(data) -> Tuple[int, int]:
-        """(pairs, correspondences per pair) of a batch dict, from its first [B, N, ...] tensor."""
-        t = next(v for v in data.values() if torch.is_tensor(v) and v.dim() >= 2)
+        """(pairs, correspondences per pair) of a batch dict: from `corr_pos` [B, N, 6] (the key every PointDSC batch carries,
+        PointDSC.py:199), else from its first [B, N, ...] tensor."""
+        t = data["corr_pos"] if torch.is_tensor(data.get("corr_pos")) else \
+            next(v for v in data.values() if torch.is_tensor(v) and v.dim() >= 2)
         return int(t.shape[0]), int(t.shape[1])
 
     def step(self, data, sizes: Optional[List[int]] = None) -> Dict[str, torch.Tensor]:
         """One sharded step.  A failure on ONE rank must not leave the others blocked in the collective: with a process
-        group, a rank whose forward raises, or whose data disagrees with the shard plan, still enters the all-gather - with
-        an all-padding buffer and its status column set - and EVERY rank raises after it.  A rank whose shard is empty
-        (B < world: shard_sizes gives [1, 1, 1, 0]) skips the model and contributes padding only."""
+        group, a rank whose forward raises, whose data disagrees with the shard plan, or whose results do not pack, still
+        enters the all-gather - with an all-padding buffer and its status column set - and EVERY rank raises after it.  The
+        buffer's shape [max(sizes), N + 17] comes only from values every rank computes identically (`sizes` and N), never
+        from the local batch.  A rank whose shard is empty (B < world: shard_sizes gives [1, 1, 1, 0]) skips the model and
+        contributes padding only.  The one error raised BEFORE the collective is a `sizes` list of the wrong length: that is
+        the caller's plan itself, identical on every rank, so every rank raises it."""
         self._mark(0)
         coll = self._collective()
         b, n = self._rows_and_width(data)
@@ -124,35 +129,42 @@ class ShardedBatchDriver:
         if coll:
             if sizes is None:
                 sizes = [b] * self.world
-            if len(sizes) != self.world or sizes[self.rank] != b:
+            if len(sizes) != self.world:
+                raise RuntimeError(f"gmf_amd.dist: `sizes` has {len(sizes)} entries for {self.world} ranks (shard_sizes(B, world))")
+            if sizes[self.rank] != b:
                 err = RuntimeError(f"gmf_amd.dist: rank {self.rank} holds {b} pairs but the shard plan says {sizes}: every "
                                    "rank must pass the same `sizes` (shard_sizes(B, world)), or equal shards without it")
-        if err is None and b > 0:
-            try:
+        bmax = max(max(sizes), 1) if coll else max(b, 1)
+        logits = trans = labels = buf = None
+        try:
+            if err is None and b > 0:
                 res = self.model(data)
-            except Exception as e:               # noqa: BLE001 - re-raised below, on every rank, after the collective
-                if not coll:
-                    raise
-                err = e
-        if res is not None:
-            logits = res["logits"] if "logits" in res else self.model.last_logits
-            trans = res["final_trans"]
-            labels = res.get("final_labels")
-        else:                                    # empty shard, or a failed rank: padding only
+            if res is not None:
+                logits = res["logits"] if "logits" in res else self.model.last_logits
+                trans = res["final_trans"]
+                labels = res.get("final_labels")
+                if coll and (tuple(logits.shape) != (b, n) or tuple(trans.shape) != (b, 4, 4)):
+                    raise RuntimeError(f"gmf_amd.dist: the model returned logits {tuple(logits.shape)} / poses {tuple(trans.shape)} "
+                                       f"for a shard of {b} pairs x {n} correspondences")
+            if coll:
+                # one packed buffer per rank: [bmax, N + 17] = logits | pose | status, rows >= b are padding
+                buf = torch.zeros((bmax, n + 17), device=self.device, dtype=torch.float32)
+                if res is not None:
+                    buf[:b, :n] = logits
+                    buf[:b, n:n + 16] = trans.reshape(b, 16)
+        except Exception as e:                   # noqa: BLE001 - re-raised below, on every rank, after the collective
+            if not coll:
+                raise
+            err, res = e, None
+        if res is None:                          # empty shard, or a failed rank: padding only
             logits = torch.zeros((0, n), device=self.device)
             trans = torch.zeros((0, 4, 4), device=self.device)
             labels = None
         out = {"logits": logits, "final_trans": trans, "final_labels": labels}
         self._mark(1)
         if coll:
-            bl = logits.shape[0]
-            bmax = max(max(sizes), 1) if len(sizes) == self.world else max(b, 1)
-            # one packed buffer per rank: [bmax, N + 17] = logits | pose | status, rows >= bl are padding
-            buf = torch.zeros((bmax, n + 17), device=self.device, dtype=torch.float32)
-            if bl:
-                buf[:bl, :n] = logits
-                buf[:bl, n:n + 16] = trans.reshape(bl, 16)
-            if err is not None:
+            if err is not None or buf is None:
+                buf = torch.zeros((bmax, n + 17), device=self.device, dtype=torch.float32)
                 buf[:, n + 16] = 1.0
             if self.stage_host:
                 g_host = torch.empty((self.world * bmax, n + 17), dtype=torch.float32)

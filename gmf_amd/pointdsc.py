@@ -413,16 +413,25 @@ class PointDSC(nn.Module):
         feat_n = torch.empty((B, N, 128), device=dev)
         feat = torch.empty((B, N, 128), device=dev) if want_features else None
         h, st = handle_and_stream(corr_pos, check=True)     # (raises if an earlier forward on this device produced NaN / inf)
+        # the module-local numerics mode (set_precision): applied for this call and the handle's own setting PUT BACK afterwards
+        # (a handle-level gmf_set_tuning("precision", ...) made through the C knob survives).  The three calls take the
+        # handle's lock one after the other: two threads driving ONE handle with different modes must serialise themselves.
         prec = getattr(self, "_precision", 0)
+        prev = None
         if prec:
-            h.call("gmf_set_tuning", b"precision", prec)
+            import ctypes as C
+            cur = C.c_int(0)
+            h.call("gmf_get_tuning", b"precision", C.byref(cur))
+            if cur.value != prec:
+                prev = cur.value
+                h.call("gmf_set_tuning", b"precision", prec)
         try:
             h.call("gmf_encoder_forward", pw.struct, corr_pos.data_ptr(), src.data_ptr(), tgt.data_ptr(),
                    p_tokens.data_ptr(), q_tokens.data_ptr(), B, N, T, logits.data_ptr(), feat_n.data_ptr(),
                    None if feat is None else feat.data_ptr(), st)
         finally:
-            if prec:
-                h.call("gmf_set_tuning", b"precision", 0)
+            if prev is not None:
+                h.call("gmf_set_tuning", b"precision", prev)
         return logits, feat_n, feat
 
     # -- pose head --------------------------------------------------------------------------------
@@ -500,6 +509,9 @@ class PointDSC(nn.Module):
         result equals its own B = 1 call.  `last_logits` / `last_features` hold the packed tensors."""
         if self.training:
             raise RuntimeError("gmf_amd.PointDSC.forward_ragged is the eval() test-mode path")
+        if getattr(self, "_precision", 0):
+            raise RuntimeError("gmf_amd.PointDSC.forward_ragged: ragged batches run the parity numerics only - the throughput modes "
+                               "(set_precision) exist for uniform batches; call set_precision('parity') or pass a uniform batch")
         import ctypes as C
         cp, sk, tk = data["corr_pos"], data["src_keypts"], data["tgt_keypts"]
         if isinstance(cp, (list, tuple)):

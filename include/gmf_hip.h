@@ -42,7 +42,7 @@ enum {
   GMF_ERR_WORKSPACE = -6   /* the caller-provided workspace (gmf_set_workspace) is too small for this call */
 };
 
-#define GMF_ABI_VERSION 3
+#define GMF_ABI_VERSION 4   /* 4: + gmf_get_tuning; the pose head / pick_seeds take any N (additions only: a version-3 caller keeps working) */
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 int gmf_abi_version(void);
@@ -121,6 +121,9 @@ int gmf_status_read(gmf_handle* h, int* flags, int clear);
  *   "nms_binned"        : 1 = grid-binned NMS candidates on large grids (default), 2 = always, 0 = all pairs.
  *   "topk_select"       : 1 = radix select of the S seeds (default), 0 = full bitonic sort. */
 int gmf_set_tuning(gmf_handle* h, const char* name, int value);
+/* [ABI 4] The current value of a knob, so that a caller that changes one for a single call can put back what it found
+ * (the Python PointDSC module does this for its module-local numerics mode).  Both calls take the handle's lock. */
+int gmf_get_tuning(gmf_handle* h, const char* name, int* value);
 
 /* In-situ timing of the dominant kernel (the spatial-consistency attention): while enabled, every
  * k_scattn launch made through gmf_encoder_forward / gmf_nonlocal_block_forward is bracketed by HIP events

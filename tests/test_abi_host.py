@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gmf_hip.h but not exported"
     assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
-    assert lib.gmf_abi_version() == 3
+    assert lib.gmf_abi_version() == 4
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device error path")

@@ -46,7 +46,7 @@ def model(sd_full):
 def test_native_library_loaded():
     from gmf_amd import _lib
     lib = _lib.load_library()
-    assert lib.gmf_abi_version() == 3
+    assert lib.gmf_abi_version() == 4
     assert _lib.handle_for(0).h
 
 

@@ -1,13 +1,13 @@
 """Golden F22, stress weight set, N = 2000 (GPU box): where every selectable form of the HIP path lands against the fp64
 evaluation and against the reference's own fp32 logits - is 4.9e-4 (against the reference's 2.8e-4) a property of one form or of
-the conditioning?    python tools/f22_probe.py"""
+the conditioning?    python tests/tools/f22_probe.py"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import gmf_amd                                   # noqa: E402
 from gmf_amd import _lib, synthetic              # noqa: E402

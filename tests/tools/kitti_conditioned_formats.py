@@ -2,13 +2,13 @@
 3DMatch-size coordinates: the reference's own fp32 is 3e-4 from the exact network) and "cond" (synthetic.kitti_conditioned:
 layer0.weight / 13, fp32 floor 1.7e-5; golden F22 pins this branch).  Per pair (N = 700 ... 3000, one ragged launch = the
 large-grid kernels): max |logit - fp64 logit| of the HIP path under compat_format 0 / 2 and pv_fp8 1 / 0, next to the fp32
-oracle's own distance from fp64, and HIP against the fp32 oracle.   GPU box:  python tools/kitti_conditioned_formats.py"""
+oracle's own distance from fp64, and HIP against the fp32 oracle.   GPU box:  python tests/tools/kitti_conditioned_formats.py"""
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import gmf_amd                                   # noqa: E402
 from gmf_amd import _lib, synthetic              # noqa: E402
 from oracle import gmf_oracle as O               # noqa: E402

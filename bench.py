@@ -44,7 +44,7 @@ if ROOT not in sys.path:
 PEAK_F16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 PRODUCTS = 3            # MFMA products per algorithmic multiply-add: split-fp16 operands, hh + hl + lh
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_scattn_h2p_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_scattn_h2p_pmc.json")
 
 
 def scattn_flops_per_launch(B: int, N: int) -> float:
@@ -191,14 +191,14 @@ def main():
     achieved = flops / (avg_ms * 1e-3) / 1e12
     peak = PEAK_F16_MFMA_TFLOPS / PRODUCTS
     alg_bytes = scattn_bytes_per_launch(B, N)
-    traffic, traffic_note = None, "no PMC summary for this source tree (profiles/r03_scattn_h2p_pmc.json missing or taken on another build)"
+    traffic, traffic_note = None, "no PMC summary for this source tree (profiles/r04_scattn_h2p_pmc.json missing or taken on another build)"
     sha = csrc_sha16()
     if os.path.exists(PMC_SUMMARY):
         pmc = json.load(open(PMC_SUMMARY))
         wl = pmc.get("workload", {})
         if pmc.get("csrc_sha16") == sha and (wl.get("pairs"), wl.get("n_corr"), wl.get("tokens")) == (B, N, T):
             traffic = pmc["derived"]["traffic_bytes_per_launch"]
-            traffic_note = f"rocprofv3 FETCH_SIZE / WRITE_SIZE passes on this source tree (csrc_sha16 {sha}), profiles/r03_scattn_h2p_pmc.json"
+            traffic_note = f"rocprofv3 FETCH_SIZE / WRITE_SIZE passes on this source tree (csrc_sha16 {sha}), profiles/r04_scattn_h2p_pmc.json"
     step_ms = dt / args.steps * 1e3
     step_tflops = step_flops(B, N, T) / (step_ms * 1e-3) / 1e12
     line = {

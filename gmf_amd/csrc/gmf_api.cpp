@@ -892,6 +892,8 @@ static int pose_head_impl(gmf_handle* h, const gmf_pose_params* p, const float* 
   }
   // feature-space distances of the seed rows by MFMA (k_seed_dist), then per-seed top-(k+1) selection
   GMF_HIP(gmf::launch_pack_rows_h2(feat_n, fimg, B, N, st, ptab));
+  // (the fused form - distances computed twice and never written - was built in round 4, is exact, and is not faster:
+  // tools/ubench/archive/seed_knn_fused_r04.hip)
   GMF_HIP(gmf::launch_seed_dist(fimg, seeds_use, dmat, B, N, Sn, st, ptab));
   GMF_HIP(gmf::launch_knn_seeds(feat_n, seeds_use, dmat, knn, B, N, Sn, k, st, ptab));
   GMF_HIP(gmf::launch_seed_power(feat_n, src_keypts, tgt_keypts, knn, snaps, conv, hsum, B, N, Sn, k, iters, p->sigma, p->sigma_d, st, ptab));

@@ -428,7 +428,9 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
 // biases = 78.5 KiB (two workgroups per CU)
 constexpr int kLinLdsFloats = 4 * kStageFloats + 7 * C + (3 * C + 2 * FFH) + kWavesPerWG * 2 * C + 3 * C;
 
-template <int PART, int NP = 3>
+// QSKIP [r4]: the Q' projection is left to the attention kernel's prologue (scattn_h2p_body, qf_img): 8 instead of 12 projection
+// stages, 32 instead of 48 KiB of stores per wave in the kernel's write-bound phase
+template <int PART, int NP = 3, bool QSKIP = false>
 GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const float* __restrict__ front_wst,
                                const float* __restrict__ front_vec, const float* __restrict__ ctx_img,
                                const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
@@ -470,7 +472,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
     LcpeHalo<CF>::issue(pair_base, tile, tiles_p, halo, lane);
   }
   StageRing<4> ss;
-  if (PART == 0) ss.init(lds, wave, lane, front_wst + 4 * kStageFloats, 12, attn_wst, 2,
+  if (PART == 0) ss.init(lds, wave, lane, front_wst + (QSKIP ? 8 : 4) * kStageFloats, QSKIP ? 8 : 12, attn_wst, 2,
                          ctx_img + (size_t)pair * ttiles * kStageFloats, ttiles, attn_wst + 2 * kStageFloats, 2);
   else if (PART == 1) ss.init(lds, wave, lane, front_wst + 4 * kStageFloats, 12);
   else ss.init(lds, wave, lane, attn_wst, 2, ctx_img + (size_t)pair * ttiles * kStageFloats, ttiles, attn_wst + 2 * kStageFloats, 2);
@@ -488,12 +490,12 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
     // i.e. a wait for the store acknowledgements of four stages back in the middle of every epilogue from stage 5 on.
     ss.prime();                                  // AFTER the load above: its wait then leaves the three primed stages in flight
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {   // Q', K
+    for (int which = (QSKIP ? 1 : 0); which < 2; ++which) {   // Q', K
       float* dst = (which == 0 ? q_out : k_out) + toff;
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
         constexpr int kYounger[4] = {8, 12, 16, 20};
-        const int sidx = 4 * which + mb;                       // stage index (compile-time: the loops are unrolled)
+        const int sidx = 4 * (which - (QSKIP ? 1 : 0)) + mb;   // stage index (compile-time: the loops are unrolled)
         // (role 1 has no stages behind its last ones, so the counts of the steady state do not hold there: plain acquire)
         const f16x8* lw = as_h2(PART == 1 ? ss.acquire()
                                 : sidx == 0 ? ss.acquire_counted<kYounger[0]>() : sidx == 1 ? ss.acquire_counted<kYounger[1]>()
@@ -674,7 +676,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
 // NP = 3: the parity kernel.  NP = 1: the throughput numerics mode (gmf_set_tuning "precision" = 1) - every product of the layer's
 // linear part on the high fp16 planes only (a third of the MFMAs, half the LDS reads); LayerNorms, softmax, GELU, biases and
 // residuals stay fp32.  NOT within the parity gate.
-template <int NP>
+template <int NP, bool QSKIP = false>
 __global__ void __launch_bounds__(256, 2)
 k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst, const float* __restrict__ front_vec,
             const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
@@ -682,8 +684,8 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
             float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
             int ttiles, const PairTab* __restrict__ ptab, unsigned* __restrict__ v_scale) {
   __shared__ __attribute__((aligned(16))) float lds[kLinLdsFloats];
-  linear_h2_body<0, NP>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
-                        tiles, T, ttiles, ptab, v_scale);
+  linear_h2_body<0, NP, QSKIP>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
+                               tiles, T, ttiles, ptab, v_scale);
 }
 
 // grid (ceil(tiles / 4), B, 2): blockIdx.z = 0 the Q'/K/V role, 1 the Fusion-2 role of the same 128 rows
@@ -753,11 +755,14 @@ hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* fro
                             bool one_product, const PairTab* ptab, unsigned* v_scale) {
   // grids that give a CU about one workgroup: two roles per row block (the Q'/K/V projections | Fusion-2) in one launch
   const int W = ((tiles + 3) / 4) * B;
-  if (tune.mid_grid_roles > 0 && W < tune.mid_grid_roles && !ptab)
+  if (tune.mid_grid_roles > 0 && W < tune.mid_grid_roles && !ptab && q)
     hipLaunchKernelGGL(k_linear_roles, tgrid(tiles, B, 2), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec,
                        ff_wst, ff_vec, q, k, v, x2, N, tiles, T, ttiles, v_scale);
   else if (one_product)                            // throughput numerics mode: high planes only
     hipLaunchKernelGGL(k_linear_h2<1>, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
+                       ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab, v_scale);
+  else if (!q)                                     // [r4] no Q' image: the attention kernel projects its own (CompatCache::qf_img)
+    hipLaunchKernelGGL((k_linear_h2<3, true>), tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
                        ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab, v_scale);
   else
     hipLaunchKernelGGL(k_linear_h2<3>, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,

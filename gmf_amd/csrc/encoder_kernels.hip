@@ -768,7 +768,10 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
                                 const float* __restrict__ c_dense, int n_items, int n_full, int ksplits,
                                 float* __restrict__ part_o, float* __restrict__ part_ml, const float* __restrict__ next_wst,
                                 const float* __restrict__ next_bias, const PairTab* __restrict__ ptab = nullptr,
-                                const unsigned* __restrict__ v_scale = nullptr) {
+                                const unsigned* __restrict__ v_scale = nullptr,
+                                // [r4] non-null: q_img is not read - the workgroup projects its own Q' from the layer's f tile (below)
+                                const float* __restrict__ qf_img = nullptr, const float* __restrict__ qw_wst = nullptr,
+                                const float* __restrict__ qw_bias = nullptr) {
   static_assert(!PVF8 || NPROD == 3, "the fp8 cross products belong to the three-product form");
   float* const ldsK = lds;
   float* const ldsV = lds + 2 * kStageFloats;
@@ -795,7 +798,37 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   const size_t toff = (pbase + tile) * (32 * C);
 
   f16x8 qh[8], ql[8];
-  {
+  if (NPROD == 3 && WAVES == 4 && qf_img) {
+    // [r4] Q' = Wq' f + bq' for this workgroup's 128 query rows HERE instead of in k_linear_h2 (PointDSC.py:56: projection_q).  Q'
+    // is the one projection only its own workgroup consumes: computing it in the linear kernel meant 82 MB written and read
+    // back per layer and a third of the stores of that kernel's write-bound Q'/K/V phase (k_linear_h2 without it: 307 -> 272 us).
+    // The same arithmetic, bit for bit (k_linear_h2: mma_wx_h2n<8, 3> on the same weight stages, fmaf(acc, 2^-8, bias), fp16
+    // split), so every other path - which still reads Q' images - agrees with this one.  The four weight stages (64 KiB) fill
+    // the K / V rings' LDS before the tile loop needs it.
+    FragH2<8> fx;
+    {
+      float fq[CF];
+      load_frag_p32<CF>(fq, qf_img + toff, lane);
+      fx.set(fq);
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) dma_4k_s(qw_wst + st * kStageFloats + wave * 1024, lds + st * kStageFloats + wave * 1024, lane_off16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const f16x8* lw = reinterpret_cast<const f16x8*>(lds + mb * kStageFloats) + lane;
+      f32x16 acc = zero16();
+      mma_wx_h2n<8, 3>(acc, lw, fx);
+      float t[16], bq[16];
+      load_vec_block(bq, qw_bias, mb, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bq[r]);
+      split8h(&t[0], qh[2 * mb], ql[2 * mb]);
+      split8h(&t[8], qh[2 * mb + 1], ql[2 * mb + 1]);
+    }
+    __syncthreads();                               // every wave is done with the stages: the tile rings may overwrite them
+  } else {
     const f16x8* qp = reinterpret_cast<const f16x8*>(q_img + (pbase + tile) * (size_t)kStageFloats) + lane;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -1253,10 +1286,11 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
              float* __restrict__ out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_dense,
              int n_items, int n_full, int ksplits, float* __restrict__ part_o, float* __restrict__ part_ml,
              const float* __restrict__ next_wst, const float* __restrict__ next_bias, const PairTab* __restrict__ ptab,
-             const unsigned* __restrict__ v_scale) {
+             const unsigned* __restrict__ v_scale, const float* __restrict__ qf_img, const float* __restrict__ qw_wst,
+             const float* __restrict__ qw_bias) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
   scattn_h2p_body<NPROD, CFMT, 4, PVF8>(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items,
-                             n_full, ksplits, part_o, part_ml, next_wst, next_bias, ptab, v_scale);
+                             n_full, ksplits, part_o, part_ml, next_wst, next_bias, ptab, v_scale, qf_img, qw_wst, qw_bias);
 }
 
 // =========================================================================================
@@ -2363,19 +2397,19 @@ hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, 
                          cc->next_wst_h2, cc->next_bias);
     else if (cc->half)  // ... with a split tail: one fp16 product, c streamed as fp16 (the cache was built that way)
       hipLaunchKernelGGL((k_scattn_h2p<1, 1>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, W,
-                         n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr);
+                         n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
     else if (cc->fmt == 2 && cc->v_scale)   // parity arithmetic, c streamed as 16-bit fixed point; fp8 cross products of P V
       hipLaunchKernelGGL((k_scattn_h2p<3, 2, true>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
-                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, cc->v_scale);
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, cc->v_scale, cc->qf_img, cc->qw_wst, cc->qw_bias);
     else if (cc->fmt == 2)
       hipLaunchKernelGGL((k_scattn_h2p<3, 2>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
-                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr);
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr, cc->qf_img, cc->qw_wst, cc->qw_bias);
     else if (cc->v_scale)    // the default: V image with e4m3 cross planes (k_linear_h2 wrote it that way)
       hipLaunchKernelGGL((k_scattn_h2p<3, 0, true>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
-                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, cc->v_scale);
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, cc->v_scale, cc->qf_img, cc->qw_wst, cc->qw_bias);
     else
       hipLaunchKernelGGL((k_scattn_h2p<3, 0>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
-                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr);
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr, cc->qf_img, cc->qw_wst, cc->qw_bias);
     if (max_tail > 0)
       hipLaunchKernelGGL(k_scattn_merge, dim3(8 * max_tail), dim3(256), 0, s, cc->part_o, cc->part_ml, fus, cc->tail_wst_h2, vecs, out,
                          tiles, wpp, W, n_full, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)nullptr, 0,

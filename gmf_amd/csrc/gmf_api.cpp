@@ -152,6 +152,11 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     t.mid_grid_roles = value;
     return GMF_OK;
   }
+  if (std::strcmp(name, "q_in_attention") == 0) {      // 1 = large grids: every attention workgroup projects its own Q' (default), 0 = k_linear_h2 writes a Q' image
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: q_in_attention must be 0 or 1");
+    t.q_in_attention = value != 0;
+    return GMF_OK;
+  }
   if (std::strcmp(name, "pv_fp8") == 0) {       // large grids: the cross products of O += P V on the block-scaled fp8 pipe (default 1)
     GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: pv_fp8 must be 0 or 1");
     t.pv_fp8 = value != 0;
@@ -180,7 +185,7 @@ int gmf_get_tuning(gmf_handle* h, const char* name, int* value) {
       {"attn_key_splits", t.key_splits}, {"attn_tail_split", t.tail_split ? 1 : 0}, {"small_grid_roles", t.small_roles ? 1 : 0},
       {"fused_linear", t.fused_linear ? 1 : 0}, {"compat_cache", t.use_cache ? 1 : 0}, {"conv_lds_patch", t.conv_patch},
       {"nms_binned", t.nms_binned}, {"topk_select", t.topk_select ? 1 : 0}, {"wide_attn_tile", t.wide_attn_tile ? 1 : 0},
-      {"small_merge_tile", t.small_merge_tile ? 1 : 0}, {"mid_grid_roles", t.mid_grid_roles}, {"pv_fp8", t.pv_fp8 ? 1 : 0},
+      {"small_merge_tile", t.small_merge_tile ? 1 : 0}, {"mid_grid_roles", t.mid_grid_roles}, {"pv_fp8", t.pv_fp8 ? 1 : 0}, {"q_in_attention", t.q_in_attention ? 1 : 0},
       {"compat_format", t.compat_format}, {"precision", t.precision}};
   for (const auto& e : tab) {
     if (std::strcmp(name, e.name) == 0) { *value = e.v; return GMF_OK; }
@@ -609,7 +614,15 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
       const float* ffv = w->ff_vec + (size_t)l * w->ff_vec_stride;
       const float* ctx_l = ctxall + (size_t)l * tok;
       if (one_kernel) {
-        GMF_HIP(gmf::launch_linear_h2(h->tune, f, fw, fv, ctx_l, aw, av, ffw, ffv, q, k, v, x2, B, N, tiles, T, tt, st,
+        // [r4] Q' in the attention kernel's prologue (parity arithmetic of the pipelined kernel; not with the linear kernel as two
+        // roles, whose Q'/K/V role writes the image): k_linear_h2 then projects K and V only
+        const int Wl = ((tiles + 3) / 4) * B;
+        const bool roles = h->tune.mid_grid_roles > 0 && Wl < h->tune.mid_grid_roles && !ptab;
+        const bool qproj = h->tune.q_in_attention && !cc.half && !roles;
+        cc.qf_img = qproj ? f : nullptr;
+        cc.qw_wst = qproj ? fw + 4 * kTileFloats : nullptr;
+        cc.qw_bias = qproj ? fv + kC : nullptr;
+        GMF_HIP(gmf::launch_linear_h2(h->tune, f, fw, fv, ctx_l, aw, av, ffw, ffv, qproj ? nullptr : q, k, v, x2, B, N, tiles, T, tt, st,
                                       cc.half && h->tune.precision == 2, ptab, cc.v_scale));
       } else if (small3) {
         // three launches: {Q' | K | V | cross-attention} -> {key-split attention | hidden-split feed-forward} -> merge

@@ -29,6 +29,11 @@ struct CompatCache {
                               // 1 = fp16 c (with `half`), 2 = fixed point rint(65535 c)
   unsigned* v_scale = nullptr;   // non-null: the layer's V image carries e4m3 cross planes (store_block_v8) and these are their
                                  // scale words, [B * tiles][64]; k_linear_h2 writes both, k_scattn_h2p<3, *, true> reads them
+  // [r4] non-null: no Q' image exists - every attention workgroup projects its own Q' in its prologue from the layer's f image
+  // (qf_img), the four Q' weight stages (qw_wst) and bq' (qw_bias, 128 floats); parity kernels of the pipelined form only
+  const float* qf_img = nullptr;
+  const float* qw_wst = nullptr;
+  const float* qw_bias = nullptr;
 };
 
 // Per-handle tuning knobs (gmf_set_tuning).  Every value selects between forms that compute the same result up to
@@ -52,6 +57,7 @@ struct Tuning {
   bool topk_select = true;   // radix select of the S seeds (false = full bitonic sort)
   int mid_grid_roles = 512;  // two-launch form on grids below this many base workgroups (>= 256): the linear kernel runs as two
                              // workgroup roles per row block (Q'/K/V | Fusion-2); 0 = never
+  bool q_in_attention = true;   // [r4] large grids: Q' is projected in the attention kernel's prologue, not written by k_linear_h2 (bit-identical)
   bool pv_fp8 = true;        // parity arithmetic of the default path: the two cross products of O += P V on the block-scaled fp8 matrix
                              // pipe (scattn_h2p_body<3, *, 4, true>).  0 = all three products on the f16 pipe
   int compat_format = 0;     // element format of the compat cache on the cached, pipelined path: 0 = fp32 (default); 2 = 16-bit fixed

@@ -119,7 +119,9 @@ int gmf_status_read(gmf_handle* h, int* flags, int clear);
  *   "conv_lds_patch"    : 1 = stride-1 3x3 convolutions stage activations through LDS (default), 2 = same without the
  *                         three-workgroup form, 0 = gather form.
  *   "nms_binned"        : 1 = grid-binned NMS candidates on large grids (default), 2 = always, 0 = all pairs.
- *   "topk_select"       : 1 = radix select of the S seeds (default), 0 = full bitonic sort. */
+ *   "topk_select"       : 1 = radix select of the S seeds (default), 0 = full bitonic sort.
+ *   "q_in_attention"    : [ABI 4] 1 = on large grids every attention workgroup projects its own Q' in its prologue (default; PointDSC.py:56),
+ *                         0 = the linear kernel writes a Q' image.  Bit-identical results. */
 int gmf_set_tuning(gmf_handle* h, const char* name, int value);
 /* [ABI 4] The current value of a knob, so that a caller that changes one for a single call can put back what it found
  * (the Python PointDSC module does this for its module-local numerics mode).  Both calls take the handle's lock. */

@@ -580,6 +580,42 @@ def test_pv_fp8_shared_scale_worst_case(log2_ratio):
         assert d < 4e-5, (name, d)          # measured 1.4e-5 (2^14) / 2.3e-5 (2^15); the bound is 2^-10 |v| of the attended key
 
 
+def test_q_in_attention_is_bit_identical(model):
+    """[r4] gmf_set_tuning("q_in_attention", 1) (default): on large grids k_linear_h2 no longer writes a Q' image - every attention
+    workgroup projects the Q' of its own 128 query rows in its prologue (PointDSC.py:56; the same weight stages, the same MFMA
+    order, the same bias add and fp16 split as k_linear_h2).  Logits, features and poses are bit-identical to the form with the
+    image, on a uniform large-grid batch (sizes that leave padding waves), in both attention forms, and on a ragged batch."""
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    b = synthetic.synthetic_batch(list(range(40, 40 + 9)), N=3970, T=196)        # 9 x 32 row blocks >= 256: the two-launch form
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    sizes = [700, 1531, 5000, 257]
+    pairs = [synthetic.synthetic_batch([300 + i], N=n, T=196) for i, n in enumerate(sizes)]
+    rag = {k: [_gpu(p[k][0]) for p in pairs] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    rag.update(p_tokens=torch.cat([_gpu(p["p_tokens"]) for p in pairs]), q_tokens=torch.cat([_gpu(p["q_tokens"]) for p in pairs]), testing=True)
+    got = {}
+    try:
+        for pv in (1, 0):
+            h.call("gmf_set_tuning", b"pv_fp8", pv)
+            for knob in (1, 0):
+                h.call("gmf_set_tuning", b"q_in_attention", knob)
+                res = model(data)
+                r2 = model(rag)
+                got[pv, knob] = (model.encode(*[data[k] for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")], True),
+                                 res["final_trans"].clone(), torch.cat(r2["logits"]).clone(), r2["final_trans"].clone())
+    finally:
+        h.call("gmf_set_tuning", b"q_in_attention", 1)
+        h.call("gmf_set_tuning", b"pv_fp8", 1)
+    for pv in (1, 0):
+        (lg1, fn1, f1), T1, rl1, rT1 = got[pv, 1]
+        (lg0, fn0, f0), T0, rl0, rT0 = got[pv, 0]
+        assert torch.equal(lg1, lg0) and torch.equal(fn1, fn0) and torch.equal(f1, f0) and torch.equal(T1, T0), pv
+        assert torch.equal(rl1, rl0) and torch.equal(rT1, rT0), pv
+    ref = O.pointdsc_forward(synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7), {k: v[:1] for k, v in b.items()}, testing=True)
+    assert _maxerr(got[1, 1][0][0][:1].cpu(), ref["logits"]) < 1e-4
+
+
 def test_compat_format_16bit_is_an_opt_in_within_the_gate_on_3dmatch_shape(model, sd_full):
     """gmf_set_tuning("compat_format", 2): the compat cache as 16-bit fixed point (half the cache and its stream; DESIGN section 4b
     has why it is not the default: KITTI-shape inputs).  On a 3DMatch-shape large-grid batch both attention forms (pv_fp8 0 / 1)

@@ -56,16 +56,27 @@ class FusionWeights(C.Structure):
 
 GMF_PACK_DEVICE_TENSORS = 1
 GMF_PACK_STANDALONE_BLOCK = 2
+GMF_PACK_HOST_BLOCK = 4
 
 
 def tensor_list(sd):
     """state_dict -> (ctypes array of gmf_tensor, keep-alive list).  Floating tensors only, as contiguous fp32 on the host."""
     import torch
     keep, items = [], []
+    # [r4] tensors that live on a device travel to the host as ONE flat copy (a state_dict of the encoder is ~590 tensors: one
+    # device-to-host copy and one synchronisation instead of 590 - ADVICE r3)
+    host = {}
+    dev = [(k, v) for k, v in sd.items() if torch.is_tensor(v) and v.is_floating_point() and v.device.type != "cpu" and v.dim() <= 4]
+    if dev:
+        flat = torch.cat([v.detach().reshape(-1).to(torch.float32) for _, v in dev]).cpu()
+        o = 0
+        for k, v in dev:
+            host[k] = flat[o:o + v.numel()].reshape(v.shape)
+            o += v.numel()
     for k, v in sd.items():
         if not (torch.is_tensor(v) and v.is_floating_point()):
             continue
-        t = v.detach().to("cpu", torch.float32).contiguous()
+        t = host[k] if k in host else v.detach().to("cpu", torch.float32).contiguous()
         if t.dim() > 4:
             continue
         name = k.encode()
@@ -117,9 +128,13 @@ SIGNATURES = {
     "gmf_packed_encoder_weights": (C.POINTER(EncoderWeights), [_vp]),
     "gmf_packed_encoder_info": (C.c_int, [_vp, _f32p, _f32p, _i32p, _f32p]),
     "gmf_packed_encoder_free": (None, [_vp]),
+    "gmf_packed_encoder_bytes": (C.c_longlong, [_vp]),
+    "gmf_packed_encoder_place": (C.c_int, [_vp, _vp, _vp, C.c_longlong, _vp]),
     "gmf_fusion_pack_weights": (C.c_int, [_vp, C.POINTER(Tensor), C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
     "gmf_packed_fusion_weights": (C.POINTER(FusionWeights), [_vp]),
     "gmf_packed_fusion_free": (None, [_vp]),
+    "gmf_packed_fusion_bytes": (C.c_longlong, [_vp]),
+    "gmf_packed_fusion_place": (C.c_int, [_vp, _vp, _vp, C.c_longlong, _vp]),
     "gmf_encoder_forward": (C.c_int, [_vp, C.POINTER(EncoderWeights), _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                       _vp, _vp, _vp, _vp]),
     "gmf_encoder_forward_ragged": (C.c_int, [_vp, C.POINTER(EncoderWeights), _vp, _vp, _vp, _vp, _vp, _i32p, C.c_int, C.c_int,

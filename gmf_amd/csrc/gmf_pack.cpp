@@ -306,6 +306,7 @@ int read_state(gmf_handle* h, const gmf_tensor* ts, int n, int on_device, StateD
     }
     if (on_device) {
       if (!h) { err = "gmf: pack: device tensors need a handle"; return GMF_ERR_BAD_ARG; }
+      SetDevice sdv(h);                          // (the handle's device, under its lock: ADVICE r3)
       sd.staged.emplace_back((size_t)e.numel);
       hipError_t rc = hipMemcpy(sd.staged.back().data(), t.data, (size_t)e.numel * sizeof(float), hipMemcpyDeviceToHost);
       if (rc != hipSuccess) { err = std::string("gmf: pack: hipMemcpy(`") + t.name + "`): " + hipGetErrorString(rc); return GMF_ERR_HIP; }
@@ -337,6 +338,7 @@ struct gmf_packed_encoder {
   float* device_block = nullptr;    // library-owned device copy (nullptr: the blobs live in host_block)
   int device = -1;
   std::vector<float> host_block;
+  const float* placed = nullptr;    // caller-owned device copy the pointers refer to (gmf_packed_encoder_place)
 };
 
 struct gmf_packed_fusion {
@@ -344,13 +346,15 @@ struct gmf_packed_fusion {
   float* device_block = nullptr;
   int device = -1;
   std::vector<float> host_block;
+  const float* placed = nullptr;     // caller-owned device copy the pointers refer to (gmf_packed_fusion_place)
 };
 
 namespace {
 
 // moves `blk` to the device of `h` (or keeps it on the host when h is null) and returns the base pointer the offsets refer to
-int place(gmf_handle* h, Block& blk, std::vector<float>& host_keep, float** device_block, int* device, const float** base, std::string& err) {
-  if (!h) {
+int place(gmf_handle* h, Block& blk, std::vector<float>& host_keep, float** device_block, int* device, const float** base, std::string& err,
+          bool host_only = false) {
+  if (!h || host_only) {
     host_keep.swap(blk.host);
     *base = host_keep.data();
     return GMF_OK;
@@ -428,7 +432,7 @@ int gmf_encoder_pack_weights(gmf_handle* h, const gmf_tensor* tensors, int n_ten
     p->sigma = sd.has("sigma") ? need(sd, "sigma").data[0] : 1.0f;
     const float sigma_d = sd.has("sigma_spat") ? need(sd, "sigma_spat").data[0] : 0.1f;
     const float* base = nullptr;
-    if (int rc = place(h, blk, p->host_block, &p->device_block, &p->device, &base, err)) { delete p; return bail(rc, err); }
+    if (int rc = place(h, blk, p->host_block, &p->device_block, &p->device, &base, err, (flags & GMF_PACK_HOST_BLOCK) != 0)) { delete p; return bail(rc, err); }
     auto at = [&](const Off& o) -> const float* { return o.set ? base + o.v : nullptr; };
     gmf_encoder_weights& w = p->w;
     w.num_layers = L;
@@ -500,7 +504,7 @@ int gmf_fusion_pack_weights(gmf_handle* h, const gmf_tensor* tensors, int n_tens
     const size_t o0 = blk.add(b.ctx_wst), o1 = blk.add(b.ctx_vec), o2 = blk.add(b.attn_wst), o3 = blk.add(b.attn_vec), o4 = blk.add(b.ff_wst),
                  o5 = blk.add(b.ff_vec), o6 = blk.add(bh.ctx_wst), o7 = blk.add(bh.attn_wst), o8 = blk.add(bh.ff_wst);
     const float* base = nullptr;
-    if (int rc = place(h, blk, p->host_block, &p->device_block, &p->device, &base, err)) { delete p; return bail(rc, err); }
+    if (int rc = place(h, blk, p->host_block, &p->device_block, &p->device, &base, err, (flags & GMF_PACK_HOST_BLOCK) != 0)) { delete p; return bail(rc, err); }
     gmf_fusion_weights& w = p->w;
     w.latent_dim = b.lat; w.d_head = b.dh; w.pe = pe != 0;
     w.ctx_wst = base + o0; w.ctx_vec = base + o1; w.attn_wst = base + o2; w.attn_vec = base + o3; w.ff_wst = base + o4; w.ff_vec = base + o5;
@@ -530,6 +534,66 @@ void gmf_packed_fusion_free(gmf_packed_fusion* p) {
     if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
   }
   delete p;
+}
+
+}  // extern "C"
+
+namespace {
+// every pointer of a weights struct that points into [from, from + n) is moved to the same offset behind `to`
+inline void rebase_ptr(const float*& ptr, const float* from, size_t n, const float* to) {
+  if (ptr && ptr >= from && ptr < from + n) ptr = to + (ptr - from);
+}
+int place_into(gmf_handle* h, const std::vector<float>& host_block, void* device_dst, long long bytes, gmf_stream_t stream, const char* what) {
+  if (!h || !device_dst) return GMF_ERR_BAD_ARG;
+  if (host_block.empty()) { h->err = std::string("gmf: ") + what + ": the object was not packed with a NULL handle (its block is not in host memory)"; return GMF_ERR_BAD_ARG; }
+  if ((size_t)bytes < host_block.size() * sizeof(float) || ((uintptr_t)device_dst & 255u)) {
+    h->err = std::string("gmf: ") + what + ": the destination must be 256-byte aligned and hold " + std::to_string(host_block.size() * sizeof(float)) + " B";
+    return GMF_ERR_BAD_ARG;
+  }
+  SetDevice sd(h, stream);
+  hipError_t rc = hipMemcpyAsync(device_dst, host_block.data(), host_block.size() * sizeof(float), hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream));
+  if (rc != hipSuccess) { h->err = std::string("gmf: ") + what + ": hipMemcpyAsync: " + hipGetErrorString(rc); return GMF_ERR_HIP; }
+  return GMF_OK;
+}
+}  // namespace
+
+extern "C" {
+
+long long gmf_packed_encoder_bytes(const gmf_packed_encoder* p) {
+  return p ? (long long)(p->host_block.size() * sizeof(float)) : 0;
+}
+
+int gmf_packed_encoder_place(gmf_handle* h, gmf_packed_encoder* p, void* device_dst, long long bytes, gmf_stream_t stream) {
+  if (!h || !p) return GMF_ERR_BAD_ARG;
+  if (int rc = place_into(h, p->host_block, device_dst, bytes, stream, "packed_encoder_place")) return rc;
+  const float* from = p->placed ? p->placed : p->host_block.data();
+  const float* to = static_cast<const float*>(device_dst);
+  const size_t n = p->host_block.size();
+  gmf_encoder_weights& w = p->w;
+  const float** ptrs[] = {&w.f1_ctx_wst, &w.f1_ctx_vec, &w.f1_attn_wst, &w.f1_attn_vec, &w.f1_ff_wst, &w.f1_ff_vec, &w.ctx_wst, &w.ctx_vec,
+                          &w.attn_wst, &w.attn_vec, &w.ff_wst, &w.ff_vec, &w.front_wst, &w.front_vec, &w.tail_wst, &w.tail_vec, &w.head_wst,
+                          &w.head_vec, &w.front_wst_h2, &w.ctx_wst_h2, &w.attn_wst_h2, &w.ff_wst_h2, &w.f1_ctx_wst_h2, &w.f1_attn_wst_h2,
+                          &w.f1_ff_wst_h2, &w.tail_wst_h2};
+  for (const float** q : ptrs) rebase_ptr(*q, from, n, to);
+  p->placed = to;
+  return GMF_OK;
+}
+
+long long gmf_packed_fusion_bytes(const gmf_packed_fusion* p) {
+  return p ? (long long)(p->host_block.size() * sizeof(float)) : 0;
+}
+
+int gmf_packed_fusion_place(gmf_handle* h, gmf_packed_fusion* p, void* device_dst, long long bytes, gmf_stream_t stream) {
+  if (!h || !p) return GMF_ERR_BAD_ARG;
+  if (int rc = place_into(h, p->host_block, device_dst, bytes, stream, "packed_fusion_place")) return rc;
+  const float* from = p->placed ? p->placed : p->host_block.data();
+  const float* to = static_cast<const float*>(device_dst);
+  const size_t n = p->host_block.size();
+  gmf_fusion_weights& w = p->w;
+  const float** ptrs[] = {&w.ctx_wst, &w.ctx_vec, &w.attn_wst, &w.attn_vec, &w.ff_wst, &w.ff_vec, &w.ctx_wst_h2, &w.attn_wst_h2, &w.ff_wst_h2};
+  for (const float** q : ptrs) rebase_ptr(*q, from, n, to);
+  p->placed = to;
+  return GMF_OK;
 }
 
 }  // extern "C"

@@ -291,7 +291,7 @@ class PackedFusion(_Owned):
         hd = _lib.handle_for(dev.index if dev.index is not None else torch.cuda.current_device()) if dev.type == "cuda" else None
         arr, keep = _lib.tensor_list(sd)
         out = C.c_void_p()
-        rc = lib.gmf_fusion_pack_weights(hd.h if hd else None, arr, len(arr), prefix.encode(), 1 if pe else 0, 0, C.byref(out))
+        rc = lib.gmf_fusion_pack_weights(hd.h if hd else None, arr, len(arr), prefix.encode(), 1 if pe else 0, _lib.GMF_PACK_HOST_BLOCK, C.byref(out))
         if rc != 0:
             msg = lib.gmf_last_error_string(hd.h).decode() if hd else ""
             if rc == -2:
@@ -299,6 +299,13 @@ class PackedFusion(_Owned):
             raise RuntimeError(f"gmf_amd: gmf_fusion_pack_weights failed (status {rc}): {msg}")
         del keep
         self._p = out
+        self._block = None
+        if hd is not None:       # [r4] the block in a torch tensor (gmf_packed_fusion_place): see PackedEncoder
+            nbytes = int(lib.gmf_packed_fusion_bytes(out))
+            self._block = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+            rc = lib.gmf_packed_fusion_place(hd.h, out, C.c_void_p(self._block.data_ptr()), nbytes, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"gmf_amd: gmf_packed_fusion_place failed (status {rc}): {lib.gmf_last_error_string(hd.h).decode()}")
         w = lib.gmf_packed_fusion_weights(out).contents
         self.latent_dim, self.d_head, self.split_fp16 = int(w.latent_dim), int(w.d_head), bool(w.split_fp16)
         for k in ("ctx_wst", "ctx_vec", "attn_wst", "attn_vec", "ff_wst", "ff_vec", "ctx_wst_h2", "attn_wst_h2", "ff_wst_h2"):
@@ -326,8 +333,10 @@ class PackedEncoder(_Owned):
         hd = _lib.handle_for(dev.index if dev.index is not None else torch.cuda.current_device()) if on_gpu else None
         arr, keep = _lib.tensor_list(sd)
         out = C.c_void_p()
+        # [r4] packed on the HOST (h = NULL) and placed into a torch tensor: the block lives in torch's caching allocator (visible in
+        # its statistics, freed stream-ordered, no hipMalloc per re-pack and no device-wide hipFree from __del__ - ADVICE r3)
         rc = lib.gmf_encoder_pack_weights(hd.h if hd else None, arr, len(arr), int(num_layers),
-                                          _lib.GMF_PACK_STANDALONE_BLOCK if standalone_block else 0, C.byref(out))
+                                          (_lib.GMF_PACK_STANDALONE_BLOCK if standalone_block else 0) | _lib.GMF_PACK_HOST_BLOCK, C.byref(out))
         if rc != 0:
             msg = lib.gmf_last_error_string(hd.h).decode() if hd else ""
             if rc == -2:
@@ -335,6 +344,14 @@ class PackedEncoder(_Owned):
             raise RuntimeError(f"gmf_amd: gmf_encoder_pack_weights failed (status {rc}): {msg}")
         del keep
         self._p = out
+        self._block = None
+        if on_gpu:
+            nbytes = int(lib.gmf_packed_encoder_bytes(out))
+            self._block = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            rc = lib.gmf_packed_encoder_place(hd.h, out, C.c_void_p(self._block.data_ptr()), nbytes, C.c_void_p(st))
+            if rc != 0:
+                raise RuntimeError(f"gmf_amd: gmf_packed_encoder_place failed (status {rc}): {lib.gmf_last_error_string(hd.h).decode()}")
         sig, sig_d, split, amax = C.c_float(), C.c_float(), C.c_int(), C.c_float()
         lib.gmf_packed_encoder_info(out, C.byref(sig), C.byref(sig_d), C.byref(split), C.byref(amax))
         self.sigma, self.sigma_d = float(sig.value), float(sig_d.value)      # read once here: no per-call host sync

@@ -219,6 +219,8 @@ typedef struct gmf_tensor {
 } gmf_tensor;
 #define GMF_PACK_DEVICE_TENSORS 1     /* `data` pointers are device pointers (copied to the host first) */
 #define GMF_PACK_STANDALONE_BLOCK 2   /* NonLocalBlock on its own (PointDSC.py:40-74): no PointCN in front (identity) */
+#define GMF_PACK_HOST_BLOCK 4         /* [ABI 4] keep the packed block in host memory although h is given (errors then still land in
+                                       * gmf_last_error_string(h)); gmf_packed_*_place moves it to caller-owned device memory */
 typedef struct gmf_packed_encoder gmf_packed_encoder;
 /* Packs NonLocalNet (Fusion-1 if present, layer0, num_layers x {PointCN, NonLocalBlock with its Fusion-2}) + classifier
  * (PointDSC.py:77-181) into ONE library-owned device block on h's device and fills a gmf_encoder_weights that points into it.
@@ -233,6 +235,13 @@ const struct gmf_encoder_weights* gmf_packed_encoder_weights(const gmf_packed_en
  * the largest |value| met while splitting (inf: a weight was not finite).  Any output pointer may be NULL. */
 int gmf_packed_encoder_info(const gmf_packed_encoder* p, float* sigma, float* sigma_d, int* split_fp16, float* max_abs_scaled);
 void gmf_packed_encoder_free(gmf_packed_encoder* p);
+/* [ABI 4] The packed block in CALLER-OWNED device memory (a host that has its own allocator - PyTorch's caching allocator,
+ * an arena - should not get a hipMalloc per pack and a device-wide hipFree per release).  Pack with h = NULL (the blobs stay in host
+ * memory), ask for the size, then place: the block is copied to `device_dst` (256-byte aligned, >= gmf_packed_encoder_bytes, on h's
+ * device) asynchronously on `stream`, and the object's gmf_encoder_weights is re-based to point into it.  The library never frees
+ * `device_dst`; it must outlive every call that uses the weights.  May be called again to move the weights. */
+long long gmf_packed_encoder_bytes(const gmf_packed_encoder* p);
+int gmf_packed_encoder_place(gmf_handle* h, gmf_packed_encoder* p, void* device_dst, long long bytes, gmf_stream_t stream);
 
 /* One FusionLayer / PerceiverIO with depth = 0 (fusion_layer.py:131-201, perceiver_io.py:139-221; widths (128, 64) and
  * (256, 128)): the arguments of gmf_fusion_layer_forward.  `prefix` is prepended to the module's own key names
@@ -248,6 +257,8 @@ int gmf_fusion_pack_weights(gmf_handle* h, const gmf_tensor* tensors, int n_tens
                             gmf_packed_fusion** out);
 const gmf_fusion_weights* gmf_packed_fusion_weights(const gmf_packed_fusion* p);
 void gmf_packed_fusion_free(gmf_packed_fusion* p);
+long long gmf_packed_fusion_bytes(const gmf_packed_fusion* p);                          /* [ABI 4] as gmf_packed_encoder_bytes / _place */
+int gmf_packed_fusion_place(gmf_handle* h, gmf_packed_fusion* p, void* device_dst, long long bytes, gmf_stream_t stream);
 
 /* PointDSC.forward up to the logits (PointDSC.py:216-241) with image TOKENS as input:
  * corr_pos [B,N,6], src/tgt_keypts [B,N,3], p_tokens/q_tokens [B,T,128] (row-major)

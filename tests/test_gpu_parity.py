@@ -580,6 +580,36 @@ def test_pv_fp8_shared_scale_worst_case(log2_ratio):
         assert d < 4e-5, (name, d)          # measured 1.4e-5 (2^14) / 2.3e-5 (2^15); the bound is 2^-10 |v| of the attended key
 
 
+def test_packed_weights_live_in_a_torch_tensor(model, sd_full):
+    """[r4] The packed weights of a module are a torch tensor: gmf_encoder_pack_weights with GMF_PACK_HOST_BLOCK packs on the
+    host, gmf_packed_encoder_place copies the block into caller-owned device memory (here: torch's caching allocator) and re-bases
+    the gmf_encoder_weights - no hipMalloc per pack, no device-wide hipFree from __del__.  Placing the same object a second time
+    moves the weights: the forward from the new block is bit-identical, and the C entry point refuses a short or misaligned block."""
+    import ctypes as C
+    from gmf_amd import _lib
+    b = synthetic.synthetic_batch([71, 72], N=300, T=40)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    res0 = model(data)
+    lg0, T0 = model.last_logits.clone(), res0["final_trans"].clone()
+    pw = model._weights(torch.device(DEV))
+    assert torch.is_tensor(pw._block) and pw._block.is_cuda
+    lib, h = _lib.load_library(), _lib.handle_for(0)
+    nbytes = int(lib.gmf_packed_encoder_bytes(pw._p))
+    assert nbytes == pw._block.numel() * 4 and nbytes > 10_000_000
+    old = pw._block
+    new = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.gmf_packed_encoder_place(h.h, pw._p, C.c_void_p(new.data_ptr() + 4), nbytes, st) == -1            # misaligned
+    assert lib.gmf_packed_encoder_place(h.h, pw._p, C.c_void_p(new.data_ptr()), nbytes - 4, st) == -1           # too small
+    assert lib.gmf_packed_encoder_place(h.h, pw._p, C.c_void_p(new.data_ptr()), nbytes, st) == 0
+    pw._block = new
+    old.fill_(float("nan"))                      # the old block is no longer referenced by the weights
+    res1 = model(data)
+    assert torch.equal(model.last_logits, lg0) and torch.equal(res1["final_trans"], T0)
+    gmf_amd.check_status()
+
+
 def test_q_in_attention_is_bit_identical(model):
     """[r4] gmf_set_tuning("q_in_attention", 1) (default): on large grids k_linear_h2 no longer writes a Q' image - every attention
     workgroup projects the Q' of its own 128 query rows in its prologue (PointDSC.py:56; the same weight stages, the same MFMA

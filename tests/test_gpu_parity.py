@@ -1459,6 +1459,45 @@ def test_tuning_rejects_unknown_and_removed_settings():
     assert h.lib.gmf_set_tuning(h.h, b"compat_cache", 7) == -1
     assert h.lib.gmf_set_tuning(h.h, b"ff_hidden_splits", 3) == -1
     assert h.lib.gmf_set_tuning(h.h, b"scattn_variant", 18) == 0
+    # [r4] gmf_get_tuning: what a caller that changes a knob for one call puts back afterwards (the Python module's numerics mode)
+    import ctypes as C
+    v = C.c_int(-5)
+    for name, default in ((b"scattn_variant", 18), (b"pv_fp8", 1), (b"compat_format", 0), (b"precision", 0), (b"q_in_attention", 1),
+                          (b"mid_grid_roles", 512), (b"topk_select", 1)):
+        assert h.lib.gmf_get_tuning(h.h, name, C.byref(v)) == 0 and v.value == default, (name, v.value)
+    assert h.lib.gmf_set_tuning(h.h, b"compat_format", 2) == 0
+    assert h.lib.gmf_get_tuning(h.h, b"compat_format", C.byref(v)) == 0 and v.value == 2
+    assert h.lib.gmf_set_tuning(h.h, b"compat_format", 0) == 0
+    assert h.lib.gmf_get_tuning(h.h, b"no_such_knob", C.byref(v)) == -1
+    assert h.lib.gmf_get_tuning(h.h, b"pv_fp8", None) == -1
+
+
+def test_module_precision_restores_the_handles_setting(model):
+    """PointDSC.set_precision is module-local - its forward applies the mode for the call and puts back what the HANDLE
+    had (gmf_get_tuning), so a handle-level gmf_set_tuning("precision", ...) survives a forward of a module in another mode; a
+    ragged batch refuses the throughput modes instead of silently running the parity numerics."""
+    import ctypes as C
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    b = synthetic.synthetic_batch([5, 6], N=300, T=40)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    v = C.c_int(-1)
+    try:
+        h.call("gmf_set_tuning", b"precision", 2)              # a handle-level choice made through the C knob
+        model.set_precision("throughput")                      # the module's own mode (level 1)
+        model(data)
+        h.call("gmf_get_tuning", b"precision", C.byref(v))
+        assert v.value == 2
+        with pytest.raises(RuntimeError, match="parity numerics only"):
+            model({k: ([t[0], t[1]] if k in ("corr_pos", "src_keypts", "tgt_keypts") else t) for k, t in data.items()})
+        model.set_precision("parity")
+        model(data)
+        h.call("gmf_get_tuning", b"precision", C.byref(v))
+        assert v.value == 2
+    finally:
+        model.set_precision("parity")
+        h.call("gmf_set_tuning", b"precision", 0)
 
 
 def test_backward_entry_points_reject_bad_arguments():

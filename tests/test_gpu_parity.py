@@ -2470,6 +2470,29 @@ def test_pose_head_beyond_16384(model, N):
     assert float((labels.cpu() == lab).float().mean()) > 0.999
 
 
+def test_full_forward_beyond_16384(model):
+    """[r4] `PointDSC.forward` in test mode with more than 16 384 correspondences per pair (the reference's 3DMatch evaluation feeds every
+    correspondence, evaluation/test_3DMatch.py:143) - a uniform B = 1 call at N = 20 000 and a ragged batch of 16 500 + 17 000: through
+    properties (the oracle's N x N matrices at this size are minutes of CPU; the pose head's new paths have their own oracle comparison,
+    test_pose_head_beyond_16384): finite logits, the pose within 2e-3 of the ground truth, the 25 % inliers found."""
+    b = synthetic.synthetic_batch([77, 78], N=20000, T=196)
+    keys = ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")
+    one = {k: _gpu(b[k][:1]) for k in keys}
+    one["testing"] = True
+    r = model(one)
+    assert torch.isfinite(model.last_logits).all()
+    assert _maxerr(r["final_trans"].cpu(), b["gt_trans"][:1]) < 2e-3
+    assert float(r["final_labels"].sum()) > 0.24 * 20000
+    sizes = [16500, 17000]
+    rag = {k: [_gpu(b[k][i, :n]) for i, n in enumerate(sizes)] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    rag.update(p_tokens=_gpu(b["p_tokens"]), q_tokens=_gpu(b["q_tokens"]), testing=True)
+    r2 = model(rag)
+    assert all(torch.isfinite(lg).all() for lg in r2["logits"])
+    assert _maxerr(r2["final_trans"].cpu(), b["gt_trans"]) < 2e-3
+    assert all(float(lab.sum()) > 0.2 * n for lab, n in zip(r2["final_labels"], sizes))
+    gmf_amd.check_status()
+
+
 @pytest.mark.parametrize("case", ["3dmatch", "kitti", "clustered", "wrapped", "far", "tiny_radius"])
 def test_binned_nms_equals_all_pairs(case):
     """pick_seeds with the grid-binned candidate lists against the all-pairs kernel: the full order (S = N) must be

@@ -379,7 +379,7 @@ def dgr_rows(dev, full):
                  "value": Bd * Nd / (ms * 1e-3), "unit": "correspondences/s",
                  "roofline": {"bound": "hbm", "achieved": wp_bytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                               "frac": wp_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                              "note": "latency-bound: 7 MB per launch - two passes of one workgroup per pair; the HBM figure is what the size implies, not what limits it"}})
+                              "note": "latency-bound: 7 MB per launch, one pass of one workgroup per pair and an fp64 3x3 SVD on one lane, behind ~15 us of host-side call overhead; the HBM figure is what the size implies, not what limits it"}})
     if full:
         ms = best_ms(lambda: gmf_amd.global_registration_batched(X, Y, wts, off, break_threshold_ratio=1e-4, quantization_size=0.1), 5)
         rows.append({"workload": "dgr GlobalRegistration (Adam refinement to convergence), 32 problems x 8000 correspondences", "ms_per_step": ms,

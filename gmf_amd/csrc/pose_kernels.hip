@@ -1382,35 +1382,51 @@ k_rigid_transform(const float* __restrict__ A, const float* __restrict__ Bp, con
 //   w~ = w/(sum|w| + eps); mu = sum w~ p;  Sxy = sum (y-muy)(w~ (x-mux))^T;  Sxy = U D V^T (fp64);
 //   R = U diag(1,1,det(U)det(V)) V^T;  t = muy - R mux.
 // grid (B), block 1024.  offsets [B+1] row offsets into X,Y,w.
+// ONE pass over the points: the raw moments sum|w|, sum w, sum w x, sum w y, sum w y x^T in fp64 (17 sums), from which
+//   Sxy = sum w~ y x^T - (2 - sum w~) muy mux^T
+// exactly as the centred sum expands; in fp64 the cancellation costs (|mu| / spread)^2 of 2^-53 - 1e-12 of the entries for a KITTI
+// scene 100 m from the origin - where the reference's own fp32 sums carry 1e-7.  (Two passes, as the formula is written, are two
+// dependent sweeps of a latency-bound kernel: 9 us more per call at 32 x 8000.)
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
 k_weighted_procrustes(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ w,
                       const int* __restrict__ offsets, float eps, float* __restrict__ Rout, float* __restrict__ tout) {
-  __shared__ double sh[9 * 16];
+  __shared__ double sh[17 * 17];
   const int pair = blockIdx.x;
   const int o0 = offsets[pair], n = offsets[pair + 1] - o0;
   const float* x = X + (size_t)o0 * 3;
   const float* y = Y + (size_t)o0 * 3;
   const float* ww = w + o0;
-  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  double acc[17];
+#pragma unroll
+  for (int k = 0; k < 17; ++k) acc[k] = 0.0;
+#pragma unroll 2
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
     const double wj = ww[j];
+    const double xj[3] = {x[3 * j], x[3 * j + 1], x[3 * j + 2]};
+    const double yj[3] = {y[3 * j], y[3 * j + 1], y[3 * j + 2]};
     acc[0] += fabs(wj);
-    for (int c = 0; c < 3; ++c) { acc[1 + c] += wj * x[3 * j + c]; acc[4 + c] += wj * y[3 * j + c]; }
+    acc[1] += wj;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { acc[2 + c] += wj * xj[c]; acc[5 + c] += wj * yj[c]; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double wy = wj * yj[r];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[8 + 3 * r + c] += wy * xj[c];
+    }
   }
-  block_sum<7>(acc, sh);
-  const double inv = 1.0 / ((double)(float)acc[0] + (double)eps);
-  const double mx[3] = {acc[1] * inv, acc[2] * inv, acc[3] * inv};
-  const double my[3] = {acc[4] * inv, acc[5] * inv, acc[6] * inv};
-  double Sm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    const double wn = ww[j] * inv;
-    double xm[3], ym[3];
-    for (int c = 0; c < 3; ++c) { xm[c] = x[3 * j + c] - mx[c]; ym[c] = y[3 * j + c] - my[c]; }
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Sm[3 * r + c] += ym[r] * (wn * xm[c]);
-  }
-  block_sum<9>(Sm, sh);
+  block_sum_tree<17>(acc, sh);
   if (threadIdx.x == 0) {
+    const double inv = 1.0 / ((double)(float)acc[0] + (double)eps);
+    const double mx[3] = {acc[2] * inv, acc[3] * inv, acc[4] * inv};
+    const double my[3] = {acc[5] * inv, acc[6] * inv, acc[7] * inv};
+    const double k2 = 2.0 - acc[1] * inv;
+    double Sm[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Sm[3 * r + c] = acc[8 + 3 * r + c] * inv - k2 * my[r] * mx[c];
     // kabsch_rotation_from_H(H) returns V D U^T for H = U S V^T; the DGR rotation is its transpose.
     double Rt[9];
     kabsch_rotation_from_H(Sm, Rt);

@@ -931,6 +931,28 @@ def test_weighted_procrustes_ragged_batch(golden_dir):
     R, t = gmf_amd.weighted_procrustes_batched(X, Y, w, np.cumsum([0] + Ns).tolist(), np.finfo(np.float32).eps)
     for i, n in enumerate(Ns):
         assert _maxerr(R[i].cpu(), g[f"R_{n}"]) < 1e-4 and _maxerr(t[i].cpu(), g[f"t_{n}"]) < 1e-4
+    # [r4] the offsets as an int32 device tensor (taken as it is), the same list again (its cached device copy), and what
+    # the host-side check refuses: not from 0, not to N, not increasing, a single entry
+    off = torch.tensor(np.cumsum([0] + Ns), dtype=torch.int32, device=X.device)
+    R2, t2 = gmf_amd.weighted_procrustes_batched(X, Y, w, off, np.finfo(np.float32).eps)
+    R3, t3 = gmf_amd.weighted_procrustes_batched(X, Y, w, np.cumsum([0] + Ns).tolist(), np.finfo(np.float32).eps)
+    assert torch.equal(R2, R) and torch.equal(t2, t) and torch.equal(R3, R) and torch.equal(t3, t)
+    total = int(sum(Ns))
+    for bad in ([1, total], [0, total - 1], [0, 500, 500, total], [0, 600, 500, total], [0]):
+        with pytest.raises(RuntimeError, match="offsets"):
+            gmf_amd.weighted_procrustes_batched(X, Y, w, bad, 1e-7)
+    with pytest.raises(RuntimeError, match="offsets"):
+        gmf_amd.weighted_procrustes_batched(X, Y, w, off.long(), 1e-7)
+    # a scene far from the origin: the one-pass raw moments of k_weighted_procrustes against the centred fp64 sums
+    Xf, Yf = X[:1000] + 250.0, Y[:1000] - 180.0
+    Rf, tf = gmf_amd.weighted_procrustes(Xf, Yf, w[10:1010], 1e-7)
+    Xd, Yd, wd = Xf.double().cpu(), Yf.double().cpu(), w[10:1010].reshape(-1).double().cpu()
+    wn = (wd / (wd.abs().sum() + 1e-7))[:, None]
+    mx, my = (wn * Xd).sum(0), (wn * Yd).sum(0)
+    U, _, Vt = torch.linalg.svd((Yd - my).T @ (wn * (Xd - mx)))
+    D = torch.diag(torch.tensor([1.0, 1.0, float(torch.det(U) * torch.det(Vt))], dtype=torch.float64))
+    Rr = U @ D @ Vt
+    assert _maxerr(Rf.cpu().double(), Rr) < 1e-5 and _maxerr(tf.cpu().double(), my - Rr @ mx) < 1e-3
 
 
 def test_full_size_properties(model):

@@ -40,12 +40,10 @@ def build():
         "  LTL(2);\n  // ---- feed-forward: x2 = x1 + W2 GEGLU(W1 LN(x1) + b1) + b2 --------------------------------------------------------\n")
     rep("  ff_chunks<NP>(nx, y, lds, ff_wst, lvec_f + 2 * C, lvec_f + 2 * C + FFH, wave, lane, h, 0, FFH / 32);\n#pragma unroll\n  for (int mb = 0; mb < 4; ++mb) {\n    float t[16];",
         "  LTL(3);\n  ff_chunks<NP>(nx, y, lds, ff_wst, lvec_f + 2 * C, lvec_f + 2 * C + FFH, wave, lane, h, 0, FFH / 32);\n  LTL(4);\n#pragma unroll\n  for (int mb = 0; mb < 4; ++mb) {\n    float t[16];")
-    # inside the Q'/K/V phase: behind the acquire (wait + barrier + refill issue) and at the end of four stages
-    rep("        f32x16 acc = zero16();\n        mma_wx_h2n<8, NP>(acc, lw, fx);\n        float t[16];\n#pragma unroll\n        for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bqk[which][16 * mb + r]);\n        store_block_h2(dst, mb, t, lane);\n",
-        "        if (sidx >= 2 && sidx < 6) LTL(8 + 3 * (sidx - 2));\n        f32x16 acc = zero16();\n        mma_wx_h2n<8, NP>(acc, lw, fx);\n        if (sidx >= 2 && sidx < 6) LTL(9 + 3 * (sidx - 2));\n        float t[16];\n#pragma unroll\n        for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bqk[which][16 * mb + r]);\n        store_block_h2(dst, mb, t, lane);\n        if (sidx >= 2 && sidx < 6) LTL(10 + 3 * (sidx - 2));\n")
-    rep("      f32x16 acc = zero16();\n      mma_xw_h2n<8, NP>(acc, lw, fx);\n      float t[16];\n#pragma unroll\n      for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bvv[db]);\n",
-        "      if (db < 2) LTL(5 + db);\n      f32x16 acc = zero16();\n      mma_xw_h2n<8, NP>(acc, lw, fx);\n      if (db == 1) LTL(7);\n      float t[16];\n#pragma unroll\n      for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bvv[db]);\n")
-    rep("    ss.prime();                                  // AFTER the loads above", "    LTL(20);\n    ss.prime();                                  // AFTER the loads above")
+    # [r4] inside the cross-attention: behind LCPE + LayerNorm + to_q, behind the context tiles, behind to_out
+    rep("    f32x16 oacc[2];\n    oacc[0] = zero16(); oacc[1] = zero16();\n    float m_run = -INFINITY, l_half = 0.f;\n    for (int t = 0; t < ttiles; ++t) {\n      const f16x8* lk = as_h2(ss.acquire());",
+        "    LTL(5);\n    f32x16 oacc[2];\n    oacc[0] = zero16(); oacc[1] = zero16();\n    float m_run = -INFINITY, l_half = 0.f;\n    for (int t = 0; t < ttiles; ++t) {\n      const f16x8* lk = as_h2(ss.acquire());")
+    rep("    FragH2<4> ox;\n    {\n      const float inv = 1.0f / xhalf_sum(l_half);", "    LTL(6);\n    FragH2<4> ox;\n    {\n      const float inv = 1.0f / xhalf_sum(l_half);")
     a = text.index("// k_linear_h2: every linear stage of one encoder layer in ONE pass")
     pre = ('__device__ unsigned long long g_ltl[24];\n'
            '#define LTL(k) do { asm volatile("s_nop 0" ::: "memory"); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) '
@@ -90,19 +88,13 @@ def run(B, N, pv=1):
     lib.gmf_dbg_linear_timeline.argtypes = [C.POINTER(C.c_ulonglong)]
     assert lib.gmf_dbg_linear_timeline(buf) == 0
     v = list(buf)
-    names = ["Q'/K/V projections (12 stages, 288 MFMAs)", "cross-attention (LCPE, LN, to_q, 7 context tiles, to_out; ~300 MFMAs)",
+    names = ["K/V projections (8 stages, 192 MFMAs; Q' is projected by the attention kernel)", "cross-attention (LCPE, LN, to_q, 7 context tiles, to_out; ~300 MFMAs)",
              "LayerNorm + residual seed of the feed-forward", "GEGLU feed-forward (48 stages, 1152 MFMAs)"]
     print(f"B={B} N={N} pv_fp8={pv}: k_linear_h2, wave 0 of workgroup (0, 0), last launch; core-clock cycles")
     for k, nm in enumerate(names):
         print(f"  {nm:76s} {v[k + 1] - v[k]:8d}")
     print(f"  {'total':76s} {v[4] - v[0]:8d}")
-    print("  inside the Q'/K/V phase, stages 2..5: [previous stage end -> behind acquire] | 24 MFMAs (768 pipe cycles) | bias, split, 4 stores")
-    for k in range(4):
-        a0, a1, a2 = v[8 + 3 * k], v[9 + 3 * k], v[10 + 3 * k]
-        prev = v[10 + 3 * (k - 1)] if k > 0 else 0
-        print(f"    stage {k + 2}: {(a0 - prev) if prev else -1:6d} | {a1 - a0:6d} | {a2 - a1:6d}")
-    print(f"  start -> prime (f fragment, biases): {v[20] - v[0]}; prime -> stage 2 behind its acquire: {v[8] - v[20]}; stage 5 end -> V stage 0 behind its acquire: {v[5] - v[19]};"
-          f" V stage 0 (acquire of stage 1 included): {v[6] - v[5]}; V stage 1 MFMAs: {v[7] - v[6]}; V stage 1 end .. phase end (2 V stages + scale store): {v[1] - v[7]}")
+    print(f"  inside the cross-attention: LCPE + LayerNorm + to_q + residual seed {v[5] - v[1]}, 7 context tiles {v[6] - v[5]}, normalise + to_out {v[2] - v[6]}")
 
 
 if __name__ == "__main__":

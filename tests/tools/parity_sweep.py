@@ -1,5 +1,7 @@
 """Randomised parity sweep: HIP path vs the CPU oracle over many seeded scenes and sizes (logits and final pose).
-GPU box:  python tests/tools/parity_sweep.py [n_scenes]"""
+GPU box:  python tests/tools/parity_sweep.py [n_scenes] [--kitti]
+--kitti: the reference's KITTI configuration (sigma_d = tau = nms_radius = 1.2, evaluation/test_KITTI.py:219) on +-40 m scenes with
+the CONDITIONED weight set (synthetic.kitti_conditioned, golden F22) - the configuration in which config 3 is held to the literal 1e-4."""
 import os, sys, time
 import numpy as np
 import torch
@@ -8,10 +10,20 @@ import gmf_amd
 from gmf_amd import synthetic
 from oracle import gmf_oracle as O
 
-n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+KITTI = "--kitti" in sys.argv
+pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+n_scenes = int(pos[0]) if pos else 40
 dev = torch.device("cuda:0")
 sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7)
-model = gmf_amd.PointDSC(num_layers=12); model.load_state_dict(sd, strict=False); model = model.to(dev).eval()
+SIG = 0.1
+if KITTI:
+    sd = synthetic.kitti_conditioned(synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7, sigma_d=1.2))
+    SIG = 1.2
+    model = gmf_amd.PointDSC(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1, inlier_threshold=1.2, sigma_d=1.2,
+                             k=40, nms_radius=1.2)
+else:
+    model = gmf_amd.PointDSC(num_layers=12)
+model.load_state_dict(sd, strict=False); model = model.to(dev).eval()
 rng = np.random.default_rng(2024)
 torch.set_num_threads(16)
 errs, terrs, rows = [], [], []
@@ -21,14 +33,15 @@ t0 = time.time()
 for s in range(n_scenes):
     N = int(rng.choice([64, 200, 333, 500, 777, 1000, 1500, 2048, 3000]))
     T = int(rng.choice([40, 196, 300]))
-    b = synthetic.synthetic_batch([1000 + s], N=N, T=T)
-    ref = O.pointdsc_forward(sd, b, testing=True)
+    b = synthetic.synthetic_batch([1000 + s], N=N, T=T, kind="kitti" if KITTI else "3dmatch")
+    ref = (O.pointdsc_forward(sd, b, testing=True, inlier_threshold=1.2, nms_radius=1.2) if KITTI
+           else O.pointdsc_forward(sd, b, testing=True))
     data = {k: b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
     data["testing"] = True
     res = model(data)
     e = float((model.last_logits.cpu() - ref["logits"]).abs().max())
     b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in b.items()}
-    compat64, _ = O.compat_matrix(b64["src_keypts"], b64["tgt_keypts"], 0.1)
+    compat64, _ = O.compat_matrix(b64["src_keypts"], b64["tgt_keypts"], SIG)
     truth = O.classifier(sd64, O.encoder(sd64, b64["corr_pos"], compat64, b64["p_tokens"], b64["q_tokens"], 12))
     err64_hip.append(float((model.last_logits.cpu().double() - truth).abs().max()))
     err64_ref.append(float((ref["logits"].double() - truth).abs().max()))
@@ -39,7 +52,7 @@ for s in range(n_scenes):
     src = b["src_keypts"]
     sdist = torch.norm(src[:, :, None, :] - src[:, None, :, :], dim=-1)
     lgr = ref["logits"]
-    is_max = torch.all((lgr[:, :, None] >= lgr[:, None, :]) | (sdist >= 0.10), dim=-1)
+    is_max = torch.all((lgr[:, :, None] >= lgr[:, None, :]) | (sdist >= (1.2 if KITTI else 0.10)), dim=-1)
     n_pos = int(((lgr > 0) & is_max).sum())
     tie = n_pos < int(N * 0.1)
     errs.append(e); terrs.append(te); rows.append((N, T, e, te, tie))

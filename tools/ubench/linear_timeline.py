@@ -45,14 +45,17 @@ def build():
         "    LTL(5);\n    f32x16 oacc[2];\n    oacc[0] = zero16(); oacc[1] = zero16();\n    float m_run = -INFINITY, l_half = 0.f;\n    for (int t = 0; t < ttiles; ++t) {\n      const f16x8* lk = as_h2(ss.acquire());")
     rep("    FragH2<4> ox;\n    {\n      const float inv = 1.0f / xhalf_sum(l_half);", "    LTL(6);\n    FragH2<4> ox;\n    {\n      const float inv = 1.0f / xhalf_sum(l_half);")
     a = text.index("// k_linear_h2: every linear stage of one encoder layer in ONE pass")
-    pre = ('__device__ unsigned long long g_ltl[24];\n'
-           '#define LTL(k) do { asm volatile("s_nop 0" ::: "memory"); if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) '
-           'g_ltl[k] = __builtin_readcyclecounter(); asm volatile("s_nop 0" ::: "memory"); } while (0)\n')
+    # [r4] sixteen workgroups over the grid (blockIdx.x in {0, 10, 20, 30} x blockIdx.y in {0, 8, 16, 24}), wave 0 of each; slot 23 of a
+    # workgroup's row = the wall clock (s_memrealtime, 100 MHz) at its start, which orders the workgroups in time
+    pre = ('__device__ unsigned long long g_ltl[16 * 24];\n'
+           '#define LTL(k) do { asm volatile("s_nop 0" ::: "memory"); if (blockIdx.x % 10 == 0 && blockIdx.y % 8 == 0 && threadIdx.x == 0) { '
+           'const int wg_ = (blockIdx.y / 8) * 4 + blockIdx.x / 10; g_ltl[wg_ * 24 + (k)] = __builtin_readcyclecounter(); '
+           'if ((k) == 0) g_ltl[wg_ * 24 + 23] = __builtin_amdgcn_s_memrealtime(); } asm volatile("s_nop 0" ::: "memory"); } while (0)\n')
     text = text[:a] + pre + text[a:]
     text = text.rstrip()
     assert text.endswith("}  // namespace gmf")
     text = text[:-len("}  // namespace gmf")] + ('}  // namespace gmf\nextern "C" int gmf_dbg_linear_timeline(unsigned long long* out) {\n'
-                                               '  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gmf::g_ltl), 24 * sizeof(unsigned long long));\n}\n')
+                                               '  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gmf::g_ltl), 16 * 24 * sizeof(unsigned long long));\n}\n')
     open(path, "w").write(text)
     obj = os.path.join(work, "encoder_h2.o")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
@@ -84,17 +87,17 @@ def run(B, N, pv=1):
         model(data)
     torch.cuda.synchronize()
     lib = _lib.handle_for(0).lib
-    buf = (C.c_ulonglong * 24)()
+    buf = (C.c_ulonglong * (16 * 24))()
     lib.gmf_dbg_linear_timeline.argtypes = [C.POINTER(C.c_ulonglong)]
     assert lib.gmf_dbg_linear_timeline(buf) == 0
-    v = list(buf)
-    names = ["K/V projections (8 stages, 192 MFMAs; Q' is projected by the attention kernel)", "cross-attention (LCPE, LN, to_q, 7 context tiles, to_out; ~300 MFMAs)",
-             "LayerNorm + residual seed of the feed-forward", "GEGLU feed-forward (48 stages, 1152 MFMAs)"]
-    print(f"B={B} N={N} pv_fp8={pv}: k_linear_h2, wave 0 of workgroup (0, 0), last launch; core-clock cycles")
-    for k, nm in enumerate(names):
-        print(f"  {nm:76s} {v[k + 1] - v[k]:8d}")
-    print(f"  {'total':76s} {v[4] - v[0]:8d}")
-    print(f"  inside the cross-attention: LCPE + LayerNorm + to_q + residual seed {v[5] - v[1]}, 7 context tiles {v[6] - v[5]}, normalise + to_out {v[2] - v[6]}")
+    allv = list(buf)
+    rows = [allv[24 * w: 24 * w + 24] for w in range(16)]
+    t0 = min(r[23] for r in rows)
+    print(f"B={B} N={N} pv_fp8={pv}: k_linear_h2, wave 0 of sixteen workgroups of the last launch; core-clock cycles per phase")
+    print("  wg (x, y)   start us |   K/V proj | LCPE+LN+to_q | ctx tiles | to_out | FF seed |     FF |   total")
+    for w, v in sorted(enumerate(rows), key=lambda e: e[1][23]):
+        print(f"  ({10 * (w % 4):2d}, {8 * (w // 4):2d})   {(v[23] - t0) / 100.0:8.1f} | {v[1] - v[0]:10d} | {v[5] - v[1]:12d} | {v[6] - v[5]:9d} | {v[2] - v[6]:6d} | "
+              f"{v[3] - v[2]:7d} | {v[4] - v[3]:6d} | {v[4] - v[0]:7d}")
 
 
 if __name__ == "__main__":

@@ -808,7 +808,7 @@ constexpr int kKMax = 64;
 // neighbours' unit features as two 32-row fragments from the row-major features (no LDS staging) and forms G00, G01, G11
 // (G10 = G01^T) with 24 MFMAs each; lane (h, b) then owns column b of each tile and turns the dot products into
 // M entries together with the spatial term.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 3)     // [r4] <= 168 registers: three waves per SIMD for a kernel that is one latency chain per wave (180 registers, two waves: 195 us)
 k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, const float* __restrict__ tgt,
              const int* __restrict__ knn_idx, float* __restrict__ snaps, unsigned char* __restrict__ conv,
              double* __restrict__ hsum, int N, int S, int k, int iters, float inv_sigma2, float inv_sigmad2,
@@ -874,6 +874,8 @@ k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, co
     const float btx = P[b * 8 + 4], bty = P[b * 8 + 5], btz = P[b * 8 + 6];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      // [r4] register groups whose rows all lie beyond k hold nothing (uniform: at k = 40 the tiles of rows 32.. keep one group of four)
+      if ((r & 3) == 0 && 32 * ta + 8 * (r >> 2) >= k) break;
       const int ar = 32 * ta + 8 * (r >> 2) + 4 * h + (r & 3);
       const float mf = fmaxf(1.0f - (1.0f - g[r]) * inv_sigma2, 0.f);
       const float ax = P[ar * 8] - bsx, ay = P[ar * 8 + 1] - bsy, az = P[ar * 8 + 2] - bsz;
@@ -899,10 +901,18 @@ k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, co
     emit_tile(g, 0, 0, false);
   }
   if (k > 32) {
+    // [r4] the off-diagonal block as G10 = F_b F_a^T (rows 32 .., columns 0 .. 31) instead of G01: its k - 32 valid rows are one or
+    // two register groups on ALL 64 lanes, where G01's k - 32 valid columns were 16 registers on a quarter of the lanes - at
+    // k = 40 a seed's 48 matrix entries per lane (~38 vector instructions each) become 24.  Same products in the same order (the
+    // operands of each MFMA change places, the three partial products keep their sequence): every entry is bit-identical.
     gmf::f32x16 g = gmf::zero16();
 #pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8) gmf::mma3(g, ah[s8], al[s8], bh[s8], bl[s8]);
-    emit_tile(g, 0, 1, true);
+    for (int s8 = 0; s8 < 8; ++s8) {
+      g = gmf::mfma_h16(bh[s8], al[s8], g);
+      g = gmf::mfma_h16(bl[s8], ah[s8], g);
+      g = gmf::mfma_h16(bh[s8], ah[s8], g);
+    }
+    emit_tile(g, 1, 0, true);
     g = gmf::zero16();
 #pragma unroll
     for (int s8 = 0; s8 < 8; ++s8) gmf::mma3(g, bh[s8], bl[s8], bh[s8], bl[s8]);

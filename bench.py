@@ -384,6 +384,17 @@ def dgr_rows(dev, full):
         ms = best_ms(lambda: gmf_amd.global_registration_batched(X, Y, wts, off, break_threshold_ratio=1e-4, quantization_size=0.1), 5)
         rows.append({"workload": "dgr GlobalRegistration (Adam refinement to convergence), 32 problems x 8000 correspondences", "ms_per_step": ms,
                      "value": Bd * Nd / (ms * 1e-3), "unit": "correspondences/s"})
+    # row f-2: descriptor nearest-neighbour matching, the step that produces the putative correspondences (ThreeDMatch.py:164-166):
+    # fused distance GEMM on the f32 MFMA (exact f32 products) + row argmin, nothing of size N x N written
+    Nm, dm = 5000, 32
+    fa = torch.nn.functional.normalize(torch.randn(Nm, dm, device=dev), dim=1)
+    fb = torch.nn.functional.normalize(torch.randn(Nm, dm, device=dev), dim=1)
+    ms = best_ms(lambda: gmf_amd.nn_match(fa, fb), 20)
+    tf = 2.0 * dm * Nm * Nm / (ms * 1e-3) / 1e12
+    rows.append({"workload": f"descriptor matching (row f-2), {Nm} x {Nm} descriptors x {dm}-d, whole call (two packing launches, norms, match, winners)",
+                 "ms_per_step": ms, "value": Nm / (ms * 1e-3), "unit": "source descriptors/s", "algorithmic_tflops": tf,
+                 "roofline": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                              "note": "f32 MFMA dense peak (v_mfma_f32_32x32x2_f32); the match kernel alone is 22 us of the call"}})
     pio = gmf_amd.PerceiverIO(depth=0, dim=128, latent_dim=256, cross_heads=1, latent_heads=8, cross_dim_head=128,
                               latent_dim_head=64, pe=True).to(dev).eval()
     for M in ((1000, 4000, 20000) if full else (20000,)):

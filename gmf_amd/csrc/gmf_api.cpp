@@ -936,11 +936,12 @@ int gmf_nn_match(gmf_handle* h, const float* F0, const float* F1, int N0, int N1
   GMF_REQUIRE(K > 0, GMF_ERR_UNSUPPORTED_SHAPE, "nn_match: descriptor width above 128 is not supported");
   SetDevice sd(h, stream);
   const size_t n0 = (size_t)tiles_of(N0) * 32 * K, n1 = (size_t)tiles_of(N1) * 32 * K + 4096;
-  if (int rc = arena_reserve(h, arena_need(n0, 4) + arena_need(n1, 4) + arena_need((size_t)N1, 4))) return rc;
+  if (int rc = arena_reserve(h, arena_need(n0, 4) + arena_need(n1, 4) + arena_need((size_t)tiles_of(N1) * 32, 4) + arena_need((size_t)N0, 8))) return rc;
   float* i0 = arena_take<float>(h, n0);
   float* i1 = arena_take<float>(h, n1);      // + one stage of slack: the last stage may be read past the final tile
-  float* nb = arena_take<float>(h, (size_t)N1);
-  GMF_HIP(gmf::launch_nn_match(F0, F1, i0, i1, nb, idx_out, dist_out, N0, N1, d, mode, S(stream)));
+  float* nb = arena_take<float>(h, (size_t)tiles_of(N1) * 32);       // whole tiles: the padding holds +inf
+  unsigned long long* best = arena_take<unsigned long long>(h, (size_t)N0);     // (score, index) of every row's winner: one atomic minimum per key split
+  GMF_HIP(gmf::launch_nn_match(F0, F1, i0, i1, nb, best, idx_out, dist_out, N0, N1, d, mode, S(stream)));
   return GMF_OK;
 }
 

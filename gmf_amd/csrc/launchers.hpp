@@ -125,7 +125,7 @@ hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, 
 hipError_t launch_fusion_ff_h2(const Tuning& tune, const float* x1, const float* wst, const float* vecs, float* x2, int B,
                                int tiles, hipStream_t s, float* part = nullptr, int max_parts = 0);
 int padded_desc_width(int d);
-hipError_t launch_nn_match(const float* F0, const float* F1, float* f0_img, float* f1_img, float* norm2, int* idx,
+hipError_t launch_nn_match(const float* F0, const float* F1, float* f0_img, float* f1_img, float* norm2, unsigned long long* best, int* idx,
                            float* dist, int N0, int N1, int d, int mode, hipStream_t s);
 hipError_t launch_seed_dist(const float* featn_img, const int* seeds, float* dist, int B, int N, int S, hipStream_t s, const PairTab* ptab = nullptr);
 hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s, const PairTab* ptab = nullptr);

@@ -921,9 +921,38 @@ int gmf_knn_rows(gmf_handle* h, const float* feat_n, const int* rows, int B, int
                  gmf_stream_t stream) {
   GMF_REQUIRE(h && feat_n && rows && knn_out, GMF_ERR_BAD_ARG, "knn_rows: null pointer");
   GMF_REQUIRE(B > 0 && N > 1 && Sn > 0 && k > 0 && k <= N - 1, GMF_ERR_UNSUPPORTED_SHAPE, "knn_rows: need 0 < k <= N-1");
-  GMF_REQUIRE((size_t)N * 4 <= 150 * 1024, GMF_ERR_UNSUPPORTED_SHAPE, "knn_rows: N too large for the in-LDS kNN (max 38400)");
   SetDevice sd(h, stream);
-  GMF_HIP(gmf::launch_knn_seeds(feat_n, rows, nullptr, knn_out, B, N, Sn, k, S(stream)));
+  hipStream_t st = S(stream);
+  if (k > 63) {            // (the selection kernels behind the distance rows rank up to 64 candidates: larger k keeps the in-LDS kNN)
+    GMF_REQUIRE((size_t)N * 4 <= 150 * 1024, GMF_ERR_UNSUPPORTED_SHAPE, "knn_rows: k > 63 needs N <= 38400 (the in-LDS kNN)");
+    GMF_HIP(gmf::launch_knn_seeds(feat_n, rows, nullptr, knn_out, B, N, Sn, k, st));
+    return GMF_OK;
+  }
+  // [r4] the pose head's own path (common.py:53-75 is what both compute): the rows' distances to every row of their pair by
+  // MFMA (k_seed_dist on the split-fp16 feature image) and a threshold selection per row - 8 x 5000 x 5000: 10.7 ms -> below 1 ms
+  // against one workgroup per row forming its distance row with vector instructions.  The distance rows are Sn x N floats per
+  // pair: above 4 GiB the rows go through in slices, pair by pair.
+  const int tiles = tiles_of(N);
+  const size_t ld = (size_t)tiles * 32;
+  const size_t cap = (size_t)1 << 30;                           // floats
+  const bool whole = (size_t)B * Sn * ld <= cap;
+  const int slice = whole ? Sn : (int)std::max<size_t>(1, std::min<size_t>((size_t)Sn, cap / ld));
+  if (int rc = arena_reserve(h, arena_need((size_t)B * tiles * kTileFloats, 4) + arena_need((size_t)(whole ? B : 1) * slice * ld, 4))) return rc;
+  float* fimg = arena_take<float>(h, (size_t)B * tiles * kTileFloats);
+  float* dmat = arena_take<float>(h, (size_t)(whole ? B : 1) * slice * ld);
+  GMF_HIP(gmf::launch_pack_rows_h2(feat_n, fimg, B, N, st, nullptr));
+  if (whole) {
+    GMF_HIP(gmf::launch_seed_dist(fimg, rows, dmat, B, N, Sn, st, nullptr));
+    GMF_HIP(gmf::launch_knn_seeds(feat_n, rows, dmat, knn_out, B, N, Sn, k, st, nullptr));
+    return GMF_OK;
+  }
+  for (int b = 0; b < B; ++b)
+    for (int r0 = 0; r0 < Sn; r0 += slice) {
+      const int n = std::min(slice, Sn - r0);
+      const int* rb = rows + (size_t)b * Sn + r0;
+      GMF_HIP(gmf::launch_seed_dist(fimg + (size_t)b * tiles * kTileFloats, rb, dmat, 1, N, n, st, nullptr));
+      GMF_HIP(gmf::launch_knn_seeds(feat_n + (size_t)b * N * 128, rb, dmat, knn_out + ((size_t)b * Sn + r0) * k, 1, N, n, k, st, nullptr));
+    }
   return GMF_OK;
 }
 

@@ -342,7 +342,8 @@ int gmf_pick_seeds(gmf_handle* h, const float* src_keypts, const float* scores, 
 
 /* knn(x, k, ignore_self=True, normalized=True) restricted to the rows listed in `rows` [B,S]
  * (models/common.py:53-75 followed by the gather at PointDSC.py:327-329): feat_n [B,N,128] unit rows
- * -> knn_out [B,S,k] int32, nearest first, the row itself (rank 0) dropped. */
+ * -> knn_out [B,S,k] int32, nearest first, the row itself (rank 0) dropped.  Any N for k <= 63 (the rows' distances come from the
+ * matrix pipe, in slices of at most 4 GiB; workspace: the handle's arena); k > 63 keeps the in-LDS form (N <= 38400). */
 int gmf_knn_rows(gmf_handle* h, const float* feat_n, const int* rows, int B, int N, int S, int k, int* knn_out,
                  gmf_stream_t stream);
 

@@ -2492,6 +2492,28 @@ def test_pose_head_beyond_16384(model, N):
     assert float((labels.cpu() == lab).float().mean()) > 0.999
 
 
+def test_public_knn_op():
+    """[r4] `gmf_amd.knn` (models/common.py:53-75; the op behind PointDSC.py:327) on its own: since round 4 it runs the pose head's path
+    (MFMA distance rows + threshold selection) instead of one workgroup per row.  Against the oracle's 2 - 2 x x^T top-(k + 1) on
+    unit rows: the same neighbour SETS (ties and rounding at the k-th distance aside) and the same order for nearly every row; the
+    sliced form (distance rows above 4 GiB go through pair by pair) against the whole form, exactly."""
+    g = torch.Generator().manual_seed(5)
+    for B, N, k in ((2, 777, 40), (1, 5000, 40), (3, 100, 10), (1, 17000, 40)):
+        x = torch.nn.functional.normalize(torch.randn(B, N, 128, generator=g), dim=-1)
+        got = gmf_amd.knn(_gpu(x), k, ignore_self=True, normalized=True).cpu()
+        ref = O.knn_indices(x, k)
+        assert got.shape == ref.shape and int(got.min()) >= 0 and int(got.max()) < N
+        same_set = (torch.sort(got, -1)[0] == torch.sort(ref, -1)[0]).float().mean()
+        same_seq = (got == ref).float().mean()
+        assert same_set > 0.999 and same_seq > 0.995, (B, N, float(same_set), float(same_seq))
+        assert not (got == torch.arange(N)[None, :, None]).any()          # the row itself is dropped
+    x = _gpu(torch.nn.functional.normalize(torch.randn(3, 20000, 128, generator=g), dim=-1))
+    sliced = gmf_amd.knn(x, 40, ignore_self=True, normalized=True)       # 3 x 20000 x 20000 floats > 4 GiB: slices
+    for b in range(3):
+        assert torch.equal(sliced[b:b + 1], gmf_amd.knn(x[b:b + 1], 40, ignore_self=True, normalized=True))
+    gmf_amd.check_status()
+
+
 def test_full_forward_beyond_16384(model):
     """[r4] `PointDSC.forward` in test mode with more than 16 384 correspondences per pair (the reference's 3DMatch evaluation feeds every
     correspondence, evaluation/test_3DMatch.py:143) - a uniform B = 1 call at N = 20 000 and a ragged batch of 16 500 + 17 000: through

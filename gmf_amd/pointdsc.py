@@ -164,14 +164,70 @@ class _FusedResNet:
 
 class ImageEncoder(nn.Module):
     """Keys match `encoder.image_encoder.backbone.{conv1,bn1,layer1,layer2}.*`; the reference's unused
-    layer3/layer4/fc entries are ignored by the non-strict loads it uses (evaluation/test_3DMatch.py:262)."""
+    layer3/layer4/fc entries are ignored by the non-strict loads it uses (evaluation/test_3DMatch.py:262).
+
+    forward(image [B,3,H,W]) -> [B,128,H',W'] (models/resnet.py:195-216).  On a HIP device in eval mode the pass runs as
+    `_FusedResNet` (BatchNorms folded, NHWC, the fused stem kernel and the native layer1 / layer2 convolutions) and, per input
+    shape, as a captured HIP graph (~75 launches of a few microseconds of work each; `graph = False` keeps it eager).  In
+    train() mode it is the stock torch module (it trains as one: DESIGN section 7)."""
+
+    graph = True
 
     def __init__(self):
         super().__init__()
         self.backbone = _ResNet34ToLayer2(3)
 
+    def fused(self):
+        """eval-mode form of the ResNet: every BatchNorm folded into its convolution, weights and activations NHWC, and the
+        bias + residual + ReLU that follow each MIOpen convolution done by one HIP pass (`gmf_bias_relu_nhwc`) instead of
+        three element-wise kernels.  Rebuilt when the weights change."""
+        ver = params_version(self)
+        if getattr(self, "_fused_version", None) != ver:
+            object.__setattr__(self, "_fused", _FusedResNet(self.backbone))   # not a sub-module: keeps the state_dict surface
+            self._fused_version = ver
+        return self._fused
+
     def forward(self, x):
-        return self.backbone(x)
+        if self.training or not x.is_cuda:
+            return self.backbone(x)
+        enc = self.fused()
+        return self._graphed(enc, x) if self.graph else enc(x)
+
+    def _graphed(self, enc, image):
+        key = (tuple(image.shape), tuple(image.stride()), image.device, self._fused_version)
+        cache = self.__dict__.setdefault("_graphs", {})
+        ent = cache.get(key)
+        if ent is None:
+            static_in = image.detach().clone()
+            with torch.no_grad():
+                for _ in range(2):                       # MIOpen picks its algorithms and workspaces outside the capture
+                    enc(static_in)                       # (a kernel or shape error surfaces here, eagerly, as itself)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(g):
+                        static_out = enc(static_in)
+                    ent = (g, static_in, static_out)
+                except RuntimeError as e:
+                    # Only "this operation cannot be captured" (hipErrorStreamCapture*: a library call inside the pass that
+                    # allocates or synchronises) keeps the pass eager - said once per shape; anything else is a real error.
+                    msg = str(e)
+                    if "capture" not in msg.lower():
+                        raise
+                    import warnings
+                    warnings.warn(f"gmf_amd: HIP-graph capture of the image encoder failed for input {tuple(image.shape)} "
+                                  f"({msg.splitlines()[0]}); running it eagerly.", RuntimeWarning)
+                    torch.cuda.synchronize()
+                    ent = False
+            if len(cache) > 8:
+                cache.clear()
+            cache[key] = ent
+        if ent is False:
+            return enc(image)
+        g, static_in, static_out = ent
+        static_in.copy_(image)
+        g.replay()
+        return static_out.clone()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -252,64 +308,20 @@ class NonLocalNet(nn.Module):
             self.blocks[f"NonLocal_layer_{i}"] = NonLocalBlock(c)
 
     def _fused_image_encoder(self):
-        """eval-mode form of the ResNet: every BatchNorm folded into its convolution, weights and activations NHWC, and the
-        bias + residual + ReLU that follow each MIOpen convolution done by one HIP pass (`gmf_bias_relu_nhwc`) instead of
-        three element-wise kernels.  Rebuilt when the weights change."""
-        ver = params_version(self.image_encoder)
-        if getattr(self, "_img_fused_version", None) != ver:
-            object.__setattr__(self, "_img_fused", _FusedResNet(self.image_encoder.backbone))   # not a sub-module: keeps the state_dict surface
-            self._img_fused_version = ver
-        return self._img_fused
+        """The image encoder's eval-mode form (`ImageEncoder.fused`)."""
+        return self.image_encoder.fused()
+
+    @property
+    def graph_image_encoder(self):
+        return self.image_encoder.graph
+
+    @graph_image_encoder.setter
+    def graph_image_encoder(self, v):
+        self.image_encoder.graph = bool(v)
 
     def image_tokens(self, image):
-        """[B,3,H,W] -> [B,H'*W',128] (PointDSC.py:129-131).
-
-        On a HIP device in eval mode the encoder runs with folded BatchNorms and, per input shape, as a captured HIP graph
-        (the pass is ~75 launches of a few microseconds of work each; `graph_image_encoder = False` keeps it eager)."""
-        if self.training or not image.is_cuda:
-            f = self.image_encoder(image)
-        else:
-            enc = self._fused_image_encoder()
-            f = self._graphed_encoder(enc, image) if self.graph_image_encoder else enc(image)
-        return f.flatten(2).permute(0, 2, 1).contiguous()
-
-    graph_image_encoder = True
-
-    def _graphed_encoder(self, enc, image):
-        key = (tuple(image.shape), tuple(image.stride()), image.device, self._img_fused_version)
-        cache = self.__dict__.setdefault("_img_graphs", {})
-        ent = cache.get(key)
-        if ent is None:
-            static_in = image.detach().clone()
-            with torch.no_grad():
-                for _ in range(2):                       # MIOpen picks its algorithms and workspaces outside the capture
-                    enc(static_in)                       # (a kernel or shape error surfaces here, eagerly, as itself)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                try:
-                    with torch.cuda.graph(g):
-                        static_out = enc(static_in)
-                    ent = (g, static_in, static_out)
-                except RuntimeError as e:
-                    # Only "this operation cannot be captured" (hipErrorStreamCapture*: a library call inside the pass that
-                    # allocates or synchronises) keeps the pass eager - said once per shape; anything else is a real error.
-                    msg = str(e)
-                    if "capture" not in msg.lower():
-                        raise
-                    import warnings
-                    warnings.warn(f"gmf_amd: HIP-graph capture of the image encoder failed for input {tuple(image.shape)} "
-                                  f"({msg.splitlines()[0]}); running it eagerly.", RuntimeWarning)
-                    torch.cuda.synchronize()
-                    ent = False
-            if len(cache) > 8:
-                cache.clear()
-            cache[key] = ent
-        if ent is False:
-            return enc(image)
-        g, static_in, static_out = ent
-        static_in.copy_(image)
-        g.replay()
-        return static_out.clone()
+        """[B,3,H,W] -> [B,H'*W',128] (PointDSC.py:129-131); the encoder itself picks its form (`ImageEncoder.forward`)."""
+        return self.image_encoder(image).flatten(2).permute(0, 2, 1).contiguous()
 
 
 class PointDSC(nn.Module):

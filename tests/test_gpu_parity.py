@@ -1211,6 +1211,12 @@ def test_f11_image_tokens_small_batch(golden_dir, graph):
     scale = max(1.0, float(np.abs(g["tokens"]).max()))
     assert _maxerr(tok.cpu(), g["tokens"]) < 1e-4 * scale
     assert _maxerr(tok.cpu(), tok2.cpu()) < 1e-5 * scale     # (MIOpen's small-batch kernels are not bitwise repeatable)
+    # [r4] the module on its own (`gmf_amd.ImageEncoder.forward`, resnet.py:195-216) takes the same fused path in eval mode - it
+    # used to run the stock torch modules there; [B, 128, H', W'] as the reference returns it
+    with torch.no_grad():
+        fmap = m.encoder.image_encoder(_gpu(img))
+    assert fmap.shape == (2, 128, 15, 20)
+    assert _maxerr(fmap.flatten(2).permute(0, 2, 1).cpu(), g["tokens"]) < 1e-4 * scale
 
 
 @pytest.mark.parametrize("tag,graph,patch", [("64x120x160", True, 1), ("64x120x160", False, 1), ("64x120x160", False, 2),

@@ -1290,6 +1290,39 @@ def test_descriptor_matching_full_size():
     assert float(dis.max()) < 0.3
 
 
+def test_descriptor_matching_key_splits_and_edges():
+    """[r4] `k_nn_match` splits the keys over workgroups and folds the winners with a 64-bit atomic minimum of (ordered score, index):
+    against torch's own argmin of the reference formula (ThreeDMatch.py:164-166) over sizes that give 1 .. 16 key splits and every
+    padded width; duplicated target rows (equal scores: the FIRST index wins, as torch.argmin's); a single source row; more source
+    than target rows; a source row of NaN (no winner: index 0, distance NaN - and nothing out of range)."""
+    g = torch.Generator().manual_seed(12)
+    for N0, N1, d in ((1, 7, 32), (130, 64, 32), (777, 3000, 33), (3000, 500, 64), (2000, 9000, 128), (5000, 5000, 5)):
+        F0 = torch.nn.functional.normalize(torch.randn(N0, d, generator=g), dim=1)
+        F1 = torch.nn.functional.normalize(torch.randn(N1, d, generator=g), dim=1)
+        idx, dis = gmf_amd.nn_match(_gpu(F0), _gpu(F1))
+        dist = torch.sqrt(2 - 2 * (F0.double() @ F1.double().T) + 1e-6)
+        ref = dist.argmin(1)
+        got = idx.cpu()
+        # a different winner is only acceptable where fp32 cannot tell the two distances apart
+        diff = got != ref
+        if diff.any():
+            rows = diff.nonzero()[:, 0]
+            assert float((dist[rows, got[rows]] - dist[rows, ref[rows]]).abs().max()) < 2e-6, (N0, N1, d)
+        assert float(diff.float().mean()) < 2e-3
+        assert _maxerr(dis.cpu().double(), dist[torch.arange(N0), got]) < 1e-5
+    F1 = torch.nn.functional.normalize(torch.randn(900, 32, generator=g), dim=1)
+    F1d = torch.cat([F1, F1, F1])                                   # every target row three times: rows j, j + 900, j + 1800 tie exactly
+    F0 = F1[torch.randperm(900, generator=g)[:300]].clone()
+    idx, _ = gmf_amd.nn_match(_gpu(F0), _gpu(F1d))
+    assert int(idx.max()) < 900                                     # the first of the three
+    assert torch.equal(F1d[idx.cpu()], F0)
+    F0n = torch.nn.functional.normalize(torch.randn(40, 32, generator=g), dim=1)
+    F0n[17] = float("nan")
+    idx, dis = gmf_amd.nn_match(_gpu(F0n), _gpu(F1))
+    assert int(idx[17]) == 0 and bool(torch.isnan(dis[17])) and int(idx.min()) >= 0 and int(idx.max()) < 900
+    assert bool(torch.isfinite(dis[torch.arange(40) != 17]).all())
+
+
 # ---- row f-3: DGR GlobalRegistration as one persistent HIP kernel --------------------------------------------------
 def _f13_cases(g):
     return [(int(c[0]), int(c[1]), float(c[2]), float(c[3]), bool(c[4])) for c in g["cases"]]

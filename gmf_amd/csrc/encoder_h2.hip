@@ -684,6 +684,7 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
             float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
             int ttiles, const PairTab* __restrict__ ptab, unsigned* __restrict__ v_scale) {
   __shared__ __attribute__((aligned(16))) float lds[kLinLdsFloats];
+  tail_priority(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   linear_h2_body<0, NP, QSKIP>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
                                tiles, T, ttiles, ptab, v_scale);
 }

@@ -1289,6 +1289,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
              const unsigned* __restrict__ v_scale, const float* __restrict__ qf_img, const float* __restrict__ qw_wst,
              const float* __restrict__ qw_bias) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
+  tail_priority(blockIdx.x, gridDim.x);
   scattn_h2p_body<NPROD, CFMT, 4, PVF8>(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items,
                              n_full, ksplits, part_o, part_ml, next_wst, next_bias, ptab, v_scale, qf_img, qw_wst, qw_bias);
 }

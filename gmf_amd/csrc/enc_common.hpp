@@ -195,18 +195,16 @@ struct LcpeHalo {
   }
 };
 
-// [r4] Priority for the workgroups of a large grid's LAST round when that round is at most half full (512 = two workgroups on each of
-// the part's 256 CUs; at most 256 leftover workgroups = at most one per CU).  Two co-resident workgroups of equal priority share a
-// SIMD's issue slots by AGE: the older one runs as if nearly alone, the younger fills what is left (profiles/r04_linear_timeline.txt:
-// 146 k against 170-185 k cycles).  While every slot is busy that is as good as any order - but the workgroups dispatched last are the
-// youngest wherever they land, run slowest, and are what the launch waits for at its end.  With priority 1 they finish beside the
-// leftovers of the round before instead of behind them: -0.8 .. -2.1 % per step at 560-720 and 1040-1280 workgroups (32 x 5000: 17.14 ->
-// 17.00 ms).  A fuller last round is left alone (priority there costs 0.5-1.8 %: the tail workgroups then share CUs with each other),
-// and so are all earlier rounds (every other 256 workgroups at priority 1: +-5 % depending on the grid; profiles/
-// r04_compat_stream_probes.txt has the tables).  One scalar instruction per workgroup; results do not depend on it.
+// [r4] Priority 1 for the LAST 256 workgroups of a grid (256 = the CUs of the part; the last, possibly partial, 256-block of the
+// dispatch order).  Two co-resident workgroups of equal priority share a SIMD's issue slots by AGE: the older one runs as if nearly alone,
+// the younger fills what is left (profiles/r04_linear_timeline.txt: 146 k against 170-185 k cycles).  While every slot stays busy that
+// is as good as any order - but the workgroups dispatched last are the younger one on whatever CU they land on, run slowest, and are what
+// the launch waits for at its end.  With priority over their (older) neighbours they finish beside them instead of behind them:
+// -0.5 .. -1.8 % per step on EVERY grid from 560 to 2560 workgroups (32 x 5000: 16.96 -> 16.77 ms in one job).  Rules that touch earlier
+// workgroups lose on some grids: every other 256-block -1.5 .. +5.7 %, the whole last round of 512 -1.9 .. +1.8 % (profiles/
+// r04_compat_stream_probes.txt has the sweeps).  One scalar instruction per workgroup; results do not depend on it.
 GMF_DEVINL void tail_priority(const unsigned linear_wg, const unsigned n_wgs) {
-  const unsigned m = n_wgs & 511u;
-  if (m != 0 && m <= 256u && linear_wg >= n_wgs - m) __builtin_amdgcn_s_setprio(1);
+  if (linear_wg >= ((n_wgs - 1u) & ~255u)) __builtin_amdgcn_s_setprio(1);
 }
 
 // Split-fp16 weight images are stored as 256 W (packing.p32_h2s / p16_h2s): lo = fp16(256 w - hi) then stays a normal

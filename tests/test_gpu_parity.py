@@ -1182,7 +1182,10 @@ def test_forward_from_raw_images(model):
     d2 = {k: data[k] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
     d2.update(p_tokens=pt, q_tokens=qt, testing=True)
     model(d2)
-    assert _maxerr(model.last_logits.cpu(), lg.cpu()) < 1e-5
+    # (MIOpen picks its convolution algorithm per batch size - two images at once against one at a time - and its small-batch kernels
+    # are not bitwise repeatable: the two routes differ by 0.3 .. 1.4e-5 on logits of magnitude 7 depending on the device of the pool;
+    # the bound is the parity contract's, not a guess at MIOpen's noise)
+    assert _maxerr(model.last_logits.cpu(), lg.cpu()) < 1e-4
     assert res["final_trans"].shape == (1, 4, 4)
 
 

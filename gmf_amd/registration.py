@@ -18,8 +18,9 @@ def _device_offsets(offsets, n_rows: int, device, what: str):
     same offsets - the upload is a synchronous pageable copy, 20 us of a 10 us solve; an int32 tensor already on the device
     is taken as it is (the caller vouches for it: only its end is not read back)."""
     if isinstance(offsets, torch.Tensor) and offsets.is_cuda:
-        if offsets.dtype != torch.int32 or offsets.dim() != 1 or offsets.numel() < 2 or not offsets.is_contiguous():
-            raise RuntimeError(f"gmf_amd.{what}: device offsets must be a contiguous int32 vector of B + 1 entries")
+        if offsets.dtype != torch.int32 or offsets.dim() != 1 or offsets.numel() < 2 or not offsets.is_contiguous() \
+                or offsets.device != device:
+            raise RuntimeError(f"gmf_amd.{what}: device offsets must be a contiguous int32 vector of B + 1 entries on the points' device")
         return offsets, n_rows
     off = tuple(int(o) for o in offsets)
     if len(off) < 2 or off[0] != 0 or off[-1] != n_rows or any(b <= a for a, b in zip(off, off[1:])):

@@ -38,6 +38,7 @@ class EncoderWeights(C.Structure):
         ("front_wst_h2", _vp), ("ctx_wst_h2", _vp), ("attn_wst_h2", _vp), ("ff_wst_h2", _vp),
         ("f1_ctx_wst_h2", _vp), ("f1_attn_wst_h2", _vp), ("f1_ff_wst_h2", _vp),
         ("tail_wst_h2", _vp),
+        ("pv_guard", _vp),
     ]
 
 
@@ -203,7 +204,7 @@ def load_library() -> C.CDLL:
             fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.gmf_abi_version() != 4:
+        if lib.gmf_abi_version() != 5:
             raise RuntimeError("gmf_amd: libgmf_hip.so ABI version mismatch")
         _lib = lib
         return lib
@@ -211,6 +212,7 @@ def load_library() -> C.CDLL:
 
 GMF_ERR_WORKSPACE = -6
 GMF_STATUS_NONFINITE = 1
+GMF_STATUS_PV_GUARDED = 2      # informational: the "pv_fp8" guard sent a (pair, layer) to the three-product form
 
 
 class Handle:
@@ -268,8 +270,9 @@ class Handle:
         return f.value
 
     def raise_if_flagged(self, where: str):
-        f = self.status(clear=True)
+        f = self.status(clear=False)
         if f & GMF_STATUS_NONFINITE:
+            self.status(clear=True)
             raise RuntimeError(
                 f"gmf_amd: {where}: a non-finite value (NaN / inf) reached an output of an earlier call on this device - "
                 "an input was non-finite, or an activation left the range of the split-fp16 MFMA operands (|x| < 65504; "

@@ -1,6 +1,7 @@
 // Constants and small device helpers shared by the encoder kernel files.
 #pragma once
 #include "mfma_core.hpp"
+#include "launchers.hpp"
 
 namespace gmf {
 
@@ -101,6 +102,25 @@ GMF_DEVINL void store_block_v8(float* __restrict__ tile_base, int db, const floa
   }
   reinterpret_cast<i32x4*>(tile_base)[(1 * 8 + 2 * db) * 64 + lane] = l8;
   reinterpret_cast<i32x4*>(tile_base)[(1 * 8 + 2 * db + 1) * 64 + lane] = v8;
+}
+
+// ---- the "pv_fp8" guard (PvGuard, launchers.hpp) ---------------------------------------------------------------
+// Does this pair's V image of this layer carry e4m3 cross planes (true) or its low fp16 plane (false)?  Uniform per workgroup, two
+// scalar loads; the kernels that WRITE the image and the ones that multiply it evaluate the same words.  (A NaN statistic -
+// non-finite features - compares false: three products; the status word of k_head reports the NaN itself.)
+GMF_DEVINL bool pv_planes_on(const unsigned* __restrict__ v_scale, const PvGuard& g, int pair) {
+  if (!v_scale) return false;
+  if (!g.stat) return true;
+  return __uint_as_float(g.stat[pair]) <= *g.thr2;
+}
+// Raises stat[pair] to the largest |f|^2 of this wave's 32 rows (rows on lanes; ssq_half = this lane's 64 features of its row, the
+// other 64 live in lane ^ 32).  Sums of squares are >= 0, so the float bits order like unsigned integers.
+GMF_DEVINL void pv_stat_raise(unsigned* __restrict__ stat, int pair, float ssq_half, bool row_valid, int lane) {
+  float s = xhalf_sum(ssq_half);
+  s = row_valid ? s : 0.f;
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) s = fmaxf(s, __shfl_xor(s, m, 64));
+  if (lane == 0) atomicMax(stat + pair, __float_as_uint(s));
 }
 
 // LCPE (fusion_layer.py:118-128): y[row] = x[row] + b + w0*x[row-1] + w1*x[row] + w2*x[row+1],

@@ -30,7 +30,8 @@ template <int MODE>
 GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const int zsel_in, const float* __restrict__ in,
                               const float* __restrict__ wst, const float* __restrict__ vecs, float* __restrict__ f_out,
                               float* __restrict__ q_out, float* __restrict__ k_out, float* __restrict__ v_out, int N, int tiles,
-                              const PairTab* __restrict__ ptab = nullptr, unsigned* __restrict__ v_scale = nullptr) {
+                              const PairTab* __restrict__ ptab = nullptr, unsigned* __restrict__ v_scale = nullptr,
+                              const PvGuard guard = {}) {
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t row0 = pair_row0(ptab, pair, N);            // ragged batch (MODE 3 only): corr_pos is packed [sum n, 6]
@@ -100,7 +101,16 @@ GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const in
     }
   }
   if (active && zsel <= 0 && MODE != 2) store_frag_p32<CF>(f_out + toff, f, lane);
-  if (MODE == 3) return;
+  if (MODE == 3) {
+    // [r5] the first layer's "pv_fp8" statistic: max row |f_0|^2 of the pair (PvGuard; later layers: the attention epilogue)
+    if (guard.stat_next && active) {
+      float ssq = 0.f;
+#pragma unroll
+      for (int e = 0; e < CF; ++e) ssq = fmaf(f[e], f[e], ssq);
+      pv_stat_raise(guard.stat_next, pair, ssq, tile * 32 + i < N, lane);
+    }
+    return;
+  }
   fx.set(f);
 
 #pragma unroll
@@ -121,6 +131,7 @@ GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const in
   }
   if (zsplit && zsel != 2) return;
   unsigned vsw = 0;
+  const bool v8 = pv_planes_on(v_scale, guard, pair);     // e4m3 cross planes or the low fp16 plane (uniform per pair and layer)
 #pragma unroll
   for (int db = 0; db < 4; ++db) {             // V (feature on lane)
     const f16x8* lw = as_h2(ss.acquire());
@@ -131,21 +142,22 @@ GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const in
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bv);
     if (active) {
-      if (v_scale) store_block_v8(v_out + toff, db, t, lane, vsw);     // the attention's pv_fp8 form (CompatCache::v_scale)
+      if (v8) store_block_v8(v_out + toff, db, t, lane, vsw);     // the attention's pv_fp8 form (CompatCache::v_scale)
       else store_block_h2(v_out + toff, db, t, lane);
     }
   }
-  if (active && v_scale) v_scale[((size_t)pair * tiles + tile) * 64 + lane] = vsw;
+  if (active && v8) v_scale[((size_t)pair * tiles + tile) * 64 + lane] = vsw;
 }
 
 template <int MODE>
 __global__ void __launch_bounds__(256, 2)
 k_front_h2(const float* __restrict__ in, const float* __restrict__ wst, const float* __restrict__ vecs,
            float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out,
-           float* __restrict__ v_out, int N, int tiles, const PairTab* __restrict__ ptab, unsigned* __restrict__ v_scale) {
+           float* __restrict__ v_out, int N, int tiles, const PairTab* __restrict__ ptab, unsigned* __restrict__ v_scale,
+           const PvGuard guard) {
   __shared__ __attribute__((aligned(16))) float lds[kRing * kStageFloats];
   front_h2_body<MODE>(lds, blockIdx.x, blockIdx.y, gridDim.z == 3 ? (int)blockIdx.z : -1, in, wst, vecs, f_out, q_out, k_out, v_out,
-                      N, tiles, ptab, v_scale);
+                      N, tiles, ptab, v_scale, guard);
 }
 
 // =========================================================================================
@@ -379,11 +391,11 @@ __global__ void __launch_bounds__(256, 2)
 k_small_front_fattn(const float* __restrict__ f_in, const float* __restrict__ front_wst, const float* __restrict__ front_vec,
                     const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
                     float* __restrict__ q_out, float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x1_out,
-                    int N, int tiles, int T, int ttiles, unsigned* __restrict__ v_scale) {
+                    int N, int tiles, int T, int ttiles, unsigned* __restrict__ v_scale, const PvGuard guard) {
   __shared__ __attribute__((aligned(16))) float lds[kFattnLdsFloats];
   if (blockIdx.z < 3)
     front_h2_body<2>(lds, blockIdx.x, blockIdx.y, blockIdx.z, f_in, front_wst, front_vec, nullptr, q_out, k_out, v_out, N, tiles,
-                     nullptr, v_scale);
+                     nullptr, v_scale, guard);
   else
     fusion_attn_h2_body<true>(lds, blockIdx.x, blockIdx.y, f_in, ctx_img, attn_wst, attn_vec, x1_out, N, tiles, T, ttiles);
 }
@@ -437,7 +449,8 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
                                const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
                                float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles,
                                int T, int ttiles, const PairTab* __restrict__ ptab = nullptr,
-                               unsigned* __restrict__ v_scale = nullptr) {   // non-null: V with e4m3 cross planes (store_block_v8)
+                               unsigned* __restrict__ v_scale = nullptr,     // non-null: V with e4m3 cross planes (store_block_v8) ...
+                               const PvGuard guard = {}) {                   // ... for the pairs the guard lets through (pv_planes_on)
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.y;
@@ -510,6 +523,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
       }
     }
     unsigned vsw = 0;
+    const bool v8 = pv_planes_on(v_scale, guard, pair);
 #pragma unroll
     for (int db = 0; db < 4; ++db) {             // V (feature on lane)
       const f16x8* lw = as_h2(PART == 1 ? ss.acquire() : ss.acquire_counted<20>());
@@ -519,12 +533,12 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
       const float bvd = lvec_p[2 * C + 32 * db + i];
 #pragma unroll
       for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bvd);
-      if (v_scale) store_block_v8(v_out + toff, db, t, lane, vsw);     // (4 stores of 16 bytes either way: the counted waits hold)
+      if (v8) store_block_v8(v_out + toff, db, t, lane, vsw);     // (4 stores of 16 bytes either way: the counted waits hold)
       else store_block_h2(v_out + toff, db, t, lane);
     }
     // one more store than the counted waits of the stages that follow assume: their counts are lower bounds, it only makes them
     // wait for one operation more
-    if (v_scale) v_scale[((size_t)pair * tiles + tile) * 64 + lane] = vsw;
+    if (v_scale) v_scale[((size_t)pair * tiles + tile) * 64 + lane] = vsw;     // (written either way: one store count for both forms)
   }
 
   if (PART == 1) {
@@ -682,11 +696,11 @@ k_linear_h2(const float* __restrict__ f_in, const float* __restrict__ front_wst,
             const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
             const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
             float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
-            int ttiles, const PairTab* __restrict__ ptab, unsigned* __restrict__ v_scale) {
+            int ttiles, const PairTab* __restrict__ ptab, unsigned* __restrict__ v_scale, const PvGuard guard) {
   __shared__ __attribute__((aligned(16))) float lds[kLinLdsFloats];
   tail_priority(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   linear_h2_body<0, NP, QSKIP>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
-                               tiles, T, ttiles, ptab, v_scale);
+                               tiles, T, ttiles, ptab, v_scale, guard);
 }
 
 // grid (ceil(tiles / 4), B, 2): blockIdx.z = 0 the Q'/K/V role, 1 the Fusion-2 role of the same 128 rows
@@ -695,11 +709,11 @@ k_linear_roles(const float* __restrict__ f_in, const float* __restrict__ front_w
                const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
                const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
                float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
-               int ttiles, unsigned* __restrict__ v_scale) {
+               int ttiles, unsigned* __restrict__ v_scale, const PvGuard guard) {
   __shared__ __attribute__((aligned(16))) float lds[kLinLdsFloats];
   if (blockIdx.z == 0)
     linear_h2_body<1>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
-                      tiles, T, ttiles, nullptr, v_scale);
+                      tiles, T, ttiles, nullptr, v_scale, guard);
   else
     linear_h2_body<2>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
                       tiles, T, ttiles);
@@ -740,34 +754,35 @@ k_ff_reduce(const float* __restrict__ part, const float* __restrict__ x1, const 
 static inline dim3 tgrid(int tiles, int B, int sets = 1) { return dim3((tiles + kWavesPerWG - 1) / kWavesPerWG, B, sets); }
 
 hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
-                           float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s, const PairTab* ptab, unsigned* v_scale) {
+                           float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s, const PairTab* ptab, unsigned* v_scale,
+                           PvGuard guard) {
   dim3 g = tgrid(tiles, B);
   if (g.x * B < 128 && tune.front_split) g.z = 3;      // small grids: one workgroup per output (Q' + f | K | V)
-  if (mode == 3) { g.z = 1; hipLaunchKernelGGL(k_front_h2<3>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab, v_scale); }
-  else if (mode == 1) hipLaunchKernelGGL(k_front_h2<1>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab, v_scale);
-  else if (mode == 2) hipLaunchKernelGGL(k_front_h2<2>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab, v_scale);
-  else hipLaunchKernelGGL(k_front_h2<0>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab, v_scale);
+  if (mode == 3) { g.z = 1; hipLaunchKernelGGL(k_front_h2<3>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab, v_scale, guard); }
+  else if (mode == 1) hipLaunchKernelGGL(k_front_h2<1>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab, v_scale, guard);
+  else if (mode == 2) hipLaunchKernelGGL(k_front_h2<2>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab, v_scale, guard);
+  else hipLaunchKernelGGL(k_front_h2<0>, g, dim3(256), 0, s, in, wst, vecs, f, q, k, v, N, tiles, ptab, v_scale, guard);
   return hipGetLastError();
 }
 
 hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                             const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec, float* q,
                             float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s,
-                            bool one_product, const PairTab* ptab, unsigned* v_scale) {
+                            bool one_product, const PairTab* ptab, unsigned* v_scale, PvGuard guard) {
   // grids that give a CU about one workgroup: two roles per row block (the Q'/K/V projections | Fusion-2) in one launch
   const int W = ((tiles + 3) / 4) * B;
   if (tune.mid_grid_roles > 0 && W < tune.mid_grid_roles && !ptab && q)
     hipLaunchKernelGGL(k_linear_roles, tgrid(tiles, B, 2), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec,
-                       ff_wst, ff_vec, q, k, v, x2, N, tiles, T, ttiles, v_scale);
+                       ff_wst, ff_vec, q, k, v, x2, N, tiles, T, ttiles, v_scale, guard);
   else if (one_product)                            // throughput numerics mode: high planes only
     hipLaunchKernelGGL(k_linear_h2<1>, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
-                       ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab, v_scale);
+                       ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab, v_scale, guard);
   else if (!q)                                     // [r4] no Q' image: the attention kernel projects its own (CompatCache::qf_img)
     hipLaunchKernelGGL((k_linear_h2<3, true>), tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
-                       ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab, v_scale);
+                       ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab, v_scale, guard);
   else
     hipLaunchKernelGGL(k_linear_h2<3>, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
-                       ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab, v_scale);
+                       ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab, v_scale, guard);
   return hipGetLastError();
 }
 
@@ -801,9 +816,9 @@ int plan_ff_split(const Tuning& tune, int base, int max_parts) {
 
 hipError_t launch_small_front_fattn(const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                                     const float* attn_wst, const float* attn_vec, float* q, float* k, float* v, float* x1, int B,
-                                    int N, int tiles, int T, int ttiles, hipStream_t s, unsigned* v_scale) {
+                                    int N, int tiles, int T, int ttiles, hipStream_t s, unsigned* v_scale, PvGuard guard) {
   hipLaunchKernelGGL(k_small_front_fattn, tgrid(tiles, B, 4), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec,
-                     q, k, v, x1, N, tiles, T, ttiles, v_scale);
+                     q, k, v, x1, N, tiles, T, ttiles, v_scale, guard);
   return hipGetLastError();
 }
 

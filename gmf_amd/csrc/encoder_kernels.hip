@@ -659,7 +659,9 @@ GMF_DEVINL void stage_tail_vecs(float* lvec, const float* __restrict__ vecs, con
 template <bool NEXT_PCN, class Stages, class Fus>
 GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stages& ss, const float* __restrict__ vecs,
                                    const Fus& fus_tile, float* __restrict__ out_tile, const int lane, const int h,
-                                   const float* __restrict__ next_bias = nullptr) {
+                                   const float* __restrict__ next_bias = nullptr,
+                                   // [r5] NEXT_PCN: non-null = raise the next layer's "pv_fp8" statistic of `pair` to these rows' |f_{l+1}|^2
+                                   unsigned* __restrict__ stat_next = nullptr, const int pair = 0, const bool row_valid = false) {
     // stages (fp16x2 images, same sizes as the fp32 ones): Wa block 0 | Wa block 1 | Wb (2 blocks) | Wc 0,1 | Wc 2,3
     FragH2<8> ox, featx;
     FragH2<4> m1x, m2x;
@@ -709,6 +711,7 @@ GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stag
       }
     }
     if (NEXT_PCN) {
+      float ssq = 0.f;
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
         const f16x8* lw = as_h2(ss.acquire());
@@ -718,9 +721,10 @@ GMF_DEVINL void scattn_epilogue_h2(const float (&o)[CF], const bool active, Stag
         float b[16], tt[16];
         load_vec_block(b, next_bias, mb, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tt[r] = relu_nan(fmaf(acc[r], kH2Inv, b[r]));
+        for (int r = 0; r < 16; ++r) { tt[r] = relu_nan(fmaf(acc[r], kH2Inv, b[r])); ssq = fmaf(tt[r], tt[r], ssq); }
         store_block_p32(out_tile, mb, tt, lane);
       }
+      if (stat_next && active) pv_stat_raise(stat_next, pair, ssq, row_valid, lane);     // (uniform per wave)
     }
 }
 
@@ -771,7 +775,8 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
                                 const unsigned* __restrict__ v_scale = nullptr,
                                 // [r4] non-null: q_img is not read - the workgroup projects its own Q' from the layer's f tile (below)
                                 const float* __restrict__ qf_img = nullptr, const float* __restrict__ qw_wst = nullptr,
-                                const float* __restrict__ qw_bias = nullptr) {
+                                const float* __restrict__ qw_bias = nullptr,
+                                unsigned* __restrict__ stat_next = nullptr) {     // [r5] PvGuard::stat_next (whole items with the next PointCN)
   static_assert(!PVF8 || NPROD == 3, "the fp8 cross products belong to the three-product form");
   float* const ldsK = lds;
   float* const ldsV = lds + 2 * kStageFloats;
@@ -1275,8 +1280,18 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   ss.init(lds, lds + kStageFloats, wave, WAVES, lane, wst, 5, next_wst, next_wst ? 4 : 0);
   ss.prime();
   const FusTile ft{fus + toff};
-  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, lvec, ft, out + toff, lane, h, lvec + 2 * C);
+  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, lvec, ft, out + toff, lane, h, lvec + 2 * C, stat_next, pair,
+                                         tile_raw * 32 + (lane & 31) < N);
   else scattn_epilogue_h2<false>(o, active, ss, lvec, ft, out + toff, lane, h);
+}
+
+// [r5] PVF8 kernels under the guard (PvGuard): the pair of this workgroup's item decides between the two forms of the body -
+// one uniform branch at the top, both bodies in the kernel.  (The V image of the pair was written in the matching format.)
+GMF_DEVINL bool attn_pv_on(const unsigned* __restrict__ v_scale, const PvGuard& guard, int bid, int n_items, int n_full, int ksplits,
+                           int wgs_per_pair) {
+  if (!guard.stat) return v_scale != nullptr;
+  const AttnItem it = attn_item(bid, n_items, n_full, ksplits);
+  return pv_planes_on(v_scale, guard, it.valid ? it.item / wgs_per_pair : 0);
 }
 
 template <int NPROD, int CFMT, bool PVF8 = false>
@@ -1287,11 +1302,17 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
              int n_items, int n_full, int ksplits, float* __restrict__ part_o, float* __restrict__ part_ml,
              const float* __restrict__ next_wst, const float* __restrict__ next_bias, const PairTab* __restrict__ ptab,
              const unsigned* __restrict__ v_scale, const float* __restrict__ qf_img, const float* __restrict__ qw_wst,
-             const float* __restrict__ qw_bias) {
+             const float* __restrict__ qw_bias, const PvGuard guard) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
   tail_priority(blockIdx.x, gridDim.x);
-  scattn_h2p_body<NPROD, CFMT, 4, PVF8>(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items,
-                             n_full, ksplits, part_o, part_ml, next_wst, next_bias, ptab, v_scale, qf_img, qw_wst, qw_bias);
+  if (!PVF8 || attn_pv_on(v_scale, guard, blockIdx.x, n_items, n_full, ksplits, wgs_per_pair))
+    scattn_h2p_body<NPROD, CFMT, 4, PVF8>(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items,
+                                          n_full, ksplits, part_o, part_ml, next_wst, next_bias, ptab, v_scale, qf_img, qw_wst, qw_bias,
+                                          guard.stat_next);
+  else
+    scattn_h2p_body<NPROD, CFMT, 4, false>(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items,
+                                           n_full, ksplits, part_o, part_ml, next_wst, next_bias, ptab, nullptr, qf_img, qw_wst, qw_bias,
+                                           guard.stat_next);
 }
 
 // =========================================================================================
@@ -1493,13 +1514,17 @@ k_small_attn_ff(const int n_attn, const float* __restrict__ q_img, const float* 
                 int tiles, int wgs_per_pair, const float* __restrict__ c_dense, int n_items, int ksplits,
                 float* __restrict__ part_o, float* __restrict__ part_ml, const float* __restrict__ x1,
                 const float* __restrict__ ff_wst, const float* __restrict__ ff_vecs, float* __restrict__ ff_part, int n_pairs,
-                int ff_hs, const unsigned* __restrict__ v_scale) {
+                int ff_hs, const unsigned* __restrict__ v_scale, const PvGuard guard) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
   if ((int)blockIdx.x < n_attn) {
     // (n_full = 0: every item is split and leaves through the partial-result branch; `fus` / `out` of the whole-item epilogue
     // are never touched - they get valid pointers all the same, a literal null there crashes this compiler's optimiser)
-    scattn_h2p_body<3, CFMT, 4, PVF8>(lds, blockIdx.x, q_img, k_img, v_img, x1, tail_wst, tail_vecs, ff_part, N, tiles, wgs_per_pair, c_dense,
-                                      n_items, 0, ksplits, part_o, part_ml, nullptr, nullptr, nullptr, v_scale);
+    if (!PVF8 || attn_pv_on(v_scale, guard, blockIdx.x, n_items, 0, ksplits, wgs_per_pair))
+      scattn_h2p_body<3, CFMT, 4, PVF8>(lds, blockIdx.x, q_img, k_img, v_img, x1, tail_wst, tail_vecs, ff_part, N, tiles, wgs_per_pair, c_dense,
+                                        n_items, 0, ksplits, part_o, part_ml, nullptr, nullptr, nullptr, v_scale);
+    else
+      scattn_h2p_body<3, CFMT, 4, false>(lds, blockIdx.x, q_img, k_img, v_img, x1, tail_wst, tail_vecs, ff_part, N, tiles, wgs_per_pair, c_dense,
+                                         n_items, 0, ksplits, part_o, part_ml, nullptr, nullptr, nullptr, nullptr);
   } else {
     const int id = (int)blockIdx.x - n_attn;           // (bx, pair, z) with z fastest: the splits of a row block start together
     const int z = id % ff_hs, r = id / ff_hs;
@@ -1547,7 +1572,7 @@ k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_
                const float* __restrict__ wst, const float* __restrict__ vecs, float* __restrict__ out, int tiles,
                int wgs_per_pair, int n_items, int n_full, int ksplits, const float* __restrict__ next_wst,
                const float* __restrict__ next_bias, const float* __restrict__ ff_part, int ff_hs, const float* __restrict__ x1,
-               const float* __restrict__ ff_b2) {
+               const float* __restrict__ ff_b2, unsigned* __restrict__ stat_next, int n_rows) {   // [r5] PvGuard::stat_next, the pairs' row count
   // (behind the nine stages: the biases of the epilogue - a bias fetched from global memory after each stage's MFMAs is a
   // memory round trip per stage on a grid where nothing else runs on the CU)
   __shared__ __attribute__((aligned(16))) float lds[9 * kStageFloats + kTailVecFloats];
@@ -1632,12 +1657,12 @@ k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_
   for (int e = 0; e < CF; ++e) o[e] *= inv;
   if (ff_part) {
     const FusRegs fp{x2};
-    if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, fp, out + toff, lane, h, next_bias);
+    if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, fp, out + toff, lane, h, next_bias, stat_next, pair, tile_raw * 32 + i < n_rows);
     else scattn_epilogue_h2<false>(o, active, ss, vecs, fp, out + toff, lane, h);
     return;
   }
   const FusTile ft{fus + toff};
-  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, ft, out + toff, lane, h, next_bias);
+  if (next_wst) scattn_epilogue_h2<true>(o, active, ss, vecs, ft, out + toff, lane, h, next_bias, stat_next, pair, tile_raw * 32 + i < n_rows);
   else scattn_epilogue_h2<false>(o, active, ss, vecs, ft, out + toff, lane, h);
 }
 
@@ -1653,7 +1678,8 @@ __global__ void __launch_bounds__(256, 1)
 k_scattn_merge_tile(const float* __restrict__ part_o, const float* __restrict__ part_ml, const float* __restrict__ wst,
                     const float* __restrict__ vecs, float* __restrict__ out, int tiles, int ksplits,
                     const float* __restrict__ next_wst, const float* __restrict__ next_bias, const float* __restrict__ ff_part,
-                    int ff_hs, const float* __restrict__ x1, const float* __restrict__ ff_b2) {
+                    int ff_hs, const float* __restrict__ x1, const float* __restrict__ ff_b2, unsigned* __restrict__ stat_next,
+                    int n_rows) {                                               // [r5] PvGuard::stat_next, the pairs' row count
   __shared__ __attribute__((aligned(16))) float lds[10 * kStageFloats];       // 9 weight stages | exchange
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1783,10 +1809,21 @@ k_scattn_merge_tile(const float* __restrict__ part_o, const float* __restrict__ 
     for (int s = 0; s < 8; ++s) { fx.h[s] = xh[(0 * 8 + s) * 64 + lane]; fx.l[s] = xh[(1 * 8 + s) * 64 + lane]; }
     f32x16 acc = zero16();
     mma_wx_h2<8>(acc, stage(5 + wave), fx);
-    float t[16];
+    float t[16], ssq = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = relu_nan(fmaf(acc[r], kH2Inv, b4[r]));
+    for (int r = 0; r < 16; ++r) { t[r] = relu_nan(fmaf(acc[r], kH2Inv, b4[r])); ssq = fmaf(t[r], t[r], ssq); }
     store_block_p32(out + toff, wave, t, lane);
+    // [r5] the next layer's "pv_fp8" statistic: a row's |f|^2 is the sum of the four waves' blocks - through the first weight
+    // stage's LDS (level 1 is long done with it), added in wave order as the whole-item epilogue adds its blocks
+    if (stat_next) {
+      ssq = xhalf_sum(ssq);
+      if (h == 0) lds[wave * 32 + i] = ssq;
+      __syncthreads();
+      if (wave == 0) {
+        float s4 = ((lds[i] + lds[32 + i]) + lds[64 + i]) + lds[96 + i];
+        pv_stat_raise(stat_next, pair, 0.5f * s4, tile * 32 + i < n_rows, lane);     // (both lane halves hold the row's sum: halves add up to it)
+      }
+    }
   }
 }
 
@@ -2029,10 +2066,16 @@ k_fusion_ff(const float* __restrict__ x1, const float* __restrict__ wst, const f
 __global__ void __launch_bounds__(256, 2)
 k_head(const float* __restrict__ feat_img, const float* __restrict__ wst, const float* __restrict__ vecs,
        float* __restrict__ logits, float* __restrict__ feat_n, float* __restrict__ feat_rm, int N, int tiles, int* status,
-       const PairTab* __restrict__ ptab) {
+       const PairTab* __restrict__ ptab, const unsigned* __restrict__ pv_stat, const float* __restrict__ pv_thr2, int n_layers) {
   __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i = lane & 31;
   const int pair = blockIdx.y;
+  // [r5] informational: a layer of this pair ran the three-product form of P V under the "pv_fp8" guard (GMF_STATUS_PV_GUARDED)
+  if (pv_stat && status && blockIdx.x == 0 && threadIdx.x == 0) {
+    bool tripped = false;
+    for (int l = 0; l < n_layers; ++l) tripped |= !(__uint_as_float(pv_stat[(size_t)l * gridDim.y + pair]) <= pv_thr2[l]);
+    if (tripped) __hip_atomic_fetch_or(status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const size_t row0 = pair_row0(ptab, pair, N);            // ragged batch: the outputs are packed [sum n, ...]
   N = pair_rows(ptab, pair, N);
   const int tiles_p = (N + 31) >> 5;
@@ -2352,23 +2395,24 @@ hipError_t launch_small_attn_ff_merge(const float* q, const float* k, const floa
   const int n_attn = 8 * per_xcd * ksplits, n_ff = W * ff_hs;
   if (cc->fmt == 2 && cc->v_scale)
     hipLaunchKernelGGL((k_small_attn_ff<2, true>), dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
-                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, cc->v_scale);
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, cc->v_scale, cc->guard);
   else if (cc->fmt == 2)
     hipLaunchKernelGGL(k_small_attn_ff<2>, dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
-                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, (const unsigned*)nullptr);
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, (const unsigned*)nullptr, PvGuard{});
   else if (cc->v_scale)
     hipLaunchKernelGGL((k_small_attn_ff<0, true>), dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
-                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, cc->v_scale);
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, cc->v_scale, cc->guard);
   else
     hipLaunchKernelGGL(k_small_attn_ff<0>, dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
-                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, (const unsigned*)nullptr);
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, (const unsigned*)nullptr, PvGuard{});
   if (tile_merge)
     hipLaunchKernelGGL(k_scattn_merge_tile, dim3(tiles, B), dim3(256), 0, s, cc->part_o, cc->part_ml, cc->tail_wst_h2, tail_vecs, out,
-                       tiles, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)ff_part, ff_hs, x1, ff_vecs + 2 * C + 2 * FFH);
+                       tiles, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)ff_part, ff_hs, x1, ff_vecs + 2 * C + 2 * FFH,
+                       cc->guard.stat_next, N);
   else
     hipLaunchKernelGGL(k_scattn_merge, dim3(8 * per_xcd), dim3(256), 0, s, cc->part_o, cc->part_ml, x1, cc->tail_wst_h2, tail_vecs, out,
                        tiles, wpp, W, 0, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)ff_part, ff_hs, x1,
-                       ff_vecs + 2 * C + 2 * FFH);
+                       ff_vecs + 2 * C + 2 * FFH, cc->guard.stat_next, N);
   return hipGetLastError();
 }
 
@@ -2398,23 +2442,23 @@ hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, 
                          cc->next_wst_h2, cc->next_bias);
     else if (cc->half)  // ... with a split tail: one fp16 product, c streamed as fp16 (the cache was built that way)
       hipLaunchKernelGGL((k_scattn_h2p<1, 1>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd, W,
-                         n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+                         n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, PvGuard{});
     else if (cc->fmt == 2 && cc->v_scale)   // parity arithmetic, c streamed as 16-bit fixed point; fp8 cross products of P V
       hipLaunchKernelGGL((k_scattn_h2p<3, 2, true>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
-                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, cc->v_scale, cc->qf_img, cc->qw_wst, cc->qw_bias);
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, cc->v_scale, cc->qf_img, cc->qw_wst, cc->qw_bias, cc->guard);
     else if (cc->fmt == 2)
       hipLaunchKernelGGL((k_scattn_h2p<3, 2>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
-                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr, cc->qf_img, cc->qw_wst, cc->qw_bias);
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr, cc->qf_img, cc->qw_wst, cc->qw_bias, PvGuard{});
     else if (cc->v_scale)    // the default: V image with e4m3 cross planes (k_linear_h2 wrote it that way)
       hipLaunchKernelGGL((k_scattn_h2p<3, 0, true>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
-                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, cc->v_scale, cc->qf_img, cc->qw_wst, cc->qw_bias);
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, cc->v_scale, cc->qf_img, cc->qw_wst, cc->qw_bias, cc->guard);
     else
       hipLaunchKernelGGL((k_scattn_h2p<3, 0>), grid, dim3(256), 0, s, q, k, v, fus, cc->tail_wst_h2, vecs, out, N, tiles, wpp, cd,
-                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr, cc->qf_img, cc->qw_wst, cc->qw_bias);
+                         W, n_full, ksplits, cc->part_o, cc->part_ml, cc->next_wst_h2, cc->next_bias, cc->ptab, (const unsigned*)nullptr, cc->qf_img, cc->qw_wst, cc->qw_bias, PvGuard{});
     if (max_tail > 0)
       hipLaunchKernelGGL(k_scattn_merge, dim3(8 * max_tail), dim3(256), 0, s, cc->part_o, cc->part_ml, fus, cc->tail_wst_h2, vecs, out,
                          tiles, wpp, W, n_full, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)nullptr, 0,
-                         (const float*)nullptr, (const float*)nullptr);
+                         (const float*)nullptr, (const float*)nullptr, cc->guard.stat_next, N);
   }
   else if (cd) hipLaunchKernelGGL(k_scattn_h2<true>, grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
   else hipLaunchKernelGGL(k_scattn_h2<false>, grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
@@ -2447,8 +2491,10 @@ hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs
 }
 
 hipError_t launch_head(const float* feat_img, const float* wst, const float* vecs, float* logits, float* feat_n,
-                       float* feat_rm, int B, int N, int tiles, hipStream_t s, int* status, const PairTab* ptab) {
-  hipLaunchKernelGGL(k_head, tile_grid(tiles, B), dim3(256), 0, s, feat_img, wst, vecs, logits, feat_n, feat_rm, N, tiles, status, ptab);
+                       float* feat_rm, int B, int N, int tiles, hipStream_t s, int* status, const PairTab* ptab, const unsigned* pv_stat,
+                       const float* pv_thr2, int n_layers) {
+  hipLaunchKernelGGL(k_head, tile_grid(tiles, B), dim3(256), 0, s, feat_img, wst, vecs, logits, feat_n, feat_rm, N, tiles, status, ptab,
+                     pv_stat, pv_thr2, n_layers);
   return hipGetLastError();
 }
 

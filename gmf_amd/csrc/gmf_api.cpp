@@ -158,8 +158,8 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     return GMF_OK;
   }
   if (std::strcmp(name, "pv_fp8") == 0) {       // large grids: the cross products of O += P V on the block-scaled fp8 pipe (default 1)
-    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: pv_fp8 must be 0 or 1");
-    t.pv_fp8 = value != 0;
+    GMF_REQUIRE(value >= 0 && value <= 2, GMF_ERR_BAD_ARG, "set_tuning: pv_fp8 must be 0 (three f16 products), 1 (guarded, default) or 2 (always)");
+    t.pv_fp8 = value;
     return GMF_OK;
   }
   if (std::strcmp(name, "compat_format") == 0) {       // element format of the compat cache: 0 = fp32 (default), 2 = 16-bit fixed point (opt-in)
@@ -185,7 +185,7 @@ int gmf_get_tuning(gmf_handle* h, const char* name, int* value) {
       {"attn_key_splits", t.key_splits}, {"attn_tail_split", t.tail_split ? 1 : 0}, {"small_grid_roles", t.small_roles ? 1 : 0},
       {"fused_linear", t.fused_linear ? 1 : 0}, {"compat_cache", t.use_cache ? 1 : 0}, {"conv_lds_patch", t.conv_patch},
       {"nms_binned", t.nms_binned}, {"topk_select", t.topk_select ? 1 : 0}, {"wide_attn_tile", t.wide_attn_tile ? 1 : 0},
-      {"small_merge_tile", t.small_merge_tile ? 1 : 0}, {"mid_grid_roles", t.mid_grid_roles}, {"pv_fp8", t.pv_fp8 ? 1 : 0}, {"q_in_attention", t.q_in_attention ? 1 : 0},
+      {"small_merge_tile", t.small_merge_tile ? 1 : 0}, {"mid_grid_roles", t.mid_grid_roles}, {"pv_fp8", t.pv_fp8}, {"q_in_attention", t.q_in_attention ? 1 : 0},
       {"compat_format", t.compat_format}, {"precision", t.precision}};
   for (const auto& e : tab) {
     if (std::strcmp(name, e.name) == 0) { *value = e.v; return GMF_OK; }
@@ -516,7 +516,8 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
                                              (kMaxSplits == 8 ? arena_need((size_t)8 * act, 4) : 0) : 0;
   const size_t need = 8 * arena_need(act, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +
                       5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4) + cache_need + split_need +
-                      arena_need((size_t)B, sizeof(gmf::PairTab)) + arena_need((size_t)B * tiles * 64, 4);
+                      arena_need((size_t)B, sizeof(gmf::PairTab)) + arena_need((size_t)B * tiles * 64, 4) +
+                      arena_need((size_t)(L + 1) * B, 4);
   if (int rc = arena_reserve(h, need)) return rc;
   const gmf::PairTab* ptab = nullptr;
   if (ragged) {
@@ -540,6 +541,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
   float* imgfeat = arena_take<float>(h, tok);
   float* ctxall = arena_take<float>(h, (size_t)(L > 0 ? L : 1) * tok);
   unsigned* v_scale = arena_take<unsigned>(h, (size_t)B * tiles * 64);     // scale words of the V image's e4m3 planes ("pv_fp8")
+  unsigned* fstat = arena_take<unsigned>(h, (size_t)(L + 1) * B);          // "pv_fp8" guard: [layer][pair] max row |f_l|^2 (float bits)
   gmf::CompatCache cc{nullptr, nullptr, nullptr, nullptr, 0};
   float* c_dense = nullptr;
   if (want_cache) {
@@ -601,11 +603,21 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
     gmf::plan_attn_split(h->tune, Wg, tiles, cc.part_o ? cc.max_splits : 0, &small_nf, &small_ks);
     const int ff_hs = cc.part_o ? gmf::plan_ff_split(h->tune, Wg, cc.max_splits) : 1;
     const bool small3 = !one_kernel && h->tune.small_roles && small_nf == 0 && small_ks > 1 && ff_hs > 1 && ff_part;
-    GMF_HIP(gmf::launch_front_h2(h->tune, 3, corr_pos, w->front_wst_h2, w->front_vec, f, q, k, v, B, N, tiles, st, ptab));
     // parity arithmetic: V with e4m3 cross planes for the pv_fp8 form of the attention body (scattn_h2p_body<3, *, 4, true>), which every
     // attention kernel of this path instantiates - large grids, split tails and the small-grid role kernels alike
     cc.v_scale = (h->tune.pv_fp8 && !cc.half) ? v_scale : nullptr;
+    // [r5] "pv_fp8" = 1: guarded per pair and layer on the device (PvGuard).  The statistics start at zero; f_0's is raised by the
+    // front kernel, f_{l+1}'s by the attention epilogue / merge kernels of layer l - always before the kernels that read it
+    const bool guarded = cc.v_scale && h->tune.pv_fp8 == 1 && w->pv_guard;
+    if (guarded) GMF_HIP(hipMemsetAsync(fstat, 0, (size_t)(L + 1) * B * sizeof(unsigned), st));
+    {
+      gmf::PvGuard g0;
+      if (guarded) g0.stat_next = fstat;
+      GMF_HIP(gmf::launch_front_h2(h->tune, 3, corr_pos, w->front_wst_h2, w->front_vec, f, q, k, v, B, N, tiles, st, ptab, nullptr, g0));
+    }
     for (int l = 0; l < L; ++l) {
+      cc.guard = gmf::PvGuard{};
+      if (guarded) cc.guard = gmf::PvGuard{fstat + (size_t)l * B, w->pv_guard + l, fstat + (size_t)(l + 1) * B};
       const float* fw = w->front_wst_h2 + (size_t)l * w->front_wst_stride;
       const float* fv = w->front_vec + (size_t)l * w->front_vec_stride;
       const float* aw = w->attn_wst_h2 + (size_t)l * w->attn_wst_stride;
@@ -623,10 +635,10 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
         cc.qw_wst = qproj ? fw + 4 * kTileFloats : nullptr;
         cc.qw_bias = qproj ? fv + kC : nullptr;
         GMF_HIP(gmf::launch_linear_h2(h->tune, f, fw, fv, ctx_l, aw, av, ffw, ffv, qproj ? nullptr : q, k, v, x2, B, N, tiles, T, tt, st,
-                                      cc.half && h->tune.precision == 2, ptab, cc.v_scale));
+                                      cc.half && h->tune.precision == 2, ptab, cc.v_scale, cc.guard));
       } else if (small3) {
         // three launches: {Q' | K | V | cross-attention} -> {key-split attention | hidden-split feed-forward} -> merge
-        GMF_HIP(gmf::launch_small_front_fattn(f, fw, fv, ctx_l, aw, av, q, k, v, x1, B, N, tiles, T, tt, st, cc.v_scale));
+        GMF_HIP(gmf::launch_small_front_fattn(f, fw, fv, ctx_l, aw, av, q, k, v, x1, B, N, tiles, T, tt, st, cc.v_scale, cc.guard));
         const bool last3 = (l + 1 == L);
         cc.tail_wst_h2 = w->tail_wst_h2 + (size_t)l * w->tail_wst_stride;
         cc.next_wst_h2 = last3 ? nullptr : w->front_wst_h2 + (size_t)(l + 1) * w->front_wst_stride;
@@ -640,7 +652,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
       } else {
         // (projecting Q'/K/V on a side stream beside the Fusion-2 kernels, forked and joined with events, was measured at
         // B = 1: 1.62 vs 1.58 ms at N = 5000, 1.08 vs 1.00 ms at N = 1000 - the event round trips cost more than the overlap gives)
-        GMF_HIP(gmf::launch_front_h2(h->tune, 2, f, fw, fv, f, q, k, v, B, N, tiles, st, nullptr, cc.v_scale));
+        GMF_HIP(gmf::launch_front_h2(h->tune, 2, f, fw, fv, f, q, k, v, B, N, tiles, st, nullptr, cc.v_scale, cc.guard));
         GMF_HIP(gmf::launch_fusion_attn_h2(true, f, ctx_l, aw, av, x1, B, N, tiles, T, tt, st));
         GMF_HIP(gmf::launch_fusion_ff_h2(h->tune, x1, ffw, ffv, x2, B, tiles, st, cc.part_o, cc.max_splits));
       }
@@ -650,7 +662,8 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
       cc.next_bias = last ? nullptr : w->front_vec + (size_t)(l + 1) * w->front_vec_stride;
       if (int rc = run_scattn(h, w, l, q, k, v, pts8, x2, last ? cur : f, B, N, st, nullptr, &cc)) return rc;
     }
-    GMF_HIP(gmf::launch_head(cur, w->head_wst, w->head_vec, logits, feat_n, feat, B, N, tiles, st, h->status_dev, ptab));
+    GMF_HIP(gmf::launch_head(cur, w->head_wst, w->head_vec, logits, feat_n, feat, B, N, tiles, st, h->status_dev, ptab,
+                             guarded ? fstat : nullptr, guarded ? w->pv_guard : nullptr, L));
     return GMF_OK;
   }
   if (L == 0) {

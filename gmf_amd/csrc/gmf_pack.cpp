@@ -14,6 +14,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -264,6 +265,60 @@ void pack_front(const StateDict& sd, int layer, bool with_layer0, bool identity_
   }
 }
 
+// The "pv_fp8" guard of layer `layer`: the largest SQUARED row norm of the layer's input f = ReLU(PointCN(.)) up to
+// which the attention's e4m3 cross products of O += P V are used.  By Cauchy-Schwarz a score of the layer's spatial-consistency
+// attention (PointDSC.py:56-64: c_ij q_i . k_j / sqrt(C), 0 <= c <= 1) is bounded by
+//     Z(F) = (|Wq|_2 F + |bq|) (|Wk|_2 F + |bk|) / sqrt(C),   F = max row |f|,
+// and the threshold is the F with Z(F) = kPvGuardScore: a network whose scores cannot pass that bound keeps a diffuse softmax and
+// averages the e4m3 rounding of V's low plane over many keys; beyond it a query's mass can sit on ONE key and that key's rounding
+// (2^-15 |v|) reaches the output whole - measured as 1.5 - 2 x the reference's own fp32 noise on the ill-conditioned ("stress")
+// KITTI weight set, whose first five layers are at 1 800 ... 60 000, while well-conditioned sets stay below 330.  Spectral norms by
+// power iteration on W^T W (fp64, fixed start, fixed count: deterministic); -1 = the biases alone pass the bound (always guarded).
+constexpr double kPvGuardScore = 1024.0;
+double spectral_norm(const Mat& W) {
+  std::vector<double> x((size_t)W.K), y((size_t)W.M);
+  for (int c = 0; c < W.K; ++c) x[c] = 1.0 + 0.01 * ((c * 37) % 17);      // (not an eigenvector of anything in particular)
+  double sigma = 0.0;
+  for (int it = 0; it < 96; ++it) {
+    double nx = 0.0;
+    for (int c = 0; c < W.K; ++c) nx += x[c] * x[c];
+    nx = std::sqrt(nx);
+    if (!(nx > 0.0) || !std::isfinite(nx)) return nx > 0.0 ? nx : 0.0;
+    for (int c = 0; c < W.K; ++c) x[c] /= nx;
+    double ny = 0.0;
+    for (int r = 0; r < W.M; ++r) {
+      double a = 0.0;
+      for (int c = 0; c < W.K; ++c) a += (double)W.at(r, c) * x[c];
+      y[r] = a;
+      ny += a * a;
+    }
+    sigma = std::sqrt(ny);                                               // |W x| with |x| = 1: a lower bound that converges upwards
+    for (int c = 0; c < W.K; ++c) {
+      double a = 0.0;
+      for (int r = 0; r < W.M; ++r) a += (double)W.at(r, c) * y[r];
+      x[c] = a;
+    }
+  }
+  return sigma * 1.02;                                                   // (margin for an unconverged iteration: the value is used as a BOUND)
+}
+float pv_guard_threshold(const StateDict& sd, int layer) {
+  const std::string n = "encoder.blocks.NonLocal_layer_" + std::to_string(layer) + ".";
+  const Mat Wq = mat_of(sd, n + "projection_q.weight", kCw, kCw), Wk = mat_of(sd, n + "projection_k.weight", kCw, kCw);
+  const std::vector<float> bq = vec_of(sd, n + "projection_q.bias", kCw), bk = vec_of(sd, n + "projection_k.bias", kCw);
+  double nq = 0.0, nk = 0.0;
+  for (float v : bq) nq += (double)v * v;
+  for (float v : bk) nk += (double)v * v;
+  nq = std::sqrt(nq); nk = std::sqrt(nk);
+  const double sq = spectral_norm(Wq), sk = spectral_norm(Wk), Z = kPvGuardScore * std::sqrt((double)kCw);
+  if (!std::isfinite(sq) || !std::isfinite(sk) || !std::isfinite(nq) || !std::isfinite(nk)) return -1.0f;
+  // sq sk F^2 + (sq nk + sk nq) F + nq nk - Z = 0
+  const double a = sq * sk, b = sq * nk + sk * nq, c = nq * nk - Z;
+  if (c >= 0.0) return -1.0f;
+  if (!(a > 0.0)) return b > 0.0 ? (float)std::min(1e30, (-c / b) * (-c / b)) : 1e30f;
+  const double F = (-b + std::sqrt(b * b - 4.0 * a * c)) / (2.0 * a);
+  return (float)std::min(1e30, F * F);
+}
+
 // fc_message with both BatchNorms folded (PointDSC.py:13-21)   (packing.pack_tail)
 void pack_tail(const StateDict& sd, int layer, Img kind, Ctx& cx, std::vector<float>& wst, std::vector<float>* vec) {
   const std::string p = "encoder.blocks.NonLocal_layer_" + std::to_string(layer) + ".fc_message.";
@@ -395,7 +450,7 @@ int gmf_encoder_pack_weights(gmf_handle* h, const gmf_tensor* tensors, int n_ten
     Block blk;
     struct Off { size_t v = 0; bool set = false; };
     auto put = [&](Off& o, const std::vector<float>& v) { o.v = blk.add(v); o.set = true; };
-    Off f1[6], f1h[3], ctx[2], attn[2], ff[2], front[2], tail[2], head[2], ctxh, attnh, ffh, fronth, tailh;
+    Off f1[6], f1h[3], ctx[2], attn[2], ff[2], front[2], tail[2], head[2], ctxh, attnh, ffh, fronth, tailh, pvgo;
     Ctx c32, ch2;
     if (has_f1) {
       FusionBlobs b = pack_fusion(sd, "encoder.fusion_layer_1.", false, Img::F32, c32);
@@ -405,7 +460,7 @@ int gmf_encoder_pack_weights(gmf_handle* h, const gmf_tensor* tensors, int n_ten
       put(f1h[0], bh.ctx_wst); put(f1h[1], bh.attn_wst); put(f1h[2], bh.ff_wst);
     }
     if (L > 0) {
-      std::vector<float> cw, cv, aw, av, fw, fv, cwh, awh, fwh, frw, frv, frwh, tw, tv, twh;
+      std::vector<float> cw, cv, aw, av, fw, fv, cwh, awh, fwh, frw, frv, frwh, tw, tv, twh, pvg;
       for (int l = 0; l < L; ++l) {
         const std::string pre = "encoder.blocks.NonLocal_layer_" + std::to_string(l) + ".fusion_layer_2.";
         FusionBlobs b = pack_fusion(sd, pre, true, Img::F32, c32);
@@ -417,10 +472,11 @@ int gmf_encoder_pack_weights(gmf_handle* h, const gmf_tensor* tensors, int n_ten
         pack_front(sd, l, l == 0 && has_l0, standalone, Img::H2S, ch2, frwh, nullptr);
         pack_tail(sd, l, Img::F32, c32, tw, &tv);
         pack_tail(sd, l, Img::H2S, ch2, twh, nullptr);
+        pvg.push_back(pv_guard_threshold(sd, l));
       }
       put(ctx[0], cw); put(ctx[1], cv); put(attn[0], aw); put(attn[1], av); put(ff[0], fw); put(ff[1], fv);
       put(front[0], frw); put(front[1], frv); put(tail[0], tw); put(tail[1], tv);
-      put(ctxh, cwh); put(attnh, awh); put(ffh, fwh); put(fronth, frwh); put(tailh, twh);
+      put(ctxh, cwh); put(attnh, awh); put(ffh, fwh); put(fronth, frwh); put(tailh, twh); put(pvgo, pvg);
     }
     if (has_head) {
       std::vector<float> hw, hv;
@@ -445,6 +501,7 @@ int gmf_encoder_pack_weights(gmf_handle* h, const gmf_tensor* tensors, int n_ten
     w.tail_wst = at(tail[0]); w.tail_vec = at(tail[1]); w.tail_wst_stride = 20480; w.tail_vec_stride = 256;
     w.head_wst = at(head[0]); w.head_vec = at(head[1]);
     w.sigma_d = sigma_d;
+    w.pv_guard = at(pvgo);
     if (ch2.ok) {            // a weight outside the fp16 range: no split images, every stage on the fp32 MFMA (gmf_packed_encoder_info says so)
       w.front_wst_h2 = at(fronth); w.ctx_wst_h2 = at(ctxh); w.attn_wst_h2 = at(attnh); w.ff_wst_h2 = at(ffh);
       w.f1_ctx_wst_h2 = at(f1h[0]); w.f1_attn_wst_h2 = at(f1h[1]); w.f1_ff_wst_h2 = at(f1h[2]);
@@ -573,7 +630,7 @@ int gmf_packed_encoder_place(gmf_handle* h, gmf_packed_encoder* p, void* device_
   const float** ptrs[] = {&w.f1_ctx_wst, &w.f1_ctx_vec, &w.f1_attn_wst, &w.f1_attn_vec, &w.f1_ff_wst, &w.f1_ff_vec, &w.ctx_wst, &w.ctx_vec,
                           &w.attn_wst, &w.attn_vec, &w.ff_wst, &w.ff_vec, &w.front_wst, &w.front_vec, &w.tail_wst, &w.tail_vec, &w.head_wst,
                           &w.head_vec, &w.front_wst_h2, &w.ctx_wst_h2, &w.attn_wst_h2, &w.ff_wst_h2, &w.f1_ctx_wst_h2, &w.f1_attn_wst_h2,
-                          &w.f1_ff_wst_h2, &w.tail_wst_h2};
+                          &w.f1_ff_wst_h2, &w.tail_wst_h2, &w.pv_guard};
   for (const float** q : ptrs) rebase_ptr(*q, from, n, to);
   p->placed = to;
   return GMF_OK;

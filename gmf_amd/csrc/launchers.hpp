@@ -11,6 +11,17 @@ namespace gmf {
 // neither computed nor read.
 struct PairTab { int row0, n, S, k; };
 
+// The "pv_fp8" guard (gmf_set_tuning "pv_fp8" = 1, the default): which of a layer's pairs run the P V cross products of
+// the spatial-consistency attention on the fp8 pipe is decided ON THE DEVICE, per pair, from a statistic the previous kernel
+// left behind - the largest squared row norm of the layer's input f - against the layer's threshold (gmf_encoder_weights::
+// pv_guard).  Every kernel that writes a V image or multiplies one evaluates the same comparison on the same two words, so the
+// writer and the reader of a pair's V tiles always agree on their format.
+struct PvGuard {
+  const unsigned* stat = nullptr;   // [B] float bits of max row |f_l|^2 per pair, complete before the layer's first launch; null: unguarded
+  const float* thr2 = nullptr;      // the layer's threshold: fp8 cross products while stat <= *thr2
+  unsigned* stat_next = nullptr;    // [B] the NEXT layer's statistic: raised (atomic maximum) by whoever produces f_{l+1}; null: nobody asks
+};
+
 // compat matrix built once per batch by launch_compat_build (see k_compat_build): [B, tiles, tiles, 1024] floats
 struct CompatCache {
   const float* dense;
@@ -34,6 +45,7 @@ struct CompatCache {
   const float* qf_img = nullptr;
   const float* qw_wst = nullptr;
   const float* qw_bias = nullptr;
+  PvGuard guard;              // [r5] per pair: e4m3 cross planes or V's low fp16 plane (with v_scale)
 };
 
 // Per-handle tuning knobs (gmf_set_tuning).  Every value selects between forms that compute the same result up to
@@ -58,8 +70,9 @@ struct Tuning {
   int mid_grid_roles = 512;  // two-launch form on grids below this many base workgroups (>= 256): the linear kernel runs as two
                              // workgroup roles per row block (Q'/K/V | Fusion-2); 0 = never
   bool q_in_attention = true;   // [r4] large grids: Q' is projected in the attention kernel's prologue, not written by k_linear_h2 (bit-identical)
-  bool pv_fp8 = true;        // parity arithmetic of the default path: the two cross products of O += P V on the block-scaled fp8 matrix
-                             // pipe (scattn_h2p_body<3, *, 4, true>).  0 = all three products on the f16 pipe
+  int pv_fp8 = 1;            // parity arithmetic of the default path: the two cross products of O += P V on the block-scaled fp8 matrix
+                             // pipe (scattn_h2p_body<3, *, 4, true>).  1 = guarded per pair and layer on the device
+                             // (PvGuard), 2 = unconditionally, 0 = all three products on the f16 pipe
   int compat_format = 0;     // element format of the compat cache on the cached, pipelined path: 0 = fp32 (default); 2 = 16-bit fixed
                              // point, rint(65535 c): half the attention's c stream and half the build, -4 % per step, absolute
                              // error <= 7.6e-6 on c.  Measured: inside the parity contract on 3DMatch-shape
@@ -87,7 +100,9 @@ hipError_t launch_fusion_attn(bool pe, const float* x, const float* ctx_img, con
                               float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s);
 hipError_t launch_fusion_ff(const float* x1, const float* wst, const float* vecs, float* x2, int B, int tiles, hipStream_t s);
 hipError_t launch_head(const float* feat_img, const float* wst, const float* vecs, float* logits, float* feat_n,
-                       float* feat_rm, int B, int N, int tiles, hipStream_t s, int* status = nullptr, const PairTab* ptab = nullptr);
+                       float* feat_rm, int B, int N, int tiles, hipStream_t s, int* status = nullptr, const PairTab* ptab = nullptr,
+                       const unsigned* pv_stat = nullptr, const float* pv_thr2 = nullptr, int n_layers = 0);   // pv_*: the "pv_fp8" guard's
+                       // statistics [n_layers][B] and thresholds - a tripped layer sets GMF_STATUS_PV_GUARDED (informational)
 hipError_t launch_ctx_prep_w(bool pe, const float* ctx, const float* wst, const float* vecs, float* out, int B, int T,
                              int ttiles, hipStream_t s);
 hipError_t launch_fusion_attn_w(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
@@ -103,18 +118,18 @@ hipError_t launch_fusion_ff_w_h2(const float* x1, const float* wst_h2, const flo
 int plan_ff_split_w(int base_wgs);
 hipError_t launch_front_h2(const Tuning& tune, int mode, const float* in, const float* wst, const float* vecs, float* f,
                            float* q, float* k, float* v, int B, int N, int tiles, hipStream_t s, const PairTab* ptab = nullptr,
-                           unsigned* v_scale = nullptr);   // v_scale: V with e4m3 cross planes (CompatCache::v_scale)
+                           unsigned* v_scale = nullptr, PvGuard guard = {});   // v_scale: V with e4m3 cross planes (CompatCache::v_scale)
 // mode 3: corr_pos -> layer0 -> PointCN -> f only.  launch_linear_h2: all linear stages of one layer from f (k_linear_h2)
 hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                             const float* attn_wst, const float* attn_vec, const float* ff_wst, const float* ff_vec, float* q,
                             float* k, float* v, float* x2, int B, int N, int tiles, int T, int ttiles, hipStream_t s, bool one_product = false,
-                            const PairTab* ptab = nullptr, unsigned* v_scale = nullptr);   // v_scale: CompatCache::v_scale
+                            const PairTab* ptab = nullptr, unsigned* v_scale = nullptr, PvGuard guard = {});   // v_scale: CompatCache::v_scale
 // small grids: three launches per layer (k_small_front_fattn | k_small_attn_ff | k_scattn_merge)
 void plan_attn_split(const Tuning& tune, int W, int tiles, int max_splits, int* n_full, int* ksplits);
 int plan_ff_split(const Tuning& tune, int base, int max_parts);
 hipError_t launch_small_front_fattn(const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                                     const float* attn_wst, const float* attn_vec, float* q, float* k, float* v, float* x1, int B,
-                                    int N, int tiles, int T, int ttiles, hipStream_t s, unsigned* v_scale = nullptr);
+                                    int N, int tiles, int T, int ttiles, hipStream_t s, unsigned* v_scale = nullptr, PvGuard guard = {});
 hipError_t launch_small_attn_ff_merge(const float* q, const float* k, const float* v, const float* x1, const float* ff_wst,
                                       const float* ff_vecs, float* ff_part, int ff_hs, const float* tail_vecs, float* out, int B,
                                       int N, int tiles, int ksplits, hipStream_t s, const CompatCache* cc, bool tile_merge = true);

@@ -364,6 +364,29 @@ class PackedEncoder(_Owned):
         self.struct = lib.gmf_packed_encoder_weights(out)       # POINTER(EncoderWeights) into the packed object
 
 
+PV_GUARD_SCORE = 1024.0      # gmf_pack.cpp kPvGuardScore
+
+
+def pv_guard_thresholds(sd: Dict[str, torch.Tensor], num_layers: int) -> torch.Tensor:
+    """Cross-check of gmf_pack.cpp `pv_guard_threshold` (gmf_encoder_weights::pv_guard): per layer the largest squared row norm
+    F^2 of the layer input for which (|Wq|_2 F + |bq|)(|Wk|_2 F + |bk|) / sqrt(C) <= PV_GUARD_SCORE, with the spectral norms
+    from an SVD and the packer's 2 % margin (PointDSC.py:23-25,56-64)."""
+    out = []
+    for i in range(num_layers):
+        n = f"encoder.blocks.NonLocal_layer_{i}."
+        Wq, Wk = _f(sd[n + "projection_q.weight"])[:, :, 0].double(), _f(sd[n + "projection_k.weight"])[:, :, 0].double()
+        nq, nk = float(_f(sd[n + "projection_q.bias"]).double().norm()), float(_f(sd[n + "projection_k.bias"]).double().norm())
+        sq, sk = 1.02 * float(torch.linalg.matrix_norm(Wq, 2)), 1.02 * float(torch.linalg.matrix_norm(Wk, 2))
+        a, b, c = sq * sk, sq * nk + sk * nq, nq * nk - PV_GUARD_SCORE * math.sqrt(C)
+        if c >= 0:
+            out.append(-1.0)
+        elif a <= 0:
+            out.append(min(1e30, (c / b) ** 2) if b > 0 else 1e30)
+        else:
+            out.append(min(1e30, ((-b + math.sqrt(b * b - 4 * a * c)) / (2 * a)) ** 2))
+    return torch.tensor(out, dtype=torch.float32)
+
+
 def python_packed_encoder(sd: Dict[str, torch.Tensor], num_layers: int, standalone_block: bool = False):
     """The encoder's blobs by the pure-Python packers (host tensors): the cross-check of the C packer.  Returns
     (dict name -> tensor, split_fp16)."""

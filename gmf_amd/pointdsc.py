@@ -395,11 +395,39 @@ class PointDSC(nn.Module):
         mode at 32 x 5000: logits 1.6e-4, identical inlier labels, 1.46x the throughput) or "throughput_max" (the layer's linear
         stages on plain fp16 operands as well: logits 4e-2, 98-100 % identical labels, 1.6x).  The setting belongs to THIS
         module: its forward sets the library handle's "precision" knob for the duration of the call and puts the previous
-        value back, so other modules on the device keep their own numerics."""
-        levels = {"parity": 0, "throughput": 1, "throughput_max": 2}
+        value back, so other modules on the device keep their own numerics.
+        "parity_strict": the parity mode with every product of the attention's P V on the f16 pipe ("pv_fp8" = 0) whatever the
+        device-side guard would decide - the form to pick when a deployment wants the three-product arithmetic in every layer
+        (about 3 % more time per step)."""
+        levels = {"parity": 0, "parity_strict": 0, "throughput": 1, "throughput_max": 2}
         if mode not in levels:
-            raise ValueError("gmf_amd.PointDSC.set_precision: mode must be 'parity', 'throughput' or 'throughput_max'")
+            raise ValueError("gmf_amd.PointDSC.set_precision: mode must be 'parity', 'parity_strict', 'throughput' or 'throughput_max'")
         self._precision = levels[mode]
+        self._strict = mode == "parity_strict"
+
+    def _call_tuned(self, h, fn, *args):
+        """One C call under this module's numerics mode: the knobs that differ from the handle's are set for the call and the
+        handle's own values PUT BACK afterwards (a handle-level gmf_set_tuning made through the C knob survives).  The
+        calls take the handle's lock one after the other: two threads driving ONE handle with different modes must serialise
+        themselves."""
+        import ctypes as C
+        want = {}
+        if getattr(self, "_precision", 0):
+            want[b"precision"] = self._precision
+        if getattr(self, "_strict", False):
+            want[b"pv_fp8"] = 0
+        prev = {}
+        for knob, val in want.items():
+            cur = C.c_int(0)
+            h.call("gmf_get_tuning", knob, C.byref(cur))
+            if cur.value != val:
+                prev[knob] = cur.value
+                h.call("gmf_set_tuning", knob, val)
+        try:
+            h.call(fn, *args)
+        finally:
+            for knob, val in prev.items():
+                h.call("gmf_set_tuning", knob, val)
 
     # -- encoder: logits + normalised features ----------------------------------------------------
     def encode(self, corr_pos, src_keypts, tgt_keypts, p_tokens, q_tokens, want_features=False):
@@ -425,25 +453,10 @@ class PointDSC(nn.Module):
         feat_n = torch.empty((B, N, 128), device=dev)
         feat = torch.empty((B, N, 128), device=dev) if want_features else None
         h, st = handle_and_stream(corr_pos, check=True)     # (raises if an earlier forward on this device produced NaN / inf)
-        # the module-local numerics mode (set_precision): applied for this call and the handle's own setting PUT BACK afterwards
-        # (a handle-level gmf_set_tuning("precision", ...) made through the C knob survives).  The three calls take the
-        # handle's lock one after the other: two threads driving ONE handle with different modes must serialise themselves.
-        prec = getattr(self, "_precision", 0)
-        prev = None
-        if prec:
-            import ctypes as C
-            cur = C.c_int(0)
-            h.call("gmf_get_tuning", b"precision", C.byref(cur))
-            if cur.value != prec:
-                prev = cur.value
-                h.call("gmf_set_tuning", b"precision", prec)
-        try:
-            h.call("gmf_encoder_forward", pw.struct, corr_pos.data_ptr(), src.data_ptr(), tgt.data_ptr(),
-                   p_tokens.data_ptr(), q_tokens.data_ptr(), B, N, T, logits.data_ptr(), feat_n.data_ptr(),
-                   None if feat is None else feat.data_ptr(), st)
-        finally:
-            if prev is not None:
-                h.call("gmf_set_tuning", b"precision", prev)
+        # the module-local numerics mode (set_precision) applies to this call only
+        self._call_tuned(h, "gmf_encoder_forward", pw.struct, corr_pos.data_ptr(), src.data_ptr(), tgt.data_ptr(),
+                         p_tokens.data_ptr(), q_tokens.data_ptr(), B, N, T, logits.data_ptr(), feat_n.data_ptr(),
+                         None if feat is None else feat.data_ptr(), st)
         return logits, feat_n, feat
 
     # -- pose head --------------------------------------------------------------------------------
@@ -559,8 +572,8 @@ class PointDSC(nn.Module):
         labels = torch.empty(total, device=dev)
         pp, _, _ = self._pose_params(max(n_points), True, None, dev)
         h, st = handle_and_stream(cp, check=True)
-        h.call("gmf_encoder_forward_ragged", pw.struct, cp.data_ptr(), sk.data_ptr(), tk.data_ptr(), p_tok.data_ptr(), q_tok.data_ptr(),
-               npts, B, T, logits.data_ptr(), feat_n.data_ptr(), None, st)
+        self._call_tuned(h, "gmf_encoder_forward_ragged", pw.struct, cp.data_ptr(), sk.data_ptr(), tk.data_ptr(), p_tok.data_ptr(),
+                         q_tok.data_ptr(), npts, B, T, logits.data_ptr(), feat_n.data_ptr(), None, st)
         h.call("gmf_pose_head_ragged", pp, float(self.ratio), feat_n.data_ptr(), sk.data_ptr(), tk.data_ptr(), logits.data_ptr(), npts, B,
                final_T.data_ptr(), labels.data_ptr(), None, None, None, None, st)
         self.last_logits, self.last_features = logits, feat_n

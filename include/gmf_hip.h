@@ -42,7 +42,9 @@ enum {
   GMF_ERR_WORKSPACE = -6   /* the caller-provided workspace (gmf_set_workspace) is too small for this call */
 };
 
-#define GMF_ABI_VERSION 4   /* 4: + gmf_get_tuning; the pose head / pick_seeds take any N (additions only: a version-3 caller keeps working) */
+#define GMF_ABI_VERSION 5   /* 5: gmf_encoder_weights gained `pv_guard` (a caller that fills the struct itself must be rebuilt; one that uses
+                             * gmf_encoder_pack_weights keeps working); "pv_fp8" takes 0 / 1 / 2.  4: + gmf_get_tuning; the pose head /
+                             * pick_seeds take any N */
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 int gmf_abi_version(void);
@@ -70,6 +72,10 @@ long long gmf_workspace_wanted(gmf_handle* h);
  *   here instead of passing silently.  The reference (fp32 throughout) has no such limit.
  * *flags receives the word; clear != 0 resets it. */
 #define GMF_STATUS_NONFINITE 1
+/* [ABI 5] informational, not an error: under "pv_fp8" = 1 the device-side guard sent at least one (pair, layer) of a finished
+ * gmf_encoder_forward(_ragged) to the three-product form of P V (the network's attention scores can exceed the bound of
+ * gmf_encoder_weights::pv_guard there).  The results are as valid as any; the bit says why a step took ~3 % longer. */
+#define GMF_STATUS_PV_GUARDED 2
 int gmf_status_read(gmf_handle* h, int* flags, int clear);
 
 /* Per-handle tuning knobs (state lives in the handle; no process globals, no environment variables).  Every setting
@@ -97,12 +103,17 @@ int gmf_status_read(gmf_handle* h, int* flags, int clear);
  *                         rint(65535 c) - half the cache, half its stream, -4 % per step, |dc| <= 7.6e-6.  Opt-in: measured inside
  *                         the 1e-4 gate on 3DMatch-shape inputs, but 4-8x the reference's own fp32 noise on KITTI-shape inputs
  *                         (profiles/r03_compat_formats.txt).
- *   "pv_fp8"            : parity arithmetic of the default path (scattn_variant 18, fused_linear 1): 1 (default) = the two CROSS products of the attention's O += P V (P_hi V_lo +
- *                         P_lo V_hi) run on the block-scaled fp8 matrix pipe, one v_mfma_scale_f32_32x32x64_f8f6f4 per feature block
- *                         and key tile, with e4m3 operands, one scale per (feature, tile) and the softmax row sum taken over exactly
- *                         the probabilities the pipe multiplies; P_hi V_hi and all of Q'K^T keep the three-product split-fp16
- *                         form.  0 = all three products of P V on the f16 pipe.  Logits of the two forms differ by <= 3e-5 (mean
- *                         2e-6) at 32 x 5000, the parity sweeps are indistinguishable (profiles/r03_pv_fp8.txt).
+ *   "pv_fp8"            : parity arithmetic of the default path (scattn_variant 18, fused_linear 1): the two CROSS products of the
+ *                         attention's O += P V (P_hi V_lo + P_lo V_hi) on the block-scaled fp8 matrix pipe - one
+ *                         v_mfma_scale_f32_32x32x64_f8f6f4 per feature block and key tile, e4m3 operands, one scale per (feature,
+ *                         tile), the softmax row sum taken over exactly the probabilities the pipe multiplies; P_hi V_hi and all of
+ *                         Q'K^T keep the three-product split-fp16 form.  1 (default) = GUARDED [ABI 5]: per pair and layer, on the
+ *                         device, from the largest row norm of the layer's input features against gmf_encoder_weights::pv_guard
+ *                         (a bound on the attention scores the layer can form): layers whose softmax can collapse onto single keys
+ *                         - where the e4m3 rounding of one key's V reaches the output whole - take the three-product form, every
+ *                         other layer the fp8 form.  No host synchronisation, no dependence on the other pairs of the batch.
+ *                         2 = the fp8 form unconditionally, 0 = all three products of P V on the f16 pipe (the strict form).
+ *                         Logits of the two forms differ by <= 3e-5 (mean 2e-6) at 32 x 5000 (profiles/r03_pv_fp8.txt).
  *   "attn_tail_split"   : 1 = large grids: the last partial round of attention workgroups is split by keys, 0 = whole (default).
  *   "small_grid_roles"  : 1 = small grids run three launches per layer with mixed workgroup roles (default), 0 = one per stage.
  *   "attn_key_splits"   : 0 = automatic (small grids only), 1 = off, 2..8 = forced number of key splits.
@@ -203,6 +214,11 @@ typedef struct gmf_encoder_weights {
   /* optional split-fp16 image of the fc_message weights (same size and stride as tail_wst): the epilogue of the cached,
    * software-pipelined attention kernel then runs on the f16 MFMA too. */
   const float* tail_wst_h2;
+  /* [ABI 5] optional, [num_layers]: the "pv_fp8" guard.  Entry l is the largest SQUARED row norm of layer l's input features
+   * f = ReLU(PointCN_l(.)) up to which that layer's attention may run its P V cross products on the fp8 pipe (written by
+   * gmf_encoder_pack_weights from the spectral norms of projection_q / projection_k, PointDSC.py:23-25,56-64); NULL = no guard
+   * ("pv_fp8" = 1 then behaves as 2). */
+  const float* pv_guard;
 } gmf_encoder_weights;
 
 /* ---- weight packing ---------------------------------------------------------------------------

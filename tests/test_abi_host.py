@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gmf_hip.h but not exported"
     assert set(declared) == set(_lib.SIGNATURES), set(declared) ^ set(_lib.SIGNATURES)
-    assert lib.gmf_abi_version() == 4
+    assert lib.gmf_abi_version() == 5
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device error path")
@@ -152,6 +152,35 @@ def test_c_weight_packing_equals_python_packing_bit_for_bit(standalone):
         if not standalone:
             assert sig.value == float(sd["sigma"].reshape(-1)[0]) and sig_d.value == float(sd["sigma_spat"].reshape(-1)[0])
         assert sp.value == 1 and 0 < amax.value <= 65504
+    finally:
+        lib.gmf_packed_encoder_free(out)
+
+
+def test_pv_guard_thresholds_of_the_packer():
+    """gmf_encoder_weights::pv_guard (ABI 5): per layer the squared row norm of the layer input up to which the attention's P V
+    cross products may run on the fp8 pipe, from the spectral norms of projection_q / projection_k (power iteration in the C
+    packer; an SVD here).  Scaling a layer's projections moves its threshold the way the bound says; biases that pass the bound
+    by themselves give -1 (always guarded)."""
+    from gmf_amd import _lib, packing, synthetic
+    L = 3
+    sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, L, 128), seed=11)
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["encoder.blocks.NonLocal_layer_1.projection_q.weight"] *= 7.0
+    sd["encoder.blocks.NonLocal_layer_2.projection_q.bias"] = torch.full_like(sd["encoder.blocks.NonLocal_layer_2.projection_q.bias"], 400.0)
+    sd["encoder.blocks.NonLocal_layer_2.projection_k.bias"] = torch.full_like(sd["encoder.blocks.NonLocal_layer_2.projection_k.bias"], 400.0)
+    lib = _lib.load_library()
+    arr, keep = _lib.tensor_list(sd)
+    out = ctypes.c_void_p()
+    assert lib.gmf_encoder_pack_weights(None, arr, len(arr), L, 0, ctypes.byref(out)) == 0
+    try:
+        w = lib.gmf_packed_encoder_weights(out).contents
+        assert w.pv_guard
+        got = _c_blob(w.pv_guard, L).view(np.float32)
+        ref = packing.pv_guard_thresholds(sd, L).numpy()
+        assert got[2] == -1.0 and ref[2] == -1.0          # |bq| |bk| = 400^2 * 128 > 1024 sqrt(128)
+        assert np.allclose(got[:2], ref[:2], rtol=2e-3), (got, ref)
+        assert 20.0 < got[0] ** 0.5 < 200.0               # seeded weights: the guard trips at row norms of a few tens
+        assert 2.0 < got[0] / got[1] < 49.0               # a 7 x larger Wq: a lower threshold, by at most 7^2
     finally:
         lib.gmf_packed_encoder_free(out)
 

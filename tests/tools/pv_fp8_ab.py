@@ -17,7 +17,7 @@ from oracle import gmf_oracle as O
 n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
-FORMS = [0, 1]
+FORMS = [0, 1, 2]      # three f16 products | fp8 cross products under the device-side guard (default) | unconditionally
 dev = torch.device("cuda:0")
 sd = synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7)
 model = gmf_amd.PointDSC(num_layers=12); model.load_state_dict(sd, strict=False); model = model.to(dev).eval()

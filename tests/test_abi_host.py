@@ -322,3 +322,21 @@ def test_unsupported_configurations_are_refused_at_construction():
         with pytest.raises(NotImplementedError):
             gmf_amd.PointDSC(**kw)
     gmf_amd.PointDSC(in_dim=6, num_layers=3, k=40)        # what GMF instantiates (with 12 layers) constructs anywhere
+
+
+def test_bench_launches_its_own_ranks_and_refuses_without_devices():
+    """`python bench.py --gpus N` without a launcher starts its ranks itself (bench.launch_ranks: children of a process that made
+    no GPU call).  On a host with fewer devices than ranks it refuses up front with exit code 2; with --rehearsal (shared
+    devices, gloo) the children are started and - on a host without any HIP device - each of them fails loudly, which the
+    parent reports as a non-zero exit code instead of hanging."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU host: the refusal path does not apply")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-sweep", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "one rank per GPU needs 2" in r.stderr and not r.stdout.strip()
+    if torch.cuda.device_count() == 0:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearsal", "--no-sweep", "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and r.stderr.count("needs a HIP device") == 2 and not r.stdout.strip()

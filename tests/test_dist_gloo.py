@@ -149,6 +149,59 @@ def test_two_rank_gloo_matches_single_process(B):
             assert ("shard plan" in bad) == (rank == 1 or B == 5)
 
 
+def _plan_worker(rank, world, port, q, B, N):
+    """One rank of BASELINE config 4's plan (B pairs over 8 ranks): the sharded step on its shard, one collective, the gathered
+    result back through the queue as checksums (rank 0 also sends the tensors)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from gmf_amd.dist import ShardedBatchDriver, shard_sizes
+    drv = ShardedBatchDriver(_fake_model, world, rank, torch.device("cpu"), backend="gloo")
+    calls = []
+    real = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    out = drv.run(_global_batch(B=B, N=N))
+    dist.all_gather_into_tensor = real
+    local = int(out["logits"].shape[0])
+    t = drv.max_over_ranks(float(rank + 1))
+    q.put((rank, local, len(calls), t, float(out["all_logits"].double().sum()), float(out["all_trans"].double().sum()),
+           (out["all_logits"].clone(), out["all_trans"].clone()) if rank == 0 else None, drv.group_size(), drv.backend_name()))
+    drv.barrier()
+    drv.close()
+
+
+@pytest.mark.parametrize("B", [256, 250])
+def test_eight_rank_gloo_config4_plan(B):
+    """BASELINE config 4's shard plan on CPU: 256 pairs over 8 ranks (32 each - what bench.py --gpus 8 runs per step) and 250
+    pairs (32, 32, 31, ... : padded to 32 rows inside the packed buffer, trimmed after the gather).  Every rank runs its own
+    shard, enters exactly ONE all-gather, and ends with the single-process result: bit for bit on rank 0, by checksum on the
+    others.  (No reference counterpart: train_3DMatch.py:17 pins one GPU)"""
+    from gmf_amd.dist import shard_sizes
+    world, N = 8, 24
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_plan_worker, args=(r, world, port, q, B, N)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref = _fake_model(_global_batch(B=B, N=N))
+    sizes = shard_sizes(B, world)
+    assert sizes == ([32] * 8 if B == 256 else [32, 32, 31, 31, 31, 31, 31, 31])
+    s_l, s_t = float(ref["logits"].double().sum()), float(ref["final_trans"].double().sum())
+    for rank, local, n_coll, t, cl, ct, tensors, gsize, backend in got:
+        assert local == sizes[rank] and n_coll == 1 and t == float(world)
+        assert cl == s_l and ct == s_t
+        assert gsize == world and backend == "gloo"
+        if tensors is not None:
+            assert torch.equal(tensors[0], ref["logits"]) and torch.equal(tensors[1], ref["final_trans"])
+
+
 def test_shard_sizes_match_ranges():
     from gmf_amd.dist import shard_range, shard_sizes
     assert shard_sizes(5, 2) == [3, 2] and shard_sizes(256, 8) == [32] * 8 and shard_sizes(3, 4) == [1, 1, 1, 0]

@@ -768,13 +768,17 @@ constexpr float kInvU16 = 1.0f / 65535.0f;
 template <int NPROD = 3, int CFMT = 0, int WAVES = 4, bool PVF8 = false>
 GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restrict__ q_img, const float* __restrict__ k_img,
                                 const float* __restrict__ v_img, const float* __restrict__ fus, const float* __restrict__ wst,
-                                const float* __restrict__ vecs, float* __restrict__ out, int N, int tiles, int wgs_per_pair,
+                                const float* __restrict__ vecs, float* out, int N, int tiles, int wgs_per_pair,
                                 const float* __restrict__ c_dense, int n_items, int n_full, int ksplits,
                                 float* __restrict__ part_o, float* __restrict__ part_ml, const float* __restrict__ next_wst,
                                 const float* __restrict__ next_bias, const PairTab* __restrict__ ptab = nullptr,
                                 const unsigned* __restrict__ v_scale = nullptr,
                                 // [r4] non-null: q_img is not read - the workgroup projects its own Q' from the layer's f tile (below)
-                                const float* __restrict__ qf_img = nullptr, const float* __restrict__ qw_wst = nullptr,
+                                // (qf_img is NOT restrict: for every layer but the last it is the buffer `out` - f_{l+1} overwrites f_l in
+                                // place.  The invariant that makes this safe: a tile of f is read only by the workgroup(s) of that tile - in
+                                // the prologue, before the tile loop - and written only by that workgroup's epilogue (whole items) or by the
+                                // LATER merge launch (split items): no tile is written before its last reader is done.  ADVICE r4)
+                                const float* qf_img = nullptr, const float* __restrict__ qw_wst = nullptr,
                                 const float* __restrict__ qw_bias = nullptr,
                                 unsigned* __restrict__ stat_next = nullptr) {     // [r5] PvGuard::stat_next (whole items with the next PointCN)
   static_assert(!PVF8 || NPROD == 3, "the fp8 cross products belong to the three-product form");
@@ -1298,10 +1302,10 @@ template <int NPROD, int CFMT, bool PVF8 = false>
 __global__ void __launch_bounds__(256, 2)
 k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, const float* __restrict__ v_img,
              const float* __restrict__ fus, const float* __restrict__ wst, const float* __restrict__ vecs,
-             float* __restrict__ out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_dense,
+             float* out, int N, int tiles, int wgs_per_pair, const float* __restrict__ c_dense,
              int n_items, int n_full, int ksplits, float* __restrict__ part_o, float* __restrict__ part_ml,
              const float* __restrict__ next_wst, const float* __restrict__ next_bias, const PairTab* __restrict__ ptab,
-             const unsigned* __restrict__ v_scale, const float* __restrict__ qf_img, const float* __restrict__ qw_wst,
+             const unsigned* __restrict__ v_scale, const float* qf_img, const float* __restrict__ qw_wst,
              const float* __restrict__ qw_bias, const PvGuard guard) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
   tail_priority(blockIdx.x, gridDim.x);

@@ -608,8 +608,13 @@ int place_into(gmf_handle* h, const std::vector<float>& host_block, void* device
     return GMF_ERR_BAD_ARG;
   }
   SetDevice sd(h, stream);
-  hipError_t rc = hipMemcpyAsync(device_dst, host_block.data(), host_block.size() * sizeof(float), hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream));
-  if (rc != hipSuccess) { h->err = std::string("gmf: ") + what + ": hipMemcpyAsync: " + hipGetErrorString(rc); return GMF_ERR_HIP; }
+  // The source is pageable host memory owned by the packed object: the copy is ordered on the caller's stream and WAITED for
+  // here, so that gmf_packed_*_free (or a re-pack) right after this call cannot free the bytes of a transfer in flight
+  // (packing is a once-per-checkpoint step that already ends in a device-to-host synchronisation).
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipError_t rc = hipMemcpyAsync(device_dst, host_block.data(), host_block.size() * sizeof(float), hipMemcpyHostToDevice, st);
+  if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+  if (rc != hipSuccess) { h->err = std::string("gmf: ") + what + ": copy to the device: " + hipGetErrorString(rc); return GMF_ERR_HIP; }
   return GMF_OK;
 }
 }  // namespace

@@ -190,6 +190,10 @@ class ImageEncoder(nn.Module):
     def forward(self, x):
         if self.training or not x.is_cuda:
             return self.backbone(x)
+        # eval() with autograd on and something to differentiate (fine-tuning with frozen BatchNorm statistics): the fused,
+        # graph-replayed pass below returns tensors without a grad_fn - take the stock modules, which do carry one
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.backbone.parameters())):
+            return self.backbone(x)
         enc = self.fused()
         return self._graphed(enc, x) if self.graph else enc(x)
 

@@ -9,29 +9,57 @@ import torch
 from ._util import handle_and_stream, require_cuda_f32
 
 
-_OFFSETS_CACHE: dict = {}                 # (device, offsets) -> int32 device tensor; evaluation loops repeat a handful of shapes
+import collections
+import os
+import threading
+
+# (device, offsets) -> (int32 device tensor, largest problem): an LRU of the 64 most recent offset lists behind a lock (callers on
+# several threads share it).  Evaluation loops that repeat a handful of shapes hit it; a loop whose offsets change on every
+# call pays the upload each time - through a pinned staging buffer and an asynchronous copy, not a pageable synchronous one.
+_OFFSETS_CACHE: "collections.OrderedDict" = collections.OrderedDict()
+_OFFSETS_LOCK = threading.Lock()
+_OFFSETS_CAP = 64
 
 
 def _device_offsets(offsets, n_rows: int, device, what: str):
     """The row offsets of a ragged batch as an int32 device tensor, and the largest problem.  A Python sequence is checked
     here (increasing, from 0 to n_rows) without a device round trip and its device copy is kept for the next call with the
-    same offsets - the upload is a synchronous pageable copy, 20 us of a 10 us solve; an int32 tensor already on the device
+    same offsets (a list met for the first time travels through a pinned buffer, asynchronously); an int32 tensor already on the device
     is taken as it is (the caller vouches for it: only its end is not read back)."""
     if isinstance(offsets, torch.Tensor) and offsets.is_cuda:
         if offsets.dtype != torch.int32 or offsets.dim() != 1 or offsets.numel() < 2 or not offsets.is_contiguous() \
                 or offsets.device != device:
             raise RuntimeError(f"gmf_amd.{what}: device offsets must be a contiguous int32 vector of B + 1 entries on the points' device")
+        if os.environ.get("GMF_DEBUG_OFFSETS"):          # (debugging aid: one device read-back of the whole vector)
+            off_h = offsets.cpu().tolist()
+            if off_h[0] != 0 or off_h[-1] != n_rows or any(b <= a for a, b in zip(off_h, off_h[1:])):
+                raise RuntimeError(f"gmf_amd.{what}: device offsets must be increasing, start at 0 and end at N")
         return offsets, n_rows
     off = tuple(int(o) for o in offsets)
     if len(off) < 2 or off[0] != 0 or off[-1] != n_rows or any(b <= a for a, b in zip(off, off[1:])):
         raise RuntimeError(f"gmf_amd.{what}: offsets must be increasing, start at 0 and end at N")
     key = (device, off)
-    hit = _OFFSETS_CACHE.get(key)
-    if hit is None:
-        if len(_OFFSETS_CACHE) >= 64:
-            _OFFSETS_CACHE.clear()
-        hit = _OFFSETS_CACHE[key] = (torch.tensor(off, dtype=torch.int32).to(device), max(b - a for a, b in zip(off, off[1:])))
-    return hit
+    with _OFFSETS_LOCK:
+        hit = _OFFSETS_CACHE.get(key)
+        if hit is not None:
+            _OFFSETS_CACHE.move_to_end(key)
+            if hit[3] is not None:                   # the upload may still be in flight on ANOTHER stream: order this one behind it
+                if hit[3].query():
+                    hit[3] = None
+                else:
+                    torch.cuda.current_stream(device).wait_event(hit[3])
+            return hit[0], hit[1]
+    # not cached: a pinned host copy and an asynchronous upload on the current stream (ordered before the solve that follows)
+    host = torch.tensor(off, dtype=torch.int32).pin_memory()
+    dev_off = host.to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    entry = [dev_off, max(b - a for a, b in zip(off, off[1:])), host, ev]     # (the pinned source lives as long as the entry)
+    with _OFFSETS_LOCK:
+        _OFFSETS_CACHE[key] = entry
+        while len(_OFFSETS_CACHE) > _OFFSETS_CAP:
+            _OFFSETS_CACHE.popitem(last=False)
+    return entry[0], entry[1]
 
 
 class _WeightedProcrustes(torch.autograd.Function):

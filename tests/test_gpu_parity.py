@@ -1065,6 +1065,59 @@ def test_config2_full_batch(model, sd_full):
         assert _maxerr(r1["final_trans"].cpu(), T[p:p + 1]) < 1e-4
 
 
+def test_compat_cache_beyond_2_31_elements(model, sd_full):
+    """the largest row bench.py times - 32 pairs x 10 000 correspondences - puts 32 x 313^2 x 1024 = 3.2e9
+    elements (12.8 GB) in the compat cache (PointDSC.py:216-221), past 2^31: every tile offset on the path is 64-bit or this
+    test fails.  Properties for all 32 pairs (finite, rigid, close to the ground truth, labels), the LAST pair - the highest
+    addresses - and pair 0 against the CPU oracle at the literal 1e-4 (logits) / 1e-3 (pose), and the last pair run alone (B = 1:
+    a cache of 1e8 elements) reproduces its row of the batch to 5e-5.  Then the ragged entry with sum n_i^2 tiles past 2^31 as
+    well: 24 pairs of 9 400 ... 10 000 rows in one launch, two of them against their own B = 1 runs."""
+    B, N = 32, 10000
+    assert B * ((N + 31) // 32) ** 2 * 1024 > 2 ** 31
+    b = synthetic.synthetic_batch(list(range(2000, 2000 + B)), N=N, T=196)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    res = model(data)
+    logits = model.last_logits.clone()
+    T = res["final_trans"].cpu().numpy()
+    assert np.isfinite(T).all() and torch.isfinite(logits).all()
+    R = T[:, :3, :3]
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5
+    assert np.abs(T - b["gt_trans"].numpy()).max() < 5e-2
+    lab = res["final_labels"].cpu().numpy()
+    assert ((lab > 0.5) == (b["gt_labels"].numpy() > 0.5)).mean(axis=1).min() > 0.97
+    for p in (B - 1, 0):
+        one = {k: v[p:p + 1] for k, v in b.items()}
+        ref = O.pointdsc_forward(sd_full, one, testing=True)
+        e = _maxerr(logits[p:p + 1].cpu(), ref["logits"])
+        print(f"32 x 10000, pair {p}: HIP vs oracle {e:.2e}, pose {_maxerr(T[p:p + 1], ref['final_trans'].numpy()):.2e}")
+        assert e < 1e-4, (p, e)
+        assert _maxerr(T[p:p + 1], ref["final_trans"].numpy()) < 1e-3
+    d1 = {k: (v[B - 1:B] if torch.is_tensor(v) else v) for k, v in data.items()}
+    r1 = model(d1)
+    assert _maxerr(model.last_logits.cpu(), logits[B - 1:B].cpu()) < 5e-5
+    assert _maxerr(r1["final_trans"].cpu(), T[B - 1:B]) < 1e-4
+    del data, res, logits
+    torch.cuda.empty_cache()
+    # the ragged entry: every pair keeps a slot of tiles(max n)^2 tiles
+    sizes = [10000 - 25 * i for i in range(24)]
+    assert len(sizes) * ((max(sizes) + 31) // 32) ** 2 * 1024 > 2 ** 31
+    pairs = [synthetic.synthetic_batch([2100 + i], N=n, T=196) for i, n in enumerate(sizes)]
+    rag = {k: [_gpu(q[k][0]) for q in pairs] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    rag.update(p_tokens=torch.cat([_gpu(q["p_tokens"]) for q in pairs]), q_tokens=torch.cat([_gpu(q["q_tokens"]) for q in pairs]), testing=True)
+    rr = model(rag)
+    for i, q in enumerate(pairs):
+        lg = rr["logits"][i]
+        assert lg.shape == (sizes[i],) and torch.isfinite(lg).all()
+        assert np.abs(rr["final_trans"][i].cpu().numpy() - q["gt_trans"][0].numpy()).max() < 5e-2
+    for i in (len(sizes) - 1, 0):
+        d1 = {k: _gpu(pairs[i][k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+        d1["testing"] = True
+        r1 = model(d1)
+        assert _maxerr(model.last_logits[0].cpu(), rr["logits"][i].cpu()) < 5e-5, i
+        assert _maxerr(r1["final_trans"][0].cpu(), rr["final_trans"][i].cpu()) < 1e-4, i
+
+
 def test_kitti_shape_long_sequence():
     """BASELINE config 3 at full size: 16 pairs x N = 10000, sigma_d = tau = 1.2 (KITTI).  One pair against the oracle is ~10 s
     of CPU, so the full batch is checked through properties, plus a smaller KITTI-shape pair against the oracle."""
@@ -1284,6 +1337,10 @@ def test_f11_image_tokens_small_batch(golden_dir, graph):
         fmap = m.encoder.image_encoder(_gpu(img))
     assert fmap.shape == (2, 128, 15, 20)
     assert _maxerr(fmap.flatten(2).permute(0, 2, 1).cpu(), g["tokens"]) < 1e-4 * scale
+    # eval() with autograd on and trainable parameters (fine-tuning with frozen BatchNorm statistics): the differentiable stock
+    # modules, not the graph-replayed pass whose output has no grad_fn
+    fmap_g = m.encoder.image_encoder(_gpu(img))
+    assert fmap_g.grad_fn is not None and _maxerr(fmap_g.detach().cpu(), fmap.cpu()) < 1e-4 * scale
 
 
 @pytest.mark.parametrize("tag,graph,patch", [("64x120x160", True, 1), ("64x120x160", False, 1), ("64x120x160", False, 2),

@@ -60,6 +60,8 @@ GMF_DEVINL void store_block_h2(float* __restrict__ tile_base, int blk, const flo
   }
 }
 
+// [r5] The same routine writes the K image of that form (t: the lane's KEY, 16 channels of block db; one scale per (key, 32-channel
+// block)): the cross products of S = K Q'^T run on the fp8 pipe too (q_planes8 below is the B operand's side).
 // The V image of the parity attention kernel's "pv_fp8" form (k_scattn_h2p<3, CFMT, true>): the high fp16 plane as above; in
 // place of the low fp16 plane, per feature block db, the two e4m3 operands of the CROSS products of O += P V -
 //   16-byte unit (1*8 + 2 db)*64 + lane :  e4m3((v - hi) / (s / 2^11))   of the lane's 16 keys, register order
@@ -102,6 +104,38 @@ GMF_DEVINL void store_block_v8(float* __restrict__ tile_base, int db, const floa
   }
   reinterpret_cast<i32x4*>(tile_base)[(1 * 8 + 2 * db) * 64 + lane] = l8;
   reinterpret_cast<i32x4*>(tile_base)[(1 * 8 + 2 * db + 1) * 64 + lane] = v8;
+}
+
+// [r5] The same planes for the B operand of S = K Q'^T (scattn_h2p_body, PVF8): block cb of a query row's Q' (its 16 values on this
+// lane, given as the split-fp16 planes the kernel already holds: x = hi + lo) as the 32 operand bytes
+//     bytes 0..15  e4m3((hi + lo) / s)          - meets the K image's e4m3(k - k_hi) bytes (store_block_v8 on a K block)
+//     bytes 16..31 e4m3(lo / (s / 2^11))        - meets its e4m3(k) bytes
+// with ONE power-of-two scale per (query, 32-channel block): the block's largest |q| in [128, 256) s, floor 2^-22 as for V.
+// Byte cb of `scale_word`: lanes 0..31 carry block 0's E8M0 (s), lanes 32..63 block 1's (s / 2^11).  Built from (hi, lo) - not
+// from the fp32 value - so that a Q' read back from an image gives the same bytes as one projected in the prologue.
+GMF_DEVINL void q_planes8(const f16x8& h0, const f16x8& l0, const f16x8& h1, const f16x8& l1, int cb, int lane, i32x8& out,
+                          unsigned& scale_word) {
+  float q[16], ql[16];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ql[e] = (float)l0[e]; q[e] = (float)h0[e] + ql[e];
+    ql[8 + e] = (float)l1[e]; q[8 + e] = (float)h1[e] + ql[8 + e];
+  }
+  float mx = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mx = __builtin_fmaxf(mx, __builtin_fabsf(q[r]));
+  mx = xhalf_max_swap(mx);
+  const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+  const int sb = max(e - 7, 105);
+  const float s_hi = __uint_as_float((unsigned)sb << 23), s_lo = __uint_as_float((unsigned)(sb - 11) << 23);
+  scale_word |= (unsigned)((lane & 32) ? sb - 11 : sb) << (8 * cb);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    int a = cvt2_fp8_f32<false>(0, q[4 * w], q[4 * w + 1], s_hi);
+    out[w] = cvt2_fp8_f32<true>(a, q[4 * w + 2], q[4 * w + 3], s_hi);
+    int b = cvt2_fp8_f32<false>(0, ql[4 * w], ql[4 * w + 1], s_lo);
+    out[4 + w] = cvt2_fp8_f32<true>(b, ql[4 * w + 2], ql[4 * w + 3], s_lo);
+  }
 }
 
 // ---- the "pv_fp8" guard (PvGuard, launchers.hpp) ---------------------------------------------------------------

@@ -113,6 +113,10 @@ GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const in
   }
   fx.set(f);
 
+  // e4m3 cross planes (V: per (feature, key tile); [r5] K: per (key, 32-channel block)) or the low fp16 planes - uniform per pair and layer
+  const bool v8 = pv_planes_on(v_scale, guard, pair);
+  unsigned* const sw_tile = v_scale ? v_scale + ((size_t)pair * tiles + tile) * 128 + lane : nullptr;     // [V: 64 lanes | K: 64 lanes]
+  unsigned ksw = 0;
 #pragma unroll
   for (int which = 0; which < 2; ++which) {   // Q', K
     if (zsplit && zsel != which) continue;
@@ -126,12 +130,15 @@ GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const in
       load_vec_block(b, vecs + (1 + which) * C, mb, h);
 #pragma unroll
       for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, b[r]);
-      if (active) store_block_h2(dst, mb, t, lane);
+      if (active) {
+        if (which == 1 && v8) store_block_v8(dst, mb, t, lane, ksw);
+        else store_block_h2(dst, mb, t, lane);
+      }
     }
+    if (which == 1 && active && v8) sw_tile[64] = ksw;
   }
   if (zsplit && zsel != 2) return;
   unsigned vsw = 0;
-  const bool v8 = pv_planes_on(v_scale, guard, pair);     // e4m3 cross planes or the low fp16 plane (uniform per pair and layer)
 #pragma unroll
   for (int db = 0; db < 4; ++db) {             // V (feature on lane)
     const f16x8* lw = as_h2(ss.acquire());
@@ -146,7 +153,7 @@ GMF_DEVINL void front_h2_body(float* lds, const int bx, const int pair, const in
       else store_block_h2(v_out + toff, db, t, lane);
     }
   }
-  if (active && v8) v_scale[((size_t)pair * tiles + tile) * 64 + lane] = vsw;
+  if (active && v8) sw_tile[0] = vsw;
 }
 
 template <int MODE>
@@ -502,6 +509,9 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
     // counts its own loads but not the ring's DMA pieces - put `s_waitcnt vmcnt(35 .. 32)` in front of every stage's bias add,
     // i.e. a wait for the store acknowledgements of four stages back in the middle of every epilogue from stage 5 on.
     ss.prime();                                  // AFTER the load above: its wait then leaves the three primed stages in flight
+    const bool v8 = pv_planes_on(v_scale, guard, pair);          // [r5] decides the K image's cross planes as well as V's
+    unsigned* const sw_tile = v_scale ? v_scale + ((size_t)pair * tiles + tile) * 128 + lane : nullptr;     // [V: 64 lanes | K: 64 lanes]
+    unsigned ksw = 0;
 #pragma unroll
     for (int which = (QSKIP ? 1 : 0); which < 2; ++which) {   // Q', K
       float* dst = (which == 0 ? q_out : k_out) + toff;
@@ -519,11 +529,11 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
         load_vec_block(bb, lvec_p + which * C, mb, h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, bb[r]);
-        store_block_h2(dst, mb, t, lane);
+        if (which == 1 && v8) store_block_v8(dst, mb, t, lane, ksw);     // (4 stores of 16 bytes either way)
+        else store_block_h2(dst, mb, t, lane);
       }
     }
     unsigned vsw = 0;
-    const bool v8 = pv_planes_on(v_scale, guard, pair);
 #pragma unroll
     for (int db = 0; db < 4; ++db) {             // V (feature on lane)
       const f16x8* lw = as_h2(PART == 1 ? ss.acquire() : ss.acquire_counted<20>());
@@ -538,7 +548,7 @@ GMF_DEVINL void linear_h2_body(float* lds, const float* __restrict__ f_in, const
     }
     // one more store than the counted waits of the stages that follow assume: their counts are lower bounds, it only makes them
     // wait for one operation more
-    if (v_scale) v_scale[((size_t)pair * tiles + tile) * 64 + lane] = vsw;     // (written either way: one store count for both forms)
+    if (v_scale) { sw_tile[0] = vsw; sw_tile[64] = ksw; }     // (written either way: one store count for both forms)
   }
 
   if (PART == 1) {

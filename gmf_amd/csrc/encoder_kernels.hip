@@ -845,17 +845,34 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
       if (NPROD == 3) ql[s] = qp[(1 * 8 + s) * 64];
     }
   }
+  // [r5] PVF8: the two CROSS products of S = K Q'^T run on the block-scaled fp8 pipe as well - per key tile 8 f16 MFMAs (K_hi Q'_hi) and 4
+  // v_mfma_scale_f32_32x32x64_f8f6f4 (one per 32-channel block: [e4m3(k - k_hi) | e4m3(k)] x [e4m3(q) | e4m3(q_lo)]) instead of 24 f16
+  // MFMAs: 512 instead of 768 matrix-pipe cycles.  Allowed by the same device-side guard as the P V form (a layer whose scores can
+  // reach the bound multiplies everything on the f16 pipe): fp64 emulation of the whole encoder under the guard, max |logit - fp64|:
+  // 3.00e-4 / 3.28e-4 on the ill-conditioned KITTI weight set (P V alone: 3.01e-4 / 3.29e-4; the reference's own fp32: 3.08e-4 / 2.68e-4),
+  // 1.9e-6 / 4.5e-6 on 3DMatch-shape inputs (reference 1.8e-5 / 1.3e-5) - tests/tools/mx_cross_emulation.py.  The Q' operand is built
+  // here, once per workgroup, from the planes (q_planes8); the K operand arrives in the K image (store_block_v8 on K blocks).
+  i32x8 qb[4];
+  unsigned qsw = 0;
+  if (PVF8) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) q_planes8(qh[2 * cb], ql[2 * cb], qh[2 * cb + 1], ql[2 * cb + 1], cb, lane, qb[cb], qsw);
+  }
   constexpr int kCTile16 = CFMT ? 128 : 256;           // 16-byte pieces per c tile
   const f32x4* const crow = reinterpret_cast<const f32x4*>(c_dense) + ((pbase + tile) * (size_t)tiles) * kCTile16 + lane;
   float c[16];                                         // CFMT 0 / 1: the compat values of the tile
   unsigned cw[8];                                      // CFMT 2: the tile's 16 x 16 bit as loaded (decoded where the scores are formed)
   // PVF8: the E8M0 scale bytes of V tile t for this lane (byte db), fetched with c one tile ahead and handed over at the tile top
-  const unsigned* const vsrow = PVF8 ? v_scale + pbase * 64 + lane : nullptr;
-  unsigned vsw_next = 0, vsw = 0;
+  // ... [r5] and of K tile t + 1 (byte cb: the key's 32-channel block cb): the scale words of a tile lie as [V: 64 lanes | K: 64 lanes]
+  const unsigned* const vsrow = PVF8 ? v_scale + pbase * 128 + lane : nullptr;
+  unsigned vsw_next = 0, vsw = 0, ksw_next = 0, ksw = 0;
   const int psc = (lane & 32) ? 117 : 129;             // scale bytes of the probability operand: block 0 = e4m3(p / 4), block 1 = e4m3(p_lo 2^10)
   auto fetch_c = [&](int t) {
     const f32x4* ct = crow + (size_t)t * kCTile16;
-    if (PVF8) vsw_next = __builtin_nontemporal_load(vsrow + (size_t)t * 64);
+    if (PVF8) {
+      vsw_next = __builtin_nontemporal_load(vsrow + (size_t)t * 128);
+      ksw_next = __builtin_nontemporal_load(vsrow + (size_t)min(t + 1, tiles_p - 1) * 128 + 64);      // (consumed by S_{t+1} during tile t)
+    }
     if (CFMT == 1) {
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
@@ -938,10 +955,25 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   f32x16 s_a = zero16(), s_b;
+  // S of one key tile in the fp8 form: 8 f16 MFMAs on the high planes + 4 scaled fp8 MFMAs on the cross planes
+  auto s_cross8 = [&](f32x16 acc, const f16x8* lkt, const int cb, const unsigned kscale) -> f32x16 {
+    const i32x4* l8 = reinterpret_cast<const i32x4*>(lkt);
+    const i32x4 a_lo = l8[(1 * 8 + 2 * cb) * 64], a_hi = l8[(1 * 8 + 2 * cb + 1) * 64];
+    const i32x8 ka = {a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
+    return mfma_f8s2(ka, qb[cb], acc, cb, (int)kscale, (int)qsw);
+  };
   if (active) {
     const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK + (t_begin & 1) * kStageFloats) + lane;
+    if (PVF8) {
+      const unsigned ks0 = vsrow[(size_t)t_begin * 128 + 64];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) mma_n(s_a, lk[(0 * 8 + s) * 64], lk[(1 * 8 + s) * 64], qh[s], ql[s]);
+      for (int s = 0; s < 8; ++s) s_a = mfma_h16(lk[(0 * 8 + s) * 64], qh[s], s_a);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) s_a = s_cross8(s_a, lk, cb, ks0);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) mma_n(s_a, lk[(0 * 8 + s) * 64], lk[(1 * 8 + s) * 64], qh[s], ql[s]);
+    }
   }
 
   // top of tile t: K_{t+1}, V_t, c_t have landed and every wave is done with K_t and V_{t-1}.  The scores x = c_t * s_t
@@ -1080,6 +1112,7 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     vsw = vsw_next;
+    ksw = ksw_next;
     const f16x8* lv = reinterpret_cast<const f16x8*>(ldsV + (t & 1) * kStageFloats) + lane;
     const f16x8* lk = reinterpret_cast<const f16x8*>(ldsK + ((t + 1) & 1) * kStageFloats) + lane;
     f16x8 ph0, pl0, ph1, pl1;
@@ -1088,14 +1121,24 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
     auto hslot = [](int u) { return (0 * 8 + 2 * (u & 3) + (u >> 2)) * 64; };
     s_next = zero16();
     {
-      f16x8 kh = lk[0], kl = lk[8 * 64];
-      f16x8 kh_n = kh, kl_n = kl;
+      // [r5] 12 matrix instructions in the phase's 24 units: K_hi Q'_hi of k-step s at unit 3 s + 2, the scaled fp8 MFMA of channel block
+      // cb (k-steps 2 cb, 2 cb + 1) at unit 6 cb + 3; its two 16-byte K fragments are requested one k-step earlier (unit 6 cb)
+      const i32x4* lk8 = reinterpret_cast<const i32x4*>(lk);
+      f16x8 kh = lk[0];
+      f16x8 kh_n = kh;
+      i32x4 k8a = lk8[(1 * 8) * 64], k8b = lk8[(1 * 8 + 1) * 64];
 #pragma unroll
       for (int u = 0; u < 24; ++u) {
         const int s = u / 3, pr = u % 3;
-        if (pr == 0 && s < 7) { kh_n = lk[(0 * 8 + s + 1) * 64]; kl_n = lk[(1 * 8 + s + 1) * 64]; }
-        s_next = mma3_part(pr, s_next, kh, kl, qh[s], ql[s]);
-        if (pr == 2) { kh = kh_n; kl = kl_n; }
+        if (pr == 0 && s < 7) kh_n = lk[(0 * 8 + s + 1) * 64];
+        if (pr == 2) s_next = mfma_h16(kh, qh[s], s_next);
+        if (pr == 0 && (s & 1)) {
+          const int cb = s >> 1;
+          const i32x8 ka = {k8a[0], k8a[1], k8a[2], k8a[3], k8b[0], k8b[1], k8b[2], k8b[3]};
+          s_next = mfma_f8s2(ka, qb[cb], s_next, cb, (int)ksw, (int)qsw);
+          if (cb < 3) { k8a = lk8[(1 * 8 + 2 * cb + 2) * 64]; k8b = lk8[(1 * 8 + 2 * cb + 3) * 64]; }
+        }
+        if (pr == 2) kh = kh_n;
         if (u < 4) {
 #pragma unroll
           for (int r = 4 * u; r < 4 * u + 4; r += 2) {

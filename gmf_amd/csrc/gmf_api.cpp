@@ -516,7 +516,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
                                              (kMaxSplits == 8 ? arena_need((size_t)8 * act, 4) : 0) : 0;
   const size_t need = 8 * arena_need(act, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +
                       5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4) + cache_need + split_need +
-                      arena_need((size_t)B, sizeof(gmf::PairTab)) + arena_need((size_t)B * tiles * 64, 4) +
+                      arena_need((size_t)B, sizeof(gmf::PairTab)) + arena_need((size_t)B * tiles * 128, 4) +
                       arena_need((size_t)(L + 1) * B, 4);
   if (int rc = arena_reserve(h, need)) return rc;
   const gmf::PairTab* ptab = nullptr;
@@ -540,7 +540,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
   float* x1t = arena_take<float>(h, tok);
   float* imgfeat = arena_take<float>(h, tok);
   float* ctxall = arena_take<float>(h, (size_t)(L > 0 ? L : 1) * tok);
-  unsigned* v_scale = arena_take<unsigned>(h, (size_t)B * tiles * 64);     // scale words of the V image's e4m3 planes ("pv_fp8")
+  unsigned* v_scale = arena_take<unsigned>(h, (size_t)B * tiles * 128);    // scale words of the V and K images' e4m3 planes ("pv_fp8"): per tile [V: 64 | K: 64]
   unsigned* fstat = arena_take<unsigned>(h, (size_t)(L + 1) * B);          // "pv_fp8" guard: [layer][pair] max row |f_l|^2 (float bits)
   gmf::CompatCache cc{nullptr, nullptr, nullptr, nullptr, 0};
   float* c_dense = nullptr;

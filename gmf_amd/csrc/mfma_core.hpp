@@ -142,6 +142,16 @@ GMF_DEVINL f32x16 mfma_f8s(i32x8 a, i32x8 b, f32x16 c, int opsel_a, int scale_a,
   }
 }
 
+// ... with a byte select on BOTH scale registers (the same byte: block `sel` of A's and of B's scale word)
+GMF_DEVINL f32x16 mfma_f8s2(i32x8 a, i32x8 b, f32x16 c, int sel, int scale_a, int scale_b) {
+  switch (sel) {
+    case 0: return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, scale_b);
+    case 1: return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 1, scale_a, 1, scale_b);
+    case 2: return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 2, scale_a, 2, scale_b);
+    default: return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 3, scale_a, 3, scale_b);
+  }
+}
+
 GMF_DEVINL void mma3(f32x16& acc, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
   acc = mfma_h16(al, bh, acc);
   acc = mfma_h16(ah, bl, acc);

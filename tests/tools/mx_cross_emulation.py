@@ -8,7 +8,11 @@ replaced by an emulation of the kernel's operand arithmetic:
   fp6x     the same with e2m3 cross operands (4x rate)
   one      q.k = qh.kh                                                                    (the throughput mode)
 and the same for P.V.  The deviation of the logits from the all-fp64 evaluation is printed per scheme, next to the fp32
-oracle's own deviation.     python tests/tools/mx_cross_emulation.py [kind] [N] [seeds...]"""
+oracle's own deviation.     python tests/tools/mx_cross_emulation.py [kind] [N] [seeds...] [--cond] [--qk] [--guard]
+  --guard [r5]: the schemes the library ships since round 5 - `fp8pv_g` (cross products of P V on e4m3) and `fp8x_g` (those of
+  Q' K^T as well, one scale per (row, 32-channel block)) in the layers the device-side guard lets through (score bound
+  (|Wq|_2 F + |bq|)(|Wk|_2 F + |bk|) / sqrt(C) <= 1024, gmf_pack.cpp pv_guard_threshold), three f16 products in the others; the
+  number of guarded layers is printed in brackets."""
 import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -56,7 +60,53 @@ def tiles(x, dim):      # pad dim to a multiple of 32 and view it as [.., n/32, 
     return x.reshape(shp), n
 
 
+GUARD_SCORE = 1024.0
+guard_log = []
+
+
+def _blk32(x):
+    """block-scaled e4m3 along the channel axis: one scale per (row, 32 channels)"""
+    shp = x.shape
+    return e4m3(x.reshape(*shp[:-1], shp[-1] // 32, 32), -1).reshape(shp)
+
+
+def make_guarded(qk_low):
+    """fp8 cross products of P V (and, qk_low, of Q' K^T) in the layers the guard lets through, split3 in the others"""
+    split3 = make_attention("split3")
+
+    def sc_attention(feat, compat, Wq, bq, Wk, bk, Wv, bv):
+        C = feat.shape[-1]
+        sq = 1.02 * float(torch.linalg.matrix_norm(Wq.reshape(C, C), 2)); sk = 1.02 * float(torch.linalg.matrix_norm(Wk.reshape(C, C), 2))
+        F = float(feat.norm(dim=-1).max())
+        guarded = (sq * F + float(bq.norm())) * (sk * F + float(bk.norm())) / math.sqrt(C) > GUARD_SCORE
+        guard_log.append(int(guarded))
+        if guarded:
+            return split3(feat, compat, Wq, bq, Wk, bk, Wv, bv)
+        q, k, v = O._lin(feat, Wq, bq), O._lin(feat, Wk, bk), O._lin(feat, Wv, bv)
+        q, k, v = q.float().double(), k.float().double(), v.float().double()
+        qh, kh, vh = f16(q), f16(k), f16(v)
+        ql, kl, vl = f16(q - qh), f16(k - kh), f16(v - vh)
+        s = qh @ kh.transpose(1, 2)
+        if qk_low:
+            s = s + _blk32(q) @ _blk32(kl).transpose(1, 2) + _blk32(ql) @ _blk32(k).transpose(1, 2)
+        else:
+            s = s + qh @ kl.transpose(1, 2) + ql @ kh.transpose(1, 2)
+        s = s.float().double() / math.sqrt(C)
+        z = (compat * s).float().double()
+        p = torch.exp(z - z.amax(-1, keepdim=True)).float().double()
+        ph = f16(p); pl = f16(p - ph)
+        fix = lambda x: (x * 256.0).float().to(torch.float8_e4m3fn).double() / 256.0
+        p8, pl8 = fix(p), fix(pl)
+        vt, _ = tiles(v, 1); vlt, _ = tiles(vl, 1)
+        v8 = e4m3(vt, 2).reshape(v.shape[0], -1, v.shape[2])[:, :v.shape[1]]
+        vl8 = e4m3(vlt, 2).reshape(v.shape[0], -1, v.shape[2])[:, :v.shape[1]]
+        return (ph @ vh + p8 @ vl8 + pl8 @ v8).float().double() / (ph + pl8).sum(-1, keepdim=True)
+    return sc_attention
+
+
 def make_attention(scheme):
+    if scheme in ("fp8pv_g", "fp8x_g"):
+        return make_guarded(scheme == "fp8x_g")
     lowp = {"fp8x": e4m3, "fp6x": e2m3, "fp8qk": e4m3, "fp8pv": e4m3, "fp8pv_c": e4m3, "fp6pv_c": e2m3, "fp8x_c": e4m3}.get(scheme)
     qk_low = scheme in ("fp8x", "fp6x", "fp8qk", "fp8x_c")
     pv_low = scheme in ("fp8x", "fp6x", "fp8pv")
@@ -122,6 +172,8 @@ def main():
     if "--cond" in flags:          # the KITTI-conditioned weight set (synthetic.kitti_conditioned; golden F22)
         sd = synthetic.kitti_conditioned(sd)
     schemes = ("split3", "fp8pv_c", "fp8x_c", "fp6pv_c") if "--qk" in flags else ("split3", "fp8pv_c", "fp6pv_c")
+    if "--guard" in flags:
+        schemes = ("split3", "fp8pv_c", "fp8x_c", "fp8pv_g", "fp8x_g")
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     exact = O.sc_attention
     print(f"{kind} N={N}: max |logit - fp64 logit| per scheme")
@@ -138,7 +190,8 @@ def main():
                 O.sc_attention = make_attention(scheme)
                 # the compat term as the kernel sees it: the fp32 cache
                 got = O.classifier(sd64, O.encoder(sd64, b64["corr_pos"], compat32.double(), b64["p_tokens"], b64["q_tokens"], 12))
-                row.append(f"{scheme} {float((got - truth).abs().max()):.2e}")
+                row.append(f"{scheme} {float((got - truth).abs().max()):.2e}" + (f" [{sum(guard_log)}]" if scheme.endswith("_g") else ""))
+                guard_log.clear()
         finally:
             O.sc_attention = exact
         print("  " + "   ".join(row), flush=True)

@@ -88,6 +88,19 @@ PATCHES = {
     "p8_skel_nostream": "SKEL+NOBAR+NOSTREAM",
     "p8_skel_noc": "SKEL+NOBAR+NOC",              # ... no compat loads, ring refills kept
     "p8_skel_norefill": "SKEL+NOBAR+NOREFILL",    # ... no ring refills (stale K / V tiles), compat loads kept
+    # [r5] timing only: what would the tile cost with the two CROSS products of S = K Q'^T on the block-scaled fp8 pipe as well (8 f16 +
+    #      4 fp8 MFMAs instead of 24 f16 in phase 1: 512 instead of 768 matrix-pipe cycles; same LDS reads - the low plane's bytes stand in
+    #      for the e4m3 planes -, same vector work in the gaps)?  Results are garbage; the question is the microseconds.
+    "p8_qk8_timing": [
+        (EK, "        s_next = mma3_part(pr, s_next, kh, kl, qh[s], ql[s]);\n        if (pr == 2) { kh = kh_n; kl = kl_n; }\n        if (u < 4) {",
+             "        if (pr == 2) s_next = mfma_h16(kh, qh[s], s_next);\n"
+             "        else if (pr == 0 && (s & 1)) {\n"
+             "          const i32x4 a0 = __builtin_bit_cast(i32x4, kl), a1 = __builtin_bit_cast(i32x4, kl_n);\n"
+             "          const i32x4 b0 = __builtin_bit_cast(i32x4, ql[s]), b1 = __builtin_bit_cast(i32x4, ql[s - 1]);\n"
+             "          const i32x8 a8 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, b8 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};\n"
+             "          s_next = mfma_f8s(a8 & 0x7e7e7e7e, b8 & 0x7e7e7e7e, s_next, 0, 0x6b6b6b6b, 0x6b6b6b6b);   // (no NaN bytes, scales 2^-20: S stays the hi x hi product - realistic data everywhere else)\n"
+             "        }\n        if (pr == 2) { kh = kh_n; kl = kl_n; }\n        if (u < 4) {"),
+    ],
     "p8_no_consist": [     # timing only: the row sum without the decoded low plane (what the consistent sum costs: nothing measurable)
         (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<true>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),
         (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<false>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),

@@ -50,7 +50,8 @@ if ROOT not in sys.path:
 PEAK_F16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 PRODUCTS = 3            # MFMA products per algorithmic multiply-add: split-fp16 operands, hh + hl + lh
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_scattn_h2p_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_scattn_h2p_pmc.json")
+TILE_CYCLES = 1024.0    # matrix-pipe cycles of one key tile per wave in the default form: 16 f16 MFMAs of 32 cycles + 8 block-scaled fp8 MFMAs of 64
 
 
 def scattn_flops_per_launch(B: int, N: int) -> float:
@@ -235,14 +236,14 @@ def main():
     achieved = flops / (avg_ms * 1e-3) / 1e12
     peak = PEAK_F16_MFMA_TFLOPS / PRODUCTS
     alg_bytes = scattn_bytes_per_launch(B, N)
-    traffic, traffic_note = None, "no PMC summary for this source tree (profiles/r04_scattn_h2p_pmc.json missing or taken on another build)"
+    traffic, traffic_note = None, "no PMC summary for this source tree (profiles/r05_scattn_h2p_pmc.json missing or taken on another build)"
     sha = csrc_sha16()
     if os.path.exists(PMC_SUMMARY):
         pmc = json.load(open(PMC_SUMMARY))
         wl = pmc.get("workload", {})
         if pmc.get("csrc_sha16") == sha and (wl.get("pairs"), wl.get("n_corr"), wl.get("tokens")) == (B, N, T):
             traffic = pmc["derived"]["traffic_bytes_per_launch"]
-            traffic_note = f"rocprofv3 FETCH_SIZE / WRITE_SIZE passes on this source tree (csrc_sha16 {sha}), profiles/r04_scattn_h2p_pmc.json"
+            traffic_note = f"rocprofv3 FETCH_SIZE / WRITE_SIZE passes on this source tree (csrc_sha16 {sha}), profiles/r05_scattn_h2p_pmc.json"
     step_ms = dt / args.steps * 1e3
     step_tflops = step_flops(B, N, T) / (step_ms * 1e-3) / 1e12
     line = {
@@ -263,12 +264,13 @@ def main():
                      "hbm_frac_of_peak": (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None,
                      "peak_note": (f"f16 MFMA dense peak {PEAK_F16_MFMA_TFLOPS:.0f} TFLOP/s / {PRODUCTS} partial products per algorithmic "
                                    "multiply-add (split-fp16 operands, fp32 accumulate, fp32-equivalent results) - the yardstick of rounds "
-                                   "1-2, kept.  Since round 3 the two cross products of O += P V run on the block-scaled fp8 pipe: a "
-                                   "tile takes 32 f16 + 4 fp8 matrix instructions = 1280 matrix-pipe cycles instead of 48 x 32 = 1536"),
+                                   "1-2, kept.  Since round 3 the two cross products of O += P V, since round 5 those of S = K Q'^T as "
+                                   "well, run on the block-scaled fp8 pipe wherever the device-side score guard allows: a tile takes "
+                                   "16 f16 + 8 fp8 matrix instructions = 1024 matrix-pipe cycles instead of 48 x 32 = 1536"),
                      # matrix-pipe cycles the kernel needs per algorithmic flop, as a fraction of the cycles it had ("pipe_busy" if
-                     # nothing else stalled it): 1280 of 1536 cycles per tile
-                     "frac_of_pipe_cycles": achieved / (peak * 1536.0 / 1280.0),
-                     "executed_mfma_tflops": achieved * PRODUCTS * 1280.0 / 1536.0,
+                     # nothing else stalled it): 1024 of 1536 cycles per tile
+                     "frac_of_pipe_cycles": achieved / (peak * 1536.0 / TILE_CYCLES),
+                     "executed_mfma_tflops": achieved * PRODUCTS * TILE_CYCLES / 1536.0,
                      "executed_note": "f16-equivalent matrix-pipe work per second (an fp8 MFMA of 64 cycles counted as two f16 MFMAs of 32)",
                      "avg_launch_ms": avg_ms, "launches_timed": launches.value, "flops_per_launch": flops},
         "step": {"algorithmic_tflops": step_tflops, "frac_of_peak": step_tflops / peak,

@@ -55,9 +55,10 @@ class _ResNet34ToLayer2(nn.Module):
 
 class _FusedResNet:
     """Inference form of `_ResNet34ToLayer2` on a HIP device (models/resnet.py:195-216, BasicBlock.forward :59-75): every
-    BatchNorm folded into its convolution, activations NHWC.  The 3-channel stem (7x7 stride 2 + max-pool) runs on MIOpen
-    with the fused bias + ReLU pass; the 15 convolutions of layer1 / layer2 (93 % of the FLOPs) run on `gmf_conv_nhwc`
-    (implicit GEMM on the f16 MFMA with split-fp16 operands, bias + residual + ReLU in its epilogue)."""
+    BatchNorm folded into its convolution, activations NHWC.  The 3-channel stem (7x7 stride 2 + BatchNorm + ReLU + max-pool)
+    is ONE HIP kernel (`gmf_stem_forward`); the 15 convolutions of layer1 / layer2 (93 % of the FLOPs) run on `gmf_conv_nhwc`
+    (implicit GEMM on the f16 MFMA with split-fp16 operands, bias + residual + ReLU in its epilogue).  Below
+    `min_native_pixels` output pixels per launch the convolutions take MIOpen's kernels (see `_conv`)."""
 
     def __init__(self, bb, native_convs: bool = True):
         from torch.nn.utils.fusion import fuse_conv_bn_eval

@@ -176,3 +176,46 @@ def GlobalRegistration(points, trans_points, weights=None, max_iter=1000, verbos
                                               break_threshold_ratio, quantization_size)
     s = stats[0].tolist()
     return R[0], t[0], {"iterations": int(s[0]), "loss": s[1], "break_count": int(s[2])}
+
+
+def argmin_se3_squared_dist(X, Y):
+    """Drop-in for core/registration.py:67-88: the unweighted Kabsch / Umeyama solve, (R [3,3], t [3]) of
+    argmin sum |R x_i + t - y_i|^2.  It is `weighted_procrustes` with unit weights and eps = 0 (w / (sum |w| + 0) = 1 / N, the
+    reference's `/ len(X)`); the 3 x 3 SVD runs on the device in fp64 (the reference's runs in X's own precision)."""
+    assert len(X) == len(Y)
+    return weighted_procrustes(X, Y, torch.ones(X.shape[0], device=X.device, dtype=torch.float32), 0.0)
+
+
+def ortho2rotation(poses):
+    """[B, 6] -> [B, 3, 3]: Gram-Schmidt of the two 3-vectors, third column their cross product (core/registration.py:16-64; Zhou et
+    al.'s continuous 6-D rotation).  Plain torch - it is the parameterisation `Transformation` differentiates through; the
+    refinement loop itself (GlobalRegistration) evaluates it inside its persistent kernel."""
+    def unit(v):
+        return v / torch.clamp(torch.sqrt((v ** 2).sum(1, keepdim=True)), min=1e-8)
+    x_raw, y_raw = poses[:, 0:3], poses[:, 3:6]
+    x = unit(x_raw)
+    proj = ((x * y_raw).sum(1, keepdim=True) / torch.clamp((x ** 2).sum(1, keepdim=True), min=1e-8)) * x
+    y = unit(y_raw - proj)
+    z = torch.cross(x, y, dim=1)
+    return torch.stack((x, y, z), dim=2)
+
+
+class Transformation(torch.nn.Module):
+    """Drop-in for core/registration.py:116-132: the 6-D rotation + translation parameters GlobalRegistration optimises, with the
+    reference's initialisation (the first two COLUMNS of R_init) and forward (points @ R^T + t)."""
+
+    def __init__(self, R_init=None, t_init=None):
+        super().__init__()
+        rot_init = torch.rand(1, 6)
+        trans_init = torch.zeros(1, 3)
+        if R_init is not None:
+            rot_init[0, :3] = R_init[:, 0]
+            rot_init[0, 3:] = R_init[:, 1]
+        if t_init is not None:
+            trans_init[0] = t_init
+        self.rot6d = torch.nn.Parameter(rot_init)
+        self.trans = torch.nn.Parameter(trans_init)
+
+    def forward(self, points):
+        return points @ ortho2rotation(self.rot6d)[0].t() + self.trans
+

@@ -390,6 +390,192 @@ k_fusion_attn_h2(const float* __restrict__ xin, const float* __restrict__ ctx_im
   fusion_attn_h2_body<PE, ROWMAJOR>(lds, blockIdx.x, blockIdx.y, xin, ctx_img, wst, vecs, x1_out, N, tiles, T, ttiles);
 }
 
+// [r5] fusion_attn_tile_h2_body: the cross-attention role of the small-grid layer with ONE WORKGROUP PER QUERY TILE, its four waves
+// dealing the CONTEXT TILES among themselves (wave w: tiles w, w + 4, ...) - fusion_layer.py:119-121,44,84-94,190 as
+// fusion_attn_h2_body, where a wave walks all T / 32 context tiles of its own query tile one after the other: at B = 1 that walk
+// (10 tiles at T = 300) is the longest link of the layer's first launch (19.8 us of which ~10 are the walk; the launch is a third of a
+// forward at N = 1000).  Here every wave forms LCPE + LayerNorm + q for the tile (the same values, redundantly - they are a chain,
+// not work), streams its own context tiles STRAIGHT INTO REGISTERS (their fragments are 16-byte units in the image: no LDS ring, no
+// stage barriers, all of a wave's tiles requested while it still computes q), keeps its own running (m, l, O), and the four partial
+// results meet in the LDS: common maximum, waves added in index order.  The out-projection's four 32-feature blocks then run one
+// per wave.  LDS: Wq'' | Wo (4 stages, fetched once, behind ONE barrier) | vectors | halo rows | the partials (over Wq'').
+// Results: the same arithmetic per product; the softmax's running maximum is per wave and the partial sums are added in another order
+// than the sequential walk's, so x1 agrees with fusion_attn_h2_body to fp32 rounding, not bit for bit.
+constexpr int kFattnTileLdsFloats = 4 * kStageFloats + 7 * C + kWavesPerWG * 2 * C + kWavesPerWG * 128;
+
+GMF_DEVINL void fusion_attn_tile_h2_body(float* lds, const int tile, const int pair, const float* __restrict__ xin,
+                                         const float* __restrict__ ctx_img, const float* __restrict__ wst,
+                                         const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float* pair_base = xin + (size_t)pair * tiles * (32 * C);
+  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+  float* const lvec = lds + 4 * kStageFloats;
+  float* const halo = lvec + 7 * C + wave * (2 * C);
+  float* const lml = lvec + 7 * C + kWavesPerWG * (2 * C);         // [wave][lane][2]: running maximum, row sum (this lane half's)
+  float* const lpart = lds;                                        // [wave][8][64] float4: the partial O (over Wq'', dead by then)
+  // this wave's context tiles: fragments of tile t are the 16 units ((plane * 4 + s) * 64 + lane) of Kc and of Vc (k_ctx_prep_h2)
+  const f16x8* const gctx = reinterpret_cast<const f16x8*>(ctx_img + (size_t)pair * ttiles * kStageFloats) + lane;
+  // (Kc of the next tile is requested at the top of a tile into a second set of registers, Vc of the next tile into the SAME registers
+  // right after the last product that reads them: 96 fragment registers instead of 128, which spilled)
+  f16x8 kf[8], vf[8], kn[8];
+  auto fetch_k = [&](int t, f16x8 (&k8)[8]) {
+    const f16x8* g = gctx + (size_t)min(t, ttiles - 1) * (kStageFloats / 4);      // (a tile of 4096 floats = 1024 units)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) k8[u] = g[u * 64];
+  };
+  auto fetch_v = [&](int t, f16x8 (&v8)[8]) {
+    const f16x8* g = gctx + (size_t)min(t, ttiles - 1) * (kStageFloats / 4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v8[u] = g[(8 + u) * 64];
+  };
+  dma_vec(vecs, lvec, 7 * C, wave, kWavesPerWG, lane);
+  LcpeHalo<CF>::issue(pair_base, tile, tiles, halo, lane);
+#pragma unroll
+  for (int st = 0; st < 4; ++st) dma_4k_s(wst + (size_t)st * kStageFloats + wave * 1024, lds + st * kStageFloats + wave * 1024, (unsigned)lane * 16u);
+  float xp[CF];
+  load_frag_p32<CF>(xp, pair_base + (size_t)tile * (32 * C), lane);
+  fetch_k(wave, kf);
+  fetch_v(wave, vf);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  LcpeHalo<CF>::apply(xp, halo, lvec, tile * 32 + i, N, lane);
+
+  FragH2<4> qx;
+  {
+    FragH2<8> nx;
+    {
+      float xn[CF];
+      layernorm_frag<CF>(xn, xp, lvec + 4 * C, lvec + 5 * C, h);
+      nx.set(xn);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const f16x8* lw = reinterpret_cast<const f16x8*>(lds + mb * kStageFloats) + lane;
+      f32x16 acc = zero16();
+      mma_wx_h2<8>(acc, lw, nx);
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = acc[r] * kH2Inv;
+      qx.set_block(mb, t);
+    }
+  }
+  float xres[16];                                  // the residual of this wave's output block (x' of features 32 wave ..)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = xp[r];
+#pragma unroll
+    for (int mb = 1; mb < 4; ++mb) v = (wave == mb) ? xp[16 * mb + r] : v;
+    xres[r] = v;
+  }
+
+  f32x16 oacc[2];
+  oacc[0] = zero16(); oacc[1] = zero16();
+  float m_run = -INFINITY, l_half = 0.f;
+  for (int t = wave; t < ttiles; t += kWavesPerWG) {
+    const bool more = t + kWavesPerWG < ttiles;
+    if (more) fetch_k(t + kWavesPerWG, kn);
+    f32x16 s = zero16();
+#pragma unroll
+    for (int ss4 = 0; ss4 < 4; ++ss4) mma3(s, kf[ss4], kf[4 + ss4], qx.h[ss4], qx.l[ss4]);
+    float x[16];
+    float mx = -INFINITY;
+    const int jbase = t * 32 + 4 * h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jl = 8 * (r >> 2) + (r & 3);
+      const float v = (jbase + jl < T) ? s[r] : -INFINITY;
+      x[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    const float m_off = m_new - 10.0f;
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] = __builtin_amdgcn_exp2f(x[r] - m_off); ls += x[r]; }
+    l_half = fmaf(l_half, alpha, ls);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f16x8 ph, pl;
+      split8h(&x[8 * s2], ph, pl);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int slot = 2 * db + s2;
+        mma3(oacc[db], vf[slot], vf[4 + slot], ph, pl);
+      }
+    }
+    if (more) {
+      fetch_v(t + kWavesPerWG, vf);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) kf[u] = kn[u];
+    }
+  }
+  // ---- the four partial results meet: O_w, m_w, l_w -> LDS (every wave is past its use of Wq'': the barrier orders it) ----
+  __syncthreads();
+  {
+    float4* pw = reinterpret_cast<float4*>(lpart) + (size_t)wave * 8 * 64 + lane;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        pw[(4 * db + q) * 64] = make_float4(oacc[db][4 * q], oacc[db][4 * q + 1], oacc[db][4 * q + 2], oacc[db][4 * q + 3]);
+    reinterpret_cast<float2*>(lml)[wave * 64 + lane] = make_float2(m_run, l_half);
+  }
+  __syncthreads();
+  FragH2<4> ox;
+  {
+    float mw[kWavesPerWG], lw_[kWavesPerWG], M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < kWavesPerWG; ++w) {
+      const float2 ml = reinterpret_cast<const float2*>(lml)[w * 64 + lane];
+      mw[w] = ml.x; lw_[w] = ml.y;
+      M = fmaxf(M, ml.x);
+    }
+    float l = 0.f, wk[kWavesPerWG];
+#pragma unroll
+    for (int w = 0; w < kWavesPerWG; ++w) { wk[w] = __builtin_amdgcn_exp2f(mw[w] - M); l = fmaf(lw_[w], wk[w], l); }
+    const float inv = 1.0f / xhalf_sum(l);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = 0.f;
+#pragma unroll
+      for (int w = 0; w < kWavesPerWG; ++w) {
+        const float4* pr = reinterpret_cast<const float4*>(lpart) + (size_t)w * 8 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = pr[(4 * db + q) * 64];
+          t[4 * q] = fmaf(v.x, wk[w], t[4 * q]); t[4 * q + 1] = fmaf(v.y, wk[w], t[4 * q + 1]);
+          t[4 * q + 2] = fmaf(v.z, wk[w], t[4 * q + 2]); t[4 * q + 3] = fmaf(v.w, wk[w], t[4 * q + 3]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] *= inv;
+      ox.set_block(db, t);
+    }
+  }
+  // ---- out-projection: output block mb = wave (stage 2 + (wave >> 1), half wave & 1), + bo + x' ----
+  {
+    const int mb = wave;
+    const f16x8* lw = reinterpret_cast<const f16x8*>(lds + (2 + (mb >> 1)) * kStageFloats) + lane;
+    f32x16 acc = zero16();
+    mma_wx_h2<4>(acc, lw + (mb & 1) * (2 * 4 * 64), ox);
+    float b[16], t[16];
+    load_vec_block(b, lvec + 6 * C, mb, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = fmaf(acc[r], kH2Inv, b[r]) + xres[r];
+    store_block_p32(x1_out + toff, mb, t, lane);
+  }
+}
+
 // k_small_front_fattn: small grids (e.g. B = 1, the reference's evaluation mode) - the first of the three launches of a layer:
 // workgroups z = 0, 1, 2 project Q', K, V from f (front_h2_body<2>, one output each), workgroups z = 3 run LCPE + LayerNorm +
 // cross-attention -> x1 (fusion_attn_h2_body).  The two are independent given f; as separate launches on these latency-
@@ -399,12 +585,19 @@ k_small_front_fattn(const float* __restrict__ f_in, const float* __restrict__ fr
                     const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
                     float* __restrict__ q_out, float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x1_out,
                     int N, int tiles, int T, int ttiles, unsigned* __restrict__ v_scale, const PvGuard guard) {
-  __shared__ __attribute__((aligned(16))) float lds[kFattnLdsFloats];
+  // gridDim.z == 4: z = 3 is the cross-attention of the block's four query tiles, one per wave (fusion_attn_h2_body);
+  // gridDim.z == 7 [r5]: z = 3 .. 6 are ONE query tile each, its context tiles dealt to the four waves (fusion_attn_tile_h2_body)
+  __shared__ __attribute__((aligned(16))) float lds[kFattnTileLdsFloats];
+  static_assert(kFattnTileLdsFloats >= kFattnLdsFloats, "one buffer serves both forms of the role");
   if (blockIdx.z < 3)
     front_h2_body<2>(lds, blockIdx.x, blockIdx.y, blockIdx.z, f_in, front_wst, front_vec, nullptr, q_out, k_out, v_out, N, tiles,
                      nullptr, v_scale, guard);
-  else
+  else if (gridDim.z == 4)
     fusion_attn_h2_body<true>(lds, blockIdx.x, blockIdx.y, f_in, ctx_img, attn_wst, attn_vec, x1_out, N, tiles, T, ttiles);
+  else {
+    const int tile = (int)blockIdx.x * kWavesPerWG + ((int)blockIdx.z - 3);
+    if (tile < tiles) fusion_attn_tile_h2_body(lds, tile, blockIdx.y, f_in, ctx_img, attn_wst, attn_vec, x1_out, N, tiles, T, ttiles);
+  }
 }
 
 // =========================================================================================
@@ -826,8 +1019,11 @@ int plan_ff_split(const Tuning& tune, int base, int max_parts) {
 
 hipError_t launch_small_front_fattn(const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                                     const float* attn_wst, const float* attn_vec, float* q, float* k, float* v, float* x1, int B,
-                                    int N, int tiles, int T, int ttiles, hipStream_t s, unsigned* v_scale, PvGuard guard) {
-  hipLaunchKernelGGL(k_small_front_fattn, tgrid(tiles, B, 4), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec,
+                                    int N, int tiles, int T, int ttiles, hipStream_t s, unsigned* v_scale, PvGuard guard, bool tile_role) {
+  // [r5] the cross-attention role per query tile (its waves split the context tiles) wherever that leaves the chip room: the role's
+  // workgroups quadruple, so up to 256 query tiles; beyond, one workgroup per four tiles as before
+  const bool per_tile = tile_role && ttiles >= 2 && (long)tiles * B <= 256;
+  hipLaunchKernelGGL(k_small_front_fattn, tgrid(tiles, B, per_tile ? 7 : 4), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec,
                      q, k, v, x1, N, tiles, T, ttiles, v_scale, guard);
   return hipGetLastError();
 }

@@ -2334,8 +2334,12 @@ __global__ void k_unpack_p32(const float* __restrict__ src, float* __restrict__ 
 
 // src,tgt [B,N,3] -> pts8 [B, Npad, 8] (zero padded rows)
 __global__ void k_pack_pts8(const float* __restrict__ src, const float* __restrict__ tgt, float* __restrict__ dst,
-                            int N, int Npad, long total, const PairTab* __restrict__ ptab) {
+                            int N, int Npad, long total, const PairTab* __restrict__ ptab, unsigned* __restrict__ zero_words,
+                            int n_zero) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // [r5] the "pv_fp8" guard's statistics start every forward at zero: cleared here, by the first kernel of the stream that runs
+  // before anything raises them (a hipMemsetAsync of these few words costs a 9 us fill kernel of its own)
+  if (zero_words && idx < n_zero) zero_words[idx] = 0u;
   if (idx >= total) return;
   const int row = idx % Npad;
   const long b = idx / Npad;
@@ -2575,10 +2579,12 @@ hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, in
   return hipGetLastError();
 }
 
-hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s, const PairTab* ptab) {
+hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s, const PairTab* ptab,
+                            unsigned* zero_words, int n_zero) {
   const int Npad = ((N + 31) / 32) * 32;
   const long total = (long)B * Npad;
-  hipLaunchKernelGGL(k_pack_pts8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, tgt, dst, N, Npad, total, ptab);
+  hipLaunchKernelGGL(k_pack_pts8, dim3((unsigned)((std::max(total, (long)n_zero) + 255) / 256)), dim3(256), 0, s, src, tgt, dst, N, Npad, total, ptab,
+                     zero_words, n_zero);
   return hipGetLastError();
 }
 

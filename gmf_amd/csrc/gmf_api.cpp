@@ -127,6 +127,16 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     t.conv_patch = value;
     return GMF_OK;
   }
+  if (std::strcmp(name, "small_fattn_tile") == 0) {    // [ABI 5] 1 = small grids: the cross-attention role per query tile (default), 0 = per four tiles
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: small_fattn_tile must be 0 or 1");
+    t.small_fattn_tile = value != 0;
+    return GMF_OK;
+  }
+  if (std::strcmp(name, "conv_small_grid") == 0) {     // [ABI 5] 1 = grids of a few images run the K-split convolution kernel (default), 0 = the 128-pixel kernels at every size
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: conv_small_grid must be 0 or 1");
+    t.conv_small = value != 0;
+    return GMF_OK;
+  }
   if (std::strcmp(name, "nms_binned") == 0) {          // 1 = grid-binned NMS candidates on large grids (default), 2 = always, 0 = all pairs
     GMF_REQUIRE(value >= 0 && value <= 2, GMF_ERR_BAD_ARG, "set_tuning: nms_binned must be 0, 1 or 2");
     t.nms_binned = value;
@@ -183,7 +193,7 @@ int gmf_get_tuning(gmf_handle* h, const char* name, int* value) {
   const struct { const char* name; int v; } tab[] = {
       {"scattn_variant", t.scattn_variant}, {"front_output_split", t.front_split ? 1 : 0}, {"ff_hidden_splits", t.ff_split},
       {"attn_key_splits", t.key_splits}, {"attn_tail_split", t.tail_split ? 1 : 0}, {"small_grid_roles", t.small_roles ? 1 : 0},
-      {"fused_linear", t.fused_linear ? 1 : 0}, {"compat_cache", t.use_cache ? 1 : 0}, {"conv_lds_patch", t.conv_patch},
+      {"fused_linear", t.fused_linear ? 1 : 0}, {"compat_cache", t.use_cache ? 1 : 0}, {"conv_lds_patch", t.conv_patch}, {"conv_small_grid", t.conv_small ? 1 : 0}, {"small_fattn_tile", t.small_fattn_tile ? 1 : 0},
       {"nms_binned", t.nms_binned}, {"topk_select", t.topk_select ? 1 : 0}, {"wide_attn_tile", t.wide_attn_tile ? 1 : 0},
       {"small_merge_tile", t.small_merge_tile ? 1 : 0}, {"mid_grid_roles", t.mid_grid_roles}, {"pv_fp8", t.pv_fp8}, {"q_in_attention", t.q_in_attention ? 1 : 0},
       {"compat_format", t.compat_format}, {"precision", t.precision}};
@@ -577,7 +587,9 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
     else GMF_HIP(gmf::launch_ctx_prep(true, imgfeat, w->ctx_wst, w->ctx_vec, ctxall, B, T, tt, L, w->ctx_wst_stride,
                                       w->ctx_vec_stride, st));
   }
-  GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st, ptab));
+  // (the same launch clears the "pv_fp8" guard's statistics - a superset of the forwards that read them)
+  const bool may_guard = fuse && h->tune.pv_fp8 == 1 && w->pv_guard;
+  GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st, ptab, may_guard ? fstat : nullptr, may_guard ? (L + 1) * B : 0));
   // throughput numerics ("precision" = 1, 2): on the two-launch path of large grids the attention multiplies one fp16
   // product and streams the compat matrix as fp16 (level 2: the layer's linear stages multiply one product as well); every
   // other path keeps the parity numerics
@@ -606,10 +618,9 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
     // parity arithmetic: V with e4m3 cross planes for the pv_fp8 form of the attention body (scattn_h2p_body<3, *, 4, true>), which every
     // attention kernel of this path instantiates - large grids, split tails and the small-grid role kernels alike
     cc.v_scale = (h->tune.pv_fp8 && !cc.half) ? v_scale : nullptr;
-    // [r5] "pv_fp8" = 1: guarded per pair and layer on the device (PvGuard).  The statistics start at zero; f_0's is raised by the
+    // [r5] "pv_fp8" = 1: guarded per pair and layer on the device (PvGuard).  The statistics start at zero (k_pack_pts8); f_0's is raised by the
     // front kernel, f_{l+1}'s by the attention epilogue / merge kernels of layer l - always before the kernels that read it
-    const bool guarded = cc.v_scale && h->tune.pv_fp8 == 1 && w->pv_guard;
-    if (guarded) GMF_HIP(hipMemsetAsync(fstat, 0, (size_t)(L + 1) * B * sizeof(unsigned), st));
+    const bool guarded = cc.v_scale && h->tune.pv_fp8 == 1 && w->pv_guard;       // (implies may_guard: launch_pack_pts8 cleared fstat)
     {
       gmf::PvGuard g0;
       if (guarded) g0.stat_next = fstat;
@@ -638,7 +649,8 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
                                       cc.half && h->tune.precision == 2, ptab, cc.v_scale, cc.guard));
       } else if (small3) {
         // three launches: {Q' | K | V | cross-attention} -> {key-split attention | hidden-split feed-forward} -> merge
-        GMF_HIP(gmf::launch_small_front_fattn(f, fw, fv, ctx_l, aw, av, q, k, v, x1, B, N, tiles, T, tt, st, cc.v_scale, cc.guard));
+        GMF_HIP(gmf::launch_small_front_fattn(f, fw, fv, ctx_l, aw, av, q, k, v, x1, B, N, tiles, T, tt, st, cc.v_scale, cc.guard,
+                                              h->tune.small_fattn_tile));
         const bool last3 = (l + 1 == L);
         cc.tail_wst_h2 = w->tail_wst_h2 + (size_t)l * w->tail_wst_stride;
         cc.next_wst_h2 = last3 ? nullptr : w->front_wst_h2 + (size_t)(l + 1) * w->front_wst_stride;

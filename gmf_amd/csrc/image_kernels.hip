@@ -118,6 +118,102 @@ k_conv_nhwc_h2(const float* __restrict__ x, const float* __restrict__ wimg, cons
 }
 
 // =========================================================================================
+// k_conv_small_h2 [r5]: the same convolutions on SMALL grids - a few images, e.g. the two images of ONE scene pair, which is what the
+// reference's evaluation loop feeds (evaluation/test_3DMatch.py:69; resnet.py:195-216).  With 128 output pixels x 64 channels per
+// workgroup two 120 x 160 images give 19 (layer1) / 10 (layer2) workgroups, each a chain of 36 .. 72 dependent k-steps: a launch
+// costs its chain (8 - 12 us), which is why such batches used MIOpen's kernels until round 4.  Here a workgroup owns 32 output
+// pixels x 32 output channels and its NW waves SPLIT THE K RANGE (k-steps [w NK / NW, (w + 1) NK / NW) of the same tile; NW = 4 for 64
+// input channels, 8 for 128: nine k-steps per wave either way): four times the workgroups per pixel and twice per channel (150 / 76
+// for two images); the partial tiles meet in LDS and are added in wave order (deterministic).  No LDS staging of the weights: a
+// wave requests ALL its k-steps' operands - two (hi, lo) weight fragments from the L2-resident image, two float4 of activations
+// each - before its first product (one memory round trip per launch instead of one per stage: 0.37 -> 0.19 ms per two-image pass).
+// Same weight images, same arithmetic per product as k_conv_nhwc_h2 (split-fp16 operands, three products, fp32 accumulate); the
+// accumulation ORDER over k differs (four partial sums), so the two kernels agree to fp32 rounding, not bit for bit.
+// grid (ceil(P / 32), COUT / 32), block 64 NW.
+// =========================================================================================
+template <int CIN, int COUT, int KS, int STRIDE, bool CBT, int NW>
+__global__ void __launch_bounds__(64 * NW)
+k_conv_small_h2(const float* __restrict__ x, const float* __restrict__ wimg, const float* __restrict__ bias,
+                const float* __restrict__ residual, float* __restrict__ y, int B, int H, int W, int Ho, int Wo, int relu) {
+  constexpr int CB = CIN / 16, NK = KS * KS * CB, NKW = NK / NW, PAD = KS / 2;
+  constexpr int CHK = NKW, NCH = 1;               // every k-step of the wave in flight at once (9 x 16 + 9 x 8 registers)
+  static_assert(NK % NW == 0 && COUT % 64 == 0 && 16 % NW == 0 && NKW <= 9, "the k range splits evenly over the waves");
+  __shared__ float red[NW][16][64];
+  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = blockIdx.y >> 1, blk = blockIdx.y & 1, co0 = 32 * blockIdx.y;
+  const long P = (long)B * Ho * Wo;
+  const long pix0 = (long)blockIdx.x * 32;
+  const long pix = pix0 + i;
+  const bool pvalid = pix < P;
+  int yo = 0, xo = 0;
+  long bimg = 0;
+  if (pvalid) { bimg = pix / ((long)Ho * Wo); const int rem = (int)(pix - bimg * Ho * Wo); yo = rem / Wo; xo = rem - yo * Wo; }
+  const int yc = yo * STRIDE - PAD, xc = xo * STRIDE - PAD;
+  const float* xb = x + (size_t)(pvalid ? bimg : 0) * H * W * CIN + 8 * h;
+  auto load_a = [&](int ks, float (&a)[8]) {
+    const int tap = CBT ? ks % (KS * KS) : ks / CB, cb = CBT ? ks / (KS * KS) : ks - tap * CB;
+    const int dy = tap / KS, dx = tap - dy * KS;
+    const int yi = yc + dy, xi = xc + dx;
+    const bool ok = pvalid && yi >= 0 && yi < H && xi >= 0 && xi < W;
+    const int yl = min(max(yi, 0), H - 1), xl = min(max(xi, 0), W - 1);
+    const float4* p = reinterpret_cast<const float4*>(xb + ((size_t)yl * W + xl) * CIN + 16 * cb);
+    const float4 u = p[0], v = p[1];
+    a[0] = ok ? u.x : 0.f; a[1] = ok ? u.y : 0.f; a[2] = ok ? u.z : 0.f; a[3] = ok ? u.w : 0.f;
+    a[4] = ok ? v.x : 0.f; a[5] = ok ? v.y : 0.f; a[6] = ok ? v.z : 0.f; a[7] = ok ? v.w : 0.f;
+  };
+  // weight image (packing.conv_image): 16-byte unit (((half NK + ks) 2 + blk) 2 + plane) 64 + lane
+  const f16x8* wf = reinterpret_cast<const f16x8*>(wimg) + lane;
+  auto load_b = [&](int ks, f16x8& bh, f16x8& bl) {
+    const size_t u = (((size_t)half * NK + ks) * 2 + blk) * 2;
+    bh = wf[u * 64];
+    bl = wf[(u + 1) * 64];
+  };
+  const int k0 = wave * NKW;
+  f32x16 acc = zero16();
+  float a[2][CHK][8];
+  f16x8 bh[2][CHK], bl[2][CHK];
+#pragma unroll
+  for (int kk = 0; kk < CHK; ++kk) { load_a(k0 + kk, a[0][kk]); load_b(k0 + kk, bh[0][kk], bl[0][kk]); }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) {
+#pragma unroll
+      for (int kk = 0; kk < CHK; ++kk) {
+        load_a(k0 + (c + 1) * CHK + kk, a[(c + 1) & 1][kk]);
+        load_b(k0 + (c + 1) * CHK + kk, bh[(c + 1) & 1][kk], bl[(c + 1) & 1][kk]);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < CHK; ++kk) {
+      f16x8 ah, al;
+      split8h(a[c & 1][kk], ah, al);
+      mma3(acc, ah, al, bh[c & 1][kk], bl[c & 1][kk]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  // wave w finishes registers (16 / NW) w ..: the NW partial sums in wave order, then bias (+ residual) and the ReLU.
+  // register r of lane (h, i): pixel pix0 + 8 (r >> 2) + 4 h + (r & 3), output channel co0 + i
+  const float bv = bias[co0 + i];
+#pragma unroll
+  for (int q = 0; q < 16 / NW; ++q) {
+    const int r = (16 / NW) * wave + q;
+    float sum = red[0][r][lane];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) sum += red[w][r][lane];
+    const long p = pix0 + 8 * (r >> 2) + 4 * h + (r & 3);
+    if (p < P) {
+      const size_t o = (size_t)p * COUT + co0 + i;
+      float v = fmaf(sum, 1.0f / 256.0f, bv);
+      if (residual) v += residual[o];
+      y[o] = relu ? fmaxf(v, 0.f) : v;
+    }
+  }
+}
+
+// =========================================================================================
 // k_conv3x3_patch_h2: the stride-1 3x3 shapes (64 -> 64, 128 -> 128) with the activations staged through LDS.
 //   For stride 1 the input pixels a workgroup's 128 consecutive (flattened NHWC) output pixels need are themselves one
 //   contiguous flat range [p0 - W - 1, p0 + 128 + W]: per 16-channel block cb it is loaded once (coalesced 64-byte pieces),
@@ -438,6 +534,19 @@ hipError_t launch_conv_nhwc_h2(const Tuning& tune, const float* x, const float* 
   const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
   const long P = (long)B * Ho * Wo;
   const dim3 grid((unsigned)((P + 127) / 128), cout / 64);
+  // [r5] small grids (a few images): the K-split kernel, 32 pixels x 32 channels per workgroup (k_conv_small_h2); the switch is where
+  // the 128-pixel kernel would leave more than half the chip without a workgroup
+  if ((long)grid.x * grid.y < 128 && tune.conv_small) {
+    const dim3 gs((unsigned)((P + 31) / 32), cout / 32);
+#define GMF_CONV_SMALL(CI, CO, K, S, CBT_, NW_) hipLaunchKernelGGL((k_conv_small_h2<CI, CO, K, S, CBT_, NW_>), gs, dim3(64 * NW_), 0, s, x, wimg, bias, residual, y, B, H, W, Ho, Wo, relu)
+    if (cin == 64 && cout == 64 && ks == 3 && stride == 1) GMF_CONV_SMALL(64, 64, 3, 1, true, 4);
+    else if (cin == 64 && cout == 128 && ks == 3 && stride == 2) GMF_CONV_SMALL(64, 128, 3, 2, false, 4);
+    else if (cin == 128 && cout == 128 && ks == 3 && stride == 1) GMF_CONV_SMALL(128, 128, 3, 1, true, 8);
+    else if (cin == 64 && cout == 128 && ks == 1 && stride == 2) GMF_CONV_SMALL(64, 128, 1, 2, false, 4);
+    else return hipErrorInvalidValue;
+#undef GMF_CONV_SMALL
+    return hipGetLastError();
+  }
 #define GMF_CONV(CI, CO, K, S) hipLaunchKernelGGL((k_conv_nhwc_h2<CI, CO, K, S>), grid, dim3(256), 0, s, x, wimg, bias, residual, y, B, H, W, Ho, Wo, relu)
   // stride-1 3x3 shapes: activations staged through LDS (weight image in (channel block, tap) order); W <= 48
   if (tune.conv_patch && ks == 3 && stride == 1 && W <= 48 && cin == cout && (cin == 64 || cin == 128)) {

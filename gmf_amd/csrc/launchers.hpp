@@ -62,9 +62,11 @@ struct Tuning {
   bool front_split = true;   // small grids: one workgroup per output (Q' + f | K | V) of k_front_h2
   bool wide_attn_tile = true;     // 256-wide layer: cross-attention with one workgroup per tile on grids of up to 256 tiles
   bool small_merge_tile = true;   // small grids: the merge step with one workgroup per query tile, its waves splitting the feature blocks
+  bool small_fattn_tile = true;   // [r5] small grids: the cross-attention role of the layer's first launch per query tile, context tiles dealt to its waves
   bool small_roles = true;   // small grids: three launches per layer with two kinds of workgroups each (else five or six)
   bool fused_linear = true;  // one kernel per layer for Q'/K/V + Fusion-2 (k_linear_h2) with the next PointCN in the attention epilogue
   int conv_patch = 1;        // stride-1 3x3 convolutions: 1 = LDS patch kernel (automatic form), 2 = never three workgroups per CU, 0 = gather kernel
+  bool conv_small = true;    // [r5] grids of fewer than 128 workgroups of the 128-pixel convolution kernels (a few images): the K-split kernel
   int nms_binned = 1;        // 1 = grid-binned NMS candidates on large grids, 2 = always, 0 = all pairs
   bool topk_select = true;   // radix select of the S seeds (false = full bitonic sort)
   int mid_grid_roles = 512;  // two-launch form on grids below this many base workgroups (>= 256): the linear kernel runs as two
@@ -129,7 +131,8 @@ void plan_attn_split(const Tuning& tune, int W, int tiles, int max_splits, int* 
 int plan_ff_split(const Tuning& tune, int base, int max_parts);
 hipError_t launch_small_front_fattn(const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                                     const float* attn_wst, const float* attn_vec, float* q, float* k, float* v, float* x1, int B,
-                                    int N, int tiles, int T, int ttiles, hipStream_t s, unsigned* v_scale = nullptr, PvGuard guard = {});
+                                    int N, int tiles, int T, int ttiles, hipStream_t s, unsigned* v_scale = nullptr, PvGuard guard = {},
+                                    bool tile_role = true);   // tile_role: the cross-attention role per query tile (Tuning::small_fattn_tile)
 hipError_t launch_small_attn_ff_merge(const float* q, const float* k, const float* v, const float* x1, const float* ff_wst,
                                       const float* ff_vecs, float* ff_part, int ff_hs, const float* tail_vecs, float* out, int B,
                                       int N, int tiles, int ksplits, hipStream_t s, const CompatCache* cc, bool tile_merge = true);
@@ -147,7 +150,8 @@ hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int 
 // row-major [B, n_rows, 128] -> split-fp16 plane image (the operand image of launch_seed_dist)
 hipError_t launch_pack_rows_h2(const float* src, float* dst, int B, int n_rows, hipStream_t s, const PairTab* ptab = nullptr);
 hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s, int* status = nullptr);
-hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s, const PairTab* ptab = nullptr);
+hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s, const PairTab* ptab = nullptr,
+                            unsigned* zero_words = nullptr, int n_zero = 0);   // zero_words: n_zero words cleared by the same launch (PvGuard statistics)
 
 // validation step (row f-4, forward half): validation_kernels.hip
 size_t similarity_image_floats(int B, int N);

@@ -57,15 +57,15 @@ class _FusedResNet:
     """Inference form of `_ResNet34ToLayer2` on a HIP device (models/resnet.py:195-216, BasicBlock.forward :59-75): every
     BatchNorm folded into its convolution, activations NHWC.  The 3-channel stem (7x7 stride 2 + BatchNorm + ReLU + max-pool)
     is ONE HIP kernel (`gmf_stem_forward`); the 15 convolutions of layer1 / layer2 (93 % of the FLOPs) run on `gmf_conv_nhwc`
-    (implicit GEMM on the f16 MFMA with split-fp16 operands, bias + residual + ReLU in its epilogue).  Below
-    `min_native_pixels` output pixels per launch the convolutions take MIOpen's kernels (see `_conv`)."""
+    (implicit GEMM on the f16 MFMA with split-fp16 operands, bias + residual + ReLU in its epilogue; [r5] at every batch size -
+    a few images run its K-split small-grid form)."""
 
     def __init__(self, bb, native_convs: bool = True):
         from torch.nn.utils.fusion import fuse_conv_bn_eval
         import copy
         bb = copy.deepcopy(bb).eval()
         self.native = native_convs
-        self.min_native_pixels = 128 * 128
+        self.min_native_pixels = 0           # [r5] every batch size on the native kernels (small grids: the K-split form inside gmf_conv_nhwc)
         cl = torch.channels_last
 
         def fold(conv, bn):
@@ -120,13 +120,14 @@ class _FusedResNet:
         B, _, H, W = x.shape
         Ho = (H + 2 * c["pad"] - c["ks"]) // c["stride"] + 1
         Wo = (W + 2 * c["pad"] - c["ks"]) // c["stride"] + 1
-        # the native kernel maps 128 output pixels to a workgroup: below ~128 workgroups (a few images) MIOpen's kernels,
-        # which also split the output channels, fill the chip better
+        # [r5] gmf_conv_nhwc picks its own form: 128 output pixels x 64 channels per workgroup at batch size, 32 x 32 with the k range
+        # split over the waves for a few images (until round 4 those went to MIOpen).  MIOpen remains only for a convolution whose
+        # folded weights left the fp16 range of the split operands (no "img"), and as the A/B partner of tools/image_encoder_ab.py
         if "img" in c and B * Ho * Wo >= self.min_native_pixels:
             x = self._nhwc(x, "convolution input")
             if residual is not None:
                 residual = self._nhwc(residual, "residual")
-            y = torch.empty((B, c["cout"], Ho, Wo), device=x.device, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+            y = torch.empty((B, c["cout"], Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)   # (no copy kernel)
             h, st = handle_and_stream(x)
             h.call("gmf_conv_nhwc", x.data_ptr(), c["img"].data_ptr(), c["b"].data_ptr(),
                    None if residual is None else residual.data_ptr(), y.data_ptr(), B, H, W, c["cin"], c["cout"], c["ks"],
@@ -147,7 +148,7 @@ class _FusedResNet:
             raise RuntimeError(f"gmf_amd image encoder: images must be float32, got {x.dtype}")
         B, _, H, W = x.shape
         Hp, Wp = ((H - 1) // 2) // 2 + 1, ((W - 1) // 2) // 2 + 1
-        y = torch.empty((B, 64, Hp, Wp), device=x.device, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+        y = torch.empty((B, 64, Hp, Wp), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         h, st = handle_and_stream(x)
         for b0 in range(0, B, 65535):
             xb, yb = x[b0:b0 + 65535], y[b0:b0 + 65535]

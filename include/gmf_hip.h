@@ -129,6 +129,13 @@ int gmf_status_read(gmf_handle* h, int* flags, int clear);
  *                         row block (Q'/K/V | Fusion-2; bit-identical results); 0 = never.
  *   "conv_lds_patch"    : 1 = stride-1 3x3 convolutions stage activations through LDS (default), 2 = same without the
  *                         three-workgroup form, 0 = gather form.
+ *   "small_fattn_tile"  : [ABI 5] 1 = on small grids (B = 1, the reference's evaluation mode) the cross-attention role of a layer's first
+ *                         launch runs one workgroup per query tile whose four waves deal the context tiles among themselves (default;
+ *                         fusion_layer.py:84-94), 0 = one workgroup per four query tiles, each wave walking all context tiles.
+ *                         Same products, another order of the softmax's partial sums.
+ *   "conv_small_grid"   : [ABI 5] 1 = grids of fewer than 128 workgroups of those kernels - a few images, e.g. the two of one scene pair - run
+ *                         the K-split kernel: 32 pixels x 32 channels per workgroup, its four waves a quarter of the k range each
+ *                         (default); 0 = the 128-pixel kernels at every size.  Same products, another accumulation order.
  *   "nms_binned"        : 1 = grid-binned NMS candidates on large grids (default), 2 = always, 0 = all pairs.
  *   "topk_select"       : 1 = radix select of the S seeds (default), 0 = full bitonic sort.
  *   "q_in_attention"    : [ABI 4] 1 = on large grids every attention workgroup projects its own Q' in its prologue (default; PointDSC.py:56),

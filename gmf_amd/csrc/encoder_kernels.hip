@@ -1173,10 +1173,12 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
         }
         if (u == 20) split2h(x[14], x[15], ph1, pl1, 6);
         // the tile ring's refills ride in the lighter units of this phase, each as ONE statement (dma_4k_s): K_{t+2} (its slot held K_t, read
-        // during tile t - 1) at unit 12, V_{t+1} (slot of V_{t-1}) at unit 20 - 1028 us per launch against 1043 for eight separately set-up
+        // during tile t - 1) at unit 12, V_{t+1} (slot of V_{t-1}) at unit 20 [round 4; round 5: units 16 / 23, below] - 1028 us per launch against 1043 for eight separately set-up
         // pieces at units 12..15 / 20..23, which in turn beat V in the first units of phase 2 by 1 % (tools/ubench/ablate_h2p.py p8_*)
-        if (u == 12) issue_k4(t);
-        if (u == 20) issue_v4(t);
+        // [r5] with the cross products of S on the fp8 pipe the phase is 256 matrix-pipe cycles shorter; re-measured: (16, 23) 11.60-11.62 ms per
+        // pass of 12 launches, (12, 20) 11.67-11.69, (8, 16) 12.05, (0, 8) 12.54, V in phase 2 11.74-11.90 (profiles/r05_attention_notes.txt)
+        if (u == 16) issue_k4(t);
+        if (u == 23) issue_v4(t);
         if (u >= 21) vr[u - 21] = lv[hslot(u - 21)];
         __builtin_amdgcn_sched_barrier(0);
       }

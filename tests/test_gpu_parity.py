@@ -1314,9 +1314,9 @@ def test_dgr_config5_batched_procrustes():
 
 
 def test_forward_from_raw_images(model):
-    """The reference's own input dict: p_image / q_image [B,3,120,160] through the ResNet-34 -> layer2 encoder
-    (PyTorch-ROCm convolutions, both images of a pair in one batch), then the HIP path; tokens fed directly give the same
-    logits up to MIOpen's choice of convolution algorithm per batch size."""
+    """The reference's own input dict: p_image / q_image [B,3,120,160] through the ResNet-34 -> layer2 encoder (native HIP
+    convolutions, both images of a pair in one batch), then the HIP path; tokens computed one image at a time and fed directly
+    give the same logits bit for bit (resnet.py:195-216, PointDSC.py:129-137)."""
     b = synthetic.synthetic_batch([91], N=200, T=300)
     g = torch.Generator().manual_seed(5)
     p_img, q_img = torch.rand(1, 3, 120, 160, generator=g), torch.rand(1, 3, 120, 160, generator=g)
@@ -1330,10 +1330,11 @@ def test_forward_from_raw_images(model):
     d2 = {k: data[k] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
     d2.update(p_tokens=pt, q_tokens=qt, testing=True)
     model(d2)
-    # (MIOpen picks its convolution algorithm per batch size - two images at once against one at a time - and its small-batch kernels
-    # are not bitwise repeatable: the two routes differ by 0.3 .. 1.4e-5 on logits of magnitude 7 depending on the device of the pool;
-    # the bound is the parity contract's, not a guess at MIOpen's noise)
-    assert _maxerr(model.last_logits.cpu(), lg.cpu()) < 1e-4
+    # [r5] every convolution of the eval path is a native kernel at every batch size (k_conv_small_h2 for a few images): an output
+    # pixel's accumulation order does not depend on how many images share the launch, so the two routes - two images at once
+    # against one at a time - give the SAME bits (until round 4 small batches ran MIOpen's kernels, which are not repeatable
+    # across batch sizes: the bound was 1e-4)
+    assert torch.equal(model.last_logits, lg)
     assert res["final_trans"].shape == (1, 4, 4)
 
 
@@ -1361,7 +1362,7 @@ def test_f11_image_tokens_small_batch(golden_dir, graph):
     assert tok.shape == (2, 300, 128)
     scale = max(1.0, float(np.abs(g["tokens"]).max()))
     assert _maxerr(tok.cpu(), g["tokens"]) < 1e-4 * scale
-    assert _maxerr(tok.cpu(), tok2.cpu()) < 1e-5 * scale     # (MIOpen's small-batch kernels are not bitwise repeatable)
+    assert torch.equal(tok, tok2)                            # [r5] native kernels at this size too: repeatable bit for bit
     # [r4] the module on its own (`gmf_amd.ImageEncoder.forward`, resnet.py:195-216) takes the same fused path in eval mode - it
     # used to run the stock torch modules there; [B, 128, H', W'] as the reference returns it
     with torch.no_grad():

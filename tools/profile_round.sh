@@ -1,6 +1,6 @@
 #!/bin/bash
-# The round's committed profiles, one GPU job:  bash tools/profile_round.sh r04      (results under gpurun_out/, copied to profiles/ by hand)
-R=${1:-r04}
+# The round's committed profiles, one GPU job:  bash tools/profile_round.sh r05      (results under gpurun_out/, copied to profiles/ by hand)
+R=${1:-r05}
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out

@@ -101,6 +101,17 @@ PATCHES = {
              "          s_next = mfma_f8s(a8 & 0x7e7e7e7e, b8 & 0x7e7e7e7e, s_next, 0, 0x6b6b6b6b, 0x6b6b6b6b);   // (no NaN bytes, scales 2^-20: S stays the hi x hi product - realistic data everywhere else)\n"
              "        }\n        if (pr == 2) { kh = kh_n; kl = kl_n; }\n        if (u < 4) {"),
     ],
+    # [r5] schedule variants of the refills after the cross products of S moved to the fp8 pipe (the tile is 256 matrix-pipe cycles shorter, so
+    #      every lead time measured in units shrank): K_{t+2} / V_{t+1} issued at other units of phase 1.  Same results as the shipped kernel.
+    "r5_dma_6_14": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 6) issue_k4(t);\n        if (u == 14) issue_v4(t);\n")],
+    "r5_dma_4_10": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 4) issue_k4(t);\n        if (u == 10) issue_v4(t);\n")],
+    "r5_dma_0_8": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 0) issue_k4(t);\n        if (u == 8) issue_v4(t);\n")],
+    "r5_dma_8_16": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 8) issue_k4(t);\n        if (u == 16) issue_v4(t);\n")],
+    "r5_dma_v_first": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 4) issue_v4(t);\n        if (u == 14) issue_k4(t);\n")],
+    "r5_dma_16_23": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n")],
+    "r5_dma_14_22": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 14) issue_k4(t);\n        if (u == 22) issue_v4(t);\n")],
+    "r5_dma_12_p2": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 12) issue_k4(t);\n"), (EK, "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n", "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n" "          if (u == 2) issue_v4(t);\n")],
+    "r5_dma_20_p2": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 20) issue_k4(t);\n"), (EK, "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n", "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n" "          if (u == 4) issue_v4(t);\n")],
     "p8_no_consist": [     # timing only: the row sum without the decoded low plane (what the consistent sum costs: nothing measurable)
         (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<true>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),
         (EK, "      ls_l = __builtin_amdgcn_fdot2(dec2_fp8_f16<false>(pb[4 + w], 0x1p-10f), ones, ls_l, false);", ""),
@@ -111,7 +122,7 @@ PATCHES = {
              "      if (lane > 100000) store_block_h2(v_out + toff, db, t, lane);\n      asm volatile(\"\" :: \"v\"(t[0]), \"v\"(t[5]), \"v\"(t[10]), \"v\"(t[15]));"),
     ],
     "p8_dma_pieces": [     # the attention tile ring refilled by eight separately set-up pieces (K at units 12..15, V at 20..23) instead of two statements
-        (EK, "        if (u == 12) issue_k4(t);\n        if (u == 20) issue_v4(t);\n", "        if (u >= 12 && u < 16) issue_piece(t, u - 12);\n        if (u >= 20) issue_piece(t, u - 16);\n"),
+        (EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u >= 12 && u < 16) issue_piece(t, u - 12);\n        if (u >= 20) issue_piece(t, u - 16);\n"),
         (EK, "        if (PVF8) { issue_k4(t); issue_v4(t); }", "        if (false) { }"),
     ],
     "lin_dma_pieces": [    # the stage refills as four separately set-up 1 KiB pieces per wave (the form before dma_4k_s)
@@ -179,11 +190,11 @@ _NOC = [
     (EK, "    if (PVF8) vsw_next = __builtin_nontemporal_load(vsrow + (size_t)t * 64);", "    if (PVF8) vsw_next = 0x7f7f7f7fu;"),
 ]
 _NOREFILL = [
-    (EK, "        if (u == 12) issue_k4(t);\n        if (u == 20) issue_v4(t);\n", ""),
+    (EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", ""),
 ]
 _NOSTREAM = [
     (EK, "const f32x4 v = __builtin_nontemporal_load(ct + q * 64);", "const f32x4 v = {1.f, 1.f, 1.f, 1.f}; (void)ct;"),
-    (EK, "        if (u == 12) issue_k4(t);\n        if (u == 20) issue_v4(t);\n", ""),
+    (EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", ""),
     (EK, "    if (PVF8) vsw_next = __builtin_nontemporal_load(vsrow + (size_t)t * 64);", "    if (PVF8) vsw_next = 0x7f7f7f7fu;"),
 ]
 for _k, _v in list(PATCHES.items()):

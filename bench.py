@@ -370,8 +370,6 @@ def sweep(dev, full=False):
     del model, rag, packed, singles, pairs
     torch.cuda.empty_cache()
     rows += dgr_rows(dev, full)
-    if not full:
-        return rows
     # the throughput numerics modes (gmf_set_tuning "precision" = 1, 2; NOT the parity path, never the headline) on the headline
     # workload, with its measured deviation from the parity mode on the same batch
     from gmf_amd import _lib
@@ -383,7 +381,9 @@ def sweep(dev, full=False):
     lg0, T0 = model.last_logits.clone(), res0["final_trans"].clone()
     labels = {1: "throughput numerics (precision = 1: fp16 one-product attention, fp16 compat)",
               2: "throughput numerics, level 2 (precision = 2: level 1 + one-product linear stages)"}
-    for level in (1, 2):
+    # (level 1 rides in the DEFAULT line - BASELINE configs 2-3 name bf16-class arithmetic; it is labelled outside the parity gate - level 2
+    # only with --sweep)
+    for level in ((1, 2) if full else (1,)):
         try:
             hnd.call("gmf_set_tuning", b"precision", level)
             res1 = model(data)

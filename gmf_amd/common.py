@@ -37,16 +37,29 @@ def rigid_transform_3d(A, B, weights=None, weight_threshold=0):
 def knn(x, k, ignore_self=False, normalized=True):
     """Indices of the k nearest rows under 2 - 2 x x^T (common.py:53-75): x [bs,N,C] -> [bs,N,k] int64.
 
-    Only the configuration GMF uses is implemented (ignore_self=True, normalized=True, C=128;
-    PointDSC.py:327)."""
-    if not (ignore_self and normalized):
-        raise NotImplementedError("gmf_amd.knn: GMF only calls knn(ignore_self=True, normalized=True) (PointDSC.py:327)")
+    `normalized=True` (unit rows - what GMF feeds, PointDSC.py:229,327) with either value of `ignore_self`: the reference takes
+    top-(k+1) and drops rank 0 (`ignore_self=True`) or top-k including rank 0, which for unit rows is the row itself (distance 0;
+    [r5] returned here as the row's own index followed by its k - 1 nearest - identical to the reference except among exact
+    duplicates of a row, whose order torch.topk leaves unspecified).  `normalized=False` (raw squared distances of unnormalised
+    rows) has no HIP kernel - GMF never calls it - and raises."""
+    if not normalized:
+        raise NotImplementedError("gmf_amd.knn: normalized=False (distances of unnormalised rows) has no HIP kernel; GMF only calls "
+                                  "knn(..., normalized=True) on unit features (PointDSC.py:229,327)")
     x = require_cuda_f32(x, "x").contiguous()
     bs, N, C = x.shape
     if C != 128:
         raise NotImplementedError("gmf_amd.knn: HIP kernel is built for 128-d features")
-    rows = torch.arange(N, device=x.device, dtype=torch.int32).repeat(bs, 1).contiguous()
+    kk = k if ignore_self else k - 1                   # neighbours behind rank 0
     out = torch.empty((bs, N, k), device=x.device, dtype=torch.int32)
-    h, st = handle_and_stream(x)
-    h.call("gmf_knn_rows", x.data_ptr(), rows.data_ptr(), bs, N, N, k, out.data_ptr(), st)
+    rows = torch.arange(N, device=x.device, dtype=torch.int32).repeat(bs, 1).contiguous()
+    if ignore_self:
+        nb = out
+    else:
+        out[:, :, 0] = rows
+        nb = torch.empty((bs, N, max(kk, 1)), device=x.device, dtype=torch.int32)
+    if kk > 0:
+        h, st = handle_and_stream(x)
+        h.call("gmf_knn_rows", x.data_ptr(), rows.data_ptr(), bs, N, N, kk, nb.data_ptr(), st)
+        if not ignore_self:
+            out[:, :, 1:] = nb[:, :, :kk]
     return out.long()

@@ -150,6 +150,36 @@ def seeded_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, gain: float
     return out
 
 
+F23_CASES = {
+    # golden F23 (oracle/gen_fixtures.py): class, depth, dim, latent_dim, cross_heads, latent_heads, cross_dim_head, latent_dim_head,
+    # weight_tie_layers, pe, B, N, T - configurations of FusionLayer / PerceiverIO that GMF never instantiates
+    "fl_d2_h2": ("fl", 2, 128, 128, 2, 4, 32, 32, False, True, 2, 70, 33),
+    "fl_tied": ("fl", 3, 128, 128, 1, 2, 64, 48, True, True, 1, 97, 40),
+    "fl_w96": ("fl", 1, 96, 96, 3, 2, 16, 24, False, False, 2, 45, 12),
+    "pio_d1": ("pio", 1, 128, 256, 2, 8, 64, 32, False, True, 1, 130, 50),
+}
+
+
+def f23_state_dict(shapes: Dict[str, Tuple[int, ...]], tied: bool) -> SD:
+    """The weights of a golden-F23 module from its own key -> shape map: every tensor seeded by its key (seed 123); with
+    weight_tie_layers the tensors of layers 1 .. share those of layer 0 (the reference's modules are the same objects there)."""
+    import re
+    sd: SD = {}
+    for k, shp in shapes.items():
+        src = re.sub(r"^layers\.\d+\.", "layers.0.", k) if tied else k
+        sd[k] = seeded_state_dict({src: tuple(shp)}, seed=123)[src]
+    return sd
+
+
+def f23_inputs(name: str):
+    """(queries [B,N,latent], context [B,T,dim]) of golden F23 case `name`."""
+    cls, depth, dim, lat, ch, lh, cdh, ldh, tie, pe, B, N, T = F23_CASES[name]
+    r = np.random.default_rng([123, N, T])
+    x = torch.from_numpy(r.normal(0, 1, (B, N, lat)).astype(np.float32))
+    ctx = torch.from_numpy(r.normal(0, 1, (B, T, dim)).astype(np.float32))
+    return x, ctx
+
+
 def kitti_conditioned(sd: SD, div: float = 13.0) -> SD:
     """The seeded weights re-conditioned for KITTI-shape inputs (coordinates of +-40 m instead of 0..3 m).
 

@@ -226,6 +226,9 @@ def _param_list(layer):
 def fusion_layer_train(layer, data, queries):
     """Differentiable FusionLayer / PerceiverIO forward (depth = 0, one cross head): gradients flow to `data`, `queries`
     and every parameter of `layer`."""
+    if getattr(layer, "depth", 0) != 0 or getattr(layer, "cross_heads", 1) != 1:
+        raise NotImplementedError("gmf_amd.FusionLayer: the differentiable path covers what GMF trains (depth 0, one cross-attention head: "
+                                  "PointDSC.py:29-38,92-100); latent self-attention layers / several heads are forward-only (eval())")
     return _FusionLayerTrain.apply(data, queries, bool(layer.pe), *_param_list(layer))
 
 

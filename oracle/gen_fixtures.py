@@ -14,6 +14,7 @@ reference flattens at PointDSC.py:129-135).
 from __future__ import annotations
 
 import importlib.util
+import json
 import os
 import sys
 import types
@@ -544,7 +545,51 @@ def gen_f22(pdsc):
     np.savez_compressed(os.path.join(GOLD, "f22_kitti_branch.npz"), sigma_d=1.2, tau=1.2, layer0_div=13.0, **out)
 
 
+F23_CASES = {
+    # name: (class, depth, dim, latent_dim, cross_heads, latent_heads, cross_dim_head, latent_dim_head, weight_tie_layers, pe, B, N, T)
+    "fl_d2_h2": ("fl", 2, 128, 128, 2, 4, 32, 32, False, True, 2, 70, 33),
+    "fl_tied": ("fl", 3, 128, 128, 1, 2, 64, 48, True, True, 1, 97, 40),
+    "fl_w96": ("fl", 1, 96, 96, 3, 2, 16, 24, False, False, 2, 45, 12),
+    "pio_d1": ("pio", 1, 128, 256, 2, 8, 64, 32, False, True, 1, 130, 50),
+}
+
+
+def gen_f23(fl, pio):
+    """F23 [r5]: the reference's FusionLayer (fusion_layer.py:131-201) and DGR PerceiverIO (perceiver_io.py:139-221) in
+    configurations GMF never instantiates - latent self-attention layers (depth 1 .. 3), several heads, tied layers, widths other
+    than 128 - for the general forward of gmf_amd.FusionLayer / PerceiverIO.  Weights seeded by state_dict key from the MODULE'S
+    OWN key list (tied layers: the shared tensors get the seed of their FIRST name); inputs N(0, 1)."""
+    out, keys = {}, {}
+    for name, (cls, depth, dim, lat, ch, lh, cdh, ldh, tie, pe, B, N, T) in F23_CASES.items():
+        mod = (fl.FusionLayer if cls == "fl" else pio.PerceiverIO)(depth=depth, dim=dim, latent_dim=lat, cross_heads=ch, latent_heads=lh,
+                                                                    cross_dim_head=cdh, latent_dim_head=ldh, weight_tie_layers=tie, pe=pe).eval()
+        own = mod.state_dict()
+        first = {}
+        for k, v in own.items():                     # tied layers: one tensor under several names
+            first.setdefault(v.data_ptr(), k)
+        sd = {}
+        for k, v in own.items():
+            src = first[v.data_ptr()]
+            sd[k] = O.seeded_state_dict({src: tuple(v.shape)}, seed=123)[src]
+        mod.load_state_dict(sd)
+        r = np.random.default_rng([123, N, T])
+        x = torch.from_numpy(r.normal(0, 1, (B, N, lat)).astype(np.float32))
+        ctx = torch.from_numpy(r.normal(0, 1, (B, T, dim)).astype(np.float32))
+        with torch.no_grad():
+            y = mod(ctx, queries_encoder=x)
+        out[f"out_{name}"] = _np(y)
+        keys[name] = sorted(own.keys())
+        print("F23", name, tuple(y.shape), "|out|max", float(y.abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "f23_fusion_layer_general.npz"), seed=123, **out)
+    with open(os.path.join(GOLD, "f23_state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f23":
+        _, fl, _, pio, _ = _import_reference()
+        gen_f23(fl, pio)
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f22":
         gen_f22(_import_reference()[0])
         return

@@ -97,6 +97,49 @@ def fusion_layer(sd: SD, prefix: str, data, queries, pe: bool):
     return x
 
 
+def multihead_attention(xn, cn, Wq, Wkv, Wo, bo, heads: int):
+    """Attention.forward with `heads` heads (fusion_layer.py:82-94): 'b n (h d) -> (b h) n d', softmax(q k^T d^-1/2) v, heads
+    concatenated, to_out.  xn / cn are already normed."""
+    B, N, _ = xn.shape
+    T = cn.shape[1]
+    inner = Wq.shape[0]
+    d = inner // heads
+    q = (xn @ Wq.t()).reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    kv = cn @ Wkv.t()
+    k = kv[..., :inner].reshape(B, T, heads, d).permute(0, 2, 1, 3)
+    v = kv[..., inner:].reshape(B, T, heads, d).permute(0, 2, 1, 3)
+    p = torch.softmax((q @ k.transpose(-1, -2)) * (d ** -0.5), dim=-1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B, N, inner)
+    return o @ Wo.t() + bo
+
+
+def fusion_layer_general(sd: SD, prefix: str, data, queries, pe: bool, depth: int, cross_heads: int, latent_heads: int):
+    """FusionLayer.forward / PerceiverIO.forward for any constructor arguments (fusion_layer.py:172-201): the cross-attention block
+    with `cross_heads` heads, then `depth` x {latent self-attention with `latent_heads` heads over the normed x, feed-forward}
+    (test infrastructure for golden F23; GMF itself only builds depth 0 with one head)."""
+    x = queries
+    if pe:
+        x = conv_pos_enc_1(x, sd[prefix + "cpe.proj_q.weight"], sd[prefix + "cpe.proj_q.bias"])
+        data = conv_pos_enc_1(data, sd[prefix + "cpe.proj_content.weight"], sd[prefix + "cpe.proj_content.bias"])
+    a = prefix + "cross_attend_blocks.0."
+    xn = layer_norm(x, sd[a + "norm.weight"], sd[a + "norm.bias"])
+    cn = layer_norm(data, sd[a + "norm_context.weight"], sd[a + "norm_context.bias"])
+    x = multihead_attention(xn, cn, sd[a + "fn.to_q.weight"], sd[a + "fn.to_kv.weight"], sd[a + "fn.to_out.weight"],
+                            sd[a + "fn.to_out.bias"], cross_heads) + x
+
+    def ff(p, x):
+        xn = layer_norm(x, sd[p + "norm.weight"], sd[p + "norm.bias"])
+        return geglu_ff(xn, sd[p + "fn.net.0.weight"], sd[p + "fn.net.0.bias"], sd[p + "fn.net.2.weight"], sd[p + "fn.net.2.bias"]) + x
+    x = ff(prefix + "cross_attend_blocks.1.", x)
+    for i in range(depth):
+        p = f"{prefix}layers.{i}.0."
+        xn = layer_norm(x, sd[p + "norm.weight"], sd[p + "norm.bias"])
+        x = multihead_attention(xn, xn, sd[p + "fn.to_q.weight"], sd[p + "fn.to_kv.weight"], sd[p + "fn.to_out.weight"],
+                                sd[p + "fn.to_out.bias"], latent_heads) + x
+        x = ff(f"{prefix}layers.{i}.1.", x)
+    return x
+
+
 # --------------------------------------------------------------------------
 # PointDSC encoder (models/PointDSC.py:10-143)
 # --------------------------------------------------------------------------

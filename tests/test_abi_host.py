@@ -79,8 +79,9 @@ def test_wide_fusion_packing():
 
 def test_unsupported_configurations_raise():
     import gmf_amd
-    with pytest.raises(NotImplementedError):
-        gmf_amd.FusionLayer(depth=2, dim=128, latent_dim=128)
+    # [r5] every constructor argument of the reference's FusionLayer is honoured (golden F23); NonLocalBlock widths other than GMF's are not
+    fl = gmf_amd.FusionLayer(depth=2, dim=128, latent_dim=128)
+    assert "layers.1.0.fn.to_kv.weight" in fl.state_dict()
     with pytest.raises(NotImplementedError):
         gmf_amd.NonLocalBlock(num_channels=64)
 

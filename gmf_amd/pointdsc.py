@@ -242,9 +242,8 @@ class NonLocalBlock(nn.Module):
 
     def __init__(self, num_channels=128, num_heads=1):
         super().__init__()
-        if num_channels != 128 or num_heads != 1:
-            raise NotImplementedError("gmf_amd.NonLocalBlock: HIP kernels are built for num_channels=128, num_heads=1 "
-                                      "(the only configuration GMF instantiates, PointDSC.py:111)")
+        if num_channels < 2 or num_channels % 2 or num_channels % num_heads:
+            raise NotImplementedError("gmf_amd.NonLocalBlock: num_channels must be even and a multiple of num_heads (PointDSC.py:11-25,56-58)")
         c = num_channels
         self.fc_message = nn.Sequential(
             nn.Conv1d(c, c // 2, 1), nn.BatchNorm1d(c // 2), nn.ReLU(inplace=True),
@@ -277,6 +276,8 @@ class NonLocalBlock(nn.Module):
         T = image_feat.shape[1]
         if attention.shape != (B, N, N):
             raise RuntimeError(f"gmf_amd.NonLocalBlock: attention must be [B,N,N], got {tuple(attention.shape)}")
+        if self.num_channels != 128 or self.head != 1:
+            return self._forward_general(feat, attention, image_feat)
         pw = self._weights(feat.device)
         h, st = handle_and_stream(feat)
         tiles, tt = (N + 31) // 32, (T + 31) // 32
@@ -290,6 +291,50 @@ class NonLocalBlock(nn.Module):
         out = torch.empty((B, Cc, N), device=feat.device, dtype=torch.float32)
         h.call("gmf_unpack_rows_p32", oimg.data_ptr(), B, N, Cc, out.data_ptr(), out.stride(0), out.stride(2), out.stride(1), st)
         return out
+
+
+    # -- [r5] widths / head counts GMF never instantiates (PointDSC.py:11: num_channels, num_heads are constructor arguments) ----------
+    def _folded(self):
+        """fc_message with its two eval-mode BatchNorms folded into the convolutions before them, cached until a parameter changes."""
+        ver = params_version(self)
+        if getattr(self, "_fold_version", None) != ver:
+            if self.training:
+                raise RuntimeError("gmf_amd.NonLocalBlock: only eval() mode is implemented (BatchNorm uses running stats)")
+            sd = {k: v.detach() for k, v in self.fc_message.state_dict().items()}
+            Wa, ba = packing.fold_bn(sd["0.weight"][:, :, 0], sd["0.bias"], sd, "1.")
+            Wb, bb = packing.fold_bn(sd["3.weight"][:, :, 0], sd["3.bias"], sd, "4.")
+            self._fold = tuple(t.contiguous() for t in (Wa, ba, Wb, bb, sd["6.weight"][:, :, 0], sd["6.bias"]))
+            self._fold_version = ver
+        return self._fold
+
+    def _forward_general(self, feat, attention, image_feat):
+        """PointDSC.py:40-74 for any (num_channels, num_heads), forward only, from the library's HIP primitives (`gmf_gemm_f32`,
+        `gmf_softmax_rows` with the spatial-consistency matrix as the logits' multiplier): rows are token-major [B N, C]."""
+        from . import train as P
+        with torch.no_grad():
+            B, C, N = feat.shape
+            hds, d = self.head, C // self.head
+            f = feat.permute(0, 2, 1).contiguous().reshape(B * N, C)
+            q = P.gemm(f, self.projection_q.weight[:, :, 0], tb=True, bias=self.projection_q.bias)
+            k = P.gemm(f, self.projection_k.weight[:, :, 0], tb=True, bias=self.projection_k.bias)
+            v = P.gemm(f, self.projection_v.weight[:, :, 0], tb=True, bias=self.projection_v.bias)
+            S = torch.empty((hds, B, N, N), device=f.device, dtype=torch.float32)
+            msg = torch.empty((B * N, C), device=f.device, dtype=torch.float32)
+            for hd in range(hds):                       # 'bhco, bhci -> bhoi' / sqrt(C / heads), one batched product per head
+                P.gemm(q, k, tb=True, out=S, m=N, n=N, k=d, lda=C, ldb=C, ldc=N, a_off=hd * d, b_off=hd * d, c_off=hd * B * N * N,
+                       batch=B, sa=N * C, sb=N * C, sc=N * N)
+            W = torch.empty_like(S)
+            for hd in range(hds):                       # softmax(attention * S / sqrt(d)) per row (PointDSC.py:62)
+                W[hd] = P.softmax_rows(S[hd].reshape(B * N, N), d ** -0.5, mul=attention.reshape(B * N, N)).reshape(B, N, N)
+            for hd in range(hds):                       # 'bhoi, bhci -> bhco'
+                P.gemm(W, v, out=msg, m=N, n=d, k=N, lda=N, ldb=C, ldc=C, a_off=hd * B * N * N, b_off=hd * d, c_off=hd * d,
+                       batch=B, sa=N * N, sb=N * C, sc=N * C)
+            Wa, ba, Wb, bb, Wc, bc = self._folded()
+            m1 = P.gemm(msg, Wa, tb=True, bias=ba, relu=True)
+            m2 = P.gemm(m1, Wb, tb=True, bias=bb, relu=True)
+            fus = self.fusion_layer_2(image_feat, queries_encoder=f.reshape(B, N, C)).reshape(B * N, C)
+            out = P.gemm(m2, Wc, tb=True, bias=bc, residual=fus)          # message + image_feat (PointDSC.py:73)
+            return out.reshape(B, N, C).permute(0, 2, 1).contiguous()
 
 
 class NonLocalNet(nn.Module):

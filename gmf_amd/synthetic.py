@@ -180,6 +180,20 @@ def f23_inputs(name: str):
     return x, ctx
 
 
+F24_CASES = {"c64_h2": (64, 2, 2, 90, 20), "c128_h4": (128, 4, 1, 150, 33), "c32_h1": (32, 1, 2, 40, 7)}     # golden F24: channels, heads, B, N, T
+
+
+def f24_inputs(name: str):
+    """(feat [B,C,N], src, tgt [B,N,3], image_feat [B,T,C]) of golden F24 case `name` (oracle/gen_fixtures.py gen_f24 draws the same stream)."""
+    C, H, B, N, T = F24_CASES[name]
+    r = np.random.default_rng([124, C, N])
+    feat = torch.from_numpy(r.normal(0, 1, (B, C, N)).astype(np.float32))
+    img = torch.from_numpy(r.normal(0, 1, (B, T, C)).astype(np.float32))
+    src = torch.from_numpy(r.uniform(0, 3, (B, N, 3)).astype(np.float32))
+    tgt = src + torch.from_numpy(r.normal(0, 0.05, (B, N, 3)).astype(np.float32))
+    return feat, src, tgt, img
+
+
 def kitti_conditioned(sd: SD, div: float = 13.0) -> SD:
     """The seeded weights re-conditioned for KITTI-shape inputs (coordinates of +-40 m instead of 0..3 m).
 

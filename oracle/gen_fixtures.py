@@ -585,7 +585,34 @@ def gen_f23(fl, pio):
         json.dump(keys, f, indent=0)
 
 
+F24_CASES = {"c64_h2": (64, 2, 2, 90, 20), "c128_h4": (128, 4, 1, 150, 33), "c32_h1": (32, 1, 2, 40, 7)}     # channels, heads, B, N, T
+
+
+def gen_f24(pdsc):
+    """F24 [r5]: the reference's NonLocalBlock (PointDSC.py:10-74) with widths / head counts GMF never instantiates (its constructor
+    takes num_channels and num_heads).  eval() mode, seeded weights and BatchNorm statistics by key, compat matrix from seeded points."""
+    out = {}
+    for name, (C, H, B, N, T) in F24_CASES.items():
+        blk = pdsc.NonLocalBlock(num_channels=C, num_heads=H).eval()
+        sd = O.seeded_state_dict({k: tuple(v.shape) for k, v in blk.state_dict().items()}, seed=124)
+        blk.load_state_dict(sd)
+        r = np.random.default_rng([124, C, N])
+        feat = torch.from_numpy(r.normal(0, 1, (B, C, N)).astype(np.float32))
+        img = torch.from_numpy(r.normal(0, 1, (B, T, C)).astype(np.float32))
+        src = torch.from_numpy(r.uniform(0, 3, (B, N, 3)).astype(np.float32))
+        tgt = src + torch.from_numpy(r.normal(0, 0.05, (B, N, 3)).astype(np.float32))
+        compat, _ = O.compat_matrix(src, tgt, 0.1)
+        with torch.no_grad():
+            y = blk(feat, compat, img)
+        out[f"out_{name}"] = _np(y)
+        print("F24", name, tuple(y.shape), "|out|max", float(y.abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "f24_nonlocal_block_general.npz"), seed=124, **out)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f24":
+        gen_f24(_import_reference()[0])
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "f23":
         _, fl, _, pio, _ = _import_reference()
         gen_f23(fl, pio)

@@ -185,12 +185,23 @@ def fc_message(x, sd, p):
     return _lin(x, sd[p + "6.weight"], sd[p + "6.bias"])
 
 
-def nonlocal_block(sd: SD, p: str, feat, compat, image_feat):
+def sc_attention_heads(feat, compat, Wq, bq, Wk, bk, Wv, bv, heads: int):
+    """PointDSC.py:56-64 with `heads` heads: channels [h (C / heads)] ('bhco, bhci -> bhoi' / sqrt(C / heads)), the compat matrix
+    broadcast over the heads, heads concatenated (test infrastructure for golden F24; GMF builds one head)."""
+    B, N, C = feat.shape
+    d = C // heads
+    q = _lin(feat, Wq, bq).reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    k = _lin(feat, Wk, bk).reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    v = _lin(feat, Wv, bv).reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    p = torch.softmax(compat[:, None] * (q @ k.transpose(-1, -2)) / math.sqrt(d), dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B, N, C)
+
+
+def nonlocal_block(sd: SD, p: str, feat, compat, image_feat, heads: int = 1):
     """NonLocalBlock.forward (PointDSC.py:40-74) on token-major feat [B,N,C]."""
-    msg = sc_attention(feat, compat,
-                       sd[p + "projection_q.weight"], sd[p + "projection_q.bias"],
-                       sd[p + "projection_k.weight"], sd[p + "projection_k.bias"],
-                       sd[p + "projection_v.weight"], sd[p + "projection_v.bias"])
+    qkv = (sd[p + "projection_q.weight"], sd[p + "projection_q.bias"], sd[p + "projection_k.weight"], sd[p + "projection_k.bias"],
+           sd[p + "projection_v.weight"], sd[p + "projection_v.bias"])
+    msg = sc_attention(feat, compat, *qkv) if heads == 1 else sc_attention_heads(feat, compat, *qkv, heads)
     msg = fc_message(msg, sd, p + "fc_message.")
     img = fusion_layer(sd, p + "fusion_layer_2.", image_feat, feat, pe=True)
     return msg + img

@@ -79,11 +79,12 @@ def test_wide_fusion_packing():
 
 def test_unsupported_configurations_raise():
     import gmf_amd
-    # [r5] every constructor argument of the reference's FusionLayer is honoured (golden F23); NonLocalBlock widths other than GMF's are not
+    # [r5] every constructor argument of the reference's FusionLayer (golden F23) and NonLocalBlock (F24) is honoured
     fl = gmf_amd.FusionLayer(depth=2, dim=128, latent_dim=128)
     assert "layers.1.0.fn.to_kv.weight" in fl.state_dict()
+    assert gmf_amd.NonLocalBlock(num_channels=64, num_heads=2).projection_q.weight.shape == (64, 64, 1)
     with pytest.raises(NotImplementedError):
-        gmf_amd.NonLocalBlock(num_channels=64)
+        gmf_amd.NonLocalBlock(num_channels=64, num_heads=3)
 
 
 def test_p32_image_definition():

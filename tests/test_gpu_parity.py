@@ -104,6 +104,22 @@ def test_f2_fusion2(golden_dir, N, T):
     assert _maxerr(m(_gpu(ctx), queries_encoder=_gpu(x)).cpu(), g[f"out_N{N}_T{T}"]) < 1e-4
 
 
+@pytest.mark.parametrize("name", ["c64_h2", "c128_h4", "c32_h1"])
+def test_f24_general_nonlocal_block(golden_dir, name):
+    """Golden F24 [r5]: `NonLocalBlock(num_channels, num_heads)` for values GMF never passes (PointDSC.py:11; VERDICT r4 missing 3) -
+    the forward-only composition of HIP primitives (`NonLocalBlock._forward_general`) against the reference's own output."""
+    C, H, B, N, T = synthetic.F24_CASES[name]
+    blk = gmf_amd.NonLocalBlock(num_channels=C, num_heads=H)
+    blk.load_state_dict(synthetic.seeded_state_dict({k: tuple(v.shape) for k, v in blk.state_dict().items()}, seed=124))
+    blk = blk.to(DEV).eval()
+    feat, src, tgt, img = synthetic.f24_inputs(name)
+    compat, _ = O.compat_matrix(src, tgt, 0.1)
+    out = blk(_gpu(feat), _gpu(compat), _gpu(img))
+    ref = _load(golden_dir, "f24_nonlocal_block_general.npz")[f"out_{name}"]
+    print(f"F24 {name}: max |out - reference| {_maxerr(out.cpu(), ref):.2e}")
+    assert out.shape == (B, C, N) and _maxerr(out.cpu(), ref) < 1e-4
+
+
 @pytest.mark.parametrize("name", ["fl_d2_h2", "fl_tied", "fl_w96", "pio_d1"])
 def test_f23_general_fusion_layer(golden_dir, name):
     """Golden F23 [r5]: every constructor argument of the reference's FusionLayer / PerceiverIO is honoured - latent self-attention

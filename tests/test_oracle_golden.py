@@ -436,3 +436,19 @@ def test_f23_oracle_and_surface_of_the_general_fusion_layer(golden_dir, name):
     out = O.fusion_layer_general(sd, "", ctx, x, pe, depth, ch, lh)
     assert float((out - torch.from_numpy(g[f"out_{name}"])).abs().max()) < 2e-5
 
+
+@pytest.mark.parametrize("name", ["c64_h2", "c128_h4", "c32_h1"])
+def test_f24_oracle_nonlocal_block_general(golden_dir, name):
+    """Golden F24 [r5]: the reference's NonLocalBlock (PointDSC.py:10-74) with other widths and head counts than GMF's (128, 1): the
+    drop-in module has the reference's keys and the oracle reproduces the reference's output."""
+    import gmf_amd
+    from gmf_amd import synthetic
+    C, H, B, N, T = synthetic.F24_CASES[name]
+    blk = gmf_amd.NonLocalBlock(num_channels=C, num_heads=H)
+    sd = synthetic.seeded_state_dict({k: tuple(v.shape) for k, v in blk.state_dict().items()}, seed=124)
+    feat, src, tgt, img = synthetic.f24_inputs(name)
+    compat, _ = O.compat_matrix(src, tgt, 0.1)
+    out = O.nonlocal_block(sd, "", feat.permute(0, 2, 1), compat, img, heads=H).permute(0, 2, 1)
+    g = np.load(os.path.join(golden_dir, "f24_nonlocal_block_general.npz"))
+    assert float((out - torch.from_numpy(g[f"out_{name}"])).abs().max()) < 2e-5
+

@@ -113,6 +113,7 @@ SIGNATURES = {
     "gmf_status_read": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
     "gmf_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "gmf_get_tuning": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int)]),
+    "gmf_set_sigma_device": (C.c_int, [_vp, _vp]),
     "gmf_profile_enable": (C.c_int, [_vp, C.c_int]),
     "gmf_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "gmf_pack_rows_p32": (C.c_int, [_vp, _vp, _ll, _ll, _ll, C.c_int, C.c_int, C.c_int, _vp, _vp]),

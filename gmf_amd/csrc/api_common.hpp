@@ -39,6 +39,7 @@ struct gmf_handle {
   int* status_host = nullptr;
   int* status_dev = nullptr;
   gmf::Tuning tune;   // per-handle knobs (gmf_set_tuning); no process-global state
+  const float* sigma_dev = nullptr;   // [ABI 5] gmf_set_sigma_device: PointDSC's learnable sigma read on the device instead of by value
   // optional in-situ timing of the dominant kernel (k_scattn): event pairs recorded on the caller's stream
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

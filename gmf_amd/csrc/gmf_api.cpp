@@ -76,6 +76,13 @@ int gmf_status_read(gmf_handle* h, int* flags, int clear) {
   return GMF_OK;
 }
 
+int gmf_set_sigma_device(gmf_handle* h, const float* sigma_dev) {
+  GMF_REQUIRE(h, GMF_ERR_BAD_ARG, "set_sigma_device: null handle");
+  std::lock_guard<std::mutex> lock(h->mu);
+  h->sigma_dev = sigma_dev;
+  return GMF_OK;
+}
+
 int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
   GMF_REQUIRE(h && name, GMF_ERR_BAD_ARG, "set_tuning: null pointer");
   std::lock_guard<std::mutex> lock(h->mu);        // (forwards read h->tune under the same lock)
@@ -876,7 +883,7 @@ static int pose_head_impl(gmf_handle* h, const gmf_pose_params* p, const float* 
   // [r4] no limit on N (the reference has none: PointDSC.py:268-286, common.py:53-75; evaluation/test_3DMatch.py:143 feeds num_node = 'all'):
   // above 16 384 rows the seed selection reads its keys from global memory and the kNN selection streams the distance rows
   GMF_REQUIRE(seeds_in || (size_t)Sn * 8 <= 156 * 1024, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head: more than 19968 seeds per pair (the winners' list lives in the LDS)");
-  GMF_REQUIRE(p->sigma > 0.f && p->sigma_d > 0.f, GMF_ERR_BAD_ARG, "pose_head: sigma, sigma_d must be positive");
+  GMF_REQUIRE((p->sigma > 0.f || h->sigma_dev) && p->sigma_d > 0.f, GMF_ERR_BAD_ARG, "pose_head: sigma, sigma_d must be positive");
   hipStream_t st = S(stream);
   const size_t BS = (size_t)B * Sn;
   const size_t need = arena_need((size_t)B * N, 4) + arena_need(BS, 4) + arena_need(BS * k, 4) +
@@ -934,7 +941,7 @@ static int pose_head_impl(gmf_handle* h, const gmf_pose_params* p, const float* 
   // tools/ubench/archive/seed_knn_fused_r04.hip)
   GMF_HIP(gmf::launch_seed_dist(fimg, seeds_use, dmat, B, N, Sn, st, ptab));
   GMF_HIP(gmf::launch_knn_seeds(feat_n, seeds_use, dmat, knn, B, N, Sn, k, st, ptab));
-  GMF_HIP(gmf::launch_seed_power(feat_n, src_keypts, tgt_keypts, knn, snaps, conv, hsum, B, N, Sn, k, iters, p->sigma, p->sigma_d, st, ptab));
+  GMF_HIP(gmf::launch_seed_power(feat_n, src_keypts, tgt_keypts, knn, snaps, conv, hsum, B, N, Sn, k, iters, p->sigma, p->sigma_d, st, ptab, h->sigma_dev));
   GMF_HIP(gmf::launch_seed_kabsch(src_keypts, tgt_keypts, knn, snaps, conv, sT, B, N, Sn, k, iters, hsum, stop_it, st, ptab));
   GMF_HIP(gmf::launch_score_hyp(src_keypts, tgt_keypts, sT, counts, B, N, Sn, p->inlier_threshold, st, ptab));
   GMF_HIP(gmf::launch_finalize_pose(src_keypts, tgt_keypts, sT, counts, fit, final_trans, final_labels, best, B, N, Sn,
@@ -1046,12 +1053,12 @@ int gmf_similarity_matrix(gmf_handle* h, const float* feat_n, int B, int N, floa
   GMF_REQUIRE(h && feat_n && M, GMF_ERR_BAD_ARG, "similarity_matrix: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "similarity_matrix: empty input");
   GMF_REQUIRE(ldm >= N, GMF_ERR_BAD_ARG, "similarity_matrix: ldm (row stride of M in floats) must be >= N");
-  GMF_REQUIRE(sigma != 0.f, GMF_ERR_BAD_ARG, "similarity_matrix: sigma must be non-zero");
+  GMF_REQUIRE(sigma != 0.f || h->sigma_dev, GMF_ERR_BAD_ARG, "similarity_matrix: sigma must be non-zero");
   SetDevice sd(h, stream);
   const size_t n_img = gmf::similarity_image_floats(B, N);
   if (int rc = arena_reserve(h, arena_need(n_img, 4))) return rc;
   float* img = arena_take<float>(h, n_img);
-  GMF_HIP(gmf::launch_similarity_matrix(feat_n, img, M, B, N, ldm, sigma, S(stream)));
+  GMF_HIP(gmf::launch_similarity_matrix(feat_n, img, M, B, N, ldm, sigma, S(stream), h->sigma_dev));
   return GMF_OK;
 }
 
@@ -1073,7 +1080,7 @@ int gmf_spectral_matching_loss_fused(gmf_handle* h, const float* feat_n, const f
                                      int balanced, float* loss_out, gmf_stream_t stream) {
   GMF_REQUIRE(h && feat_n && gt_labels && loss_out, GMF_ERR_BAD_ARG, "spectral_matching_loss_fused: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "spectral_matching_loss_fused: empty input");
-  GMF_REQUIRE(sigma != 0.f, GMF_ERR_BAD_ARG, "spectral_matching_loss_fused: sigma must be non-zero");
+  GMF_REQUIRE(sigma != 0.f || h->sigma_dev, GMF_ERR_BAD_ARG, "spectral_matching_loss_fused: sigma must be non-zero");
   SetDevice sd(h, stream);
   const size_t n_img = gmf::similarity_image_floats(B, N);
   const size_t n_part = (size_t)2 * B * gmf::sm_fused_parts_per_pair(B, N);
@@ -1081,7 +1088,7 @@ int gmf_spectral_matching_loss_fused(gmf_handle* h, const float* feat_n, const f
   float* img = arena_take<float>(h, n_img);
   double* part = arena_take<double>(h, n_part);
   double* pair_loss = arena_take<double>(h, (size_t)B);
-  GMF_HIP(gmf::launch_sm_loss_fused(feat_n, gt_labels, img, part, pair_loss, B, N, sigma, balanced, loss_out, S(stream)));
+  GMF_HIP(gmf::launch_sm_loss_fused(feat_n, gt_labels, img, part, pair_loss, B, N, sigma, balanced, loss_out, S(stream), h->sigma_dev));
   return GMF_OK;
 }
 
@@ -1089,7 +1096,7 @@ int gmf_spectral_matching_backward(gmf_handle* h, const float* feat_n, const flo
                                    int balanced, float* d_feat_n, float* d_sigma, gmf_stream_t stream) {
   GMF_REQUIRE(h && feat_n && gt_labels && d_feat_n && d_sigma, GMF_ERR_BAD_ARG, "spectral_matching_backward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "spectral_matching_backward: empty input");
-  GMF_REQUIRE(sigma != 0.f, GMF_ERR_BAD_ARG, "spectral_matching_backward: sigma must be non-zero");
+  GMF_REQUIRE(sigma != 0.f || h->sigma_dev, GMF_ERR_BAD_ARG, "spectral_matching_backward: sigma must be non-zero");
   SetDevice sd(h, stream);
   const size_t n_img = gmf::similarity_image_floats(B, N);
   const size_t n_part = (size_t)gmf::sm_backward_parts(B, N);
@@ -1098,7 +1105,7 @@ int gmf_spectral_matching_backward(gmf_handle* h, const float* feat_n, const flo
   float* timg = arena_take<float>(h, n_img);
   float* consts = arena_take<float>(h, (size_t)4 * B);
   double* part = arena_take<double>(h, n_part);
-  GMF_HIP(gmf::launch_sm_backward(feat_n, gt_labels, img, timg, consts, part, B, N, sigma, balanced, d_feat_n, d_sigma, S(stream)));
+  GMF_HIP(gmf::launch_sm_backward(feat_n, gt_labels, img, timg, consts, part, B, N, sigma, balanced, d_feat_n, d_sigma, S(stream), h->sigma_dev));
   return GMF_OK;
 }
 

@@ -175,7 +175,7 @@ int gmf_similarity_backward(gmf_handle* h, const float* feat_n, const float* dM,
                             float* d_sigma, gmf_stream_t stream) {
   GMF_REQUIRE(h && feat_n && dM && d_feat_n && d_sigma, GMF_ERR_BAD_ARG, "similarity_backward: null pointer");
   GMF_REQUIRE(B > 0 && N > 0, GMF_ERR_UNSUPPORTED_SHAPE, "similarity_backward: empty input");
-  GMF_REQUIRE(sigma != 0.f, GMF_ERR_BAD_ARG, "similarity_backward: sigma must be non-zero");
+  GMF_REQUIRE(sigma != 0.f || h->sigma_dev, GMF_ERR_BAD_ARG, "similarity_backward: sigma must be non-zero");
   SetDevice sd(h, stream);
   const size_t nn = (size_t)B * N * N, rows = (size_t)B * N;
   const size_t n_part = (size_t)gmf::colsum_chunks((long)rows);
@@ -188,7 +188,7 @@ int gmf_similarity_backward(gmf_handle* h, const float* feat_n, const float* dM,
   const long ld = 128, sF = (long)N * 128, sN = (long)N * N;
   // S = Fn Fn^T per pair, G = dM * [0 <= u <= 1] / sigma^2, dFn = G Fn + G^T Fn, dsigma = sum of the row partials
   GMF_HIP(gmf::launch_gemm_f32(false, true, feat_n, feat_n, Sm, nullptr, nullptr, N, N, 128, ld, ld, N, sF, sF, sN, B, 1.0f, nullptr, 1, 0, st));
-  GMF_HIP(gmf::launch_sim_bwd_G(Sm, dM, G, rowdsig, B, N, sigma, st));
+  GMF_HIP(gmf::launch_sim_bwd_G(Sm, dM, G, rowdsig, B, N, sigma, st, h->sigma_dev));
   GMF_HIP(gmf::launch_gemm_f32(false, false, G, feat_n, d_feat_n, nullptr, nullptr, N, 128, N, N, ld, ld, sN, sF, sF, B, 1.0f, nullptr, 1, 0, st));
   GMF_HIP(gmf::launch_gemm_f32(true, false, G, feat_n, d_feat_n, nullptr, d_feat_n, N, 128, N, N, ld, ld, sN, sF, sF, B, 1.0f, nullptr, 1, 0, st));
   GMF_HIP(gmf::launch_colsum(rowdsig, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, (int)rows, (long)rows, 1, part, d_sigma, st));
@@ -224,7 +224,7 @@ int gmf_pose_head_backward(gmf_handle* h, const gmf_pose_params* p, const float*
   GMF_REQUIRE(k > 0 && k <= 64 && k <= N - 1, GMF_ERR_UNSUPPORTED_SHAPE, "pose_head_backward: need 0 < k <= min(64, N-1)");
   GMF_REQUIRE(iters > 0 && iters <= 64, GMF_ERR_BAD_ARG, "pose_head_backward: bad num_iterations");
   GMF_REQUIRE(p->refine_iters == 0, GMF_ERR_BAD_ARG, "pose_head_backward: the post-refinement (test mode) is not differentiable");
-  GMF_REQUIRE(p->sigma > 0.f && p->sigma_d > 0.f, GMF_ERR_BAD_ARG, "pose_head_backward: sigma, sigma_d must be positive");
+  GMF_REQUIRE((p->sigma > 0.f || h->sigma_dev) && p->sigma_d > 0.f, GMF_ERR_BAD_ARG, "pose_head_backward: sigma, sigma_d must be positive");
   SetDevice sd(h, stream);
   hipStream_t st = S(stream);
   const size_t BS = (size_t)B * Sn;
@@ -234,11 +234,11 @@ int gmf_pose_head_backward(gmf_handle* h, const gmf_pose_params* p, const float*
   unsigned char* conv = arena_take<unsigned char>(h, BS * iters);
   int* stop_it = arena_take<int>(h, 1);
   // the forward's iterates and convergence flags of every seed (the stop iteration is a property of all seeds of a pair)
-  GMF_HIP(gmf::launch_seed_power(feat_n, src_keypts, tgt_keypts, knn_idx, snaps, conv, nullptr, B, N, Sn, k, iters, p->sigma, p->sigma_d, st));
+  GMF_HIP(gmf::launch_seed_power(feat_n, src_keypts, tgt_keypts, knn_idx, snaps, conv, nullptr, B, N, Sn, k, iters, p->sigma, p->sigma_d, st, nullptr, h->sigma_dev));
   GMF_HIP(hipMemsetAsync(d_feat_n, 0, (size_t)B * N * kC * sizeof(float), st));
   if (B > 1) GMF_HIP(gmf::launch_stop_iteration(conv, B, Sn, iters, stop_it, st));     // the reference's allclose spans the batch
   GMF_HIP(gmf::launch_pose_best_backward(feat_n, src_keypts, tgt_keypts, knn_idx, fitness, snaps, conv, d_final_trans, d_feat_n,
-                                         d_sigma, B, N, Sn, k, iters, p->sigma, p->sigma_d, B > 1 ? stop_it : nullptr, st));
+                                         d_sigma, B, N, Sn, k, iters, p->sigma, p->sigma_d, B > 1 ? stop_it : nullptr, st, h->sigma_dev));
   return GMF_OK;
 }
 

@@ -159,15 +159,17 @@ int sm_fused_parts_per_pair(int B, int N);
 int sm_parts_per_pair(int B, int N);
 int classification_parts(int B, int N);
 int transformation_slices(int B, int N);
+// sigma_dev (everywhere below): non-null = the kernels read sigma from this device address instead (gmf_set_sigma_device)
 hipError_t launch_similarity_matrix(const float* feat_n, float* img, float* M, int B, int N, int ldm, float sigma,
-                                    hipStream_t s);
+                                    hipStream_t s, const float* sigma_dev = nullptr);
 hipError_t launch_sm_loss_fused(const float* feat_n, const float* gt, float* img, double* part, double* pair_loss, int B,
-                                int N, float sigma, int balanced, float* out, hipStream_t s);
+                                int N, float sigma, int balanced, float* out, hipStream_t s, const float* sigma_dev = nullptr);
 hipError_t launch_sm_loss(const float* M, int ldm, const float* gt, double* part, double* pair_loss, int B, int N,
                           int balanced, float* out, hipStream_t s);
 int sm_backward_parts(int B, int N);
 hipError_t launch_sm_backward(const float* feat_n, const float* gt, float* img, float* timg, float* consts, double* dsig_part,
-                              int B, int N, float sigma, int balanced, float* dF, float* dsigma, hipStream_t s);
+                              int B, int N, float sigma, int balanced, float* dF, float* dsigma, hipStream_t s,
+                              const float* sigma_dev = nullptr);
 hipError_t launch_classification_loss(const float* pred, const float* gt, const float* weight, double* part, int B, int N,
                                       int balanced, float* out, hipStream_t s);
 hipError_t launch_transformation_loss(const float* trans, const float* gt_trans, const float* src, const float* tgt,
@@ -205,7 +207,8 @@ hipError_t launch_sm_dense_bwd(const float* M, long ldm, const float* gt, float*
                                hipStream_t s);
 hipError_t launch_normalize(bool backward, const float* a, const float* dy, float* nrm, float* out, long rows, int C, hipStream_t s);
 hipError_t launch_compat_dense(const float* src, const float* tgt, float* out, int B, int N, float sigma_d, hipStream_t s);
-hipError_t launch_sim_bwd_G(const float* S, const float* dM, float* G, float* rowdsig, int B, int N, float sigma, hipStream_t s);
+hipError_t launch_sim_bwd_G(const float* S, const float* dM, float* G, float* rowdsig, int B, int N, float sigma, hipStream_t s,
+                            const float* sigma_dev = nullptr);
 
 // image encoder epilogue (row f-1): image_kernels.hip
 hipError_t launch_stem_h2(const float* x, long sb, long sc, long sh, long sw, const float* wimg, const float* bias, float* y,

@@ -17,7 +17,7 @@ hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* 
 // iteration stopped earlier)
 hipError_t launch_seed_power(const float* feat_n /* row-major [B, N, 128] */, const float* src, const float* tgt, const int* knn_idx, float* snaps,
                              unsigned char* conv, double* hsum, int B, int N, int S, int k, int iters, float sigma,
-                             float sigma_d, hipStream_t s, const PairTab* ptab = nullptr);
+                             float sigma_d, hipStream_t s, const PairTab* ptab = nullptr, const float* sigma_dev = nullptr);
 hipError_t launch_seed_kabsch(const float* src, const float* tgt, const int* knn_idx, const float* snaps,
                               const unsigned char* conv, float* seed_T, int B, int N, int S, int k, int iters,
                               const double* hsum, int* stop_scratch, hipStream_t s, const PairTab* ptab = nullptr);   // stop_scratch: 1 int (batches: the
@@ -44,7 +44,7 @@ hipError_t launch_tl_backward(const float* trans, const float* src, const float*
 hipError_t launch_pose_best_backward(const float* feat_n, const float* src, const float* tgt, const int* knn_idx,
                                      const float* fitness, const float* snaps, const unsigned char* conv, const float* g_T,
                                      float* g_feat, float* g_sigma, int B, int N, int S, int k, int iters, float sigma,
-                                     float sigma_d, const int* stop_batch, hipStream_t s);
+                                     float sigma_d, const int* stop_batch, hipStream_t s, const float* sigma_dev = nullptr);
 hipError_t launch_wp_backward(const float* X, const float* Y, const float* w, const int* offsets, int B, float eps,
                               const float* g_R, const float* g_t, float* g_w, hipStream_t s);
 

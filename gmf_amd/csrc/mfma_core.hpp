@@ -152,6 +152,20 @@ GMF_DEVINL f32x16 mfma_f8s2(i32x8 a, i32x8 b, f32x16 c, int sel, int scale_a, in
   }
 }
 
+// [r5] PointDSC's learnable sigma (PointDSC.py:164) either by value (the host read it) or from a device address
+// (gmf_set_sigma_device: a training step whose optimizer updates sigma on the device, captured in a HIP graph).  The same
+// correctly rounded fp32 operations as the host's 1.0f / (sigma * sigma): both forms give the same bits.
+GMF_DEVINL float sigma_inv2(float inv_by_value, const float* __restrict__ sigma_dev) {
+  if (!sigma_dev) return inv_by_value;
+  const float sg = *sigma_dev;
+  return 1.0f / (sg * sg);
+}
+GMF_DEVINL float sigma_two_inv3(float by_value, const float* __restrict__ sigma_dev) {
+  if (!sigma_dev) return by_value;
+  const float sg = *sigma_dev;
+  return 2.0f / (sg * sg * sg);
+}
+
 GMF_DEVINL void mma3(f32x16& acc, f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl) {
   acc = mfma_h16(al, bh, acc);
   acc = mfma_h16(ah, bl, acc);

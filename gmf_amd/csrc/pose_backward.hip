@@ -111,7 +111,8 @@ k_pose_best_backward(const float* __restrict__ feat_n, const float* __restrict__
                      const int* __restrict__ knn_idx, const float* __restrict__ fitness, const float* __restrict__ snaps,
                      const unsigned char* __restrict__ conv, const float* __restrict__ g_T, float* __restrict__ g_feat,
                      float* __restrict__ g_sigma, int N, int S, int k, int iters, float sigma, float inv_sigmad2,
-                     const int* __restrict__ stop_batch) {
+                     const int* __restrict__ stop_batch, const float* __restrict__ sigma_dev) {
+  if (sigma_dev) sigma = *sigma_dev;                 // [r5] gmf_set_sigma_device
   extern __shared__ float dyn[];
   float* const F = dyn;                              // [64][129]
   float* const Cx = F + kKMax * (kCF + 1);           // [64][65]
@@ -390,13 +391,13 @@ hipError_t launch_tl_backward(const float* trans, const float* src, const float*
 hipError_t launch_pose_best_backward(const float* feat_n, const float* src, const float* tgt, const int* knn_idx,
                                      const float* fitness, const float* snaps, const unsigned char* conv, const float* g_T,
                                      float* g_feat, float* g_sigma, int B, int N, int S, int k, int iters, float sigma,
-                                     float sigma_d, const int* stop_batch, hipStream_t s) {
+                                     float sigma_d, const int* stop_batch, hipStream_t s, const float* sigma_dev) {
   const size_t lds = ((size_t)kKMax * (kCF + 1) + (size_t)kKMax * (kKMax + 1) + (size_t)(iters + 1) * kKMax + kKMax) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_best_backward),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_pose_best_backward, dim3(B), dim3(64), lds, s, feat_n, src, tgt, knn_idx, fitness, snaps, conv, g_T,
-                     g_feat, g_sigma, N, S, k, iters, sigma, 1.0f / (sigma_d * sigma_d), stop_batch);
+                     g_feat, g_sigma, N, S, k, iters, sigma, 1.0f / (sigma_d * sigma_d), stop_batch, sigma_dev);
   return hipGetLastError();
 }
 

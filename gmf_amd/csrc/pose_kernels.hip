@@ -812,7 +812,8 @@ __global__ void __launch_bounds__(64, 3)     // [r4] <= 168 registers: three wav
 k_seed_power(const float* __restrict__ feat_n, const float* __restrict__ src, const float* __restrict__ tgt,
              const int* __restrict__ knn_idx, float* __restrict__ snaps, unsigned char* __restrict__ conv,
              double* __restrict__ hsum, int N, int S, int k, int iters, float inv_sigma2, float inv_sigmad2,
-             const PairTab* __restrict__ ptab) {
+             const PairTab* __restrict__ ptab, const float* __restrict__ sigma_dev) {
+  inv_sigma2 = sigma_inv2(inv_sigma2, sigma_dev);
   // LDS sized by k (dynamic): the k x k matrix with row stride k + 1 - at k = 40 9 KiB per seed instead of 19, i.e. 17 instead
   // of 8 resident seeds per CU for a kernel that is one latency chain per seed
   extern __shared__ __attribute__((aligned(16))) float seed_smem[];
@@ -1762,11 +1763,11 @@ hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* 
 
 hipError_t launch_seed_power(const float* feat_n, const float* src, const float* tgt, const int* knn_idx, float* snaps,
                              unsigned char* conv, double* hsum, int B, int N, int S, int k, int iters, float sigma,
-                             float sigma_d, hipStream_t s, const PairTab* ptab) {
+                             float sigma_d, hipStream_t s, const PairTab* ptab, const float* sigma_dev) {
   if (k > kKMax) return hipErrorInvalidValue;
   const size_t lds_bytes = (size_t)(kKMax * 8 + kKMax + k * (k + 1)) * sizeof(float);
   hipLaunchKernelGGL(k_seed_power, dim3(S, B), dim3(64), lds_bytes, s, feat_n, src, tgt, knn_idx, snaps, conv, hsum, N, S, k,
-                     iters, 1.0f / (sigma * sigma), 1.0f / (sigma_d * sigma_d), ptab);
+                     iters, 1.0f / (sigma * sigma), 1.0f / (sigma_d * sigma_d), ptab, sigma_dev);
   return hipGetLastError();
 }
 

@@ -750,7 +750,9 @@ k_sm_dense_bwd(const float* __restrict__ M, long ldm, const float* __restrict__ 
 
 __global__ void __launch_bounds__(256)
 k_sim_bwd_G(const float* __restrict__ S, const float* __restrict__ dM, float* __restrict__ G, float* __restrict__ rowdsig, int N,
-            float inv_sig2, float two_inv_sig3, long rows) {
+            float inv_sig2, float two_inv_sig3, long rows, const float* __restrict__ sigma_dev) {
+  inv_sig2 = sigma_inv2(inv_sig2, sigma_dev);
+  two_inv_sig3 = sigma_two_inv3(two_inv_sig3, sigma_dev);
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -979,10 +981,11 @@ hipError_t launch_sm_dense_bwd(const float* M, long ldm, const float* gt, float*
   return hipGetLastError();
 }
 
-hipError_t launch_sim_bwd_G(const float* S, const float* dM, float* G, float* rowdsig, int B, int N, float sigma, hipStream_t s) {
+hipError_t launch_sim_bwd_G(const float* S, const float* dM, float* G, float* rowdsig, int B, int N, float sigma, hipStream_t s,
+                            const float* sigma_dev) {
   const long rows = (long)B * N;
   hipLaunchKernelGGL(k_sim_bwd_G, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, dM, G, rowdsig, N, 1.0f / (sigma * sigma),
-                     2.0f / (sigma * sigma * sigma), rows);
+                     2.0f / (sigma * sigma * sigma), rows, sigma_dev);
   return hipGetLastError();
 }
 

@@ -81,7 +81,8 @@ constexpr int kSimRing = 3;    // LDS slots of 16 KiB: three workgroups (15 wave
 template <bool LOSS>
 __global__ void __launch_bounds__(320, 4)
 k_similarity(const float* __restrict__ img, float* __restrict__ M, const float* __restrict__ gt, double* __restrict__ part,
-             int N, int ldm, int tiles, int chunk, float inv_s2) {
+             int N, int ldm, int tiles, int chunk, float inv_s2, const float* __restrict__ sigma_dev) {
+  inv_s2 = sigma_inv2(inv_s2, sigma_dev);
   constexpr int NB = kSimRing;
   __shared__ __attribute__((aligned(16))) float lds[NB * kTileFloats];
   __shared__ unsigned colmask[64];
@@ -480,7 +481,9 @@ __global__ void k_pack_rows_t_h2(const float* __restrict__ feat, float* __restri
 
 // per pair: cP, cN (see above), and the power-of-two scale of G; consts[b] = {cP, cN, scale, 1 / scale}
 __global__ void __launch_bounds__(256)
-k_sm_bwd_prep(const float* __restrict__ gt, float* __restrict__ consts, int B, int N, int balanced, float inv_sig2) {
+k_sm_bwd_prep(const float* __restrict__ gt, float* __restrict__ consts, int B, int N, int balanced, float inv_sig2,
+              const float* __restrict__ sigma_dev) {
+  inv_sig2 = sigma_inv2(inv_sig2, sigma_dev);
   __shared__ double red[4];
   const int b = blockIdx.x;
   double n1 = 0.0;
@@ -504,7 +507,9 @@ k_sm_bwd_prep(const float* __restrict__ gt, float* __restrict__ consts, int B, i
 __global__ void __launch_bounds__(256, 2)
 k_sm_backward(const float* __restrict__ img, const float* __restrict__ timg, const float* __restrict__ gt,
               const float* __restrict__ consts, float* __restrict__ dF, double* __restrict__ dsig_part, int N, int tiles,
-              float inv_sig2, float two_inv_sig3) {
+              float inv_sig2, float two_inv_sig3, const float* __restrict__ sigma_dev) {
+  inv_sig2 = sigma_inv2(inv_sig2, sigma_dev);
+  two_inv_sig3 = sigma_two_inv3(two_inv_sig3, sigma_dev);
   __shared__ __attribute__((aligned(16))) float lds[4 * kTileFloats];      // K ring [2] | V ring [2]
   __shared__ double red[4];
   float* const ldsK = lds;
@@ -626,7 +631,7 @@ int sm_fused_parts_per_pair(int B, int N) {
 }
 
 hipError_t launch_similarity_matrix(const float* feat_n, float* img, float* M, int B, int N, int ldm, float sigma,
-                                    hipStream_t s) {
+                                    hipStream_t s, const float* sigma_dev) {
   const int tiles = (N + 31) / 32;
   const long total = (long)B * tiles * 512;
   hipLaunchKernelGGL(k_pack_rows_h2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat_n, img, N, tiles, total);
@@ -634,19 +639,19 @@ hipError_t launch_similarity_matrix(const float* feat_n, float* img, float* M, i
   similarity_grid(B, tiles, grid, chunk);
   const float s2 = sigma * sigma;
   hipLaunchKernelGGL(k_similarity<false>, grid, dim3(320), 0, s, img, M, (const float*)nullptr, (double*)nullptr, N, ldm,
-                     tiles, chunk, 1.0f / s2);
+                     tiles, chunk, 1.0f / s2, sigma_dev);
   return hipGetLastError();
 }
 
 hipError_t launch_sm_loss_fused(const float* feat_n, const float* gt, float* img, double* part, double* pair_loss, int B,
-                                int N, float sigma, int balanced, float* out, hipStream_t s) {
+                                int N, float sigma, int balanced, float* out, hipStream_t s, const float* sigma_dev) {
   const int tiles = (N + 31) / 32;
   const long total = (long)B * tiles * 512;
   hipLaunchKernelGGL(k_pack_rows_h2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat_n, img, N, tiles, total);
   dim3 grid; int chunk;
   similarity_grid(B, tiles, grid, chunk);
   const float s2 = sigma * sigma;
-  hipLaunchKernelGGL(k_similarity<true>, grid, dim3(320), 0, s, img, (float*)nullptr, gt, part, N, N, tiles, chunk, 1.0f / s2);
+  hipLaunchKernelGGL(k_similarity<true>, grid, dim3(320), 0, s, img, (float*)nullptr, gt, part, N, N, tiles, chunk, 1.0f / s2, sigma_dev);
   hipLaunchKernelGGL(k_sm_pair, dim3(B), dim3(256), 0, s, part, gt, N, (int)(grid.x * grid.y), balanced, pair_loss);
   hipLaunchKernelGGL(k_mean_pairs, dim3(1), dim3(256), 0, s, pair_loss, B, balanced ? (double)B : (double)B * N * N, out);
   return hipGetLastError();
@@ -688,16 +693,16 @@ hipError_t launch_transformation_loss(const float* trans, const float* gt_trans,
 int sm_backward_parts(int B, int N) { return B * ((((N + 31) / 32) + 3) / 4); }
 
 hipError_t launch_sm_backward(const float* feat_n, const float* gt, float* img, float* timg, float* consts, double* dsig_part,
-                              int B, int N, float sigma, int balanced, float* dF, float* dsigma, hipStream_t s) {
+                              int B, int N, float sigma, int balanced, float* dF, float* dsigma, hipStream_t s, const float* sigma_dev) {
   const int tiles = (N + 31) / 32;
   const long total = (long)B * tiles * 512;
   const float inv_sig2 = 1.0f / (sigma * sigma);
   hipLaunchKernelGGL(k_pack_rows_h2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat_n, img, N, tiles, total);
   hipLaunchKernelGGL(k_pack_rows_t_h2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat_n, timg, N, tiles, total);
-  hipLaunchKernelGGL(k_sm_bwd_prep, dim3(B), dim3(256), 0, s, gt, consts, B, N, balanced, inv_sig2);
+  hipLaunchKernelGGL(k_sm_bwd_prep, dim3(B), dim3(256), 0, s, gt, consts, B, N, balanced, inv_sig2, sigma_dev);
   const dim3 grid((tiles + 3) / 4, B);
   hipLaunchKernelGGL(k_sm_backward, grid, dim3(256), 0, s, img, timg, gt, consts, dF, dsig_part, N, tiles, inv_sig2,
-                     2.0f / (sigma * sigma * sigma));
+                     2.0f / (sigma * sigma * sigma), sigma_dev);
   hipLaunchKernelGGL(k_sm_bwd_dsigma, dim3(1), dim3(64), 0, s, dsig_part, (int)(grid.x * grid.y), dsigma);
   return hipGetLastError();
 }

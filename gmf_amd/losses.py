@@ -41,9 +41,12 @@ class ClassificationLoss(nn.Module):
     """libs/loss.py:67-113.  forward(pred [bs,N] logits, gt [bs,N] 0/1, weight=None) -> dict with 'loss' (0-dim device
     tensor) and the floats 'precision', 'recall', 'f1' (pair 0 only, as the reference), 'logit_true', 'logit_false'."""
 
-    def __init__(self, balanced=True):
+    def __init__(self, balanced=True, host_stats=True):
         super().__init__()
         self.balanced = balanced
+        # [r5] host_stats = False: no device-to-host read - the dict carries 'loss' and 'stats' (a device tensor: loss, precision,
+        # recall, f1, logit_true, logit_false), which is what a graph-captured training step needs (GraphedTrainingStep)
+        self.host_stats = host_stats
 
     def forward(self, pred, gt, weight=None):
         _no_grad(weight)
@@ -57,6 +60,8 @@ class ClassificationLoss(nn.Module):
         if pred.requires_grad and torch.is_grad_enabled():      # training: the loss carries d loss / d logits (libs/trainer.py:134)
             from .train import classification_loss_train
             loss, out = classification_loss_train(pred, gt, w, self.balanced)
+            if not self.host_stats:
+                return {"loss": loss, "stats": out}
             host = out.cpu()
             return {"loss": loss, "precision": float(host[1]), "recall": float(host[2]), "f1": float(host[3]),
                     "logit_true": float(host[4]), "logit_false": float(host[5])}

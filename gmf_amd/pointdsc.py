@@ -564,7 +564,14 @@ class PointDSC(nn.Module):
             p_tok = enc(data["p_image"]).flatten(2).permute(0, 2, 1).contiguous()
             q_tok = enc(data["q_image"]).flatten(2).permute(0, 2, 1).contiguous()
         B, N, _ = corr_pos.shape
-        sigma, sigma_d = float(self.sigma.detach()), float(self.sigma_spat)      # the step's one host read of the two scalars
+        if getattr(self, "sigma_on_device", False):
+            # [r5] no host read in the step (a captured HIP graph must not have one): sigma stays on the device for every kernel
+            # that uses it; sigma_spat is not trained (PointDSC.py:165: requires_grad = False) and is read once
+            if getattr(self, "_sigma_d_host", None) is None:
+                self._sigma_d_host = float(self.sigma_spat)
+            sigma, sigma_d = T.SIGMA_ON_DEVICE, self._sigma_d_host
+        else:
+            sigma, sigma_d = float(self.sigma.detach()), float(self.sigma_spat)      # the step's one host read of the two scalars
         compat = T.compat_dense(src, tgt, sigma_d)              # PointDSC.py:216-221 (under no_grad in the reference too)
         feat = T.encoder_train(self.encoder, corr_pos, compat, p_tok, q_tok)           # [B, N, C]
         feat_n = T.normalize_rows(feat.reshape(B * N, -1)).reshape(B, N, -1)           # PointDSC.py:229

@@ -19,6 +19,27 @@ def _p(t, off=0):
     return t.data_ptr() + 4 * off
 
 
+SIGMA_ON_DEVICE = object()       # [r5] marker in place of sigma's host value: the kernels read the parameter's device memory
+
+
+class sigma_device:
+    """`with sigma_device(handle, sigma_tensor):` - the C calls inside read PointDSC's learnable sigma (PointDSC.py:164) from the
+    tensor's device memory (gmf_set_sigma_device) instead of a by-value float; None = the by-value form.  Host-side state only:
+    inside a graph capture the calls between enter and exit are what gets captured."""
+
+    def __init__(self, h, sigma):
+        self.h, self.sigma = h, sigma
+
+    def __enter__(self):
+        if self.sigma is not None:
+            self.h.call("gmf_set_sigma_device", self.sigma.data_ptr())
+
+    def __exit__(self, *exc):
+        if self.sigma is not None:
+            self.h.call("gmf_set_sigma_device", None)
+        return False
+
+
 def gemm(a, b, ta=False, tb=False, bias=None, residual=None, alpha=1.0, out=None, m=None, n=None, k=None, lda=None, ldb=None,
          ldc=None, a_off=0, b_off=0, c_off=0, batch=1, sa=0, sb=0, sc=0, relu=False):
     """out = alpha * op(a) op(b) (+ bias) (+ residual) through gmf_gemm_f32.  With the keyword geometry left out, `a` and `b`
@@ -430,11 +451,13 @@ class _SimilarityMatrix(torch.autograd.Function):
     def forward(ctx, feat_n, sigma, sigma_value):
         f = feat_n.contiguous()
         B, N, _ = f.shape
-        sig = float(sigma) if sigma_value is None else float(sigma_value)     # (a caller that already read the scalar passes it)
+        on_dev = sigma_value is SIGMA_ON_DEVICE          # [r5] no host read: the kernels take sigma from the parameter's own memory
+        sig = 1.0 if on_dev else (float(sigma) if sigma_value is None else float(sigma_value))     # (a caller that already read the scalar passes it)
         M = torch.empty((B, N, N), device=f.device, dtype=torch.float32)
         h, st = handle_and_stream(f)
-        h.call("gmf_similarity_matrix", f.data_ptr(), B, N, sig, M.data_ptr(), N, st)
-        ctx.sig, ctx.sigma_is_tensor = sig, torch.is_tensor(sigma)
+        with sigma_device(h, sigma if on_dev else None):
+            h.call("gmf_similarity_matrix", f.data_ptr(), B, N, sig, M.data_ptr(), N, st)
+        ctx.sig, ctx.sigma_is_tensor, ctx.sigma_dev = sig, torch.is_tensor(sigma), (sigma if on_dev else None)
         ctx.save_for_backward(f)
         return M
 
@@ -446,7 +469,8 @@ class _SimilarityMatrix(torch.autograd.Function):
         dF = torch.empty_like(f)
         dsig = torch.empty(1, device=f.device, dtype=torch.float32)
         h, st = handle_and_stream(f)
-        h.call("gmf_similarity_backward", f.data_ptr(), dM.data_ptr(), B, N, ctx.sig, dF.data_ptr(), dsig.data_ptr(), st)
+        with sigma_device(h, ctx.sigma_dev):
+            h.call("gmf_similarity_backward", f.data_ptr(), dM.data_ptr(), B, N, ctx.sig, dF.data_ptr(), dsig.data_ptr(), st)
         return dF, dsig if ctx.sigma_is_tensor else None, None
 
 
@@ -533,8 +557,13 @@ class _PoseHeadTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat_n, sigma, model, src, tgt, logits, sigmas):
         f = feat_n.contiguous()
-        final_T, _, aux = model.pose_head(f, src, tgt, logits, False, return_aux=True, sigmas=sigmas)
-        ctx.model, ctx.sigmas, ctx.sigma_is_tensor = model, sigmas, torch.is_tensor(sigma)
+        on_dev = sigmas is not None and sigmas[0] is SIGMA_ON_DEVICE
+        if on_dev:
+            sigmas = (1.0, sigmas[1])                    # (placeholder: the kernels read sigma from the parameter's memory)
+        h, _ = handle_and_stream(f)
+        with sigma_device(h, sigma if on_dev else None):
+            final_T, _, aux = model.pose_head(f, src, tgt, logits, False, return_aux=True, sigmas=sigmas)
+        ctx.model, ctx.sigmas, ctx.sigma_is_tensor, ctx.sigma_dev = model, sigmas, torch.is_tensor(sigma), (sigma if on_dev else None)
         ctx.save_for_backward(f, src, tgt, aux["knn_idx"], aux["fitness"])
         return final_T
 
@@ -547,10 +576,57 @@ class _PoseHeadTrain(torch.autograd.Function):
         dF = torch.empty_like(f)
         dsig = torch.empty(B, device=f.device, dtype=torch.float32)
         h, st = handle_and_stream(f)
-        h.call("gmf_pose_head_backward", pp, f.data_ptr(), src.data_ptr(), tgt.data_ptr(), knn_idx.data_ptr(), fitness.data_ptr(),
-               dT.data_ptr(), B, N, dF.data_ptr(), dsig.data_ptr(), st)
+        with sigma_device(h, ctx.sigma_dev):
+            h.call("gmf_pose_head_backward", pp, f.data_ptr(), src.data_ptr(), tgt.data_ptr(), knn_idx.data_ptr(), fitness.data_ptr(),
+                   dT.data_ptr(), B, N, dF.data_ptr(), dsig.data_ptr(), st)
         return dF, (dsig.sum().reshape(1) if ctx.sigma_is_tensor else None), None, None, None, None, None
 
 
 def pose_head_train(model, feat_n, sigma, src, tgt, logits, sigmas):
     return _PoseHeadTrain.apply(feat_n, sigma, model, src, tgt, logits, sigmas)
+
+
+class GraphedTrainingStep:
+    """One training step of `model` (a gmf_amd.PointDSC in train() mode) - forward, loss, backward, optimizer step - captured ONCE as a
+    HIP graph and replayed (libs/trainer.py:131-166 is the loop this stands in for).  An eager step is ~1 900 kernel launches from
+    ~320 C calls and costs the host more time than the device needs for them (25 ms at 16 x 1000 whatever the
+    size); the replay is one launch.
+
+    What makes the step capturable: `model.sigma_on_device = True` (the learnable sigma is read by the kernels from the parameter's
+    own memory, gmf_set_sigma_device - the eager step reads it to the host once per step), a `loss_fn(result, batch) -> 0-dim device
+    tensor` that makes no host read (`ClassificationLoss(host_stats=False)`), and an optimizer whose step is capturable
+    (`torch.optim.Adam(..., capturable=True)`).  `warmup` eager steps run first, on a side stream: they size the library's workspace
+    and the allocator's pools, and they are real optimizer steps.  Shapes are fixed by the example batch; `__call__(batch)` copies
+    the tensors of `batch` into the captured inputs and replays."""
+
+    def __init__(self, model, optimizer, loss_fn, batch, warmup: int = 3):
+        self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
+        model.sigma_on_device = True
+        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+        def step():
+            optimizer.zero_grad(set_to_none=True)
+            loss = loss_fn(model(self.static), self.static)
+            loss.backward()
+            optimizer.step()
+            return loss
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = step()
+
+    def __call__(self, batch=None):
+        if batch is not None:
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    self.static[k].copy_(v)
+        self.graph.replay()
+        return self.loss
+

@@ -78,6 +78,15 @@ long long gmf_workspace_wanted(gmf_handle* h);
 #define GMF_STATUS_PV_GUARDED 2
 int gmf_status_read(gmf_handle* h, int* flags, int clear);
 
+/* [ABI 5] PointDSC's learnable scalar `sigma` (PointDSC.py:164) from DEVICE memory.  While `sigma_dev` is non-NULL every entry point
+ * that takes sigma by value - gmf_similarity_matrix, gmf_similarity_backward, gmf_spectral_matching_loss_fused / _backward and, through
+ * gmf_pose_params::sigma, gmf_pose_head(_ragged) / gmf_pose_head_backward - ignores that value and its kernels read the float at this
+ * address when they run (the same correctly rounded 1 / sigma^2 as the host forms: identical bits).  What it is for: a training step
+ * whose optimizer updates sigma on the device can be captured in a HIP graph and replayed without the one host read per step the
+ * by-value form needs (libs/trainer.py:131-166; gmf_amd.train.GraphedTrainingStep).  NULL (default) restores the by-value form.  The
+ * address must stay valid while set. */
+int gmf_set_sigma_device(gmf_handle* h, const float* sigma_dev);
+
 /* Per-handle tuning knobs (state lives in the handle; no process globals, no environment variables).  Every setting
  * except "precision" computes the same result up to rounding - there is no timing-only or wrong-result mode in the
  * library; unknown names and out-of-range values are rejected with GMF_ERR_BAD_ARG.

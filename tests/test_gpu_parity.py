@@ -1029,6 +1029,60 @@ def test_f8_weighted_procrustes(golden_dir, N):
     assert _maxerr(t.cpu(), g[f"t_{N}"]) < 1e-4
 
 
+def test_graph_captured_training_step_equals_eager_steps(sd_full):
+    """the reference's default training step (libs/trainer.py:131-166: train-mode forward, ClassificationLoss +
+    SpectralMatchingLoss, backward, Adam) captured ONCE as a HIP graph (`gmf_amd.train.GraphedTrainingStep`) and replayed.  What made
+    it capturable: sigma read by the kernels from the parameter's own device memory (`gmf_set_sigma_device`, ABI 5: the eager step
+    reads it to the host once per step), loss statistics left on the device, a capturable Adam.  Two copies of the same model, same
+    data: one takes 3 + 4 eager steps, the other 3 warm-up steps and 4 replays - the same parameters afterwards, bit for bit
+    (every kernel is deterministic and both run the same optimizer code), and the per-step losses agree."""
+    from gmf_amd import train as T
+    B, N = 4, 500
+    b = synthetic.synthetic_batch(list(range(600, 600 + B)), N=N, T=40)
+    data = {k: _gpu(b[k]) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["gt"] = _gpu(b["gt_labels"])
+    cl_fn, sm_fn = gmf_amd.ClassificationLoss(balanced=False, host_stats=False), gmf_amd.SpectralMatchingLoss(balanced=False)
+
+    def loss_fn(res, batch):
+        return cl_fn(res["final_labels"], batch["gt"])["loss"] + sm_fn(res["M"], batch["gt"])
+
+    def make():
+        m = gmf_amd.PointDSC(num_layers=3)
+        m.load_state_dict({k: v for k, v in synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 3, 128), seed=7).items()}, strict=False)
+        m = m.to(DEV).train()
+        return m, torch.optim.Adam([p for n, p in m.named_parameters() if not n.startswith("encoder.image_encoder.")], lr=1e-3, capturable=True)
+    m_e, opt_e = make()
+    m_e.sigma_on_device = True
+    eager_losses = []
+    for _ in range(7):
+        opt_e.zero_grad(set_to_none=True)
+        loss = loss_fn(m_e(data), data)
+        loss.backward()
+        opt_e.step()
+        eager_losses.append(float(loss.detach()))
+    m_g, opt_g = make()
+    step = T.GraphedTrainingStep(m_g, opt_g, loss_fn, data, warmup=3)
+    graph_losses = [float(step(data).detach()) for _ in range(4)]
+    torch.cuda.synchronize()
+    print("eager losses", [f"{x:.6f}" for x in eager_losses[3:]], "graph losses", [f"{x:.6f}" for x in graph_losses])
+    assert graph_losses == eager_losses[3:]
+    assert float(m_e.sigma.detach()) != 1.0                      # sigma is being trained ...
+    for (n1, p1), (n2, p2) in zip(m_e.named_parameters(), m_g.named_parameters()):
+        if not n1.startswith("encoder.image_encoder."):          # (not part of the token-fed step; randomly initialised per copy)
+            assert n1 == n2 and torch.equal(p1, p2), n1          # ... and every parameter, sigma included, took the same seven steps
+    for (n1, b1), (n2, b2) in zip(m_e.named_buffers(), m_g.named_buffers()):
+        if "num_batches_tracked" not in n1 and not n1.startswith("encoder.image_encoder."):
+            assert torch.equal(b1, b2), n1                       # BatchNorm running statistics
+    # the by-value form (sigma read to the host every step) computes the same step
+    m_v, opt_v = make()
+    for _ in range(2):
+        opt_v.zero_grad(set_to_none=True)
+        lv = loss_fn(m_v(data), data)
+        lv.backward()
+        opt_v.step()
+    assert float(lv.detach()) == eager_losses[1]
+
+
 def test_dgr_argmin_se3_and_transformation():
     """The two remaining helper names of the DGR registration module (core/registration.py:67-88, 116-132; VERDICT r4 missing 6):
     `argmin_se3_squared_dist` (unweighted Kabsch: weighted_procrustes with unit weights, eps 0) against the oracle's solve and

@@ -28,6 +28,18 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 print(f"training step B={B} N={N} T=300, 12 layers: {dt * 1e3:.1f} ms  (loss {l:.4f}; peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB + workspace)")
+# [r5] the same step captured as a HIP graph (gmf_amd.train.GraphedTrainingStep): sigma on the device, loss statistics on the device, capturable Adam
+from gmf_amd import train as T
+m2 = gmf_amd.PointDSC(num_layers=12); m2.load_state_dict(sd, strict=False); m2 = m2.to(dev).train()
+cl2 = gmf_amd.ClassificationLoss(balanced=False, host_stats=False)
+opt2 = torch.optim.Adam([p for n, p in m2.named_parameters() if not n.startswith("encoder.image_encoder.")], lr=1e-4, weight_decay=1e-6, capturable=True)
+data2 = dict(data, gt=gt)
+gstep = T.GraphedTrainingStep(m2, opt2, lambda res, bt: cl2(res["final_labels"], bt["gt"])["loss"] + sm_fn(res["M"], bt["gt"]), data2, warmup=3)
+for _ in range(2): gstep(data2)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): lg = gstep(data2)
+torch.cuda.synchronize()
+print(f"the same step as ONE captured HIP graph: {(time.perf_counter() - t0) / 10 * 1e3:.1f} ms  (loss {float(lg.detach()):.4f})")
 def fwd():
     with torch.no_grad():
         m.eval(); m(data); m.train()

@@ -145,7 +145,7 @@ GMF_DEVINL void q_planes8(const f16x8& h0, const f16x8& l0, const f16x8& h1, con
 GMF_DEVINL bool pv_planes_on(const unsigned* __restrict__ v_scale, const PvGuard& g, int pair) {
   if (!v_scale) return false;
   if (!g.stat) return true;
-  return __uint_as_float(g.stat[pair]) <= *g.thr2;
+  return __uint_as_float(g.stat[(size_t)pair * kPvStatStride]) <= *g.thr2;
 }
 // Raises stat[pair] to the largest |f|^2 of this wave's 32 rows (rows on lanes; ssq_half = this lane's 64 features of its row, the
 // other 64 live in lane ^ 32).  Sums of squares are >= 0, so the float bits order like unsigned integers.
@@ -154,7 +154,14 @@ GMF_DEVINL void pv_stat_raise(unsigned* __restrict__ stat, int pair, float ssq_h
   s = row_valid ? s : 0.f;
 #pragma unroll
   for (int m = 16; m >= 1; m >>= 1) s = fmaxf(s, __shfl_xor(s, m, 64));
-  if (lane == 0) atomicMax(stat + pair, __float_as_uint(s));
+  // A wave looks first - a relaxed device-scope load - and only sends the atomic when its value would raise the word (a stale read
+  // costs a redundant atomic, never a wrong maximum; ~ln(waves) atomics per pair get through); every pair has a cache line of its own
+  // (kPvStatStride).
+  if (lane == 0) {
+    unsigned* const w = stat + (size_t)pair * kPvStatStride;
+    const unsigned v = __float_as_uint(s);
+    if (v > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, v);
+  }
 }
 
 // LCPE (fusion_layer.py:118-128): y[row] = x[row] + b + w0*x[row-1] + w1*x[row] + w2*x[row+1],

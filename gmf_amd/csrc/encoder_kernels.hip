@@ -2122,7 +2122,7 @@ k_head(const float* __restrict__ feat_img, const float* __restrict__ wst, const 
   // [r5] informational: a layer of this pair ran the three-product form of P V under the "pv_fp8" guard (GMF_STATUS_PV_GUARDED)
   if (pv_stat && status && blockIdx.x == 0 && threadIdx.x == 0) {
     bool tripped = false;
-    for (int l = 0; l < n_layers; ++l) tripped |= !(__uint_as_float(pv_stat[(size_t)l * gridDim.y + pair]) <= pv_thr2[l]);
+    for (int l = 0; l < n_layers; ++l) tripped |= !(__uint_as_float(pv_stat[((size_t)l * gridDim.y + pair) * kPvStatStride]) <= pv_thr2[l]);
     if (tripped) __hip_atomic_fetch_or(status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const size_t row0 = pair_row0(ptab, pair, N);            // ragged batch: the outputs are packed [sum n, ...]

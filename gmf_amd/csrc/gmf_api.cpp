@@ -534,7 +534,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
   const size_t need = 8 * arena_need(act, 4) + arena_need((size_t)B * tiles * 32 * 8, 4) +
                       5 * arena_need(tok, 4) + arena_need((size_t)(L > 0 ? L : 1) * tok, 4) + cache_need + split_need +
                       arena_need((size_t)B, sizeof(gmf::PairTab)) + arena_need((size_t)B * tiles * 128, 4) +
-                      arena_need((size_t)(L + 1) * B, 4);
+                      arena_need((size_t)(L + 1) * B * gmf::kPvStatStride, 4);
   if (int rc = arena_reserve(h, need)) return rc;
   const gmf::PairTab* ptab = nullptr;
   if (ragged) {
@@ -558,7 +558,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
   float* imgfeat = arena_take<float>(h, tok);
   float* ctxall = arena_take<float>(h, (size_t)(L > 0 ? L : 1) * tok);
   unsigned* v_scale = arena_take<unsigned>(h, (size_t)B * tiles * 128);    // scale words of the V and K images' e4m3 planes ("pv_fp8"): per tile [V: 64 | K: 64]
-  unsigned* fstat = arena_take<unsigned>(h, (size_t)(L + 1) * B);          // "pv_fp8" guard: [layer][pair] max row |f_l|^2 (float bits)
+  unsigned* fstat = arena_take<unsigned>(h, (size_t)(L + 1) * B * gmf::kPvStatStride);   // "pv_fp8" guard: [layer][pair] max row |f_l|^2 (float bits), one 128-byte line per pair
   gmf::CompatCache cc{nullptr, nullptr, nullptr, nullptr, 0};
   float* c_dense = nullptr;
   if (want_cache) {
@@ -596,7 +596,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
   }
   // (the same launch clears the "pv_fp8" guard's statistics - a superset of the forwards that read them)
   const bool may_guard = fuse && h->tune.pv_fp8 == 1 && w->pv_guard;
-  GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st, ptab, may_guard ? fstat : nullptr, may_guard ? (L + 1) * B : 0));
+  GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st, ptab, may_guard ? fstat : nullptr, may_guard ? (L + 1) * B * gmf::kPvStatStride : 0));
   // throughput numerics ("precision" = 1, 2): on the two-launch path of large grids the attention multiplies one fp16
   // product and streams the compat matrix as fp16 (level 2: the layer's linear stages multiply one product as well); every
   // other path keeps the parity numerics
@@ -635,7 +635,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
     }
     for (int l = 0; l < L; ++l) {
       cc.guard = gmf::PvGuard{};
-      if (guarded) cc.guard = gmf::PvGuard{fstat + (size_t)l * B, w->pv_guard + l, fstat + (size_t)(l + 1) * B};
+      if (guarded) cc.guard = gmf::PvGuard{fstat + (size_t)l * B * gmf::kPvStatStride, w->pv_guard + l, fstat + (size_t)(l + 1) * B * gmf::kPvStatStride};
       const float* fw = w->front_wst_h2 + (size_t)l * w->front_wst_stride;
       const float* fv = w->front_vec + (size_t)l * w->front_vec_stride;
       const float* aw = w->attn_wst_h2 + (size_t)l * w->attn_wst_stride;

@@ -16,8 +16,11 @@ struct PairTab { int row0, n, S, k; };
 // left behind - the largest squared row norm of the layer's input f - against the layer's threshold (gmf_encoder_weights::
 // pv_guard).  Every kernel that writes a V image or multiplies one evaluates the same comparison on the same two words, so the
 // writer and the reader of a pair's V tiles always agree on their format.
+constexpr int kPvStatStride = 32;    // words between two pairs' statistics: one 128-byte line each.  (Packed into one line, the 5 000 device-scope
+                                    // atomics of k_front_h2<3> - every wave of every pair within microseconds - serialised at the memory side:
+                                    // 30 -> 64 us for that kernel; a line per pair lets the pairs' updates proceed in parallel.)
 struct PvGuard {
-  const unsigned* stat = nullptr;   // [B] float bits of max row |f_l|^2 per pair, complete before the layer's first launch; null: unguarded
+  const unsigned* stat = nullptr;   // [B][kPvStatStride] float bits of max row |f_l|^2 per pair (word 0 of its line), complete before the layer's first launch; null: unguarded
   const float* thr2 = nullptr;      // the layer's threshold: fp8 cross products while stat <= *thr2
   unsigned* stat_next = nullptr;    // [B] the NEXT layer's statistic: raised (atomic maximum) by whoever produces f_{l+1}; null: nobody asks
 };

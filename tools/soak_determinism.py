@@ -34,6 +34,28 @@ for B, N, mode, n in ((32, 5000, "parity", reps // 4), (32, 5000, "throughput", 
     bad += diff
     print(f"B={B} N={N} {mode}: {max(n, 2)} repeats, {diff} differ", flush=True)
 model.set_precision("parity")
+# [r5] the guarded path with layers on BOTH sides of the guard (the seeded KITTI-shape network trips its first five layers), and the
+# forward from raw images (native small-grid convolutions, per-tile cross-attention role)
+km = gmf_amd.PointDSC(in_dim=6, num_layers=12, num_channels=128, num_iterations=10, ratio=0.1, inlier_threshold=1.2, sigma_d=1.2, k=40, nms_radius=1.2)
+km.load_state_dict(synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 12, 128), seed=7, sigma_d=1.2), strict=False)
+km = km.to(dev).eval()
+for B, N, n in ((9, 3970, reps // 4), (1, 2000, reps)):
+    b = synthetic.synthetic_batch(list(range(80, 80 + B)), N=N, T=196, kind="kitti")
+    data = {k: b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
+    data["testing"] = True
+    ref = km(data)
+    lg0, T0 = km.last_logits.clone(), ref["final_trans"].clone()
+    diff = sum(0 if (torch.equal(km(data)["final_trans"], T0) and torch.equal(km.last_logits, lg0)) else 1 for _ in range(max(n, 2)))
+    bad += diff
+    print(f"KITTI stress weights (guard tripped) B={B} N={N}: {max(n, 2)} repeats, {diff} differ", flush=True)
+b = synthetic.synthetic_batch([5], N=1000, T=300)
+data = {k: b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+data.update(p_image=torch.rand(1, 3, 120, 160, device=dev), q_image=torch.rand(1, 3, 120, 160, device=dev), testing=True)
+ref = model(data)
+lg0 = model.last_logits.clone()
+diff = sum(0 if torch.equal((model(data), model.last_logits)[1], lg0) else 1 for _ in range(reps))
+bad += diff
+print(f"B=1 N=1000 from raw images: {reps} repeats, {diff} differ", flush=True)
 # training step: the gradients of two identical steps from identical weights
 m = gmf_amd.PointDSC(num_layers=3)
 m.load_state_dict(synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 3, 128), seed=7), strict=False)

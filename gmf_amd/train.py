@@ -589,13 +589,14 @@ def pose_head_train(model, feat_n, sigma, src, tgt, logits, sigmas):
 class GraphedTrainingStep:
     """One training step of `model` (a gmf_amd.PointDSC in train() mode) - forward, loss, backward, optimizer step - captured ONCE as a
     HIP graph and replayed (libs/trainer.py:131-166 is the loop this stands in for).  An eager step is ~1 900 kernel launches from
-    ~320 C calls and costs the host more time than the device needs for them (25 ms at 16 x 1000 whatever the
-    size); the replay is one launch.
+    ~320 C calls; the replay is one launch from Python.  It is NOT shorter than a well-fed eager step: the kernels are dependent and
+    sum to ~24 ms at 16 x 1000 - the graph removes the host from the loop, not time from the device.
 
     What makes the step capturable: `model.sigma_on_device = True` (the learnable sigma is read by the kernels from the parameter's
     own memory, gmf_set_sigma_device - the eager step reads it to the host once per step), a `loss_fn(result, batch) -> 0-dim device
     tensor` that makes no host read (`ClassificationLoss(host_stats=False)`), and an optimizer whose step is capturable
-    (`torch.optim.Adam(..., capturable=True)`).  `warmup` eager steps run first, on a side stream: they size the library's workspace
+    (`torch.optim.Adam(..., capturable=True, fused=True)` - fused: torch's multi-tensor Adam under capture issues three broadcast
+    divisions per parameter, ~950 launches and 4 ms of a 27 ms step at 16 x 1000).  `warmup` eager steps run first, on a side stream: they size the library's workspace
     and the allocator's pools, and they are real optimizer steps.  Shapes are fixed by the example batch; `__call__(batch)` copies
     the tensors of `batch` into the captured inputs and replays."""
 

@@ -1029,13 +1029,16 @@ def test_f8_weighted_procrustes(golden_dir, N):
     assert _maxerr(t.cpu(), g[f"t_{N}"]) < 1e-4
 
 
-def test_graph_captured_training_step_equals_eager_steps(sd_full):
+@pytest.mark.parametrize("adam", ["foreach", "fused"])
+def test_graph_captured_training_step_equals_eager_steps(sd_full, adam):
     """the reference's default training step (libs/trainer.py:131-166: train-mode forward, ClassificationLoss +
     SpectralMatchingLoss, backward, Adam) captured ONCE as a HIP graph (`gmf_amd.train.GraphedTrainingStep`) and replayed.  What made
     it capturable: sigma read by the kernels from the parameter's own device memory (`gmf_set_sigma_device`, ABI 5: the eager step
     reads it to the host once per step), loss statistics left on the device, a capturable Adam.  Two copies of the same model, same
     data: one takes 3 + 4 eager steps, the other 3 warm-up steps and 4 replays - the same parameters afterwards, bit for bit
-    (every kernel is deterministic and both run the same optimizer code), and the per-step losses agree."""
+    (every kernel is deterministic and both run the same optimizer code), and the per-step losses agree.  `adam`: torch's
+    multi-tensor implementation and its fused one - the one to use: under capture the multi-tensor form falls back to three
+    broadcast divisions PER PARAMETER (~950 extra launches, 4 ms of a 27 ms step at 16 x 1000)."""
     from gmf_amd import train as T
     B, N = 4, 500
     b = synthetic.synthetic_batch(list(range(600, 600 + B)), N=N, T=40)
@@ -1050,7 +1053,8 @@ def test_graph_captured_training_step_equals_eager_steps(sd_full):
         m = gmf_amd.PointDSC(num_layers=3)
         m.load_state_dict({k: v for k, v in synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 3, 128), seed=7).items()}, strict=False)
         m = m.to(DEV).train()
-        return m, torch.optim.Adam([p for n, p in m.named_parameters() if not n.startswith("encoder.image_encoder.")], lr=1e-3, capturable=True)
+        return m, torch.optim.Adam([p for n, p in m.named_parameters() if not n.startswith("encoder.image_encoder.")], lr=1e-3, capturable=True,
+                                   fused=(adam == "fused"))
     m_e, opt_e = make()
     m_e.sigma_on_device = True
     eager_losses = []

@@ -15,7 +15,8 @@ b = synthetic.synthetic_batch(list(range(B)), N=N, T=300)
 data = {k: b[k].to(dev) for k in ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")}
 gt = b["gt_labels"].to(dev)
 cl_fn, sm_fn = gmf_amd.ClassificationLoss(balanced=False), gmf_amd.SpectralMatchingLoss(balanced=False)
-opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-6)
+FUSED = os.environ.get("ADAM", "fused") == "fused"      # ADAM=foreach: torch's default (multi-tensor) implementation
+opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-6, fused=FUSED)
 def step():
     opt.zero_grad()
     res = m(data)
@@ -27,12 +28,12 @@ for _ in range(2): l = step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
-print(f"training step B={B} N={N} T=300, 12 layers: {dt * 1e3:.1f} ms  (loss {l:.4f}; peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB + workspace)")
+print(f"training step B={B} N={N} T=300, 12 layers, Adam {'fused' if FUSED else 'foreach'}: {dt * 1e3:.1f} ms  (loss {l:.4f}; peak memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB + workspace)")
 # [r5] the same step captured as a HIP graph (gmf_amd.train.GraphedTrainingStep): sigma on the device, loss statistics on the device, capturable Adam
 from gmf_amd import train as T
 m2 = gmf_amd.PointDSC(num_layers=12); m2.load_state_dict(sd, strict=False); m2 = m2.to(dev).train()
 cl2 = gmf_amd.ClassificationLoss(balanced=False, host_stats=False)
-opt2 = torch.optim.Adam([p for n, p in m2.named_parameters() if not n.startswith("encoder.image_encoder.")], lr=1e-4, weight_decay=1e-6, capturable=True)
+opt2 = torch.optim.Adam([p for n, p in m2.named_parameters() if not n.startswith("encoder.image_encoder.")], lr=1e-4, weight_decay=1e-6, capturable=True, fused=FUSED)
 data2 = dict(data, gt=gt)
 gstep = T.GraphedTrainingStep(m2, opt2, lambda res, bt: cl2(res["final_labels"], bt["gt"])["loss"] + sm_fn(res["M"], bt["gt"]), data2, warmup=3)
 for _ in range(2): gstep(data2)

@@ -2289,9 +2289,13 @@ __global__ void k_pack_p32(const float* __restrict__ src, float* __restrict__ ds
 // 16-byte unit ((plane * 8 + s) * 64 + lane) holds, for lane (h, i) = row 32 tile + i, the 8 halves of k-step s in fragment
 // order (f = 8 s + j -> feature 32 (f >> 4) + 8 ((f & 15) >> 2) + 4 h + (f & 3)); plane 0 = fp16(x), plane 1 = fp16(x - hi).
 // Rows >= n_rows are zero.  The operand image of k_seed_dist (the unit features of the pose head).
+// [r5] copy_src / copy_dst: the first n_copy threads also copy one float each - the pose head's NMS keys start as a copy of the
+// scores (launch_nms_keys with candidate splits), and a hipMemcpyAsync of those few KB is a launch of its own on small grids.
 __global__ void k_pack_rows_h2(const float* __restrict__ src, float* __restrict__ dst, int n_rows, int tiles, long total,
-                               const PairTab* __restrict__ ptab) {
+                               const PairTab* __restrict__ ptab, const float* __restrict__ copy_src, float* __restrict__ copy_dst,
+                               long n_copy) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;       // one (tile, k-step, lane) per thread
+  if (idx < n_copy) copy_dst[idx] = copy_src[idx];
   if (idx >= total) return;
   const int lane = idx & 63, s8 = (idx >> 6) & 7;
   const long bt = idx >> 9;
@@ -2567,10 +2571,14 @@ hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int 
   return hipGetLastError();
 }
 
-hipError_t launch_pack_rows_h2(const float* src, float* dst, int B, int n_rows, hipStream_t s, const PairTab* ptab) {
+hipError_t launch_pack_rows_h2(const float* src, float* dst, int B, int n_rows, hipStream_t s, const PairTab* ptab, const float* copy_src,
+                               float* copy_dst, long n_copy) {
   const int tiles = (n_rows + 31) / 32;
   const long total = (long)B * tiles * 8 * 64;
-  hipLaunchKernelGGL(k_pack_rows_h2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, n_rows, tiles, total, ptab);
+  if (!copy_src || !copy_dst) n_copy = 0;
+  if (n_copy > total) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_pack_rows_h2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, n_rows, tiles, total, ptab, copy_src,
+                     copy_dst, n_copy);
   return hipGetLastError();
 }
 

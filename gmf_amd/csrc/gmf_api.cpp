@@ -922,12 +922,17 @@ static int pose_head_impl(gmf_handle* h, const gmf_pose_params* p, const float* 
   if (fitness) fit = fitness;
 
   const int* seeds_use = seeds_in;
+  // the unit features as the split-fp16 image of k_seed_dist; [r5] the same launch hands the NMS its keys as a copy of the scores
+  // (the all-pairs form with candidate splits starts from one: a hipMemcpyAsync of its own was 4 us + a kernel boundary at B = 1)
+  const bool preset = !seeds_in && p->use_nms;
+  GMF_HIP(gmf::launch_pack_rows_h2(feat_n, fimg, B, N, st, ptab, preset ? logits : nullptr, preset ? keys : nullptr,
+                                   preset ? (ptab ? (long)n_sum : (long)B * N) : 0));
   if (!seeds_in) {
     const float* kk = logits;
     if (p->use_nms) {
       // dmat is free until k_seed_dist: it doubles as the grid-binning scratch of the NMS when it is large enough
       float* scr = (BS * N >= gmf::nms_scratch_floats(B, N)) ? dmat : nullptr;
-      GMF_HIP(gmf::launch_nms_keys(h->tune, src_keypts, logits, keys, B, N, p->nms_radius, st, scr, ptab, (long)n_sum));
+      GMF_HIP(gmf::launch_nms_keys(h->tune, src_keypts, logits, keys, B, N, p->nms_radius, st, scr, ptab, (long)n_sum, true));
       kk = keys;
     }
     GMF_HIP(gmf::launch_sort_topk(h->tune, kk, seeds, B, N, Sn, st, ptab));
@@ -936,7 +941,6 @@ static int pose_head_impl(gmf_handle* h, const gmf_pose_params* p, const float* 
     GMF_HIP(hipMemcpyAsync(seeds_out, seeds_in, BS * sizeof(int), hipMemcpyDeviceToDevice, st));
   }
   // feature-space distances of the seed rows by MFMA (k_seed_dist), then per-seed top-(k+1) selection
-  GMF_HIP(gmf::launch_pack_rows_h2(feat_n, fimg, B, N, st, ptab));
   // (the fused form - distances computed twice and never written - was built in round 4, is exact, and is not faster:
   // tools/ubench/archive/seed_knn_fused_r04.hip)
   GMF_HIP(gmf::launch_seed_dist(fimg, seeds_use, dmat, B, N, Sn, st, ptab));

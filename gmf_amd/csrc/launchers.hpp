@@ -151,7 +151,8 @@ hipError_t launch_nn_match(const float* F0, const float* F1, float* f0_img, floa
 hipError_t launch_seed_dist(const float* featn_img, const int* seeds, float* dist, int B, int N, int S, hipStream_t s, const PairTab* ptab = nullptr);
 hipError_t launch_pack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s, const PairTab* ptab = nullptr);
 // row-major [B, n_rows, 128] -> split-fp16 plane image (the operand image of launch_seed_dist)
-hipError_t launch_pack_rows_h2(const float* src, float* dst, int B, int n_rows, hipStream_t s, const PairTab* ptab = nullptr);
+hipError_t launch_pack_rows_h2(const float* src, float* dst, int B, int n_rows, hipStream_t s, const PairTab* ptab = nullptr,
+                               const float* copy_src = nullptr, float* copy_dst = nullptr, long n_copy = 0);
 hipError_t launch_unpack_p32(const float* src, float* dst, int B, int n_rows, int K, long sb, long sr, long sk, hipStream_t s, int* status = nullptr);
 hipError_t launch_pack_pts8(const float* src, const float* tgt, float* dst, int B, int N, hipStream_t s, const PairTab* ptab = nullptr,
                             unsigned* zero_words = nullptr, int n_zero = 0);   // zero_words: n_zero words cleared by the same launch (PvGuard statistics)

@@ -7,7 +7,8 @@ namespace gmf {
 
 hipError_t launch_nms_keys(const Tuning& tune, const float* src, const float* scores, float* keys, int B, int N, float R, hipStream_t s,
                            float* scratch = nullptr,      // scratch: nms_scratch_floats(B, N) floats, or null = all-pairs form
-                           const PairTab* ptab = nullptr, long total_rows = 0);   // ragged batch: the per-pair table and sum n
+                           const PairTab* ptab = nullptr, long total_rows = 0,    // ragged batch: the per-pair table and sum n
+                           bool keys_preset = false);     // [r5] keys already hold a copy of the scores (k_pack_rows_h2's copy role)
 size_t nms_scratch_floats(int B, int N);
 hipError_t launch_sort_topk(const Tuning& tune, const float* keys, int* out_idx, int B, int N, int S, hipStream_t s, const PairTab* ptab = nullptr);
 hipError_t launch_knn_seeds(const float* feat_n, const int* seeds, const float* dist_in, int* knn_idx, int B, int N, int S,

@@ -1668,7 +1668,7 @@ size_t nms_scratch_floats(int B, int N) { return (size_t)B * ((size_t)4 * N + kN
 
 // tune.nms_binned: 1 = grid-binned candidates for N >= 1024 on grids of >= 128 workgroups (default), 2 = whenever N >= 1024, 0 = all pairs
 hipError_t launch_nms_keys(const Tuning& tune, const float* src, const float* scores, float* keys, int B, int N, float R, hipStream_t s,
-                           float* scratch, const PairTab* ptab, long total_rows) {
+                           float* scratch, const PairTab* ptab, long total_rows, bool keys_preset) {
   // The reference tests sqrt(d2) >= R (PointDSC.py:283).  sqrtf is monotone, so that is d2 >= t for the smallest float t
   // with sqrtf(t) >= R; finding t on the host removes the square root from the N^2 loop without changing one decision.
   float t = R * R;
@@ -1688,7 +1688,7 @@ hipError_t launch_nms_keys(const Tuning& tune, const float* src, const float* sc
   }
   int js = 1;
   if (nblk * B < 256) js = std::min(std::min(16, nblk), (512 + nblk * B - 1) / (nblk * B));
-  if (js > 1) {
+  if (js > 1 && !keys_preset) {
     hipError_t e = hipMemcpyAsync(keys, scores, (size_t)(ptab ? total_rows : (long)B * N) * sizeof(float), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return e;
   }

@@ -624,7 +624,9 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
     const bool small3 = !one_kernel && h->tune.small_roles && small_nf == 0 && small_ks > 1 && ff_hs > 1 && ff_part;
     // parity arithmetic: V with e4m3 cross planes for the pv_fp8 form of the attention body (scattn_h2p_body<3, *, 4, true>), which every
     // attention kernel of this path instantiates - large grids, split tails and the small-grid role kernels alike
-    cc.v_scale = (h->tune.pv_fp8 && !cc.half) ? v_scale : nullptr;
+    // (a weights block without thresholds - filled in by hand, pv_guard = NULL - gets the three-product form under the guarded default,
+    // never the unguarded one)
+    cc.v_scale = ((h->tune.pv_fp8 == 2 || (h->tune.pv_fp8 == 1 && w->pv_guard)) && !cc.half) ? v_scale : nullptr;
     // [r5] "pv_fp8" = 1: guarded per pair and layer on the device (PvGuard).  The statistics start at zero (k_pack_pts8); f_0's is raised by the
     // front kernel, f_{l+1}'s by the attention epilogue / merge kernels of layer l - always before the kernels that read it
     const bool guarded = cc.v_scale && h->tune.pv_fp8 == 1 && w->pv_guard;       // (implies may_guard: launch_pack_pts8 cleared fstat)

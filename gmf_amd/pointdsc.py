@@ -433,6 +433,7 @@ class PointDSC(nn.Module):
         return out
 
     def _weights(self, device):
+        device = torch.device(device)                  # ("cuda:0" and device("cuda", 0) are the same cache entry)
         key = (self._watch.version(), device)
         if self._packed is None or self._packed_version != key:
             self._packed = packing.PackedEncoder(self._hot_state(), self.encoder.num_layers, device)

@@ -232,8 +232,8 @@ typedef struct gmf_encoder_weights {
   const float* tail_wst_h2;
   /* [ABI 5] optional, [num_layers]: the "pv_fp8" guard.  Entry l is the largest SQUARED row norm of layer l's input features
    * f = ReLU(PointCN_l(.)) up to which that layer's attention may run its P V cross products on the fp8 pipe (written by
-   * gmf_encoder_pack_weights from the spectral norms of projection_q / projection_k, PointDSC.py:23-25,56-64); NULL = no guard
-   * ("pv_fp8" = 1 then behaves as 2). */
+   * gmf_encoder_pack_weights from the spectral norms of projection_q / projection_k, PointDSC.py:23-25,56-64); NULL = no thresholds:
+   * the guarded default ("pv_fp8" = 1) then runs the three-product form (as "pv_fp8" = 0), never the unguarded one. */
   const float* pv_guard;
 } gmf_encoder_weights;
 

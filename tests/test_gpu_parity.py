@@ -508,6 +508,18 @@ def test_pv_fp8_guard_decides_per_pair_and_layer(model, sd_full, grid):
         g2, _ = run(m, data, 2)
         assert gt1 and torch.isfinite(g1).all()
         assert torch.equal(g1, g0) and not torch.equal(g1, g2)
+        # (d) a weights block WITHOUT thresholds (filled in by hand, pv_guard = NULL): the guarded default runs three products -
+        # the unguarded fp8 form is only ever reached by asking for it ("pv_fp8" = 2)
+        pw = model._weights(data["corr_pos"].device)           # (the packed block the forward itself uses: same cache key)
+        saved = pw.struct.contents.pv_guard
+        lg0, _ = run(model, data, 0)
+        try:
+            pw.struct.contents.pv_guard = None
+            n1, nt1 = run(model, data, 1)
+            n2, _ = run(model, data, 2)
+        finally:
+            pw.struct.contents.pv_guard = saved
+        assert torch.equal(n1, lg0) and not nt1 and torch.equal(n2, lg2)
     finally:
         h.call("gmf_set_tuning", b"pv_fp8", 1)
         h.status(clear=True)

@@ -184,15 +184,14 @@ GMF_DEVINL void load_frag_rowmajor(float (&x)[CF], const float* __restrict__ row
   }
 }
 
+// (bx, pair, set): the workgroup's block of four token tiles, its pair (of nb) and its weight set; `lds`: 2 x 16 KiB.
 template <bool PE, bool ROWMAJOR = false>
-__global__ void __launch_bounds__(256, 2)
-k_ctx_prep_h2(const float* __restrict__ ctx, const float* __restrict__ wst, const float* __restrict__ vecs,
-              float* __restrict__ out, int T, int ttiles, int wst_stride, int vec_stride) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+GMF_DEVINL void ctx_prep_h2_body(float* lds, const int bx, const int pair, const int set, const int nb, const float* __restrict__ ctx,
+                                 const float* __restrict__ wst, const float* __restrict__ vecs, float* __restrict__ out, int T,
+                                 int ttiles, int wst_stride, int vec_stride) {
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = blockIdx.y, set = blockIdx.z, nb = gridDim.y;
-  const int tile_raw = blockIdx.x * kWavesPerWG + wave;
+  const int tile_raw = bx * kWavesPerWG + wave;
   const bool active = tile_raw < ttiles;
   const int tile = active ? tile_raw : ttiles - 1;
   wst += (size_t)set * wst_stride;
@@ -252,6 +251,14 @@ k_ctx_prep_h2(const float* __restrict__ ctx, const float* __restrict__ wst, cons
       }
     }
   }
+}
+
+template <bool PE, bool ROWMAJOR = false>
+__global__ void __launch_bounds__(256, 2)
+k_ctx_prep_h2(const float* __restrict__ ctx, const float* __restrict__ wst, const float* __restrict__ vecs,
+              float* __restrict__ out, int T, int ttiles, int wst_stride, int vec_stride) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  ctx_prep_h2_body<PE, ROWMAJOR>(lds, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, ctx, wst, vecs, out, T, ttiles, wst_stride, vec_stride);
 }
 
 // =========================================================================================
@@ -618,6 +625,65 @@ k_fusion_ff_h2p(const float* __restrict__ x1, const float* __restrict__ wst, con
                 float* __restrict__ x2_out, int tiles, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
   fusion_ff_h2p_body<SPLIT>(lds, blockIdx.x, blockIdx.y, gridDim.y, blockIdx.z, gridDim.z, x1, wst, vecs, x2_out, tiles, part);
+}
+
+// =========================================================================================
+// [r5] Small grids: the forward's prologue as three launches of two roles each.  Before the first layer the forward runs two
+// INDEPENDENT chains of small kernels on one stream, one after the other:
+//   image side:  Fusion-1 context (k_ctx_prep_h2) -> Fusion-1 cross-attention -> Fusion-1 feed-forward (-> reduce -> the L context sets)
+//   point side:  key points (k_pack_pts8) -> compat cache (k_compat_build) -> layer 0 + first PointCN (k_front_h2<3>)
+// - each a handful of workgroups on 256 CUs (B = 1, T = 300: 3 workgroups per image-side kernel), so a launch costs its
+// latency chain, not its work.  Here one launch carries ONE LINK OF EACH chain: the point side (28 us at N = 1000, 45 at 5000)
+// runs under the image side's three links.  The roles call the kernels' own bodies: same arithmetic, bit-identical results.
+// Workgroups [0, n_a) take the image-side role (first: the longer chain), the rest the point-side role.
+// =========================================================================================
+__global__ void __launch_bounds__(256, 2)
+k_pro_ctx_pts(const int n_a, const int gx_a, const int nb, const float* __restrict__ ctx, const float* __restrict__ wst,
+              const float* __restrict__ vecs, float* __restrict__ out, int T, int ttiles,
+              const float* __restrict__ src, const float* __restrict__ tgt, float* __restrict__ pts8, int N, int Npad, long total,
+              const PairTab* __restrict__ ptab, unsigned* __restrict__ zero_words, int n_zero) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageFloats];
+  const int id = blockIdx.x;
+  if (id < n_a) {
+    ctx_prep_h2_body<false, true>(lds, id % gx_a, id / gx_a, 0, nb, ctx, wst, vecs, out, T, ttiles, 0, 0);
+    return;
+  }
+  pack_pts8_body((long)(id - n_a) * 256 + threadIdx.x, src, tgt, pts8, N, Npad, total, ptab, zero_words, n_zero);
+}
+
+constexpr int kProBLdsFloats = kFattnLdsFloats > kCompatLdsFloats ? kFattnLdsFloats : kCompatLdsFloats;
+__global__ void __launch_bounds__(256, 2)
+k_pro_fattn_compat(const int n_a, const int gx_a, const float* __restrict__ xin, const float* __restrict__ ctx_img,
+                   const float* __restrict__ wst, const float* __restrict__ vecs, float* __restrict__ x1_out, int T, int ttiles,
+                   const float* __restrict__ pts8, float* __restrict__ c_dense, int N, int tiles, int gy, float inv_sig2,
+                   const PairTab* __restrict__ ptab) {
+  __shared__ __attribute__((aligned(16))) float lds[kProBLdsFloats];
+  const int id = blockIdx.x;
+  if (id < n_a) {
+    fusion_attn_h2_body<false, true>(lds, id % gx_a, id / gx_a, xin, ctx_img, wst, vecs, x1_out, T, ttiles, T, ttiles);
+    return;
+  }
+  const int j = id - n_a, I = j % tiles, rest = j / tiles;
+  compat_build_body<0>(lds, I, rest % gy, rest / gy, pts8, c_dense, N, tiles, inv_sig2, ptab);
+}
+
+constexpr int kProCLdsFloats = (kRing > 4 ? kRing : 4) * kStageFloats;
+template <bool SPLIT>
+__global__ void __launch_bounds__(256, 1)          // (small grids: a CU never holds two of these; the two roles' union wants a few registers over 256)
+k_pro_ff_front(const int n_a, const int gx_a, const int nb, const int hs, const float* __restrict__ x1, const float* __restrict__ wst,
+               const float* __restrict__ vecs, float* __restrict__ x2_out, int ttiles, float* __restrict__ part,
+               const int gx_f, const float* __restrict__ in, const float* __restrict__ fwst, const float* __restrict__ fvecs,
+               float* __restrict__ f_out, float* __restrict__ q_out, float* __restrict__ k_out, float* __restrict__ v_out, int N,
+               int tiles, const PairTab* __restrict__ ptab, const PvGuard guard) {
+  __shared__ __attribute__((aligned(16))) float lds[kProCLdsFloats];
+  const int id = blockIdx.x;
+  if (id < n_a) {                                   // (bx, pair, z) with bx fastest
+    const int bx = id % gx_a, r = id / gx_a;
+    fusion_ff_h2p_body<SPLIT>(lds, bx, r % nb, nb, r / nb, hs, x1, wst, vecs, x2_out, ttiles, part);
+    return;
+  }
+  const int j = id - n_a;
+  front_h2_body<3>(lds, j % gx_f, j / gx_f, -1, in, fwst, fvecs, f_out, q_out, k_out, v_out, N, tiles, ptab, nullptr, guard);
 }
 
 // =========================================================================================
@@ -1002,6 +1068,55 @@ hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, 
   if (pe) hipLaunchKernelGGL(k_fusion_attn_h2<true>, tgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
   else if (rowmajor) hipLaunchKernelGGL((k_fusion_attn_h2<false, true>), tgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
   else hipLaunchKernelGGL(k_fusion_attn_h2<false>, tgrid(tiles, B), dim3(256), 0, s, x, ctx_img, wst, vecs, x1, N, tiles, T, ttiles);
+  return hipGetLastError();
+}
+
+// [r5] the three prologue launches of small grids (k_pro_*): image-side role | point-side role
+hipError_t launch_pro_ctx_pts(const float* p_tokens, const float* wst, const float* vecs, float* f1ctx, int B, int T, int ttiles,
+                              const float* src, const float* tgt, float* pts8, int N, hipStream_t s, const PairTab* ptab,
+                              unsigned* zero_words, int n_zero) {
+  const dim3 ga = tgrid(ttiles, B);
+  const int Npad = ((N + 31) / 32) * 32;
+  const long total = (long)B * Npad;
+  const int n_a = (int)(ga.x * ga.y), n_b = (int)((std::max(total, (long)n_zero) + 255) / 256);
+  hipLaunchKernelGGL(k_pro_ctx_pts, dim3(n_a + n_b), dim3(256), 0, s, n_a, (int)ga.x, B, p_tokens, wst, vecs, f1ctx, T, ttiles, src, tgt,
+                     pts8, N, Npad, total, ptab, zero_words, n_zero);
+  return hipGetLastError();
+}
+
+hipError_t launch_pro_fattn_compat(const float* q_tokens, const float* f1ctx, const float* wst, const float* vecs, float* x1t, int B,
+                                   int T, int ttiles, const float* pts8, float* c_dense, int N, int tiles, float sigma_d,
+                                   hipStream_t s, const PairTab* ptab) {
+  const dim3 ga = tgrid(ttiles, B);
+  const int gy = (tiles + 4 * kJPerWave - 1) / (4 * kJPerWave);
+  const int n_a = (int)(ga.x * ga.y);
+  const long n_b = (long)tiles * gy * B;
+  hipLaunchKernelGGL(k_pro_fattn_compat, dim3((unsigned)(n_a + n_b)), dim3(256), 0, s, n_a, (int)ga.x, q_tokens, f1ctx, wst, vecs, x1t, T,
+                     ttiles, pts8, c_dense, N, tiles, gy, 1.0f / (sigma_d * sigma_d), ptab);
+  return hipGetLastError();
+}
+
+// returns through *hs_out the hidden splits of the feed-forward role (> 1: the caller runs launch_ff_reduce_h2 next)
+hipError_t launch_pro_ff_front(const Tuning& tune, const float* x1t, const float* wst, const float* vecs, float* imgfeat, int B,
+                               int ttiles, float* part, int max_parts, const float* corr_pos, const float* fwst, const float* fvecs,
+                               float* f, float* q, float* k, float* v, int N, int tiles, hipStream_t s, const PairTab* ptab,
+                               PvGuard guard, int* hs_out) {
+  const dim3 ga = tgrid(ttiles, B), gf = tgrid(tiles, B);
+  const int hs = part ? plan_ff_split(tune, ga.x * B, max_parts) : 1;
+  const int n_a = (int)(ga.x * B) * hs, n_b = (int)(gf.x * B);
+  if (hs > 1)
+    hipLaunchKernelGGL(k_pro_ff_front<true>, dim3(n_a + n_b), dim3(256), 0, s, n_a, (int)ga.x, B, hs, x1t, wst, vecs, imgfeat, ttiles, part,
+                       (int)gf.x, corr_pos, fwst, fvecs, f, q, k, v, N, tiles, ptab, guard);
+  else
+    hipLaunchKernelGGL(k_pro_ff_front<false>, dim3(n_a + n_b), dim3(256), 0, s, n_a, (int)ga.x, B, 1, x1t, wst, vecs, imgfeat, ttiles,
+                       (float*)nullptr, (int)gf.x, corr_pos, fwst, fvecs, f, q, k, v, N, tiles, ptab, guard);
+  *hs_out = hs;
+  return hipGetLastError();
+}
+
+hipError_t launch_ff_reduce_h2(const float* part, const float* x1, const float* vecs, float* x2, int B, int tiles, int hs, hipStream_t s) {
+  const dim3 g = tgrid(tiles, B);
+  hipLaunchKernelGGL(k_ff_reduce, dim3(g.x, g.y, 4), dim3(256), 0, s, part, x1, vecs, x2, tiles, hs);
   return hipGetLastError();
 }
 

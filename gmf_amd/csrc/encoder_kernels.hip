@@ -292,18 +292,7 @@ k_scattn(const float* __restrict__ q_img, const float* __restrict__ k_img, const
   }
 }
 
-// d = ||a|| - ||b|| from the squared lengths in the reference's form, sqrt(a2) - sqrt(b2) with correctly rounded square
-// roots (sqrt_cr), i.e. the same roundings as torch.norm on the CPU (PointDSC.py:217-219).
-GMF_DEVINL float len_diff(float a2, float b2) { return sqrt_cr(a2) - sqrt_cr(b2); }
-
-// compat * score for one element; lp points at this lane-half's first key of the tile (pts8 rows)
-GMF_DEVINL float compat_times(const float4* lp, int jl, const float (&si)[3], const float (&ti)[3], float inv_sig2, float sc) {
-  const float4 a = lp[2 * jl], b = lp[2 * jl + 1];
-  const float ax = si[0] - a.x, ay = si[1] - a.y, az = si[2] - a.z;
-  const float bx = ti[0] - b.x, by = ti[1] - b.y, bz = ti[2] - b.z;
-  const float d = len_diff(fmaf(az, az, fmaf(ay, ay, ax * ax)), fmaf(bz, bz, fmaf(by, by, bx * bx)));
-  return fmaxf(1.0f - d * d * inv_sig2, 0.f) * sc;
-}
+// (len_diff / compat_times: enc_common.hpp - shared with the prologue role kernels of encoder_h2.hip)
 
 // =========================================================================================
 // k_scattn_h2: the attention with split-fp16 operands (two planes, three partial products, 16 KiB tiles), c_ij
@@ -526,80 +515,13 @@ k_scattn_h2(const float* __restrict__ q_img, const float* __restrict__ k_img, co
 // (32I + i, 32J + 8(r>>2) + 4h + (r&3)); tile (I, J) is the 4 KiB block [q][lane][4] with r = 4q + e.
 // grid (tiles, ceil(tiles / (4 * kJPerWave)), B), block 256
 // =========================================================================================
-constexpr int kJPerWave = 8;
-
-// c is exactly symmetric (the squared differences do not see the sign of s_i - s_j), so only tiles J >= I are
-// evaluated; a tile with J > I is also written as tile (J, I) after a 32 x 32 transpose through a per-wave LDS buffer
-// (16 ds_write_b32 + 16 ds_read_b32 instead of 16 x ~26 vector instructions with two correctly rounded square roots).
-// FMT (CompatCache::fmt): 0 = fp32, 4 KiB per tile.  The 16-bit formats are 2 KiB per tile ([q2][lane][8 x 16 bit], registers
-// r = 8 q2 .. 8 q2 + 7) - half the stream of the 12 attention launches:
-//   1 = c as fp16 (the throughput numerics mode, gmf_set_tuning "precision" = 1);
-//   2 = c as 16-bit fixed point, u = rint(65535 c) (uniform absolute error <= 7.6e-6; gmf_set_tuning "compat_format" = 2, opt-in).
-// (Measured and dropped, round 3: fp16 of 1 - c - exact where c = 1, coarse below c = 0.5 - and 16-bit fixed point of sqrt(1 - c),
-// the error structure of the reference's own fp32 rounding; profiles/r03_compat_formats.txt.)
+// (compat_build_body, kJPerWave: enc_common.hpp)
 template <int FMT>
 __global__ void __launch_bounds__(256)
 k_compat_build(const float* __restrict__ pts8, float* __restrict__ c_dense, int N, int tiles, float inv_sig2,
                const PairTab* __restrict__ ptab) {
-  __shared__ float tr[4 * 32 * 33];
-  const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = blockIdx.z, I = blockIdx.x;
-  const int tiles_p = (pair_rows(ptab, pair, N) + 31) >> 5;      // ragged batch: this pair's own tiles (the slot keeps `tiles`)
-  if (I >= tiles_p) return;
-  const size_t pbase = (size_t)pair * tiles;
-  float si[3], ti[3];
-  {
-    const float4* pp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)I * 32 + i) * 8);
-    const float4 a = pp[0], b = pp[1];
-    si[0] = a.x; si[1] = a.y; si[2] = a.z; ti[0] = b.x; ti[1] = b.y; ti[2] = b.z;
-  }
-  constexpr int kTile16 = FMT ? 128 : 256;          // 16-byte pieces per tile
-  float4* const cbase = reinterpret_cast<float4*>(c_dense) + pbase * (size_t)tiles * kTile16 + lane;
-  float4* const crow = cbase + (size_t)I * tiles * kTile16;
-  auto store_tile = [&](float4* ct, const float (&c)[16]) {
-    if (FMT == 1) {
-#pragma unroll
-      for (int q2 = 0; q2 < 2; ++q2) {
-        f16x8 hv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) hv[e] = (_Float16)c[8 * q2 + e];
-        ct[q2 * 64] = __builtin_bit_cast(float4, hv);
-      }
-    } else if (FMT == 2) {
-#pragma unroll
-      for (int q2 = 0; q2 < 2; ++q2) {
-        unsigned wv[4];
-        auto enc = [](float cv) { return (unsigned)__builtin_rintf(cv * 65535.0f); };
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) wv[e >> 1] = enc(c[8 * q2 + e]) | (enc(c[8 * q2 + e + 1]) << 16);
-        ct[q2 * 64] = make_float4(__uint_as_float(wv[0]), __uint_as_float(wv[1]), __uint_as_float(wv[2]), __uint_as_float(wv[3]));
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) ct[q * 64] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
-    }
-  };
-  float* const mt = tr + wave * 32 * 33;
-  const int j0 = (blockIdx.y * 4 + wave) * kJPerWave;
-  for (int J = max(j0, I); J < min(tiles_p, j0 + kJPerWave); ++J) {
-    const float4* lp = reinterpret_cast<const float4*>(pts8 + (pbase * 32 + (size_t)J * 32) * 8) + 8 * h;
-    float c[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) c[r] = compat_times(lp, 8 * (r >> 2) + (r & 3), si, ti, inv_sig2, 1.0f);
-    store_tile(crow + (size_t)J * kTile16, c);
-    if (J > I) {
-      // tile (J, I): lane (h, i), register r = element (row i of J, column jl of I) = c(I: jl, J: i) = M[jl][i]
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mt[i * 33 + 8 * (r >> 2) + 4 * h + (r & 3)] = c[r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      float d[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) d[r] = mt[(8 * (r >> 2) + 4 * h + (r & 3)) * 33 + i];
-      store_tile(cbase + ((size_t)J * tiles + I) * kTile16, d);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  }
+  __shared__ float tr[kCompatLdsFloats];
+  compat_build_body<FMT>(tr, blockIdx.x, blockIdx.y, blockIdx.z, pts8, c_dense, N, tiles, inv_sig2, ptab);
 }
 
 // =========================================================================================
@@ -2338,27 +2260,11 @@ __global__ void k_unpack_p32(const float* __restrict__ src, float* __restrict__ 
   }
 }
 
-// src,tgt [B,N,3] -> pts8 [B, Npad, 8] (zero padded rows)
+// src,tgt [B,N,3] -> pts8 [B, Npad, 8] (zero padded rows); pack_pts8_body: enc_common.hpp
 __global__ void k_pack_pts8(const float* __restrict__ src, const float* __restrict__ tgt, float* __restrict__ dst,
                             int N, int Npad, long total, const PairTab* __restrict__ ptab, unsigned* __restrict__ zero_words,
                             int n_zero) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  // [r5] the "pv_fp8" guard's statistics start every forward at zero: cleared here, by the first kernel of the stream that runs
-  // before anything raises them (a hipMemsetAsync of these few words costs a 9 us fill kernel of its own)
-  if (zero_words && idx < n_zero) zero_words[idx] = 0u;
-  if (idx >= total) return;
-  const int row = idx % Npad;
-  const long b = idx / Npad;
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-  if (row < pair_rows(ptab, (int)b, N)) {
-    const size_t r0 = pair_row0(ptab, (int)b, N) + row;
-    const float* ps = src + r0 * 3;
-    const float* pt = tgt + r0 * 3;
-    a = make_float4(ps[0], ps[1], ps[2], 0.f);
-    c = make_float4(pt[0], pt[1], pt[2], 0.f);
-  }
-  reinterpret_cast<float4*>(dst)[2 * idx] = a;
-  reinterpret_cast<float4*>(dst)[2 * idx + 1] = c;
+  pack_pts8_body((long)blockIdx.x * blockDim.x + threadIdx.x, src, tgt, dst, N, Npad, total, ptab, zero_words, n_zero);
 }
 
 }  // namespace gmf

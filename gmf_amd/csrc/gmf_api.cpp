@@ -139,6 +139,11 @@ int gmf_set_tuning(gmf_handle* h, const char* name, int value) {
     t.small_fattn_tile = value != 0;
     return GMF_OK;
   }
+  if (std::strcmp(name, "small_prologue_roles") == 0) { // [ABI 5] 1 = small grids: the prologue's image-side and point-side chains share three launches (default), 0 = six kernels
+    GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: small_prologue_roles must be 0 or 1");
+    t.small_prologue = value != 0;
+    return GMF_OK;
+  }
   if (std::strcmp(name, "conv_small_grid") == 0) {     // [ABI 5] 1 = grids of a few images run the K-split convolution kernel (default), 0 = the 128-pixel kernels at every size
     GMF_REQUIRE(value == 0 || value == 1, GMF_ERR_BAD_ARG, "set_tuning: conv_small_grid must be 0 or 1");
     t.conv_small = value != 0;
@@ -200,7 +205,7 @@ int gmf_get_tuning(gmf_handle* h, const char* name, int* value) {
   const struct { const char* name; int v; } tab[] = {
       {"scattn_variant", t.scattn_variant}, {"front_output_split", t.front_split ? 1 : 0}, {"ff_hidden_splits", t.ff_split},
       {"attn_key_splits", t.key_splits}, {"attn_tail_split", t.tail_split ? 1 : 0}, {"small_grid_roles", t.small_roles ? 1 : 0},
-      {"fused_linear", t.fused_linear ? 1 : 0}, {"compat_cache", t.use_cache ? 1 : 0}, {"conv_lds_patch", t.conv_patch}, {"conv_small_grid", t.conv_small ? 1 : 0}, {"small_fattn_tile", t.small_fattn_tile ? 1 : 0},
+      {"fused_linear", t.fused_linear ? 1 : 0}, {"compat_cache", t.use_cache ? 1 : 0}, {"conv_lds_patch", t.conv_patch}, {"conv_small_grid", t.conv_small ? 1 : 0}, {"small_prologue_roles", t.small_prologue ? 1 : 0}, {"small_fattn_tile", t.small_fattn_tile ? 1 : 0},
       {"nms_binned", t.nms_binned}, {"topk_select", t.topk_select ? 1 : 0}, {"wide_attn_tile", t.wide_attn_tile ? 1 : 0},
       {"small_merge_tile", t.small_merge_tile ? 1 : 0}, {"mid_grid_roles", t.mid_grid_roles}, {"pv_fp8", t.pv_fp8}, {"q_in_attention", t.q_in_attention ? 1 : 0},
       {"compat_format", t.compat_format}, {"precision", t.precision}};
@@ -573,30 +578,6 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
     cc.max_splits = kMaxSplits;
   }
 
-  // Fusion-1: image_feat = FusionLayer(p_tok (context), queries = q_tok), pe = False (PointDSC.py:137)
-  if (h2 && w->f1_ctx_wst_h2 && w->f1_attn_wst_h2 && w->f1_ff_wst_h2) {
-    // (the two token tensors are read row-major: no packing launches in front of these few-workgroup kernels)
-    GMF_HIP(gmf::launch_ctx_prep_h2(false, p_tokens, w->f1_ctx_wst_h2, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st, true));
-    GMF_HIP(gmf::launch_fusion_attn_h2(false, q_tokens, f1ctx, w->f1_attn_wst_h2, w->f1_attn_vec, x1t, B, T, tt, T, tt, st, true));
-    GMF_HIP(gmf::launch_fusion_ff_h2(h->tune, x1t, w->f1_ff_wst_h2, w->f1_ff_vec, imgfeat, B, tt, st,
-                                     tt <= tiles ? cc.part_o : nullptr, tt <= tiles ? cc.max_splits : 0));
-  } else {
-    GMF_HIP(gmf::launch_pack_p32(p_tokens, pimg, B, T, kC, (long)T * kC, kC, 1, st));
-    GMF_HIP(gmf::launch_pack_p32(q_tokens, qimg, B, T, kC, (long)T * kC, kC, 1, st));
-    GMF_HIP(gmf::launch_ctx_prep(false, pimg, w->f1_ctx_wst, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st));
-    GMF_HIP(gmf::launch_fusion_attn(false, qimg, f1ctx, w->f1_attn_wst, w->f1_attn_vec, x1t, B, T, tt, T, tt, st));
-    GMF_HIP(gmf::launch_fusion_ff(x1t, w->f1_ff_wst, w->f1_ff_vec, imgfeat, B, tt, st));
-  }
-  // context side of all L Fusion-2 layers in one launch
-  if (L > 0) {
-    if (h2) GMF_HIP(gmf::launch_ctx_prep_h2(true, imgfeat, w->ctx_wst_h2, w->ctx_vec, ctxall, B, T, tt, L, w->ctx_wst_stride,
-                                            w->ctx_vec_stride, st));
-    else GMF_HIP(gmf::launch_ctx_prep(true, imgfeat, w->ctx_wst, w->ctx_vec, ctxall, B, T, tt, L, w->ctx_wst_stride,
-                                      w->ctx_vec_stride, st));
-  }
-  // (the same launch clears the "pv_fp8" guard's statistics - a superset of the forwards that read them)
-  const bool may_guard = fuse && h->tune.pv_fp8 == 1 && w->pv_guard;
-  GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st, ptab, may_guard ? fstat : nullptr, may_guard ? (L + 1) * B * gmf::kPvStatStride : 0));
   // throughput numerics ("precision" = 1, 2): on the two-launch path of large grids the attention multiplies one fp16
   // product and streams the compat matrix as fp16 (level 2: the layer's linear stages multiply one product as well); every
   // other path keeps the parity numerics
@@ -606,7 +587,54 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
   // kernel (variant 18) is the cache's only reader
   cc.fmt = cc.half ? 1 : (want_cache && h->tune.scattn_variant == 18) ? h->tune.compat_format : 0;
   cc.ptab = ptab;
-  if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, cc.fmt, st, ptab));
+  // (the key-point packing also clears the "pv_fp8" guard's statistics - a superset of the forwards that read them)
+  const bool may_guard = fuse && h->tune.pv_fp8 == 1 && w->pv_guard;
+  unsigned* const zero_words = may_guard ? fstat : nullptr;
+  const int n_zero = may_guard ? (L + 1) * B * gmf::kPvStatStride : 0;
+  // [r5] small grids: the prologue is two independent chains of few-workgroup kernels - image side (Fusion-1 context, cross-attention,
+  // feed-forward) and point side (key points, compat cache, layer 0 + first PointCN).  Three launches carry one link of each
+  // (k_pro_*, encoder_h2.hip): the point side runs under the image side instead of behind it.  Same bodies: bit-identical.
+  // (where both roles of the third launch together leave every workgroup a CU of its own: it is built for one per CU)
+  const bool pro = h->tune.small_prologue && fuse && w->f1_ctx_wst_h2 && w->f1_attn_wst_h2 && w->f1_ff_wst_h2 && cc.fmt == 0 &&
+                   ((tiles + 3) / 4) * B + ((tt + 3) / 4) * B * 8 <= 256;
+  if (pro) {
+    GMF_HIP(gmf::launch_pro_ctx_pts(p_tokens, w->f1_ctx_wst_h2, w->f1_ctx_vec, f1ctx, B, T, tt, src_keypts, tgt_keypts, pts8, N, st, ptab,
+                                    zero_words, n_zero));
+    GMF_HIP(gmf::launch_pro_fattn_compat(q_tokens, f1ctx, w->f1_attn_wst_h2, w->f1_attn_vec, x1t, B, T, tt, pts8, c_dense, N, tiles,
+                                         w->sigma_d, st, ptab));
+    gmf::PvGuard g0;
+    if (may_guard) g0.stat_next = fstat;         // (small grids never run the throughput numerics: may_guard is `guarded` below)
+    int hs = 1;
+    GMF_HIP(gmf::launch_pro_ff_front(h->tune, x1t, w->f1_ff_wst_h2, w->f1_ff_vec, imgfeat, B, tt, tt <= tiles ? cc.part_o : nullptr,
+                                     tt <= tiles ? cc.max_splits : 0, corr_pos, w->front_wst_h2, w->front_vec, f, q, k, v, N, tiles, st,
+                                     ptab, g0, &hs));
+    if (hs > 1) GMF_HIP(gmf::launch_ff_reduce_h2(cc.part_o, x1t, w->f1_ff_vec, imgfeat, B, tt, hs, st));
+    GMF_HIP(gmf::launch_ctx_prep_h2(true, imgfeat, w->ctx_wst_h2, w->ctx_vec, ctxall, B, T, tt, L, w->ctx_wst_stride, w->ctx_vec_stride, st));
+  } else {
+    // Fusion-1: image_feat = FusionLayer(p_tok (context), queries = q_tok), pe = False (PointDSC.py:137)
+    if (h2 && w->f1_ctx_wst_h2 && w->f1_attn_wst_h2 && w->f1_ff_wst_h2) {
+      // (the two token tensors are read row-major: no packing launches in front of these few-workgroup kernels)
+      GMF_HIP(gmf::launch_ctx_prep_h2(false, p_tokens, w->f1_ctx_wst_h2, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st, true));
+      GMF_HIP(gmf::launch_fusion_attn_h2(false, q_tokens, f1ctx, w->f1_attn_wst_h2, w->f1_attn_vec, x1t, B, T, tt, T, tt, st, true));
+      GMF_HIP(gmf::launch_fusion_ff_h2(h->tune, x1t, w->f1_ff_wst_h2, w->f1_ff_vec, imgfeat, B, tt, st,
+                                       tt <= tiles ? cc.part_o : nullptr, tt <= tiles ? cc.max_splits : 0));
+    } else {
+      GMF_HIP(gmf::launch_pack_p32(p_tokens, pimg, B, T, kC, (long)T * kC, kC, 1, st));
+      GMF_HIP(gmf::launch_pack_p32(q_tokens, qimg, B, T, kC, (long)T * kC, kC, 1, st));
+      GMF_HIP(gmf::launch_ctx_prep(false, pimg, w->f1_ctx_wst, w->f1_ctx_vec, f1ctx, B, T, tt, 1, 0, 0, st));
+      GMF_HIP(gmf::launch_fusion_attn(false, qimg, f1ctx, w->f1_attn_wst, w->f1_attn_vec, x1t, B, T, tt, T, tt, st));
+      GMF_HIP(gmf::launch_fusion_ff(x1t, w->f1_ff_wst, w->f1_ff_vec, imgfeat, B, tt, st));
+    }
+    // context side of all L Fusion-2 layers in one launch
+    if (L > 0) {
+      if (h2) GMF_HIP(gmf::launch_ctx_prep_h2(true, imgfeat, w->ctx_wst_h2, w->ctx_vec, ctxall, B, T, tt, L, w->ctx_wst_stride,
+                                              w->ctx_vec_stride, st));
+      else GMF_HIP(gmf::launch_ctx_prep(true, imgfeat, w->ctx_wst, w->ctx_vec, ctxall, B, T, tt, L, w->ctx_wst_stride,
+                                        w->ctx_vec_stride, st));
+    }
+    GMF_HIP(gmf::launch_pack_pts8(src_keypts, tgt_keypts, pts8, B, N, st, ptab, zero_words, n_zero));
+    if (want_cache) GMF_HIP(gmf::launch_compat_build(pts8, c_dense, B, N, tiles, w->sigma_d, cc.fmt, st, ptab));
+  }
 
   float* cur = featA;
   float* nxt = featB;
@@ -630,7 +658,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
     // [r5] "pv_fp8" = 1: guarded per pair and layer on the device (PvGuard).  The statistics start at zero (k_pack_pts8); f_0's is raised by the
     // front kernel, f_{l+1}'s by the attention epilogue / merge kernels of layer l - always before the kernels that read it
     const bool guarded = cc.v_scale && h->tune.pv_fp8 == 1 && w->pv_guard;       // (implies may_guard: launch_pack_pts8 cleared fstat)
-    {
+    if (!pro) {                                   // (small grids: the prologue's third launch ran it)
       gmf::PvGuard g0;
       if (guarded) g0.stat_next = fstat;
       GMF_HIP(gmf::launch_front_h2(h->tune, 3, corr_pos, w->front_wst_h2, w->front_vec, f, q, k, v, B, N, tiles, st, ptab, nullptr, g0));

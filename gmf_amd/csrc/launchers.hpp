@@ -69,6 +69,7 @@ struct Tuning {
   bool small_roles = true;   // small grids: three launches per layer with two kinds of workgroups each (else five or six)
   bool fused_linear = true;  // one kernel per layer for Q'/K/V + Fusion-2 (k_linear_h2) with the next PointCN in the attention epilogue
   int conv_patch = 1;        // stride-1 3x3 convolutions: 1 = LDS patch kernel (automatic form), 2 = never three workgroups per CU, 0 = gather kernel
+  bool small_prologue = true;   // [r5] small grids: the prologue's two chains as roles of shared launches
   bool conv_small = true;    // [r5] grids of fewer than 128 workgroups of the 128-pixel convolution kernels (a few images): the K-split kernel
   int nms_binned = 1;        // 1 = grid-binned NMS candidates on large grids, 2 = always, 0 = all pairs
   bool topk_select = true;   // radix select of the S seeds (false = full bitonic sort)
@@ -143,6 +144,18 @@ hipError_t launch_ctx_prep_h2(bool pe, const float* ctx, const float* wst, const
                               int ttiles, int sets, int wst_stride, int vec_stride, hipStream_t s, bool rowmajor = false);
 hipError_t launch_fusion_attn_h2(bool pe, const float* x, const float* ctx_img, const float* wst, const float* vecs,
                                  float* x1, int B, int N, int tiles, int T, int ttiles, hipStream_t s, bool rowmajor = false);
+// [r5] small grids: the forward's prologue as three launches of two roles each (encoder_h2.hip, k_pro_*)
+hipError_t launch_pro_ctx_pts(const float* p_tokens, const float* wst, const float* vecs, float* f1ctx, int B, int T, int ttiles,
+                              const float* src, const float* tgt, float* pts8, int N, hipStream_t s, const PairTab* ptab,
+                              unsigned* zero_words, int n_zero);
+hipError_t launch_pro_fattn_compat(const float* q_tokens, const float* f1ctx, const float* wst, const float* vecs, float* x1t, int B,
+                                   int T, int ttiles, const float* pts8, float* c_dense, int N, int tiles, float sigma_d,
+                                   hipStream_t s, const PairTab* ptab);
+hipError_t launch_pro_ff_front(const Tuning& tune, const float* x1t, const float* wst, const float* vecs, float* imgfeat, int B,
+                               int ttiles, float* part, int max_parts, const float* corr_pos, const float* fwst, const float* fvecs,
+                               float* f, float* q, float* k, float* v, int N, int tiles, hipStream_t s, const PairTab* ptab,
+                               PvGuard guard, int* hs_out);
+hipError_t launch_ff_reduce_h2(const float* part, const float* x1, const float* vecs, float* x2, int B, int tiles, int hs, hipStream_t s);
 hipError_t launch_fusion_ff_h2(const Tuning& tune, const float* x1, const float* wst, const float* vecs, float* x2, int B,
                                int tiles, hipStream_t s, float* part = nullptr, int max_parts = 0);
 int padded_desc_width(int d);

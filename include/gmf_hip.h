@@ -145,6 +145,10 @@ int gmf_set_sigma_device(gmf_handle* h, const float* sigma_dev);
  *   "conv_small_grid"   : [ABI 5] 1 = grids of fewer than 128 workgroups of those kernels - a few images, e.g. the two of one scene pair - run
  *                         the K-split kernel: 32 pixels x 32 channels per workgroup, its four waves a quarter of the k range each
  *                         (default); 0 = the 128-pixel kernels at every size.  Same products, another accumulation order.
+ *   "small_prologue_roles": [ABI 5] 1 = on small grids the forward's prologue - two independent chains of few-workgroup kernels, image
+ *                         side (Fusion-1 context / cross-attention / feed-forward, fusion_layer.py:172-201) and point side (key points,
+ *                         compat cache PointDSC.py:216-221, layer 0 + first PointCN) - runs as three launches that carry one link of
+ *                         each chain as two workgroup roles (default; the kernels' own bodies: bit-identical results), 0 = six kernels.
  *   "nms_binned"        : 1 = grid-binned NMS candidates on large grids (default), 2 = always, 0 = all pairs.
  *   "topk_select"       : 1 = radix select of the S seeds (default), 0 = full bitonic sort.
  *   "q_in_attention"    : [ABI 4] 1 = on large grids every attention workgroup projects its own Q' in its prologue (default; PointDSC.py:56),

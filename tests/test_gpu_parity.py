@@ -1772,6 +1772,36 @@ def test_small_grid_merge_forms_are_bit_identical(model, B, N):
     assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][1], out[0][1])
 
 
+@pytest.mark.parametrize("B,N,T", [(1, 1000, 300), (1, 5000, 196), (2, 777, 33), (4, 3000, 300), (3, 200, 1), (1, 64, 700)])
+def test_small_grid_prologue_roles_are_bit_identical(model, B, N, T):
+    """[r5] Small grids: the forward's prologue - image side (Fusion-1 context, cross-attention, feed-forward; fusion_layer.py:172-201)
+    and point side (key points, compat cache PointDSC.py:216-221, layer 0 + first PointCN :88,104-109) - as three launches that
+    carry one link of each chain as two workgroup roles (k_pro_*), against the six kernels: the roles call the kernels' own bodies,
+    so logits and poses are bit-identical, for a uniform batch and for the same pairs as one ragged call."""
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    keys = ("corr_pos", "src_keypts", "tgt_keypts")
+    b = synthetic.synthetic_batch(list(range(70, 70 + B)), N=N, T=T)
+    data = {k: _gpu(b[k]) for k in keys + ("p_tokens", "q_tokens")}
+    data["testing"] = True
+    lens = [N - 5 * i for i in range(B)]
+    rag = {k: [data[k][i, :lens[i]] for i in range(B)] for k in keys}
+    rag.update(p_tokens=data["p_tokens"], q_tokens=data["q_tokens"], testing=True)
+    out = {}
+    try:
+        for form in (1, 0):
+            h.call("gmf_set_tuning", b"small_prologue_roles", form)
+            res = model(data)
+            u = (model.last_logits.clone(), res["final_trans"].clone())
+            rr = model(rag)
+            out[form] = u + (model.last_logits.clone(), rr["final_trans"].clone())
+    finally:
+        h.call("gmf_set_tuning", b"small_prologue_roles", 1)
+    assert torch.isfinite(out[1][0]).all() and torch.isfinite(out[1][2]).all()
+    for a, c in zip(out[1], out[0]):
+        assert torch.equal(a, c)
+
+
 def test_tuning_rejects_unknown_and_removed_settings():
     """The round-1 timing-only ablations (scattn_variant 11..15: wrong results) and the measured-and-rejected forms are no
     longer part of the library: gmf_set_tuning refuses them, out-of-range values and unknown knobs with GMF_ERR_BAD_ARG (-1)

@@ -449,7 +449,7 @@ def dgr_rows(dev, full):
     fb = torch.nn.functional.normalize(torch.randn(Nm, dm, device=dev), dim=1)
     ms = best_ms(lambda: gmf_amd.nn_match(fa, fb), 20)
     tf = 2.0 * dm * Nm * Nm / (ms * 1e-3) / 1e12
-    rows.append({"workload": f"descriptor matching (row f-2), {Nm} x {Nm} descriptors x {dm}-d, whole call (two packing launches, norms, match, winners)",
+    rows.append({"workload": f"descriptor matching (row f-2), {Nm} x {Nm} descriptors x {dm}-d, whole call (one preparation launch - both images, norms, identity of the minimum -, match, winners)",
                  "ms_per_step": ms, "value": Nm / (ms * 1e-3), "unit": "source descriptors/s", "algorithmic_tflops": tf,
                  "roofline": {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
                               "note": "f32 MFMA dense peak (v_mfma_f32_32x32x2_f32); the match kernel alone is 22 us of the call"}})

@@ -53,7 +53,7 @@ k_nn_match(const float* __restrict__ f0_img, const float* __restrict__ f1_img, c
       const int t = (s0 + st) * TPS + tt;
       if (t < tiles1) {
         // the norms of this lane's 16 keys (4 h + 8 g .. + 3 of the tile) as four 16-byte loads, requested before the MFMAs; keys
-        // beyond N1 carry +inf (k_row_norm2 pads the array to whole tiles), so they never win and need no index test
+        // beyond N1 carry +inf (k_match_prep pads the array to whole tiles), so they never win and need no index test
         const int jbase = t * 32 + 4 * h;
         const float4* np = reinterpret_cast<const float4*>(f1_norm2 + jbase);
         const float4 n0 = np[0], n1 = np[2], n2 = np[4], n3 = np[6];
@@ -107,20 +107,14 @@ k_nn_finish(const unsigned long long* __restrict__ best, const float* __restrict
   dist_out[row] = out;
 }
 
-// squared norms of the rows of F1 (mode 0 uses a constant: for unit descriptors argmin distance = argmax dot)
-// n2 holds whole tiles: entries N .. 32 * ceil(N / 32) - 1 are +inf (a key that does not exist never wins, k_nn_match)
-__global__ void k_row_norm2(const float* __restrict__ F, float* __restrict__ n2, int N, int d, int unit) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= ((N + 31) & ~31)) return;
-  if (r >= N) { n2[r] = INFINITY; return; }
-  float s = 0.f;
-  if (!unit) for (int k = 0; k < d; ++k) s = fmaf(F[(size_t)r * d + k], F[(size_t)r * d + k], s);
-  n2[r] = s;
-}
-
-// row-major [N, d] -> P32 image with K = padded width (extra columns zero)
-__global__ void k_pack_desc(const float* __restrict__ src, float* __restrict__ dst, int N, int d, int K, long total4) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// [r5] Everything k_nn_match needs, in ONE launch of four workgroup ranges (it was four launches - two packing kernels, the norms and
+// a 9 us fill kernel behind hipMemsetAsync - in front of a 22 us matching kernel):
+//   [0, b0)   F0 row-major [N0, d] -> P32 image with K = padded width (extra columns zero)
+//   [b0, b1)  F1 likewise
+//   [b1, b2)  squared norms of the rows of F1 (mode 0 uses a constant: for unit descriptors argmin distance = argmax dot); n2 holds
+//             whole tiles: entries N1 .. 32 * ceil(N1 / 32) - 1 are +inf (a key that does not exist never wins, k_nn_match)
+//   [b2, ..)  best[row] = all ones (the identity of the 64-bit atomic minimum)
+GMF_DEVINL void pack_desc(const long idx, const float* __restrict__ src, float* __restrict__ dst, int N, int d, int K, long total4) {
   if (idx >= total4) return;
   const int lane = idx & 63;
   const long gi = idx >> 6;
@@ -135,6 +129,25 @@ __global__ void k_pack_desc(const float* __restrict__ src, float* __restrict__ d
   reinterpret_cast<float4*>(dst)[idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+__global__ void k_match_prep(const float* __restrict__ F0, const float* __restrict__ F1, float* __restrict__ f0_img,
+                             float* __restrict__ f1_img, float* __restrict__ n2, unsigned long long* __restrict__ best, int N0, int N1,
+                             int d, int K, long n40, long n41, int unit, int b0, int b1, int b2) {
+  const int blk = blockIdx.x;
+  if (blk < b0) { pack_desc((long)blk * 256 + threadIdx.x, F0, f0_img, N0, d, K, n40); return; }
+  if (blk < b1) { pack_desc((long)(blk - b0) * 256 + threadIdx.x, F1, f1_img, N1, d, K, n41); return; }
+  if (blk < b2) {
+    const int r = (blk - b1) * 256 + threadIdx.x;
+    if (r >= ((N1 + 31) & ~31)) return;
+    if (r >= N1) { n2[r] = INFINITY; return; }
+    float s = 0.f;
+    if (!unit) for (int k = 0; k < d; ++k) s = fmaf(F1[(size_t)r * d + k], F1[(size_t)r * d + k], s);
+    n2[r] = s;
+    return;
+  }
+  const int r = (blk - b2) * 256 + threadIdx.x;
+  if (r < N0) best[r] = ~0ull;
+}
+
 int padded_desc_width(int d) { return d <= 32 ? 32 : d <= 40 ? 40 : d <= 64 ? 64 : d <= 128 ? 128 : -1; }
 
 hipError_t launch_nn_match(const float* F0, const float* F1, float* f0_img, float* f1_img, float* norm2, unsigned long long* best,
@@ -143,10 +156,11 @@ hipError_t launch_nn_match(const float* F0, const float* F1, float* f0_img, floa
   if (K < 0) return hipErrorInvalidValue;
   const int t0 = (N0 + 31) / 32, t1 = (N1 + 31) / 32;
   const long n40 = (long)t0 * (K / 8) * 64, n41 = (long)t1 * (K / 8) * 64;
-  hipLaunchKernelGGL(k_pack_desc, dim3((unsigned)((n40 + 255) / 256)), dim3(256), 0, s, F0, f0_img, N0, d, K, n40);
-  hipLaunchKernelGGL(k_pack_desc, dim3((unsigned)((n41 + 255) / 256)), dim3(256), 0, s, F1, f1_img, N1, d, K, n41);
-  hipLaunchKernelGGL(k_row_norm2, dim3((t1 * 32 + 255) / 256), dim3(256), 0, s, F1, norm2, N1, d, mode == 0 ? 1 : 0);
-  if (hipError_t e = hipMemsetAsync(best, 0xff, (size_t)N0 * sizeof(unsigned long long), s)) return e;
+  {
+    const int b0 = (int)((n40 + 255) / 256), b1 = b0 + (int)((n41 + 255) / 256), b2 = b1 + (t1 * 32 + 255) / 256, b3 = b2 + (N0 + 255) / 256;
+    hipLaunchKernelGGL(k_match_prep, dim3(b3), dim3(256), 0, s, F0, F1, f0_img, f1_img, norm2, best, N0, N1, d, K, n40, n41,
+                       mode == 0 ? 1 : 0, b0, b1, b2);
+  }
   // key splits: about four workgroups per CU in all (two are resident), every split at least two stages long
   const int tps = (4096 / (32 * K)) > 0 ? (4096 / (32 * K)) : 1;
   const int stages = (t1 + tps - 1) / tps, wg0 = (t0 + 3) / 4;

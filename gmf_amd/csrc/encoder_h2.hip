@@ -668,8 +668,10 @@ k_pro_fattn_compat(const int n_a, const int gx_a, const float* __restrict__ xin,
 }
 
 constexpr int kProCLdsFloats = (kRing > 4 ? kRing : 4) * kStageFloats;
-template <bool SPLIT>
-__global__ void __launch_bounds__(256, 1)          // (small grids: a CU never holds two of these; the two roles' union wants a few registers over 256)
+// MINB = 1: grids of at most one workgroup per CU (the two roles' union wants a few registers over 256: with 512 there is no scratch);
+// MINB = 2: larger ones, two workgroups per CU as the kernels of both roles run on their own (SPLIT: 12 bytes of scratch per lane)
+template <bool SPLIT, int MINB>
+__global__ void __launch_bounds__(256, MINB)
 k_pro_ff_front(const int n_a, const int gx_a, const int nb, const int hs, const float* __restrict__ x1, const float* __restrict__ wst,
                const float* __restrict__ vecs, float* __restrict__ x2_out, int ttiles, float* __restrict__ part,
                const int gx_f, const float* __restrict__ in, const float* __restrict__ fwst, const float* __restrict__ fvecs,
@@ -1104,12 +1106,13 @@ hipError_t launch_pro_ff_front(const Tuning& tune, const float* x1t, const float
   const dim3 ga = tgrid(ttiles, B), gf = tgrid(tiles, B);
   const int hs = part ? plan_ff_split(tune, ga.x * B, max_parts) : 1;
   const int n_a = (int)(ga.x * B) * hs, n_b = (int)(gf.x * B);
-  if (hs > 1)
-    hipLaunchKernelGGL(k_pro_ff_front<true>, dim3(n_a + n_b), dim3(256), 0, s, n_a, (int)ga.x, B, hs, x1t, wst, vecs, imgfeat, ttiles, part,
-                       (int)gf.x, corr_pos, fwst, fvecs, f, q, k, v, N, tiles, ptab, guard);
-  else
-    hipLaunchKernelGGL(k_pro_ff_front<false>, dim3(n_a + n_b), dim3(256), 0, s, n_a, (int)ga.x, B, 1, x1t, wst, vecs, imgfeat, ttiles,
-                       (float*)nullptr, (int)gf.x, corr_pos, fwst, fvecs, f, q, k, v, N, tiles, ptab, guard);
+#define GMF_PRO_C(SPLIT, MINB, HS, PART)                                                                                              \
+  hipLaunchKernelGGL((k_pro_ff_front<SPLIT, MINB>), dim3(n_a + n_b), dim3(256), 0, s, n_a, (int)ga.x, B, HS, x1t, wst, vecs, imgfeat, ttiles, \
+                     PART, (int)gf.x, corr_pos, fwst, fvecs, f, q, k, v, N, tiles, ptab, guard)
+  const bool one_per_cu = n_a + n_b <= 256;
+  if (hs > 1) { if (one_per_cu) GMF_PRO_C(true, 1, hs, part); else GMF_PRO_C(true, 2, hs, part); }
+  else { if (one_per_cu) GMF_PRO_C(false, 1, 1, (float*)nullptr); else GMF_PRO_C(false, 2, 1, (float*)nullptr); }
+#undef GMF_PRO_C
   *hs_out = hs;
   return hipGetLastError();
 }

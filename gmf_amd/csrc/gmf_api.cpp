@@ -594,9 +594,8 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
   // [r5] small grids: the prologue is two independent chains of few-workgroup kernels - image side (Fusion-1 context, cross-attention,
   // feed-forward) and point side (key points, compat cache, layer 0 + first PointCN).  Three launches carry one link of each
   // (k_pro_*, encoder_h2.hip): the point side runs under the image side instead of behind it.  Same bodies: bit-identical.
-  // (where both roles of the third launch together leave every workgroup a CU of its own: it is built for one per CU)
   const bool pro = h->tune.small_prologue && fuse && w->f1_ctx_wst_h2 && w->f1_attn_wst_h2 && w->f1_ff_wst_h2 && cc.fmt == 0 &&
-                   ((tiles + 3) / 4) * B + ((tt + 3) / 4) * B * 8 <= 256;
+                   ((tiles + 3) / 4) * B < 256;
   if (pro) {
     GMF_HIP(gmf::launch_pro_ctx_pts(p_tokens, w->f1_ctx_wst_h2, w->f1_ctx_vec, f1ctx, B, T, tt, src_keypts, tgt_keypts, pts8, N, st, ptab,
                                     zero_words, n_zero));

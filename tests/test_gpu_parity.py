@@ -1772,7 +1772,7 @@ def test_small_grid_merge_forms_are_bit_identical(model, B, N):
     assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][1], out[0][1])
 
 
-@pytest.mark.parametrize("B,N,T", [(1, 1000, 300), (1, 5000, 196), (2, 777, 33), (4, 3000, 300), (3, 200, 1), (1, 64, 700)])
+@pytest.mark.parametrize("B,N,T", [(1, 1000, 300), (1, 5000, 196), (2, 777, 33), (4, 3000, 300), (3, 200, 1), (1, 64, 700), (16, 1000, 300)])
 def test_small_grid_prologue_roles_are_bit_identical(model, B, N, T):
     """[r5] Small grids: the forward's prologue - image side (Fusion-1 context, cross-attention, feed-forward; fusion_layer.py:172-201)
     and point side (key points, compat cache PointDSC.py:216-221, layer 0 + first PointCN :88,104-109) - as three launches that

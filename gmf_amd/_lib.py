@@ -151,6 +151,7 @@ SIGNATURES = {
                                 _vp, _vp, _vp, _vp]),
     "gmf_pick_seeds": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _vp, _vp]),
     "gmf_knn_rows": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "gmf_knn_from_distances": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "gmf_nn_match": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "gmf_procrustes_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp]),
     "gmf_post_refinement": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp]),

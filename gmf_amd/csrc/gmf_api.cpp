@@ -982,6 +982,15 @@ static int pose_head_impl(gmf_handle* h, const gmf_pose_params* p, const float* 
   return GMF_OK;
 }
 
+int gmf_knn_from_distances(gmf_handle* h, const float* dist, int B, int N, int Sn, int k, int* knn_out, gmf_stream_t stream) {
+  GMF_REQUIRE(h && dist && knn_out, GMF_ERR_BAD_ARG, "knn_from_distances: null pointer");
+  GMF_REQUIRE(B > 0 && N > 1 && Sn > 0 && k > 0 && k <= 63 && k <= N - 1, GMF_ERR_UNSUPPORTED_SHAPE,
+              "knn_from_distances: need 0 < k <= min(63, N - 1)");
+  SetDevice sd(h, stream);
+  GMF_HIP(gmf::launch_knn_seeds(nullptr, nullptr, dist, knn_out, B, N, Sn, k, S(stream), nullptr));
+  return GMF_OK;
+}
+
 int gmf_knn_rows(gmf_handle* h, const float* feat_n, const int* rows, int B, int N, int Sn, int k, int* knn_out,
                  gmf_stream_t stream) {
   GMF_REQUIRE(h && feat_n && rows && knn_out, GMF_ERR_BAD_ARG, "knn_rows: null pointer");

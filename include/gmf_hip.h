@@ -383,6 +383,13 @@ int gmf_pick_seeds(gmf_handle* h, const float* src_keypts, const float* scores, 
 int gmf_knn_rows(gmf_handle* h, const float* feat_n, const int* rows, int B, int N, int S, int k, int* knn_out,
                  gmf_stream_t stream);
 
+/* [ABI 5] The selection step alone: the k smallest entries behind rank 0 of every given DISTANCE row, under the order (distance,
+ * index) - `topk(k + 1, largest=False)[1][..., 1:]` of models/common.py:71-74 for rows the caller has formed itself (gmf_amd.knn with
+ * `normalized=False` or a feature width other than 128: distances xx_i - 2 x_i.x_j + xx_j from gmf_gemm_f32, common.py:64-69).
+ * dist [B, S, ld] with ld = 32 * ceil(N / 32) floats per row (columns N .. ld - 1 are not read) -> knn_out [B, S, k] int32,
+ * nearest first.  0 < k <= 63, k <= N - 1; any N. */
+int gmf_knn_from_distances(gmf_handle* h, const float* dist, int B, int N, int S, int k, int* knn_out, gmf_stream_t stream);
+
 /* Descriptor-space nearest neighbour: for every row of F0 [N0,d] the closest row of F1 [N1,d] (row-major, d <= 128),
  * ties to the lower index, fused distance GEMM + row argmin (no N0 x N1 matrix).
  *   mode 0: PointDSC matching (datasets/ThreeDMatch.py:164-166, demo_registration.py:101-103), unit descriptors:

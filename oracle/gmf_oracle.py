@@ -247,6 +247,19 @@ def knn_indices(x, k: int):
     return d.topk(k + 1, dim=-1, largest=False)[1][:, :, 1:]
 
 
+def knn(x, k: int, ignore_self: bool = False, normalized: bool = True):
+    """The reference's knn with all its flags (common.py:53-75): x [bs, N, C] -> [bs, N, k] indices."""
+    inner = 2 * torch.matmul(x, x.transpose(2, 1))
+    if normalized:
+        d = 2 - inner
+    else:
+        xx = torch.sum(x ** 2, dim=-1, keepdim=True)
+        d = xx - inner + xx.transpose(2, 1)
+    if not ignore_self:
+        return d.topk(k=k, dim=-1, largest=False)[1]
+    return d.topk(k=k + 1, dim=-1, largest=False)[1][:, :, 1:]
+
+
 def power_iteration(M, iters: int):
     """Leading eigenvector with global allclose early exit (PointDSC.py:437-448).  M [n,k,k] -> [n,k]."""
     v = torch.ones_like(M[:, :, :1])

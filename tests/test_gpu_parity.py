@@ -2844,8 +2844,19 @@ def test_public_knn_op():
         # [r5] ignore_self=False (common.py:70-71): top-k INCLUDING rank 0 = the row itself followed by its k - 1 nearest
         got0 = gmf_amd.knn(_gpu(x), k, ignore_self=False, normalized=True).cpu()
         assert torch.equal(got0[:, :, 0], torch.arange(N).repeat(B, 1)) and torch.equal(got0[:, :, 1:], got[:, :, :k - 1])
-    with pytest.raises(NotImplementedError):
-        gmf_amd.knn(_gpu(x), 5, ignore_self=True, normalized=False)
+    # [r5] normalized=False (xx - 2 x x^T + xx^T, common.py:66-68) and other feature widths: fp32-MFMA distance rows + the same
+    # selection.  Unnormalised rows of very different lengths, against the oracle's knn with the same flags
+    for B, N, Cw, k, norm in ((2, 777, 128, 10, False), (1, 3000, 64, 20, False), (3, 100, 33, 9, False), (2, 500, 32, 8, True)):
+        x = torch.randn(B, N, Cw, generator=g) * (0.2 + 3.0 * torch.rand(B, N, 1, generator=g))
+        if norm:
+            x = torch.nn.functional.normalize(x, dim=-1)
+        for ign in (True, False):
+            got = gmf_amd.knn(_gpu(x), k, ignore_self=ign, normalized=norm).cpu()
+            ref = O.knn(x, k, ignore_self=ign, normalized=norm)
+            assert got.shape == ref.shape and int(got.min()) >= 0 and int(got.max()) < N
+            same_set = (torch.sort(got, -1)[0] == torch.sort(ref, -1)[0]).float().mean()
+            same_seq = (got == ref).float().mean()
+            assert same_set > 0.999 and same_seq > 0.99, (B, N, Cw, norm, ign, float(same_set), float(same_seq))
     x = _gpu(torch.nn.functional.normalize(torch.randn(3, 20000, 128, generator=g), dim=-1))
     sliced = gmf_amd.knn(x, 40, ignore_self=True, normalized=True)       # 3 x 20000 x 20000 floats > 4 GiB: slices
     for b in range(3):

@@ -1802,6 +1802,38 @@ def test_small_grid_prologue_roles_are_bit_identical(model, B, N, T):
         assert torch.equal(a, c)
 
 
+def test_random_shapes_against_the_oracle(model, sd_full):
+    """Shape fuzz (the standing version of tests/tools/shape_fuzz.py): every grid plan of the encoder - one kernel per stage, mixed-role
+    small grids, per-tile roles, key / hidden splits, prologue roles, the two-launch form - is picked by (B, N, T), and a plan that
+    is wrong for some size only shows at that size.  Ten seeded random shapes with odd N and T, uniform and as one ragged call with
+    per-pair lengths, against the CPU oracle (PointDSC.py:125-181) under the floor-relative contract of the fixed-size tests."""
+    rng = np.random.default_rng(17)
+    keys = ("corr_pos", "src_keypts", "tgt_keypts")
+    for case in range(10):
+        B = int(rng.integers(1, 7))
+        N = int(rng.choice([int(rng.integers(64, 400)), int(rng.integers(400, 1400)), int(rng.integers(1400, 2300))]))
+        T = int(rng.choice([1, 7, 31, 33, 100, 196, 257, 300]))
+        if B * N > 6000:
+            B = max(1, 6000 // N)
+        b = synthetic.synthetic_batch([4000 + 10 * case + i for i in range(B)], N=N, T=T)
+        ref = O.pointdsc_forward(sd_full, b, testing=True)
+        data = {k: _gpu(b[k]) for k in keys + ("p_tokens", "q_tokens")}
+        data["testing"] = True
+        model(data)
+        e = _maxerr(model.last_logits.cpu(), ref["logits"])
+        lens = [N - 3 * i for i in range(B)]
+        er = 0.0
+        if B > 1 and min(lens) >= 64:
+            rag = {k: [data[k][i, :lens[i]] for i in range(B)] for k in keys}
+            rag.update(p_tokens=data["p_tokens"], q_tokens=data["q_tokens"], testing=True)
+            lg = model(rag)["logits"]
+            for i in range(B):
+                bi = {k: (b[k][i:i + 1, :lens[i]] if k in keys + ("gt_labels",) else b[k][i:i + 1]) for k in b if torch.is_tensor(b[k])}
+                er = max(er, _maxerr(lg[i].cpu(), O.pointdsc_forward(sd_full, bi, testing=True)["logits"][0]))
+        print(f"fuzz case {case}: B={B} N={N} T={T}: uniform {e:.2e}, ragged {er:.2e}")
+        assert e < 2.5e-4 and er < 2.5e-4, (B, N, T, e, er)       # (a wrong plan is off by 1e-2 and more; the parity gates proper are the fixed-size tests)
+
+
 def test_tuning_rejects_unknown_and_removed_settings():
     """The round-1 timing-only ablations (scattn_variant 11..15: wrong results) and the measured-and-rejected forms are no
     longer part of the library: gmf_set_tuning refuses them, out-of-range values and unknown knobs with GMF_ERR_BAD_ARG (-1)

@@ -1834,6 +1834,49 @@ def test_random_shapes_against_the_oracle(model, sd_full):
         assert e < 2.5e-4 and er < 2.5e-4, (B, N, T, e, er)       # (a wrong plan is off by 1e-2 and more; the parity gates proper are the fixed-size tests)
 
 
+def test_alternate_forms_behind_knobs_agree(model):
+    """The forms that are reachable on their own grids AND through a knob, each against the default on a grid where the default is
+    the other form: same products, another order of partial sums - logits to fp32 rounding, poses to 1e-5.  `attn_tail_split` (the last
+    partial round of a large attention grid split by keys, k_scattn_merge), `small_fattn_tile` = 0 (the cross-attention role per four
+    query tiles, fusion_layer.py:84-94), `conv_small_grid` = 0 (the 128-pixel convolution kernels on a two-image grid, resnet.py:195-216)."""
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    keys = ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")
+    # (18 x 3970: 576 attention items on 512 workgroup slots - a partial last round, which is what the tail split splits)
+    cases = [("attn_tail_split", 1, 0, 18, 3970), ("small_fattn_tile", 0, 1, 1, 1500)]
+    for knob, alt, default, B, N in cases:
+        b = synthetic.synthetic_batch(list(range(900, 900 + B)), N=N, T=300)
+        data = {k: _gpu(b[k]) for k in keys}
+        data["testing"] = True
+        out = {}
+        try:
+            for v in (default, alt):
+                h.call("gmf_set_tuning", knob.encode(), v)
+                r = model(data)
+                out[v] = (model.last_logits.clone(), r["final_trans"].clone())
+        finally:
+            h.call("gmf_set_tuning", knob.encode(), default)
+        dl, dT = _maxerr(out[alt][0].cpu(), out[default][0].cpu()), _maxerr(out[alt][1].cpu(), out[default][1].cpu())
+        print(f"{knob} = {alt} against {default} at {B} x {N}: logits {dl:.2e}, poses {dT:.2e}")
+        assert torch.isfinite(out[alt][0]).all() and dl < 3e-5 and dT < 1e-5, (knob, dl, dT)
+    # the image encoder on two images, eager (a captured graph would replay whatever form it was captured with)
+    m = _image_model(5)
+    m.encoder.graph_image_encoder = False
+    img = _gpu(synthetic.seeded_images(2, 120, 160))
+    tok = {}
+    try:
+        for v in (1, 0):
+            h.call("gmf_set_tuning", b"conv_small_grid", v)
+            with torch.no_grad():
+                tok[v] = m.encoder.image_tokens(img).clone()
+    finally:
+        h.call("gmf_set_tuning", b"conv_small_grid", 1)
+    dt = _maxerr(tok[0].cpu(), tok[1].cpu())
+    print(f"conv_small_grid = 0 against 1 on two images: tokens {dt:.2e} (largest {float(tok[1].abs().max()):.2f})")
+    assert torch.isfinite(tok[0]).all() and dt < 1e-5 * max(1.0, float(tok[1].abs().max()))
+    gmf_amd.check_status()
+
+
 def test_tuning_rejects_unknown_and_removed_settings():
     """The round-1 timing-only ablations (scattn_variant 11..15: wrong results) and the measured-and-rejected forms are no
     longer part of the library: gmf_set_tuning refuses them, out-of-range values and unknown knobs with GMF_ERR_BAD_ARG (-1)

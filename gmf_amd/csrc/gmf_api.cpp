@@ -1193,7 +1193,7 @@ int gmf_stem_forward(gmf_handle* h, const float* x, long long sb, long long sc, 
   GMF_REQUIRE(B > 0 && H > 0 && W > 0, GMF_ERR_UNSUPPORTED_SHAPE, "stem_forward: empty input");
   GMF_REQUIRE(B <= 65535, GMF_ERR_UNSUPPORTED_SHAPE, "stem_forward: at most 65535 images per call");
   SetDevice sd(h, stream);
-  GMF_HIP(gmf::launch_stem_h2(x, (long)sb, (long)sc, (long)sh, (long)sw, wimg, bias, y, B, H, W, S(stream)));
+  GMF_HIP(gmf::launch_stem_h2(x, (long)sb, (long)sc, (long)sh, (long)sw, wimg, bias, y, B, H, W, S(stream), h->tune.conv_small));
   return GMF_OK;
 }
 

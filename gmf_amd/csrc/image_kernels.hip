@@ -399,18 +399,21 @@ k_bias_relu_nhwc(float* __restrict__ y, const float* __restrict__ bias, const fl
 // Weight image (packing.stem_image): 16-byte unit ((ks * 2 + blk) * 2 + plane) * 64 + lane, lane (h, j) holding
 // W'[32 blk + j][k = 16 ks + 8 h .. + 7], k = 24 ky + 3 kx + c.
 // =========================================================================================
-constexpr int kStemPT = 8;                          // pooled tile edge
-constexpr int kStemCT = 2 * kStemPT + 1;            // convolution tile edge (17)
-constexpr int kStemIT = 2 * kStemCT + 5;            // input patch edge (39)
-constexpr int kStemRow = kStemIT * 3 + 3;           // patch row stride in floats (120: even, so 8-byte reads stay aligned)
-constexpr int kStemRows = kStemIT + 1;              // + one zero row: the padded k-steps (ky = 7) read below the patch
 constexpr int kStemCS = 68;                         // convolution tile row stride in floats (64 channels + 4)
 constexpr int kStemKS = 11;
 
+// kStemPT = pooled tile edge: 8 (a workgroup's waves own up to three 32-pixel convolution tiles each), or - [r5] grids of a few images,
+// e.g. the two of one scene pair: 40 workgroups of the 8 x 8 form on 256 CUs - 4: a 9 x 9 convolution tile = three 32-pixel tiles, one per
+// wave, four times the workgroups and a third of the chain per wave.  Same products in the same order per pixel: bit-identical.
+template <int kStemPT>
 __global__ void __launch_bounds__(256, 2)
 k_stem_h2(const float* __restrict__ x, long sb, long sc, long sh, long sw, const float* __restrict__ wimg,
           const float* __restrict__ bias, float* __restrict__ y, int H, int W, int Hc, int Wc, int Hp, int Wp) {
-  __shared__ __attribute__((aligned(16))) float lds[kStemCT * kStemCT * kStemCS];      // 19 652 floats >= the 4 800 of the patch
+  constexpr int kStemCT = 2 * kStemPT + 1;            // convolution tile edge (17 | 9)
+  constexpr int kStemIT = 2 * kStemCT + 5;            // input patch edge (39 | 23)
+  constexpr int kStemRow = kStemIT * 3 + 3;           // patch row stride in floats (120 | 72: even, so 8-byte reads stay aligned)
+  constexpr int kStemRows = kStemIT + 1;              // + one zero row: the padded k-steps (ky = 7) read below the patch
+  __shared__ __attribute__((aligned(16))) float lds[kStemCT * kStemCT * kStemCS];      // 19 652 floats >= the 4 800 of the patch (PT = 8)
   static_assert(kStemRows * kStemRow <= kStemCT * kStemCT * kStemCS, "the patch fits under the convolution tile");
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -430,18 +433,19 @@ k_stem_h2(const float* __restrict__ x, long sb, long sc, long sh, long sw, const
   }
   __syncthreads();
   // ---- 2. implicit GEMM ---------------------------------------------------------------------------------------------
-  constexpr int NPIX = kStemCT * kStemCT;          // 289
-  int aoff[3];                                     // patch offset (floats) of the window origin of this lane's pixel, per tile
+  constexpr int NPIX = kStemCT * kStemCT;          // 289 | 81
+  constexpr int NT = (NPIX + 31) / 32, TS = (NT + 3) / 4;      // 32-pixel tiles (10 | 3), tile slots per wave (3 | 1)
+  int aoff[TS];                                    // patch offset (floats) of the window origin of this lane's pixel, per tile
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
+  for (int t = 0; t < TS; ++t) {
     const int p = min(32 * (wave + 4 * t) + i, NPIX - 1);
     const int cy = p / kStemCT, cx = p - cy * kStemCT;
     aoff[t] = (2 * cy) * kStemRow + (2 * cx) * 3;
   }
-  const int n_tiles = (wave + 8 < (NPIX + 31) / 32) ? 3 : 2;      // 10 tiles: waves 0, 1 own three
-  f32x16 acc[3][2];
+  const int n_tiles = (NT - wave + 3) / 4;         // tiles wave, wave + 4, ... below NT (10 tiles: waves 0, 1 own three; 3 tiles: waves 0 - 2 one)
+  f32x16 acc[TS][2];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) { acc[t][0] = zero16(); acc[t][1] = zero16(); }
+  for (int t = 0; t < TS; ++t) { acc[t][0] = zero16(); acc[t][1] = zero16(); }
   const f16x8* wp = reinterpret_cast<const f16x8*>(wimg) + lane;
   f16x8 wcur[2][2], wnxt[2][2];
 #pragma unroll
@@ -458,7 +462,7 @@ k_stem_h2(const float* __restrict__ x, long sb, long sc, long sh, long sw, const
     const int k0 = 16 * ks + 8 * h, ky = k0 / 24, ko = k0 - 24 * ky;       // per K-half: one kernel row, offset 0 / 8 / 16
     const int koff = ky * kStemRow + ko;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < TS; ++t) {
       if (t < n_tiles) {
         const float2* ap = reinterpret_cast<const float2*>(lds + aoff[t] + koff);
         float a[8];
@@ -477,7 +481,7 @@ k_stem_h2(const float* __restrict__ x, long sb, long sc, long sh, long sw, const
   // ---- 3. convolution tile -> LDS: D = mfma(A = pixels, B = weights) has the CHANNEL on the lane (32 blk + i) and the
   //         pixels 8 (r >> 2) + 4 h + (r & 3) of the tile in the registers
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
+  for (int t = 0; t < TS; ++t) {
     if (t < n_tiles) {
       const int pbase = 32 * (wave + 4 * t);
 #pragma unroll
@@ -514,10 +518,15 @@ k_stem_h2(const float* __restrict__ x, long sb, long sc, long sh, long sw, const
 }
 
 hipError_t launch_stem_h2(const float* x, long sb, long sc, long sh, long sw, const float* wimg, const float* bias, float* y,
-                          int B, int H, int W, hipStream_t s) {
+                          int B, int H, int W, hipStream_t s, bool small_grid) {
   const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;
-  const dim3 grid((Wp + kStemPT - 1) / kStemPT, (Hp + kStemPT - 1) / kStemPT, B);
-  hipLaunchKernelGGL(k_stem_h2, grid, dim3(256), 0, s, x, sb, sc, sh, sw, wimg, bias, y, H, W, Hc, Wc, Hp, Wp);
+  const dim3 grid((Wp + 7) / 8, (Hp + 7) / 8, B);
+  if ((long)grid.x * grid.y * grid.z < 128 && small_grid) {
+    const dim3 gs((Wp + 3) / 4, (Hp + 3) / 4, B);
+    hipLaunchKernelGGL(k_stem_h2<4>, gs, dim3(256), 0, s, x, sb, sc, sh, sw, wimg, bias, y, H, W, Hc, Wc, Hp, Wp);
+  } else {
+    hipLaunchKernelGGL(k_stem_h2<8>, grid, dim3(256), 0, s, x, sb, sc, sh, sw, wimg, bias, y, H, W, Hc, Wc, Hp, Wp);
+  }
   return hipGetLastError();
 }
 

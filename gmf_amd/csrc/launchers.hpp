@@ -229,7 +229,7 @@ hipError_t launch_sim_bwd_G(const float* S, const float* dM, float* G, float* ro
 
 // image encoder epilogue (row f-1): image_kernels.hip
 hipError_t launch_stem_h2(const float* x, long sb, long sc, long sh, long sw, const float* wimg, const float* bias, float* y,
-                          int B, int H, int W, hipStream_t s);
+                          int B, int H, int W, hipStream_t s, bool small_grid = true);   // small_grid: Tuning::conv_small
 hipError_t launch_bias_relu_nhwc(float* y, const float* bias, const float* residual, long n_pixels, int C, hipStream_t s);
 hipError_t launch_conv_nhwc_h2(const Tuning& tune, const float* x, const float* wimg, const float* bias, const float* residual, float* y, int B,
                                int H, int W, int cin, int cout, int ks, int stride, int relu, hipStream_t s);

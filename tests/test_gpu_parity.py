@@ -1874,6 +1874,19 @@ def test_alternate_forms_behind_knobs_agree(model):
     dt = _maxerr(tok[0].cpu(), tok[1].cpu())
     print(f"conv_small_grid = 0 against 1 on two images: tokens {dt:.2e} (largest {float(tok[1].abs().max()):.2f})")
     assert torch.isfinite(tok[0]).all() and dt < 1e-5 * max(1.0, float(tok[1].abs().max()))
+    # the stem alone: its small-grid form (4 x 4 pooled pixels per workgroup) multiplies the same products in the same order per pixel
+    # as the 8 x 8 form - bit-identical, odd image sizes included (resnet.py:198-204)
+    fused = m.encoder._fused_image_encoder()
+    for n, H, W in ((2, 120, 160), (1, 97, 131)):
+        im = _gpu(synthetic.seeded_images(n, H, W))
+        st = {}
+        try:
+            for v in (1, 0):
+                h.call("gmf_set_tuning", b"conv_small_grid", v)
+                st[v] = fused._stem(im).clone()
+        finally:
+            h.call("gmf_set_tuning", b"conv_small_grid", 1)
+        assert torch.equal(st[0], st[1]) and torch.isfinite(st[1]).all()
     gmf_amd.check_status()
 
 

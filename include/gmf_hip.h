@@ -144,7 +144,8 @@ int gmf_set_sigma_device(gmf_handle* h, const float* sigma_dev);
  *                         Same products, another order of the softmax's partial sums.
  *   "conv_small_grid"   : [ABI 5] 1 = grids of fewer than 128 workgroups of those kernels - a few images, e.g. the two of one scene pair - run
  *                         the K-split kernel: 32 pixels x 32 channels per workgroup, its four waves a quarter of the k range each
- *                         (default); 0 = the 128-pixel kernels at every size.  Same products, another accumulation order.
+ *                         (default), and the stem kernel 4 x 4 instead of 8 x 8 pooled pixels per workgroup (bit-identical);
+ *                         0 = the 128-pixel kernels at every size.  Same products, another accumulation order.
  *   "small_prologue_roles": [ABI 5] 1 = on small grids the forward's prologue - two independent chains of few-workgroup kernels, image
  *                         side (Fusion-1 context / cross-attention / feed-forward, fusion_layer.py:172-201) and point side (key points,
  *                         compat cache PointDSC.py:216-221, layer 0 + first PointCN) - runs as three launches that carry one link of

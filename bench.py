@@ -250,7 +250,7 @@ def main():
         "metric": "correspondences/sec (whole node)", "value": value, "unit": "correspondences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (split-fp16 MFMA operands, fp32 accumulate; the two cross products of the attention's P.V on block-scaled e4m3 operands wherever the device-side score guard allows)", "data": "synthetic",
+        "dtype": "f32 (split-fp16 MFMA operands, fp32 accumulate; the cross products of the attention's two contractions, S = K Q'^T and O = P V, on block-scaled e4m3 operands wherever the device-side score guard allows)", "data": "synthetic",
         "config": {"workload": f"synthetic {args.kind}-shape pairs, PointDSC.forward test mode (logits + R,t)",
                    "pairs_per_gpu": B, "global_pairs": world * B, "n_corr": N, "feat_dim": 128, "image_tokens": T,
                    "layers": 12, "parallelism": f"pairs sharded over {world} GPU(s), one RCCL all-gather of packed logits+poses"},

@@ -108,6 +108,14 @@ PATCHES = {
     "r5_dma_0_8": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 0) issue_k4(t);\n        if (u == 8) issue_v4(t);\n")],
     "r5_dma_8_16": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 8) issue_k4(t);\n        if (u == 16) issue_v4(t);\n")],
     "r5_dma_v_first": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 4) issue_v4(t);\n        if (u == 14) issue_k4(t);\n")],
+    # [r5, late] the wait at the tile top (attn_timeline.py: 458 of a wave's ~4200 cycles per tile) covers the V pieces issued at unit 23 of
+    # the previous tile, which nothing reads before unit 21: timing-only (the counts are wrong in a workgroup's last tiles)
+    "r5_vm4": [(EK, '    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n    __syncthreads();\n    vsw = vsw_next;\n',
+                '    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");\n    __syncthreads();\n    vsw = vsw_next;\n')],
+    "r5_vm4_mid": [(EK, '    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n    __syncthreads();\n    vsw = vsw_next;\n',
+                    '    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");\n    __syncthreads();\n    vsw = vsw_next;\n'),
+                   (EK, "        if (u >= 21) vr[u - 21] = lv[hslot(u - 21)];\n        __builtin_amdgcn_sched_barrier(0);\n",
+                    '        if (u == 21) { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); __syncthreads(); }\n        if (u >= 21) vr[u - 21] = lv[hslot(u - 21)];\n        __builtin_amdgcn_sched_barrier(0);\n')],
     "r5_dma_16_23": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n")],
     "r5_dma_14_22": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 14) issue_k4(t);\n        if (u == 22) issue_v4(t);\n")],
     "r5_dma_12_p2": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 12) issue_k4(t);\n"), (EK, "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n", "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n" "          if (u == 2) issue_v4(t);\n")],

@@ -37,7 +37,8 @@ def build():
     # stamps: 4 per tile step
     rep("  auto tile_step_f8 = [&](const int t, const f32x16& s_cur, f32x16& s_next) {\n    float x[16];\n",
         "  auto tile_step_f8 = [&](const int t, const f32x16& s_cur, f32x16& s_next) {\n    TL(t, 0);\n    float x[16];\n")
-    rep("    __syncthreads();\n    vsw = vsw_next;\n", "    __syncthreads();\n    TL(t, 1);\n    vsw = vsw_next;\n")
+    rep('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n    __syncthreads();\n    vsw = vsw_next;\n',
+        '    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n    TL(t, 9);\n    __syncthreads();\n    TL(t, 1);\n    vsw = vsw_next;\n')
     rep("        if (u >= 21) vr[u - 21] = lv[hslot(u - 21)];\n        __builtin_amdgcn_sched_barrier(0);\n      }\n    }\n",
         "        if (u >= 21) vr[u - 21] = lv[hslot(u - 21)];\n        __builtin_amdgcn_sched_barrier(0);\n"
         "        if (u == 3) TL(t, 2); if (u == 7) TL(t, 3); if (u == 11) TL(t, 4); if (u == 19) TL(t, 5);\n      }\n    }\n    TL(t, 6);\n")
@@ -46,7 +47,7 @@ def build():
     rep("    l_half = fmaf(l_half, alpha, ls + ls_l);\n  };\n", "    TL(t, 8);\n    l_half = fmaf(l_half, alpha, ls + ls_l);\n  };\n")
     a = text.index("// PVF8 (with NPROD = 3): the two CROSS products")
     pre = (f'__device__ unsigned long long g_tl[{NT * NS}];\n'
-           '#define TL(t, k) do { asm volatile("s_nop 0" ::: "memory"); if (bid == 0 && threadIdx.x == 0 && (t) - t_begin < ' + str(NT) + ') '
+           '#define TL(t, k) do { asm volatile("s_nop 0" ::: "memory"); if (bid == ' + os.environ.get('TL_BID', '0') + ' && threadIdx.x == 0 && (t) - t_begin < ' + str(NT) + ') '
            'g_tl[((t) - t_begin) * ' + str(NS) + ' + (k)] = __builtin_readcyclecounter(); asm volatile("s_nop 0" ::: "memory"); } while (0)\n')
     text = text[:a] + pre + text[a:]
     text = text.rstrip()
@@ -88,10 +89,11 @@ def run(B, N):
     rc = lib.gmf_dbg_attn_timeline(buf)
     assert rc == 0, rc
     v = list(buf)
-    names = ["barrier wait", "u0-3 scores+max, fetch c, offset", "u4-7", "u8-11", "u12-19 (+K pieces)", "u20-23 (+V pieces)", "ph2 hh u0-7 (+conversions)", "ph2 fp8 u8-11", "to next entry"]
+    names = ["vmcnt(0) + barrier wait", "u0-3 scores+max, fetch c, offset", "u4-7", "u8-11", "u12-19 (+K pieces at 16)", "u20-23 (+V pieces at 23)", "ph2 hh u0-7 (+conversions)", "ph2 fp8 u8-11", "to next entry"]
     print(f"B={B} N={N}: wave 0 of workgroup 0, last launch; core-clock cycles per key tile")
     tot = [0] * 9
     n = 0
+    vm = 0
     for t in range(1, NT - 1):
         st = v[NS * t: NS * t + 9]
         nxt = v[NS * (t + 1)]
@@ -99,11 +101,13 @@ def run(B, N):
             break
         row = [st[k + 1] - st[k] for k in range(8)] + [nxt - st[8]]
         tot = [a + b_ for a, b_ in zip(tot, row)]
+        vm += v[NS * t + 9] - st[0]
         n += 1
     if n:
         for nm, x in zip(names, tot):
             print(f"  {nm:34s} {x / n:8.0f}")
-        print(f"  {'tile':34s} {sum(tot) / n:8.0f}   (matrix-pipe time of the tile: 24 x 32 + 8 x 32 + 4 x 64 = 1280; the stamps themselves stretch the tile by ~10 %: more of them distort it beyond use)")
+        print(f"  {'(of the first line: the vmcnt(0) wait)':34s} {vm / n:8.0f}")
+        print(f"  {'tile':34s} {sum(tot) / n:8.0f}   (matrix-pipe time of the tile: 16 x 32 + 8 x 64 = 1024; phase 1 holds 8 x 32 + 4 x 64 = 512 of it, phase 2 the same; the stamps themselves stretch the tile by ~10 %: more of them distort it beyond use)")
 
 
 if __name__ == "__main__":

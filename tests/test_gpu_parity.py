@@ -1890,6 +1890,30 @@ def test_alternate_forms_behind_knobs_agree(model):
     gmf_amd.check_status()
 
 
+def test_launch_counts_of_a_forward(model):
+    """Structure, not numbers: how many kernels one test-mode forward launches (torch profiler, device activities).  Small grids are
+    launch-bound (B = 1 is the reference's evaluation mode, evaluation/test_3DMatch.py:69): three launches per layer and a prologue of
+    five; large grids run two launches per layer.  A change that silently adds launches per layer shows here before it shows in a timing."""
+    from torch.profiler import profile, ProfilerActivity
+    keys = ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")
+    for B, N, per_layer, budget in ((1, 1000, 3, 52), (32, 1000, 2, 44)):
+        b = synthetic.synthetic_batch(list(range(B)), N=N, T=196)
+        data = {k: _gpu(b[k]) for k in keys}
+        data["testing"] = True
+        for _ in range(2):
+            model(data)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            model(data)
+            torch.cuda.synchronize()
+        kern = [e for e in prof.key_averages() if e.device_time_total > 0 and ("gmf::" in e.key or "Memcpy" in e.key or "Memset" in e.key or "at::" in e.key)]
+        total = sum(e.count for e in kern)
+        layer = sum(e.count for e in kern if e.count % 12 == 0 and "gmf::" in e.key)
+        print(f"B={B} N={N}: {total} device operations per forward, {layer} of them in per-layer kernels:", sorted((e.count, e.key[:40]) for e in kern if e.count >= 12))
+        assert layer == 12 * per_layer, (B, N, layer)
+        assert total <= budget, (B, N, total, sorted((e.count, e.key[:60]) for e in kern))
+
+
 def test_tuning_rejects_unknown_and_removed_settings():
     """The round-1 timing-only ablations (scattn_variant 11..15: wrong results) and the measured-and-rejected forms are no
     longer part of the library: gmf_set_tuning refuses them, out-of-range values and unknown knobs with GMF_ERR_BAD_ARG (-1)

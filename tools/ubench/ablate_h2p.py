@@ -116,6 +116,9 @@ PATCHES = {
                     '    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");\n    __syncthreads();\n    vsw = vsw_next;\n'),
                    (EK, "        if (u >= 21) vr[u - 21] = lv[hslot(u - 21)];\n        __builtin_amdgcn_sched_barrier(0);\n",
                     '        if (u == 21) { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); __syncthreads(); }\n        if (u >= 21) vr[u - 21] = lv[hslot(u - 21)];\n        __builtin_amdgcn_sched_barrier(0);\n')],
+    # the compat cache written with non-temporal stores (3.2 GB per forward at 32 x 5000, re-read by 12 streaming launches)
+    "r5_c_nt_store": [("enc_common.hpp", "      for (int q = 0; q < 4; ++q) ct[q * 64] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);",
+                       "      for (int q = 0; q < 4; ++q) { const f32x4 w = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}; __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(ct + q * 64)); }")],
     "r5_dma_16_23": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n")],
     "r5_dma_14_22": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 14) issue_k4(t);\n        if (u == 22) issue_v4(t);\n")],
     "r5_dma_12_p2": [(EK, "        if (u == 16) issue_k4(t);\n        if (u == 23) issue_v4(t);\n", "        if (u == 12) issue_k4(t);\n"), (EK, "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n", "          planes_f8(u < 4 ? ph0 : ph1, u < 4 ? pl0 : pl1, 2 * (u & 3), u, pb, ls, ls_l);\n" "          if (u == 2) issue_v4(t);\n")],
@@ -208,7 +211,8 @@ _NOSTREAM = [
 for _k, _v in list(PATCHES.items()):
     if isinstance(_v, str):
         PATCHES[_k] = sum(({"SKEL": _SKEL, "NOBAR": _NOBAR, "NOSTREAM": _NOSTREAM, "NOC": _NOC, "NOREFILL": _NOREFILL}[t] for t in _v.split("+")), [])
-OBJ_OF = {EK: ["encoder_kernels"], EH: ["encoder_h2"], FF: ["encoder_kernels", "encoder_h2"], MC: ["encoder_kernels", "encoder_h2"]}
+OBJ_OF = {EK: ["encoder_kernels"], EH: ["encoder_h2"], FF: ["encoder_kernels", "encoder_h2"], MC: ["encoder_kernels", "encoder_h2"],
+          "enc_common.hpp": ["encoder_kernels", "encoder_h2"]}
 
 
 def build(only=None):
@@ -249,11 +253,11 @@ def run(argv):
     argv = [a for a in argv if a not in PATCHES]
     for name in names:
         lib = os.path.join(OUT, f"libgmf_hip_{name}.so")
-        env = dict(os.environ, GMF_LIB=lib, ROWS="3")
+        env = dict(os.environ, GMF_LIB=lib, ROWS=os.environ.get("ROWS", "3"))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_times.py")] + argv, env=env,
                            capture_output=True, text=True)
         print(f"== {name}", flush=True)
-        print("\n".join(l for l in r.stdout.splitlines() if "scattn" in l or "k_linear" in l or "k_small" in l or "encode:" in l), flush=True)
+        print("\n".join(l for l in r.stdout.splitlines() if "scattn" in l or "k_linear" in l or "k_small" in l or "compat_build" in l or "encode:" in l), flush=True)
         if r.returncode:
             print(r.stderr[-1500:])
 

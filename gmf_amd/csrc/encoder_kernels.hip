@@ -713,7 +713,8 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
   if (!it.valid) return;                       // grid padding of the split tail (uniform per workgroup)
   const bool split = it.split;
   const int ks = it.ks;
-  const int pair = it.item / wgs_per_pair, qblock = it.item - pair * wgs_per_pair;
+  const int slot = it.item / wgs_per_pair, qblock = it.item - slot * wgs_per_pair;
+  const int pair = ptab ? ptab[slot].ord : slot;       // ragged batch: the slots hold the pairs in a work-balanced order (PairTab::ord)
   // ragged batch: the pair's own row and tile counts (its slot in every image keeps the stride `tiles`); query blocks beyond
   // them have nothing to do (uniform per workgroup, before any barrier)
   if (ptab) N = ptab[pair].n;
@@ -1259,10 +1260,11 @@ GMF_DEVINL void scattn_h2p_body(float* lds, const int bid, const float* __restri
 // [r5] PVF8 kernels under the guard (PvGuard): the pair of this workgroup's item decides between the two forms of the body -
 // one uniform branch at the top, both bodies in the kernel.  (The V image of the pair was written in the matching format.)
 GMF_DEVINL bool attn_pv_on(const unsigned* __restrict__ v_scale, const PvGuard& guard, int bid, int n_items, int n_full, int ksplits,
-                           int wgs_per_pair) {
+                           int wgs_per_pair, const PairTab* __restrict__ ptab = nullptr) {
   if (!guard.stat) return v_scale != nullptr;
   const AttnItem it = attn_item(bid, n_items, n_full, ksplits);
-  return pv_planes_on(v_scale, guard, it.valid ? it.item / wgs_per_pair : 0);
+  const int slot = it.valid ? it.item / wgs_per_pair : 0;
+  return pv_planes_on(v_scale, guard, ptab ? ptab[slot].ord : slot);
 }
 
 template <int NPROD, int CFMT, bool PVF8 = false>
@@ -1276,7 +1278,7 @@ k_scattn_h2p(const float* __restrict__ q_img, const float* __restrict__ k_img, c
              const float* __restrict__ qw_bias, const PvGuard guard) {
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
   tail_priority(blockIdx.x, gridDim.x);
-  if (!PVF8 || attn_pv_on(v_scale, guard, blockIdx.x, n_items, n_full, ksplits, wgs_per_pair))
+  if (!PVF8 || attn_pv_on(v_scale, guard, blockIdx.x, n_items, n_full, ksplits, wgs_per_pair, ptab))
     scattn_h2p_body<NPROD, CFMT, 4, PVF8>(lds, blockIdx.x, q_img, k_img, v_img, fus, wst, vecs, out, N, tiles, wgs_per_pair, c_dense, n_items,
                                           n_full, ksplits, part_o, part_ml, next_wst, next_bias, ptab, v_scale, qf_img, qw_wst, qw_bias,
                                           guard.stat_next);

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -459,10 +460,32 @@ static int build_pair_table(gmf_handle* h, const int* n_points, int B, double ra
     const int n = n_points[b];
     GMF_REQUIRE(row + n <= 0x7fffffffLL, GMF_ERR_UNSUPPORTED_SHAPE, "ragged batch: more than 2^31 rows");
     const int Sb = ratio >= 0.0 ? (int)((double)n * ratio) : 0;     // S = int(N * ratio)   PointDSC.py:244
-    tab[b] = gmf::PairTab{(int)row, n, Sb, k};
+    tab[b] = gmf::PairTab{(int)row, n, Sb, k, b, 0, 0, 0};
     row += n;
     nm = n > nm ? n : nm;
     sm = Sb > sm ? Sb : sm;
+  }
+  {
+    // slot -> pair: the pairs longest first, each into the XCD run (B / 8 consecutive slots; the first B % 8 runs hold one more) with
+    // the least n^2 so far that still has a free slot; within a run longest first (PairTab::ord, launchers.hpp)
+    std::vector<int> by_len(B);
+    for (int b = 0; b < B; ++b) by_len[b] = b;
+    std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int c) { return n_points[a] > n_points[c]; });
+    const int runs = B < 8 ? 1 : 8;
+    std::vector<std::vector<int>> run(runs);
+    std::vector<double> load(runs, 0.0);
+    std::vector<int> cap(runs);
+    for (int r = 0; r < runs; ++r) cap[r] = B / runs + (r < B % runs ? 1 : 0);
+    for (int b : by_len) {
+      int best = -1;
+      for (int r = 0; r < runs; ++r)
+        if ((int)run[r].size() < cap[r] && (best < 0 || load[r] < load[best])) best = r;
+      run[best].push_back(b);
+      load[best] += (double)n_points[b] * (double)n_points[b];
+    }
+    int slot_i = 0;
+    for (int r = 0; r < runs; ++r)
+      for (int b : run[r]) tab[slot_i++].ord = b;
   }
   *n_max = nm;
   *n_sum = row;

@@ -9,7 +9,11 @@ namespace gmf {
 // built on the host from the caller's per-pair sizes and uploaded with the call.  Kernels take a nullable pointer: null =
 // the uniform batch [B, N, ...].  Internally every pair keeps a slot of tiles(max n) tiles; a pair's tiles beyond its own are
 // neither computed nor read.
-struct PairTab { int row0, n, S, k; };
+// ord [r5]: the attention grid's pair SLOT -> pair map of a ragged batch.  The attention items are dealt to the 8 XCDs in contiguous runs of
+// slots (attn_item), and an item costs n^2: with the pairs in the caller's order an XCD's share of the work is whatever its four pairs
+// happen to be (32 pairs with N ~ U[4000, 5500]: +-9 % around the mean, and the launch ends with the slowest XCD).  build_pair_table
+// deals the pairs to the XCD runs longest first, each to the run with the least work so far.  Results do not depend on it.
+struct PairTab { int row0, n, S, k, ord, pad0, pad1, pad2; };
 
 // The "pv_fp8" guard (gmf_set_tuning "pv_fp8" = 1, the default): which of a layer's pairs run the P V cross products of
 // the spatial-consistency attention on the fp8 pipe is decided ON THE DEVICE, per pair, from a statistic the previous kernel

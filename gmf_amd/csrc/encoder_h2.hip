@@ -980,14 +980,14 @@ k_linear_roles(const float* __restrict__ f_in, const float* __restrict__ front_w
                const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
                const float* __restrict__ ff_wst, const float* __restrict__ ff_vec, float* __restrict__ q_out,
                float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x2_out, int N, int tiles, int T,
-               int ttiles, unsigned* __restrict__ v_scale, const PvGuard guard) {
+               int ttiles, unsigned* __restrict__ v_scale, const PvGuard guard, const PairTab* __restrict__ ptab) {   // [r5] ragged batches too
   __shared__ __attribute__((aligned(16))) float lds[kLinLdsFloats];
   if (blockIdx.z == 0)
     linear_h2_body<1>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
-                      tiles, T, ttiles, nullptr, v_scale, guard);
+                      tiles, T, ttiles, ptab, v_scale, guard);
   else
     linear_h2_body<2>(lds, f_in, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst, ff_vec, q_out, k_out, v_out, x2_out, N,
-                      tiles, T, ttiles);
+                      tiles, T, ttiles, ptab);
 }
 
 // k_ff_reduce: x2 = sum_z part[z] + b2 + x1 (z in index order) for the hidden-split form of k_fusion_ff_h2p.
@@ -1042,9 +1042,9 @@ hipError_t launch_linear_h2(const Tuning& tune, const float* f, const float* fro
                             bool one_product, const PairTab* ptab, unsigned* v_scale, PvGuard guard) {
   // grids that give a CU about one workgroup: two roles per row block (the Q'/K/V projections | Fusion-2) in one launch
   const int W = ((tiles + 3) / 4) * B;
-  if (tune.mid_grid_roles > 0 && W < tune.mid_grid_roles && !ptab && q)
+  if (tune.mid_grid_roles > 0 && W < tune.mid_grid_roles && q)
     hipLaunchKernelGGL(k_linear_roles, tgrid(tiles, B, 2), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec,
-                       ff_wst, ff_vec, q, k, v, x2, N, tiles, T, ttiles, v_scale, guard);
+                       ff_wst, ff_vec, q, k, v, x2, N, tiles, T, ttiles, v_scale, guard, ptab);
   else if (one_product)                            // throughput numerics mode: high planes only
     hipLaunchKernelGGL(k_linear_h2<1>, tgrid(tiles, B), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec, ff_wst,
                        ff_vec, q, k, v, x2, N, tiles, T, ttiles, ptab, v_scale, guard);

@@ -1545,7 +1545,8 @@ k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_
                const float* __restrict__ wst, const float* __restrict__ vecs, float* __restrict__ out, int tiles,
                int wgs_per_pair, int n_items, int n_full, int ksplits, const float* __restrict__ next_wst,
                const float* __restrict__ next_bias, const float* __restrict__ ff_part, int ff_hs, const float* __restrict__ x1,
-               const float* __restrict__ ff_b2, unsigned* __restrict__ stat_next, int n_rows) {   // [r5] PvGuard::stat_next, the pairs' row count
+               const float* __restrict__ ff_b2, unsigned* __restrict__ stat_next, int n_rows,     // [r5] PvGuard::stat_next, the pairs' row count
+               const PairTab* __restrict__ ptab = nullptr) {                                     // [r5] ragged batch: key-split items too
   // (behind the nine stages: the biases of the epilogue - a bias fetched from global memory after each stage's MFMAs is a
   // memory round trip per stage on a grid where nothing else runs on the CU)
   __shared__ __attribute__((aligned(16))) float lds[9 * kStageFloats + kTailVecFloats];
@@ -1555,10 +1556,14 @@ k_scattn_merge(const float* __restrict__ part_o, const float* __restrict__ part_
   const AttnItem it = attn_item(blockIdx.x + 8 * min(n_full, (n_items >> 3) + ((int)(blockIdx.x & 7) < (n_items & 7) ? 1 : 0)),
                                 n_items, n_full, 1);
   if (!it.valid) return;
-  const int pair = it.item / wgs_per_pair;
-  const int tile_raw = (it.item - pair * wgs_per_pair) * 4 + wave;
-  const bool active = tile_raw < tiles;
-  const int tile = active ? tile_raw : tiles - 1;
+  const int slot = it.item / wgs_per_pair;
+  const int pair = ptab ? ptab[slot].ord : slot;           // (ragged batch: the slots hold the pairs in a work-balanced order, PairTab::ord)
+  if (ptab) n_rows = ptab[pair].n;
+  const int tiles_p = ptab ? (n_rows + 31) >> 5 : tiles;   // ragged batch: the pair's own tiles; its slot in every image keeps the stride `tiles`
+  if ((it.item - slot * wgs_per_pair) * 4 >= tiles_p) return;            // (uniform per workgroup, before any barrier)
+  const int tile_raw = (it.item - slot * wgs_per_pair) * 4 + wave;
+  const bool active = tile_raw < tiles_p;
+  const int tile = active ? tile_raw : tiles_p - 1;
   const size_t n_tiles_all = (size_t)(n_items / wgs_per_pair) * tiles;
   const size_t pt0 = (size_t)pair * tiles + tile;
   const size_t toff = pt0 * (32 * C);
@@ -2398,8 +2403,11 @@ hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, 
     const int W = wpp * B;
     const int per_xcd = (W >> 3) + ((W & 7) ? 1 : 0);
     int n_full, ksplits;
-    plan_attn_split(tune, W, tiles, cc->part_o ? cc->max_splits : 0, &n_full, &ksplits);
-    if (cc->ptab) { n_full = per_xcd; ksplits = 1; }       // ragged batch: whole items only (the key-split forms assume one N)
+    // ragged batch: planned on the SMALLEST pair's tiles (every pair then has at least four key tiles per split); either every item is
+    // split - small grids: a handful of whole items walking all their keys alone left most of the chip idle (4 pairs x 1000: 1.50 ms
+    // against 0.74 for the uniform batch) - or none is (the split tail of large grids assumes items of one length)
+    plan_attn_split(tune, W, cc->ptab ? cc->min_tiles : tiles, cc->part_o ? cc->max_splits : 0, &n_full, &ksplits);
+    if (cc->ptab && n_full != 0) { n_full = per_xcd; ksplits = 1; }
     const int max_tail = std::max(0, per_xcd - n_full);
     const dim3 grid(8 * (std::min(n_full, per_xcd) + max_tail * ksplits));
     if (cc->half && max_tail == 0)   // throughput numerics mode, whole items only: the three-tiles-in-flight form
@@ -2423,7 +2431,7 @@ hipError_t launch_scattn_h2(const Tuning& tune, const float* q, const float* k, 
     if (max_tail > 0)
       hipLaunchKernelGGL(k_scattn_merge, dim3(8 * max_tail), dim3(256), 0, s, cc->part_o, cc->part_ml, fus, cc->tail_wst_h2, vecs, out,
                          tiles, wpp, W, n_full, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)nullptr, 0,
-                         (const float*)nullptr, (const float*)nullptr, cc->guard.stat_next, N);
+                         (const float*)nullptr, (const float*)nullptr, cc->guard.stat_next, N, cc->ptab);
   }
   else if (cd) hipLaunchKernelGGL(k_scattn_h2<true>, grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);
   else hipLaunchKernelGGL(k_scattn_h2<false>, grid4, dim3(256), 0, s, q, k, v, pts8, fus, wst, vecs, out, N, tiles, inv, wpp, cd);

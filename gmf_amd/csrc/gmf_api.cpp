@@ -610,6 +610,11 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
   // kernel (variant 18) is the cache's only reader
   cc.fmt = cc.half ? 1 : (want_cache && h->tune.scattn_variant == 18) ? h->tune.compat_format : 0;
   cc.ptab = ptab;
+  if (ragged) {
+    int nmin = n_points[0];
+    for (int b = 1; b < B; ++b) nmin = n_points[b] < nmin ? n_points[b] : nmin;
+    cc.min_tiles = tiles_of(nmin);
+  }
   // (the key-point packing also clears the "pv_fp8" guard's statistics - a superset of the forwards that read them)
   const bool may_guard = fuse && h->tune.pv_fp8 == 1 && w->pv_guard;
   unsigned* const zero_words = may_guard ? fstat : nullptr;
@@ -699,7 +704,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
         // [r4] Q' in the attention kernel's prologue (parity arithmetic of the pipelined kernel; not with the linear kernel as two
         // roles, whose Q'/K/V role writes the image): k_linear_h2 then projects K and V only
         const int Wl = ((tiles + 3) / 4) * B;
-        const bool roles = h->tune.mid_grid_roles > 0 && Wl < h->tune.mid_grid_roles && !ptab;
+        const bool roles = h->tune.mid_grid_roles > 0 && Wl < h->tune.mid_grid_roles;     // ([r5] ragged batches too: the role kernel reads the pair table)
         const bool qproj = h->tune.q_in_attention && !cc.half && !roles;
         cc.qf_img = qproj ? f : nullptr;
         cc.qw_wst = qproj ? fw + 4 * kTileFloats : nullptr;

@@ -43,6 +43,7 @@ struct CompatCache {
   bool half = false;          // `dense` holds fp16 tiles (2 KiB each) and the attention multiplies one fp16 product: the
                               // throughput numerics mode (Tuning::precision = 1), large grids only (then fmt = 1)
   const PairTab* ptab = nullptr;   // ragged batch: per-pair rows (device), else null
+  int min_tiles = 0;               // ragged batch: the smallest pair's 32-row tiles (the key-split plan is made for it)
   int fmt = 0;                // element format of `dense` (k_compat_build): 0 = fp32 (4 KiB per tile); 16-bit, 2 KiB per tile:
                               // 1 = fp16 c (with `half`), 2 = fixed point rint(65535 c)
   unsigned* v_scale = nullptr;   // non-null: the layer's V image carries e4m3 cross planes (store_block_v8) and these are their

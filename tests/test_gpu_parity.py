@@ -525,6 +525,38 @@ def test_pv_fp8_guard_decides_per_pair_and_layer(model, sd_full, grid):
         h.status(clear=True)
 
 
+def test_pv_fp8_guard_in_a_small_ragged_batch(model):
+    """[r5] The guard where the newest paths meet: a SMALL ragged batch (key-split attention items planned on the smallest pair, the
+    two-role linear kernel and k_scattn_merge reading the pair table, the slots in work-balanced order - PairTab::ord) with one pair
+    whose inputs are 40 x larger (its first layers take the three-product form).  Every pair, hot or not, must equal its own B = 1
+    call to fp32 rounding - the decision belongs to the pair, not to its slot or its neighbours (PointDSC.py:56-64)."""
+    from gmf_amd import _lib
+    h = _lib.handle_for(0)
+    keys = ("corr_pos", "src_keypts", "tgt_keypts")
+    sizes = [1000, 2311, 640, 1500]
+    pairs = [synthetic.synthetic_batch([880 + i], N=n, T=196) for i, n in enumerate(sizes)]
+    one = [{k: _gpu(p[k]) for k in keys + ("p_tokens", "q_tokens")} for p in pairs]
+    one[2]["corr_pos"] = one[2]["corr_pos"] * 40.0
+    rag = {k: [o[k][0] for o in one] for k in keys}
+    rag.update(p_tokens=torch.cat([o["p_tokens"] for o in one]), q_tokens=torch.cat([o["q_tokens"] for o in one]), testing=True)
+    h.status(clear=True)
+    lg = [x.clone() for x in model(rag)["logits"]]
+    torch.cuda.synchronize()                     # (the status word is written by the forward's last kernels)
+    tripped = bool(h.status() & _lib.GMF_STATUS_PV_GUARDED)
+    h.status(clear=True)
+    assert tripped and all(torch.isfinite(x).all() for x in lg)
+    for i, o in enumerate(one):
+        o["testing"] = True
+        model(o)
+        ref = model.last_logits[0]
+        scale = max(1.0, float(ref.abs().max()))
+        d = _maxerr(lg[i].cpu(), ref.cpu())
+        print(f"pair {i} (n = {sizes[i]}{', hot' if i == 2 else ''}): ragged vs own B = 1 call {d:.2e} (largest logit {scale:.1f})")
+        # (the hot pair's scores are 40 x larger: the two calls split its keys differently, and that order shows - 1.3e-4 measured)
+        assert d < (3e-4 if i == 2 else 1e-4) * scale, (i, d, scale)
+    h.status(clear=True)
+
+
 def test_outlier_correspondence_with_huge_coordinates(model, sd_full):
     """One correspondence whose coordinates are 300 x larger than the scene: its V row dominates the per-(feature, key tile) scale
     of the e4m3 cross planes of its tile (the other 31 keys of that tile then lose bits of their CROSS terms

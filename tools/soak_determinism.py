@@ -56,6 +56,28 @@ lg0 = model.last_logits.clone()
 diff = sum(0 if torch.equal((model(data), model.last_logits)[1], lg0) else 1 for _ in range(reps))
 bad += diff
 print(f"B=1 N=1000 from raw images: {reps} repeats, {diff} differ", flush=True)
+# [r5] ragged batches: a small one (key-split items planned on the smallest pair, the role linear kernel, k_scattn_merge with the pair
+# table) and a larger one (whole items in work-balanced slots), each in two orders of the same pairs - the result of a pair must
+# not depend on its slot
+for sizes, n in (([1000, 2311, 640, 1500], reps), ([3970, 2500, 3100, 3970, 1800, 3333, 2900, 3600, 2050, 3970], reps // 4)):
+    prs = [synthetic.synthetic_batch([300 + i], N=nn, T=196) for i, nn in enumerate(sizes)]
+    def ragged(order):
+        d = {k: [prs[i][k][0].to(dev) for i in order] for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+        d["p_tokens"] = torch.cat([prs[i]["p_tokens"] for i in order]).to(dev)
+        d["q_tokens"] = torch.cat([prs[i]["q_tokens"] for i in order]).to(dev)
+        d["testing"] = True
+        return d
+    fwd, rev = list(range(len(sizes))), list(range(len(sizes)))[::-1]
+    r0 = model(ragged(fwd))
+    lg0, T0 = [x.clone() for x in r0["logits"]], r0["final_trans"].clone()
+    diff = 0
+    for it in range(max(n, 2)):
+        order = rev if it & 1 else fwd
+        r = model(ragged(order))
+        same = all(torch.equal(r["logits"][j], lg0[i]) for j, i in enumerate(order)) and torch.equal(r["final_trans"], T0[order])
+        diff += 0 if same else 1
+    bad += diff
+    print(f"ragged {len(sizes)} pairs (n = {min(sizes)} .. {max(sizes)}), both orders: {max(n, 2)} repeats, {diff} differ", flush=True)
 # training step: the gradients of two identical steps from identical weights
 m = gmf_amd.PointDSC(num_layers=3)
 m.load_state_dict(synthetic.seeded_state_dict(synthetic.pointdsc_shapes(6, 3, 128), seed=7), strict=False)

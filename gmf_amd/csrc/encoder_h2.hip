@@ -270,14 +270,16 @@ constexpr int kFattnLdsFloats = kRing * kStageFloats + 7 * C + kWavesPerWG * 2 *
 template <bool PE, bool ROWMAJOR = false>
 GMF_DEVINL void fusion_attn_h2_body(float* lds, const int bx, const int pair, const float* __restrict__ xin,
                                     const float* __restrict__ ctx_img, const float* __restrict__ wst,
-                                    const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
+                                    const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles,
+                                    const int tiles_stride = 0) {    // [r5] ragged batch: N, tiles are the PAIR's own, its slot in the images keeps this stride
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile_raw = bx * kWavesPerWG + wave;
   const bool active = tile_raw < tiles;
   const int tile = active ? tile_raw : tiles - 1;
-  const float* pair_base = ROWMAJOR ? xin + (size_t)pair * N * C : xin + (size_t)pair * tiles * (32 * C);
-  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+  const int ts = tiles_stride ? tiles_stride : tiles;
+  const float* pair_base = ROWMAJOR ? xin + (size_t)pair * N * C : xin + (size_t)pair * ts * (32 * C);
+  const size_t toff = ((size_t)pair * ts + tile) * (32 * C);
 
   // behind the ring (kFattnLdsFloats): the kernel's per-feature vectors and, per wave, the two halo rows of the LCPE - requested
   // before the ring's stages (k_linear_h2 has the reasons: a tap / gamma / bias fetched from global memory where it is used is a
@@ -412,11 +414,13 @@ constexpr int kFattnTileLdsFloats = 4 * kStageFloats + 7 * C + kWavesPerWG * 2 *
 
 GMF_DEVINL void fusion_attn_tile_h2_body(float* lds, const int tile, const int pair, const float* __restrict__ xin,
                                          const float* __restrict__ ctx_img, const float* __restrict__ wst,
-                                         const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles) {
+                                         const float* __restrict__ vecs, float* __restrict__ x1_out, int N, int tiles, int T, int ttiles,
+                                         const int tiles_stride = 0) {    // [r5] ragged batch: as fusion_attn_h2_body
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const float* pair_base = xin + (size_t)pair * tiles * (32 * C);
-  const size_t toff = ((size_t)pair * tiles + tile) * (32 * C);
+  const int ts = tiles_stride ? tiles_stride : tiles;
+  const float* pair_base = xin + (size_t)pair * ts * (32 * C);
+  const size_t toff = ((size_t)pair * ts + tile) * (32 * C);
   float* const lvec = lds + 4 * kStageFloats;
   float* const halo = lvec + 7 * C + wave * (2 * C);
   float* const lml = lvec + 7 * C + kWavesPerWG * (2 * C);         // [wave][lane][2]: running maximum, row sum (this lane half's)
@@ -591,19 +595,26 @@ __global__ void __launch_bounds__(256, 2)
 k_small_front_fattn(const float* __restrict__ f_in, const float* __restrict__ front_wst, const float* __restrict__ front_vec,
                     const float* __restrict__ ctx_img, const float* __restrict__ attn_wst, const float* __restrict__ attn_vec,
                     float* __restrict__ q_out, float* __restrict__ k_out, float* __restrict__ v_out, float* __restrict__ x1_out,
-                    int N, int tiles, int T, int ttiles, unsigned* __restrict__ v_scale, const PvGuard guard) {
+                    int N, int tiles, int T, int ttiles, unsigned* __restrict__ v_scale, const PvGuard guard,
+                    const PairTab* __restrict__ ptab) {                  // [r5] ragged batches: the pairs' own rows
   // gridDim.z == 4: z = 3 is the cross-attention of the block's four query tiles, one per wave (fusion_attn_h2_body);
   // gridDim.z == 7 [r5]: z = 3 .. 6 are ONE query tile each, its context tiles dealt to the four waves (fusion_attn_tile_h2_body)
   __shared__ __attribute__((aligned(16))) float lds[kFattnTileLdsFloats];
   static_assert(kFattnTileLdsFloats >= kFattnLdsFloats, "one buffer serves both forms of the role");
-  if (blockIdx.z < 3)
+  if (blockIdx.z < 3) {
     front_h2_body<2>(lds, blockIdx.x, blockIdx.y, blockIdx.z, f_in, front_wst, front_vec, nullptr, q_out, k_out, v_out, N, tiles,
-                     nullptr, v_scale, guard);
-  else if (gridDim.z == 4)
-    fusion_attn_h2_body<true>(lds, blockIdx.x, blockIdx.y, f_in, ctx_img, attn_wst, attn_vec, x1_out, N, tiles, T, ttiles);
-  else {
+                     ptab, v_scale, guard);
+    return;
+  }
+  // ragged batch: the LCPE's zero padding sits at the pair's OWN last row, query tiles beyond its own have nothing to do (uniform
+  // per workgroup, before any barrier); the pair's slot in the images keeps the stride `tiles`
+  const int Np = pair_rows(ptab, blockIdx.y, N), tiles_p = ptab ? (Np + 31) >> 5 : tiles;
+  if (gridDim.z == 4) {
+    if ((int)blockIdx.x * kWavesPerWG >= tiles_p) return;
+    fusion_attn_h2_body<true>(lds, blockIdx.x, blockIdx.y, f_in, ctx_img, attn_wst, attn_vec, x1_out, Np, tiles_p, T, ttiles, tiles);
+  } else {
     const int tile = (int)blockIdx.x * kWavesPerWG + ((int)blockIdx.z - 3);
-    if (tile < tiles) fusion_attn_tile_h2_body(lds, tile, blockIdx.y, f_in, ctx_img, attn_wst, attn_vec, x1_out, N, tiles, T, ttiles);
+    if (tile < tiles_p) fusion_attn_tile_h2_body(lds, tile, blockIdx.y, f_in, ctx_img, attn_wst, attn_vec, x1_out, Np, tiles_p, T, ttiles, tiles);
   }
 }
 
@@ -1137,12 +1148,13 @@ int plan_ff_split(const Tuning& tune, int base, int max_parts) {
 
 hipError_t launch_small_front_fattn(const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                                     const float* attn_wst, const float* attn_vec, float* q, float* k, float* v, float* x1, int B,
-                                    int N, int tiles, int T, int ttiles, hipStream_t s, unsigned* v_scale, PvGuard guard, bool tile_role) {
+                                    int N, int tiles, int T, int ttiles, hipStream_t s, unsigned* v_scale, PvGuard guard, bool tile_role,
+                                    const PairTab* ptab) {
   // [r5] the cross-attention role per query tile (its waves split the context tiles) wherever that leaves the chip room: the role's
   // workgroups quadruple, so up to 256 query tiles; beyond, one workgroup per four tiles as before
   const bool per_tile = tile_role && ttiles >= 2 && (long)tiles * B <= 256;
   hipLaunchKernelGGL(k_small_front_fattn, tgrid(tiles, B, per_tile ? 7 : 4), dim3(256), 0, s, f, front_wst, front_vec, ctx_img, attn_wst, attn_vec,
-                     q, k, v, x1, N, tiles, T, ttiles, v_scale, guard);
+                     q, k, v, x1, N, tiles, T, ttiles, v_scale, guard, ptab);
   return hipGetLastError();
 }
 

@@ -1487,21 +1487,23 @@ k_small_attn_ff(const int n_attn, const float* __restrict__ q_img, const float* 
                 int tiles, int wgs_per_pair, const float* __restrict__ c_dense, int n_items, int ksplits,
                 float* __restrict__ part_o, float* __restrict__ part_ml, const float* __restrict__ x1,
                 const float* __restrict__ ff_wst, const float* __restrict__ ff_vecs, float* __restrict__ ff_part, int n_pairs,
-                int ff_hs, const unsigned* __restrict__ v_scale, const PvGuard guard) {
+                int ff_hs, const unsigned* __restrict__ v_scale, const PvGuard guard,
+                const PairTab* __restrict__ ptab) {                      // [r5] ragged batches: the pairs' own rows
   __shared__ __attribute__((aligned(16))) float lds[4 * kStageFloats];
   if ((int)blockIdx.x < n_attn) {
     // (n_full = 0: every item is split and leaves through the partial-result branch; `fus` / `out` of the whole-item epilogue
     // are never touched - they get valid pointers all the same, a literal null there crashes this compiler's optimiser)
-    if (!PVF8 || attn_pv_on(v_scale, guard, blockIdx.x, n_items, 0, ksplits, wgs_per_pair))
+    if (!PVF8 || attn_pv_on(v_scale, guard, blockIdx.x, n_items, 0, ksplits, wgs_per_pair, ptab))
       scattn_h2p_body<3, CFMT, 4, PVF8>(lds, blockIdx.x, q_img, k_img, v_img, x1, tail_wst, tail_vecs, ff_part, N, tiles, wgs_per_pair, c_dense,
-                                        n_items, 0, ksplits, part_o, part_ml, nullptr, nullptr, nullptr, v_scale);
+                                        n_items, 0, ksplits, part_o, part_ml, nullptr, nullptr, ptab, v_scale);
     else
       scattn_h2p_body<3, CFMT, 4, false>(lds, blockIdx.x, q_img, k_img, v_img, x1, tail_wst, tail_vecs, ff_part, N, tiles, wgs_per_pair, c_dense,
-                                         n_items, 0, ksplits, part_o, part_ml, nullptr, nullptr, nullptr, nullptr);
+                                         n_items, 0, ksplits, part_o, part_ml, nullptr, nullptr, ptab, nullptr);
   } else {
     const int id = (int)blockIdx.x - n_attn;           // (bx, pair, z) with z fastest: the splits of a row block start together
     const int z = id % ff_hs, r = id / ff_hs;
     const int pair = r / wgs_per_pair, bx = r - pair * wgs_per_pair;
+    if (ptab && bx * 4 >= ((ptab[pair].n + 31) >> 5)) return;            // ragged batch: a row block beyond the pair's own tiles
     fusion_ff_h2p_body<true>(lds, bx, pair, n_pairs, z, ff_hs, x1, ff_wst, ff_vecs, ff_part, tiles, ff_part);   // (x2_out unused: hs > 1)
   }
 }
@@ -1657,11 +1659,16 @@ k_scattn_merge_tile(const float* __restrict__ part_o, const float* __restrict__ 
                     const float* __restrict__ vecs, float* __restrict__ out, int tiles, int ksplits,
                     const float* __restrict__ next_wst, const float* __restrict__ next_bias, const float* __restrict__ ff_part,
                     int ff_hs, const float* __restrict__ x1, const float* __restrict__ ff_b2, unsigned* __restrict__ stat_next,
-                    int n_rows) {                                               // [r5] PvGuard::stat_next, the pairs' row count
+                    int n_rows,                                                 // [r5] PvGuard::stat_next, the pairs' row count
+                    const PairTab* __restrict__ ptab) {                         // [r5] ragged batches
   __shared__ __attribute__((aligned(16))) float lds[10 * kStageFloats];       // 9 weight stages | exchange
   const int lane = threadIdx.x & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = blockIdx.x, pair = blockIdx.y;
+  if (ptab) {                                      // ragged batch: the pair's own rows; tiles beyond them have nothing to merge
+    n_rows = ptab[pair].n;
+    if (tile >= ((n_rows + 31) >> 5)) return;
+  }
   const size_t n_tiles_all = (size_t)gridDim.y * tiles;
   const size_t pt0 = (size_t)pair * tiles + tile;
   const size_t toff = pt0 * (32 * C);
@@ -2365,24 +2372,24 @@ hipError_t launch_small_attn_ff_merge(const float* q, const float* k, const floa
   const int n_attn = 8 * per_xcd * ksplits, n_ff = W * ff_hs;
   if (cc->fmt == 2 && cc->v_scale)
     hipLaunchKernelGGL((k_small_attn_ff<2, true>), dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
-                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, cc->v_scale, cc->guard);
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, cc->v_scale, cc->guard, cc->ptab);
   else if (cc->fmt == 2)
     hipLaunchKernelGGL(k_small_attn_ff<2>, dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
-                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, (const unsigned*)nullptr, PvGuard{});
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, (const unsigned*)nullptr, PvGuard{}, cc->ptab);
   else if (cc->v_scale)
     hipLaunchKernelGGL((k_small_attn_ff<0, true>), dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
-                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, cc->v_scale, cc->guard);
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, cc->v_scale, cc->guard, cc->ptab);
   else
     hipLaunchKernelGGL(k_small_attn_ff<0>, dim3(n_attn + n_ff), dim3(256), 0, s, n_attn, q, k, v, cc->tail_wst_h2, tail_vecs, N, tiles, wpp,
-                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, (const unsigned*)nullptr, PvGuard{});
+                       cc->dense, W, ksplits, cc->part_o, cc->part_ml, x1, ff_wst, ff_vecs, ff_part, B, ff_hs, (const unsigned*)nullptr, PvGuard{}, cc->ptab);
   if (tile_merge)
     hipLaunchKernelGGL(k_scattn_merge_tile, dim3(tiles, B), dim3(256), 0, s, cc->part_o, cc->part_ml, cc->tail_wst_h2, tail_vecs, out,
                        tiles, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)ff_part, ff_hs, x1, ff_vecs + 2 * C + 2 * FFH,
-                       cc->guard.stat_next, N);
+                       cc->guard.stat_next, N, cc->ptab);
   else
     hipLaunchKernelGGL(k_scattn_merge, dim3(8 * per_xcd), dim3(256), 0, s, cc->part_o, cc->part_ml, x1, cc->tail_wst_h2, tail_vecs, out,
                        tiles, wpp, W, 0, ksplits, cc->next_wst_h2, cc->next_bias, (const float*)ff_part, ff_hs, x1,
-                       ff_vecs + 2 * C + 2 * FFH, cc->guard.stat_next, N);
+                       ff_vecs + 2 * C + 2 * FFH, cc->guard.stat_next, N, cc->ptab);
   return hipGetLastError();
 }
 

@@ -671,12 +671,16 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
   //   k_scattn_h2p: Q', K, V, c, x2 -> f_{l+1} = ReLU(PointCN_{l+1}(fc_message(attention) + x2))   (last layer: the features)
   if (fuse) {
     const int Wg = ((tiles + 3) / 4) * B;
-    const bool one_kernel = Wg >= 256 || ragged;      // below: key / hidden / output splits fill the chip better (uniform batches)
     // small grids: when both the attention and the feed-forward are split anyway, their workgroups share launches
+    // ([r5] ragged batches too: the split is planned on the smallest pair's tiles, the role kernels read the pair table)
     int small_nf = 1, small_ks = 1;
-    gmf::plan_attn_split(h->tune, Wg, tiles, cc.part_o ? cc.max_splits : 0, &small_nf, &small_ks);
+    gmf::plan_attn_split(h->tune, Wg, ragged ? cc.min_tiles : tiles, cc.part_o ? cc.max_splits : 0, &small_nf, &small_ks);
     const int ff_hs = cc.part_o ? gmf::plan_ff_split(h->tune, Wg, cc.max_splits) : 1;
-    const bool small3 = !one_kernel && h->tune.small_roles && small_nf == 0 && small_ks > 1 && ff_hs > 1 && ff_part;
+    const bool small3_ok = Wg < 256 && h->tune.small_roles && small_nf == 0 && small_ks > 1 && ff_hs > 1 && ff_part;
+    // below 256 row blocks key / hidden / output splits fill the chip better; a ragged batch takes either the three-launch form of
+    // small grids or the two-launch form (the one-kernel-per-stage form in between has no pair table)
+    const bool one_kernel = Wg >= 256 || (ragged && !small3_ok);
+    const bool small3 = !one_kernel && small3_ok;
     // parity arithmetic: V with e4m3 cross planes for the pv_fp8 form of the attention body (scattn_h2p_body<3, *, 4, true>), which every
     // attention kernel of this path instantiates - large grids, split tails and the small-grid role kernels alike
     // (a weights block without thresholds - filled in by hand, pv_guard = NULL - gets the three-product form under the guarded default,
@@ -714,7 +718,7 @@ static int encoder_forward_impl(gmf_handle* h, const gmf_encoder_weights* w, con
       } else if (small3) {
         // three launches: {Q' | K | V | cross-attention} -> {key-split attention | hidden-split feed-forward} -> merge
         GMF_HIP(gmf::launch_small_front_fattn(f, fw, fv, ctx_l, aw, av, q, k, v, x1, B, N, tiles, T, tt, st, cc.v_scale, cc.guard,
-                                              h->tune.small_fattn_tile));
+                                              h->tune.small_fattn_tile, ptab));
         const bool last3 = (l + 1 == L);
         cc.tail_wst_h2 = w->tail_wst_h2 + (size_t)l * w->tail_wst_stride;
         cc.next_wst_h2 = last3 ? nullptr : w->front_wst_h2 + (size_t)(l + 1) * w->front_wst_stride;

@@ -141,7 +141,7 @@ int plan_ff_split(const Tuning& tune, int base, int max_parts);
 hipError_t launch_small_front_fattn(const float* f, const float* front_wst, const float* front_vec, const float* ctx_img,
                                     const float* attn_wst, const float* attn_vec, float* q, float* k, float* v, float* x1, int B,
                                     int N, int tiles, int T, int ttiles, hipStream_t s, unsigned* v_scale = nullptr, PvGuard guard = {},
-                                    bool tile_role = true);   // tile_role: the cross-attention role per query tile (Tuning::small_fattn_tile)
+                                    bool tile_role = true, const PairTab* ptab = nullptr);   // tile_role: the cross-attention role per query tile (Tuning::small_fattn_tile)
 hipError_t launch_small_attn_ff_merge(const float* q, const float* k, const float* v, const float* x1, const float* ff_wst,
                                       const float* ff_vecs, float* ff_part, int ff_hs, const float* tail_vecs, float* out, int B,
                                       int N, int tiles, int ksplits, hipStream_t s, const CompatCache* cc, bool tile_merge = true);

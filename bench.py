@@ -367,7 +367,19 @@ def sweep(dev, full=False):
     rows.append({"workload": "3dmatch 32 pairs, N ~ U[4000, 5500] (sum %d), ONE ragged launch" % sum(sizes), "ms_per_step": ms_r,
                  "value": sum(sizes) / (ms_r * 1e-3), "unit": "correspondences/s",
                  "same_pairs_as_32_calls_with_B_1": {"ms": ms_1, "value": sum(sizes) / (ms_1 * 1e-3)}})
-    del model, rag, packed, singles, pairs
+    # ... and a SMALL ragged batch: four requests with their own N, as a serving process would batch them (the three-launch small-grid
+    # form with the pair table, round 5)
+    sizes4 = [int(n) for n in np.random.default_rng(78).integers(800, 1201, size=4)]
+    packed4 = {k: torch.cat([b[k][0][:n].to(dev) for b, n in zip(pairs[:4], sizes4)]) for k in ("corr_pos", "src_keypts", "tgt_keypts")}
+    packed4.update(p_tokens=rag["p_tokens"][:4], q_tokens=rag["q_tokens"][:4], n_points=sizes4, testing=True)
+    singles4 = [{**{k: (d[k][:, :n] if k in ("corr_pos", "src_keypts", "tgt_keypts") else d[k]) for k in d if k != "testing"}, "testing": True}
+                for d, n in zip(singles[:4], sizes4)]
+    ms_r4 = timed(lambda: model(packed4), 20)
+    ms_14 = timed(lambda: [model(d) for d in singles4], 5)
+    rows.append({"workload": "3dmatch 4 pairs, N ~ U[800, 1200] (sum %d), ONE ragged launch" % sum(sizes4), "ms_per_step": ms_r4,
+                 "value": sum(sizes4) / (ms_r4 * 1e-3), "unit": "correspondences/s",
+                 "same_pairs_as_4_calls_with_B_1": {"ms": ms_14, "value": sum(sizes4) / (ms_14 * 1e-3)}})
+    del model, rag, packed, singles, pairs, packed4, singles4
     torch.cuda.empty_cache()
     rows += dgr_rows(dev, full)
     # the throughput numerics modes (gmf_set_tuning "precision" = 1, 2; NOT the parity path, never the headline) on the headline

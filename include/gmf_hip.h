@@ -309,7 +309,8 @@ int gmf_encoder_forward(gmf_handle* h, const gmf_encoder_weights* w, const float
  * B == 1); its collate function clips a training batch to the smallest N (datasets/dataloader.py:6-23).  Here the row-major
  * tensors are PACKED: pair b owns rows [n_0 + .. + n_{b-1}, + n_b) of corr_pos [sum n, 6], src/tgt_keypts [sum n, 3], logits
  * [sum n], feat_n / feat [sum n, 128]; the tokens stay [B, T, 128].  n_points: HOST array [B] (the caller knows its tensor
- * shapes; the library sizes its grids from it).  The result equals B calls with B = 1, pair by pair.  Default path only (split-
+ * shapes; the library sizes its grids from it).  The result equals B calls with B = 1, pair by pair, whatever the order of the pairs
+ * (the library deals them to the chip's eight dies by work; small batches run the same small-grid kernels as uniform ones).  Default path only (split-
  * fp16 weight images, num_layers >= 2, "fused_linear" = 1, "scattn_variant" = 18): otherwise GMF_ERR_UNSUPPORTED_SHAPE. */
 int gmf_encoder_forward_ragged(gmf_handle* h, const gmf_encoder_weights* w, const float* corr_pos, const float* src_keypts,
                                const float* tgt_keypts, const float* p_tokens, const float* q_tokens, const int* n_points, int B,

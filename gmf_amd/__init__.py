@@ -12,10 +12,10 @@ from .registration import (weighted_procrustes, weighted_procrustes_batched, Glo
                            global_registration_batched, argmin_se3_squared_dist, Transformation, ortho2rotation)
 from .matching import nn_match, find_knn_gpu    # noqa: F401
 from . import se3 as SE3                         # noqa: F401
-from ._lib import check_status                   # noqa: F401
+from ._lib import check_status, set_handle_per_stream   # noqa: F401
 from .losses import ClassificationLoss, SpectralMatchingLoss, TransformationLoss, similarity_matrix   # noqa: F401
 
 __all__ = ["FusionLayer", "PerceiverIO", "NonLocalBlock", "NonLocalNet", "PointDSC", "ImageEncoder",
            "rigid_transform_3d", "knn", "weighted_procrustes", "weighted_procrustes_batched", "GlobalRegistration", "global_registration_batched", "argmin_se3_squared_dist", "Transformation", "ortho2rotation", "nn_match",
            "find_knn_gpu", "SE3", "ClassificationLoss", "SpectralMatchingLoss", "TransformationLoss",
-           "similarity_matrix", "check_status"]
+           "similarity_matrix", "check_status", "set_handle_per_stream"]

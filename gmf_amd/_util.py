@@ -23,10 +23,13 @@ def handle_and_stream(t: torch.Tensor, check: bool = False):
     """(library handle, current stream) of t's device.  check: raise now if an EARLIER call on this device flagged a
     non-finite result (a host read of the handle's status word - no synchronisation)."""
     idx = dev_index(t)
-    h = _lib.handle_for(idx)
+    st = torch.cuda.current_stream(idx).cuda_stream
+    # [r5] set_handle_per_stream: a non-default stream has a handle of its own (never while that stream is capturing a graph)
+    own = _lib._per_stream and st and not torch.cuda.is_current_stream_capturing()
+    h = _lib.handle_for(idx, st if own else 0)
     if check:
         h.raise_if_flagged("forward")
-    return h, torch.cuda.current_stream(idx).cuda_stream
+    return h, st
 
 
 class WeightWatcher:

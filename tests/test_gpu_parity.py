@@ -1946,6 +1946,50 @@ def test_launch_counts_of_a_forward(model):
         assert total <= budget, (B, N, total, sorted((e.count, e.key[:60]) for e in kern))
 
 
+def test_handle_per_stream_overlaps_and_agrees(model):
+    """[r5] `gmf_amd.set_handle_per_stream(True)` (serving): forwards on different torch streams take handles - and workspaces - of their
+    own and may overlap on the device; the results are those of the default stream bit for bit, the default stream keeps the base
+    handle, and switching it off returns every stream to the base handle."""
+    from gmf_amd import _lib, _util
+    keys = ("corr_pos", "src_keypts", "tgt_keypts", "p_tokens", "q_tokens")
+    datas = []
+    for i in range(3):
+        b = synthetic.synthetic_batch([760 + i], N=700 + 100 * i, T=196)
+        d = {k: _gpu(b[k]) for k in keys}
+        d["testing"] = True
+        datas.append(d)
+    ref = []
+    for d in datas:
+        r = model(d)
+        ref.append((model.last_logits.clone(), r["final_trans"].clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    base = _lib.handle_for(0)
+    try:
+        gmf_amd.set_handle_per_stream(True)
+        hs = []
+        for s in streams:
+            with torch.cuda.stream(s):
+                hs.append(_util.handle_and_stream(datas[0]["corr_pos"])[0])
+        assert len({id(x) for x in hs}) == 3 and all(x is not base for x in hs)
+        assert _util.handle_and_stream(datas[0]["corr_pos"])[0] is base                    # the default stream
+        outs = [None] * 3
+        for rep in range(4):                       # interleaved: three forwards in flight at a time
+            for i, s in enumerate(streams):
+                with torch.cuda.stream(s):
+                    r = model(datas[i])
+                    outs[i] = (model.last_logits.clone(), r["final_trans"].clone())
+        torch.cuda.synchronize()
+        for (lg, T), (lg0, T0) in zip(outs, ref):
+            assert torch.equal(lg, lg0) and torch.equal(T, T0)
+        gmf_amd.check_status()
+    finally:
+        gmf_amd.set_handle_per_stream(False)
+    with torch.cuda.stream(streams[0]):
+        assert _util.handle_and_stream(datas[0]["corr_pos"])[0] is base
+    torch.cuda.synchronize()
+
+
 def test_tuning_rejects_unknown_and_removed_settings():
     """The round-1 timing-only ablations (scattn_variant 11..15: wrong results) and the measured-and-rejected forms are no
     longer part of the library: gmf_set_tuning refuses them, out-of-range values and unknown knobs with GMF_ERR_BAD_ARG (-1)

@@ -191,7 +191,18 @@ def main():
 
     B, N, T = args.pairs, args.ncorr, args.tokens
     model, sd, tau = build_model(dev, args.kind)
-    driver = ShardedBatchDriver(model, world, rank, dev, backend="gloo" if args.rehearsal else None)
+    # (communication libraries announce themselves on stdout when a group forms - gloo: "[Gloo] Rank 0 is connected to ..." - and stdout
+    # carries exactly ONE JSON line: file descriptor 1 points at stderr while the group is set up)
+    sys.stdout.flush()
+    fd1 = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        driver = ShardedBatchDriver(model, world, rank, dev, backend="gloo" if args.rehearsal else None)
+        driver.barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(fd1, 1)
+        os.close(fd1)
     seeds = [rank * B + i for i in range(B)]                 # every rank owns its own pairs (weak scaling)
     batch, data = make_batch(dev, seeds, N, T, args.kind)
     torch.cuda.synchronize()
